@@ -1,0 +1,357 @@
+"""ctypes binding of the CPU oracle (oracle/libsvs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by scavislam_amd/.  Parity unpinned (see svs_oracle.h header).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from scavislam_amd.ctypes_types import (BA_CONSTRAINT_DTYPE, BA_EDGE_DTYPE, CANDIDATE_DTYPE,
+                                        DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
+                                        BaParams, BaStats, Cam, FastGrid)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsvs_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("vision.c", "ba.c", "svs_oracle.h", "svs_math.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.svs_ref_ba_chi2.restype = C.c_double
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+# ---- image ops -------------------------------------------------------------------------------
+def pyr_down_u8(img):
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    img = np.ascontiguousarray(img)
+    lib().svs_ref_pyr_down_u8(_p(img), w, h, img.strides[0], _p(out), out.strides[0])
+    return out
+
+
+def build_pyramid(img, levels=3):
+    pyr = [np.ascontiguousarray(img)]
+    for _ in range(levels - 1):
+        pyr.append(pyr_down_u8(pyr[-1]))
+    return pyr
+
+
+def convert_sobel(img):
+    h, w = img.shape
+    img = np.ascontiguousarray(img)
+    f = np.zeros((h, w), np.float32)
+    dx = np.zeros_like(f)
+    dy = np.zeros_like(f)
+    lib().svs_ref_convert_sobel(_p(img), w, h, img.strides[0], _p(f), _p(dx), _p(dy), w)
+    return f, dx, dy
+
+
+# ---- FAST ------------------------------------------------------------------------------------
+def fast9_16(img, thr, cap=1 << 20):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    xy = np.zeros((cap, 2), np.int16)
+    n = lib().svs_ref_fast9_16(_p(img), w, h, img.strides[0], int(thr), _p(xy), cap)
+    return xy[:n].copy()
+
+
+def fast_score(img, x, y):
+    img = np.ascontiguousarray(img)
+    return lib().svs_ref_fast_score(_p(img), img.strides[0], int(x), int(y))
+
+
+def fastgrid_for_level(w, h, level):
+    g = FastGrid()
+    lib().svs_ref_fastgrid_init_level(C.byref(g), w, h, level)
+    return g
+
+
+def fastgrid_detect_adaptively(g, img, trials, cap=1 << 16):
+    img = np.ascontiguousarray(img)
+    xy = np.zeros((cap, 2), np.int16)
+    nc = g.gx * g.gy
+    cc = np.zeros(nc, np.int32)
+    et = np.zeros(nc, np.int32)
+    n = lib().svs_ref_fastgrid_detect_adaptively(C.byref(g), _p(img), img.strides[0], int(trials),
+                                                 _p(xy), cap, _p(cc), _p(et))
+    assert n <= cap
+    return xy[:n].copy(), cc, et
+
+
+def fastgrid_detect(g, img, cap=1 << 16):
+    img = np.ascontiguousarray(img)
+    xy = np.zeros((cap, 2), np.int16)
+    cc = np.zeros(g.gx * g.gy, np.int32)
+    n = lib().svs_ref_fastgrid_detect(C.byref(g), _p(img), img.strides[0], _p(xy), cap, _p(cc))
+    assert n <= cap
+    return xy[:n].copy(), cc
+
+
+# ---- quadtree --------------------------------------------------------------------------------
+class QuadTree:
+    def __init__(self, w, h, delta=1.0):
+        L = lib()
+        L.svs_ref_qt_create.restype = C.c_void_p
+        L.svs_ref_qt_create.argtypes = [C.c_double] * 5
+        self.h = C.c_void_p(L.svs_ref_qt_create(0.0, 0.0, float(w), float(h), float(delta)))
+
+    def insert(self, x, y, content):
+        L = lib()
+        L.svs_ref_qt_insert.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        return L.svs_ref_qt_insert(self.h, float(x), float(y), int(content))
+
+    def query(self, x, y, w, h, cap=4096):
+        L = lib()
+        L.svs_ref_qt_query.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_int]
+        out = np.zeros((cap, 3), np.int32)
+        n = L.svs_ref_qt_query(self.h, float(x), float(y), float(w), float(h), _p(out), cap)
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            L = lib()
+            L.svs_ref_qt_destroy.argtypes = [C.c_void_p]
+            L.svs_ref_qt_destroy(self.h)
+        except Exception:
+            pass
+
+
+def quadtree_from_corners(xy, cell_count, w, h):
+    """Insert corners the way FastGrid does (content = index within the cell)."""
+    qt = QuadTree(w, h, 1.0)
+    k = 0
+    for c in cell_count:
+        for idx in range(int(c)):
+            qt.insert(xy[k, 0], xy[k, 1], idx)
+            k += 1
+    return qt
+
+
+# ---- matcher ---------------------------------------------------------------------------------
+def warp_affine(frame, T, depth, key_uv, cam, halfpatch=5):
+    frame = np.ascontiguousarray(frame)
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    kuv = np.ascontiguousarray(key_uv, np.float64)
+    out = np.zeros((2 * halfpatch, 2 * halfpatch), np.uint8)
+    L = lib()
+    L.svs_ref_warp_affine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_void_p]
+    L.svs_ref_warp_affine(_p(frame), frame.strides[0], _p(T), float(depth), _p(kuv), C.byref(cam),
+                          halfpatch, _p(out))
+    return out
+
+
+def znssd(key, cur):
+    key = np.ascontiguousarray(key, np.uint8).reshape(64)
+    cur = np.ascontiguousarray(cur, np.uint8).reshape(64)
+    sA = int(key.astype(np.int64).sum())
+    sAA = int((key.astype(np.int64) ** 2).sum())
+    return lib().svs_ref_znssd(_p(key), _p(cur), sA, sAA)
+
+
+def match(kf_pyrs, kf_poses, T_cur_from_actkey, T_actkey_from_w, cur_pyr, disp, trees, cams, pts,
+          radius=8, thr_mean=22, thr_std=10):
+    """kf_pyrs: list (per keyframe) of 3 u8 arrays; kf_poses: [n_kf,12]; trees: 3 QuadTree."""
+    n_kf = len(kf_pyrs)
+    kfs = np.zeros(n_kf, KEYFRAME_DTYPE)
+    keep = []
+    for i, pyr in enumerate(kf_pyrs):
+        kfs[i]["T_anchor_from_w"] = np.asarray(kf_poses[i], np.float64).reshape(12)
+        for l in range(3):
+            a = np.ascontiguousarray(pyr[l])
+            keep.append(a)
+            kfs[i]["pyr"][l] = a.ctypes.data
+            kfs[i]["stride"][l] = a.strides[0]
+    cur = [np.ascontiguousarray(a) for a in cur_pyr]
+    cur_ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in cur])
+    cur_strides = (C.c_int * 3)(*[a.strides[0] for a in cur])
+    disp = np.ascontiguousarray(disp, np.float32)
+    tree_ptrs = (C.c_void_p * 3)(*[t.h for t in trees])
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    out = np.zeros(len(pts), MATCH_RESULT_DTYPE)
+    Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+    Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(12)
+    L = lib()
+    L.svs_ref_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.svs_ref_match(_p(kfs), n_kf, _p(Tc), _p(Ta), cur_ptrs, cur_strides, _p(disp),
+                    disp.strides[0] // 4, tree_ptrs, cams, _p(pts), len(pts), radius, thr_mean,
+                    thr_std, _p(out))
+    return out
+
+
+# ---- dense tracking --------------------------------------------------------------------------
+def dense_pass_cpu(cloud, prev_u8, cur, dx, dy, cam, T, do_jac, want_rimg=False):
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    ch, cw = cloud.shape[:2]
+    prev_u8 = np.ascontiguousarray(prev_u8)
+    cur, dx, dy = [np.ascontiguousarray(a, np.float32) for a in (cur, dx, dy)]
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    out = np.zeros(1, DENSE_SUMS_DTYPE)
+    rimg = np.zeros((ch, cw, 4), np.float32) if want_rimg else None
+    L = lib()
+    L.svs_ref_dense_pass_cpu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.svs_ref_dense_pass_cpu(_p(cloud), cw, ch, _p(prev_u8), prev_u8.strides[0], _p(cur), _p(dx),
+                             _p(dy), cur.strides[0] // 4, C.byref(cam), _p(T), int(do_jac), _p(out),
+                             _p(rimg) if want_rimg else None)
+    return (out[0], rimg) if want_rimg else out[0]
+
+
+def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T):
+    clouds = [np.ascontiguousarray(a, np.float32) for a in clouds]
+    prev = [np.ascontiguousarray(a) for a in prev_pyr]
+    cur = [np.ascontiguousarray(a, np.float32) for a in cur_f]
+    dx = [np.ascontiguousarray(a, np.float32) for a in dx_f]
+    dy = [np.ascontiguousarray(a, np.float32) for a in dy_f]
+    P3 = C.c_void_p * 3
+    I3 = C.c_int * 3
+    T = np.array(T, np.float64).reshape(12).copy()
+    L = lib()
+    L.svs_ref_dense_tracking_cpu.argtypes = [C.c_void_p] * 2 + [C.c_void_p] + [C.c_void_p] * 3 + \
+        [C.c_void_p, C.c_void_p, C.c_void_p]
+    passes = L.svs_ref_dense_tracking_cpu(
+        P3(*[a.ctypes.data for a in clouds]), P3(*[a.ctypes.data for a in prev]),
+        I3(*[a.strides[0] for a in prev]), P3(*[a.ctypes.data for a in cur]),
+        P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]),
+        I3(*[a.strides[0] // 4 for a in cur]), cams, _p(T))
+    return T.reshape(3, 4), passes
+
+
+def pointcloud_cpu(disp, cam, level, T_cur_from_actkey):
+    disp = np.ascontiguousarray(disp, np.float32)
+    out = np.zeros((cam.h // 4, cam.w // 4, 4), np.float32)
+    T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+    L = lib()
+    L.svs_ref_pointcloud_cpu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.svs_ref_pointcloud_cpu(_p(disp), disp.strides[0] // 4, C.byref(cam), level, _p(T), _p(out))
+    return out
+
+
+def dense_pass_full(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor, do_jac):
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    h, w = cloud.shape[:2]
+    prev, cur, dx, dy = [np.ascontiguousarray(a, np.float32) for a in (prev, cur, dx, dy)]
+    T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+    out = np.zeros(1, DENSE_SUMS_DTYPE)
+    L = lib()
+    L.svs_ref_dense_pass_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + \
+        [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.svs_ref_dense_pass_full(_p(cloud), w, h, w, _p(prev), _p(cur), _p(dx), _p(dy), w, f, cx, cy,
+                              _p(T), int(do_jac), _p(out))
+    return out[0]
+
+
+def pointcloud_full(TQ_colmajor, disp, w, h, factor):
+    disp = np.ascontiguousarray(disp, np.float32)
+    TQ = np.ascontiguousarray(TQ_colmajor, np.float32).reshape(16)
+    out = np.zeros((h, w, 4), np.float32)
+    L = lib()
+    L.svs_ref_pointcloud_full.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.svs_ref_pointcloud_full(_p(TQ), _p(disp), w, h, disp.strides[0] // 4, w, factor, _p(out))
+    return out
+
+
+# ---- SE3 -------------------------------------------------------------------------------------
+def se3_exp(x):
+    T = np.zeros(12)
+    x = np.ascontiguousarray(x, np.float64)
+    lib().svs_ref_se3_exp(_p(x), _p(T))
+    return T.reshape(3, 4)
+
+
+def se3_log(T):
+    x = np.zeros(6)
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    lib().svs_ref_se3_log(_p(T), _p(x))
+    return x
+
+
+def se3_mul(A, B):
+    Cm = np.zeros(12)
+    A = np.ascontiguousarray(A, np.float64).reshape(12)
+    B = np.ascontiguousarray(B, np.float64).reshape(12)
+    lib().svs_ref_se3_mul(_p(A), _p(B), _p(Cm))
+    return Cm.reshape(3, 4)
+
+
+def se3_inv(A):
+    B = np.zeros(12)
+    A = np.ascontiguousarray(A, np.float64).reshape(12)
+    lib().svs_ref_se3_inv(_p(A), _p(B))
+    return B.reshape(3, 4)
+
+
+# ---- BA --------------------------------------------------------------------------------------
+def edge_psi2uvu(psi, T_obs, T_anc, obs, cam):
+    psi, obs = [np.ascontiguousarray(a, np.float64) for a in (psi, obs)]
+    T_obs, T_anc = [np.ascontiguousarray(a, np.float64).reshape(12) for a in (T_obs, T_anc)]
+    err, Jp, Jo, Ja = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 6)), np.zeros((3, 6))
+    lib().svs_ref_edge_psi2uvu(_p(psi), _p(T_obs), _p(T_anc), _p(obs), C.byref(cam), _p(err), _p(Jp),
+                               _p(Jo), _p(Ja))
+    return err, Jp, Jo, Ja
+
+
+def edge_se3(T21, T1, T2):
+    T21, T1, T2 = [np.ascontiguousarray(a, np.float64).reshape(12) for a in (T21, T1, T2)]
+    err, J1, J2 = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+    lib().svs_ref_edge_se3(_p(T21), _p(T1), _p(T2), _p(err), _p(J1), _p(J2))
+    return err, J1, J2
+
+
+def _ba_args(poses, psi, edges, cons):
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+    psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cons = np.ascontiguousarray(cons if cons is not None else np.zeros(0, BA_CONSTRAINT_DTYPE),
+                                BA_CONSTRAINT_DTYPE)
+    return poses, psi, edges, cons
+
+
+def ba_chi2(poses, psi, edges, cons, cam, prm):
+    poses, psi, edges, cons = _ba_args(poses, psi, edges, cons)
+    return lib().svs_ref_ba_chi2(len(poses), _p(poses), len(psi), _p(psi), len(edges), _p(edges),
+                                 len(cons), _p(cons), C.byref(cam), C.byref(prm))
+
+
+def ba_reduced_system(poses, psi, edges, cons, cam, prm, lam):
+    poses, psi, edges, cons = _ba_args(poses, psi, edges, cons)
+    n = 6 * len(poses)
+    H = np.zeros((n, n))
+    b = np.zeros(n)
+    L = lib()
+    L.svs_ref_ba_reduced_system.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_double, C.c_void_p, C.c_void_p]
+    L.svs_ref_ba_reduced_system(len(poses), _p(poses), len(psi), _p(psi), len(edges), _p(edges),
+                                len(cons), _p(cons), C.byref(cam), C.byref(prm), float(lam), _p(H), _p(b))
+    return H, b
+
+
+def ba_optimize(poses, psi, edges, cons, cam, prm):
+    poses, psi, edges, cons = _ba_args(poses, psi, edges, cons)
+    poses = poses.copy()
+    psi = psi.copy()
+    st = BaStats()
+    lib().svs_ref_ba_optimize(len(poses), _p(poses), len(psi), _p(psi), len(edges), _p(edges),
+                              len(cons), _p(cons), C.byref(cam), C.byref(prm), C.byref(st))
+    return poses, psi, st

@@ -1,0 +1,83 @@
+"""ctypes mirrors of the POD structs in include/scavislam_hip.h (same layout in oracle/svs_oracle.h).
+
+Names follow the reference's domain: FastGridCell grids (keyframes.h:31-44), CandidatePoint
+(data_structures.h:37-69), the BA edge records of SlamGraph::copyDataToG2o
+(slam_graph.cpp:983-1032).
+"""
+import ctypes as C
+
+import numpy as np
+
+SVS_MAX_CELLS = 64
+
+
+class Cam(C.Structure):
+    """Per-level StereoCamera (frame_grabber-impl.cpp:48-60)."""
+    _fields_ = [("f", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("b", C.c_double),
+                ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class FastGrid(C.Structure):
+    """FastGrid members (fast_grid.cpp:23-58)."""
+    _fields_ = [("gx", C.c_int32), ("gy", C.c_int32), ("cell_w", C.c_int32), ("cell_h", C.c_int32),
+                ("min_inner", C.c_int32), ("min_outer", C.c_int32),
+                ("max_inner", C.c_int32), ("max_outer", C.c_int32),
+                ("fast_min", C.c_int32), ("fast_max", C.c_int32),
+                ("thr", C.c_int32 * SVS_MAX_CELLS)]
+
+
+CANDIDATE_DTYPE = np.dtype([("xyz_anchor", "<f8", 3), ("anchor_obs_pyr", "<f8", 3),
+                            ("anchor_level", "<i4"), ("kf_index", "<i4"),
+                            ("point_id", "<i4"), ("pad_", "<i4")], align=True)
+assert CANDIDATE_DTYPE.itemsize == 64
+
+MATCH_RESULT_DTYPE = np.dtype([("status", "<i4"), ("u", "<i4"), ("v", "<i4"), ("znssd", "<i4"),
+                               ("obs", "<f8", 3), ("xyz_actkey", "<f8", 3)], align=True)
+assert MATCH_RESULT_DTYPE.itemsize == 64
+
+KEYFRAME_DTYPE = np.dtype([("T_anchor_from_w", "<f8", 12), ("pyr", "<u8", 3),
+                           ("stride", "<i4", 3), ("pad_", "<i4")], align=True)
+assert KEYFRAME_DTYPE.itemsize == 136
+
+DENSE_SUMS_DTYPE = np.dtype([("H", "<f8", 21), ("b", "<f8", 6), ("chi2", "<f8"),
+                             ("n_valid", "<i8")], align=True)
+assert DENSE_SUMS_DTYPE.itemsize == 232
+
+BA_EDGE_DTYPE = np.dtype([("obs", "<f8", 3), ("info", "<f8", 3), ("point", "<i4"),
+                          ("pose", "<i4"), ("anchor", "<i4"), ("pad_", "<i4")], align=True)
+assert BA_EDGE_DTYPE.itemsize == 64
+
+BA_CONSTRAINT_DTYPE = np.dtype([("T_21", "<f8", 12), ("info", "<f8", 36),
+                                ("pose1", "<i4"), ("pose2", "<i4")], align=True)
+assert BA_CONSTRAINT_DTYPE.itemsize == 392
+
+
+class BaParams(C.Structure):
+    """OptParams (slam_graph.hpp:36-50) + the g2o settings of setupG2o/optimize."""
+    _fields_ = [("num_iters", C.c_int32), ("use_robust", C.c_int32), ("huber_delta", C.c_double),
+                ("lambda_init", C.c_double), ("max_trials", C.c_int32),
+                ("self_edge_mode", C.c_int32)]
+
+    @classmethod
+    def reference_defaults(cls):
+        # backend.cpp:187 OptParams(2,true,3); delta stays 1 (slam_graph-impl.cpp:86-90);
+        # lambda 50 (slam_graph.cpp:338); maxTrialsAfterFailure 5 (slam_graph.cpp:1073)
+        return cls(2, 1, 1.0, 50.0, 5, 0)
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("accepted", C.c_int32),
+                ("terminated", C.c_int32), ("chi2_init", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
+MATCH_OK, MATCH_NO_ANCHOR, MATCH_BORDER, MATCH_DEPTH, MATCH_TEXTURE, MATCH_NONE, MATCH_NO_DISP = range(7)
+
+
+def level_cams(f, cx, cy, b, w, h, levels=3):
+    """cam_vec of FrameGrabber<StereoCamera> (frame_grabber-impl.cpp:48-60)."""
+    out = (Cam * levels)()
+    for l in range(levels):
+        s = float(1 << l)
+        out[l] = Cam(f / s, cx / s, cy / s, b * (1 << l), int(w / s), int(h / s))
+    return out
