@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: "stereo frames/sec + DWO Schur ms @ 50 KF / 20k pts".
+
+One JSON line on rank 0.  Two timed regions per run, each K steps, barrier + synchronize on both
+sides, max over ranks:
+  A. front-end: a step = one pass of the per-frame hot path (pyramid, f32+Sobel, device-resident
+     dense tracking, dense point cloud, grid FAST, guided ZNSSD matching of 2000 candidate points)
+     over a batch of B independent 640x480 camera streams, inputs resident in HBM.
+     value = N * B * K / time  [frames/s]   (weak scaling: front-end frames are replicas)
+  B. back-end: a step = one SlamGraph::optimize (2 LM iterations) of a 50-keyframe / 20k-landmark
+     window, landmarks sharded over the N ranks, one RCCL all-reduce of the packed reduced camera
+     system per LM trial.  schur.ms_per_optimize (strong scaling: the window is fixed).
+`roofline` is the Schur (landmark) kernel: algorithmic bytes / its average launch duration measured
+with HIP events on its own stream; `roofline_frontend` lists the front-end kernels the same way.
+`cpu_baseline` is the CPU oracle (a port of the reference's CPU path) timed on the host cores of
+this box on a bounded sample; it is the checker's code used as a baseline, never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="independent camera streams per rank per step")
+    ap.add_argument("--points", type=int, default=2000, help="candidate points per frame (SURVEY 8d config 2)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer, make_allreduce, shard_problem
+    from scavislam_amd.ctypes_types import BaParams, Cam
+    from scavislam_amd.frontend import DenseTracker, FastGrid, FramePyramid, GuidedMatcher
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx, stream = capi.torch_context(local_rank)
+    dev = torch.device("cuda", local_rank)
+    K, W, B = args.steps, args.warmup, args.batch
+
+    def barrier_sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ synthetic inputs (8d)
+    cam = synth.CAM_DEFAULT
+    scene = synth.Scene(2011)
+    traj = synth.trajectory(8)
+    NPAIR = 2
+    kf_id = 0
+    rend = {i: scene.render(cam, traj[i], seed=i) for i in [kf_id] + [4 + p for p in range(NPAIR + 1)]}
+    prev_imgs = np.stack([rend[4 + (b % NPAIR)][0] for b in range(B)])
+    prev_disp = np.stack([rend[4 + (b % NPAIR)][1] for b in range(B)])
+    cur_imgs = np.stack([rend[5 + (b % NPAIR)][0] for b in range(B)])
+    cur_disp = np.stack([rend[5 + (b % NPAIR)][1] for b in range(B)])
+    I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
+
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
+    prev.upload(prev_imgs, prev_disp)
+    cur.upload(cur_imgs, cur_disp)
+    kf.upload(rend[kf_id][0][None], rend[kf_id][1][None])
+    prev.preprocessing()
+    kf.preprocessing()
+    fast = FastGrid(ctx, cur)
+    dtrack = DenseTracker(ctx, cur)
+    dprev = DenseTracker(ctx, prev)
+    dprev.computeDensePointCloudCpu(I34)          # reference cloud of the previous frame
+    track_args = dtrack.track_args(prev.pyr)
+    for l in range(3):
+        track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
+    rng = np.random.default_rng(2011)
+    n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
+    pts = synth.candidate_points(rng, cam, rend[kf_id][1], traj[kf_id], n_per_level)
+    T_kf = traj[kf_id]
+    Tc = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
+    matcher = GuidedMatcher(ctx, cur, fast)
+    margs = matcher.prepare([(kf.pyr, 0, T_kf.reshape(12))], Tc, T_kf.reshape(12), pts)
+    T_rel = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(traj[4 + (b % NPAIR)])).reshape(12) for b in range(B)])
+    with torch.cuda.stream(stream):
+        d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
+
+    def frontend_step():
+        cur.preprocessing()                                        # "preprocess"
+        dtrack.d_T.copy_(d_T0)
+        dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)   # "dense tracking"
+        fast.detectAdaptively(trials=6)                            # "fast"
+        matcher.launch(margs)                                      # "match"
+        dtrack.computeDensePointCloudCpu_dev()                     # "dense point cloud"
+
+    # computeDensePointCloudCpu with the tracked pose already on the device (no host round trip)
+    def _pc_dev():
+        import ctypes as C
+        for l in range(3):
+            cb = (cur.h[l] // 4) * (cur.w[l] // 4) * 4
+            ctx.call("svs_pointcloud_cpu_sem", cur.disp.data_ptr(), cur.stride[0], cur.bstride(0), C.byref(cur.cams[l]), l,
+                     dtrack.d_T.data_ptr(), dtrack.ref_dense_points[l].data_ptr(), cb, B)
+    dtrack.computeDensePointCloudCpu_dev = _pc_dev
+
+    with torch.cuda.stream(stream):
+        for _ in range(W):
+            frontend_step()
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            frontend_step()
+        barrier_sync()
+        t_front = time.perf_counter() - t0
+    t_front = max_over_ranks(t_front)
+    fps = world * B * K / t_front
+    T_tracked = dtrack.d_T.cpu().numpy().reshape(B, 3, 4)
+    mres = matcher.download()
+    n_matched = int((mres["status"] == 0).sum(axis=1).mean())
+    track_err = float(np.abs(T_tracked[0] - T_rel[0].reshape(3, 4)).max())
+
+    # per-stage / per-kernel timing with HIP events on the ctx stream (not part of the timed steps)
+    stage_ms = {}
+
+    def time_stage(name, fn, reps=10):
+        with torch.cuda.stream(stream):
+            fn()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(reps):
+                fn()
+            stage_ms[name] = ctx.timer_stop_ms() / reps
+
+    def _pyr_only():
+        for l in (1, 2):
+            ctx.call("svs_pyr_down_u8", cur.pyr[l - 1].data_ptr(), cur.w[l - 1], cur.h[l - 1], cur.stride[l - 1],
+                     cur.bstride(l - 1), cur.pyr[l].data_ptr(), cur.stride[l], cur.bstride(l), B)
+
+    def _sobel_only():
+        for l in range(3):
+            ctx.call("svs_convert_sobel_f32", cur.pyr[l].data_ptr(), cur.w[l], cur.h[l], cur.stride[l], cur.bstride(l),
+                     cur.f32[l].data_ptr(), cur.dx[l].data_ptr(), cur.dy[l].data_ptr(), cur.stride[l], cur.bstride(l), B)
+
+    def _track_only():
+        dtrack.d_T.copy_(d_T0)
+        dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)
+
+    time_stage("pyramid", _pyr_only)
+    time_stage("convert_sobel", _sobel_only)
+    time_stage("dense_tracking", _track_only)
+    time_stage("fast", lambda: fast.detectAdaptively(trials=6))
+    time_stage("match", lambda: matcher.launch(margs))
+    time_stage("pointcloud", _pc_dev)
+    px = sum(cur.w[l] * cur.h[l] for l in range(3))
+    n_corners = sum(len(fast.corners(0, l)[0]) for l in range(3))
+    passes = int(dtrack.d_passes.cpu().numpy().mean())
+    # algorithmic bytes per frame, SURVEY.md 8d table
+    alg = {
+        "pyramid": cur.w[0] * cur.h[0] + cur.w[1] * cur.h[1] + cur.w[2] * cur.h[2],
+        "convert_sobel": px * 13,
+        "fast": px + 4 * n_corners + 22 * 4,
+        "match": args.points * (60 + 121 + 20) + args.points * 10 * 64,
+        "dense_tracking": passes * (px // 16) * 32 // 3,     # passes are spread over 3 levels
+        "pointcloud": (px // 16) * 20,
+    }
+    roofline_frontend = {k: {"ms": round(stage_ms[k], 4), "alg_bytes_per_frame": int(alg[k]),
+                             "achieved_GBs": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 2),
+                             "frac": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in stage_ms}
+
+    # ------------------------------------------------------------------ back-end (Schur) region
+    P_, L_ = 50, 20000
+    prob = synth.ba_window(P_, L_, seed=2012)
+    camc = Cam(*(prob["cam"][k] for k in ("f", "cx", "cy", "b", "w", "h")))
+    prm = BaParams.reference_defaults()
+    sh = shard_problem(prob, rank, world) if world > 1 else dict(prob, add_pose_terms=True)
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], camc, prm, add_pose_terms=sh["add_pose_terms"])
+    allreduce = make_allreduce(stream, local_rank) if world > 1 else None
+    E_total, E_local = len(prob["edges"]), len(sh["edges"])
+    stats = None
+    t_red = t_sol = t_bs = 0.0
+    n_tr = 0
+    with torch.cuda.stream(stream):
+        for _ in range(W):
+            opt.reset_state(sh["poses"], sh["psi"])
+            opt.optimize(allreduce)
+        barrier_sync()
+        t_ba = 0.0
+        for _ in range(K):
+            opt.reset_state(sh["poses"], sh["psi"])        # untimed: restore the window
+            barrier_sync()
+            t0 = time.perf_counter()
+            stats = opt.optimize(allreduce)
+            barrier_sync()
+            t_ba += time.perf_counter() - t0
+            kt = opt.kernel_times()
+            t_red += kt["reduce_ms"]; t_sol += kt["solve_ms"]; t_bs += kt["backsub_ms"]; n_tr += kt["n_trials"]
+    t_ba = max_over_ranks(t_ba)
+    ms_opt = t_ba / K * 1e3
+    red_ms = t_red / max(n_tr, 1)
+    # algorithmic bytes of the Schur (landmark) kernel: edges + psi read once, packed system written once
+    nblk = P_ * (P_ + 1) // 2
+    n_lm_local = int(np.unique(sh["edges"]["point"]).size)
+    alg_schur = 64 * E_local + 24 * n_lm_local + 8 * (36 * nblk + 12 * P_ + 1)
+    achieved = alg_schur / (red_ms * 1e-3) / 1e9 if red_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "ba_landmark_kernel<0> (linearise + 3x3 inverse + Schur outer products)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 5),
+                "alg_bytes_per_launch": int(alg_schur), "avg_launch_ms": round(red_ms, 5), "traffic": None}
+
+    # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
+    cpu = None
+    cpu_schur_ms = None
+    if rank == 0 and not args.no_cpu:
+        import oracle as O
+        grids = [O.fastgrid_for_level(cur.w[l], cur.h[l], l) for l in range(3)]
+        # state the reference also carries over from the previous frame (not timed)
+        pyr_p_cache = {p: O.build_pyramid(rend[4 + p][0]) for p in range(NPAIR)}
+        clouds_cache = {p: [O.pointcloud_cpu(rend[4 + p][1], cur.cams[l], l, I34.reshape(3, 4)) for l in range(3)]
+                        for p in range(NPAIR)}
+        kf_pyr = O.build_pyramid(rend[kf_id][0])
+        t0 = time.perf_counter()
+        nfr = 0
+        while nfr < 3 or (time.perf_counter() - t0 < 8.0 and nfr < 40):
+            p = nfr % NPAIR
+            img_c, disp_c = rend[5 + p]
+            pyr_c = O.build_pyramid(img_c)                                      # "preprocess"
+            fl = [O.convert_sobel(x) for x in pyr_c]
+            Tt, _ = O.dense_tracking_cpu(clouds_cache[p], pyr_p_cache[p], [f[0] for f in fl], [f[1] for f in fl],
+                                         [f[2] for f in fl], cur.cams, I34.reshape(3, 4))   # "dense tracking"
+            trees = []
+            for l in range(3):                                                  # "fast"
+                xy, cc, et = O.fastgrid_detect_adaptively(grids[l], pyr_c[l], 6)
+                trees.append(O.quadtree_from_corners(xy, cc, cur.w[l], cur.h[l]))
+            O.match([kf_pyr], [T_kf.reshape(12)], Tc[p].reshape(3, 4), T_kf, pyr_c, disp_c, trees, cur.cams, pts)   # "match"
+            [O.pointcloud_cpu(disp_c, cur.cams[l], l, Tt) for l in range(3)]    # "dense point cloud"
+            nfr += 1
+        t_cpu = time.perf_counter() - t0
+        cpu_fps = nfr / t_cpu
+        t0 = time.perf_counter()
+        nba = 0
+        while nba < 2 or (time.perf_counter() - t0 < 6.0 and nba < 20):
+            O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
+            nba += 1
+        cpu_schur_ms = (time.perf_counter() - t0) / nba * 1e3
+        cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{nfr} frames 640x480 through the CPU oracle (same stages, same inputs)"
+                         f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
+               "schur_ms_per_optimize": round(cpu_schur_ms, 2)}
+
+    if rank == 0:
+        out = {
+            "metric": "stereo frames/sec + DWO Schur ms @ 50 KF / 20k pts",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(t_front / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32 (FAST, ZNSSD), f32+f64 (dense tracking), f64 (Schur)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]+[3]: per-frame front-end on 640x480 stereo frames (pyramid, f32+Sobel, dense "
+                                   "tracking, grid-FAST, ZNSSD match, dense cloud; disparity given) and DWO inner-window "
+                                   "Schur solve 50 KF / 20k landmarks",
+                       "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": args.points,
+                       "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system"},
+            "schur": {"ms_per_optimize": round(ms_opt, 4), "lm_trials_per_optimize": n_tr / K,
+                      "ms_per_schur_step": round(ms_opt / max(n_tr / K, 1), 4), "scaling": "strong",
+                      "keyframes": P_, "landmarks": L_, "edges": E_total, "edges_this_rank": E_local,
+                      "kernel_ms": {"landmark_reduce": round(red_ms, 5), "solve_cholesky": round(t_sol / max(n_tr, 1), 5),
+                                    "backsub_chi2": round(t_bs / max(n_tr, 1), 5)},
+                      "chi2_init": stats.chi2_init, "chi2_final": stats.chi2_final,
+                      "speedup_vs_cpu_port": round(cpu_schur_ms / ms_opt, 2) if cpu_schur_ms else None},
+            "frontend": {"stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+                         "dense_passes_per_frame": passes, "corners_per_frame": n_corners, "matches_per_frame": n_matched,
+                         "dense_track_pose_err": track_err,
+                         "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
+            "roofline": roofline,
+            "roofline_frontend": roofline_frontend,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,235 @@
+/*
+ * scavislam_hip.h -- C ABI of the MI355X (gfx950) implementation of ScaViSLAM's two hot paths.
+ *
+ * The reference (strasdat/ScaViSLAM) has no FFI/plugin layer: its seams are C++ member functions
+ * switched at compile time by SCAVISLAM_CUDA_SUPPORT.  Every entry point
+ * below names the reference interface it replaces (file:line under /root/reference/scavislam).
+ * INTEGRATION.md shows the adaptor a maintainer adds on the reference side; the C++ adaptor
+ * classes with the reference's method names are in include/scavislam_hip.hpp.
+ *
+ * Conventions:
+ *  - every function returns int status, 0 = SVS_OK; never throws, never aborts;
+ *  - an svs_ctx owns one HIP stream + scratch; one ctx per calling thread (the reference calls
+ *    FAST/matcher from both the front-end and the back-end thread); no process-global state;
+ *  - pointers named d_* are DEVICE pointers, h_* are HOST pointers; strides are in ELEMENTS of
+ *    the pointed-to type; *_bstride is the element distance between consecutive batch slots;
+ *  - device entry points are asynchronous on the ctx stream; svs_ctx_sync() or any *_download /
+ *    h_* output makes results visible (blocking, like every reference call);
+ *  - poses are 3x4 row-major double[12] (R | t), T_a_from_b convention of the reference;
+ *  - a "batch" is a set of independent camera streams / frames processed by one launch.
+ */
+#ifndef SCAVISLAM_HIP_H
+#define SCAVISLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SVS_OK = 0,
+  SVS_ERR_INVALID = 1,      /* bad argument */
+  SVS_ERR_HIP = 2,          /* HIP runtime error; see svs_last_error */
+  SVS_ERR_NO_DEVICE = 3,    /* no gfx950 device / kernels not loadable */
+  SVS_ERR_CAPACITY = 4,     /* caller-provided capacity too small */
+  SVS_ERR_UNSUPPORTED = 5
+};
+
+#define SVS_NUM_PYR_LEVELS 3   /* global.h:107 */
+#define SVS_MAX_CELLS 64
+
+/* ---- POD types ---------------------------------------------------------------------------*/
+typedef struct { double f, cx, cy, b; int32_t w, h; } svs_cam;   /* frame_grabber-impl.cpp:48-60 */
+
+typedef struct {                       /* FastGrid, fast_grid.cpp:23-58 / keyframes.h:31-44 */
+  int32_t gx, gy, cell_w, cell_h;
+  int32_t min_inner, min_outer, max_inner, max_outer;
+  int32_t fast_min, fast_max;
+  int32_t thr[SVS_MAX_CELLS];
+} svs_fastgrid;
+
+typedef struct {                       /* CandidatePoint<3>, data_structures.h:37-69 */
+  double xyz_anchor[3];
+  double anchor_obs_pyr[3];
+  int32_t anchor_level, kf_index, point_id, pad_;
+} svs_candidate_point;
+
+typedef struct {                       /* keyframe_map entry + vertex_map pose */
+  double T_anchor_from_w[12];
+  const uint8_t *pyr[3];               /* DEVICE pointers for svs_match */
+  int32_t stride[3];
+  int32_t pad_;
+} svs_keyframe;
+
+enum { SVS_MATCH_OK = 0, SVS_MATCH_NO_ANCHOR, SVS_MATCH_BORDER, SVS_MATCH_DEPTH,
+       SVS_MATCH_TEXTURE, SVS_MATCH_NONE, SVS_MATCH_NO_DISP };
+
+typedef struct {
+  int32_t status, u, v, znssd;
+  double obs[3];
+  double xyz_actkey[3];
+} svs_match_result;
+
+typedef struct {                       /* GpuTrackingData, gpu/dense_tracking.cuh:28-277 */
+  double H[21];                        /* packed upper-by-column */
+  double b[6];
+  double chi2;
+  int64_t n_valid;
+} svs_dense_sums;
+
+typedef struct {                       /* addObsToG2o arguments, slam_graph-impl.cpp:44-97 */
+  double obs[3];
+  double info[3];
+  int32_t point, pose, anchor, pad_;
+} svs_ba_edge;
+
+typedef struct {                       /* addConstraintToG2o, slam_graph-impl.cpp:99-126 */
+  double T_21[12];
+  double info[36];
+  int32_t pose1, pose2;
+} svs_ba_constraint;
+
+typedef struct {                       /* OptParams slam_graph.hpp:36-50 + setupG2o/optimize */
+  int32_t num_iters;
+  int32_t use_robust;
+  double huber_delta;
+  double lambda_init;
+  int32_t max_trials;
+  int32_t self_edge_mode;              /* 0 = G2O_LITERAL, 1 = EXACT */
+} svs_ba_params;
+
+typedef struct {
+  int32_t iterations, trials, accepted, terminated;
+  double chi2_init, chi2_final, lambda_final;
+} svs_ba_stats;
+
+/* ---- context -----------------------------------------------------------------------------*/
+typedef struct svs_ctx svs_ctx;
+/* hip_stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create one */
+int svs_ctx_create(int device, void *hip_stream, svs_ctx **out);
+int svs_ctx_destroy(svs_ctx *ctx);
+int svs_ctx_sync(svs_ctx *ctx);
+void *svs_ctx_stream(svs_ctx *ctx);
+const char *svs_last_error(svs_ctx *ctx);
+int svs_malloc(svs_ctx *ctx, size_t bytes, void **d_ptr);
+int svs_free(svs_ctx *ctx, void *d_ptr);
+int svs_memcpy_h2d(svs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int svs_memcpy_d2h(svs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);  /* blocking */
+/* hipEvent timing on the ctx stream (bench.py roofline leg) */
+int svs_timer_start(svs_ctx *ctx);
+int svs_timer_stop_ms(svs_ctx *ctx, float *ms);                                  /* blocking */
+
+/* ---- preprocessing: replaces FrameGrabber::preprocessing, frame_grabber.cpp:285-336 --------*/
+/* one cv::pyrDown step on u8 (cv::buildPyramid at :290), bit-exact to OpenCV semantics */
+int svs_pyr_down_u8(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride,
+                    uint8_t *d_dst, int dstride, size_t d_bstride, int batch);
+/* convertTo(CV_32F,1/255.) + Sobel(ksize=1) dx,dy (:315-333) */
+int svs_convert_sobel_f32(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride,
+                          size_t s_bstride, float *d_img, float *d_dx, float *d_dy, int fstride,
+                          size_t f_bstride, int batch);
+
+/* ---- grid FAST: replaces FastGrid (fast_grid.h:27-63) ----------------------------------------*/
+typedef struct svs_fast svs_fast;
+/* one FastGrid per level (stereo_frontend.cpp:73-88); `batch` independent threshold states */
+int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
+                    const svs_fastgrid *grids, int batch, int corner_cap_per_level,
+                    svs_fast **out);
+int svs_fast_destroy(svs_fast *f);
+/* FastGrid::detectAdaptively(img, trials, qt) for all levels and `n_batch` slots
+   (fast_grid.cpp:86-152); trials == 0 => FastGrid::detect at the stored thresholds (:60-83).
+   d_img[l] = level-l image of slot 0. */
+int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const int32_t *stride,
+                    const size_t *bstride, int n_batch, int trials);
+/* blocking download of one slot/level: corners in the reference's quadtree insertion order
+   (cells row-major, row-major inside the cell), per-cell counts, threshold used by the last
+   detection of each cell, and the persistent thresholds (cell_grid2d()). Any pointer may be NULL */
+int svs_fast_download(svs_fast *f, int slot, int level, int16_t *h_xy, int cap, int32_t *h_n,
+                      int32_t *h_cell_count, int32_t *h_emit_thr, int32_t *h_thr_state);
+int svs_fast_set_thresholds(svs_fast *f, int slot, int level, const int32_t *h_thr);
+/* device views for chaining into svs_match (score map: 0 = no corner, else score+1) */
+int svs_fast_device_view(svs_fast *f, int level, const uint8_t **d_score, int32_t *score_stride,
+                         size_t *score_bstride, const int32_t **d_emit_thr, size_t *emit_bstride);
+
+/* ---- guided matcher: replaces GuidedMatcher<StereoCamera>::match (matcher.hpp:67-83) --------*/
+typedef struct {
+  const svs_keyframe *d_kfs; int32_t n_kf;        /* keyframe table (device) */
+  const svs_candidate_point *d_pts; int32_t n_pts; /* per slot: [n_batch][n_pts] */
+  const double *d_T_cur_from_w;                    /* [n_batch][12] */
+  const double *d_T_w_from_actkey;                 /* [n_batch][12] */
+  const uint8_t *d_cur_pyr[3]; int32_t cur_stride[3]; size_t cur_bstride[3];
+  const float *d_disp; int32_t disp_stride; size_t disp_bstride;
+  svs_cam cam_vec[3];
+  int32_t search_radius, thr_mean, thr_std;        /* 8, 22, 10 at stereo_frontend.cpp:989-1004 */
+  int32_t n_batch;
+} svs_match_args;
+/* corners come from `f` (the feature_tree argument of the reference): candidate set and
+   tie-break order are those of QuadTree::query. d_out: [n_batch][n_pts] */
+int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out);
+
+/* ---- dense tracker: replaces DenseTracker / GpuTracker ---------------------------------------*/
+/* computeDensePointCloudCpu (dense_tracking.cpp:393-423): quarter-grid cloud of one level */
+int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride,
+                           const svs_cam *cam, int level, const double *d_T_cur_from_actkey,
+                           float *d_cloud, size_t cloud_bstride, int batch);
+/* one pass of denseTrackingCpu's loop body (dense_tracking.cpp:229-261 / :278-331), CPU-path
+   semantics (quarter grid, clamp +-0.1, f64 geometry).  d_out[batch] */
+int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t cloud_bstride,
+                           const uint8_t *d_prev_u8, int pstride, size_t p_bstride,
+                           const float *d_cur, const float *d_dx, const float *d_dy, int fstride,
+                           size_t f_bstride, const svs_cam *cam, const double *d_T, int do_jac,
+                           svs_dense_sums *d_out, int batch);
+/* whole DenseTracker::denseTrackingCpu(SE3*) (dense_tracking.cpp:222-391), device resident:
+   3 levels x <=15 LM iterations with no host round trip. d_T_io [batch][12] in/out */
+typedef struct {
+  const float *d_cloud[3]; size_t cloud_bstride[3];
+  const uint8_t *d_prev_u8[3]; int32_t pstride[3]; size_t p_bstride[3];
+  const float *d_cur[3]; const float *d_dx[3]; const float *d_dy[3];
+  int32_t fstride[3]; size_t f_bstride[3];
+  svs_cam cam_vec[3];
+} svs_dense_track_args;
+int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io,
+                            int32_t *d_passes_out, int batch);
+/* GpuTracker::jacobianReduction / chi2 (gpu/dense_tracking.cuh:291-342, .cu:172-263,376-453):
+   full resolution, f32, no clamp; T is GpuMatrix34 (12 floats column-major) by value */
+int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4,
+                        const float *d_prev, const float *d_cur, const float *d_dx,
+                        const float *d_dy, int stride_f, float f, float cx, float cy,
+                        const float *h_T34_colmajor, int do_jac, svs_dense_sums *d_out);
+/* computePointCloud (gpu/dense_tracking.cu:82-148) */
+int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ_colmajor, const float *d_disp, int w, int h,
+                        int stride_in, int stride_out, int factor, float *d_cloud4);
+
+/* ---- BA: replaces SlamGraph::optimize (slam_graph.hpp:457-462, slam_graph.cpp:312-355) -------*/
+typedef struct svs_ba svs_ba;
+/* all-reduce hook for landmark-sharded operation: sum `count` doubles at d_buf in place across
+   ranks, on the ctx stream (RCCL via torch.distributed in scavislam_amd/backend.py) */
+typedef int (*svs_allreduce_fn)(void *d_buf, size_t count, void *user);
+
+int svs_ba_create(svs_ctx *ctx, svs_ba **out);
+int svs_ba_destroy(svs_ba *ba);
+/* copyDataToG2o (slam_graph.cpp:983-1032): poses of the double window, active points as psi
+   (inverse depth), observation edges, pose-pose constraints.  Host arrays; edges may be in any
+   order.  In sharded runs each rank passes only its landmarks' edges (point ids stay global
+   0..L-1) and add_pose_terms = 1 on exactly one rank (constraints counted once). */
+int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const double *h_psi,
+                       int E, const svs_ba_edge *h_edges, int C, const svs_ba_constraint *h_cons,
+                       const svs_cam *cam, const svs_ba_params *prm, int add_pose_terms);
+/* optimizer.optimize(num_iters) (slam_graph.cpp:346) incl. LM control flow; allreduce may be
+   NULL (single GPU) */
+int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats);
+/* restoreDataFromG2o (slam_graph.cpp:1035-1058): poses [P][12], psi [L][3] */
+int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
+/* building blocks exposed for parity tests and profiling */
+int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
+int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,
+                          double *h_bred /* 6P */, double *h_chi2);
+/* last-call timing of the dominant kernels, ms (hipEvents on the ctx stream) */
+int svs_ba_kernel_times(svs_ba *ba, float *reduce_ms, float *solve_ms, float *backsub_ms,
+                        int32_t *n_reduce_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -136,11 +136,11 @@ class QuadTree:
 def quadtree_from_corners(xy, cell_count, w, h):
     """Insert corners the way FastGrid does (content = index within the cell)."""
     qt = QuadTree(w, h, 1.0)
-    k = 0
-    for c in cell_count:
-        for idx in range(int(c)):
-            qt.insert(xy[k, 0], xy[k, 1], idx)
-            k += 1
+    xy = np.ascontiguousarray(xy, np.int16)
+    cc = np.ascontiguousarray(cell_count, np.int32)
+    L = lib()
+    L.svs_ref_qt_insert_corners.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.svs_ref_qt_insert_corners(qt.h, _p(xy), _p(cc), len(cc))
     return qt
 
 

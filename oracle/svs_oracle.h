@@ -158,6 +158,8 @@ typedef struct svs_ref_qt svs_ref_qt;
 svs_ref_qt *svs_ref_qt_create(double x, double y, double w, double h, double delta);
 void svs_ref_qt_destroy(svs_ref_qt *);
 int svs_ref_qt_insert(svs_ref_qt *, double px, double py, int content);
+/* the insertion loop of fast_grid.cpp:143-149: content = index within the cell */
+void svs_ref_qt_insert_corners(svs_ref_qt *, const int16_t *xy, const int32_t *cell_count, int n_cells);
 /* window query in the reference's DFS order; returns count, fills (x,y,content) triples */
 int svs_ref_qt_query(const svs_ref_qt *, double wx, double wy, double ww, double wh,
                      int32_t *out_xyc, int cap);

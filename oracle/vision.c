@@ -269,6 +269,11 @@ svs_ref_qt *svs_ref_qt_create(double x, double y, double w, double h, double del
 }
 void svs_ref_qt_destroy(svs_ref_qt *q) { if (q) { qt_free(q->root); free(q); } }
 int svs_ref_qt_insert(svs_ref_qt *q, double px, double py, int c) { return qt_insert_node(q->root, px, py, c, q->delta); }
+void svs_ref_qt_insert_corners(svs_ref_qt *q, const int16_t *xy, const int32_t *cell_count, int n_cells) {
+  int k = 0;
+  for (int c = 0; c < n_cells; ++c)
+    for (int idx = 0; idx < cell_count[c]; ++idx, ++k) qt_insert_node(q->root, (double)xy[2 * k], (double)xy[2 * k + 1], idx, q->delta);
+}
 int svs_ref_qt_query(const svs_ref_qt *q, double wx, double wy, double ww, double wh, int32_t *out, int cap) {
   int cnt = 0;
   qt_query_node(q->root, wx, wy, ww, wh, out, cap, &cnt);

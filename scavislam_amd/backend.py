@@ -1,0 +1,140 @@
+"""Host-side mirror of the back-end's optimisation call surface.
+
+  SlamGraphOptimizer.optimize(OptParams)  <- SlamGraph::optimize   slam_graph.hpp:457-462,
+                                                                   slam_graph.cpp:312-355
+
+The double-window bookkeeping that produces the window / active point set
+(prepareForOptimization, slam_graph.cpp:288-310) is out of scope; this class
+takes its output the way copyDataToG2o consumes it: poses, inverse-depth points, observation
+edges, pose-pose constraints.
+
+Multi-GPU: landmarks shard across ranks, each rank reduces its own landmarks into a
+partial reduced camera system, ONE all-reduce (RCCL through torch.distributed; "nccl" backend on
+ROCm) sums the packed system, every rank runs the identical 6Px6P Cholesky, back-substitutes its
+own landmarks; two scalars per LM trial are all-reduced for the accept/reject decision.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .ctypes_types import BA_CONSTRAINT_DTYPE, BA_EDGE_DTYPE, BaParams, BaStats, Cam
+
+
+class OptParams:
+    """slam_graph.hpp:36-50.  huber_kernel_width is accepted and ignored, as in the reference
+    (slam_graph-impl.cpp:86-90 never passes it to the kernel; delta stays g2o's default 1)."""
+
+    def __init__(self, num_iters=2, use_robust_kernel=True, huber_kernel_width=3.0):
+        self.num_iters, self.use_robust_kernel, self.huber_kernel_width = num_iters, use_robust_kernel, huber_kernel_width
+
+
+def make_allreduce(stream, device, group=None):
+    """svs_allreduce_fn backed by torch.distributed: sums `count` doubles in place on `stream`."""
+    import torch.distributed as dist
+
+    def _fn(d_buf, count, _user):
+        try:
+            # zero-copy view of the library's device buffer
+            t = _as_tensor(d_buf, count, device)
+            with torch.cuda.stream(stream):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("allreduce callback failed:", repr(e))
+            return 1
+
+    return capi.ALLREDUCE_FN(_fn)
+
+
+class _CudaArray:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _as_tensor(ptr, count, device):
+    return torch.as_tensor(_CudaArray(ptr, count), device=torch.device("cuda", device))
+
+
+class SlamGraphOptimizer:
+    def __init__(self, ctx, stream=None):
+        self.ctx, self.stream = ctx, stream
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svs_ba_create(ctx.h, C.byref(self.h)))
+        ctx.children.add(self)
+        self.P = self.L = 0
+
+    def copyDataToG2o(self, poses, psi, edges, cons, cam, prm=None, add_pose_terms=True):
+        """copyDataToG2o + setupG2o (slam_graph.cpp:983-1032,1061-1080): upload the window."""
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        cons = np.ascontiguousarray(cons if cons is not None else np.zeros(0, BA_CONSTRAINT_DTYPE), BA_CONSTRAINT_DTYPE)
+        self.P, self.L = len(poses), len(psi)
+        self.prm = prm or BaParams.reference_defaults()
+        camc = cam if isinstance(cam, Cam) else Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        self.ctx.check(self.ctx.lib.svs_ba_set_problem(
+            self.h, self.P, poses.ctypes.data, self.L, psi.ctypes.data, len(edges), edges.ctypes.data, len(cons),
+            cons.ctypes.data, C.byref(camc), C.byref(self.prm), int(add_pose_terms)))
+
+    def reset_state(self, poses, psi):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)
+        self.ctx.check(self.ctx.lib.svs_ba_reset_state(self.h, poses.ctypes.data, psi.ctypes.data))
+
+    def optimize(self, allreduce=None):
+        """optimizer.optimize(num_iters) with the LM control flow of g2o (slam_graph.cpp:336-346)."""
+        st = BaStats()
+        cb = allreduce if allreduce is not None else None
+        self.ctx.check(self.ctx.lib.svs_ba_optimize(self.h, C.cast(cb, C.c_void_p) if cb else None, None, C.byref(st)))
+        return st
+
+    def restoreDataFromG2o(self):
+        """restoreDataFromG2o (slam_graph.cpp:1035-1058): poses [P,12], psi [L,3]."""
+        poses = np.zeros((self.P, 12))
+        psi = np.zeros((self.L, 3))
+        self.ctx.check(self.ctx.lib.svs_ba_get_state(self.h, poses.ctypes.data, psi.ctypes.data))
+        return poses, psi
+
+    def reduced_system(self, lam):
+        n = 6 * self.P
+        H, b, chi2 = np.zeros((n, n)), np.zeros(n), np.zeros(1)
+        self.ctx.check(self.ctx.lib.svs_ba_reduced_system(self.h, float(lam), H.ctypes.data, b.ctypes.data, chi2.ctypes.data))
+        return H, b, float(chi2[0])
+
+    def kernel_times(self):
+        r, s, b, n = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
+        self.ctx.lib.svs_ba_kernel_times(self.h, C.byref(r), C.byref(s), C.byref(b), C.byref(n))
+        return dict(reduce_ms=r.value, solve_ms=s.value, backsub_ms=b.value, n_trials=n.value)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.svs_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_problem(prob, rank, world, chunk=64):
+    """Landmark shard of a BA window for `rank`: landmarks dealt in
+    contiguous chunks of 64, round-robin; point ids stay global; constraints live on rank 0."""
+    L = len(prob["psi"])
+    owner = (np.arange(L) // chunk) % world
+    mask = owner[prob["edges"]["point"]] == rank
+    return dict(prob, edges=prob["edges"][mask], owner=owner, add_pose_terms=(rank == 0))
+
+
+def merge_sharded_psi(psi_local, owner, rank, world, device=None, group=None):
+    """Every rank only updates its own landmarks; combine them (sum of masked arrays)."""
+    import torch.distributed as dist
+    mine = np.where((owner == rank)[:, None], psi_local, 0.0)
+    t = torch.as_tensor(mine)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()

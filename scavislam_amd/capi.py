@@ -1,0 +1,163 @@
+"""ctypes binding of libscavislam_hip.so (include/scavislam_hip.h).
+
+The library is the product: there is NO CPU fallback.  Importing this module never touches the
+GPU; `load()` raises if the HIP extension has not been built, and every call raises SvsError on a
+non-zero status.  PyTorch is used only as plumbing (device buffers, streams, torch.distributed).
+"""
+import ctypes as C
+import os
+import weakref
+
+from .ctypes_types import BaParams, BaStats, Cam, FastGrid
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscavislam_hip.so")
+_LIB = None
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class SvsError(RuntimeError):
+    pass
+
+
+class DenseTrackArgs(C.Structure):
+    _fields_ = [("d_cloud", C.c_void_p * 3), ("cloud_bstride", C.c_size_t * 3),
+                ("d_prev_u8", C.c_void_p * 3), ("pstride", C.c_int32 * 3), ("p_bstride", C.c_size_t * 3),
+                ("d_cur", C.c_void_p * 3), ("d_dx", C.c_void_p * 3), ("d_dy", C.c_void_p * 3),
+                ("fstride", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3), ("cam_vec", Cam * 3)]
+
+
+class MatchArgs(C.Structure):
+    _fields_ = [("d_kfs", C.c_void_p), ("n_kf", C.c_int32),
+                ("d_pts", C.c_void_p), ("n_pts", C.c_int32),
+                ("d_T_cur_from_w", C.c_void_p), ("d_T_w_from_actkey", C.c_void_p),
+                ("d_cur_pyr", C.c_void_p * 3), ("cur_stride", C.c_int32 * 3), ("cur_bstride", C.c_size_t * 3),
+                ("d_disp", C.c_void_p), ("disp_stride", C.c_int32), ("disp_bstride", C.c_size_t),
+                ("cam_vec", Cam * 3),
+                ("search_radius", C.c_int32), ("thr_mean", C.c_int32), ("thr_std", C.c_int32),
+                ("n_batch", C.c_int32)]
+
+
+_SIGS = {
+    "svs_ctx_create": [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)],
+    "svs_ctx_destroy": [C.c_void_p],
+    "svs_ctx_sync": [C.c_void_p],
+    "svs_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
+    "svs_free": [C.c_void_p, C.c_void_p],
+    "svs_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "svs_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "svs_timer_start": [C.c_void_p],
+    "svs_timer_stop_ms": [C.c_void_p, C.POINTER(C.c_float)],
+    "svs_pyr_down_u8": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                        C.c_size_t, C.c_int],
+    "svs_convert_sobel_f32": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int],
+    "svs_fast_create": [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(FastGrid),
+                        C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "svs_fast_destroy": [C.c_void_p],
+    "svs_fast_detect": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t),
+                        C.c_int, C.c_int],
+    "svs_fast_download": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
+                          C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_fast_set_thresholds": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "svs_fast_device_view": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                             C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "svs_match": [C.c_void_p, C.POINTER(MatchArgs), C.c_void_p, C.c_void_p],
+    "svs_pointcloud_cpu_sem": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam), C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_int],
+    "svs_dense_pass_cpu_sem": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam),
+                               C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_dense_track_cpu_sem": [C.c_void_p, C.POINTER(DenseTrackArgs), C.c_void_p, C.c_void_p, C.c_int],
+    "svs_dense_pass_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                            C.c_int, C.c_void_p],
+    "svs_pointcloud_full": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_void_p],
+    "svs_ba_create": [C.c_void_p, C.POINTER(C.c_void_p)],
+    "svs_ba_destroy": [C.c_void_p],
+    "svs_ba_set_problem": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                           C.c_int, C.c_void_p, C.POINTER(Cam), C.POINTER(BaParams), C.c_int],
+    "svs_ba_optimize": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BaStats)],
+    "svs_ba_get_state": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_ba_reset_state": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_ba_reduced_system": [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                            C.POINTER(C.c_int32)],
+}
+EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error"])
+
+
+def load():
+    """dlopen the HIP extension; raises (never falls back) if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvsError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.svs_ctx_stream.argtypes = [C.c_void_p]
+        lib.svs_ctx_stream.restype = C.c_void_p
+        lib.svs_last_error.argtypes = [C.c_void_p]
+        lib.svs_last_error.restype = C.c_char_p
+        _LIB = lib
+    return _LIB
+
+
+class Context:
+    """One svs_ctx (HIP stream + scratch) per calling thread, as in SURVEY.md 8b."""
+
+    def __init__(self, device=0, stream_ptr=None):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.svs_ctx_create(int(device), C.c_void_p(stream_ptr) if stream_ptr else None, C.byref(h))
+        if rc:
+            raise SvsError(f"svs_ctx_create failed with status {rc} (no gfx950 device visible?)")
+        self.h = h
+        self.device = device
+        self.children = weakref.WeakSet()   # objects holding a pointer to this ctx; closed first
+
+    def check(self, rc):
+        if rc:
+            raise SvsError(f"status {rc}: {self.lib.svs_last_error(self.h).decode(errors='replace')}")
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self.h, *args))
+
+    def sync(self):
+        self.check(self.lib.svs_ctx_sync(self.h))
+
+    def timer_start(self):
+        self.check(self.lib.svs_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.svs_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            for ch in list(self.children):
+                ch.close()
+            self.lib.svs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_context(device=0):
+    """Context running on a dedicated torch stream, so torch copies/collectives and our kernels
+    are ordered on the same HIP stream.  Returns (ctx, torch_stream)."""
+    import torch
+    torch.cuda.set_device(device)
+    s = torch.cuda.Stream(device=device)
+    return Context(device, s.cuda_stream), s

@@ -1,0 +1,924 @@
+// ba.hip -- double-window bundle adjustment (Schur-complement LM) for gfx950.
+// Replaces SlamGraph::optimize (slam_graph.cpp:312-355): the g2o pipeline BlockSolver_6_3 +
+// OptimizationAlgorithmLevenberg + RobustKernelHuber + sparse Cholesky, with the edge
+// arithmetic of g2o_types/anchored_points.cpp:148-235 and transformations.h:62-95.
+//
+// MI355X-first design (f64 throughout; no MFMA: blocks are 3x3 / 6x3 / 6x6):
+//  * edges are sorted by (landmark, observer) and packed into chunks of <= 64 whole landmarks'
+//    edges; ONE LANE PER EDGE, one wavefront per chunk.  Everything a landmark needs from its
+//    edges (H_ll, b_l, the anchor's W and H_pp block) is a SEGMENTED wave64 shuffle reduction
+//    over the landmark's lanes -- no LDS, no per-landmark scratch in HBM;
+//  * the 3x3 block inverse and all 6x6 Schur outer products W_i D^-1 W_j^T are formed in
+//    registers (pairs of a landmark = pairs of lanes of its segment, partner data by shuffle)
+//    and go straight into the packed upper-block reduced camera system with hardware f64
+//    atomics (global_atomic_add_f64); H_pl is never materialised;
+//  * back-substitution re-linearises instead of reloading stored W blocks (64 B/edge read
+//    instead of 144+ B/edge) and fuses the trial-state chi2 into the same launch;
+//  * landmark shards (multi-GPU) only exchange the packed reduced system (one all-reduce of
+//    36*P(P+1)/2 + 12P + 1 doubles) and two scalars per LM trial; the 6P x 6P Cholesky is
+//    replicated (deterministic, no broadcast).
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+// ---- small f64 helpers ---------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+template <int N>
+__device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int seg_begin, int seg_end, int maxlen) {
+  for (int o = 1; o < maxlen; o <<= 1) {
+    const bool take = (lane - o) >= seg_begin;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double up = __shfl_up(v[i], o, 64); if (take) v[i] += up; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __shfl(v[i], seg_end, 64);
+}
+
+__device__ __forceinline__ long blk_index(int i, int j, int P) {   // i <= j, packed upper block row-major
+  return (long)i * P - (long)i * (i - 1) / 2 + (j - i);
+}
+
+__device__ __forceinline__ void huber(double e2, double delta, int robust, double &rho0, double &rho1) {
+  if (!robust) { rho0 = e2; rho1 = 1; return; }
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) { rho0 = e2; rho1 = 1.; }
+  else { const double s = sqrt(e2); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+struct EdgeLin {           // linearisation of one G2oEdgeProjectPSI2UVU (anchored_points.cpp:148-189)
+  double Jp[9], Jo[18], Ja[18];
+  double om[3], wr[3];     // rho1*Lambda (diag), -rho1*Lambda*e
+  double rho0;
+};
+
+__device__ __forceinline__ void rel_pose(const double *To, const double *Ta, double *R, double *t) {
+  // T_ca = T_obs * T_anc^-1
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = To[4 * i] * Ta[4 * j] + To[4 * i + 1] * Ta[4 * j + 1] + To[4 * i + 2] * Ta[4 * j + 2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = To[4 * i + 3] - (R[3 * i] * Ta[3] + R[3 * i + 1] * Ta[7] + R[3 * i + 2] * Ta[11]);
+}
+
+__device__ __forceinline__ double edge_chi2(const double *psi, const double *To, const double *Ta, const svs_ba_edge &ed,
+                                            const svs_cam &cam, double delta, int robust) {
+  double R[9], t[3];
+  rel_pose(To, Ta, R, t);
+  const double xa[3] = {psi[0] / psi[2], psi[1] / psi[2], 1. / psi[2]};
+  double y[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y[i] = R[3 * i] * xa[0] + R[3 * i + 1] * xa[1] + R[3 * i + 2] * xa[2] + t[i];
+  const double e0 = ed.obs[0] - ((y[0] / y[2]) * cam.f + cam.cx);
+  const double e1 = ed.obs[1] - ((y[1] / y[2]) * cam.f + cam.cy);
+  const double e2_ = ed.obs[2] - (((y[0] - cam.b) / y[2]) * cam.f + cam.cx);
+  const double e2 = e0 * e0 * ed.info[0] + e1 * e1 * ed.info[1] + e2_ * e2_ * ed.info[2];
+  double r0, r1;
+  huber(e2, delta, robust, r0, r1);
+  return r0;
+}
+
+__device__ __forceinline__ void linearize_edge(const double *psi, const double *To, const double *Ta, const svs_ba_edge &ed,
+                                               const svs_cam &cam, double delta, int robust, EdgeLin &o) {
+  double R[9], t[3];
+  rel_pose(To, Ta, R, t);
+  const double xa[3] = {psi[0] / psi[2], psi[1] / psi[2], 1. / psi[2]};   // invert_depth, maths_utils.h:66-69
+  double y[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y[i] = R[3 * i] * xa[0] + R[3 * i + 1] * xa[1] + R[3 * i + 2] * xa[2] + t[i];
+  double err[3];
+  err[0] = ed.obs[0] - ((y[0] / y[2]) * cam.f + cam.cx);
+  err[1] = ed.obs[1] - ((y[1] / y[2]) * cam.f + cam.cy);
+  err[2] = ed.obs[2] - (((y[0] - cam.b) / y[2]) * cam.f + cam.cx);
+  const double e2 = err[0] * err[0] * ed.info[0] + err[1] * err[1] * ed.info[1] + err[2] * err[2] * ed.info[2];
+  double rho1;
+  huber(e2, delta, robust, o.rho0, rho1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o.om[k] = rho1 * ed.info[k]; o.wr[k] = -o.om[k] * err[k]; }
+  // d_stereoproj_d_y (transformations.h:62-71)
+  const double f = cam.f, zsq = y[2] * y[2];
+  const double Jc[9] = {f / y[2], 0, -(f * y[0]) / zsq, 0, f / y[2], -(f * y[1]) / zsq, f / y[2], 0, -(f * (y[0] - cam.b)) / zsq};
+  // d_Tinvpsi_d_psi (transformations.h:82-95): [r1 r2 -R x] / psi_z
+  const double ipz = 1. / psi[2];
+  double D[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double Rx = R[3 * i] * xa[0] + R[3 * i + 1] * xa[1] + R[3 * i + 2] * xa[2];
+    D[3 * i] = R[3 * i] * ipz; D[3 * i + 1] = R[3 * i + 1] * ipz; D[3 * i + 2] = -Rx * ipz;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.Jp[3 * i + j] = -(Jc[3 * i] * D[j] + Jc[3 * i + 1] * D[3 + j] + Jc[3 * i + 2] * D[6 + j]);
+  // J_obs = -Jc [I, -hat(y)]  (transformations.h:73-80)
+  const double hy[9] = {0, -y[2], y[1], y[2], 0, -y[0], -y[1], y[0], 0};
+  const double hx[9] = {0, -xa[2], xa[1], xa[2], 0, -xa[0], -xa[1], xa[0], 0};
+  double JR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      o.Jo[6 * i + j] = -Jc[3 * i + j];
+      o.Jo[6 * i + 3 + j] = Jc[3 * i] * hy[j] + Jc[3 * i + 1] * hy[3 + j] + Jc[3 * i + 2] * hy[6 + j];
+      JR[3 * i + j] = Jc[3 * i] * R[j] + Jc[3 * i + 1] * R[3 + j] + Jc[3 * i + 2] * R[6 + j];
+    }
+  // J_anc = Jc R [I, -hat(x_a)]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      o.Ja[6 * i + j] = JR[3 * i + j];
+      o.Ja[6 * i + 3 + j] = -(JR[3 * i] * hx[j] + JR[3 * i + 1] * hx[3 + j] + JR[3 * i + 2] * hx[6 + j]);
+    }
+}
+
+struct BaDev {
+  int P, L, E, C, n_chunks;
+  const double *poses, *psi;            // current state
+  double *poses_trial, *psi_trial;      // trial state
+  const svs_ba_edge *edges;
+  const int *chunk_start, *chunk_len;
+  const svs_ba_constraint *cons;
+  double *H;                            // packed upper blocks [nblk][36]
+  double *bp, *bs;                      // [6P] pure b, Schur correction
+  double *chi2_cur;                     // [1]
+  const double *x;                      // [6P] pose solution
+  double *scal;                         // [0]=chi2_trial [1]=scale_l [2]=scale_p [3]=fail [4]=chi2_cur copy
+  svs_cam cam;
+  double delta, lambda;
+  int robust, self_mode;
+};
+
+// MODE 0: accumulate reduced system + chi2 at the current state.
+// MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
+template <int MODE>
+__global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
+  const int lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= B.n_chunks) return;                                  // wave-uniform
+  const int e0 = B.chunk_start[chunk], len = B.chunk_len[chunk];
+  const bool active = lane < len;
+  svs_ba_edge ed;
+  if (active) ed = B.edges[e0 + lane];
+  else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
+  // segment (= landmark) bounds inside the wave
+  const int prev_point = __shfl_up(ed.point, 1, 64);
+  const bool head = lane == 0 || prev_point != ed.point;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long le_mask = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+  const int seg_begin = 63 - __clzll((long long)(heads & le_mask));
+  const unsigned long long gt = (lane == 63) ? 0ull : (heads & ~le_mask);
+  const int seg_end = gt ? (__ffsll((long long)gt) - 2) : 63;
+  int maxlen = seg_end - seg_begin + 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+
+  const int P = B.P;
+  double psi[3] = {1, 1, 1}, To[12], Ta[12];
+  EdgeLin lin;
+  const bool self = active && ed.pose == ed.anchor;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)ed.anchor + i]; }
+    linearize_edge(psi, To, Ta, ed, B.cam, B.delta, B.robust, lin);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) lin.Jp[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { lin.Jo[i] = 0; lin.Ja[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lin.om[i] = 0; lin.wr[i] = 0; }
+    lin.rho0 = 0;
+  }
+  if (MODE == 0) {
+    const double c = wave_sum_f64(lin.rho0);
+    if (lane == 0) atomic_add_f64(B.chi2_cur, c);
+  }
+  // observer role: this lane owns pose ed.pose of its landmark; a self edge (observer == anchor)
+  // has no observer role: G2O_LITERAL folds its slot-1 terms into the anchor, EXACT drops them.
+  const bool obs_role = active && !self;
+  const bool self_lit = self && B.self_mode == 0;
+
+  // ---- H_ll, b_l -> D^-1 ------------------------------------------------------------------
+  double hl[9];   // 6 unique H_ll + 3 b_l
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) hl[k++] = lin.Jp[i] * lin.om[0] * lin.Jp[j] + lin.Jp[3 + i] * lin.om[1] * lin.Jp[3 + j] + lin.Jp[6 + i] * lin.om[2] * lin.Jp[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hl[6 + i] = lin.Jp[i] * lin.wr[0] + lin.Jp[3 + i] * lin.wr[1] + lin.Jp[6 + i] * lin.wr[2];
+  }
+  seg_allreduce<9>(hl, lane, seg_begin, seg_end, maxlen);
+  double Di[9], bl[3] = {hl[6], hl[7], hl[8]};
+  {
+    const double a00 = hl[0] + B.lambda, a01 = hl[1], a02 = hl[2], a11 = hl[3] + B.lambda, a12 = hl[4], a22 = hl[5] + B.lambda;
+    // closed-form inverse of the symmetric 3x3 (Eigen fixed-size inverse = cofactors / det)
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+    Di[0] = c00 * id; Di[1] = c01 * id; Di[2] = c02 * id;
+    Di[3] = Di[1]; Di[4] = (a00 * a22 - a02 * a02) * id; Di[5] = (a02 * a01 - a00 * a12) * id;
+    Di[6] = Di[2]; Di[7] = Di[5]; Di[8] = (a00 * a11 - a01 * a01) * id;
+  }
+  double Db[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Db[i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+
+  // ---- W blocks: own observer W_o (6x3), anchor W_A = sum over the landmark's edges ----------
+  double Wo[18], WA[18];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double wo = lin.Jo[i] * lin.om[0] * lin.Jp[j] + lin.Jo[6 + i] * lin.om[1] * lin.Jp[3 + j] + lin.Jo[12 + i] * lin.om[2] * lin.Jp[6 + j];
+      const double wa = lin.Ja[i] * lin.om[0] * lin.Jp[j] + lin.Ja[6 + i] * lin.om[1] * lin.Jp[3 + j] + lin.Ja[12 + i] * lin.om[2] * lin.Jp[6 + j];
+      Wo[3 * i + j] = obs_role ? wo : 0.0;
+      WA[3 * i + j] = self ? (self_lit ? wo + wa : 0.0) : wa;
+    }
+  seg_allreduce<18>(WA, lane, seg_begin, seg_end, maxlen);
+  const int anchor = ed.anchor;
+
+  if (MODE == 1) {
+    // x_l = D^-1 (b_l - sum_i W_i^T x_i - W_A^T x_A)
+    double c[3] = {0, 0, 0};
+    if (obs_role) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c[j] += Wo[3 * i + j] * B.x[6 * ed.pose + i];
+    }
+    seg_allreduce<3>(c, lane, seg_begin, seg_end, maxlen);
+    double xl[3] = {0, 0, 0};
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double s = bl[j] - c[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s -= WA[3 * i + j] * B.x[6 * anchor + i];
+        c[j] = s;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xl[i] = Di[3 * i] * c[0] + Di[3 * i + 1] * c[1] + Di[3 * i + 2] * c[2];
+    }
+    double npsi[3] = {psi[0] + xl[0], psi[1] + xl[1], psi[2] + xl[2]};   // G2oVertexPointXYZ::oplusImpl
+    double sc = 0, chi = 0;
+    if (active) {
+      if (head) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { B.psi_trial[3 * (size_t)ed.point + i] = npsi[i]; sc += xl[i] * (B.lambda * xl[i] + bl[i]); }
+      }
+      double Tno[12], Tna[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { Tno[i] = B.poses_trial[12 * (size_t)ed.pose + i]; Tna[i] = B.poses_trial[12 * (size_t)anchor + i]; }
+      chi = edge_chi2(npsi, Tno, Tna, ed, B.cam, B.delta, B.robust);
+    }
+    sc = wave_sum_f64(sc);
+    chi = wave_sum_f64(chi);
+    if (lane == 0) { atomic_add_f64(&B.scal[0], chi); atomic_add_f64(&B.scal[1], sc); }
+    return;
+  }
+
+  // ---- MODE 0: reduced camera system -------------------------------------------------------
+  // observer part: blocks (i,i), (i,A), b_i
+  double WoD[18];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) WoD[3 * i + j] = Wo[3 * i] * Di[j] + Wo[3 * i + 1] * Di[3 + j] + Wo[3 * i + 2] * Di[6 + j];
+  if (obs_role) {
+    const int pi = ed.pose;
+    double *Hii = B.H + blk_index(pi, pi, P) * 36;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) {
+        double m = lin.Jo[r] * lin.om[0] * lin.Jo[c] + lin.Jo[6 + r] * lin.om[1] * lin.Jo[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Jo[12 + c];
+        m -= WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2];
+        atomic_add_f64(&Hii[6 * r + c], m);
+      }
+    const bool up = pi < anchor;
+    double *HiA = B.H + (up ? blk_index(pi, anchor, P) : blk_index(anchor, pi, P)) * 36;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double m = lin.Jo[r] * lin.om[0] * lin.Ja[c] + lin.Jo[6 + r] * lin.om[1] * lin.Ja[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Ja[12 + c];
+        m -= WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2];
+        atomic_add_f64(&HiA[up ? 6 * r + c : 6 * c + r], m);
+      }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      atomic_add_f64(&B.bp[6 * pi + r], lin.Jo[r] * lin.wr[0] + lin.Jo[6 + r] * lin.wr[1] + lin.Jo[12 + r] * lin.wr[2]);
+      atomic_add_f64(&B.bs[6 * pi + r], Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
+    }
+  }
+  // observer-observer pairs of the same landmark: partner = lane + t (edges sorted by observer)
+  for (int t = 1; t < maxlen; ++t) {
+    double Wj[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Wj[i] = __shfl_down(Wo[i], t, 64);
+    const int pj = __shfl_down(ed.pose, t, 64);
+    const int rolej = __shfl_down((int)obs_role, t, 64);
+    if (obs_role && lane + t <= seg_end && rolej) {
+      double *Hij = B.H + blk_index(ed.pose, pj, P) * 36;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          atomic_add_f64(&Hij[6 * r + c], -(WoD[3 * r] * Wj[3 * c] + WoD[3 * r + 1] * Wj[3 * c + 1] + WoD[3 * r + 2] * Wj[3 * c + 2]));
+    }
+  }
+  // anchor part: (A,A) block and b_A, from segment sums; written by the head lane
+  double ma[27];   // 21 unique of sum J_a^T O J_a (+ self-literal terms), 6 of sum J_a^T wr
+  {
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) {
+        double maa = lin.Ja[r] * lin.om[0] * lin.Ja[c] + lin.Ja[6 + r] * lin.om[1] * lin.Ja[6 + c] + lin.Ja[12 + r] * lin.om[2] * lin.Ja[12 + c];
+        if (self) {
+          if (self_lit) {
+            // slot-1 + slot-2 diagonal terms and the (1,2) pair all land on the anchor's
+            // diagonal block: Moo + Maa + Moa (symmetrised: Moa = -M up to rounding)
+            const double moo = lin.Jo[r] * lin.om[0] * lin.Jo[c] + lin.Jo[6 + r] * lin.om[1] * lin.Jo[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Jo[12 + c];
+            const double moa = lin.Jo[r] * lin.om[0] * lin.Ja[c] + lin.Jo[6 + r] * lin.om[1] * lin.Ja[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Ja[12 + c];
+            const double mao = lin.Jo[c] * lin.om[0] * lin.Ja[r] + lin.Jo[6 + c] * lin.om[1] * lin.Ja[6 + r] + lin.Jo[12 + c] * lin.om[2] * lin.Ja[12 + r];
+            maa = moo + maa + 0.5 * (moa + mao);
+          } else maa = 0;
+        }
+        ma[k++] = maa;
+      }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double ba = lin.Ja[r] * lin.wr[0] + lin.Ja[6 + r] * lin.wr[1] + lin.Ja[12 + r] * lin.wr[2];
+      if (self) ba = self_lit ? ba + (lin.Jo[r] * lin.wr[0] + lin.Jo[6 + r] * lin.wr[1] + lin.Jo[12 + r] * lin.wr[2]) : 0.0;
+      ma[21 + r] = ba;
+    }
+  }
+  seg_allreduce<27>(ma, lane, seg_begin, seg_end, maxlen);
+  if (active && head) {
+    double WAD[18];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) WAD[3 * i + j] = WA[3 * i] * Di[j] + WA[3 * i + 1] * Di[3 + j] + WA[3 * i + 2] * Di[6 + j];
+    double *HAA = B.H + blk_index(anchor, anchor, P) * 36;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) {
+        const double m = ma[k++] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]);
+        atomic_add_f64(&HAA[6 * r + c], m);
+      }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      atomic_add_f64(&B.bp[6 * anchor + r], ma[21 + r]);
+      atomic_add_f64(&B.bs[6 * anchor + r], WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+    }
+  }
+}
+
+// ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
+__device__ void d_so3_log(const double *R, double *w, double &theta) {
+  double q[4];
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { double s = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s; }
+  else { double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s; }
+  const double n = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), ww = q[0];
+  double two_atan;
+  if (n < 1e-10) two_atan = 2.0 / ww - 2.0 * (n * n) / (ww * ww * ww);
+  else if (fabs(ww) < 1e-10) two_atan = (ww > 0 ? M_PI : -M_PI) / n;
+  else two_atan = 2.0 * atan(n / ww) / n;
+  w[0] = two_atan * q[1]; w[1] = two_atan * q[2]; w[2] = two_atan * q[3];
+  theta = two_atan * n;
+}
+__device__ void d_pose_mul(const double *A, const double *Bm, double *Cm) {
+  double t[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) t[4 * i + j] = A[4 * i] * Bm[j] + A[4 * i + 1] * Bm[4 + j] + A[4 * i + 2] * Bm[8 + j];
+    t[4 * i + 3] += A[4 * i + 3];
+  }
+  for (int i = 0; i < 12; ++i) Cm[i] = t[i];
+}
+__device__ void d_pose_inv(const double *A, double *Bm) {
+  double t[12];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[4 * i + j] = A[4 * j + i];
+  for (int i = 0; i < 3; ++i) t[4 * i + 3] = -(t[4 * i] * A[3] + t[4 * i + 1] * A[7] + t[4 * i + 2] * A[11]);
+  for (int i = 0; i < 12; ++i) Bm[i] = t[i];
+}
+__device__ void d_se3_log(const double *T, double *x) {
+  double R[9], W[9], W2[9], Vi[9], th;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T[4 * i + j];
+  d_so3_log(R, x + 3, th);
+  const double *w = x + 3;
+  W[0] = 0; W[1] = -w[2]; W[2] = w[1]; W[3] = w[2]; W[4] = 0; W[5] = -w[0]; W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  const double c = fabs(th) < 1e-10 ? 1.0 / 12.0 : (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
+  for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * W[i] + c * W2[i];
+  Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
+  for (int i = 0; i < 3; ++i) x[i] = Vi[3 * i] * T[3] + Vi[3 * i + 1] * T[7] + Vi[3 * i + 2] * T[11];
+}
+__device__ void d_m6_mul(const double *A, const double *Bm, double *Cm) {
+  double t[36];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += A[6 * i + k] * Bm[6 * k + j]; t[6 * i + j] = s; }
+  for (int i = 0; i < 36; ++i) Cm[i] = t[i];
+}
+__device__ void d_third(const double *A, const double *d, double *out) {   // anchored_points.cpp:207-215
+  double Adj[36], dl[36], t1[36], t2[36];
+  for (int i = 0; i < 36; ++i) { Adj[i] = 0; dl[i] = 0; }
+  double R[9], th[9], tR[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = A[4 * i + j];
+  const double t[3] = {A[3], A[7], A[11]};
+  th[0] = 0; th[1] = -t[2]; th[2] = t[1]; th[3] = t[2]; th[4] = 0; th[5] = -t[0]; th[6] = -t[1]; th[7] = t[0]; th[8] = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) tR[3 * i + j] = th[3 * i] * R[j] + th[3 * i + 1] * R[3 + j] + th[3 * i + 2] * R[6 + j];
+  const double hu[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+  const double hw[9] = {0, -d[5], d[4], d[5], 0, -d[3], -d[4], d[3], 0};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    Adj[6 * i + j] = R[3 * i + j]; Adj[6 * i + 3 + j] = tR[3 * i + j]; Adj[6 * (i + 3) + 3 + j] = R[3 * i + j];
+    dl[6 * i + j] = -hw[3 * i + j]; dl[6 * i + 3 + j] = -hu[3 * i + j]; dl[6 * (i + 3) + 3 + j] = -hw[3 * i + j];
+  }
+  d_m6_mul(dl, Adj, t1);
+  d_m6_mul(dl, t1, t2);
+  for (int i = 0; i < 36; ++i) out[i] = Adj[i] + 0.5 * t1[i] + (1. / 12.) * t2[i];
+}
+
+template <int MODE>
+__global__ void ba_constraint_kernel(BaDev B) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B.C) return;
+  const svs_ba_constraint &cc = B.cons[c];
+  const double *poses = MODE == 0 ? B.poses : B.poses_trial;
+  double T2i[12], t[12], err[6];
+  d_pose_inv(poses + 12 * cc.pose2, T2i);
+  d_pose_mul(cc.T_21, poses + 12 * cc.pose1, t);
+  d_pose_mul(t, T2i, t);
+  d_se3_log(t, err);
+  double oe[6], e2 = 0;
+  for (int i = 0; i < 6; ++i) { oe[i] = 0; for (int j = 0; j < 6; ++j) oe[i] += cc.info[6 * i + j] * err[j]; e2 += err[i] * oe[i]; }
+  if (MODE == 1) { atomic_add_f64(&B.scal[0], e2); return; }
+  atomic_add_f64(B.chi2_cur, e2);
+  double J1[36], J2[36], OJ1[36], OJ2[36], nd[6];
+  const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  d_third(cc.T_21, err, J1);
+  for (int i = 0; i < 6; ++i) nd[i] = -err[i];
+  d_third(I, nd, J2);
+  for (int i = 0; i < 36; ++i) J2[i] = -J2[i];
+  d_m6_mul(cc.info, J1, OJ1);
+  d_m6_mul(cc.info, J2, OJ2);
+  const int p1 = cc.pose1, p2 = cc.pose2, P = B.P;
+  double *H11 = B.H + blk_index(p1, p1, P) * 36, *H22 = B.H + blk_index(p2, p2, P) * 36;
+  const bool up = p1 < p2;
+  double *H12 = B.H + (up ? blk_index(p1, p2, P) : blk_index(p2, p1, P)) * 36;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s11 = 0, s22 = 0, s12 = 0;
+      for (int k = 0; k < 6; ++k) { s11 += J1[6 * k + i] * OJ1[6 * k + j]; s22 += J2[6 * k + i] * OJ2[6 * k + j]; s12 += J1[6 * k + i] * OJ2[6 * k + j]; }
+      if (j >= i) { atomic_add_f64(&H11[6 * i + j], s11); atomic_add_f64(&H22[6 * i + j], s22); }
+      if (p1 != p2) atomic_add_f64(&H12[up ? 6 * i + j : 6 * j + i], s12);
+    }
+  for (int i = 0; i < 6; ++i) {
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < 6; ++k) { s1 += J1[6 * k + i] * oe[k]; s2 += J2[6 * k + i] * oe[k]; }
+    atomic_add_f64(&B.bp[6 * p1 + i], -s1);
+    atomic_add_f64(&B.bp[6 * p2 + i], -s2);
+  }
+}
+
+// ---- reduced-system solve: blocked right-looking Cholesky on the packed upper 6x6 blocks -------
+// One workgroup (1024 lanes); the factor overwrites H in L2-resident global memory, the current
+// panel row and the rhs live in LDS.  A = U^T U, U upper.  Fused forward substitution; column
+// oriented back substitution.  Then T_trial = exp(x_p) T, scale_p, bookkeeping scalars.
+constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_MAX_P = 256;
+
+__device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   // exp(x) * T  (G2oVertexSE3::oplusImpl)
+  const double *w = x + 3;
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+  double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, W2[9], R[9], V[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  double a, b;
+  if (th < 1e-10) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  for (int i = 0; i < 9; ++i) R[i] = a * W[i] + b * W2[i];
+  R[0] += 1; R[4] += 1; R[8] += 1;
+  if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
+  else {
+    const double c = (1.0 - cos(th)) / th2, d = (th - sin(th)) / (th2 * th);
+    for (int i = 0; i < 9; ++i) V[i] = c * W[i] + d * W2[i];
+    V[0] += 1; V[4] += 1; V[8] += 1;
+  }
+  double t[3];
+  for (int i = 0; i < 3; ++i) t[i] = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+    Tn[4 * i + 3] += t[i];
+  }
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws) {
+  extern __shared__ double smem[];
+  const int P = B.P, n = 6 * P, tid = threadIdx.x;
+  double *s_b = smem;                 // [n] rhs -> y -> x
+  double *s_panel = smem + n;         // [(P)*36] current panel row U_kj, j>k
+  double *s_linv = s_panel + (size_t)P * 36;   // [36] (U_kk^T)^-1, lower
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  __syncthreads();
+  for (int k = 0; k < P; ++k) {
+    if (tid == 0) {
+      // 6x6 Cholesky of A_kk (+lambda), upper stored
+      double A[36], U[36], Li[36];
+      const double *Akk = B.H + blk_index(k, k, P) * 36;
+      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { double v = Akk[6 * r + c]; if (r == c) v += B.lambda; A[6 * r + c] = v; A[6 * c + r] = v; }
+      int fail = 0;
+      for (int i = 0; i < 36; ++i) U[i] = 0;
+      for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+        for (int q = 0; q < j; ++q) d -= U[6 * q + j] * U[6 * q + j];
+        if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1; }
+        d = sqrt(d);
+        U[6 * j + j] = d;
+        for (int c = j + 1; c < 6; ++c) {
+          double s = A[6 * j + c];
+          for (int q = 0; q < j; ++q) s -= U[6 * q + j] * U[6 * q + c];
+          U[6 * j + c] = s / d;
+        }
+      }
+      // Li = (U^T)^-1 (lower triangular): forward substitution on identity
+      for (int i = 0; i < 36; ++i) Li[i] = 0;
+      for (int c = 0; c < 6; ++c)
+        for (int r = c; r < 6; ++r) {
+          double s = (r == c) ? 1.0 : 0.0;
+          for (int q = c; q < r; ++q) s -= U[6 * q + r] * Li[6 * q + c];
+          Li[6 * r + c] = s / U[6 * r + r];
+        }
+      for (int i = 0; i < 36; ++i) { s_linv[i] = Li[i]; linv_ws[(size_t)k * 36 + i] = Li[i]; }
+      if (fail) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) break;
+    // y_k = Li * b_k (forward substitution, fused)
+    double yk[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { double s = 0; for (int q = 0; q <= r; ++q) s += s_linv[6 * r + q] * s_b[6 * k + q]; yk[r] = s; }
+    // panel: U_kj = Li * A_kj, j > k
+    const int nj = P - k - 1;
+    for (int e = tid; e < nj * 36; e += SOLVE_THREADS) {
+      const int jj = e / 36, rc = e - jj * 36, r = rc / 6, c = rc - r * 6;
+      double *Akj = B.H + (blk_index(k, k, P) + 1 + jj) * 36;
+      double s = 0;
+      for (int q = 0; q <= r; ++q) s += s_linv[6 * r + q] * Akj[6 * q + c];
+      s_panel[(size_t)jj * 36 + rc] = s;
+    }
+    __syncthreads();
+    if (tid < 6) s_b[6 * k + tid] = yk[tid];
+    for (int e = tid; e < nj * 36; e += SOLVE_THREADS) B.H[(blk_index(k, k, P) + 1) * 36 + e] = s_panel[e];   // keep U for back substitution
+    // rhs update: b_j -= U_kj^T y_k
+    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {
+      const int jj = e / 6, c = e - jj * 6;
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += s_panel[(size_t)jj * 36 + 6 * q + c] * yk[q];
+      s_b[6 * (k + 1 + jj) + c] -= s;
+    }
+    // trailing update: A_ij -= U_ki^T U_kj, k < i <= j
+    const long nblk = (long)nj * (nj + 1) / 2;
+    for (long e = tid; e < nblk * 36; e += SOLVE_THREADS) {
+      const long bidx = e / 36;
+      const int rc = (int)(e - bidx * 36), r = rc / 6, c = rc - r * 6;
+      // unrank (ii, jj) with ii <= jj in the packed upper triangle of size nj
+      int ii = (int)((2.0 * nj + 1.0 - sqrt((2.0 * nj + 1.0) * (2.0 * nj + 1.0) - 8.0 * (double)bidx)) * 0.5);
+      while ((long)ii * nj - (long)ii * (ii - 1) / 2 > bidx) --ii;
+      while ((long)(ii + 1) * nj - (long)(ii + 1) * ii / 2 <= bidx) ++ii;
+      const int jj = ii + (int)(bidx - ((long)ii * nj - (long)ii * (ii - 1) / 2));
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += s_panel[(size_t)ii * 36 + 6 * q + r] * s_panel[(size_t)jj * 36 + 6 * q + c];
+      B.H[blk_index(k + 1 + ii, k + 1 + jj, P) * 36 + rc] -= s;
+    }
+    __syncthreads();
+  }
+  const int fail = s_fail;
+  __syncthreads();
+  if (!fail) {
+    // back substitution (column oriented): x_k = Li_k^T y_k ; y_i -= U_ik x_k for i < k
+    for (int k = P - 1; k >= 0; --k) {
+      if (tid < 6) {
+        double s = 0;
+        for (int q = tid; q < 6; ++q) s += linv_ws[(size_t)k * 36 + 6 * q + tid] * s_b[6 * k + q];
+        s_linv[tid] = s;
+      }
+      __syncthreads();
+      if (tid < 6) s_b[6 * k + tid] = s_linv[tid];
+      for (int e = tid; e < k * 6; e += SOLVE_THREADS) {
+        const int i = e / 6, r = e - i * 6;
+        const double *Uik = B.H + blk_index(i, k, P) * 36;
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += Uik[6 * r + q] * s_linv[q];
+        s_b[6 * i + r] -= s;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = 0;
+    __syncthreads();
+  }
+  // outputs: x, scale_p = sum x (lambda x + b_p), trial poses
+  double sc = 0;
+  for (int i = tid; i < n; i += SOLVE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  sc = wave_sum_f64(sc);
+  if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
+  if (tid < P) {
+    double Tn[12];
+    d_se3_exp_mul(s_b + 6 * tid, B.poses + 12 * (size_t)tid, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)tid + i] = Tn[i];
+  }
+  if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
+}
+
+// expands the packed upper blocks to a full symmetric matrix + bred (parity tests)
+__global__ void ba_expand_kernel(BaDev B, double *__restrict__ Hfull, double *__restrict__ bred) {
+  const int P = B.P, n = 6 * P;
+  const long total = (long)n * n;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / n), col = (int)(e % n);
+    int bi = row / 6, bj = col / 6, r = row % 6, c = col % 6;
+    double v;
+    if (bi < bj) v = B.H[blk_index(bi, bj, P) * 36 + 6 * r + c];
+    else if (bi > bj) v = B.H[blk_index(bj, bi, P) * 36 + 6 * c + r];
+    else v = r <= c ? B.H[blk_index(bi, bi, P) * 36 + 6 * r + c] : B.H[blk_index(bi, bi, P) * 36 + 6 * c + r];
+    if (row == col) v += B.lambda;
+    Hfull[e] = v;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bred[i] = B.bp[i] - B.bs[i];
+}
+
+}  // namespace
+
+struct svs_ba {
+  svs_ctx *ctx = nullptr;
+  int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, add_pose_terms = 1;
+  svs_cam cam{};
+  svs_ba_params prm{};
+  double *d_poses[2] = {nullptr, nullptr}, *d_psi[2] = {nullptr, nullptr};
+  int cur = 0;
+  svs_ba_edge *d_edges = nullptr;
+  int *d_chunk_start = nullptr, *d_chunk_len = nullptr;
+  svs_ba_constraint *d_cons = nullptr;
+  double *d_red = nullptr;     // [nblk*36][bp 6P][bs 6P][chi2]
+  size_t red_count = 0;
+  double *d_x = nullptr, *d_scal = nullptr, *d_linv = nullptr;
+  hipEvent_t ev[6] = {};
+  float t_reduce = 0, t_solve = 0, t_backsub = 0;
+  int n_reduce = 0;
+  void free_all() {
+    for (int i = 0; i < 2; ++i) { if (d_poses[i]) (void)hipFree(d_poses[i]); if (d_psi[i]) (void)hipFree(d_psi[i]); d_poses[i] = d_psi[i] = nullptr; }
+    if (d_edges) (void)hipFree(d_edges); if (d_chunk_start) (void)hipFree(d_chunk_start); if (d_chunk_len) (void)hipFree(d_chunk_len);
+    if (d_cons) (void)hipFree(d_cons); if (d_red) (void)hipFree(d_red); if (d_x) (void)hipFree(d_x); if (d_scal) (void)hipFree(d_scal);
+    if (d_linv) (void)hipFree(d_linv);
+    d_edges = nullptr; d_chunk_start = d_chunk_len = nullptr; d_cons = nullptr; d_red = d_x = d_scal = d_linv = nullptr;
+  }
+};
+
+static BaDev make_dev(const svs_ba *ba, double lambda) {
+  BaDev B{};
+  B.P = ba->P; B.L = ba->L; B.E = ba->E; B.C = ba->add_pose_terms ? ba->C : 0; B.n_chunks = ba->n_chunks;
+  B.poses = ba->d_poses[ba->cur]; B.psi = ba->d_psi[ba->cur];
+  B.poses_trial = ba->d_poses[1 - ba->cur]; B.psi_trial = ba->d_psi[1 - ba->cur];
+  B.edges = ba->d_edges; B.chunk_start = ba->d_chunk_start; B.chunk_len = ba->d_chunk_len; B.cons = ba->d_cons;
+  const size_t nblk = (size_t)ba->P * (ba->P + 1) / 2;
+  B.H = ba->d_red; B.bp = ba->d_red + nblk * 36; B.bs = B.bp + 6 * (size_t)ba->P; B.chi2_cur = B.bs + 6 * (size_t)ba->P;
+  B.x = ba->d_x; B.scal = ba->d_scal;
+  B.cam = ba->cam; B.delta = ba->prm.huber_delta; B.lambda = lambda; B.robust = ba->prm.use_robust; B.self_mode = ba->prm.self_edge_mode;
+  return B;
+}
+
+extern "C" int svs_ba_create(svs_ctx *ctx, svs_ba **out) {
+  SVS_REQUIRE(ctx, ctx && out);
+  svs_ba *ba = new svs_ba();
+  ba->ctx = ctx;
+  for (auto &e : ba->ev) SVS_HIP(ctx, hipEventCreate(&e));
+  *out = ba;
+  return SVS_OK;
+}
+extern "C" int svs_ba_destroy(svs_ba *ba) {
+  if (!ba) return SVS_OK;
+  (void)hipStreamSynchronize(ba->ctx->stream);
+  ba->free_all();
+  for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
+  delete ba;
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const double *h_psi, int E,
+                                  const svs_ba_edge *h_edges, int C, const svs_ba_constraint *h_cons, const svs_cam *cam,
+                                  const svs_ba_params *prm, int add_pose_terms) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && h_poses && (L == 0 || h_psi) && (E == 0 || h_edges) && (C == 0 || h_cons) && cam && prm);
+  SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
+  if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ba->free_all();
+  ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
+  // sort edges by (landmark, observer) -- copyDataToG2o iterates hash sets, so the reference has no
+  // meaningful edge order to preserve -- and pack whole landmarks into <=64-edge wave chunks
+  std::vector<int> order(E);
+  for (int i = 0; i < E; ++i) {
+    order[i] = i;
+    SVS_REQUIRE(ctx, h_edges[i].point >= 0 && h_edges[i].point < L && h_edges[i].pose >= 0 && h_edges[i].pose < P && h_edges[i].anchor >= 0 && h_edges[i].anchor < P);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (h_edges[a].point != h_edges[b].point) return h_edges[a].point < h_edges[b].point;
+    return h_edges[a].pose < h_edges[b].pose;
+  });
+  std::vector<svs_ba_edge> sorted(E);
+  for (int i = 0; i < E; ++i) sorted[i] = h_edges[order[i]];
+  std::vector<int> cs, cl;
+  int i = 0;
+  while (i < E) {
+    int start = i, len = 0;
+    while (i < E) {
+      int j = i;
+      while (j < E && sorted[j].point == sorted[i].point) ++j;
+      int m = j - i;
+      if (m > 64) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
+      for (int a = i + 1; a < j; ++a) {
+        SVS_REQUIRE(ctx, sorted[a].anchor == sorted[i].anchor);          // one anchor per point (slam_graph.hpp:121-133)
+        SVS_REQUIRE(ctx, sorted[a].pose != sorted[a - 1].pose);          // one observation per (point, keyframe)
+      }
+      if (len + m > 64) break;
+      len += m; i = j;
+    }
+    cs.push_back(start); cl.push_back(len);
+  }
+  ba->n_chunks = (int)cs.size();
+  const size_t nblk = (size_t)P * (P + 1) / 2;
+  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
+  for (int k = 0; k < 2; ++k) {
+    SVS_HIP(ctx, hipMalloc(&ba->d_poses[k], sizeof(double) * 12 * (size_t)P));
+    SVS_HIP(ctx, hipMalloc(&ba->d_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+    if (L) SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[k], h_psi, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SVS_HIP(ctx, hipMalloc(&ba->d_edges, sizeof(svs_ba_edge) * (size_t)std::max(E, 1)));
+  SVS_HIP(ctx, hipMalloc(&ba->d_chunk_start, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
+  SVS_HIP(ctx, hipMalloc(&ba->d_chunk_len, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
+  SVS_HIP(ctx, hipMalloc(&ba->d_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
+  SVS_HIP(ctx, hipMalloc(&ba->d_red, sizeof(double) * ba->red_count));
+  SVS_HIP(ctx, hipMalloc(&ba->d_x, sizeof(double) * 6 * (size_t)P));
+  SVS_HIP(ctx, hipMalloc(&ba->d_scal, sizeof(double) * 8));
+  SVS_HIP(ctx, hipMalloc(&ba->d_linv, sizeof(double) * 36 * (size_t)P));
+  if (E) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges, sorted.data(), sizeof(svs_ba_edge) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
+  if (ba->n_chunks) {
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_start, cs.data(), sizeof(int) * cs.size(), hipMemcpyHostToDevice, ctx->stream));
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_len, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (C) SVS_HIP(ctx, hipMemcpyAsync(ba->d_cons, h_cons, sizeof(svs_ba_constraint) * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)P, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && h_poses && ba->d_poses[0]);
+  ba->cur = 0;
+  for (int k = 0; k < 2; ++k) {
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)ba->P, hipMemcpyHostToDevice, ctx->stream));
+    if (ba->L && h_psi) SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[k], h_psi, sizeof(double) * 3 * (size_t)ba->L, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)ba->P, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+// buildSystem + Schur reduction at the current state (MODE 0 kernels)
+static int launch_reduce(svs_ba *ba, double lambda) {
+  svs_ctx *ctx = ba->ctx;
+  BaDev B = make_dev(ba, lambda);
+  SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
+  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(div_up(B.C, 64)), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  SVS_HIP(ctx, hipEventRecord(ba->ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
+  if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  SVS_HIP(ctx, hipEventRecord(ba->ev[1], ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred, double *h_bred, double *h_chi2) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && ba->d_red);
+  int rc = launch_reduce(ba, lambda);
+  if (rc) return rc;
+  BaDev B = make_dev(ba, lambda);
+  const int n = 6 * ba->P;
+  double *d_full = nullptr, *d_b = nullptr;
+  SVS_HIP(ctx, hipMalloc(&d_full, sizeof(double) * (size_t)n * n));
+  SVS_HIP(ctx, hipMalloc(&d_b, sizeof(double) * n));
+  hipLaunchKernelGGL(ba_expand_kernel, dim3(256), dim3(256), 0, ctx->stream, B, d_full, d_b);
+  SVS_LAUNCH_CHECK(ctx);
+  if (h_Hred) SVS_HIP(ctx, hipMemcpyAsync(h_Hred, d_full, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_bred) SVS_HIP(ctx, hipMemcpyAsync(h_bred, d_b, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_chi2) SVS_HIP(ctx, hipMemcpyAsync(h_chi2, B.chi2_cur, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_full); (void)hipFree(d_b);
+  return SVS_OK;
+}
+
+// OptimizationAlgorithmLevenberg::solve x num_iters, host control flow, device math.
+extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && ba->d_red);
+  const svs_ba_params &prm = ba->prm;
+  double lambda = prm.lambda_init, ni = 2;
+  svs_ba_stats st{};
+  ba->t_reduce = ba->t_solve = ba->t_backsub = 0; ba->n_reduce = 0;
+  bool ok = true;
+  const size_t smem = sizeof(double) * ((size_t)6 * ba->P + (size_t)ba->P * 36 + 36);
+  if (smem > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  for (int it = 0; it < prm.num_iters && ok; ++it) {
+    if (it == 0) { lambda = prm.lambda_init; ni = 2; }
+    double rho = 0, currentChi = 0;
+    int qmax = 0;
+    do {
+      // (re)build at the current state with this lambda; the state only changes on accept, so a
+      // rebuilt system equals g2o's "restore diagonal + add new lambda"
+      int rc = launch_reduce(ba, lambda);
+      if (rc) return rc;
+      if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
+      BaDev B = make_dev(ba, lambda);
+      SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 8, ctx->stream));
+      SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
+      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv);
+      SVS_LAUNCH_CHECK(ctx);
+      SVS_HIP(ctx, hipEventRecord(ba->ev[3], ctx->stream));
+      if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(div_up(B.C, 64)), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+      SVS_HIP(ctx, hipEventRecord(ba->ev[5], ctx->stream));
+      if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+      SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
+      if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
+      double h[5];
+      SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+      SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      float ms;
+      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[0], ba->ev[1])); ba->t_reduce += ms; ba->n_reduce++;
+      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[2], ba->ev[3])); ba->t_solve += ms;
+      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[5], ba->ev[4])); ba->t_backsub += ms;
+      const bool fail = h[3] != 0.0;
+      if (qmax == 0) { currentChi = h[4]; if (it == 0) st.chi2_init = currentChi; }
+      double tempChi = fail ? 1.7976931348623157e308 : h[0];
+      rho = currentChi - tempChi;
+      double scale = h[1] + h[2] + 1e-3;
+      rho /= scale;
+      ++st.trials;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2; currentChi = tempChi; ++st.accepted;
+        ba->cur = 1 - ba->cur;                      // discardTop: trial state becomes current
+        // keep the other buffer's untouched landmarks coherent: psi_trial of landmarks without
+        // edges on this rank was never written, but both buffers started equal and only owned
+        // landmarks ever change, so nothing to copy.
+      } else {
+        lambda *= ni; ni *= 2;                      // pop: current state stays
+      }
+      ++qmax;
+    } while (rho < 0 && qmax < prm.max_trials);
+    ++st.iterations;
+    st.chi2_final = currentChi;
+    if (qmax == prm.max_trials || rho == 0) { ok = false; st.terminated = 1; }
+  }
+  st.lambda_final = lambda;
+  if (stats) *stats = st;
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && ba->d_poses[0]);
+  if (h_poses) SVS_HIP(ctx, hipMemcpyAsync(h_poses, ba->d_poses[ba->cur], sizeof(double) * 12 * (size_t)ba->P, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_psi && ba->L) SVS_HIP(ctx, hipMemcpyAsync(h_psi, ba->d_psi[ba->cur], sizeof(double) * 3 * (size_t)ba->L, hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_kernel_times(svs_ba *ba, float *reduce_ms, float *solve_ms, float *backsub_ms, int32_t *n_launches) {
+  if (!ba) return SVS_ERR_INVALID;
+  if (reduce_ms) *reduce_ms = ba->t_reduce;
+  if (solve_ms) *solve_ms = ba->t_solve;
+  if (backsub_ms) *backsub_ms = ba->t_backsub;
+  if (n_launches) *n_launches = ba->n_reduce;
+  return SVS_OK;
+}

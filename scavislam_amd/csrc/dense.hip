@@ -1,0 +1,488 @@
+// dense.hip -- dense (direct) SE3 tracking for gfx950.
+// Replaces DenseTracker::denseTrackingCpu / computeDensePointCloudCpu
+// (dense_tracking.cpp:222-423; the parity target, SURVEY.md section 0 last row) and the four
+// CUDA kernels of gpu/dense_tracking.cu (pointcloud :82-122, jacobianReduction :172-263,
+// chi2 :376-453) behind the GpuTracker call surface (gpu/dense_tracking.cuh:281-342).
+//
+// MI355X-first design:
+//  * per-sample work is a gather (cloud, 4-tap bilinear of cur/dx/dy) + 27 accumulators; the
+//    reduction is wave64 shuffles -> LDS across waves -> one partial per workgroup, summed by a
+//    fixed-order finalize kernel (deterministic, no float atomics, no host-side summation of
+//    block partials as in the reference's .cu:343-355);
+//  * svs_dense_track_cpu_sem keeps the WHOLE coarse-to-fine LM loop on the device: one 1024-lane
+//    workgroup per camera stream iterates chi2 / H,b / 6x6 solve / SE3 exp / accept-reject with
+//    LDS broadcasts, so a frame costs one launch instead of ~90 launch+sync+D2H round trips.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int NSUM = 28;   // 21 H + 6 b + chi2 ; n_valid kept separately
+
+struct Acc {
+  double v[NSUM];
+  long long n;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) v[i] = 0;
+    n = 0;
+  }
+};
+
+__device__ __forceinline__ float interp32f(const float *__restrict__ m, int stride, float u, float v) {
+  float x = floorf(u), y = floorf(v);
+  float sx = u - x, sy = v - y;
+  float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+  int xi = (int)x, yi = (int)y;
+  const float *p = m + (size_t)yi * stride + xi;
+  float v00 = p[0], v10 = p[1], v01 = p[stride], v11 = p[stride + 1];
+  return (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
+}
+
+struct LevelArgs {
+  const float *cloud; const uint8_t *prev; const float *cur, *dx, *dy;
+  int pstride, fstride;
+  svs_cam cam;
+};
+
+// loop body of dense_tracking.cpp:229-261 (chi2) / :278-331 (H, b), one sample
+template <bool JAC>
+__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, int u, int v, int cw, Acc &a) {
+  const float4 c4 = reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u];
+  if (!(c4.w > 0)) return;
+  const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
+  const double x = T[0] * xp0 + T[1] * xp1 + T[2] * xp2 + T[3];
+  const double y = T[4] * xp0 + T[5] * xp1 + T[6] * xp2 + T[7];
+  const double z = T[8] * xp0 + T[9] * xp1 + T[10] * xp2 + T[11];
+  const float uvx = (float)(L.cam.f * (x / z) + L.cam.cx);
+  const float uvy = (float)(L.cam.f * (y / z) + L.cam.cy);
+  if (!(fabsf(uvx) < 1e9f && fabsf(uvy) < 1e9f)) return;
+  const int ui = (int)uvx, vi = (int)uvy;
+  if (!(ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2)) return;
+  const float ip = (float)((1. / 255.) * L.prev[(size_t)(v * 4) * L.pstride + u * 4]);
+  const float ic = interp32f(L.cur, L.fstride, uvx, uvy);
+  float res = ip - ic;
+  if (res > 0.1) res = 0.1;
+  if (res < -0.1) res = -0.1;
+  a.v[27] += (double)(res * res);
+  a.n += 1;
+  if (JAC) {
+    const float gx = (float)(0.5 * interp32f(L.dx, L.fstride, uvx, uvy));
+    const float gy = (float)(0.5 * interp32f(L.dy, L.fstride, uvx, uvy));
+    const double f = L.cam.f, z2 = z * z;
+    // transformations.h:117-139 frame_jac_xyz2uv
+    double r0[6] = {-1. / z * f, 0, x / z2 * f, x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f};
+    double r1[6] = {0, -1. / z * f, y / z2 * f, (1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f};
+    double J[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) J[k] = gx * r0[k] + gy * r1[k];
+    int k = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = 0; r <= c; ++r) a.v[k++] += J[r] * J[c];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.v[21 + i] += J[i] * res;
+  }
+}
+
+// block reduction: wave shuffles then LDS; result valid in threads [0, NSUM] (index = value id)
+template <int NWAVES>
+__device__ __forceinline__ void block_reduce(Acc &a, double (*s_part)[NSUM + 1], double *out_vals /* NSUM+1 in LDS */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NSUM; ++i) a.v[i] = wave_sum_f64(a.v[i]);
+  double nn = wave_sum_f64((double)a.n);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) s_part[wave][i] = a.v[i];
+    s_part[wave][NSUM] = nn;
+  }
+  __syncthreads();
+  if (threadIdx.x <= NSUM) {
+    double s = 0;
+    for (int w = 0; w < NWAVES; ++w) s += s_part[w][threadIdx.x];
+    out_vals[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// ---- multi-workgroup single pass (GpuTracker-style API) --------------------------------------
+template <bool JAC>
+__global__ __launch_bounds__(256) void dense_pass_cpu_sem_kernel(LevelArgs L, size_t cloud_b, size_t prev_b, size_t f_b,
+                                                                 const double *__restrict__ Tarr, double *__restrict__ partials) {
+  __shared__ double s_part[4][NSUM + 1];
+  __shared__ double s_out[NSUM + 1];
+  const int slot = blockIdx.y;
+  L.cloud += slot * cloud_b; L.prev += slot * prev_b; L.cur += slot * f_b; L.dx += slot * f_b; L.dy += slot * f_b;
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = Tarr[(size_t)slot * 12 + i];
+  const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
+  Acc a;
+  a.zero();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, a);
+  block_reduce<4>(a, s_part, s_out);
+  if (threadIdx.x <= NSUM) partials[((size_t)slot * gridDim.x + blockIdx.x) * (NSUM + 1) + threadIdx.x] = s_out[threadIdx.x];
+}
+
+__global__ void dense_finalize_kernel(const double *__restrict__ partials, int nblocks, svs_dense_sums *__restrict__ out) {
+  const int slot = blockIdx.x, t = threadIdx.x;
+  if (t > NSUM) return;
+  double s = 0;
+  for (int b = 0; b < nblocks; ++b) s += partials[((size_t)slot * nblocks + b) * (NSUM + 1) + t];
+  svs_dense_sums *o = &out[slot];
+  if (t < 21) o->H[t] = s;
+  else if (t < 27) o->b[t - 21] = s;
+  else if (t == 27) o->chi2 = (double)(float)s;     // reference keeps chi2 in a float
+  else o->n_valid = (long long)s;
+}
+
+// ---- device-resident LM (whole denseTrackingCpu) ---------------------------------------------
+__device__ void d_solve6(const double *A, const double *b, double *x) {   // Gaussian elimination, partial pivoting
+  double M[6][7];
+  for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) M[i][j] = A[i * 6 + j]; M[i][6] = b[i]; }
+  for (int k = 0; k < 6; ++k) {
+    int p = k; double best = fabs(M[k][k]);
+    for (int i = k + 1; i < 6; ++i) if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); p = i; }
+    if (p != k) for (int j = 0; j < 7; ++j) { double t = M[k][j]; M[k][j] = M[p][j]; M[p][j] = t; }
+    double piv = M[k][k];
+    for (int i = k + 1; i < 6; ++i) { double f = M[i][k] / piv; for (int j = k; j < 7; ++j) M[i][j] -= f * M[k][j]; }
+  }
+  for (int i = 5; i >= 0; --i) { double s = M[i][6]; for (int j = i + 1; j < 6; ++j) s -= M[i][j] * x[j]; x[i] = s / M[i][i]; }
+}
+__device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   // Tn = exp(x) * T
+  const double *w = x + 3;
+  double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+  double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, W2[9], R[9], V[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  double a, b;
+  if (th < 1e-10) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  for (int i = 0; i < 9; ++i) R[i] = a * W[i] + b * W2[i];
+  R[0] += 1; R[4] += 1; R[8] += 1;
+  if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
+  else {
+    double c = (1.0 - cos(th)) / th2, d = (th - sin(th)) / (th2 * th);
+    for (int i = 0; i < 9; ++i) V[i] = c * W[i] + d * W2[i];
+    V[0] += 1; V[4] += 1; V[8] += 1;
+  }
+  double t[3];
+  for (int i = 0; i < 3; ++i) t[i] = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+    Tn[4 * i + 3] += t[i];
+  }
+}
+
+struct TrackArgs {
+  LevelArgs lv[3];
+  size_t cloud_b[3], prev_b[3], f_b[3];
+};
+
+constexpr int TRK_THREADS = 1024;
+
+template <bool JAC>
+__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out) {
+  const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
+  Acc a;
+  a.zero();
+  for (int i = threadIdx.x; i < n; i += TRK_THREADS) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, a);
+  block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
+}
+
+__global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out) {
+  __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
+  __shared__ double s_out[NSUM + 1];
+  __shared__ double s_T[12], s_Tn[12], s_x[6];
+  __shared__ int s_flag[2];    // [0] accepted, [1] stop
+  const int slot = blockIdx.x;
+  if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
+  __syncthreads();
+  int passes = 0;
+  for (int level = 2; level >= 0; --level) {
+    LevelArgs L = A.lv[level];
+    L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
+    L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level];
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = s_T[i];
+    track_pass<false>(L, T, s_part, s_out);
+    ++passes;
+    float chi2 = (float)s_out[27];
+    int trial = 0;
+    bool stop = false;
+    for (int it = 0; it < 15 && !stop; ++it) {
+      bool accepted = false;
+      do {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = s_T[i];
+        track_pass<true>(L, T, s_part, s_out);
+        ++passes;
+        if (threadIdx.x == 0) {
+          double H[36], nb[6], x[6];
+          int k = 0;
+          for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { H[6 * r + c] = s_out[k]; H[6 * c + r] = s_out[k]; ++k; }
+          for (int q = 0; q < 6; ++q) nb[q] = -s_out[21 + q];
+          d_solve6(H, nb, x);                       // H.ldlt().solve(-Jres): undamped (dense_tracking.cpp:332)
+          double Tn[12];
+          d_se3_exp_mul(x, s_T, Tn);
+          for (int i = 0; i < 12; ++i) s_Tn[i] = Tn[i];
+          for (int i = 0; i < 6; ++i) s_x[i] = x[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
+        track_pass<false>(L, T, s_part, s_out);
+        ++passes;
+        const float new_chi2 = (float)s_out[27];
+        const double rho = (double)chi2 - (double)new_chi2;
+        if (rho > 0) {
+          accepted = true;
+          chi2 = new_chi2;
+          double mx = -1;
+          for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(s_x[q]));
+          stop = mx <= 1e-10;
+          trial = 0;
+          __syncthreads();
+          if (threadIdx.x < 12) s_T[threadIdx.x] = s_Tn[threadIdx.x];
+          __syncthreads();
+        } else {
+          accepted = false;
+          ++trial;
+          if (trial == 2) stop = true;
+        }
+      } while (!(accepted || stop));
+    }
+  }
+  if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];
+  if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
+}
+
+// computeDensePointCloudCpu (dense_tracking.cpp:393-423)
+__global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__restrict__ disp, int ds, size_t disp_b, svs_cam cam,
+                                                                 int level, const double *__restrict__ Tarr,
+                                                                 float *__restrict__ cloud, size_t cloud_b) {
+  const int slot = blockIdx.y;
+  const int cw = cam.w / 4, ch = cam.h / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cw * ch) return;
+  const int u = i % cw, v = i / cw;
+  double T[12], Ti[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * 12 + k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) Ti[4 * r + 3] = -(Ti[4 * r] * T[3] + Ti[4 * r + 1] * T[7] + Ti[4 * r + 2] * T[11]);
+  // TQ = [Ti;0 0 0 1] * Q, Q = [1 0 0 -cx; 0 1 0 -cy; 0 0 0 f; 0 0 1/b 0] (stereo_camera.cpp:24-34),
+  // evaluated with the same term order as a dense 4x4 product
+  const double Q[16] = {1, 0, 0, -cam.cx, 0, 1, 0, -cam.cy, 0, 0, 0, cam.f, 0, 0, 1.0 / cam.b, 0};
+  double TQ[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { double tik = r < 3 ? Ti[4 * r + k] : (k == 3 ? 1.0 : 0.0); s += tik * Q[4 * k + c]; }
+      TQ[4 * r + c] = s;
+    }
+  const double inv_factor = 1.0 / (double)(1 << level);
+  const float d = (float)(disp[slot * disp_b + (size_t)((v * 4) << level) * ds + ((u * 4) << level)] * inv_factor);
+  float4 o;
+  if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
+  else {
+    const double q[4] = {(double)(u * 4), (double)(v * 4), (double)d, 1.0};
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = TQ[4 * k] * q[0] + TQ[4 * k + 1] * q[1] + TQ[4 * k + 2] * q[2] + TQ[4 * k + 3] * q[3];
+    o = make_float4((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]), 1.f);
+  }
+  reinterpret_cast<float4 *>(cloud + slot * cloud_b)[i] = o;
+}
+
+// ---- full-resolution f32 variant (gpu/dense_tracking.cu semantics) ---------------------------
+struct T34 { float m[12]; };
+struct T44 { float m[16]; };
+
+template <bool JAC>
+__global__ __launch_bounds__(256) void dense_pass_full_kernel(const float *__restrict__ cloud, int w, int h, int s4,
+                                                              const float *__restrict__ prev, const float *__restrict__ cur,
+                                                              const float *__restrict__ dxi, const float *__restrict__ dyi, int fs,
+                                                              float f, float cx, float cy, T34 T, double *__restrict__ partials) {
+  __shared__ double s_part[4][NSUM + 1];
+  __shared__ double s_out[NSUM + 1];
+  Acc a;
+  a.zero();
+  // 64x4 pixel tiles: a wavefront reads one contiguous 64-pixel row segment (1 KiB of float4)
+  const int tiles_x = div_up(w, 64), tiles_y = div_up(h, 4);
+  for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+    const int u = (t % tiles_x) * 64 + (threadIdx.x & 63), v = (t / tiles_x) * 4 + (threadIdx.x >> 6);
+    if (u >= w || v >= h) continue;
+    const float4 p = reinterpret_cast<const float4 *>(cloud)[(size_t)v * s4 + u];
+    if (!(p.w > 0)) continue;
+    const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];
+    const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
+    const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
+    const float uu = f * x / z + cx, vv = f * y / z + cy;
+    if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) continue;
+    const float ip = prev[(size_t)v * fs + u];
+    const float ic = interp32f(cur, fs, uu, vv);
+    const float res = ip - ic;
+    a.v[27] += (double)(res * res);
+    a.n += 1;
+    if (JAC) {
+      float gx = 0.5f * interp32f(dxi, fs, uu, vv), gy = 0.5f * interp32f(dyi, fs, uu, vv);
+      const float zsq = z * z;
+      gx *= f; gy *= f;
+      float J[6];
+      J[0] = (float)(-gx * (1. / z));
+      J[1] = (float)(-gy * 1. / z);
+      J[2] = (gx * x / zsq + gy * y / zsq);
+      J[3] = (gx * (x * y) / zsq + gy * (1.f + y * y / zsq));
+      J[4] = (-gx * (1.f + (x * x / zsq)) - gy * (x * y) / zsq);
+      J[5] = (gx * y / z - gy * x / z);
+      int k = 0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = 0; r <= c; ++r) a.v[k++] += (double)(J[c] * J[r]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a.v[21 + i] += (double)(J[i] * res);
+    }
+  }
+  block_reduce<4>(a, s_part, s_out);
+  if (threadIdx.x <= NSUM) partials[(size_t)blockIdx.x * (NSUM + 1) + threadIdx.x] = s_out[threadIdx.x];
+}
+
+__global__ void dense_finalize_full_kernel(const double *__restrict__ partials, int nblocks, svs_dense_sums *__restrict__ out) {
+  const int t = threadIdx.x;
+  if (t > NSUM) return;
+  double s = 0;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * (NSUM + 1) + t];
+  if (t < 21) out->H[t] = s;
+  else if (t < 27) out->b[t - 21] = s;
+  else if (t == 27) out->chi2 = s;
+  else out->n_valid = (long long)s;
+}
+
+__global__ __launch_bounds__(256) void pointcloud_full_kernel(T44 TQ, const float *__restrict__ disp, int w, int h, int si, int so,
+                                                              int factor, float *__restrict__ cloud) {
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= w || v >= h) return;
+  const float d = disp[(size_t)v * si + u * factor] * factor;     // row not scaled: .cu:97-98 quirk kept
+  float4 o;
+  if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
+  else {
+    const float q[4] = {(float)u, (float)v, d, 1.f};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = q[0] * TQ.m[i] + q[1] * TQ.m[4 + i] + q[2] * TQ.m[8 + i] + q[3] * TQ.m[12 + i];
+    o = make_float4(r[0] / r[3], r[1] / r[3], r[2] / r[3], 1.f);
+  }
+  reinterpret_cast<float4 *>(cloud)[(size_t)v * so + u] = o;
+}
+
+// per-ctx scratch for block partials (one allocation, grown on demand, owned by a static map-free
+// slot inside the ctx would need ctx changes; keep it simple: allocate per call size class)
+struct Scratch { double *p = nullptr; size_t n = 0; };
+
+}  // namespace
+
+static int ensure_scratch(svs_ctx *ctx, double **p, size_t count) {
+  // scratch lives in a thread-local cache keyed by ctx (one ctx per calling thread)
+  static thread_local svs_ctx *owner = nullptr;
+  static thread_local Scratch sc;
+  if (owner != ctx || sc.n < count) {
+    if (sc.p) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.n = 0; }
+    SVS_HIP(ctx, hipMalloc(&sc.p, count * sizeof(double)));
+    sc.n = count; owner = ctx;
+  }
+  *p = sc.p;
+  return SVS_OK;
+}
+
+extern "C" int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride,
+                                      const svs_cam *cam, int level, const double *d_T, float *d_cloud,
+                                      size_t cloud_bstride, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_disp && cam && d_T && d_cloud && level >= 0 && level < 3 && batch >= 1);
+  SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);            // dense_tracking.cpp:45-46 asserts
+  int n = (cam->w / 4) * (cam->h / 4);
+  hipLaunchKernelGGL(pointcloud_cpu_sem_kernel, dim3(div_up(n, 256), batch), dim3(256), 0, ctx->stream, d_disp, disp_stride,
+                     disp_bstride, *cam, level, d_T, d_cloud, cloud_bstride);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t cloud_bstride, const uint8_t *d_prev_u8,
+                                      int pstride, size_t p_bstride, const float *d_cur, const float *d_dx,
+                                      const float *d_dy, int fstride, size_t f_bstride, const svs_cam *cam,
+                                      const double *d_T, int do_jac, svs_dense_sums *d_out, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_cloud && d_prev_u8 && d_cur && cam && d_T && d_out && batch >= 1);
+  SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
+  SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);
+  LevelArgs L{d_cloud, d_prev_u8, d_cur, d_dx, d_dy, pstride, fstride, *cam};
+  int n = (cam->w / 4) * (cam->h / 4);
+  int nblocks = std::min(div_up(n, 256), 256);
+  double *part = nullptr;
+  int rc = ensure_scratch(ctx, &part, (size_t)batch * nblocks * (NSUM + 1));
+  if (rc) return rc;
+  if (do_jac)
+    hipLaunchKernelGGL(dense_pass_cpu_sem_kernel<true>, dim3(nblocks, batch), dim3(256), 0, ctx->stream, L, cloud_bstride, p_bstride, f_bstride, d_T, part);
+  else
+    hipLaunchKernelGGL(dense_pass_cpu_sem_kernel<false>, dim3(nblocks, batch), dim3(256), 0, ctx->stream, L, cloud_bstride, p_bstride, f_bstride, d_T, part);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(dense_finalize_kernel, dim3(batch), dim3(64), 0, ctx->stream, part, nblocks, d_out);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out,
+                                       int batch) {
+  SVS_REQUIRE(ctx, ctx && a && d_T_io && batch >= 1);
+  TrackArgs A;
+  for (int l = 0; l < 3; ++l) {
+    SVS_REQUIRE(ctx, a->d_cloud[l] && a->d_prev_u8[l] && a->d_cur[l] && a->d_dx[l] && a->d_dy[l]);
+    SVS_REQUIRE(ctx, a->cam_vec[l].w % 4 == 0 && a->cam_vec[l].h % 4 == 0);
+    A.lv[l] = LevelArgs{a->d_cloud[l], a->d_prev_u8[l], a->d_cur[l], a->d_dx[l], a->d_dy[l], a->pstride[l], a->fstride[l], a->cam_vec[l]};
+    A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l];
+  }
+  hipLaunchKernelGGL(dense_track_cpu_sem_kernel, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                                   const float *d_cur, const float *d_dx, const float *d_dy, int stride_f, float f,
+                                   float cx, float cy, const float *h_T, int do_jac, svs_dense_sums *d_out) {
+  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_out && w > 0 && h > 0);
+  SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
+  T34 T;
+  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
+  int ntiles = div_up(w, 64) * div_up(h, 4);
+  int nblocks = std::min(ntiles, 1024);
+  double *part = nullptr;
+  int rc = ensure_scratch(ctx, &part, (size_t)nblocks * (NSUM + 1));
+  if (rc) return rc;
+  if (do_jac)
+    hipLaunchKernelGGL(dense_pass_full_kernel<true>, dim3(nblocks), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy, T, part);
+  else
+    hipLaunchKernelGGL(dense_pass_full_kernel<false>, dim3(nblocks), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy, T, part);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(dense_finalize_full_kernel, dim3(1), dim3(64), 0, ctx->stream, part, nblocks, d_out);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ, const float *d_disp, int w, int h, int stride_in,
+                                   int stride_out, int factor, float *d_cloud4) {
+  SVS_REQUIRE(ctx, ctx && h_TQ && d_disp && d_cloud4 && w > 0 && h > 0 && factor >= 1);
+  T44 TQ;
+  for (int i = 0; i < 16; ++i) TQ.m[i] = h_TQ[i];
+  hipLaunchKernelGGL(pointcloud_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, TQ, d_disp, w, h,
+                     stride_in, stride_out, factor, d_cloud4);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}

@@ -1,0 +1,407 @@
+// fast.hip -- grid-adaptive FAST-9/16 for gfx950.  Replaces FastGrid::detectAdaptively /
+// FastGrid::detect (fast_grid.cpp:60-152), whose inner call is cv::FastFeatureDetector.
+//
+// MI355X-first design (not the reference's "re-run FAST up to 6 times per cell"):
+//   K1 score:   one LDS-tiled pass per frame computes, for every pixel of every cell ROI, the
+//               FAST score  s = max t such that the pixel is a FAST-9 corner at threshold t
+//               (the segment test is monotone in t) and a 256-bin histogram of
+//               scores per cell.  The <=6 adaptive re-detections of the reference then are
+//               histogram look-ups:  count(t) = #pixels with s >= t.
+//   K2 adapt:   one workgroup per camera stream runs the reference's per-row threshold state
+//               machine (prev_thr / prev_prev_thr shared along a row of cells, +-1/+-2 steps,
+//               clamps) on the suffix-summed histograms and produces the emit threshold, the
+//               persistent threshold and the output offset of every cell.
+//   K3 compact: one workgroup per cell emits the corners of the LAST executed detection in the
+//               reference's order (cells row-major, row-major inside the cell ROI).
+// Integer arithmetic throughout => corner lists are bit-exact to the oracle.
+#include "common.h"
+#include "fast_view.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+struct LevelDev {
+  int w, h;
+  int gx, gy, cell_w, cell_h;
+  int min_inner, min_outer, max_inner, max_outer, fast_min, fast_max;
+  int cell_base;          // index of this level's first cell in the per-slot cell arrays
+  uint8_t *score;         // [batch][h][score_stride]
+  int score_stride;
+  size_t score_bstride;
+  int16_t *xy;            // [batch][cap][2]
+};
+struct FastParams {
+  LevelDev lv[SVS_NUM_PYR_LEVELS];
+  int n_levels, ncell_total, cap, t_lo;
+  unsigned *hist;         // [batch][ncell_total][256]
+  int *thr, *emit, *count, *offset;   // [batch][ncell_total]
+  int *level_total;       // [batch][n_levels]
+};
+struct ImgPtrs {
+  const uint8_t *img[SVS_NUM_PYR_LEVELS];
+  int stride[SVS_NUM_PYR_LEVELS];
+  size_t bstride[SVS_NUM_PYR_LEVELS];
+};
+struct TileDesc { int16_t level, cell, x0, y0; };   // cell = index within the level
+
+constexpr int TW = 64, TH = 16, HALO = 3;
+
+// ring offsets, SURVEY.md A.1 (index 0..15)
+__device__ __constant__ int8_t c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__device__ __constant__ int8_t c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// max over the 16 arcs of 9 of the arc minimum, via the 2-4-8(+1) doubling ladder
+__device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
+  int m2[16], m4[16], best = -1024;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    int m8 = min(m4[k], m4[(k + 4) & 15]);
+    int m9 = min(m8, d[(k + 8) & 15]);
+    best = max(best, m9);
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
+  __shared__ uint8_t s_img[TH + 2 * HALO][TW + 2 * HALO + 2];
+  __shared__ unsigned s_hist[256];
+  const TileDesc td = tiles[blockIdx.x];
+  const int slot = blockIdx.y;
+  const LevelDev &L = P.lv[td.level];
+  const int tid = threadIdx.x;
+  const int ci = td.cell % L.gx, cj = td.cell / L.gx;
+  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;       // cell ROI origin (fast_grid.cpp:45-52)
+  const uint8_t *img = I.img[td.level] + (size_t)slot * I.bstride[td.level];
+  const int istride = I.stride[td.level];
+  s_hist[tid] = 0;
+  // stage tile + 3 px halo; coordinates clamped to the cell ROI (halo outside the ROI is never
+  // used: only ROI-interior pixels are scored, and their ring stays inside the ROI)
+  const int tx0 = u0 + td.x0 - HALO, ty0 = v0 + td.y0 - HALO;
+  for (int i = tid; i < (TH + 2 * HALO) * (TW + 2 * HALO); i += 256) {
+    int r = i / (TW + 2 * HALO), c = i - r * (TW + 2 * HALO);
+    int y = min(max(ty0 + r, v0), v0 + L.cell_h - 1), x = min(max(tx0 + c, u0), u0 + L.cell_w - 1);
+    s_img[r][c] = img[(size_t)y * istride + x];
+  }
+  __syncthreads();
+  const int lx = tid & 63, ly0 = tid >> 6;
+  uint8_t *score = L.score + (size_t)slot * L.score_bstride;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int ly = ly0 + 4 * k;
+    const int cx = td.x0 + lx, cy = td.y0 + ly;            // cell-local coords
+    if (cx >= L.cell_w || cy >= L.cell_h) continue;
+    int s8 = 0;
+    const bool interior = cx >= 3 && cy >= 3 && cx < L.cell_w - 3 && cy < L.cell_h - 3;
+    if (interior) {
+      const int v = s_img[ly + HALO][lx + HALO];
+      const int t = P.t_lo;
+      // compass pre-test: any 9-arc contains >= 2 of ring pixels {0,4,8,12}
+      int r0 = s_img[ly + HALO + 3][lx + HALO], r4 = s_img[ly + HALO][lx + HALO + 3];
+      int r8 = s_img[ly + HALO - 3][lx + HALO], r12 = s_img[ly + HALO][lx + HALO - 3];
+      int nd = (v - r0 > t) + (v - r4 > t) + (v - r8 > t) + (v - r12 > t);
+      int nb = (r0 - v > t) + (r4 - v > t) + (r8 - v > t) + (r12 - v > t);
+      if (nd >= 2 || nb >= 2) {
+        int d[16], e[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          int r = s_img[ly + HALO + c_ring_dy[q]][lx + HALO + c_ring_dx[q]];
+          d[q] = v - r;
+          e[q] = r - v;
+        }
+        int sc = max(arc9_maxmin(d), arc9_maxmin(e)) - 1;   // corner at t <=> sc >= t
+        if (sc >= t) s8 = min(sc + 1, 255);
+      }
+    }
+    score[(size_t)(v0 + cy) * L.score_stride + (u0 + cx)] = (uint8_t)s8;
+    if (s8) atomicAdd(&s_hist[s8], 1u);
+  }
+  __syncthreads();
+  unsigned c = s_hist[tid];
+  if (c) atomicAdd(&P.hist[((size_t)slot * P.ncell_total + L.cell_base + td.cell) * 256 + tid], c);
+}
+
+// K2: threshold state machine of fast_grid.cpp:86-152 on histogram counts.
+__global__ __launch_bounds__(256) void fast_adapt_kernel(FastParams P, int trials) {
+  extern __shared__ int s_cnt[];    // [ncell_total][256]: #pixels with stored score >= bin
+  const int slot = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned *hist = P.hist + (size_t)slot * P.ncell_total * 256;
+  for (int c = wave; c < P.ncell_total; c += 4) {
+    // lane holds bins 4*lane..4*lane+3; suffix sum inside the lane then across lanes
+    uint4 hv = *reinterpret_cast<const uint4 *>(hist + (size_t)c * 256 + 4 * lane);
+    *reinterpret_cast<uint4 *>(hist + (size_t)c * 256 + 4 * lane) = make_uint4(0, 0, 0, 0);  // ready for next frame
+    int a3 = hv.w, a2 = hv.z + a3, a1 = hv.y + a2, a0 = hv.x + a1;
+    int tot = a0, run = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int up = __shfl_down(run, o, 64); if (lane + o < 64) run += up; }
+    int above = run - tot;   // sum of bins of higher lanes
+    s_cnt[c * 256 + 4 * lane + 0] = a0 + above;
+    s_cnt[c * 256 + 4 * lane + 1] = a1 + above;
+    s_cnt[c * 256 + 4 * lane + 2] = a2 + above;
+    s_cnt[c * 256 + 4 * lane + 3] = a3 + above;
+  }
+  __syncthreads();
+  int *thr = P.thr + (size_t)slot * P.ncell_total;
+  int *emit = P.emit + (size_t)slot * P.ncell_total;
+  int *count = P.count + (size_t)slot * P.ncell_total;
+  int *offset = P.offset + (size_t)slot * P.ncell_total;
+  // one thread per (level, row of cells): prev_thr/prev_prev_thr are shared along the row
+  int row = tid, lvl = -1, j = 0;
+  for (int l = 0; l < P.n_levels; ++l) { if (row < P.lv[l].gy) { lvl = l; j = row; break; } row -= P.lv[l].gy; }
+  if (lvl >= 0) {
+    const LevelDev &L = P.lv[lvl];
+    int prev_thr = -1, prev_prev_thr = -2;
+    for (int i = 0; i < L.gx; ++i) {
+      const int c = L.cell_base + j * L.gx + i;
+      int t = thr[c], used = t, num = 0;
+      if (trials <= 0) {             // FastGrid::detect: one pass at the stored threshold
+        int tc = min(max(t, 0), 255);
+        num = tc + 1 <= 255 ? s_cnt[c * 256 + tc + 1] : 0;
+      }
+      for (int trial = 0; trial < trials; ++trial) {
+        used = t;
+        int tc = min(max(t, 0), 255);
+        num = tc + 1 <= 255 ? s_cnt[c * 256 + tc + 1] : 0;
+        if (prev_prev_thr == t) { t = (t + prev_prev_thr) / 2; break; }
+        prev_prev_thr = prev_thr;
+        prev_thr = t;
+        if (num < L.min_inner) {
+          if (t <= L.fast_min) break;
+          --t;
+          if (num < L.min_outer) { if (t <= L.fast_min) break; --t; continue; }
+        } else if (num > L.max_inner) {
+          if (t >= L.fast_max) break;
+          ++t;
+          if (num > L.max_outer) { if (t >= L.fast_max) break; ++t; continue; }
+        }
+        break;
+      }
+      thr[c] = t; emit[c] = used; count[c] = num;
+    }
+  }
+  __syncthreads();
+  if (tid < P.n_levels) {            // exclusive scan of the counts of one level
+    const LevelDev &L = P.lv[tid];
+    int run = 0;
+    for (int c = L.cell_base; c < L.cell_base + L.gx * L.gy; ++c) { offset[c] = run; run += count[c]; }
+    P.level_total[(size_t)slot * P.n_levels + tid] = run;
+  }
+}
+
+// K3: ordered compaction of one cell.  Sweep 1 counts per ROI row (one wave per row), an LDS scan
+// turns counts into offsets, sweep 2 writes (x,y) with a ballot prefix.
+__global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
+  __shared__ int s_row[1024];
+  const int slot = blockIdx.y;
+  int c = blockIdx.x, lvl = 0;
+  while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
+  const LevelDev &L = P.lv[lvl];
+  const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
+  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
+  const int base = P.offset[(size_t)slot * P.ncell_total + c];
+  const uint8_t *score = L.score + (size_t)slot * L.score_bstride;
+  const int rows = L.cell_h - 6, cols = L.cell_w - 6;    // ROI interior
+  if (rows <= 0 || cols <= 0 || thr1 > 255) return;
+  {
+    const int nr = rows;                                   // <= 1024, checked at create
+    for (int r = wave; r < nr; r += 4) {
+      const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
+      int n = 0;
+      for (int xb = 0; xb < cols; xb += 64) {
+        int x = xb + lane;
+        bool hit = x < cols && p[x] >= thr1;
+        n += __popcll(__ballot(hit));
+      }
+      if (lane == 0) s_row[r] = n;
+    }
+    __syncthreads();
+    // exclusive scan of s_row[0..nr) by wave 0 (16 values per lane)
+    if (wave == 0) {
+      int v[16], tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; v[k] = idx < nr ? s_row[idx] : 0; tot += v[k]; }
+      int run = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { int dn = __shfl_up(run, o, 64); if (lane >= o) run += dn; }
+      int excl = run - tot;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; if (idx < nr) s_row[idx] = excl; excl += v[k]; }
+    }
+    __syncthreads();
+    int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
+    for (int r = wave; r < nr; r += 4) {
+      const int y = v0 + 3 + r;
+      const uint8_t *p = score + (size_t)y * L.score_stride + u0 + 3;
+      int o = base + s_row[r];
+      for (int xb = 0; xb < cols; xb += 64) {
+        int x = xb + lane;
+        bool hit = x < cols && p[x] >= thr1;
+        unsigned long long m = __ballot(hit);
+        if (hit) {
+          int pos = o + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < P.cap) { xy[2 * pos] = (int16_t)(u0 + 3 + x); xy[2 * pos + 1] = (int16_t)y; }
+        }
+        o += __popcll(m);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+struct svs_fast {
+  svs_ctx *ctx;
+  FastParams P;
+  int batch;
+  TileDesc *d_tiles; int n_tiles;
+  std::vector<int> t_lo_src;
+};
+
+extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
+                               const svs_fastgrid *grids, int batch, int cap, svs_fast **out) {
+  SVS_REQUIRE(ctx, ctx && out && w && h && grids && n_levels >= 1 && n_levels <= SVS_NUM_PYR_LEVELS && batch >= 1 && cap >= 1);
+  svs_fast *f = new svs_fast();
+  f->ctx = ctx; f->batch = batch;
+  FastParams &P = f->P;
+  P = FastParams{};
+  P.n_levels = n_levels; P.cap = cap;
+  std::vector<TileDesc> tiles;
+  int cell_base = 0, t_lo = 255;
+  for (int l = 0; l < n_levels; ++l) {
+    const svs_fastgrid &g = grids[l];
+    SVS_REQUIRE(ctx, g.gx >= 1 && g.gy >= 1 && g.gx * g.gy <= SVS_MAX_CELLS && g.cell_w * g.gx <= w[l] && g.cell_h * g.gy <= h[l]);
+    SVS_REQUIRE(ctx, g.cell_h - 6 <= 1024);
+    LevelDev &L = P.lv[l];
+    L.w = w[l]; L.h = h[l]; L.gx = g.gx; L.gy = g.gy; L.cell_w = g.cell_w; L.cell_h = g.cell_h;
+    L.min_inner = g.min_inner; L.min_outer = g.min_outer; L.max_inner = g.max_inner; L.max_outer = g.max_outer;
+    L.fast_min = g.fast_min; L.fast_max = g.fast_max; L.cell_base = cell_base;
+    L.score_stride = (w[l] + 63) / 64 * 64;
+    L.score_bstride = (size_t)L.score_stride * h[l];
+    SVS_HIP(ctx, hipMalloc(&L.score, L.score_bstride * batch));
+    SVS_HIP(ctx, hipMemsetAsync(L.score, 0, L.score_bstride * batch, ctx->stream));
+    SVS_HIP(ctx, hipMalloc(&L.xy, sizeof(int16_t) * 2 * (size_t)cap * batch));
+    for (int c = 0; c < g.gx * g.gy; ++c) {
+      t_lo = std::min(t_lo, std::min(g.fast_min, g.thr[c]));
+      for (int y0 = 0; y0 < g.cell_h; y0 += TH)
+        for (int x0 = 0; x0 < g.cell_w; x0 += TW) tiles.push_back(TileDesc{(int16_t)l, (int16_t)c, (int16_t)x0, (int16_t)y0});
+    }
+    cell_base += g.gx * g.gy;
+  }
+  P.ncell_total = cell_base;
+  P.t_lo = std::max(t_lo, 0);
+  SVS_REQUIRE(ctx, (size_t)P.ncell_total * 256 * 4 <= 64 * 1024);
+  size_t nc = (size_t)P.ncell_total * batch;
+  SVS_HIP(ctx, hipMalloc(&P.hist, nc * 256 * sizeof(unsigned)));
+  SVS_HIP(ctx, hipMemsetAsync(P.hist, 0, nc * 256 * sizeof(unsigned), ctx->stream));
+  SVS_HIP(ctx, hipMalloc(&P.thr, nc * sizeof(int)));
+  SVS_HIP(ctx, hipMalloc(&P.emit, nc * sizeof(int)));
+  SVS_HIP(ctx, hipMalloc(&P.count, nc * sizeof(int)));
+  SVS_HIP(ctx, hipMalloc(&P.offset, nc * sizeof(int)));
+  SVS_HIP(ctx, hipMalloc(&P.level_total, (size_t)batch * n_levels * sizeof(int)));
+  SVS_HIP(ctx, hipMemsetAsync(P.emit, 0, nc * sizeof(int), ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(P.count, 0, nc * sizeof(int), ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(P.offset, 0, nc * sizeof(int), ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(P.level_total, 0, (size_t)batch * n_levels * sizeof(int), ctx->stream));
+  std::vector<int> thr0(nc);
+  for (int b = 0; b < batch; ++b)
+    for (int l = 0; l < n_levels; ++l)
+      for (int c = 0; c < grids[l].gx * grids[l].gy; ++c) thr0[(size_t)b * P.ncell_total + P.lv[l].cell_base + c] = grids[l].thr[c];
+  SVS_HIP(ctx, hipMemcpyAsync(P.thr, thr0.data(), nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  f->n_tiles = (int)tiles.size();
+  SVS_HIP(ctx, hipMalloc(&f->d_tiles, sizeof(TileDesc) * tiles.size()));
+  SVS_HIP(ctx, hipMemcpyAsync(f->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = f;
+  return SVS_OK;
+}
+
+extern "C" int svs_fast_destroy(svs_fast *f) {
+  if (!f) return SVS_OK;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  for (int l = 0; l < f->P.n_levels; ++l) { hipFree(f->P.lv[l].score); hipFree(f->P.lv[l].xy); }
+  hipFree(f->P.hist); hipFree(f->P.thr); hipFree(f->P.emit); hipFree(f->P.count); hipFree(f->P.offset);
+  hipFree(f->P.level_total); hipFree(f->d_tiles);
+  delete f;
+  return SVS_OK;
+}
+
+extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const int32_t *stride, const size_t *bstride,
+                               int n_batch, int trials) {
+  SVS_REQUIRE(f ? f->ctx : nullptr, f && d_img && stride && bstride && n_batch >= 1 && n_batch <= f->batch && trials >= 0);
+  svs_ctx *ctx = f->ctx;
+  ImgPtrs I{};
+  for (int l = 0; l < f->P.n_levels; ++l) { I.img[l] = d_img[l]; I.stride[l] = stride[l]; I.bstride[l] = bstride[l]; }
+  hipLaunchKernelGGL(fast_score_kernel, dim3(f->n_tiles, n_batch), dim3(256), 0, ctx->stream, f->P, I, f->d_tiles);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(fast_adapt_kernel, dim3(n_batch), dim3(256), (size_t)f->P.ncell_total * 256 * sizeof(int), ctx->stream, f->P, trials);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(fast_compact_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_fast_download(svs_fast *f, int slot, int level, int16_t *h_xy, int cap, int32_t *h_n,
+                                 int32_t *h_cell_count, int32_t *h_emit_thr, int32_t *h_thr_state) {
+  SVS_REQUIRE(f ? f->ctx : nullptr, f && slot >= 0 && slot < f->batch && level >= 0 && level < f->P.n_levels);
+  svs_ctx *ctx = f->ctx;
+  const FastParams &P = f->P;
+  const LevelDev &L = P.lv[level];
+  int total = 0;
+  SVS_HIP(ctx, hipMemcpyAsync(&total, P.level_total + (size_t)slot * P.n_levels + level, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_n) *h_n = total;
+  int nc = L.gx * L.gy;
+  size_t co = (size_t)slot * P.ncell_total + L.cell_base;
+  if (h_cell_count) SVS_HIP(ctx, hipMemcpyAsync(h_cell_count, P.count + co, nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (h_emit_thr) SVS_HIP(ctx, hipMemcpyAsync(h_emit_thr, P.emit + co, nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (h_thr_state) SVS_HIP(ctx, hipMemcpyAsync(h_thr_state, P.thr + co, nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int ncopy = std::min(std::min(total, cap), P.cap);
+  if (h_xy && ncopy > 0)
+    SVS_HIP(ctx, hipMemcpyAsync(h_xy, L.xy + (size_t)slot * P.cap * 2, sizeof(int16_t) * 2 * (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_xy && (total > cap || total > P.cap)) return SVS_ERR_CAPACITY;
+  return SVS_OK;
+}
+
+extern "C" int svs_fast_set_thresholds(svs_fast *f, int slot, int level, const int32_t *h_thr) {
+  SVS_REQUIRE(f ? f->ctx : nullptr, f && h_thr && slot >= 0 && slot < f->batch && level >= 0 && level < f->P.n_levels);
+  svs_ctx *ctx = f->ctx;
+  const LevelDev &L = f->P.lv[level];
+  int nc = L.gx * L.gy;
+  for (int c = 0; c < nc; ++c) SVS_REQUIRE(ctx, h_thr[c] >= f->P.t_lo);   // scores below t_lo are not kept
+  SVS_HIP(ctx, hipMemcpyAsync(f->P.thr + (size_t)slot * f->P.ncell_total + L.cell_base, h_thr, nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_fast_device_view(svs_fast *f, int level, const uint8_t **d_score, int32_t *score_stride,
+                                    size_t *score_bstride, const int32_t **d_emit_thr, size_t *emit_bstride) {
+  SVS_REQUIRE(f ? f->ctx : nullptr, f && level >= 0 && level < f->P.n_levels);
+  const LevelDev &L = f->P.lv[level];
+  if (d_score) *d_score = L.score;
+  if (score_stride) *score_stride = L.score_stride;
+  if (score_bstride) *score_bstride = L.score_bstride;
+  if (d_emit_thr) *d_emit_thr = f->P.emit + L.cell_base;
+  if (emit_bstride) *emit_bstride = (size_t)f->P.ncell_total;
+  return SVS_OK;
+}
+
+// internal accessor for match.hip
+FastView svs_fast_view_internal(const svs_fast *f) {
+  FastView v{};
+  v.n_levels = f->P.n_levels; v.emit = f->P.emit; v.ncell_total = f->P.ncell_total;
+  for (int l = 0; l < f->P.n_levels; ++l) {
+    const LevelDev &L = f->P.lv[l];
+    v.score[l] = L.score; v.score_stride[l] = L.score_stride; v.score_bstride[l] = L.score_bstride;
+    v.cell_base[l] = L.cell_base; v.gx[l] = L.gx; v.gy[l] = L.gy; v.cell_w[l] = L.cell_w; v.cell_h[l] = L.cell_h;
+    v.w[l] = L.w; v.h[l] = L.h;
+  }
+  return v;
+}

@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's per-frame front-end call surfaces, on top of the C ABI.
+
+Same names / argument meaning as the reference (so the parity tests read like calls into
+stereo_frontend.cpp), device memory held in torch tensors:
+
+  FramePyramid.preprocessing()           <- FrameGrabber::preprocessing   frame_grabber.cpp:285-336
+  FastGrid.detectAdaptively / .detect    <- FastGrid                      fast_grid.h:40-51
+  GuidedMatcher.match                    <- GuidedMatcher<StereoCamera>   matcher.hpp:67-83
+  DenseTracker.denseTrackingCpu / computeDensePointCloudCpu               dense_tracking.h:59-79
+  GpuTracker.jacobianReduction / chi2 / computePointCloud                 gpu/dense_tracking.cuh:281-342
+
+The HIP library does all the arithmetic; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, Cam,
+                           FastGrid as FastGridPOD, level_cams)
+
+NUM_PYR_LEVELS = 3  # global.h:107
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def fastgrid_for_level(w, h, level):
+    """Grid parameters of StereoFrontend::initialize (stereo_frontend.cpp:73-88) + the FastGrid
+    constructor (fast_grid.cpp:23-58).  Host-side integer bookkeeping, no image arithmetic."""
+    dim = max(3 - int(level * 0.5), 1)
+    inv_fac = 1.0 / (1 << level)
+    total = int(2000 * inv_fac * inv_fac)
+    per_cell = total // (dim * dim)
+    bound = max(per_cell // 3, 10)
+    g = FastGridPOD()
+    g.gx = g.gy = dim
+    g.min_inner = int(per_cell - bound * 0.33)
+    g.min_outer = per_cell - bound
+    g.max_inner = int(per_cell + bound * 0.33)
+    g.max_outer = per_cell + bound
+    g.cell_w, g.cell_h = w // dim, h // dim
+    g.fast_min, g.fast_max = 10, 40
+    for i in range(len(g.thr)):
+        g.thr[i] = 25
+    return g
+
+
+class FramePyramid:
+    """Device-resident frame data of `batch` independent camera streams (FrameData<StereoCamera>,
+    frame_grabber.hpp:93-155): u8 pyramid, f32 pyramid + Sobel images, f32 disparity."""
+
+    def __init__(self, ctx, stream, cam, batch=1, with_float=True):
+        self.ctx, self.stream, self.cam, self.batch = ctx, stream, cam, batch
+        self.cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"], NUM_PYR_LEVELS)
+        dev = torch.device("cuda", ctx.device)
+        self.w = [self.cams[l].w for l in range(NUM_PYR_LEVELS)]
+        self.h = [self.cams[l].h for l in range(NUM_PYR_LEVELS)]
+        self.stride = [_round_up(w, 64) for w in self.w]
+        with torch.cuda.stream(stream):
+            self.pyr = [torch.zeros((batch, self.h[l], self.stride[l]), dtype=torch.uint8, device=dev)
+                        for l in range(NUM_PYR_LEVELS)]
+            self.disp = torch.zeros((batch, self.h[0], self.stride[0]), dtype=torch.float32, device=dev)
+            self.f32 = self.dx = self.dy = None
+            if with_float:
+                self.f32 = [torch.zeros((batch, self.h[l], self.stride[l]), dtype=torch.float32, device=dev)
+                            for l in range(NUM_PYR_LEVELS)]
+                self.dx = [torch.zeros_like(t) for t in self.f32]
+                self.dy = [torch.zeros_like(t) for t in self.f32]
+
+    def bstride(self, l):
+        return self.h[l] * self.stride[l]
+
+    def upload(self, images, disp=None):
+        """images: [batch,h,w] u8 (numpy); disp: [batch,h,w] f32 or None."""
+        with torch.cuda.stream(self.stream):
+            img = torch.as_tensor(np.ascontiguousarray(images)).to(self.pyr[0].device, non_blocking=False)
+            self.pyr[0][:, :, :self.w[0]] = img.reshape(self.batch, self.h[0], self.w[0])
+            if disp is not None:
+                d = torch.as_tensor(np.ascontiguousarray(disp, dtype=np.float32)).to(self.disp.device)
+                self.disp[:, :, :self.w[0]] = d.reshape(self.batch, self.h[0], self.w[0])
+
+    def preprocessing(self):
+        """FrameGrabber::preprocessing: cv::buildPyramid + (CPU path) convertTo/Sobel per level."""
+        for l in range(1, NUM_PYR_LEVELS):
+            self.ctx.call("svs_pyr_down_u8", self.pyr[l - 1].data_ptr(), self.w[l - 1], self.h[l - 1],
+                          self.stride[l - 1], self.bstride(l - 1), self.pyr[l].data_ptr(), self.stride[l],
+                          self.bstride(l), self.batch)
+        if self.f32 is not None:
+            for l in range(NUM_PYR_LEVELS):
+                self.ctx.call("svs_convert_sobel_f32", self.pyr[l].data_ptr(), self.w[l], self.h[l], self.stride[l],
+                              self.bstride(l), self.f32[l].data_ptr(), self.dx[l].data_ptr(), self.dy[l].data_ptr(),
+                              self.stride[l], self.bstride(l), self.batch)
+
+    def level_host(self, l, slot=0):
+        self.ctx.sync()
+        return self.pyr[l][slot, :, :self.w[l]].cpu().numpy()
+
+    def clone_pyramid(self):
+        """Frame::clone (keyframes.h:72-83): deep copy of the u8 pyramid, kept on the device."""
+        with torch.cuda.stream(self.stream):
+            return [t.clone() for t in self.pyr]
+
+
+class FastGrid:
+    """FastGrid for all matching levels and `batch` threshold states (fast_grid.h:27-63)."""
+
+    def __init__(self, ctx, frame, n_levels=NUM_PYR_LEVELS, corner_cap=8192, grids=None):
+        self.ctx, self.frame, self.n_levels, self.cap = ctx, frame, n_levels, corner_cap
+        self.grids = (FastGridPOD * n_levels)()
+        for l in range(n_levels):
+            self.grids[l] = grids[l] if grids is not None else fastgrid_for_level(frame.w[l], frame.h[l], l)
+        w = (C.c_int32 * n_levels)(*frame.w[:n_levels])
+        h = (C.c_int32 * n_levels)(*frame.h[:n_levels])
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svs_fast_create(ctx.h, n_levels, w, h, self.grids, frame.batch, corner_cap, C.byref(self.h)))
+        ctx.children.add(self)
+
+    def _detect(self, pyr, trials, n_batch):
+        n = self.n_levels
+        imgs = (C.c_void_p * n)(*[pyr[l].data_ptr() for l in range(n)])
+        strides = (C.c_int32 * n)(*self.frame.stride[:n])
+        bstrides = (C.c_size_t * n)(*[self.frame.bstride(l) for l in range(n)])
+        self.ctx.check(self.ctx.lib.svs_fast_detect(self.h, imgs, strides, bstrides, n_batch or self.frame.batch, trials))
+
+    def detectAdaptively(self, pyr=None, trials=6, n_batch=None):
+        """FastGrid::detectAdaptively(img, trials, qt) on every level (stereo_frontend.cpp:657-679)."""
+        assert trials >= 1
+        self._detect(pyr or self.frame.pyr, trials, n_batch)
+
+    def detect(self, pyr=None, n_batch=None):
+        """FastGrid::detect(img, cell_grid2d, qt): one pass at the stored thresholds."""
+        self._detect(pyr or self.frame.pyr, 0, n_batch)
+
+    def corners(self, slot=0, level=0):
+        """(xy int16 [n,2] in quadtree insertion order, cell_count, emit_thr, thr_state)."""
+        g = self.grids[level]
+        nc = g.gx * g.gy
+        xy = np.zeros((self.cap, 2), np.int16)
+        n = C.c_int32()
+        cc, et, ts = np.zeros(nc, np.int32), np.zeros(nc, np.int32), np.zeros(nc, np.int32)
+        self.ctx.check(self.ctx.lib.svs_fast_download(self.h, slot, level, xy.ctypes.data, self.cap, C.byref(n),
+                                                      cc.ctypes.data, et.ctypes.data, ts.ctypes.data))
+        return xy[:n.value].copy(), cc, et, ts
+
+    def set_thresholds(self, slot, level, thr):
+        thr = np.ascontiguousarray(thr, np.int32)
+        self.ctx.check(self.ctx.lib.svs_fast_set_thresholds(self.h, slot, level, thr.ctypes.data))
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.svs_fast_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GuidedMatcher:
+    """GuidedMatcher<StereoCamera>::match (matcher.hpp:67-83)."""
+
+    def __init__(self, ctx, frame, fast):
+        self.ctx, self.frame, self.fast = ctx, frame, fast
+
+    def match(self, keyframes, T_cur_from_actkey, T_actkey_from_w, points, search_radius=8, thr_mean=22,
+              thr_std=10):
+        """keyframes: list of (pyr device tensors [3] with frame strides, slot, T_anchor_from_w [12]);
+        T_cur_from_actkey / T_actkey_from_w: [batch,12] (or [12]); points: CANDIDATE_DTYPE array
+        [batch,n] or [n].  Returns MATCH_RESULT_DTYPE [batch,n] (appending to TrackData is host
+        bookkeeping left to the caller, matcher.cpp:183-214)."""
+        a = self.prepare(keyframes, T_cur_from_actkey, T_actkey_from_w, points, search_radius, thr_mean, thr_std)
+        self.launch(a)
+        return self.download()
+
+    def prepare(self, keyframes, T_cur_from_actkey, T_actkey_from_w, points, search_radius=8, thr_mean=22, thr_std=10):
+        """Upload the candidate points / keyframe table / poses once; returns the svs_match_args."""
+        fr, B = self.frame, self.frame.batch
+        dev = fr.pyr[0].device
+        kfs = np.zeros(len(keyframes), KEYFRAME_DTYPE)
+        for i, (pyr, slot, T) in enumerate(keyframes):
+            kfs[i]["T_anchor_from_w"] = np.asarray(T, np.float64).reshape(12)
+            for l in range(NUM_PYR_LEVELS):
+                kfs[i]["pyr"][l] = pyr[l].data_ptr() + slot * fr.bstride(l)
+                kfs[i]["stride"][l] = fr.stride[l]
+        pts = np.ascontiguousarray(points, CANDIDATE_DTYPE)
+        if pts.ndim == 1:
+            pts = np.broadcast_to(pts, (B, len(pts))).copy()
+        n = pts.shape[1]
+        Tc = np.broadcast_to(np.asarray(T_cur_from_actkey, np.float64).reshape(-1, 12), (B, 12))
+        Ta = np.broadcast_to(np.asarray(T_actkey_from_w, np.float64).reshape(-1, 12), (B, 12))
+        T_cur_from_w = np.zeros((B, 12))
+        T_w_from_actkey = np.zeros((B, 12))
+        for b in range(B):  # two 3x4 pose products per frame: host bookkeeping (matcher.cpp:326-330)
+            A, Bm = Tc[b].reshape(3, 4), Ta[b].reshape(3, 4)
+            T_cur_from_w[b, :] = np.hstack([A[:, :3] @ Bm[:, :3], (A[:, :3] @ Bm[:, 3] + A[:, 3])[:, None]]).reshape(12)
+            T_w_from_actkey[b, :] = np.hstack([Bm[:, :3].T, (-Bm[:, :3].T @ Bm[:, 3])[:, None]]).reshape(12)
+        with torch.cuda.stream(fr.stream):
+            d_kfs = torch.as_tensor(kfs.view(np.uint8)).to(dev)
+            d_pts = torch.as_tensor(pts.view(np.uint8).reshape(-1)).to(dev)
+            d_Tc = torch.as_tensor(T_cur_from_w).to(dev)
+            d_Ta = torch.as_tensor(T_w_from_actkey).to(dev)
+            d_out = torch.zeros(B * n * MATCH_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        a = capi.MatchArgs()
+        a.d_kfs, a.n_kf, a.d_pts, a.n_pts = d_kfs.data_ptr(), len(kfs), d_pts.data_ptr(), n
+        a.d_T_cur_from_w, a.d_T_w_from_actkey = d_Tc.data_ptr(), d_Ta.data_ptr()
+        for l in range(NUM_PYR_LEVELS):
+            a.d_cur_pyr[l], a.cur_stride[l], a.cur_bstride[l] = fr.pyr[l].data_ptr(), fr.stride[l], fr.bstride(l)
+            a.cam_vec[l] = fr.cams[l]
+        a.d_disp, a.disp_stride, a.disp_bstride = fr.disp.data_ptr(), fr.stride[0], fr.bstride(0)
+        a.search_radius, a.thr_mean, a.thr_std, a.n_batch = search_radius, thr_mean, thr_std, B
+        self._keep = (d_kfs, d_pts, d_Tc, d_Ta, d_out, keyframes)
+        self._n = n
+        return a
+
+    def launch(self, a):
+        self.ctx.check(self.ctx.lib.svs_match(self.ctx.h, C.byref(a), self.fast.h, self._keep[4].data_ptr()))
+
+    def download(self):
+        self.ctx.sync()
+        return self._keep[4].cpu().numpy().view(MATCH_RESULT_DTYPE).reshape(self.frame.batch, self._n)
+
+
+class DenseTracker:
+    """DenseTracker, CPU-path semantics (dense_tracking.cpp:222-423)."""
+
+    def __init__(self, ctx, frame):
+        self.ctx, self.frame = ctx, frame
+        dev = frame.pyr[0].device
+        with torch.cuda.stream(frame.stream):
+            self.ref_dense_points = [torch.zeros((frame.batch, frame.h[l] // 4, frame.w[l] // 4, 4),
+                                                 dtype=torch.float32, device=dev) for l in range(NUM_PYR_LEVELS)]
+            self.d_T = torch.zeros((frame.batch, 12), dtype=torch.float64, device=dev)
+            self.d_passes = torch.zeros(frame.batch, dtype=torch.int32, device=dev)
+            self.d_sums = torch.zeros(frame.batch * DENSE_SUMS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+
+    def _set_T(self, T):
+        T = np.broadcast_to(np.asarray(T, np.float64).reshape(-1, 12), (self.frame.batch, 12))
+        with torch.cuda.stream(self.frame.stream):
+            self.d_T.copy_(torch.as_tensor(np.ascontiguousarray(T)))
+
+    def computeDensePointCloudCpu(self, T_cur_from_actkey):
+        fr = self.frame
+        self._set_T(T_cur_from_actkey)
+        for l in range(NUM_PYR_LEVELS):
+            cb = (fr.h[l] // 4) * (fr.w[l] // 4) * 4
+            self.ctx.call("svs_pointcloud_cpu_sem", fr.disp.data_ptr(), fr.stride[0], fr.bstride(0),
+                          C.byref(fr.cams[l]), l, self.d_T.data_ptr(), self.ref_dense_points[l].data_ptr(), cb, fr.batch)
+
+    def pass_sums(self, level, prev_pyr, T, do_jac):
+        """One chi2 (do_jac=False) or H,b (True) pass of the loop body; returns DENSE_SUMS_DTYPE[batch]."""
+        fr = self.frame
+        self._set_T(T)
+        cb = (fr.h[level] // 4) * (fr.w[level] // 4) * 4
+        self.ctx.call("svs_dense_pass_cpu_sem", self.ref_dense_points[level].data_ptr(), cb,
+                      prev_pyr[level].data_ptr(), fr.stride[level], fr.bstride(level), fr.f32[level].data_ptr(),
+                      fr.dx[level].data_ptr(), fr.dy[level].data_ptr(), fr.stride[level], fr.bstride(level),
+                      C.byref(fr.cams[level]), self.d_T.data_ptr(), int(do_jac), self.d_sums.data_ptr(), fr.batch)
+        self.ctx.sync()
+        return self.d_sums.cpu().numpy().view(DENSE_SUMS_DTYPE).copy()
+
+    def track_args(self, prev_pyr):
+        fr = self.frame
+        a = capi.DenseTrackArgs()
+        for l in range(NUM_PYR_LEVELS):
+            a.d_cloud[l] = self.ref_dense_points[l].data_ptr()
+            a.cloud_bstride[l] = (fr.h[l] // 4) * (fr.w[l] // 4) * 4
+            a.d_prev_u8[l], a.pstride[l], a.p_bstride[l] = prev_pyr[l].data_ptr(), fr.stride[l], fr.bstride(l)
+            a.d_cur[l], a.d_dx[l], a.d_dy[l] = fr.f32[l].data_ptr(), fr.dx[l].data_ptr(), fr.dy[l].data_ptr()
+            a.fstride[l], a.f_bstride[l] = fr.stride[l], fr.bstride(l)
+            a.cam_vec[l] = fr.cams[l]
+        return a
+
+    def denseTrackingCpu(self, prev_pyr, T_cur_from_actkey, args=None, download=True):
+        """DenseTracker::denseTrackingCpu(SE3*): in/out pose; whole LM loop in one launch."""
+        fr = self.frame
+        if T_cur_from_actkey is not None:
+            self._set_T(T_cur_from_actkey)
+        a = args or self.track_args(prev_pyr)
+        self.ctx.check(self.ctx.lib.svs_dense_track_cpu_sem(self.ctx.h, C.byref(a), self.d_T.data_ptr(),
+                                                            self.d_passes.data_ptr(), fr.batch))
+        if not download:
+            return None
+        self.ctx.sync()
+        return self.d_T.cpu().numpy().reshape(fr.batch, 3, 4), self.d_passes.cpu().numpy()
+
+
+class GpuTracker:
+    """GpuTracker / computePointCloud (gpu/dense_tracking.cuh:281-342): full-resolution f32 passes."""
+
+    def __init__(self, ctx, stream, w, h):
+        self.ctx, self.stream, self.w, self.h = ctx, stream, w, h
+        self.d_sums = torch.zeros(DENSE_SUMS_DTYPE.itemsize, dtype=torch.uint8, device=torch.device("cuda", ctx.device))
+        self._tex = None
+
+    def bindTexture(self, I_cur, dx, dy, w, h, stride):
+        self._tex = (I_cur, dx, dy, w, h, stride)
+
+    def _pass(self, I_prev, cloud, T34_colmajor, f, cx, cy, w, h, stride_f, stride_f4, do_jac):
+        I_cur, dx, dy, _, _, _ = self._tex
+        T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+        self.ctx.call("svs_dense_pass_full", cloud.data_ptr(), w, h, stride_f4, I_prev.data_ptr(), I_cur.data_ptr(),
+                      dx.data_ptr(), dy.data_ptr(), stride_f, float(f), float(cx), float(cy), T.ctypes.data,
+                      int(do_jac), self.d_sums.data_ptr())
+        self.ctx.sync()
+        return self.d_sums.cpu().numpy().view(DENSE_SUMS_DTYPE)[0].copy()
+
+    def jacobianReduction(self, I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4):
+        return self._pass(I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4, True)
+
+    def chi2(self, I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4):
+        return float(self._pass(I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4, False)["chi2"])
+
+    def computePointCloud(self, TQ_colmajor, disp, w, h, stride_in, stride_out, factor, cloud):
+        TQ = np.ascontiguousarray(TQ_colmajor, np.float32).reshape(16)
+        self.ctx.call("svs_pointcloud_full", TQ.ctypes.data, disp.data_ptr(), w, h, stride_in, stride_out, factor,
+                      cloud.data_ptr())

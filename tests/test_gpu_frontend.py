@@ -1,0 +1,323 @@
+"""GPU parity of the per-frame front-end against the CPU oracle (all through the C ABI).
+
+Bars (BASELINE.json north_star): integer paths bit-exact (pyramid, FAST corner lists incl. order
+and thresholds, ZNSSD best match incl. tie-breaks, u8 key-patch warp); f32/f64 dense-tracking sums
+within the tolerances written next to each assert.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(ctx, stream, cam, imgs, disps=None, with_float=True):
+    from scavislam_amd.frontend import FramePyramid
+    fr = FramePyramid(ctx, stream, cam, batch=len(imgs), with_float=with_float)
+    fr.upload(np.stack(imgs), None if disps is None else np.stack(disps))
+    fr.preprocessing()
+    return fr
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (512, 384), (322, 242)])
+def test_pyramid_and_sobel_bit_exact(gpu_ctx, w, h):
+    import oracle as O
+    from scavislam_amd import synth
+    ctx, stream = gpu_ctx
+    cam = dict(synth.CAM_DEFAULT, w=w, h=h)
+    imgs = [synth.noise_image(w, h, 11 + i) for i in range(2)]
+    if (w, h) == (322, 242):           # odd level sizes exercise REFLECT_101 on both borders
+        from scavislam_amd.frontend import FramePyramid
+        import torch
+        fr = FramePyramid(ctx, stream, dict(cam, w=320, h=240), batch=1, with_float=False)
+        # direct C-ABI call on an odd-sized image
+        src = torch.as_tensor(imgs[0]).cuda()
+        dst = torch.zeros(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.call("svs_pyr_down_u8", src.data_ptr(), w, h, w, w * h, dst.data_ptr(), (w + 1) // 2, 0, 1)
+        ctx.sync()
+        assert np.array_equal(dst.cpu().numpy(), O.pyr_down_u8(imgs[0]))
+        return
+    fr = _frame(ctx, stream, cam, imgs)
+    ctx.sync()
+    for b, img in enumerate(imgs):
+        pyr = O.build_pyramid(img)
+        for l in range(3):
+            assert np.array_equal(fr.level_host(l, b), pyr[l]), f"pyramid level {l}"
+            f, dx, dy = O.convert_sobel(pyr[l])
+            wl = fr.w[l]
+            assert np.array_equal(fr.f32[l][b, :, :wl].cpu().numpy(), f)      # bit-exact f32
+            assert np.array_equal(fr.dx[l][b, :, :wl].cpu().numpy(), dx)
+            assert np.array_equal(fr.dy[l][b, :, :wl].cpu().numpy(), dy)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (512, 384)])
+def test_fastgrid_adaptive_sequence_bit_exact(gpu_ctx, w, h):
+    """Six consecutive frames: corner lists (order included), per-cell counts, emit thresholds and
+    the persistent thresholds must equal the oracle's after every frame, for two camera streams."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FastGrid
+    ctx, stream = gpu_ctx
+    cam = dict(synth.CAM_DEFAULT, w=w, h=h)
+    seqs = [[synth.noise_image(w, h, 100 * s + i) for i in range(6)] for s in range(2)]
+    fr = _frame(ctx, stream, cam, [seqs[0][0], seqs[1][0]], with_float=False)
+    fg = FastGrid(ctx, fr)
+    grids = [[O.fastgrid_for_level(fr.w[l], fr.h[l], l) for l in range(3)] for _ in range(2)]
+    for i in range(6):
+        fr.upload(np.stack([seqs[0][i], seqs[1][i]]))
+        fr.preprocessing()
+        trials = 5 if i == 0 else 6            # first frame uses 5 (stereo_frontend.cpp:131-136)
+        fg.detectAdaptively(trials=trials)
+        for s in range(2):
+            pyr = O.build_pyramid(seqs[s][i])
+            for l in range(3):
+                xy_ref, cc_ref, et_ref = O.fastgrid_detect_adaptively(grids[s][l], pyr[l], trials)
+                xy, cc, et, ts = fg.corners(s, l)
+                nc = grids[s][l].gx * grids[s][l].gy
+                assert np.array_equal(cc, cc_ref), (i, s, l, cc, cc_ref)
+                assert np.array_equal(et, et_ref)
+                assert np.array_equal(ts, np.array(grids[s][l].thr[:nc]))
+                assert np.array_equal(xy, xy_ref)
+    # FastGrid::detect (static thresholds) on the last frame
+    fg.detect()
+    for s in range(2):
+        pyr = O.build_pyramid(seqs[s][5])
+        for l in range(3):
+            xy_ref, cc_ref = O.fastgrid_detect(grids[s][l], pyr[l])
+            xy, cc, et, ts = fg.corners(s, l)
+            assert np.array_equal(xy, xy_ref) and np.array_equal(cc, cc_ref)
+
+
+def test_fast_empty_and_saturated_images(gpu_ctx):
+    """Edge cases: constant image (no corners, thresholds walk down to fast_min) and a checkerboard
+    (far too many corners, thresholds walk up to fast_max)."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FastGrid
+    ctx, stream = gpu_ctx
+    w, h = 640, 480
+    flat = np.full((h, w), 77, np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = (((xx // 4) + (yy // 4)) % 2 * 200 + 20).astype(np.uint8)
+    fr = _frame(ctx, stream, dict(synth.CAM_DEFAULT), [flat, checker], with_float=False)
+    fg = FastGrid(ctx, fr, corner_cap=60000)
+    grids = [[O.fastgrid_for_level(fr.w[l], fr.h[l], l) for l in range(3)] for _ in range(2)]
+    for it in range(10):
+        fg.detectAdaptively(trials=6)
+        for s, img in enumerate((flat, checker)):
+            pyr = O.build_pyramid(img)
+            for l in range(3):
+                xy_ref, cc_ref, et_ref = O.fastgrid_detect_adaptively(grids[s][l], pyr[l], 6, cap=1 << 17)
+                xy, cc, et, ts = fg.corners(s, l)
+                assert np.array_equal(cc, cc_ref) and np.array_equal(et, et_ref)
+                assert np.array_equal(xy, xy_ref)
+    assert all(t == 10 for t in grids[0][0].thr[:9])
+
+
+def _match_setup(scene_frames, ctx, stream, n_per_level=(300, 150, 60), seed=5):
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FastGrid
+    cam = scene_frames["cam"]
+    (img_k, disp_k), (img_p, disp_p), (img_c, disp_c) = scene_frames["frames"]
+    T_k, T_p, T_c = scene_frames["poses"]
+    fr = _frame(ctx, stream, cam, [img_c], [disp_c])
+    fg = FastGrid(ctx, fr)
+    for _ in range(3):
+        fg.detectAdaptively(trials=6)
+    rng = np.random.default_rng(seed)
+    pts = synth.candidate_points(rng, cam, disp_k, T_k, n_per_level)
+    # a few degenerate candidates: unknown anchor, border anchor, far too close, behind the camera
+    pts[0]["kf_index"] = -1
+    pts[1]["anchor_obs_pyr"][:2] = (2.0, 2.0)
+    pts[2]["xyz_anchor"] *= 0.05
+    pts[3]["xyz_anchor"][2] = -1.0
+    return cam, fr, fg, pts, (img_k, disp_k, T_k), (img_c, disp_c, T_c)
+
+
+def test_matcher_bit_exact(gpu_ctx, scene_frames):
+    """GuidedMatcher::match: status, best corner, ZNSSD score bit-exact; obs / xyz_actkey to 1e-12."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FramePyramid, GuidedMatcher
+    ctx, stream = gpu_ctx
+    cam, fr, fg, pts, (img_k, disp_k, T_k), (img_c, disp_c, T_c) = _match_setup(scene_frames, ctx, stream)
+    kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
+    kf.upload(img_k[None])
+    kf.preprocessing()
+    # active keyframe = anchor keyframe; predicted pose = true relative pose perturbed by ~1 px
+    T_cur_from_actkey = synth.pose_mul(T_c, synth.pose_inv(T_k))
+    T_cur_from_actkey[:, 3] += np.array([0.004, -0.003, 0.002])
+    gm = GuidedMatcher(ctx, fr, fg)
+    res = gm.match([(kf.pyr, 0, T_k.reshape(12))], T_cur_from_actkey.reshape(12), T_k.reshape(12), pts)[0]
+    # oracle on the same corners (taken from the oracle's own FAST, proven equal in the FAST test)
+    pyr_c, pyr_k = O.build_pyramid(img_c), O.build_pyramid(img_k)
+    trees = []
+    for l in range(3):
+        xy, cc, et, ts = fg.corners(0, l)
+        trees.append(O.quadtree_from_corners(xy, cc, pyr_c[l].shape[1], pyr_c[l].shape[0]))
+    ref = O.match([pyr_k], [T_k.reshape(12)], T_cur_from_actkey, T_k, pyr_c, disp_c, trees, fr.cams, pts)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() > 100, "test scene should produce plenty of matches"
+    found = (ref["status"] == 0) | (ref["status"] == 6)
+    assert np.array_equal(res["u"][found], ref["u"][found]) and np.array_equal(res["v"][found], ref["v"][found])
+    assert np.array_equal(res["znssd"], ref["znssd"])
+    assert np.array_equal(res["obs"][ok], ref["obs"][ok])          # exact: ints and one f32 disparity
+    np.testing.assert_allclose(res["xyz_actkey"][found], ref["xyz_actkey"][found], rtol=1e-12, atol=1e-12)
+    assert set(np.unique(ref["status"])) >= {0, 1, 2, 3}
+
+
+def test_matcher_tie_break_follows_quadtree_order(gpu_ctx):
+    """Periodic texture => many candidates with identical ZNSSD; the winner must be the first one
+    in QuadTree::query DFS order, which the kernel reproduces with quadrant keys."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import CANDIDATE_DTYPE
+    from scavislam_amd.frontend import FastGrid, FramePyramid, GuidedMatcher
+    ctx, stream = gpu_ctx
+    cam = dict(synth.CAM_DEFAULT)
+    h, w = cam["h"], cam["w"]
+    yy, xx = np.mgrid[0:h, 0:w]
+    tile = np.random.default_rng(3).integers(0, 256, (8, 8)).astype(np.uint8)
+    img = tile[yy % 8, xx % 8]                      # exactly 8-periodic: ZNSSD ties everywhere
+    disp = np.full((h, w), 6.0, np.float32)
+    fr = _frame(ctx, stream, cam, [img], [disp])
+    fg = FastGrid(ctx, fr, corner_cap=320 * 1024)
+    fg.detectAdaptively(trials=6)
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    z = cam["f"] * cam["b"] / 6.0
+    rng = np.random.default_rng(9)
+    pts = np.zeros(200, CANDIDATE_DTYPE)
+    for k in range(200):
+        u0, v0 = int(rng.integers(40, w - 40)), int(rng.integers(40, h - 40))
+        pts[k]["xyz_anchor"] = ((u0 - cam["cx"]) / cam["f"] * z, (v0 - cam["cy"]) / cam["f"] * z, z)
+        pts[k]["anchor_obs_pyr"] = (u0, v0, u0 - 6.0)
+    gm = GuidedMatcher(ctx, fr, fg)
+    res = gm.match([(fr.pyr, 0, I.reshape(12))], I.reshape(12), I.reshape(12), pts, thr_std=0)[0]
+    pyr = O.build_pyramid(img)
+    trees = []
+    for l in range(3):
+        xy, cc, et, ts = fg.corners(0, l)
+        trees.append(O.quadtree_from_corners(xy, cc, pyr[l].shape[1], pyr[l].shape[0]))
+    ref = O.match([pyr], [I.reshape(12)], I, I, pyr, disp, trees, fr.cams, pts, thr_std=0)
+    assert np.array_equal(res["status"], ref["status"])
+    assert (ref["status"] == 0).sum() > 50
+    assert np.array_equal(res["u"], ref["u"]) and np.array_equal(res["v"], ref["v"])
+    assert np.array_equal(res["znssd"], ref["znssd"])
+
+
+def _dense_setup(scene_frames, ctx, stream):
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    cam = scene_frames["cam"]
+    (_, _), (img_p, disp_p), (img_c, disp_c) = scene_frames["frames"]
+    _, T_p, T_c = scene_frames["poses"]
+    prev = _frame(ctx, stream, cam, [img_p], [disp_p])
+    cur = _frame(ctx, stream, cam, [img_c], [disp_c])
+    return cam, prev, cur, (img_p, disp_p, T_p), (img_c, disp_c, T_c)
+
+
+def test_dense_pointcloud_and_single_pass(gpu_ctx, scene_frames):
+    """computeDensePointCloudCpu bit-exact (f32 out of identical f64 ops); one H,b / chi2 pass of the
+    loop body: H and b within 1e-9 relative of the serial oracle (only the f64 summation order
+    differs), n_valid exact, chi2 within 1e-4 relative (reference accumulates a float serially)."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker
+    ctx, stream = gpu_ctx
+    cam, prev, cur, (img_p, disp_p, T_p), (img_c, disp_c, T_c) = _dense_setup(scene_frames, ctx, stream)
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    # the cloud is built from the PREVIOUS frame's disparity and used while tracking the current one
+    dt_prev = DenseTracker(ctx, prev)
+    dt_prev.computeDensePointCloudCpu(I.reshape(12))
+    ctx.sync()
+    clouds_ref = [O.pointcloud_cpu(disp_p, prev.cams[l], l, I) for l in range(3)]
+    for l in range(3):
+        got = dt_prev.ref_dense_points[l][0].cpu().numpy()
+        assert np.array_equal(got, clouds_ref[l]), f"cloud level {l}"
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dt_prev.ref_dense_points
+    T_true = synth.pose_mul(T_c, synth.pose_inv(T_p))
+    pyr_p = O.build_pyramid(img_p)
+    pyr_c = O.build_pyramid(img_c)
+    for l in range(3):
+        f, dx, dy = O.convert_sobel(pyr_c[l])
+        for T in (I, T_true):
+            for do_jac in (False, True):
+                ref = O.dense_pass_cpu(clouds_ref[l], pyr_p[l], f, dx, dy, cur.cams[l], T, do_jac)
+                got = dt.pass_sums(l, prev.pyr, T.reshape(12), do_jac)[0]
+                assert got["n_valid"] == ref["n_valid"] and ref["n_valid"] > 100
+                np.testing.assert_allclose(got["chi2"], ref["chi2"], rtol=1e-4)   # oracle sums ~2e4 floats serially
+                if do_jac:
+                    scale = np.abs(ref["H"]).max()
+                    np.testing.assert_allclose(got["H"], ref["H"], rtol=0, atol=1e-9 * scale)
+                    np.testing.assert_allclose(got["b"], ref["b"], rtol=0, atol=1e-9 * np.abs(ref["b"]).max() + 1e-12)
+
+
+def test_dense_tracking_device_resident_lm(gpu_ctx, scene_frames):
+    """Whole denseTrackingCpu in one launch vs the oracle: final pose within 1e-4 (translation, m) /
+    1e-4 (rotation entries).  Not bit-exact by construction: the accept/reject test compares float
+    chi2 sums whose summation order differs.  Both must improve on the start pose."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker
+    ctx, stream = gpu_ctx
+    cam, prev, cur, (img_p, disp_p, T_p), (img_c, disp_c, T_c) = _dense_setup(scene_frames, ctx, stream)
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dt = DenseTracker(ctx, cur)
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    dt.ref_dense_points = dtp.ref_dense_points
+    T_gpu, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12))
+    clouds = [O.pointcloud_cpu(disp_p, prev.cams[l], l, I) for l in range(3)]
+    pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
+    fl = [O.convert_sobel(p) for p in pyr_c]
+    T_ref, passes_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl],
+                                             cur.cams, I)
+    T_true = synth.pose_mul(T_c, synth.pose_inv(T_p))
+    err_gpu = np.abs(T_gpu[0] - T_true).max()
+    err_ref = np.abs(T_ref - T_true).max()
+    err_start = np.abs(I - T_true).max()
+    assert err_ref < 0.5 * err_start and err_gpu < 0.5 * err_start
+    np.testing.assert_allclose(T_gpu[0], T_ref, rtol=0, atol=1e-4)
+    assert 3 <= passes[0] <= 3 * (1 + 15 * 2 * 3)
+
+
+def test_dense_full_resolution_variant(gpu_ctx, scene_frames):
+    """GpuTracker::jacobianReduction / chi2 and computePointCloud (full-res f32 semantics of
+    gpu/dense_tracking.cu): cloud bit-exact, sums within 1e-5 relative (f32 per-pixel math; the
+    kernel accumulates in f64, the oracle too)."""
+    import torch
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import GpuTracker
+    ctx, stream = gpu_ctx
+    cam, prev, cur, (img_p, disp_p, T_p), (img_c, disp_c, T_c) = _dense_setup(scene_frames, ctx, stream)
+    l = 1
+    w, h = cur.w[l], cur.h[l]
+    c = cur.cams[l]
+    Q = np.array([[1, 0, 0, -c.cx], [0, 1, 0, -c.cy], [0, 0, 0, c.f], [0, 0, 1.0 / c.b, 0]])
+    TQ = Q.astype(np.float32)                      # T = identity
+    gt = GpuTracker(ctx, stream, w, h)
+    with torch.cuda.stream(stream):
+        cloud = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    gt.computePointCloud(TQ.T.reshape(16), prev.disp[0], w, h, prev.stride[0], w, 1 << l, cloud)
+    ctx.sync()
+    cloud_ref = O.pointcloud_full(TQ.T.reshape(16), disp_p, w, h, 1 << l)
+    assert np.array_equal(cloud.cpu().numpy(), cloud_ref)
+    pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
+    fp, _, _ = O.convert_sobel(pyr_p[l])
+    fc, dx, dy = O.convert_sobel(pyr_c[l])
+    T_true = synth.pose_mul(T_c, synth.pose_inv(T_p))
+    T34 = T_true.astype(np.float32).T.reshape(12)   # GpuMatrix34: column-major 3x4
+    gt.bindTexture(cur.f32[l][0], cur.dx[l][0], cur.dy[l][0], w, h, cur.stride[l])
+    got = gt.jacobianReduction(prev.f32[l][0], cloud, T34, c.f, c.cx, c.cy, w, h, cur.stride[l], w)
+    # oracle wants dense (stride = w) images
+    ref = O.dense_pass_full(cloud_ref, fp, fc, dx, dy, np.float32(c.f), np.float32(c.cx), np.float32(c.cy), T34, True)
+    assert got["n_valid"] == ref["n_valid"] and ref["n_valid"] > 1000
+    np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-5, atol=1e-5 * np.abs(ref["H"]).max())
+    np.testing.assert_allclose(got["b"], ref["b"], rtol=1e-5, atol=1e-5 * np.abs(ref["b"]).max())
+    chi2 = gt.chi2(prev.f32[l][0], cloud, T34, c.f, c.cx, c.cy, w, h, cur.stride[l], w)
+    np.testing.assert_allclose(chi2, ref["chi2"], rtol=1e-6)
