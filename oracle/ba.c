@@ -310,23 +310,39 @@ static void schur_reduce(const ba_sys *S, const svs_ba_edge *edges, const int *s
   free(slot_of);
 }
 
-/* dense Cholesky solve A x = b (A symmetric n x n row-major, destroyed). returns 0 ok, 1 not PD */
+/* Cholesky solve A x = b (A symmetric n x n row-major, destroyed); returns 0 ok, 1 not PD.
+   Envelope (skyline) form: first[i] = first structurally non-zero column of row i of the lower
+   triangle; Cholesky creates no fill left of it, so the inner products start there.  Skipping
+   exact zeros changes no sum, i.e. the result is bit-identical to the dense loop; it is what makes
+   this a fair stand-in for the reference's sparse solver (LinearSolverCSparse) on the CPU. */
 static int chol_solve(int n, double *A, const double *b, double *x) {
-  for (int j = 0; j < n; ++j) {
+  int *first = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) { int j = 0; while (j < i && A[(size_t)i * n + j] == 0.0) ++j; first[i] = j; }
+  int rc = 0;
+  for (int j = 0; j < n && !rc; ++j) {
     double d = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(d > 0) || !isfinite(d)) return 1;
+    for (int k = first[j]; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0) || !isfinite(d)) { rc = 1; break; }
     d = sqrt(d);
     A[(size_t)j * n + j] = d;
     for (int i = j + 1; i < n; ++i) {
+      if (first[i] > j) continue;
       double s = A[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      int k0 = first[i] > first[j] ? first[i] : first[j];
+      for (int k = k0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
       A[(size_t)i * n + j] = s / d;
     }
   }
-  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
-  for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
-  return 0;
+  if (!rc) {
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = first[i]; k < i; ++k) s -= A[(size_t)i * n + k] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int k = i + 1; k < n; ++k) if (first[k] <= i) s -= A[(size_t)k * n + i] * x[k];
+      x[i] = s / A[(size_t)i * n + i];
+    }
+  }
+  free(first);
+  return rc;
 }
 
 static ba_sys sys_alloc(int P, int L, int E) {

@@ -26,6 +26,17 @@ namespace {
 
 // ---- small f64 helpers ---------------------------------------------------------------------
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+// LDS f64 atomic (ds_add_f64): workgroup-scope relaxed add on a __shared__ double
+__device__ __forceinline__ void lds_add_f64(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Per-workgroup accumulation window over WIN consecutive poses: the packed upper block triangle
+// of the WIN x WIN pose window (plus b_p / b_s rows) lives in LDS; contributions whose poses fall
+// outside the window go straight to global atomics.  Landmarks are processed sorted by anchor,
+// so a workgroup's landmarks touch a narrow band of poses and nearly everything lands in LDS.
+constexpr int WIN = 16;
+constexpr int WIN_BLOCKS = WIN * (WIN + 1) / 2;
+__device__ __forceinline__ int win_blk(int wi, int wj) { return wi * WIN - wi * (wi - 1) / 2 + (wj - wi); }
 
 template <int N>
 __device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int seg_begin, int seg_end, int maxlen) {
@@ -159,12 +170,40 @@ template <int MODE>
 __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
   const int lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (chunk >= B.n_chunks) return;                                  // wave-uniform
-  const int e0 = B.chunk_start[chunk], len = B.chunk_len[chunk];
+  const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
+  if (MODE == 1 && !wave_valid) return;
+  const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
   const bool active = lane < len;
   svs_ba_edge ed;
   if (active) ed = B.edges[e0 + lane];
   else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
+  __shared__ double s_win[MODE == 0 ? WIN_BLOCKS * 36 : 1];
+  __shared__ double s_vec[MODE == 0 ? 2 * WIN * 6 : 1];
+  __shared__ int s_pmin;
+  int pmin = 0;
+  if (MODE == 0) {
+    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) s_win[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) s_vec[i] = 0.0;
+    if (threadIdx.x == 0) s_pmin = 0x7fffffff;
+    __syncthreads();
+    int mn = active ? min(ed.pose, ed.anchor) : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+    if (lane == 0 && mn != 0x7fffffff) atomicMin(&s_pmin, mn);
+    __syncthreads();
+    pmin = s_pmin;
+  }
+  // add v to element rc of upper block (pi <= pj) of the reduced system
+  auto add_blk = [&](int pi, int pj, int rc, double v) {
+    const int wi = pi - pmin, wj = pj - pmin;
+    if (wj < WIN) lds_add_f64(&s_win[win_blk(wi, wj) * 36 + rc], v);
+    else atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v);
+  };
+  auto add_vec = [&](int which, int p, int r, double v) {     // which: 0 = b_p, 1 = b_s
+    const int wp = p - pmin;
+    if (wp < WIN) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + r], v);
+    else atomic_add_f64((which ? B.bs : B.bp) + 6 * p + r, v);
+  };
   // segment (= landmark) bounds inside the wave
   const int prev_point = __shfl_up(ed.point, 1, 64);
   const bool head = lane == 0 || prev_point != ed.point;
@@ -294,29 +333,27 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
     for (int j = 0; j < 3; ++j) WoD[3 * i + j] = Wo[3 * i] * Di[j] + Wo[3 * i + 1] * Di[3 + j] + Wo[3 * i + 2] * Di[6 + j];
   if (obs_role) {
     const int pi = ed.pose;
-    double *Hii = B.H + blk_index(pi, pi, P) * 36;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = r; c < 6; ++c) {
         double m = lin.Jo[r] * lin.om[0] * lin.Jo[c] + lin.Jo[6 + r] * lin.om[1] * lin.Jo[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Jo[12 + c];
         m -= WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2];
-        atomic_add_f64(&Hii[6 * r + c], m);
+        add_blk(pi, pi, 6 * r + c, m);
       }
     const bool up = pi < anchor;
-    double *HiA = B.H + (up ? blk_index(pi, anchor, P) : blk_index(anchor, pi, P)) * 36;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         double m = lin.Jo[r] * lin.om[0] * lin.Ja[c] + lin.Jo[6 + r] * lin.om[1] * lin.Ja[6 + c] + lin.Jo[12 + r] * lin.om[2] * lin.Ja[12 + c];
         m -= WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2];
-        atomic_add_f64(&HiA[up ? 6 * r + c : 6 * c + r], m);
+        if (up) add_blk(pi, anchor, 6 * r + c, m); else add_blk(anchor, pi, 6 * c + r, m);
       }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      atomic_add_f64(&B.bp[6 * pi + r], lin.Jo[r] * lin.wr[0] + lin.Jo[6 + r] * lin.wr[1] + lin.Jo[12 + r] * lin.wr[2]);
-      atomic_add_f64(&B.bs[6 * pi + r], Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
+      add_vec(0, pi, r, lin.Jo[r] * lin.wr[0] + lin.Jo[6 + r] * lin.wr[1] + lin.Jo[12 + r] * lin.wr[2]);
+      add_vec(1, pi, r, Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
     }
   }
   // observer-observer pairs of the same landmark: partner = lane + t (edges sorted by observer)
@@ -327,12 +364,11 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
     const int pj = __shfl_down(ed.pose, t, 64);
     const int rolej = __shfl_down((int)obs_role, t, 64);
     if (obs_role && lane + t <= seg_end && rolej) {
-      double *Hij = B.H + blk_index(ed.pose, pj, P) * 36;
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c)
-          atomic_add_f64(&Hij[6 * r + c], -(WoD[3 * r] * Wj[3 * c] + WoD[3 * r + 1] * Wj[3 * c + 1] + WoD[3 * r + 2] * Wj[3 * c + 2]));
+          add_blk(ed.pose, pj, 6 * r + c, -(WoD[3 * r] * Wj[3 * c] + WoD[3 * r + 1] * Wj[3 * c + 1] + WoD[3 * r + 2] * Wj[3 * c + 2]));
     }
   }
   // anchor part: (A,A) block and b_A, from segment sums; written by the head lane
@@ -370,19 +406,39 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) WAD[3 * i + j] = WA[3 * i] * Di[j] + WA[3 * i + 1] * Di[3 + j] + WA[3 * i + 2] * Di[6 + j];
-    double *HAA = B.H + blk_index(anchor, anchor, P) * 36;
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = r; c < 6; ++c) {
         const double m = ma[k++] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]);
-        atomic_add_f64(&HAA[6 * r + c], m);
+        add_blk(anchor, anchor, 6 * r + c, m);
       }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      atomic_add_f64(&B.bp[6 * anchor + r], ma[21 + r]);
-      atomic_add_f64(&B.bs[6 * anchor + r], WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+      add_vec(0, anchor, r, ma[21 + r]);
+      add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+    }
+  }
+  // flush the LDS window: one global atomic per touched element per workgroup
+  __syncthreads();
+  if (pmin != 0x7fffffff) {
+    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) {
+      const double v = s_win[i];
+      if (v != 0.0) {
+        const int wb = i / 36, rc = i - wb * 36;
+        int wi = 0, rem = wb;
+        while (rem >= WIN - wi) { rem -= WIN - wi; ++wi; }
+        const int pi = pmin + wi, pj = pmin + wi + rem;
+        if (pj < P) atomic_add_f64(&B.H[blk_index(pi, pj, P) * 36 + rc], v);
+      }
+    }
+    for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) {
+      const double v = s_vec[i];
+      if (v != 0.0) {
+        const int which = i / (WIN * 6), rest = i - which * WIN * 6, wp = rest / 6, r = rest - wp * 6;
+        if (pmin + wp < P) atomic_add_f64((which ? B.bs : B.bp) + 6 * (pmin + wp) + r, v);
+      }
     }
   }
 }
@@ -499,7 +555,7 @@ __global__ void ba_constraint_kernel(BaDev B) {
 // One workgroup (1024 lanes); the factor overwrites H in L2-resident global memory, the current
 // panel row and the rhs live in LDS.  A = U^T U, U upper.  Fused forward substitution; column
 // oriented back substitution.  Then T_trial = exp(x_p) T, scale_p, bookkeeping scalars.
-constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_THREADS = 256;
 constexpr int SOLVE_MAX_P = 256;
 
 __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   // exp(x) * T  (G2oVertexSE3::oplusImpl)
@@ -525,21 +581,28 @@ __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   
   }
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws) {
+// rowmax[k] = last block column of row k inside the (filled) block envelope of the reduced system:
+// structurally H_kj == 0 and stays 0 during elimination for j > rowmax[k].  For a dense window
+// rowmax[k] = P-1 and this is a plain blocked Cholesky; for the banded co-visibility structure of a
+// sliding window it skips almost all of the P^3/6 block updates (what CSparse's sparse Cholesky
+// does for the reference).  colmin[k] = first row whose envelope reaches column k.
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws,
+                                                                 const int *__restrict__ rowmax, const int *__restrict__ colmin) {
   extern __shared__ double smem[];
   const int P = B.P, n = 6 * P, tid = threadIdx.x;
   double *s_b = smem;                 // [n] rhs -> y -> x
-  double *s_panel = smem + n;         // [(P)*36] current panel row U_kj, j>k
+  double *s_panel = smem + n;         // [P*36] current panel row U_kj, j>k
   double *s_linv = s_panel + (size_t)P * 36;   // [36] (U_kk^T)^-1, lower
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
   for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
   __syncthreads();
   for (int k = 0; k < P; ++k) {
+    const long kk = blk_index(k, k, P);
     if (tid == 0) {
       // 6x6 Cholesky of A_kk (+lambda), upper stored
       double A[36], U[36], Li[36];
-      const double *Akk = B.H + blk_index(k, k, P) * 36;
+      const double *Akk = B.H + kk * 36;
       for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { double v = Akk[6 * r + c]; if (r == c) v += B.lambda; A[6 * r + c] = v; A[6 * c + r] = v; }
       int fail = 0;
       for (int i = 0; i < 36; ++i) U[i] = 0;
@@ -549,10 +612,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
         if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1; }
         d = sqrt(d);
         U[6 * j + j] = d;
+        const double id = 1.0 / d;
         for (int c = j + 1; c < 6; ++c) {
           double s = A[6 * j + c];
           for (int q = 0; q < j; ++q) s -= U[6 * q + j] * U[6 * q + c];
-          U[6 * j + c] = s / d;
+          U[6 * j + c] = s * id;
         }
       }
       // Li = (U^T)^-1 (lower triangular): forward substitution on identity
@@ -572,18 +636,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
     double yk[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) { double s = 0; for (int q = 0; q <= r; ++q) s += s_linv[6 * r + q] * s_b[6 * k + q]; yk[r] = s; }
-    // panel: U_kj = Li * A_kj, j > k
-    const int nj = P - k - 1;
-    for (int e = tid; e < nj * 36; e += SOLVE_THREADS) {
-      const int jj = e / 36, rc = e - jj * 36, r = rc / 6, c = rc - r * 6;
-      double *Akj = B.H + (blk_index(k, k, P) + 1 + jj) * 36;
-      double s = 0;
-      for (int q = 0; q <= r; ++q) s += s_linv[6 * r + q] * Akj[6 * q + c];
-      s_panel[(size_t)jj * 36 + rc] = s;
+    // panel: U_kj = Li * A_kj, k < j <= rowmax[k]; one thread per (block, column)
+    const int nj = rowmax[k] - k;
+    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {
+      const int jj = e / 6, c = e - jj * 6;
+      const double *Akj = B.H + (kk + 1 + jj) * 36;
+      double a[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) a[q] = Akj[6 * q + c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q <= r; ++q) s += s_linv[6 * r + q] * a[q];
+        s_panel[(size_t)jj * 36 + 6 * r + c] = s;
+      }
     }
     __syncthreads();
     if (tid < 6) s_b[6 * k + tid] = yk[tid];
-    for (int e = tid; e < nj * 36; e += SOLVE_THREADS) B.H[(blk_index(k, k, P) + 1) * 36 + e] = s_panel[e];   // keep U for back substitution
+    for (int e = tid; e < nj * 36; e += SOLVE_THREADS) B.H[(kk + 1) * 36 + e] = s_panel[e];   // keep U for back substitution
     // rhs update: b_j -= U_kj^T y_k
     for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {
       const int jj = e / 6, c = e - jj * 6;
@@ -592,27 +663,34 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
       for (int q = 0; q < 6; ++q) s += s_panel[(size_t)jj * 36 + 6 * q + c] * yk[q];
       s_b[6 * (k + 1 + jj) + c] -= s;
     }
-    // trailing update: A_ij -= U_ki^T U_kj, k < i <= j
+    // trailing update inside the envelope: A_ij -= U_ki^T U_kj, k < i <= j <= rowmax[k];
+    // one thread per (block, row): 6 outputs from 6 + 36 LDS operands
     const long nblk = (long)nj * (nj + 1) / 2;
-    for (long e = tid; e < nblk * 36; e += SOLVE_THREADS) {
-      const long bidx = e / 36;
-      const int rc = (int)(e - bidx * 36), r = rc / 6, c = rc - r * 6;
-      // unrank (ii, jj) with ii <= jj in the packed upper triangle of size nj
+    for (long e = tid; e < nblk * 6; e += SOLVE_THREADS) {
+      const long bidx = e / 6;
+      const int r = (int)(e - bidx * 6);
       int ii = (int)((2.0 * nj + 1.0 - sqrt((2.0 * nj + 1.0) * (2.0 * nj + 1.0) - 8.0 * (double)bidx)) * 0.5);
       while ((long)ii * nj - (long)ii * (ii - 1) / 2 > bidx) --ii;
       while ((long)(ii + 1) * nj - (long)(ii + 1) * ii / 2 <= bidx) ++ii;
       const int jj = ii + (int)(bidx - ((long)ii * nj - (long)ii * (ii - 1) / 2));
-      double s = 0;
+      double xi[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) s += s_panel[(size_t)ii * 36 + 6 * q + r] * s_panel[(size_t)jj * 36 + 6 * q + c];
-      B.H[blk_index(k + 1 + ii, k + 1 + jj, P) * 36 + rc] -= s;
+      for (int q = 0; q < 6; ++q) xi[q] = s_panel[(size_t)ii * 36 + 6 * q + r];
+      double *Aij = B.H + blk_index(k + 1 + ii, k + 1 + jj, P) * 36 + 6 * r;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += xi[q] * s_panel[(size_t)jj * 36 + 6 * q + c];
+        Aij[c] -= s;
+      }
     }
     __syncthreads();
   }
   const int fail = s_fail;
   __syncthreads();
   if (!fail) {
-    // back substitution (column oriented): x_k = Li_k^T y_k ; y_i -= U_ik x_k for i < k
+    // back substitution (column oriented): x_k = Li_k^T y_k ; y_i -= U_ik x_k for colmin[k] <= i < k
     for (int k = P - 1; k >= 0; --k) {
       if (tid < 6) {
         double s = 0;
@@ -621,13 +699,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
       }
       __syncthreads();
       if (tid < 6) s_b[6 * k + tid] = s_linv[tid];
-      for (int e = tid; e < k * 6; e += SOLVE_THREADS) {
-        const int i = e / 6, r = e - i * 6;
-        const double *Uik = B.H + blk_index(i, k, P) * 36;
-        double s = 0;
+      const int i0 = colmin[k];
+      for (int e = tid; e < (k - i0) * 6; e += SOLVE_THREADS) {
+        const int i = i0 + e / 6, r = e % 6;
+        if (rowmax[i] >= k) {
+          const double *Uik = B.H + blk_index(i, k, P) * 36;
+          double s = 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s += Uik[6 * r + q] * s_linv[q];
-        s_b[6 * i + r] -= s;
+          for (int q = 0; q < 6; ++q) s += Uik[6 * r + q] * s_linv[q];
+          s_b[6 * i + r] -= s;
+        }
       }
       __syncthreads();
     }
@@ -640,10 +721,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
   for (int i = tid; i < n; i += SOLVE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
   sc = wave_sum_f64(sc);
   if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
-  if (tid < P) {
+  for (int p = tid; p < P; p += SOLVE_THREADS) {
     double Tn[12];
-    d_se3_exp_mul(s_b + 6 * tid, B.poses + 12 * (size_t)tid, Tn);
-    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)tid + i] = Tn[i];
+    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
   }
   if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
 }
@@ -680,6 +761,10 @@ struct svs_ba {
   double *d_red = nullptr;     // [nblk*36][bp 6P][bs 6P][chi2]
   size_t red_count = 0;
   double *d_x = nullptr, *d_scal = nullptr, *d_linv = nullptr;
+  int *d_rowmax = nullptr, *d_colmin = nullptr;
+  double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
+  std::vector<double> h_pattern;
+  bool profile_ready = false;
   hipEvent_t ev[6] = {};
   float t_reduce = 0, t_solve = 0, t_backsub = 0;
   int n_reduce = 0;
@@ -688,6 +773,8 @@ struct svs_ba {
     if (d_edges) (void)hipFree(d_edges); if (d_chunk_start) (void)hipFree(d_chunk_start); if (d_chunk_len) (void)hipFree(d_chunk_len);
     if (d_cons) (void)hipFree(d_cons); if (d_red) (void)hipFree(d_red); if (d_x) (void)hipFree(d_x); if (d_scal) (void)hipFree(d_scal);
     if (d_linv) (void)hipFree(d_linv);
+    if (d_rowmax) (void)hipFree(d_rowmax); if (d_colmin) (void)hipFree(d_colmin); if (d_pattern) (void)hipFree(d_pattern);
+    d_rowmax = d_colmin = nullptr; d_pattern = nullptr; profile_ready = false;
     d_edges = nullptr; d_chunk_start = d_chunk_len = nullptr; d_cons = nullptr; d_red = d_x = d_scal = d_linv = nullptr;
   }
 };
@@ -732,14 +819,24 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ba->free_all();
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
-  // sort edges by (landmark, observer) -- copyDataToG2o iterates hash sets, so the reference has no
-  // meaningful edge order to preserve -- and pack whole landmarks into <=64-edge wave chunks
+  // sort edges by (anchor, landmark, observer) -- copyDataToG2o iterates hash sets, so the reference
+  // has no meaningful edge order to preserve -- and pack whole landmarks into <=64-edge wave chunks.
+  // Anchor-major order keeps the poses a workgroup touches inside its LDS accumulation window.
   std::vector<int> order(E);
   for (int i = 0; i < E; ++i) {
     order[i] = i;
     SVS_REQUIRE(ctx, h_edges[i].point >= 0 && h_edges[i].point < L && h_edges[i].pose >= 0 && h_edges[i].pose < P && h_edges[i].anchor >= 0 && h_edges[i].anchor < P);
   }
+  {
+    std::vector<int> anchor_of(L, -1);
+    for (int i = 0; i < E; ++i) {
+      int &a = anchor_of[h_edges[i].point];
+      if (a < 0) a = h_edges[i].anchor;
+      SVS_REQUIRE(ctx, a == h_edges[i].anchor);                          // one anchor per point (slam_graph.hpp:121-133)
+    }
+  }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (h_edges[a].anchor != h_edges[b].anchor) return h_edges[a].anchor < h_edges[b].anchor;
     if (h_edges[a].point != h_edges[b].point) return h_edges[a].point < h_edges[b].point;
     return h_edges[a].pose < h_edges[b].pose;
   });
@@ -764,6 +861,23 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     cs.push_back(start); cl.push_back(len);
   }
   ba->n_chunks = (int)cs.size();
+  // structural pattern of the reduced camera system: poses sharing a landmark, and constraints
+  ba->h_pattern.assign((size_t)P * P, 0.0);
+  for (int a = 0; a < E;) {
+    int b = a;
+    int lo = std::min(sorted[a].pose, sorted[a].anchor), hi = std::max(sorted[a].pose, sorted[a].anchor);
+    while (b < E && sorted[b].point == sorted[a].point) { lo = std::min(lo, sorted[b].pose); hi = std::max(hi, sorted[b].pose); ++b; }
+    // envelope only needs, per pose, the farthest co-visible pose: mark (p, hi) for every pose of the landmark
+    for (int e = a; e < b; ++e) ba->h_pattern[(size_t)sorted[e].pose * P + hi] = 1.0;
+    ba->h_pattern[(size_t)sorted[a].anchor * P + hi] = 1.0;
+    ba->h_pattern[(size_t)lo * P + hi] = 1.0;
+    a = b;
+  }
+  if (add_pose_terms)
+    for (int c = 0; c < C; ++c) {
+      SVS_REQUIRE(ctx, h_cons[c].pose1 >= 0 && h_cons[c].pose1 < P && h_cons[c].pose2 >= 0 && h_cons[c].pose2 < P);
+      ba->h_pattern[(size_t)std::min(h_cons[c].pose1, h_cons[c].pose2) * P + std::max(h_cons[c].pose1, h_cons[c].pose2)] = 1.0;
+    }
   const size_t nblk = (size_t)P * (P + 1) / 2;
   ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
   for (int k = 0; k < 2; ++k) {
@@ -780,6 +894,10 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, hipMalloc(&ba->d_x, sizeof(double) * 6 * (size_t)P));
   SVS_HIP(ctx, hipMalloc(&ba->d_scal, sizeof(double) * 8));
   SVS_HIP(ctx, hipMalloc(&ba->d_linv, sizeof(double) * 36 * (size_t)P));
+  SVS_HIP(ctx, hipMalloc(&ba->d_rowmax, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, hipMalloc(&ba->d_colmin, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, hipMalloc(&ba->d_pattern, sizeof(double) * (size_t)P * P));
+  ba->profile_ready = false;
   if (E) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges, sorted.data(), sizeof(svs_ba_edge) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
   if (ba->n_chunks) {
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_start, cs.data(), sizeof(int) * cs.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -801,6 +919,34 @@ extern "C" int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const doubl
   }
   SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)ba->P, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+// Block envelope of the reduced system (with Cholesky fill).  In sharded runs the structural
+// pattern is summed over ranks first (each rank only knows its own landmarks' co-visibility).
+static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
+  if (ba->profile_ready) return SVS_OK;
+  svs_ctx *ctx = ba->ctx;
+  const int P = ba->P;
+  std::vector<double> pat = ba->h_pattern;
+  if (allreduce) {
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_pattern, pat.data(), sizeof(double) * pat.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (allreduce(ba->d_pattern, pat.size(), user)) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; }
+    SVS_HIP(ctx, hipMemcpyAsync(pat.data(), ba->d_pattern, sizeof(double) * pat.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<int> rowmax(P), colmin(P);
+  for (int i = 0; i < P; ++i) {
+    rowmax[i] = i;
+    for (int j = P - 1; j > i; --j) if (pat[(size_t)i * P + j] != 0.0) { rowmax[i] = j; break; }
+  }
+  for (int k = 0; k < P; ++k)                       // fill: row k spreads its reach to rows k+1..rowmax[k]
+    for (int i = k + 1; i <= rowmax[k]; ++i) rowmax[i] = std::max(rowmax[i], rowmax[k]);
+  for (int k = 0; k < P; ++k) { colmin[k] = k; for (int i = 0; i < k; ++i) if (rowmax[i] >= k) { colmin[k] = i; break; } }
+  SVS_HIP(ctx, hipMemcpyAsync(ba->d_rowmax, rowmax.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(ba->d_colmin, colmin.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ba->profile_ready = true;
   return SVS_OK;
 }
 
@@ -845,6 +991,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
   svs_ba_stats st{};
   ba->t_reduce = ba->t_solve = ba->t_backsub = 0; ba->n_reduce = 0;
   bool ok = true;
+  { int rc = ensure_profile(ba, allreduce, user); if (rc) return rc; }
   const size_t smem = sizeof(double) * ((size_t)6 * ba->P + (size_t)ba->P * 36 + 36);
   if (smem > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   for (int it = 0; it < prm.num_iters && ok; ++it) {
@@ -860,7 +1007,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       BaDev B = make_dev(ba, lambda);
       SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 8, ctx->stream));
       SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv);
+      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
       SVS_LAUNCH_CHECK(ctx);
       SVS_HIP(ctx, hipEventRecord(ba->ev[3], ctx->stream));
       if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(div_up(B.C, 64)), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }

@@ -1,4 +1,4 @@
-"""ctypes mirrors of the POD structs in include/scavislam_hip.h (same layout in oracle/svs_oracle.h).
+"""ctypes mirrors of the POD structs in include/scavislam_hip.h (the test oracle declares the same layouts independently).
 
 Names follow the reference's domain: FastGridCell grids (keyframes.h:31-44), CandidatePoint
 (data_structures.h:37-69), the BA edge records of SlamGraph::copyDataToG2o

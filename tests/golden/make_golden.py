@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.  The reference has no golden vectors and cannot run here, so these
+are produced by the INDEPENDENT NumPy model (tests/np_model.py), not by the oracle under test:
+the oracle is then required to reproduce them (tests/test_oracle_cpu.py::test_golden_fixtures).
+Run from the repo root:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import np_model as M  # noqa: E402
+from scavislam_amd import synth  # noqa: E402
+
+img = synth.noise_image(96, 72, 2024)
+out = dict(img=img, pyr1=M.pyr_down(img))
+for t in (10, 25, 40):
+    out[f"fast_{t}"] = M.fast_corners(img, t)
+np.savez_compressed(os.path.join(HERE, "frontend_small.npz"), **out)
+
+prob = synth.ba_window(5, 30, seed=21, n_outer=1)
+c = prob["cam"]
+camt = (c["f"], c["cx"], c["cy"], c["b"])
+xp, xl, H, b = M.ba_dense_step(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camt, 50.0)
+np.savez_compressed(os.path.join(HERE, "ba_small.npz"), poses=prob["poses"], psi=prob["psi"],
+                    edges=prob["edges"].view(np.uint8), cons=prob["cons"].view(np.uint8),
+                    cam=np.array([c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"]]), xp_dense_model=xp, xl_dense_model=xl)
+print("golden written")

@@ -1,0 +1,181 @@
+"""Independent NumPy/SciPy float64 models used ONLY to cross-check the C oracle (which itself has no
+reference ground truth: "parity unpinned", see oracle/svs_oracle.h).  Written from the definitions
+(SURVEY.md Appendix A), sharing no code with oracle/*.c:
+
+  fast9_mask / fast_score_map  FAST-9/16 segment test from its definition (vectorised over the image)
+  pyr_down                     5x5 binomial via scipy.ndimage (mirror = REFLECT_101), (s+128)>>8
+  se3_exp / se3_log            matrix exponential / logarithm of the 4x4 twist (scipy.linalg)
+  ba_dense_step                one damped Gauss-Newton step on the FULL (poses+points) normal
+                               equations assembled from numerically differentiated residuals
+"""
+import numpy as np
+from scipy import linalg, ndimage
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _ring_stack(img):
+    h, w = img.shape
+    c = img[3:h - 3, 3:w - 3].astype(np.int32)
+    ring = np.stack([img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in RING])
+    return c, ring
+
+
+def fast9_mask(img, t):
+    """Boolean map (valid region rows/cols 3..n-4) of FAST-9/16 corners at threshold t."""
+    c, ring = _ring_stack(img)
+    darker = ring < c - t
+    brighter = ring > c + t
+    out = np.zeros(c.shape, bool)
+    for flags in (darker, brighter):
+        ext = np.concatenate([flags, flags[:8]], 0)
+        for s in range(16):
+            out |= ext[s:s + 9].all(0)
+    return out
+
+
+def fast_corners(img, t):
+    m = fast9_mask(img, t)
+    ys, xs = np.nonzero(m)          # row-major
+    return np.stack([xs + 3, ys + 3], 1).astype(np.int16)
+
+
+def fast_score_map(img):
+    """max t such that pixel is a corner at t (-1 if never), from the arc definition."""
+    c, ring = _ring_stack(img)
+    best = np.full(c.shape, -10 ** 6)
+    for d in (c[None] - ring, ring - c[None]):
+        ext = np.concatenate([d, d[:8]], 0)
+        for s in range(16):
+            best = np.maximum(best, ext[s:s + 9].min(0))
+    return np.maximum(best - 1, -1)
+
+
+def pyr_down(img):
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    a = img.astype(np.int64)
+    a = ndimage.correlate1d(a, k, axis=1, mode="mirror")
+    a = ndimage.correlate1d(a, k, axis=0, mode="mirror")
+    return ((a[::2, ::2] + 128) >> 8).astype(np.uint8)
+
+
+def sobel(img_f32):
+    p = np.pad(img_f32, 1, mode="reflect")
+    return p[1:-1, 2:] - p[1:-1, :-2], p[2:, 1:-1] - p[:-2, 1:-1]
+
+
+def hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+
+def se3_exp(x):
+    """exp of the twist (upsilon, omega), translation part first; returns 3x4."""
+    M = np.zeros((4, 4))
+    M[:3, :3] = hat(x[3:])
+    M[:3, 3] = x[:3]
+    return linalg.expm(M)[:3, :]
+
+
+def se3_log(T):
+    M = np.eye(4)
+    M[:3, :] = T
+    L = np.real(linalg.logm(M))
+    return np.array([L[0, 3], L[1, 3], L[2, 3], L[2, 1], L[0, 2], L[1, 0]])
+
+
+def pose_mul(A, B):
+    R = A[:, :3] @ B[:, :3]
+    return np.hstack([R, (A[:, :3] @ B[:, 3] + A[:, 3])[:, None]])
+
+
+def pose_inv(A):
+    return np.hstack([A[:, :3].T, (-A[:, :3].T @ A[:, 3])[:, None]])
+
+
+def stereo_residual(psi, T_obs, T_anc, obs, cam):
+    xa = np.array([psi[0], psi[1], 1.0]) / psi[2]
+    T = pose_mul(T_obs, pose_inv(T_anc))
+    y = T[:, :3] @ xa + T[:, 3]
+    f, cx, cy, b = cam
+    return obs - np.array([f * y[0] / y[2] + cx, f * y[1] / y[2] + cy, f * (y[0] - b) / y[2] + cx])
+
+
+def huber(e2, delta):
+    if e2 <= delta * delta:
+        return e2, 1.0
+    s = np.sqrt(e2)
+    return 2 * s * delta - delta * delta, delta / s
+
+
+def ba_chi2(poses, psi, edges, cons, cam, delta=1.0, robust=True):
+    chi = 0.0
+    for e in edges:
+        r = stereo_residual(psi[e["point"]], poses[e["pose"]].reshape(3, 4), poses[e["anchor"]].reshape(3, 4), e["obs"], cam)
+        e2 = float(np.sum(r * r * e["info"]))
+        chi += huber(e2, delta)[0] if robust else e2
+    for c in cons:
+        T = pose_mul(pose_mul(c["T_21"].reshape(3, 4), poses[c["pose1"]].reshape(3, 4)), pose_inv(poses[c["pose2"]].reshape(3, 4)))
+        r = se3_log(T)
+        chi += float(r @ c["info"].reshape(6, 6) @ r)
+    return chi
+
+
+def _perturb_pose(T, d):
+    return pose_mul(se3_exp(d), T)
+
+
+def ba_dense_step(poses, psi, edges, cons, cam, lam, delta=1.0, robust=True, eps=1e-6, exact_self=True):
+    """Solve the FULL damped normal equations (H + lam I) x = b with numerically differentiated
+    residuals (central differences), i.e. without any Schur algebra.  Returns (x_poses[P,6], x_psi[L,3])."""
+    P, L = len(poses), len(psi)
+    n = 6 * P + 3 * L
+    H = np.zeros((n, n))
+    b = np.zeros(n)
+    for e in edges:
+        l, i, a = int(e["point"]), int(e["pose"]), int(e["anchor"])
+
+        def res(dp, di, da):
+            To = _perturb_pose(poses[i].reshape(3, 4), di)
+            Ta = _perturb_pose(poses[a].reshape(3, 4), da) if a != i else _perturb_pose(poses[a].reshape(3, 4), di)
+            return stereo_residual(psi[l] + dp, To, Ta, e["obs"], cam)
+        r0 = res(np.zeros(3), np.zeros(6), np.zeros(6))
+        J = np.zeros((3, n))
+        for k in range(3):
+            d = np.zeros(3); d[k] = eps
+            J[:, 6 * P + 3 * l + k] = (res(d, np.zeros(6), np.zeros(6)) - res(-d, np.zeros(6), np.zeros(6))) / (2 * eps)
+        for k in range(6):
+            d = np.zeros(6); d[k] = eps
+            J[:, 6 * i + k] += (res(np.zeros(3), d, np.zeros(6)) - res(np.zeros(3), -d, np.zeros(6))) / (2 * eps)
+            if a != i:
+                J[:, 6 * a + k] += (res(np.zeros(3), np.zeros(6), d) - res(np.zeros(3), np.zeros(6), -d)) / (2 * eps)
+        e2 = float(np.sum(r0 * r0 * e["info"]))
+        w = huber(e2, delta)[1] if robust else 1.0
+        Om = np.diag(w * e["info"])
+        H += J.T @ Om @ J
+        b += -J.T @ Om @ r0
+    for c in cons:
+        i, j = int(c["pose1"]), int(c["pose2"])
+
+        def res(d1, d2):
+            T = pose_mul(pose_mul(c["T_21"].reshape(3, 4), _perturb_pose(poses[i].reshape(3, 4), d1)),
+                         pose_inv(_perturb_pose(poses[j].reshape(3, 4), d2)))
+            return se3_log(T)
+        r0 = res(np.zeros(6), np.zeros(6))
+        J = np.zeros((6, n))
+        for k in range(6):
+            d = np.zeros(6); d[k] = eps
+            J[:, 6 * i + k] = (res(d, np.zeros(6)) - res(-d, np.zeros(6))) / (2 * eps)
+            J[:, 6 * j + k] = (res(np.zeros(6), d) - res(np.zeros(6), -d)) / (2 * eps)
+        Om = c["info"].reshape(6, 6)
+        H += J.T @ Om @ J
+        b += -J.T @ Om @ r0
+    used = np.ones(n, bool)
+    seen = set(int(e["point"]) for e in edges)
+    for l in range(L):
+        if l not in seen:
+            used[6 * P + 3 * l:6 * P + 3 * l + 3] = False
+    Hd = H + lam * np.eye(n)
+    x = np.zeros(n)
+    x[used] = np.linalg.solve(Hd[np.ix_(used, used)], b[used])
+    return x[:6 * P].reshape(P, 6), x[6 * P:].reshape(L, 3), H, b

@@ -1,0 +1,69 @@
+"""world_size-2 (and 4) gloo test of the landmark-sharded BA path on CPU.
+
+The HIP kernels cannot run here, so each rank builds its shard's partial reduced camera system with
+the CPU oracle (the checker) and the test exercises what is specific to N>1: the product's
+shard_problem() partition, pose terms counted on exactly one rank, lambda added once after the
+all-reduce, and torch.distributed's SUM all-reduce of the packed system -- the same exchange the GPU
+path performs through the svs_allreduce_fn hook (scavislam_amd/backend.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.backend import merge_sharded_psi, shard_problem
+    from scavislam_amd.ctypes_types import BaParams, Cam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = synth.ba_window(8, 600, seed=31)
+    c = prob["cam"]
+    cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
+    prm = BaParams.reference_defaults()
+    lam = 50.0
+    sh = shard_problem(prob, rank, world)
+    cons = sh["cons"] if sh["add_pose_terms"] else sh["cons"][:0]
+    H, b = O.ba_reduced_system(sh["poses"], sh["psi"], sh["edges"], cons, cam, prm, lam)
+    n = H.shape[0]
+    H -= lam * np.eye(n)                                  # partial system carries no damping; added once below
+    chi = O.ba_chi2(sh["poses"], sh["psi"], sh["edges"], cons, cam, prm)
+    buf = torch.as_tensor(np.concatenate([H.ravel(), b, [chi]]))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    Hs = buf[:n * n].numpy().reshape(n, n) + lam * np.eye(n)
+    bs = buf[n * n:n * n + n].numpy()
+    x = np.linalg.solve(Hs, bs)                            # identical replicated solve on every rank
+    # each rank "updates" its own landmarks; merged with one more all-reduce
+    psi_local = sh["psi"].copy()
+    psi_local[sh["owner"] == rank] += 1.0 + rank
+    merged = merge_sharded_psi(psi_local, sh["owner"], rank, world)
+    if rank == 0:
+        Hf, bf = O.ba_reduced_system(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm, lam)
+        chif = O.ba_chi2(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        ok = (np.allclose(Hs, Hf, rtol=0, atol=1e-9 * np.abs(Hf).max()) and np.allclose(bs, bf, rtol=0, atol=1e-9 * np.abs(bf).max())
+              and abs(float(buf[-1]) - chif) < 1e-9 * chif
+              and np.allclose(x, np.linalg.solve(Hf, bf), rtol=0, atol=1e-9 * np.abs(x).max())
+              and np.allclose(merged, prob["psi"] + (1.0 + sh["owner"])[:, None]))
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_reduced_system_allreduce_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(180) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
