@@ -485,69 +485,82 @@ __device__ void d_se3_log(const double *T, double *x) {
   Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
   for (int i = 0; i < 3; ++i) x[i] = Vi[3 * i] * T[3] + Vi[3 * i + 1] * T[7] + Vi[3 * i + 2] * T[11];
 }
-__device__ void d_m6_mul(const double *A, const double *Bm, double *Cm) {
-  double t[36];
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += A[6 * i + k] * Bm[6 * k + j]; t[6 * i + j] = s; }
-  for (int i = 0; i < 36; ++i) Cm[i] = t[i];
-}
-__device__ void d_third(const double *A, const double *d, double *out) {   // anchored_points.cpp:207-215
-  double Adj[36], dl[36], t1[36], t2[36];
-  for (int i = 0; i < 36; ++i) { Adj[i] = 0; dl[i] = 0; }
-  double R[9], th[9], tR[9];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = A[4 * i + j];
-  const double t[3] = {A[3], A[7], A[11]};
-  th[0] = 0; th[1] = -t[2]; th[2] = t[1]; th[3] = t[2]; th[4] = 0; th[5] = -t[0]; th[6] = -t[1]; th[7] = t[0]; th[8] = 0;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) tR[3 * i + j] = th[3 * i] * R[j] + th[3 * i + 1] * R[3 + j] + th[3 * i + 2] * R[6 + j];
-  const double hu[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
-  const double hw[9] = {0, -d[5], d[4], d[5], 0, -d[3], -d[4], d[3], 0};
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    Adj[6 * i + j] = R[3 * i + j]; Adj[6 * i + 3 + j] = tR[3 * i + j]; Adj[6 * (i + 3) + 3 + j] = R[3 * i + j];
-    dl[6 * i + j] = -hw[3 * i + j]; dl[6 * i + 3 + j] = -hu[3 * i + j]; dl[6 * (i + 3) + 3 + j] = -hw[3 * i + j];
-  }
-  d_m6_mul(dl, Adj, t1);
-  d_m6_mul(dl, t1, t2);
-  for (int i = 0; i < 36; ++i) out[i] = Adj[i] + 0.5 * t1[i] + (1. / 12.) * t2[i];
-}
+// One wavefront per constraint; lane (i,j) = element of the 6x6 products, operands staged in LDS.
+// (A one-thread-per-constraint version spent 60 us in scratch-spilled serial 6x6x6 products.)
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
 
 template <int MODE>
-__global__ void ba_constraint_kernel(BaDev B) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= B.C) return;
+__global__ __launch_bounds__(64) void ba_constraint_kernel(BaDev B) {
+  __shared__ double s_m[8][36];      // 0 Adj(T21) 1 dl(e) 2 t1 3 J1 4 dl(-e) 5 J2 6 O*J1 7 O*J2
+  const int c = blockIdx.x, lane = threadIdx.x;
   const svs_ba_constraint &cc = B.cons[c];
   const double *poses = MODE == 0 ? B.poses : B.poses_trial;
   double T2i[12], t[12], err[6];
   d_pose_inv(poses + 12 * cc.pose2, T2i);
   d_pose_mul(cc.T_21, poses + 12 * cc.pose1, t);
   d_pose_mul(t, T2i, t);
-  d_se3_log(t, err);
+  d_se3_log(t, err);                                    // redundant per lane: ~300 flop
   double oe[6], e2 = 0;
+#pragma unroll
   for (int i = 0; i < 6; ++i) { oe[i] = 0; for (int j = 0; j < 6; ++j) oe[i] += cc.info[6 * i + j] * err[j]; e2 += err[i] * oe[i]; }
-  if (MODE == 1) { atomic_add_f64(&B.scal[0], e2); return; }
-  atomic_add_f64(B.chi2_cur, e2);
-  double J1[36], J2[36], OJ1[36], OJ2[36], nd[6];
-  const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  d_third(cc.T_21, err, J1);
-  for (int i = 0; i < 6; ++i) nd[i] = -err[i];
-  d_third(I, nd, J2);
-  for (int i = 0; i < 36; ++i) J2[i] = -J2[i];
-  d_m6_mul(cc.info, J1, OJ1);
-  d_m6_mul(cc.info, J2, OJ2);
+  if (MODE == 1) { if (lane == 0) atomic_add_f64(&B.scal[0], e2); return; }
+  if (lane == 0) atomic_add_f64(B.chi2_cur, e2);
+  const int i = lane / 6, j = lane - 6 * i;             // lanes 0..35 own element (i,j)
+  const bool on = lane < 36;
+  // Adj(T21) = [[R, t^R],[0, R]];  d_lieBracketab_by_d_a(d) = -ad_d   
+  if (on) {
+    const double *A = cc.T_21;
+    const double tt[3] = {A[3], A[7], A[11]};
+    const int bi = i % 3, bj = j % 3;
+    const double Rij = A[4 * bi + bj];
+    // (t^ R)[bi][bj]
+    const double th[9] = {0, -tt[2], tt[1], tt[2], 0, -tt[0], -tt[1], tt[0], 0};
+    const double tR = th[3 * bi] * A[bj] + th[3 * bi + 1] * A[4 + bj] + th[3 * bi + 2] * A[8 + bj];
+    double adj = 0, dlp = 0, dlm = 0;
+    const double hu[9] = {0, -err[2], err[1], err[2], 0, -err[0], -err[1], err[0], 0};
+    const double hw[9] = {0, -err[5], err[4], err[5], 0, -err[3], -err[4], err[3], 0};
+    if (i < 3 && j < 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
+    else if (i < 3 && j >= 3) { adj = tR; dlp = -hu[3 * bi + bj]; }
+    else if (i >= 3 && j >= 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
+    dlm = -dlp;                                         // dl(-e)
+    s_m[0][lane] = adj; s_m[1][lane] = dlp; s_m[4][lane] = dlm;
+  }
+  wave_lds_sync();
+  auto mm = [&](int a, int b) { double s = 0; for (int k = 0; k < 6; ++k) s += s_m[a][6 * i + k] * s_m[b][6 * k + j]; return s; };
+  // J1 = third(T21, e) = Adj + 1/2 dl Adj + 1/12 dl dl Adj
+  double t1 = on ? mm(1, 0) : 0.0;
+  if (on) s_m[2][lane] = t1;
+  wave_lds_sync();
+  double t2 = on ? mm(1, 2) : 0.0;
+  const double J1 = on ? s_m[0][lane] + 0.5 * t1 + (1. / 12.) * t2 : 0.0;
+  // J2 = -third(I, -e) = -(I + 1/2 dl(-e) + 1/12 dl(-e)^2)
+  double u2 = on ? mm(4, 4) : 0.0;
+  const double J2 = on ? -((i == j ? 1.0 : 0.0) + 0.5 * s_m[4][lane] + (1. / 12.) * u2) : 0.0;
+  wave_lds_sync();
+  if (on) { s_m[3][lane] = J1; s_m[5][lane] = J2; }
+  wave_lds_sync();
+  // O*J1, O*J2
+  if (on) {
+    double a1 = 0, a2 = 0;
+    for (int k = 0; k < 6; ++k) { a1 += cc.info[6 * i + k] * s_m[3][6 * k + j]; a2 += cc.info[6 * i + k] * s_m[5][6 * k + j]; }
+    s_m[6][lane] = a1; s_m[7][lane] = a2;
+  }
+  wave_lds_sync();
   const int p1 = cc.pose1, p2 = cc.pose2, P = B.P;
-  double *H11 = B.H + blk_index(p1, p1, P) * 36, *H22 = B.H + blk_index(p2, p2, P) * 36;
-  const bool up = p1 < p2;
-  double *H12 = B.H + (up ? blk_index(p1, p2, P) : blk_index(p2, p1, P)) * 36;
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) {
-      double s11 = 0, s22 = 0, s12 = 0;
-      for (int k = 0; k < 6; ++k) { s11 += J1[6 * k + i] * OJ1[6 * k + j]; s22 += J2[6 * k + i] * OJ2[6 * k + j]; s12 += J1[6 * k + i] * OJ2[6 * k + j]; }
-      if (j >= i) { atomic_add_f64(&H11[6 * i + j], s11); atomic_add_f64(&H22[6 * i + j], s22); }
-      if (p1 != p2) atomic_add_f64(&H12[up ? 6 * i + j : 6 * j + i], s12);
+  if (on) {
+    double s11 = 0, s22 = 0, s12 = 0;
+    for (int k = 0; k < 6; ++k) { s11 += s_m[3][6 * k + i] * s_m[6][6 * k + j]; s22 += s_m[5][6 * k + i] * s_m[7][6 * k + j]; s12 += s_m[3][6 * k + i] * s_m[7][6 * k + j]; }
+    if (j >= i) { atomic_add_f64(&B.H[blk_index(p1, p1, P) * 36 + lane], s11); atomic_add_f64(&B.H[blk_index(p2, p2, P) * 36 + lane], s22); }
+    if (p1 != p2) {
+      const bool up = p1 < p2;
+      atomic_add_f64(&B.H[(up ? blk_index(p1, p2, P) : blk_index(p2, p1, P)) * 36 + (up ? 6 * i + j : 6 * j + i)], s12);
     }
-  for (int i = 0; i < 6; ++i) {
+  }
+  if (lane < 6) {
     double s1 = 0, s2 = 0;
-    for (int k = 0; k < 6; ++k) { s1 += J1[6 * k + i] * oe[k]; s2 += J2[6 * k + i] * oe[k]; }
-    atomic_add_f64(&B.bp[6 * p1 + i], -s1);
-    atomic_add_f64(&B.bp[6 * p2 + i], -s2);
+    for (int k = 0; k < 6; ++k) { s1 += s_m[3][6 * k + lane] * oe[k]; s2 += s_m[5][6 * k + lane] * oe[k]; }
+    atomic_add_f64(&B.bp[6 * p1 + lane], -s1);
+    atomic_add_f64(&B.bp[6 * p2 + lane], -s2);
   }
 }
 
@@ -600,33 +613,45 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
   for (int k = 0; k < P; ++k) {
     const long kk = blk_index(k, k, P);
     if (tid == 0) {
-      // 6x6 Cholesky of A_kk (+lambda), upper stored
+      // 6x6 Cholesky of A_kk (+lambda), upper stored; fully unrolled so A/U/Li stay in registers
       double A[36], U[36], Li[36];
       const double *Akk = B.H + kk * 36;
-      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { double v = Akk[6 * r + c]; if (r == c) v += B.lambda; A[6 * r + c] = v; A[6 * c + r] = v; }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) { double v = Akk[6 * r + c]; if (r == c) v += B.lambda; A[6 * r + c] = v; }
       int fail = 0;
-      for (int i = 0; i < 36; ++i) U[i] = 0;
+#pragma unroll
+      for (int i = 0; i < 36; ++i) { U[i] = 0; Li[i] = 0; }
+      double rd[6];
+#pragma unroll
       for (int j = 0; j < 6; ++j) {
         double d = A[6 * j + j];
+#pragma unroll
         for (int q = 0; q < j; ++q) d -= U[6 * q + j] * U[6 * q + j];
         if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1; }
         d = sqrt(d);
         U[6 * j + j] = d;
-        const double id = 1.0 / d;
+        rd[j] = 1.0 / d;
+#pragma unroll
         for (int c = j + 1; c < 6; ++c) {
           double s = A[6 * j + c];
+#pragma unroll
           for (int q = 0; q < j; ++q) s -= U[6 * q + j] * U[6 * q + c];
-          U[6 * j + c] = s * id;
+          U[6 * j + c] = s * rd[j];
         }
       }
       // Li = (U^T)^-1 (lower triangular): forward substitution on identity
-      for (int i = 0; i < 36; ++i) Li[i] = 0;
+#pragma unroll
       for (int c = 0; c < 6; ++c)
+#pragma unroll
         for (int r = c; r < 6; ++r) {
           double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
           for (int q = c; q < r; ++q) s -= U[6 * q + r] * Li[6 * q + c];
-          Li[6 * r + c] = s / U[6 * r + r];
+          Li[6 * r + c] = s * rd[r];
         }
+#pragma unroll
       for (int i = 0; i < 36; ++i) { s_linv[i] = Li[i]; linv_ws[(size_t)k * 36 + i] = Li[i]; }
       if (fail) s_fail = 1;
     }
@@ -955,7 +980,7 @@ static int launch_reduce(svs_ba *ba, double lambda) {
   svs_ctx *ctx = ba->ctx;
   BaDev B = make_dev(ba, lambda);
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
-  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(div_up(B.C, 64)), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   SVS_HIP(ctx, hipEventRecord(ba->ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
   if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   SVS_HIP(ctx, hipEventRecord(ba->ev[1], ctx->stream));
@@ -1010,7 +1035,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
       SVS_LAUNCH_CHECK(ctx);
       SVS_HIP(ctx, hipEventRecord(ba->ev[3], ctx->stream));
-      if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(div_up(B.C, 64)), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+      if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
       SVS_HIP(ctx, hipEventRecord(ba->ev[5], ctx->stream));
       if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
       SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
