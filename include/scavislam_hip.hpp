@@ -1,0 +1,292 @@
+// scavislam_hip.hpp -- C++ adaptor classes over the C ABI (scavislam_hip.h) that keep the
+// reference's call surfaces (method names, argument meaning, blocking semantics, bool/void
+// returns, no exceptions across the boundary -- README:295 house style), so that they can replace
+// the reference classes inside stereo_slam where OpenCV/Eigen/Sophus exist.  This header itself
+// depends on nothing but the C ABI and the STL: images are (pointer, w, h, stride) views, poses
+// are 3x4 row-major double[12].  INTEGRATION.md shows the 10-line glue from cv::Mat / Sophus::SE3.
+//
+//   FastGrid        <- scavislam/fast_grid.h:27-63
+//   GuidedMatcher   <- scavislam/matcher.hpp:62-186
+//   DenseTracker    <- scavislam/dense_tracking.h:53-97  (CPU-path semantics, the parity target)
+//   SlamGraphBA     <- SlamGraph::optimize, scavislam/slam_graph.hpp:457-462
+//
+// One svs_ctx per calling thread (front-end on main, re-registration matcher/FAST + optimize on
+// the backend thread, backend.cpp:452-469,738,763): no static scratch like matcher.cpp:36-38.
+#ifndef SCAVISLAM_HIP_HPP
+#define SCAVISLAM_HIP_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "scavislam_hip.h"
+
+namespace scavislam_hip {
+
+struct Image8 { const uint8_t *data; int w, h, stride; };
+struct ImageF { const float *data; int w, h, stride; };
+struct Corner { int16_t x, y; };
+
+class Context {
+ public:
+  explicit Context(int device = 0, void *hip_stream = nullptr) : ctx_(nullptr) { ok_ = svs_ctx_create(device, hip_stream, &ctx_) == SVS_OK; }
+  ~Context() { if (ctx_) svs_ctx_destroy(ctx_); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  bool ok() const { return ok_; }
+  svs_ctx *get() const { return ctx_; }
+  const char *error() const { return svs_last_error(ctx_); }
+  bool check(int rc) const { if (rc != SVS_OK) std::fprintf(stderr, "scavislam_hip: status %d: %s\n", rc, error()); return rc == SVS_OK; }
+
+ private:
+  svs_ctx *ctx_;
+  bool ok_;
+};
+
+// RAII device buffer
+template <class T>
+class DeviceBuffer {
+ public:
+  DeviceBuffer() : ctx_(nullptr), p_(nullptr), n_(0) {}
+  DeviceBuffer(const Context &c, size_t n) : ctx_(c.get()), p_(nullptr), n_(n) { void *p = nullptr; if (svs_malloc(ctx_, n * sizeof(T), &p) == SVS_OK) p_ = (T *)p; }
+  ~DeviceBuffer() { if (p_) svs_free(ctx_, p_); }
+  DeviceBuffer(DeviceBuffer &&o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+  DeviceBuffer &operator=(DeviceBuffer &&o) noexcept { if (this != &o) { if (p_) svs_free(ctx_, p_); ctx_ = o.ctx_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; } return *this; }
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  T *get() const { return p_; }
+  size_t size() const { return n_; }
+  bool upload(const T *h, size_t n) { return svs_memcpy_h2d(ctx_, p_, h, n * sizeof(T)) == SVS_OK; }
+  bool download(T *h, size_t n) const { return svs_memcpy_d2h(ctx_, h, p_, n * sizeof(T)) == SVS_OK; }
+
+ private:
+  svs_ctx *ctx_;
+  T *p_;
+  size_t n_;
+};
+
+// Device-resident u8 pyramid of one frame (Frame::pyr, keyframes.h:85) + disparity (Frame::disp)
+class FrameDev {
+ public:
+  FrameDev(const Context &c, int w, int h) : ctx_(c) {
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {
+      w_[l] = w >> l; h_[l] = h >> l; stride_[l] = (w_[l] + 63) / 64 * 64;
+      pyr_[l] = DeviceBuffer<uint8_t>(c, (size_t)stride_[l] * h_[l]);
+    }
+    disp_ = DeviceBuffer<float>(c, (size_t)stride_[0] * h_[0]);
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {     // pyr_float32 / _dx / _dy of the CPU path (frame_grabber.cpp:315-333)
+      f32_[l] = DeviceBuffer<float>(c, (size_t)stride_[l] * h_[l]);
+      dx_[l] = DeviceBuffer<float>(c, (size_t)stride_[l] * h_[l]);
+      dy_[l] = DeviceBuffer<float>(c, (size_t)stride_[l] * h_[l]);
+    }
+  }
+  // FrameGrabber::preprocessing (frame_grabber.cpp:285-336): upload level 0, build the pyramid
+  bool preprocessing(const Image8 &left) {
+    std::vector<uint8_t> tmp((size_t)stride_[0] * h_[0]);
+    for (int y = 0; y < h_[0]; ++y) std::memcpy(&tmp[(size_t)y * stride_[0]], left.data + (size_t)y * left.stride, (size_t)w_[0]);
+    if (!pyr_[0].upload(tmp.data(), tmp.size())) return false;
+    for (int l = 1; l < SVS_NUM_PYR_LEVELS; ++l)
+      if (!ctx_.check(svs_pyr_down_u8(ctx_.get(), pyr_[l - 1].get(), w_[l - 1], h_[l - 1], stride_[l - 1], 0, pyr_[l].get(), stride_[l], 0, 1))) return false;
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
+      if (!ctx_.check(svs_convert_sobel_f32(ctx_.get(), pyr_[l].get(), w_[l], h_[l], stride_[l], 0, f32_[l].get(), dx_[l].get(), dy_[l].get(), stride_[l], 0, 1))) return false;
+    return true;
+  }
+  bool setDisparity(const ImageF &d) {
+    std::vector<float> tmp((size_t)stride_[0] * h_[0]);
+    for (int y = 0; y < h_[0]; ++y) std::memcpy(&tmp[(size_t)y * stride_[0]], d.data + (size_t)y * d.stride, sizeof(float) * (size_t)w_[0]);
+    return disp_.upload(tmp.data(), tmp.size());
+  }
+  const uint8_t *pyr(int l) const { return pyr_[l].get(); }
+  const float *disp() const { return disp_.get(); }
+  const float *f32(int l) const { return f32_[l].get(); }
+  const float *dx(int l) const { return dx_[l].get(); }
+  const float *dy(int l) const { return dy_[l].get(); }
+  int w(int l) const { return w_[l]; }
+  int h(int l) const { return h_[l]; }
+  int stride(int l) const { return stride_[l]; }
+
+ private:
+  const Context &ctx_;
+  DeviceBuffer<uint8_t> pyr_[SVS_NUM_PYR_LEVELS];
+  DeviceBuffer<float> disp_;
+  DeviceBuffer<float> f32_[SVS_NUM_PYR_LEVELS], dx_[SVS_NUM_PYR_LEVELS], dy_[SVS_NUM_PYR_LEVELS];
+  int w_[SVS_NUM_PYR_LEVELS], h_[SVS_NUM_PYR_LEVELS], stride_[SVS_NUM_PYR_LEVELS];
+};
+
+// FastGrid constructor arithmetic (fast_grid.cpp:23-58) -- integer bookkeeping only
+inline svs_fastgrid makeFastGrid(int img_w, int img_h, int num_features_per_cell, int boundary_per_cell, int fast_thr,
+                                 int grid_w, int grid_h, int fast_min = 10, int fast_max = 40) {
+  svs_fastgrid g;
+  g.gx = grid_w; g.gy = grid_h;
+  g.min_inner = (int)(num_features_per_cell - boundary_per_cell * 0.33);
+  g.min_outer = num_features_per_cell - boundary_per_cell;
+  g.max_inner = (int)(num_features_per_cell + boundary_per_cell * 0.33);
+  g.max_outer = num_features_per_cell + boundary_per_cell;
+  g.cell_w = img_w / grid_w; g.cell_h = img_h / grid_h;
+  g.fast_min = fast_min; g.fast_max = fast_max;
+  for (int i = 0; i < SVS_MAX_CELLS; ++i) g.thr[i] = fast_thr;
+  return g;
+}
+
+// All per-level FastGrids of StereoFrontend::fast_grid_ (stereo_frontend.cpp:73-88) in one object.
+class FastGrid {
+ public:
+  FastGrid(const Context &c, int n_levels, const int32_t *w, const int32_t *h, const svs_fastgrid *grids, int corner_cap = 8192)
+      : ctx_(c), f_(nullptr), n_levels_(n_levels), cap_(corner_cap) {
+    for (int l = 0; l < n_levels; ++l) grids_[l] = grids[l];
+    c.check(svs_fast_create(c.get(), n_levels, w, h, grids, 1, corner_cap, &f_));
+  }
+  ~FastGrid() { if (f_) svs_fast_destroy(f_); }
+  FastGrid(const FastGrid &) = delete;
+  FastGrid &operator=(const FastGrid &) = delete;
+  // void FastGrid::detectAdaptively(const cv::Mat& img, int trials, QuadTree<int>* qt) for every level
+  // (stereo_frontend.cpp:657-679); corners[l] comes back in the quadtree insertion order
+  bool detectAdaptively(const FrameDev &fr, int trials, std::vector<Corner> *corners /* [n_levels] */) { return run(fr, trials, corners); }
+  // static void FastGrid::detect(const cv::Mat&, const CellGrid2d&, QuadTree<int>*): stored thresholds
+  bool detect(const FrameDev &fr, std::vector<Corner> *corners) { return run(fr, 0, corners); }
+  // const CellGrid2d& cell_grid2d() const : persistent per-cell thresholds of one level
+  std::vector<int32_t> cell_grid2d(int level) {
+    std::vector<int32_t> thr((size_t)grids_[level].gx * grids_[level].gy);
+    ctx_.check(svs_fast_download(f_, 0, level, nullptr, 0, nullptr, nullptr, nullptr, thr.data()));
+    return thr;
+  }
+  bool set_cell_grid2d(int level, const std::vector<int32_t> &thr) { return ctx_.check(svs_fast_set_thresholds(f_, 0, level, thr.data())); }
+  svs_fast *handle() const { return f_; }
+
+ private:
+  bool run(const FrameDev &fr, int trials, std::vector<Corner> *corners) {
+    const uint8_t *img[SVS_NUM_PYR_LEVELS]; int32_t stride[SVS_NUM_PYR_LEVELS]; size_t bs[SVS_NUM_PYR_LEVELS];
+    for (int l = 0; l < n_levels_; ++l) { img[l] = fr.pyr(l); stride[l] = fr.stride(l); bs[l] = 0; }
+    if (!ctx_.check(svs_fast_detect(f_, img, stride, bs, 1, trials))) return false;
+    for (int l = 0; corners && l < n_levels_; ++l) {
+      corners[l].resize((size_t)cap_);
+      int32_t n = 0;
+      if (!ctx_.check(svs_fast_download(f_, 0, l, &corners[l][0].x, cap_, &n, nullptr, nullptr, nullptr))) return false;
+      corners[l].resize((size_t)n);
+    }
+    return true;
+  }
+  const Context &ctx_;
+  svs_fast *f_;
+  int n_levels_, cap_;
+  svs_fastgrid grids_[SVS_NUM_PYR_LEVELS];
+};
+
+// GuidedMatcher<StereoCamera>::match (matcher.hpp:67-83).  keyframe_map / vertex_map look-ups and the
+// append into TrackData stay on the host (hash-map bookkeeping); the per-point arithmetic runs on
+// the device.  results[i].status == SVS_MATCH_OK <=> the reference appends an observation.
+class GuidedMatcher {
+ public:
+  explicit GuidedMatcher(const Context &c) : ctx_(c) {}
+  bool match(const std::vector<svs_keyframe> &keyframes /* device pyramids + T_anchor_from_w */,
+             const double T_cur_from_actkey[12], const double T_actkey_from_w[12], const FrameDev &cur_frame,
+             FastGrid &feature_tree, const svs_cam cam_vec[SVS_NUM_PYR_LEVELS],
+             const std::vector<svs_candidate_point> &ap_map, int SEARCHRADIUS, int thr_mean, int thr_std,
+             std::vector<svs_match_result> *results) {
+    const size_t n = ap_map.size();
+    results->assign(n, svs_match_result());
+    if (n == 0) return true;
+    double Tcw[12], Twk[12];
+    mul(T_cur_from_actkey, T_actkey_from_w, Tcw);     // matcher.cpp:330
+    inv(T_actkey_from_w, Twk);                        // matcher.cpp:328
+    DeviceBuffer<svs_keyframe> d_kf(ctx_, keyframes.size());
+    DeviceBuffer<svs_candidate_point> d_pts(ctx_, n);
+    DeviceBuffer<double> d_T(ctx_, 24);
+    DeviceBuffer<svs_match_result> d_out(ctx_, n);
+    double TT[24];
+    std::memcpy(TT, Tcw, sizeof Tcw); std::memcpy(TT + 12, Twk, sizeof Twk);
+    if (!d_kf.upload(keyframes.data(), keyframes.size()) || !d_pts.upload(ap_map.data(), n) || !d_T.upload(TT, 24)) return false;
+    svs_match_args a;
+    std::memset(&a, 0, sizeof a);
+    a.d_kfs = d_kf.get(); a.n_kf = (int32_t)keyframes.size(); a.d_pts = d_pts.get(); a.n_pts = (int32_t)n;
+    a.d_T_cur_from_w = d_T.get(); a.d_T_w_from_actkey = d_T.get() + 12;
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) { a.d_cur_pyr[l] = cur_frame.pyr(l); a.cur_stride[l] = cur_frame.stride(l); a.cam_vec[l] = cam_vec[l]; }
+    a.d_disp = cur_frame.disp(); a.disp_stride = cur_frame.stride(0);
+    a.search_radius = SEARCHRADIUS; a.thr_mean = thr_mean; a.thr_std = thr_std; a.n_batch = 1;
+    if (!ctx_.check(svs_match(ctx_.get(), &a, feature_tree.handle(), d_out.get()))) return false;
+    return d_out.download(results->data(), n);
+  }
+
+ private:
+  static void mul(const double *A, const double *B, double *C) {
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 4; ++j) C[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j]; C[4 * i + 3] += A[4 * i + 3]; }
+  }
+  static void inv(const double *A, double *B) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[4 * i + j] = A[4 * j + i];
+    for (int i = 0; i < 3; ++i) B[4 * i + 3] = -(B[4 * i] * A[3] + B[4 * i + 1] * A[7] + B[4 * i + 2] * A[11]);
+  }
+  const Context &ctx_;
+};
+
+// DenseTracker, CPU-path semantics (dense_tracking.h:53-97, dense_tracking.cpp:222-423).
+class DenseTracker {
+ public:
+  DenseTracker(const Context &c, const svs_cam cam_vec[SVS_NUM_PYR_LEVELS]) : ctx_(c), d_T_(c, 12), d_passes_(c, 1) {
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) { cam_[l] = cam_vec[l]; cloud_[l] = DeviceBuffer<float>(c, (size_t)(cam_vec[l].w / 4) * (cam_vec[l].h / 4) * 4); }
+  }
+  // void computeDensePointCloudCpu(const SE3& T_cur_from_actkey): ref_dense_points_ from the frame's disparity
+  bool computeDensePointCloudCpu(const FrameDev &fr, const double T_cur_from_actkey[12]) {
+    if (!d_T_.upload(T_cur_from_actkey, 12)) return false;
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
+      if (!ctx_.check(svs_pointcloud_cpu_sem(ctx_.get(), fr.disp(), fr.stride(0), 0, &cam_[l], l, d_T_.get(), cloud_[l].get(), 0, 1))) return false;
+    return svs_ctx_sync(ctx_.get()) == SVS_OK;
+  }
+  // void denseTrackingCpu(SE3* T_cur_from_actkey): in/out pose, whole LM loop in one device launch
+  bool denseTrackingCpu(const FrameDev &prev, const FrameDev &cur, double T_cur_from_actkey[12]) {
+    svs_dense_track_args a;
+    std::memset(&a, 0, sizeof a);
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {
+      a.d_cloud[l] = cloud_[l].get(); a.d_prev_u8[l] = prev.pyr(l); a.pstride[l] = prev.stride(l);
+      a.d_cur[l] = cur.f32(l); a.d_dx[l] = cur.dx(l); a.d_dy[l] = cur.dy(l); a.fstride[l] = cur.stride(l); a.cam_vec[l] = cam_[l];
+    }
+    if (!d_T_.upload(T_cur_from_actkey, 12)) return false;
+    if (!ctx_.check(svs_dense_track_cpu_sem(ctx_.get(), &a, d_T_.get(), d_passes_.get(), 1))) return false;
+    return d_T_.download(T_cur_from_actkey, 12);
+  }
+
+ private:
+  const Context &ctx_;
+  svs_cam cam_[SVS_NUM_PYR_LEVELS];
+  DeviceBuffer<float> cloud_[SVS_NUM_PYR_LEVELS];
+  DeviceBuffer<double> d_T_;
+  DeviceBuffer<int32_t> d_passes_;
+};
+
+// SlamGraph::optimize(const OptParams&) (slam_graph.hpp:457-462): the caller marshals the double
+// window exactly as copyDataToG2o does (slam_graph.cpp:983-1032) into flat arrays.
+struct OptParams {                       // slam_graph.hpp:36-50
+  OptParams(int num_iters, bool use_robust_kernel, double huber_kernel_width)
+      : num_iters(num_iters), use_robust_kernel(use_robust_kernel), huber_kernel_width(huber_kernel_width) {}
+  int num_iters; bool use_robust_kernel; double huber_kernel_width;
+};
+class SlamGraphBA {
+ public:
+  explicit SlamGraphBA(const Context &c) : ctx_(c), ba_(nullptr) { c.check(svs_ba_create(c.get(), &ba_)); }
+  ~SlamGraphBA() { if (ba_) svs_ba_destroy(ba_); }
+  SlamGraphBA(const SlamGraphBA &) = delete;
+  SlamGraphBA &operator=(const SlamGraphBA &) = delete;
+  // poses [P][12] and psi [L][3] are updated in place, like restoreDataFromG2o (slam_graph.cpp:1035-1058)
+  bool optimize(const OptParams &opt, const svs_cam &cam, std::vector<double> *poses, std::vector<double> *psi,
+                const std::vector<svs_ba_edge> &obs_edges, const std::vector<svs_ba_constraint> &constraints,
+                svs_ba_stats *stats = nullptr, bool exact_self_edges = false) {
+    svs_ba_params prm;
+    prm.num_iters = opt.num_iters; prm.use_robust = opt.use_robust_kernel ? 1 : 0;
+    prm.huber_delta = 1.0;               // huber_kernel_width is dead in the reference (slam_graph-impl.cpp:86-90)
+    prm.lambda_init = 50.0;              // slam_graph.cpp:338
+    prm.max_trials = 5;                  // slam_graph.cpp:1073
+    prm.self_edge_mode = exact_self_edges ? 1 : 0;
+    const int P = (int)(poses->size() / 12), L = (int)(psi->size() / 3);
+    if (!ctx_.check(svs_ba_set_problem(ba_, P, poses->data(), L, psi->data(), (int)obs_edges.size(), obs_edges.data(),
+                                       (int)constraints.size(), constraints.data(), &cam, &prm, 1))) return false;
+    if (!ctx_.check(svs_ba_optimize(ba_, nullptr, nullptr, stats))) return false;
+    return ctx_.check(svs_ba_get_state(ba_, poses->data(), psi->data()));
+  }
+
+ private:
+  const Context &ctx_;
+  svs_ba *ba_;
+};
+
+}  // namespace scavislam_hip
+#endif

@@ -114,3 +114,19 @@ def test_product_package_never_imports_the_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "svs_oracle" not in txt and "svs_ref_" not in txt, f
     for f in os.listdir(os.path.join(ROOT, "include")):
         assert "svs_ref_" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+def test_cpp_adaptor_header_compiles_and_links(tmp_path):
+    """include/scavislam_hip.hpp (reference-named C++ adaptor classes) builds with plain g++ -std=c++11
+    against the C-ABI library; on a box without a GPU the context reports !ok() instead of crashing."""
+    src = tmp_path / "a.cpp"
+    src.write_text('#include "scavislam_hip.hpp"\n'
+                   'int main(){ scavislam_hip::Context c(0); if(!c.ok()){ std::puts("nodev"); return 0; }\n'
+                   '  scavislam_hip::FrameDev fr(c, 64, 48); scavislam_hip::SlamGraphBA ba(c); scavislam_hip::GuidedMatcher m(c);\n'
+                   '  std::puts("dev"); return 0; }\n')
+    exe = tmp_path / "a"
+    libdir = os.path.join(ROOT, "scavislam_amd")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lscavislam_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.check_output([str(exe)]).decode().strip()
+    assert out in ("nodev", "dev")
