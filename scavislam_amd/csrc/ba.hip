@@ -20,6 +20,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -754,6 +755,238 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
   if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
 }
 
+// ---- LDS-window variant of the solve -------------------------------------------------------------
+// When the filled block envelope is narrow (R = max_k(rowmax[k]-k)+1 rows fit in LDS) the active
+// R x R block window of the elimination lives entirely in LDS: no global round trip sits on the
+// P-step critical path.  Row k+R is prefetched into registers at the start of step k and dropped
+// into the ring slot row k vacates.  The panel rows U_kj go to a separate global buffer (written
+// once, read once in the back substitution, prefetched one step ahead).  Forward substitution is
+// fused; the panel is obtained by per-column forward substitution against U_kk (no explicit inverse).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would put
+// the latency of the prefetch loads (global, ~1 us) back on the critical path of every step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int WSOLVE_PRE = 4;   // prefetch registers per lane: R*36 <= 256*WSOLVE_PRE  => R <= 28
+
+// reciprocal by hardware estimate + 2 Newton steps.  A dependent f64 op costs ~36 cycles on one
+// wave (measured, tools/clock_probe.hip), so the elimination below is written for SHORT dependency
+// chains: LDL^T instead of Cholesky (no sqrt, one reciprocal per pivot), right-looking updates.
+__device__ __forceinline__ double rcp_nr(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-d, x, 1.0);
+  return __builtin_fma(x, e, x);
+}
+
+// H + lambda I = U^T D U (U unit upper, D diagonal), organised in 6x6 block rows inside the envelope.
+//   row k:  U_kk (unit upper), Y_kj = D_k^-1 U_kk^-T A~_kj  (j > k);   Z_kj = D_k Y_kj
+//   trailing: A~_ij -= Z_ki^T Y_kj;  forward: z_k = U_kk^-T b~_k, b~_j -= Y_kj^T z_k;  w = D^-1 z
+//   backward: x_k = U_kk^-1 (w_k - sum_j Y_kj x_j)
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
+                                                                     const int *__restrict__ rowmax_g, int R) {
+  extern __shared__ double smem[];
+  const int P = B.P, n = 6 * P, tid = threadIdx.x;
+  double *s_b = smem;                          // [n]
+  double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
+  double *s_pz = s_win + (size_t)R * R * 36;   // [R][36] Z_kj of the current step
+  double *s_py = s_pz + (size_t)R * 36;        // [R][36] Y_kj
+  double *s_ud = s_py + (size_t)R * 36;        // [P][36] U_kk (unit upper; strict upper part used)
+  double *s_rd = s_ud + (size_t)P * 36;        // [P][6]  1/D_k
+  double *s_y = s_rd + (size_t)P * 6;          // [8]  z_k
+  double *s_part = s_y + 8;                    // [R][6]
+  int *rowmax = reinterpret_cast<int *>(s_part + (size_t)R * 6);   // [P] envelope, staged in LDS (off the critical path)
+  __shared__ int s_fail;
+  const long long t_begin = wall_clock64();
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < P; i += SOLVE_THREADS) rowmax[i] = rowmax_g[i];
+  for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  for (int r = 0; r < R && r < P; ++r) {
+    const long rb = blk_index(r, r, P);
+    for (int e = tid; e < R * 36; e += SOLVE_THREADS) {
+      const int c = e / 36;
+      s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+    }
+  }
+  __syncthreads();
+  const long long t_loop = wall_clock64();
+  for (int k = 0; k < P; ++k) {
+    double *row = s_win + ((size_t)(k % R) * R) * 36;
+    double pre[WSOLVE_PRE];
+    const int rn = k + R;
+    if (rn < P) {
+      const long rb = blk_index(rn, rn, P);
+#pragma unroll
+      for (int i = 0; i < WSOLVE_PRE; ++i) {
+        const int e = tid + i * SOLVE_THREADS;
+        const int c = e / 36;
+        pre[i] = (e < R * 36 && rn + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+      }
+    }
+    if (tid == 0) {
+      // right-looking LDL^T of the 6x6 pivot block: dependency chain = 6 x (rcp, scale, update)
+      double A[36];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) { double v = row[6 * r + c]; if (r == c) v += B.lambda; A[6 * r + c] = v; }
+      int fail = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double d = A[6 * j + j];
+        if (!(d > 0) || !isfinite(d)) fail = 1;
+        const double rj = rcp_nr(d);
+        s_rd[(size_t)k * 6 + j] = rj;
+        double u[6];
+#pragma unroll
+        for (int c = j + 1; c < 6; ++c) { u[c] = A[6 * j + c] * rj; s_ud[(size_t)k * 36 + 6 * j + c] = u[c]; }
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) A[6 * r + c] = __builtin_fma(-u[r], A[6 * j + c], A[6 * r + c]);
+      }
+      if (fail) s_fail = 1;
+    }
+    lds_barrier();
+    if (s_fail) break;
+    const int nj = rowmax[k] - k;
+    const double *U = s_ud + (size_t)k * 36, *rd = s_rd + (size_t)k * 6;
+    // panel columns (+ the rhs as one more column): unit-lower forward substitution, right-looking
+    for (int e = tid; e <= nj * 6; e += SOLVE_THREADS) {
+      double a[6];
+      const bool is_rhs = e == nj * 6;
+      const int jj = e / 6, c = e - jj * 6;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) a[q] = is_rhs ? s_b[6 * k + q] : row[(size_t)(1 + jj) * 36 + 6 * q + c];
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int r = q + 1; r < 6; ++r) a[r] = __builtin_fma(-U[6 * q + r], a[q], a[r]);
+      if (is_rhs) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s_y[q] = a[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const double y = a[q] * rd[q];
+          s_pz[(size_t)jj * 36 + 6 * q + c] = a[q];
+          s_py[(size_t)jj * 36 + 6 * q + c] = y;
+          upanel[((size_t)k * R + jj) * 36 + 6 * q + c] = y;
+        }
+      }
+    }
+    lds_barrier();
+    if (tid < 6) s_b[6 * k + tid] = s_y[tid] * rd[tid];        // w_k
+    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {        // b~_j -= Y_kj^T z_k
+      const int jj = e / 6, c = e - jj * 6;
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q += 2) {
+        s0 = __builtin_fma(s_py[(size_t)jj * 36 + 6 * q + c], s_y[q], s0);
+        s1 = __builtin_fma(s_py[(size_t)jj * 36 + 6 * (q + 1) + c], s_y[q + 1], s1);
+      }
+      s_b[6 * (k + 1 + jj) + c] -= s0 + s1;
+    }
+    const int nblk = nj * (nj + 1) / 2;
+    for (int e = tid; e < nblk * 6; e += SOLVE_THREADS) {      // A~_ij -= Z_ki^T Y_kj
+      const int bidx = e / 6, r = e - bidx * 6;
+      int ii = 0, rem = bidx;
+      while (rem >= nj - ii) { rem -= nj - ii; ++ii; }
+      const int jj = ii + rem;
+      double zi[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) zi[q] = s_pz[(size_t)ii * 36 + 6 * q + r];
+      double *Aij = s_win + (((size_t)((k + 1 + ii) % R) * R) + (jj - ii)) * 36 + 6 * r;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q += 2) {
+          s0 = __builtin_fma(zi[q], s_py[(size_t)jj * 36 + 6 * q + c], s0);
+          s1 = __builtin_fma(zi[q + 1], s_py[(size_t)jj * 36 + 6 * (q + 1) + c], s1);
+        }
+        Aij[c] -= s0 + s1;
+      }
+    }
+    if (rn < P) {
+#pragma unroll
+      for (int i = 0; i < WSOLVE_PRE; ++i) { const int e = tid + i * SOLVE_THREADS; if (e < R * 36) row[e] = pre[i]; }
+    }
+    lds_barrier();
+  }
+  const int fail = s_fail;
+  lds_barrier();
+  const long long t_fwd = wall_clock64();
+  if (!fail) {
+    double un[6];
+    int njn = rowmax[P - 1] - (P - 1);
+    if (tid < njn * 6) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(P - 1) * R + tid / 6) * 36 + 6 * (tid % 6) + c];
+    }
+    for (int k = P - 1; k >= 0; --k) {
+      const int nj = njn;
+      double u[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) u[c] = un[c];
+      if (k > 0) {
+        njn = rowmax[k - 1] - (k - 1);
+        if (tid < njn * 6) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(k - 1) * R + tid / 6) * 36 + 6 * (tid % 6) + c];
+        }
+      }
+      if (tid < nj * 6) {
+        const int jj = tid / 6, r = tid - jj * 6;
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          s0 = __builtin_fma(u[c], s_b[6 * (k + 1 + jj) + c], s0);
+          s1 = __builtin_fma(u[c + 1], s_b[6 * (k + 1 + jj) + c + 1], s1);
+        }
+        s_part[jj * 6 + r] = s0 + s1;
+      }
+      lds_barrier();
+      if (tid == 0) {
+        double x[6];
+        const double *U = s_ud + (size_t)k * 36;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+          int jj = 0;
+          for (; jj + 3 < nj; jj += 4) { p0 += s_part[jj * 6 + r]; p1 += s_part[(jj + 1) * 6 + r]; p2 += s_part[(jj + 2) * 6 + r]; p3 += s_part[(jj + 3) * 6 + r]; }
+          for (; jj < nj; ++jj) p0 += s_part[jj * 6 + r];
+          x[r] = s_b[6 * k + r] - ((p0 + p1) + (p2 + p3));
+        }
+#pragma unroll
+        for (int r = 5; r >= 1; --r)
+#pragma unroll
+          for (int q = 0; q < r; ++q) x[q] = __builtin_fma(-U[6 * q + r], x[r], x[q]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_b[6 * k + r] = x[r];
+      }
+      lds_barrier();
+    }
+  } else {
+    for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = 0;
+    lds_barrier();
+  }
+  const long long t_back = wall_clock64();
+  double sc = 0;
+  for (int i = tid; i < n; i += SOLVE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  sc = wave_sum_f64(sc);
+  if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
+  for (int p = tid; p < P; p += SOLVE_THREADS) {
+    double Tn[12];
+    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
+  }
+  if (tid == 0) {
+    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+    // phase timing (100 MHz wall clock ticks -> us), read by SVS_BA_DEBUG=1
+    B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
+  }
+}
+
 // expands the packed upper blocks to a full symmetric matrix + bred (parity tests)
 __global__ void ba_expand_kernel(BaDev B, double *__restrict__ Hfull, double *__restrict__ bred) {
   const int P = B.P, n = 6 * P;
@@ -787,6 +1020,9 @@ struct svs_ba {
   size_t red_count = 0;
   double *d_x = nullptr, *d_scal = nullptr, *d_linv = nullptr;
   int *d_rowmax = nullptr, *d_colmin = nullptr;
+  double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
+  int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
+  bool use_lds_solve = false; size_t lds_solve_smem = 0;
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
   bool profile_ready = false;
@@ -799,6 +1035,7 @@ struct svs_ba {
     if (d_cons) (void)hipFree(d_cons); if (d_red) (void)hipFree(d_red); if (d_x) (void)hipFree(d_x); if (d_scal) (void)hipFree(d_scal);
     if (d_linv) (void)hipFree(d_linv);
     if (d_rowmax) (void)hipFree(d_rowmax); if (d_colmin) (void)hipFree(d_colmin); if (d_pattern) (void)hipFree(d_pattern);
+    if (d_upanel) (void)hipFree(d_upanel); d_upanel = nullptr; env_R = 0; use_lds_solve = false;
     d_rowmax = d_colmin = nullptr; d_pattern = nullptr; profile_ready = false;
     d_edges = nullptr; d_chunk_start = d_chunk_len = nullptr; d_cons = nullptr; d_red = d_x = d_scal = d_linv = nullptr;
   }
@@ -971,6 +1208,18 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   SVS_HIP(ctx, hipMemcpyAsync(ba->d_rowmax, rowmax.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemcpyAsync(ba->d_colmin, colmin.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int R = 1;
+  for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
+  ba->env_R = R;
+  // LDS budget of the window solve: rhs + R*R window + panel + U_kk + 1/diag + scratch
+  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 2 * (size_t)R * 36 + (size_t)P * 42 + 8 + (size_t)R * 6) + sizeof(int) * (size_t)(P + 2);
+  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= SOLVE_THREADS * WSOLVE_PRE && (R - 1) * 6 + 1 <= SOLVE_THREADS;
+  ba->lds_solve_smem = need;
+  if (ba->use_lds_solve) {
+    if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; }
+    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * 36 * (size_t)P * R));
+    if (need > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+  }
   ba->profile_ready = true;
   return SVS_OK;
 }
@@ -1032,7 +1281,10 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       BaDev B = make_dev(ba, lambda);
       SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 8, ctx->stream));
       SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
+      if (ba->use_lds_solve)
+        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(SOLVE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+      else
+        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
       SVS_LAUNCH_CHECK(ctx);
       SVS_HIP(ctx, hipEventRecord(ba->ev[3], ctx->stream));
       if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
@@ -1040,13 +1292,14 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
       SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
       if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
-      double h[5];
+      double h[8];
       SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       float ms;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[0], ba->ev[1])); ba->t_reduce += ms; ba->n_reduce++;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[2], ba->ev[3])); ba->t_solve += ms;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[5], ba->ev[4])); ba->t_backsub += ms;
+      if (getenv("SVS_BA_DEBUG")) fprintf(stderr, "[svs_ba] solve phases: init %.1f us, forward %.1f us, backward %.1f us\n", h[5], h[6], h[7]);
       const bool fail = h[3] != 0.0;
       if (qmax == 0) { currentChi = h[4]; if (it == 0) st.chi2_init = currentChi; }
       double tempChi = fail ? 1.7976931348623157e308 : h[0];
