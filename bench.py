@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="independent camera streams per rank per step")
+    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per rank per step")
     ap.add_argument("--points", type=int, default=2000, help="candidate points per frame (SURVEY 8d config 2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -53,8 +53,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (even with 1 rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     ctx, stream = capi.torch_context(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -63,7 +65,7 @@ def main():
     def barrier_sync():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def max_over_ranks(x):
@@ -201,7 +203,7 @@ def main():
     sh = shard_problem(prob, rank, world) if world > 1 else dict(prob, add_pose_terms=True)
     opt = SlamGraphOptimizer(ctx, stream)
     opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], camc, prm, add_pose_terms=sh["add_pose_terms"])
-    allreduce = make_allreduce(stream, local_rank) if world > 1 else None
+    allreduce = make_allreduce(stream, local_rank) if use_dist else None
     E_total, E_local = len(prob["edges"]), len(sh["edges"])
     stats = None
     t_red = t_sol = t_bs = 0.0
@@ -302,7 +304,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

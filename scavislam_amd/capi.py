@@ -11,7 +11,7 @@ import weakref
 from .ctypes_types import BaParams, BaStats, Cam, FastGrid
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscavislam_hip.so")
+LIB_PATH = os.environ.get("SVS_LIB_PATH") or os.path.join(_HERE, "libscavislam_hip.so")   # override = kernel A/B experiments only
 _LIB = None
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)

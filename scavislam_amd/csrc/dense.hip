@@ -45,44 +45,56 @@ struct LevelArgs {
   svs_cam cam;
 };
 
-// loop body of dense_tracking.cpp:229-261 (chi2) / :278-331 (H, b), one sample
+// loop body of dense_tracking.cpp:229-261 (chi2) / :278-331 (H, b), one sample.
+// Branch-free (invalid samples are predicated to zero contributions and a safe address) so that the
+// unrolled caller can keep the cloud load and the 12 bilinear taps of several samples in flight:
+// the pass is bound by gather latency, not by bytes.
 template <bool JAC>
-__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, int u, int v, int cw, Acc &a) {
-  const float4 c4 = reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u];
-  if (!(c4.w > 0)) return;
+__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, int u, int v, int cw, bool in_range, Acc &a) {
+  const float4 c4 = in_range ? reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u] : make_float4(0.f, 0.f, 1.f, -1.f);
+  bool ok = in_range && (c4.w > 0);
   const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
   const double x = T[0] * xp0 + T[1] * xp1 + T[2] * xp2 + T[3];
   const double y = T[4] * xp0 + T[5] * xp1 + T[6] * xp2 + T[7];
   const double z = T[8] * xp0 + T[9] * xp1 + T[10] * xp2 + T[11];
-  const float uvx = (float)(L.cam.f * (x / z) + L.cam.cx);
-  const float uvy = (float)(L.cam.f * (y / z) + L.cam.cy);
-  if (!(fabsf(uvx) < 1e9f && fabsf(uvy) < 1e9f)) return;
-  const int ui = (int)uvx, vi = (int)uvy;
-  if (!(ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2)) return;
-  const float ip = (float)((1. / 255.) * L.prev[(size_t)(v * 4) * L.pstride + u * 4]);
+  float uvx = (float)(L.cam.f * (x / z) + L.cam.cx);
+  float uvy = (float)(L.cam.f * (y / z) + L.cam.cy);
+  ok = ok && (fabsf(uvx) < 1e9f && fabsf(uvy) < 1e9f);
+  const int ui = ok ? (int)uvx : 0, vi = ok ? (int)uvy : 0;
+  ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
+  if (!ok) { uvx = 2.f; uvy = 2.f; }                       // safe tap position, contribution masked below
+  const float ip = (float)((1. / 255.) * L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4]);
   const float ic = interp32f(L.cur, L.fstride, uvx, uvy);
   float res = ip - ic;
   if (res > 0.1) res = 0.1;
   if (res < -0.1) res = -0.1;
+  if (!ok) res = 0.f;
   a.v[27] += (double)(res * res);
-  a.n += 1;
+  a.n += ok ? 1 : 0;
   if (JAC) {
-    const float gx = (float)(0.5 * interp32f(L.dx, L.fstride, uvx, uvy));
-    const float gy = (float)(0.5 * interp32f(L.dy, L.fstride, uvx, uvy));
-    const double f = L.cam.f, z2 = z * z;
-    // transformations.h:117-139 frame_jac_xyz2uv
-    double r0[6] = {-1. / z * f, 0, x / z2 * f, x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f};
-    double r1[6] = {0, -1. / z * f, y / z2 * f, (1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f};
-    double J[6];
+    const float gx = ok ? (float)(0.5 * interp32f(L.dx, L.fstride, uvx, uvy)) : 0.f;
+    const float gy = ok ? (float)(0.5 * interp32f(L.dy, L.fstride, uvx, uvy)) : 0.f;
+    const double zs = ok ? z : 1.0, xs = ok ? x : 0.0, ys = ok ? y : 0.0;
+    // transformations.h:117-139 frame_jac_xyz2uv.  One reciprocal instead of eight f64 divisions and
+    // fused multiply-adds in the 27 accumulations: the pass is f64-issue bound on its CU, and H/b only
+    // need 1e-9 relative agreement with the serial oracle (uv above stays division-exact because the
+    // in-frame test and the tap addresses must match bit for bit).
+    {
+#pragma clang fp contract(fast)
+      const double f = L.cam.f, iz = 1.0 / zs, iz2 = iz * iz, fx = f * iz, xz = xs * iz2 * f, yz = ys * iz2 * f;
+      const double r0[6] = {-fx, 0, xz, xz * ys, -(f + xz * xs), ys * fx};
+      const double r1[6] = {0, -fx, yz, f + yz * ys, -(yz * xs), -(xs * fx)};
+      double J[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) J[k] = gx * r0[k] + gy * r1[k];
-    int k = 0;
+      for (int k = 0; k < 6; ++k) J[k] = gx * r0[k] + gy * r1[k];
+      int k = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+      for (int c = 0; c < 6; ++c)
 #pragma unroll
-      for (int r = 0; r <= c; ++r) a.v[k++] += J[r] * J[c];
+        for (int r = 0; r <= c; ++r) { a.v[k] = __builtin_fma(J[r], J[c], a.v[k]); ++k; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a.v[21 + i] += J[i] * res;
+      for (int i = 0; i < 6; ++i) a.v[21 + i] = __builtin_fma(J[i], (double)res, a.v[21 + i]);
+    }
   }
 }
 
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256) void dense_pass_cpu_sem_kernel(LevelArgs L, si
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, a);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, true, a);
   block_reduce<4>(a, s_part, s_out);
   if (threadIdx.x <= NSUM) partials[((size_t)slot * gridDim.x + blockIdx.x) * (NSUM + 1) + threadIdx.x] = s_out[threadIdx.x];
 }
@@ -179,14 +191,30 @@ struct TrackArgs {
   size_t cloud_b[3], prev_b[3], f_b[3];
 };
 
-constexpr int TRK_THREADS = 1024;
+#ifndef SVS_TRK_THREADS
+#define SVS_TRK_THREADS 1024
+#endif
+#ifndef SVS_TRK_UNROLL
+#define SVS_TRK_UNROLL 1
+#endif
+constexpr int TRK_THREADS = SVS_TRK_THREADS;
+constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
 template <bool JAC>
 __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out) {
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
-  for (int i = threadIdx.x; i < n; i += TRK_THREADS) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, a);
+  // TRK_UNROLL samples per lane per trip, predicated tail: several samples' gathers in flight per lane
+  for (int i0 = threadIdx.x; i0 < n; i0 += TRK_UNROLL * TRK_THREADS) {
+#pragma unroll
+    for (int q = 0; q < TRK_UNROLL; ++q) {
+      const int i = i0 + q * TRK_THREADS;
+      const bool in_range = i < n;
+      const int ii = in_range ? i : 0;
+      sample_cpu_sem<JAC>(L, T, ii % cw, ii / cw, cw, in_range, a);
+    }
+  }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
 

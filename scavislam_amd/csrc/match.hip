@@ -99,13 +99,19 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
   if (ap.kf_index < 0 || ap.kf_index >= A.n_kf) status = SVS_MATCH_NO_ANCHOR;
   else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) status = SVS_MATCH_NONE;  // no feature_tree for that level
   if (status == SVS_MATCH_OK) {
-    const svs_keyframe kf = A.d_kfs[ap.kf_index];
-    const int lvl = ap.anchor_level;
+    // all 64 lanes work on the same point: make the indices wave-uniform (scalar) so the keyframe
+    // record and the per-level tables are read with scalar loads instead of a per-lane scratch copy
+    const int kfi = __builtin_amdgcn_readfirstlane(ap.kf_index);
+    const int lvl = __builtin_amdgcn_readfirstlane(ap.anchor_level);
+    const svs_keyframe *kfp = A.d_kfs + kfi;
     const svs_cam cam = A.cam_vec[lvl];
+    double kfT[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) kfT[i] = kfp->T_anchor_from_w[i];
     double Tcw[12], Twk[12], T_w_from_anchor[12], T_cur_from_anchor[12], xyz_cur[3];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
-    d_pose_inv(kf.T_anchor_from_w, T_w_from_anchor);
+    d_pose_inv(kfT, T_w_from_anchor);
     d_pose_mul(Tcw, T_w_from_anchor, T_cur_from_anchor);
     d_pose_act(T_cur_from_anchor, ap.xyz_anchor, xyz_cur);
     const double uv0 = cam.f * (xyz_cur[0] / xyz_cur[2]) + cam.cx;
@@ -124,8 +130,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
       const double a00 = fu[0] - f0[0], a01 = fu[1] - f0[1], a10 = fv[0] - f0[0], a11 = fv[1] - f0[1];
       const double invdet = 1.0 / (a00 * a11 - a01 * a10);
       const double i00 = a11 * invdet, i01 = -a01 * invdet, i10 = -a10 * invdet, i11 = a00 * invdet;
-      const uint8_t *kimg = kf.pyr[lvl];
-      const int kstride = kf.stride[lvl];
+      const uint8_t *kimg = kfp->pyr[lvl];
+      const int kstride = kfp->stride[lvl];
       for (int q = lane; q < 100; q += 64) {
         const int iy = q / 10, ix = q - iy * 10;
         const double dx = ix - 5, dy = iy - 5;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
           }
         }
         double T_anchor_from_actkey[12], T_actkey_from_anchor[12];
-        d_pose_mul(kf.T_anchor_from_w, Twk, T_anchor_from_actkey);
+        d_pose_mul(kfT, Twk, T_anchor_from_actkey);
         d_pose_inv(T_anchor_from_actkey, T_actkey_from_anchor);
         d_pose_act(T_actkey_from_anchor, ap.xyz_anchor, xyz_actkey);
         if (bestkey == 0xffffffffu) { status = SVS_MATCH_NONE; best = init_dist; }
