@@ -82,55 +82,63 @@ def main():
     NPAIR = 2
     kf_id = 0
     rend = {i: scene.render(cam, traj[i], seed=i) for i in [kf_id] + [4 + p for p in range(NPAIR + 1)]}
-    prev_imgs = np.stack([rend[4 + (b % NPAIR)][0] for b in range(B)])
-    prev_disp = np.stack([rend[4 + (b % NPAIR)][1] for b in range(B)])
-    cur_imgs = np.stack([rend[5 + (b % NPAIR)][0] for b in range(B)])
-    cur_disp = np.stack([rend[5 + (b % NPAIR)][1] for b in range(B)])
     I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
+    def build_frontend(B):
+        prev_imgs = np.stack([rend[4 + (b % NPAIR)][0] for b in range(B)])
+        prev_disp = np.stack([rend[4 + (b % NPAIR)][1] for b in range(B)])
+        cur_imgs = np.stack([rend[5 + (b % NPAIR)][0] for b in range(B)])
+        cur_disp = np.stack([rend[5 + (b % NPAIR)][1] for b in range(B)])
 
-    prev = FramePyramid(ctx, stream, cam, batch=B)
-    cur = FramePyramid(ctx, stream, cam, batch=B)
-    kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
-    prev.upload(prev_imgs, prev_disp)
-    cur.upload(cur_imgs, cur_disp)
-    kf.upload(rend[kf_id][0][None], rend[kf_id][1][None])
-    prev.preprocessing()
-    kf.preprocessing()
-    fast = FastGrid(ctx, cur)
-    dtrack = DenseTracker(ctx, cur)
-    dprev = DenseTracker(ctx, prev)
-    dprev.computeDensePointCloudCpu(I34)          # reference cloud of the previous frame
-    track_args = dtrack.track_args(prev.pyr)
-    for l in range(3):
-        track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
-    rng = np.random.default_rng(2011)
-    n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
-    pts = synth.candidate_points(rng, cam, rend[kf_id][1], traj[kf_id], n_per_level)
-    T_kf = traj[kf_id]
-    Tc = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
-    matcher = GuidedMatcher(ctx, cur, fast)
-    margs = matcher.prepare([(kf.pyr, 0, T_kf.reshape(12))], Tc, T_kf.reshape(12), pts)
-    T_rel = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(traj[4 + (b % NPAIR)])).reshape(12) for b in range(B)])
-    with torch.cuda.stream(stream):
-        d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
-
-    def frontend_step():
-        cur.preprocessing()                                        # "preprocess"
-        dtrack.d_T.copy_(d_T0)
-        dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)   # "dense tracking"
-        fast.detectAdaptively(trials=6)                            # "fast"
-        matcher.launch(margs)                                      # "match"
-        dtrack.computeDensePointCloudCpu_dev()                     # "dense point cloud"
-
-    # computeDensePointCloudCpu with the tracked pose already on the device (no host round trip)
-    def _pc_dev():
-        import ctypes as C
+        prev = FramePyramid(ctx, stream, cam, batch=B)
+        cur = FramePyramid(ctx, stream, cam, batch=B)
+        kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
+        prev.upload(prev_imgs, prev_disp)
+        cur.upload(cur_imgs, cur_disp)
+        kf.upload(rend[kf_id][0][None], rend[kf_id][1][None])
+        prev.preprocessing()
+        kf.preprocessing()
+        fast = FastGrid(ctx, cur)
+        dtrack = DenseTracker(ctx, cur)
+        dprev = DenseTracker(ctx, prev)
+        dprev.computeDensePointCloudCpu(I34)          # reference cloud of the previous frame
+        track_args = dtrack.track_args(prev.pyr)
         for l in range(3):
-            cb = (cur.h[l] // 4) * (cur.w[l] // 4) * 4
-            ctx.call("svs_pointcloud_cpu_sem", cur.disp.data_ptr(), cur.stride[0], cur.bstride(0), C.byref(cur.cams[l]), l,
-                     dtrack.d_T.data_ptr(), dtrack.ref_dense_points[l].data_ptr(), cb, B)
-    dtrack.computeDensePointCloudCpu_dev = _pc_dev
+            track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
+        rng = np.random.default_rng(2011)
+        n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
+        pts = synth.candidate_points(rng, cam, rend[kf_id][1], traj[kf_id], n_per_level)
+        T_kf = traj[kf_id]
+        Tc = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
+        matcher = GuidedMatcher(ctx, cur, fast)
+        margs = matcher.prepare([(kf.pyr, 0, T_kf.reshape(12))], Tc, T_kf.reshape(12), pts)
+        T_rel = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(traj[4 + (b % NPAIR)])).reshape(12) for b in range(B)])
+        with torch.cuda.stream(stream):
+            d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
 
+        def frontend_step():
+            cur.preprocessing()                                        # "preprocess"
+            dtrack.d_T.copy_(d_T0)
+            dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)   # "dense tracking"
+            fast.detectAdaptively(trials=6)                            # "fast"
+            matcher.launch(margs)                                      # "match"
+            dtrack.computeDensePointCloudCpu_dev()                     # "dense point cloud"
+
+        # computeDensePointCloudCpu with the tracked pose already on the device (no host round trip)
+        def _pc_dev():
+            import ctypes as C
+            for l in range(3):
+                cb = (cur.h[l] // 4) * (cur.w[l] // 4) * 4
+                ctx.call("svs_pointcloud_cpu_sem", cur.disp.data_ptr(), cur.stride[0], cur.bstride(0), C.byref(cur.cams[l]), l,
+                         dtrack.d_T.data_ptr(), dtrack.ref_dense_points[l].data_ptr(), cb, B)
+        dtrack.computeDensePointCloudCpu_dev = _pc_dev
+
+
+        return dict(step=frontend_step, cur=cur, prev=prev, kf=kf, fast=fast, dtrack=dtrack, dprev=dprev, matcher=matcher, margs=margs,
+                    track_args=track_args, d_T0=d_T0, pc_dev=_pc_dev, pts=pts, Tc=Tc, T_rel=T_rel, T_kf=T_kf)
+
+    fe = build_frontend(B)
+    frontend_step, cur, prev, fast, dtrack, matcher, margs = fe["step"], fe["cur"], fe["prev"], fe["fast"], fe["dtrack"], fe["matcher"], fe["margs"]
+    track_args, d_T0, _pc_dev, pts, Tc, T_rel, T_kf = fe["track_args"], fe["d_T0"], fe["pc_dev"], fe["pts"], fe["Tc"], fe["T_rel"], fe["T_kf"]
     with torch.cuda.stream(stream):
         for _ in range(W):
             frontend_step()
@@ -194,6 +202,19 @@ def main():
     roofline_frontend = {k: {"ms": round(stage_ms[k], 4), "alg_bytes_per_frame": int(alg[k]),
                              "achieved_GBs": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 2),
                              "frac": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in stage_ms}
+
+    # latency mode: one camera stream per launch (the drop-in B = 1 call pattern), same stages
+    fe1 = build_frontend(1)
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            fe1["step"]()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fe1["step"]()
+        ctx.sync()
+        lat_ms = (time.perf_counter() - t0) / 20 * 1e3
+    del fe1
 
     # ------------------------------------------------------------------ back-end (Schur) region
     P_, L_ = 50, 20000
@@ -298,6 +319,7 @@ def main():
             "frontend": {"stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                          "dense_passes_per_frame": passes, "corners_per_frame": n_corners, "matches_per_frame": n_matched,
                          "dense_track_pose_err": track_err,
+                         "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
             "roofline": roofline,
             "roofline_frontend": roofline_frontend,

@@ -221,12 +221,17 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
-  __shared__ double s_T[12], s_Tn[12], s_x[6];
-  __shared__ int s_flag[2];    // [0] accepted, [1] stop
+  __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27];
   const int slot = blockIdx.x;
   if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
   __syncthreads();
   int passes = 0;
+  // One fused pass per LM iteration.  The reference runs, per iteration, an H,b pass at T and a
+  // chi2 pass at T_new, and after an accepted step starts the next iteration with an H,b pass at
+  // that same T_new.  Evaluating chi2 AND H,b together at T_new therefore serves both (identical
+  // sums, one gather sweep instead of two).  A rejected step makes the reference repeat the same
+  // undamped solve at the unchanged T (mu is never applied, dense_tracking.cpp:332), reject again and
+  // stop (trial == 2, :379-384): that is "stop on the first rejection" here.
   for (int level = 2; level >= 0; --level) {
     LevelArgs L = A.lv[level];
     L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
@@ -234,52 +239,42 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<false>(L, T, s_part, s_out);
+    track_pass<true>(L, T, s_part, s_out);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     ++passes;
     float chi2 = (float)s_out[27];
-    int trial = 0;
+    if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
+    __syncthreads();
     bool stop = false;
     for (int it = 0; it < 15 && !stop; ++it) {
-      bool accepted = false;
-      do {
+      if (threadIdx.x == 0) {
+        double H[36], nb[6], x[6];
+        int k = 0;
+        for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { H[6 * r + c] = s_H[k]; H[6 * c + r] = s_H[k]; ++k; }
+        for (int q = 0; q < 6; ++q) nb[q] = -s_H[21 + q];
+        d_solve6(H, nb, x);                         // H.ldlt().solve(-Jres): undamped (dense_tracking.cpp:332)
+        double Tn[12];
+        d_se3_exp_mul(x, s_T, Tn);
+        for (int i = 0; i < 12; ++i) s_Tn[i] = Tn[i];
+        for (int i = 0; i < 6; ++i) s_x[i] = x[i];
+      }
+      __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-        track_pass<true>(L, T, s_part, s_out);
-        ++passes;
-        if (threadIdx.x == 0) {
-          double H[36], nb[6], x[6];
-          int k = 0;
-          for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { H[6 * r + c] = s_out[k]; H[6 * c + r] = s_out[k]; ++k; }
-          for (int q = 0; q < 6; ++q) nb[q] = -s_out[21 + q];
-          d_solve6(H, nb, x);                       // H.ldlt().solve(-Jres): undamped (dense_tracking.cpp:332)
-          double Tn[12];
-          d_se3_exp_mul(x, s_T, Tn);
-          for (int i = 0; i < 12; ++i) s_Tn[i] = Tn[i];
-          for (int i = 0; i < 6; ++i) s_x[i] = x[i];
-        }
+      for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
+      track_pass<true>(L, T, s_part, s_out);        // new_chi2 (:335-367) + H,b for the next iteration
+      ++passes;
+      const float new_chi2 = (float)s_out[27];
+      const double rho = (double)chi2 - (double)new_chi2;
+      if (rho > 0) {
+        chi2 = new_chi2;
+        double mx = -1;
+        for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(s_x[q]));
+        stop = mx <= 1e-10;
+        if (threadIdx.x < 12) s_T[threadIdx.x] = s_Tn[threadIdx.x];
+        if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-        track_pass<false>(L, T, s_part, s_out);
-        ++passes;
-        const float new_chi2 = (float)s_out[27];
-        const double rho = (double)chi2 - (double)new_chi2;
-        if (rho > 0) {
-          accepted = true;
-          chi2 = new_chi2;
-          double mx = -1;
-          for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(s_x[q]));
-          stop = mx <= 1e-10;
-          trial = 0;
-          __syncthreads();
-          if (threadIdx.x < 12) s_T[threadIdx.x] = s_Tn[threadIdx.x];
-          __syncthreads();
-        } else {
-          accepted = false;
-          ++trial;
-          if (trial == 2) stop = true;
-        }
-      } while (!(accepted || stop));
+      } else {
+        stop = true;
+      }
     }
   }
   if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];

@@ -130,6 +130,20 @@ __global__ __launch_bounds__(256) void convert_sobel_kernel(const uint8_t *__res
   float c[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) c[k] = (float)row[reflect101(x4 - 1 + k, w)] * sc;
+  if (x4 + 3 < w && (fs & 3) == 0 && (fb & 3) == 0 && (((uintptr_t)img | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0) {
+    // full group of 4: three 16-byte stores per lane (1 KiB per wave-instruction)
+    float4 vi = make_float4(c[1], c[2], c[3], c[4]);
+    float4 vx = make_float4(c[2] - c[0], c[3] - c[1], c[4] - c[2], c[5] - c[3]);
+    float4 vy;
+    vy.x = (float)rowp[x4] * sc - (float)rowm[x4] * sc;
+    vy.y = (float)rowp[x4 + 1] * sc - (float)rowm[x4 + 1] * sc;
+    vy.z = (float)rowp[x4 + 2] * sc - (float)rowm[x4 + 2] * sc;
+    vy.w = (float)rowp[x4 + 3] * sc - (float)rowm[x4 + 3] * sc;
+    *reinterpret_cast<float4 *>(img + fo + x4) = vi;
+    *reinterpret_cast<float4 *>(dx + fo + x4) = vx;
+    *reinterpret_cast<float4 *>(dy + fo + x4) = vy;
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int x = x4 + k;

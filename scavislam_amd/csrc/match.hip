@@ -57,19 +57,22 @@ __device__ __forceinline__ void d_warp_f(const double *T, double depth, const sv
   o[1] = cam.f * (q[1] / q[2]) + cam.cy;
 }
 // DFS-order key of QuadTree::query (quadtree.h:510-544,693-708): recursive halving of the level
-// box with the reference's own double arithmetic; x-quadrant bit above y-quadrant bit.
-__device__ __forceinline__ unsigned quad_key(double px, double py, double W, double H) {
-  double bx = 0, by = 0, bw = W, bh = H;
+// box, x-quadrant bit above y-quadrant bit.  The reference decides a quadrant with
+// rel = 1 - (x0 + w - p)/w < 0.5 in doubles; for integer p and box sizes W/2^d that test is exactly
+// p < x0 + w/2 (all quantities are dyadic, the quotient is never within an ulp of 1/2), so the key
+// is computed in 2^-12 fixed point with integer compares (tests/test_oracle_cpu.py checks the order
+// against the real tree).
+__device__ __forceinline__ unsigned quad_key(int px, int py, int W, int H) {
+  int bx = 0, by = 0, bw = W << 12, bh = H << 12;
+  const int X = px << 12, Y = py << 12;
   unsigned key = 0;
-#pragma unroll 1
+#pragma unroll
   for (int d = 0; d < 12; ++d) {
-    double rel_x = 1 - (bx + bw - px) / bw;
-    double rel_y = 1 - (by + bh - py) / bh;
-    unsigned hx = !(rel_x < 0.5), hy = !(rel_y < 0.5);
+    bw >>= 1; bh >>= 1;
+    const unsigned hx = X >= bx + bw, hy = Y >= by + bh;
     key = (key << 2) | (hx << 1) | hy;
-    if (hx) bx = bx + bw * 0.5;
-    if (hy) by = by + bh * 0.5;
-    bw = bw * 0.5; bh = bh * 0.5;
+    bx += hx ? bw : 0;
+    by += hy ? bh : 0;
   }
   return key;
 }
@@ -77,12 +80,32 @@ __device__ __forceinline__ unsigned quad_key(double px, double py, double W, dou
 struct MatchParams {
   svs_match_args a;
   FastView fv;
+  const double *kf_T;     // [n_batch][n_kf][24]: T_cur_from_anchor, T_actkey_from_anchor (match_pose_kernel)
 };
+
+// The two relative poses a candidate needs depend only on (camera stream, anchor keyframe), not on
+// the point: T_cur_from_anchor = T_cur_from_w * T_anchor_from_w^-1 (matcher.cpp:113) and
+// (T_anchor_from_w * T_w_from_actkey)^-1 (matcher.cpp:393-394).  One lane per pair, same operation
+// order as the per-point formulation => bit-identical values, ~250 f64 ops less per wavefront.
+__global__ void match_pose_kernel(svs_match_args A, double *__restrict__ out) {
+  const int kf = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
+  if (kf >= A.n_kf) return;
+  double kfT[12], Tcw[12], Twk[12], t0[12], t1[12];
+  for (int i = 0; i < 12; ++i) { kfT[i] = A.d_kfs[kf].T_anchor_from_w[i]; Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
+  d_pose_inv(kfT, t0);
+  d_pose_mul(Tcw, t0, t1);
+  double *o = out + ((size_t)slot * A.n_kf + kf) * 24;
+  for (int i = 0; i < 12; ++i) o[i] = t1[i];
+  d_pose_mul(kfT, Twk, t0);
+  d_pose_inv(t0, t1);
+  for (int i = 0; i < 12; ++i) o[12 + i] = t1[i];
+}
 
 constexpr int WAVES_PER_BLOCK = 4;
 
 __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_result *__restrict__ out) {
   __shared__ uint8_t s_patch[WAVES_PER_BLOCK][104];
+  __shared__ int s_cand[WAVES_PER_BLOCK][64][2];   // per-wave list of the window chunk's hits: packed (x,y), key
   const svs_match_args &A = M.a;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ip = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -105,14 +128,10 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
     const int lvl = __builtin_amdgcn_readfirstlane(ap.anchor_level);
     const svs_keyframe *kfp = A.d_kfs + kfi;
     const svs_cam cam = A.cam_vec[lvl];
-    double kfT[12];
+    double T_cur_from_anchor[12], xyz_cur[3];
+    const double *kfT = M.kf_T + ((size_t)slot * A.n_kf + kfi) * 24;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) kfT[i] = kfp->T_anchor_from_w[i];
-    double Tcw[12], Twk[12], T_w_from_anchor[12], T_cur_from_anchor[12], xyz_cur[3];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
-    d_pose_inv(kfT, T_w_from_anchor);
-    d_pose_mul(Tcw, T_w_from_anchor, T_cur_from_anchor);
+    for (int i = 0; i < 12; ++i) T_cur_from_anchor[i] = kfT[i];
     d_pose_act(T_cur_from_anchor, ap.xyz_anchor, xyz_cur);
     const double uv0 = cam.f * (xyz_cur[0] / xyz_cur[2]) + cam.cx;
     const double uv1 = cam.f * (xyz_cur[1] / xyz_cur[2]) + cam.cy;
@@ -166,39 +185,73 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
         const uint8_t *cimg = A.d_cur_pyr[lvl] + (size_t)slot * A.cur_bstride[lvl];
         const int cstride = A.cur_stride[lvl];
         const int side = 2 * R + 1, npos = side * side;
-        unsigned bestkey = 0xffffffffu;
+        const float inv_side = 1.0f / (float)side;
+        // 16 lanes per candidate (lane = patch row x half-row, 4 pixels each): four candidates are
+        // scored per trip, sums reduced inside the 16-lane group
+        const int sub = lane & 15, grp = lane >> 4, prow = sub >> 1, phalf = sub & 1;
+        int k4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k4[j] = s_patch[wave][(prow + 1) * 10 + phalf * 4 + j + 1];
+        int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-group running best
+        unsigned gkey = 0xffffffffu;
         for (int p0 = 0; p0 < npos; p0 += 64) {
           const int pos = p0 + lane;
           int cx = 0, cy = 0;
           bool hit = false;
           if (pos < npos) {
-            const int wy = pos / side, wx = pos - wy * side;
+            const int wy = (int)(((float)pos + 0.5f) * inv_side), wx = pos - wy * side;   // exact for pos < 2^12
             cx = ui - R + wx; cy = vi - R + wy;
             if (cx >= 0 && cy >= 0 && cx < gx * cw && cy < gy * chh && d_in_frame(cam, cx, cy, 6)) {
-              const int cell = (cy / chh) * gx + cx / cw;
+              int cellx = 0, celly = 0;                   // grids are at most a few cells wide: compares beat divides
+              for (int q = 1; q < gx; ++q) cellx += cx >= q * cw;
+              for (int q = 1; q < gy; ++q) celly += cy >= q * chh;
+              const int cell = celly * gx + cellx;
               const int thr1 = min(max(emit[cell], 0), 255) + 1;
               hit = score[(size_t)cy * sstride + cx] >= thr1;
             }
           }
-          unsigned key = hit ? quad_key((double)cx, (double)cy, (double)cam.w, (double)cam.h) : 0u;
-          unsigned long long m = __ballot(hit);
-          while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int hx = __shfl(cx, src, 64), hy = __shfl(cy, src, 64);
-            const unsigned hk = __shfl(key, src, 64);
-            const int b = cimg[(size_t)(hy - 4 + pr) * cstride + (hx - 4 + pc)];
-            const int sumB = wave_sum_i32(b), sumBB = wave_sum_i32(b * b), sumAB = wave_sum_i32(b * keyv);
-            const int z = sumAA - 2 * sumAB - sumBB - (sumA * sumA - 2 * sumA * sumB - sumB * sumB) / 64;
-            // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, key)
-            if (z < best || (bestkey != 0xffffffffu && z == best && hk < bestkey)) {
-              best = z; bestkey = hk; bu = hx; bv = hy;
-            }
+          const unsigned long long m = __ballot(hit);
+          const int nhit = __popcll(m);
+          if (nhit == 0) continue;                                   // wave-uniform
+          if (hit) {
+            const int r = __popcll(m & ((1ull << lane) - 1ull));
+            s_cand[wave][r][0] = (cy << 16) | cx;
+            s_cand[wave][r][1] = (int)quad_key(cx, cy, cam.w, cam.h);
           }
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          for (int t = 0; t < nhit; t += 4) {
+            const int ci = t + grp;
+            const bool valid = ci < nhit;
+            const int packed = s_cand[wave][valid ? ci : 0][0];
+            const unsigned hk = (unsigned)s_cand[wave][valid ? ci : 0][1];
+            const int hx = packed & 0xffff, hy = packed >> 16;
+            const uint8_t *p = cimg + (size_t)(hy - 4 + prow) * cstride + (hx - 4 + phalf * 4);
+            uint32_t v4;
+            __builtin_memcpy(&v4, p, 4);                             // 4 consecutive pixels of the patch row
+            int sB = 0, sBB = 0, sAB = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int bj = (v4 >> (8 * j)) & 0xff; sB += bj; sBB += bj * bj; sAB += bj * k4[j]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { sB += __shfl_xor(sB, o, 64); sBB += __shfl_xor(sBB, o, 64); sAB += __shfl_xor(sAB, o, 64); }
+            const int z = sumAA - 2 * sAB - sBB - (sumA * sumA - 2 * sumA * sB - sB * sB) / 64;
+            // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, key); z must also beat thr_mean
+            if (valid && z < init_dist && (z < gbest || (z == gbest && hk < gkey))) { gbest = z; gkey = hk; gx_ = hx; gy_ = hy; }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        double T_anchor_from_actkey[12], T_actkey_from_anchor[12];
-        d_pose_mul(kfT, Twk, T_anchor_from_actkey);
-        d_pose_inv(T_anchor_from_actkey, T_actkey_from_anchor);
+        // lexicographic min across the four groups
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const int oz = __shfl_xor(gbest, o, 64), ox = __shfl_xor(gx_, o, 64), oy = __shfl_xor(gy_, o, 64);
+          const unsigned ok = __shfl_xor(gkey, o, 64);
+          if (oz < gbest || (oz == gbest && ok < gkey)) { gbest = oz; gkey = ok; gx_ = ox; gy_ = oy; }
+        }
+        unsigned bestkey = gkey;
+        if (bestkey != 0xffffffffu) { best = gbest; bu = gx_; bv = gy_; }
+        double T_actkey_from_anchor[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T_actkey_from_anchor[i] = kfT[12 + i];
         d_pose_act(T_actkey_from_anchor, ap.xyz_anchor, xyz_actkey);
         if (bestkey == 0xffffffffu) { status = SVS_MATCH_NONE; best = init_dist; }
         else {
@@ -232,7 +285,20 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   MatchParams M;
   M.a = *a;
   M.fv = svs_fast_view_internal(f);
-  SVS_REQUIRE(ctx, M.fv.n_levels >= 1);
+  SVS_REQUIRE(ctx, M.fv.n_levels >= 1 && a->n_kf >= 1);
+  // per-ctx scratch for the (stream, keyframe) relative poses (one ctx per calling thread)
+  static thread_local svs_ctx *owner = nullptr;
+  static thread_local double *kf_T = nullptr;
+  static thread_local size_t kf_T_n = 0;
+  const size_t need = (size_t)a->n_batch * a->n_kf * 24;
+  if (owner != ctx || kf_T_n < need) {
+    if (kf_T) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(kf_T); kf_T = nullptr; kf_T_n = 0; }
+    SVS_HIP(ctx, hipMalloc(&kf_T, need * sizeof(double)));
+    kf_T_n = need; owner = ctx;
+  }
+  M.kf_T = kf_T;
+  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, *a, kf_T);
+  SVS_LAUNCH_CHECK(ctx);
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
   hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
   SVS_LAUNCH_CHECK(ctx);
