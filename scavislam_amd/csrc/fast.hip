@@ -45,7 +45,7 @@ struct ImgPtrs {
 };
 struct TileDesc { int16_t level, cell, x0, y0; };   // cell = index within the level
 
-constexpr int TW = 64, TH = 16, HALO = 3;
+constexpr int TW = 64, TH = 32, HALO = 3;   // tile 64x32: two 16-row passes per lane amortise the per-block load/sync latency
 
 // ring offsets, SURVEY.md A.1 (index 0..15)
 __device__ __constant__ int8_t c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -67,9 +67,19 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
   return best;
 }
 
+// K1.  Each lane scores 4 horizontally adjacent pixels: the 7 x 12-byte neighbourhood it needs is read
+// from LDS as 21 dwords (instead of ~20-36 byte reads per pixel) and ring pixels are picked with
+// compile-time byte extracts; the tile itself is staged with (unaligned) dword loads and the four
+// scores leave as one dword store.  LDS row = 72 bytes: [4 left halo | 64 tile | 4 right halo].
+constexpr int LROW = 19;   // dwords per LDS row (18 used + 1 pad)
+__device__ __forceinline__ int byte_of(const uint32_t (&w)[3], int b) { return (w[b >> 2] >> (8 * (b & 3))) & 0xff; }
+
 __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
-  __shared__ uint8_t s_img[TH + 2 * HALO][TW + 2 * HALO + 2];
+  __shared__ uint32_t s_img[(TH + 2 * HALO) * LROW];
   __shared__ unsigned s_hist[256];
+  __shared__ uint32_t s_sc[TH * 16];      // scores of the tile, one dword per 4 pixels
+  __shared__ uint16_t s_list[TW * TH];    // queued corners (tile-local y<<8 | x)
+  __shared__ int s_ncorn;
   const TileDesc td = tiles[blockIdx.x];
   const int slot = blockIdx.y;
   const LevelDev &L = P.lv[td.level];
@@ -79,49 +89,95 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I
   const uint8_t *img = I.img[td.level] + (size_t)slot * I.bstride[td.level];
   const int istride = I.stride[td.level];
   s_hist[tid] = 0;
-  // stage tile + 3 px halo; coordinates clamped to the cell ROI (halo outside the ROI is never
-  // used: only ROI-interior pixels are scored, and their ring stays inside the ROI)
-  const int tx0 = u0 + td.x0 - HALO, ty0 = v0 + td.y0 - HALO;
-  for (int i = tid; i < (TH + 2 * HALO) * (TW + 2 * HALO); i += 256) {
-    int r = i / (TW + 2 * HALO), c = i - r * (TW + 2 * HALO);
-    int y = min(max(ty0 + r, v0), v0 + L.cell_h - 1), x = min(max(tx0 + c, u0), u0 + L.cell_w - 1);
-    s_img[r][c] = img[(size_t)y * istride + x];
-  }
-  __syncthreads();
-  const int lx = tid & 63, ly0 = tid >> 6;
-  uint8_t *score = L.score + (size_t)slot * L.score_bstride;
-#pragma unroll 1
-  for (int k = 0; k < 4; ++k) {
-    const int ly = ly0 + 4 * k;
-    const int cx = td.x0 + lx, cy = td.y0 + ly;            // cell-local coords
-    if (cx >= L.cell_w || cy >= L.cell_h) continue;
-    int s8 = 0;
-    const bool interior = cx >= 3 && cy >= 3 && cx < L.cell_w - 3 && cy < L.cell_h - 3;
-    if (interior) {
-      const int v = s_img[ly + HALO][lx + HALO];
-      const int t = P.t_lo;
-      // compass pre-test: any 9-arc contains >= 2 of ring pixels {0,4,8,12}
-      int r0 = s_img[ly + HALO + 3][lx + HALO], r4 = s_img[ly + HALO][lx + HALO + 3];
-      int r8 = s_img[ly + HALO - 3][lx + HALO], r12 = s_img[ly + HALO][lx + HALO - 3];
-      int nd = (v - r0 > t) + (v - r4 > t) + (v - r8 > t) + (v - r12 > t);
-      int nb = (r0 - v > t) + (r4 - v > t) + (r8 - v > t) + (r12 - v > t);
-      if (nd >= 2 || nb >= 2) {
-        int d[16], e[16];
+  // stage the tile: rows v0+y0-3 .. +18, bytes u0+x0-4 .. +67.  Anything outside the image is
+  // clamped (never used: only ROI-interior pixels are scored and their ring stays inside the ROI)
+  const int gx0 = u0 + td.x0 - 4, gy0 = v0 + td.y0 - HALO;
+  for (int i = tid; i < (TH + 2 * HALO) * 18; i += 256) {
+    const int r = i / 18, c = i - r * 18;
+    const int y = min(max(gy0 + r, 0), L.h - 1), x = gx0 + 4 * c;
+    const uint8_t *row = img + (size_t)y * istride;
+    uint32_t v;
+    if (x >= 0 && x + 3 < L.w) __builtin_memcpy(&v, row + x, 4);
+    else {
+      v = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          int r = s_img[ly + HALO + c_ring_dy[q]][lx + HALO + c_ring_dx[q]];
-          d[q] = v - r;
-          e[q] = r - v;
-        }
-        int sc = max(arc9_maxmin(d), arc9_maxmin(e)) - 1;   // corner at t <=> sc >= t
-        if (sc >= t) s8 = min(sc + 1, 255);
-      }
+      for (int q = 0; q < 4; ++q) v |= (uint32_t)row[min(max(x + q, 0), L.w - 1)] << (8 * q);
     }
-    score[(size_t)(v0 + cy) * L.score_stride + (u0 + cx)] = (uint8_t)s8;
-    if (s8) atomicAdd(&s_hist[s8], 1u);
+    s_img[r * LROW + c] = v;
   }
   __syncthreads();
-  unsigned c = s_hist[tid];
+  const int tx = tid & 15;
+  const int cx0 = td.x0 + 4 * tx;                            // cell-local x of the lane's 4 pixels
+  // ---- phase A: boolean segment test at t_lo for all pixels (bit masks + shift-AND run detection);
+  //      the few pixels that pass are queued in LDS.  Computing the full score in place would make
+  //      (nearly) every wavefront walk the expensive path because some lane always has a corner.
+  for (int i = tid; i < TH * 16; i += 256) s_sc[i] = 0;
+  if (tid == 0) s_ncorn = 0;
+  __syncthreads();
+  const int t = P.t_lo;
+  constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#pragma unroll 1
+  for (int ty = tid >> 4; ty < TH; ty += 16) {
+    const int cy = td.y0 + ty;
+    uint32_t win[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) win[r][c] = s_img[(ty + r) * LROW + tx + c];
+    const bool row_ok = cy >= 3 && cy < L.cell_h - 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cx = cx0 + k;
+      const int v = byte_of(win[3], 4 + k);
+      unsigned dm = 0, bm = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int r = byte_of(win[3 + RDY[q]], 4 + k + RDX[q]);
+        dm |= (unsigned)(v - r > t) << q;
+        bm |= (unsigned)(r - v > t) << q;
+      }
+      dm |= dm << 16; bm |= bm << 16;
+      unsigned a = dm & (dm >> 1), c = bm & (bm >> 1);
+      a &= a >> 2; c &= c >> 2;
+      a &= a >> 4; c &= c >> 4;                             // 8 consecutive ring pixels
+      a &= dm >> 8; c &= bm >> 8;                           // 9 consecutive
+      const bool corner = row_ok && cx >= 3 && cx < L.cell_w - 3 && (((a | c) & 0xffffu) != 0);
+      if (corner) { const int slot_i = atomicAdd(&s_ncorn, 1); s_list[slot_i] = (uint16_t)((ty << 8) | (4 * tx + k)); }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: FAST score (max t) only for the queued corners
+  const int ncorn = s_ncorn;
+  const uint8_t *s_b8 = reinterpret_cast<const uint8_t *>(s_img);
+  for (int i = tid; i < ncorn; i += 256) {
+    const int code = s_list[i], py = code >> 8, px = code & 0xff;           // tile-local pixel
+    const int cb = (py + 3) * (LROW * 4) + px + 4;
+    const int v = s_b8[cb];
+    int d[16], e[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = s_b8[cb + RDY[q] * (LROW * 4) + RDX[q]];
+      d[q] = v - r;
+      e[q] = r - v;
+    }
+    const int sc = max(arc9_maxmin(d), arc9_maxmin(e)) - 1;                 // corner at t <=> sc >= t
+    const int s8 = min(sc + 1, 255);
+    reinterpret_cast<uint8_t *>(s_sc)[py * 64 + px] = (uint8_t)s8;
+    atomicAdd(&s_hist[s8], 1u);
+  }
+  __syncthreads();
+  for (int ty = tid >> 4; ty < TH; ty += 16) {
+    const int cy = td.y0 + ty;
+    if (cy < L.cell_h && cx0 < L.cell_w) {
+      const uint32_t packed = s_sc[ty * 16 + tx];          // dword of this lane's 4 pixels
+      uint8_t *dst = L.score + (size_t)slot * L.score_bstride + (size_t)(v0 + cy) * L.score_stride + (u0 + cx0);
+      if (cx0 + 3 < L.cell_w) __builtin_memcpy(dst, &packed, 4);
+      else
+        for (int k = 0; k < 4 && cx0 + k < L.cell_w; ++k) dst[k] = (uint8_t)(packed >> (8 * k));
+    }
+  }
+  const unsigned c = s_hist[tid];
   if (c) atomicAdd(&P.hist[((size_t)slot * P.ncell_total + L.cell_base + td.cell) * 256 + tid], c);
 }
 
@@ -195,7 +251,7 @@ __global__ __launch_bounds__(256) void fast_adapt_kernel(FastParams P, int trial
 
 // K3: ordered compaction of one cell.  Sweep 1 counts per ROI row (one wave per row), an LDS scan
 // turns counts into offsets, sweep 2 writes (x,y) with a ballot prefix.
-__global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
+__global__ __launch_bounds__(256) void fast_compact_2sweep_kernel(FastParams P) {
   __shared__ int s_row[1024];
   const int slot = blockIdx.y;
   int c = blockIdx.x, lvl = 0;
@@ -250,6 +306,95 @@ __global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
         }
         o += __popcll(m);
       }
+    }
+  }
+}
+
+// K3 (default).  One global sweep: a wave reads one ROI row per load (4 score bytes per lane, unaligned
+// dword), turns it into four 64-bit ballots (bit = lane, one ballot per byte position) kept in LDS
+// with the row count; after the row scan the corners are emitted from the LDS masks alone.
+// Order inside a row: x = 4*lane + j  =>  rank = sum_j popc(ballot_j & lanes_below) + popc(own bits < j).
+constexpr int CMP_MAXROWS = 1024;
+__global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
+  extern __shared__ unsigned long long s_mask[];      // [rows][chunks][4]
+  __shared__ int s_row[CMP_MAXROWS];
+  const int slot = blockIdx.y;
+  int c = blockIdx.x, lvl = 0;
+  while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
+  const LevelDev &L = P.lv[lvl];
+  const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
+  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
+  const int base = P.offset[(size_t)slot * P.ncell_total + c];
+  const uint8_t *score = L.score + (size_t)slot * L.score_bstride;
+  const int rows = L.cell_h - 6, cols = L.cell_w - 6;    // ROI interior
+  if (rows <= 0 || cols <= 0 || thr1 > 255) return;
+  const int chunks = (cols + 255) / 256;
+  // 8 rows in flight per wave: the loads of a batch are issued back to back, so the sweep pays one
+  // global round trip per 8 rows instead of one per row
+  constexpr int RB = 8;
+  for (int r0 = wave * RB; r0 < rows; r0 += 4 * RB) {
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int x = ch * 256 + 4 * lane;
+      uint32_t v[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = r0 + i;
+        v[i] = 0;
+        if (r < rows) {
+          const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
+          if (x + 3 < cols) __builtin_memcpy(&v[i], p + x, 4);
+          else
+            for (int j = 0; j < 4; ++j) if (x + j < cols) v[i] |= (uint32_t)p[x + j] << (8 * j);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = r0 + i;
+        if (r >= rows) break;                              // wave-uniform
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned long long bb = __ballot((int)((v[i] >> (8 * j)) & 0xff) >= thr1);
+          n += __popcll(bb);
+          if (lane == 0) s_mask[((size_t)r * chunks + ch) * 4 + j] = bb;
+        }
+        if (lane == 0) s_row[r] = (ch == 0 ? 0 : s_row[r]) + n;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {                                       // exclusive scan of the row counts
+    int v[16], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; v[k] = idx < rows ? s_row[idx] : 0; tot += v[k]; }
+    int run = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int dn = __shfl_up(run, o, 64); if (lane >= o) run += dn; }
+    int excl = run - tot;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; if (idx < rows) s_row[idx] = excl; excl += v[k]; }
+  }
+  __syncthreads();
+  int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = wave; r < rows; r += 4) {
+    int o = base + s_row[r];
+    const int y = v0 + 3 + r;
+    for (int ch = 0; ch < chunks; ++ch) {
+      unsigned long long b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = s_mask[((size_t)r * chunks + ch) * 4 + j];
+      int pos = o + __popcll(b[0] & below) + __popcll(b[1] & below) + __popcll(b[2] & below) + __popcll(b[3] & below);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if ((b[j] >> lane) & 1ull) {
+          if (pos < P.cap) { xy[2 * pos] = (int16_t)(u0 + 3 + ch * 256 + 4 * lane + j); xy[2 * pos + 1] = (int16_t)y; }
+          ++pos;
+        }
+      }
+      o += __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
     }
   }
 }
@@ -342,7 +487,16 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(fast_adapt_kernel, dim3(n_batch), dim3(256), (size_t)f->P.ncell_total * 256 * sizeof(int), ctx->stream, f->P, trials);
   SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(fast_compact_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P);
+  // LDS need of the mask version: rows x chunks x 4 ballots of the largest cell
+  size_t mask_bytes = 0;
+  for (int l = 0; l < f->P.n_levels; ++l) {
+    const LevelDev &L = f->P.lv[l];
+    mask_bytes = std::max(mask_bytes, (size_t)std::max(L.cell_h - 6, 0) * (size_t)((std::max(L.cell_w - 6, 1) + 255) / 256) * 32);
+  }
+  if (mask_bytes <= 56 * 1024)
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P);
+  else
+    hipLaunchKernelGGL(fast_compact_2sweep_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
