@@ -255,7 +255,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": "ba_landmark_kernel<0> (linearise + 3x3 inverse + Schur outer products)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 5),
-                "alg_bytes_per_launch": int(alg_schur), "avg_launch_ms": round(red_ms, 5), "traffic": None}
+                "alg_bytes_per_launch": int(alg_schur), "avg_launch_ms": round(red_ms, 5),
+                # HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the
+                # gfx950 note in MI355X_MICROARCH.md), measured on this kernel at this size in profiles/r1_summary.md;
+                # it cannot be collected inside this process, so it is only reported for the profiled configuration
+                "traffic": 12792900 if (world == 1 and E_local == 99587) else None,
+                "traffic_source": "profiles/r1_summary.md section 3 (2*FETCH_SIZE + WRITE_SIZE)"}
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
     cpu = None
