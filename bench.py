@@ -3,8 +3,8 @@
 
 One JSON line on rank 0.  Two timed regions per run, each K steps, barrier + synchronize on both
 sides, max over ranks:
-  A. front-end: a step = one pass of the per-frame hot path (pyramid, f32+Sobel, device-resident
-     dense tracking, dense point cloud, grid FAST, guided ZNSSD matching of 2000 candidate points)
+  A. front-end: a step = one pass of the per-frame hot path (pyramid, device-resident dense tracking
+     with the f32 conversion + Sobel taps of preprocessing fused into its gathers, dense point cloud, grid FAST, guided ZNSSD matching of 2000 candidate points)
      over a batch of B independent 640x480 camera streams, inputs resident in HBM.
      value = N * B * K / time  [frames/s]   (weak scaling: front-end frames are replicas)
   B. back-end: a step = one SlamGraph::optimize (2 LM iterations) of a 50-keyframe / 20k-landmark
@@ -101,7 +101,7 @@ def main():
         dtrack = DenseTracker(ctx, cur)
         dprev = DenseTracker(ctx, prev)
         dprev.computeDensePointCloudCpu(I34)          # reference cloud of the previous frame
-        track_args = dtrack.track_args(prev.pyr)
+        track_args = dtrack.track_args(prev.pyr, from_u8=True)    # fused: f32 image + Sobel taps formed from the u8 pyramid
         for l in range(3):
             track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
         rng = np.random.default_rng(2011)
@@ -116,7 +116,7 @@ def main():
             d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
 
         def frontend_step():
-            cur.preprocessing()                                        # "preprocess"
+            cur.preprocessing(with_float=False)                        # "preprocess" (f32/Sobel fused into the tracker)
             dtrack.d_T.copy_(d_T0)
             dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)   # "dense tracking"
             fast.detectAdaptively(trials=6)                            # "fast"
@@ -193,10 +193,10 @@ def main():
     # algorithmic bytes per frame, SURVEY.md 8d table
     alg = {
         "pyramid": cur.w[0] * cur.h[0] + cur.w[1] * cur.h[1] + cur.w[2] * cur.h[2],
-        "convert_sobel": px * 13,
+        "convert_sobel": px * 13,      # stand-alone kernel, timed for reference; NOT part of the fused step
         "fast": px + 4 * n_corners + 22 * 4,
         "match": args.points * (60 + 121 + 20) + args.points * 10 * 64,
-        "dense_tracking": passes * (px // 16) * 32 // 3,     # passes are spread over 3 levels
+        "dense_tracking": passes * (px // 16) * (16 + 1 + 16) // 3,     # cloud float4 + prev u8 + 4x4 u8 taps; passes spread over 3 levels
         "pointcloud": (px // 16) * 20,
     }
     roofline_frontend = {k: {"ms": round(stage_ms[k], 4), "alg_bytes_per_frame": int(alg[k]),
@@ -309,8 +309,8 @@ def main():
             "ms_per_step": round(t_front / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (FAST, ZNSSD), f32+f64 (dense tracking), f64 (Schur)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]+[3]: per-frame front-end on 640x480 stereo frames (pyramid, f32+Sobel, dense "
-                                   "tracking, grid-FAST, ZNSSD match, dense cloud; disparity given) and DWO inner-window "
+            "config": {"workload": "configs[1]+[3]: per-frame front-end on 640x480 stereo frames (pyramid, dense tracking with fused f32+Sobel, "
+                                   " grid-FAST, ZNSSD match, dense cloud; disparity given) and DWO inner-window "
                                    "Schur solve 50 KF / 20k landmarks",
                        "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": args.points,
                        "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system"},

@@ -188,6 +188,10 @@ typedef struct {
   const float *d_cur[3]; const float *d_dx[3]; const float *d_dy[3];
   int32_t fstride[3]; size_t f_bstride[3];
   svs_cam cam_vec[3];
+  /* optional fused source: current u8 pyramid.  If d_cur_u8[0] != NULL the f32 image and its Sobel
+     taps are formed on the fly from it (bit-identical values, ~1/8 of the HBM traffic) and
+     d_cur/d_dx/d_dy are ignored, i.e. the convertTo/Sobel part of preprocessing can be skipped. */
+  const uint8_t *d_cur_u8[3]; int32_t c8stride[3]; size_t c8_bstride[3];
 } svs_dense_track_args;
 int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io,
                             int32_t *d_passes_out, int batch);

@@ -25,7 +25,8 @@ class DenseTrackArgs(C.Structure):
     _fields_ = [("d_cloud", C.c_void_p * 3), ("cloud_bstride", C.c_size_t * 3),
                 ("d_prev_u8", C.c_void_p * 3), ("pstride", C.c_int32 * 3), ("p_bstride", C.c_size_t * 3),
                 ("d_cur", C.c_void_p * 3), ("d_dx", C.c_void_p * 3), ("d_dy", C.c_void_p * 3),
-                ("fstride", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3), ("cam_vec", Cam * 3)]
+                ("fstride", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3), ("cam_vec", Cam * 3),
+                ("d_cur_u8", C.c_void_p * 3), ("c8stride", C.c_int32 * 3), ("c8_bstride", C.c_size_t * 3)]
 
 
 class MatchArgs(C.Structure):

@@ -43,13 +43,40 @@ struct LevelArgs {
   const float *cloud; const uint8_t *prev; const float *cur, *dx, *dy;
   int pstride, fstride;
   svs_cam cam;
+  const uint8_t *cur8;   // optional: current u8 level image; f32 image and Sobel taps are then formed on the fly
+  int c8stride;
 };
+
+// Bilinear taps of I, dx, dy straight from the u8 level image.  (float)u8 * float(1/255.) and the
+// centred differences are exactly the values frame_grabber.cpp:315-333 would have materialised, so
+// the results are bit-identical to reading the f32 pyramids -- at 1/8 of the HBM traffic (the f32
+// path touches ~half of three 4 B/px images per pass for a 1/16 sampling grid).  In-frame samples
+// (border 2) never need the REFLECT_101 border rule.
+__device__ __forceinline__ void taps_u8(const uint8_t *__restrict__ img, int stride, float u, float v, float &ic, float &gx, float &gy) {
+  const float sc = (float)(1. / 255.);
+  const float x = floorf(u), y = floorf(v);
+  const float sx = u - x, sy = v - y;
+  const float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+  const int xi = (int)x, yi = (int)y;
+  float f[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint32_t w4;
+    __builtin_memcpy(&w4, img + (size_t)(yi - 1 + r) * stride + (xi - 1), 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f[r][c] = (float)((w4 >> (8 * c)) & 0xff) * sc;
+  }
+  const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;   // v00=(x,y) v01=(x,y+1) v10=(x+1,y) v11
+  ic = w00 * f[1][1] + w01 * f[2][1] + w10 * f[1][2] + w11 * f[2][2];
+  gx = w00 * (f[1][2] - f[1][0]) + w01 * (f[2][2] - f[2][0]) + w10 * (f[1][3] - f[1][1]) + w11 * (f[2][3] - f[2][1]);
+  gy = w00 * (f[2][1] - f[0][1]) + w01 * (f[3][1] - f[1][1]) + w10 * (f[2][2] - f[0][2]) + w11 * (f[3][2] - f[1][2]);
+}
 
 // loop body of dense_tracking.cpp:229-261 (chi2) / :278-331 (H, b), one sample.
 // Branch-free (invalid samples are predicated to zero contributions and a safe address) so that the
 // unrolled caller can keep the cloud load and the 12 bilinear taps of several samples in flight:
 // the pass is bound by gather latency, not by bytes.
-template <bool JAC>
+template <bool JAC, bool U8SRC = false>
 __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, int u, int v, int cw, bool in_range, Acc &a) {
   const float4 c4 = in_range ? reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u] : make_float4(0.f, 0.f, 1.f, -1.f);
   bool ok = in_range && (c4.w > 0);
@@ -64,7 +91,9 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
   if (!ok) { uvx = 2.f; uvy = 2.f; }                       // safe tap position, contribution masked below
   const float ip = (float)((1. / 255.) * L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4]);
-  const float ic = interp32f(L.cur, L.fstride, uvx, uvy);
+  float ic, g8x = 0.f, g8y = 0.f;
+  if (U8SRC) taps_u8(L.cur8, L.c8stride, uvx, uvy, ic, g8x, g8y);
+  else ic = interp32f(L.cur, L.fstride, uvx, uvy);
   float res = ip - ic;
   if (res > 0.1) res = 0.1;
   if (res < -0.1) res = -0.1;
@@ -72,8 +101,8 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   a.v[27] += (double)(res * res);
   a.n += ok ? 1 : 0;
   if (JAC) {
-    const float gx = ok ? (float)(0.5 * interp32f(L.dx, L.fstride, uvx, uvy)) : 0.f;
-    const float gy = ok ? (float)(0.5 * interp32f(L.dy, L.fstride, uvx, uvy)) : 0.f;
+    const float gx = ok ? (float)(0.5 * (U8SRC ? g8x : interp32f(L.dx, L.fstride, uvx, uvy))) : 0.f;
+    const float gy = ok ? (float)(0.5 * (U8SRC ? g8y : interp32f(L.dy, L.fstride, uvx, uvy))) : 0.f;
     const double zs = ok ? z : 1.0, xs = ok ? x : 0.0, ys = ok ? y : 0.0;
     // transformations.h:117-139 frame_jac_xyz2uv.  One reciprocal instead of eight f64 divisions and
     // fused multiply-adds in the 27 accumulations: the pass is f64-issue bound on its CU, and H/b only
@@ -188,7 +217,7 @@ __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   
 
 struct TrackArgs {
   LevelArgs lv[3];
-  size_t cloud_b[3], prev_b[3], f_b[3];
+  size_t cloud_b[3], prev_b[3], f_b[3], c8_b[3];
 };
 
 #ifndef SVS_TRK_THREADS
@@ -200,7 +229,7 @@ struct TrackArgs {
 constexpr int TRK_THREADS = SVS_TRK_THREADS;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
-template <bool JAC>
+template <bool JAC, bool U8SRC>
 __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out) {
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
@@ -212,12 +241,13 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
       const int i = i0 + q * TRK_THREADS;
       const bool in_range = i < n;
       const int ii = in_range ? i : 0;
-      sample_cpu_sem<JAC>(L, T, ii % cw, ii / cw, cw, in_range, a);
+      sample_cpu_sem<JAC, U8SRC>(L, T, ii % cw, ii / cw, cw, in_range, a);
     }
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
 
+template <bool U8SRC>
 __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
@@ -235,11 +265,12 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
   for (int level = 2; level >= 0; --level) {
     LevelArgs L = A.lv[level];
     L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
-    L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level];
+    if (U8SRC) L.cur8 += slot * A.c8_b[level];
+    else { L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level]; }
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<true>(L, T, s_part, s_out);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    track_pass<true, U8SRC>(L, T, s_part, s_out);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     ++passes;
     float chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true>(L, T, s_part, s_out);        // new_chi2 (:335-367) + H,b for the next iteration
+      track_pass<true, U8SRC>(L, T, s_part, s_out);        // new_chi2 (:335-367) + H,b for the next iteration
       ++passes;
       const float new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
@@ -446,7 +477,7 @@ extern "C" int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t
   SVS_REQUIRE(ctx, ctx && d_cloud && d_prev_u8 && d_cur && cam && d_T && d_out && batch >= 1);
   SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
   SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);
-  LevelArgs L{d_cloud, d_prev_u8, d_cur, d_dx, d_dy, pstride, fstride, *cam};
+  LevelArgs L{d_cloud, d_prev_u8, d_cur, d_dx, d_dy, pstride, fstride, *cam, nullptr, 0};
   int n = (cam->w / 4) * (cam->h / 4);
   int nblocks = std::min(div_up(n, 256), 256);
   double *part = nullptr;
@@ -466,13 +497,17 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
                                        int batch) {
   SVS_REQUIRE(ctx, ctx && a && d_T_io && batch >= 1);
   TrackArgs A;
+  const bool u8src = a->d_cur_u8[0] != nullptr;
   for (int l = 0; l < 3; ++l) {
-    SVS_REQUIRE(ctx, a->d_cloud[l] && a->d_prev_u8[l] && a->d_cur[l] && a->d_dx[l] && a->d_dy[l]);
+    SVS_REQUIRE(ctx, a->d_cloud[l] && a->d_prev_u8[l]);
+    SVS_REQUIRE(ctx, u8src ? a->d_cur_u8[l] != nullptr : (a->d_cur[l] && a->d_dx[l] && a->d_dy[l]));
     SVS_REQUIRE(ctx, a->cam_vec[l].w % 4 == 0 && a->cam_vec[l].h % 4 == 0);
-    A.lv[l] = LevelArgs{a->d_cloud[l], a->d_prev_u8[l], a->d_cur[l], a->d_dx[l], a->d_dy[l], a->pstride[l], a->fstride[l], a->cam_vec[l]};
-    A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l];
+    A.lv[l] = LevelArgs{a->d_cloud[l], a->d_prev_u8[l], a->d_cur[l], a->d_dx[l], a->d_dy[l], a->pstride[l], a->fstride[l], a->cam_vec[l],
+                        a->d_cur_u8[l], a->c8stride[l]};
+    A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l]; A.c8_b[l] = a->c8_bstride[l];
   }
-  hipLaunchKernelGGL(dense_track_cpu_sem_kernel, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  if (u8src) hipLaunchKernelGGL(dense_track_cpu_sem_kernel<true>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  else hipLaunchKernelGGL(dense_track_cpu_sem_kernel<false>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -82,13 +82,15 @@ class FramePyramid:
                 d = torch.as_tensor(np.ascontiguousarray(disp, dtype=np.float32)).to(self.disp.device)
                 self.disp[:, :, :self.w[0]] = d.reshape(self.batch, self.h[0], self.w[0])
 
-    def preprocessing(self):
-        """FrameGrabber::preprocessing: cv::buildPyramid + (CPU path) convertTo/Sobel per level."""
+    def preprocessing(self, with_float=True):
+        """FrameGrabber::preprocessing: cv::buildPyramid + (CPU path) convertTo/Sobel per level.
+        with_float=False skips the f32/Sobel images (the dense tracker can form them on the fly
+        from the u8 pyramid, DenseTracker.track_args(from_u8=True))."""
         for l in range(1, NUM_PYR_LEVELS):
             self.ctx.call("svs_pyr_down_u8", self.pyr[l - 1].data_ptr(), self.w[l - 1], self.h[l - 1],
                           self.stride[l - 1], self.bstride(l - 1), self.pyr[l].data_ptr(), self.stride[l],
                           self.bstride(l), self.batch)
-        if self.f32 is not None:
+        if self.f32 is not None and with_float:
             for l in range(NUM_PYR_LEVELS):
                 self.ctx.call("svs_convert_sobel_f32", self.pyr[l].data_ptr(), self.w[l], self.h[l], self.stride[l],
                               self.bstride(l), self.f32[l].data_ptr(), self.dx[l].data_ptr(), self.dy[l].data_ptr(),
@@ -263,24 +265,28 @@ class DenseTracker:
         self.ctx.sync()
         return self.d_sums.cpu().numpy().view(DENSE_SUMS_DTYPE).copy()
 
-    def track_args(self, prev_pyr):
+    def track_args(self, prev_pyr, from_u8=False):
+        """from_u8=True: track straight from the current u8 pyramid (fused convert+Sobel taps)."""
         fr = self.frame
         a = capi.DenseTrackArgs()
         for l in range(NUM_PYR_LEVELS):
             a.d_cloud[l] = self.ref_dense_points[l].data_ptr()
             a.cloud_bstride[l] = (fr.h[l] // 4) * (fr.w[l] // 4) * 4
             a.d_prev_u8[l], a.pstride[l], a.p_bstride[l] = prev_pyr[l].data_ptr(), fr.stride[l], fr.bstride(l)
-            a.d_cur[l], a.d_dx[l], a.d_dy[l] = fr.f32[l].data_ptr(), fr.dx[l].data_ptr(), fr.dy[l].data_ptr()
+            if from_u8:
+                a.d_cur_u8[l], a.c8stride[l], a.c8_bstride[l] = fr.pyr[l].data_ptr(), fr.stride[l], fr.bstride(l)
+            else:
+                a.d_cur[l], a.d_dx[l], a.d_dy[l] = fr.f32[l].data_ptr(), fr.dx[l].data_ptr(), fr.dy[l].data_ptr()
             a.fstride[l], a.f_bstride[l] = fr.stride[l], fr.bstride(l)
             a.cam_vec[l] = fr.cams[l]
         return a
 
-    def denseTrackingCpu(self, prev_pyr, T_cur_from_actkey, args=None, download=True):
+    def denseTrackingCpu(self, prev_pyr, T_cur_from_actkey, args=None, download=True, from_u8=False):
         """DenseTracker::denseTrackingCpu(SE3*): in/out pose; whole LM loop in one launch."""
         fr = self.frame
         if T_cur_from_actkey is not None:
             self._set_T(T_cur_from_actkey)
-        a = args or self.track_args(prev_pyr)
+        a = args or self.track_args(prev_pyr, from_u8=from_u8)
         self.ctx.check(self.ctx.lib.svs_dense_track_cpu_sem(self.ctx.h, C.byref(a), self.d_T.data_ptr(),
                                                             self.d_passes.data_ptr(), fr.batch))
         if not download:

@@ -271,6 +271,10 @@ def test_dense_tracking_device_resident_lm(gpu_ctx, scene_frames):
     dtp.computeDensePointCloudCpu(I.reshape(12))
     dt.ref_dense_points = dtp.ref_dense_points
     T_gpu, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12))
+    # fused source: f32 image + Sobel taps formed on the fly from the u8 pyramid -- same values, same
+    # summation order => the tracked pose must be BIT-identical to the f32-pyramid path
+    T_u8, passes_u8 = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+    assert np.array_equal(T_u8, T_gpu) and np.array_equal(passes_u8, passes)
     clouds = [O.pointcloud_cpu(disp_p, prev.cams[l], l, I) for l in range(3)]
     pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
     fl = [O.convert_sobel(p) for p in pyr_c]
