@@ -73,6 +73,13 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
 // scores leave as one dword store.  LDS row = 72 bytes: [4 left halo | 64 tile | 4 right halo].
 constexpr int LROW = 19;   // dwords per LDS row (18 used + 1 pad)
 __device__ __forceinline__ int byte_of(const uint32_t (&w)[3], int b) { return (w[b >> 2] >> (8 * (b & 3))) & 0xff; }
+// bytes b and b+1 of the 12-byte row window, zero-extended into the two 16-bit halves (one v_perm_b32)
+__device__ __forceinline__ uint32_t pair_of(const uint32_t (&w)[3], int b) {
+  const int j = b >> 2, j1 = (j + 1 < 3) ? j + 1 : j;
+  const unsigned i0 = (unsigned)(b & 3);                                   // byte b lives in w[j]   (src1: selectors 0..3)
+  const unsigned i1 = ((b + 1) >> 2) == j ? (unsigned)((b + 1) & 3) : 4u + (unsigned)((b + 1) & 3);   // w[j+1] = src0: 4..7
+  return __builtin_amdgcn_perm(w[j1], w[j], i0 | (0x0cu << 8) | (i1 << 16) | (0x0cu << 24));
+}
 
 __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
   __shared__ uint32_t s_img[(TH + 2 * HALO) * LROW];
@@ -126,24 +133,34 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I
 #pragma unroll
       for (int c = 0; c < 3; ++c) win[r][c] = s_img[(ty + r) * LROW + tx + c];
     const bool row_ok = cy >= 3 && cy < L.cell_h - 3;
+    // SWAR: two horizontally adjacent pixels ride in the two 16-bit halves of a dword.
+    //   darker  <=> v - r > t <=> bit 15 of (v + 0x7fff - t) - r      (no carry/borrow between halves)
+    //   brighter<=> r - v > t <=> bit 15 of r + (0x7fff - t - v)
+    const uint32_t Kd = 0x7fff7fffu - (uint32_t)t * 0x00010001u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cx = cx0 + k;
-      const int v = byte_of(win[3], 4 + k);
-      unsigned dm = 0, bm = 0;
+    for (int p = 0; p < 2; ++p) {
+      const uint32_t vpair = pair_of(win[3], 4 + 2 * p);
+      const uint32_t Vd = vpair + Kd, Vb = Kd - vpair;
+      uint32_t dm = 0, bm = 0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int r = byte_of(win[3 + RDY[q]], 4 + k + RDX[q]);
-        dm |= (unsigned)(v - r > t) << q;
-        bm |= (unsigned)(r - v > t) << q;
+        const uint32_t rp = pair_of(win[3 + RDY[q]], 4 + 2 * p + RDX[q]);
+        const uint32_t X = Vd - rp, Y = rp + Vb;
+        dm = ((X >> (15 - q)) & (0x00010001u << q)) | dm;
+        bm = ((Y >> (15 - q)) & (0x00010001u << q)) | bm;
       }
-      dm |= dm << 16; bm |= bm << 16;
-      unsigned a = dm & (dm >> 1), c = bm & (bm >> 1);
-      a &= a >> 2; c &= c >> 2;
-      a &= a >> 4; c &= c >> 4;                             // 8 consecutive ring pixels
-      a &= dm >> 8; c &= bm >> 8;                           // 9 consecutive
-      const bool corner = row_ok && cx >= 3 && cx < L.cell_w - 3 && (((a | c) & 0xffffu) != 0);
-      if (corner) { const int slot_i = atomicAdd(&s_ncorn, 1); s_list[slot_i] = (uint16_t)((ty << 8) | (4 * tx + k)); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * p + h, cx = cx0 + k;
+        unsigned d16 = (dm >> (16 * h)) & 0xffffu, b16 = (bm >> (16 * h)) & 0xffffu;
+        d16 |= d16 << 16; b16 |= b16 << 16;
+        unsigned a = d16 & (d16 >> 1), c = b16 & (b16 >> 1);
+        a &= a >> 2; c &= c >> 2;
+        a &= a >> 4; c &= c >> 4;                           // 8 consecutive ring pixels
+        a &= d16 >> 8; c &= b16 >> 8;                       // 9 consecutive
+        const bool corner = row_ok && cx >= 3 && cx < L.cell_w - 3 && (((a | c) & 0xffffu) != 0);
+        if (corner) { const int slot_i = atomicAdd(&s_ncorn, 1); s_list[slot_i] = (uint16_t)((ty << 8) | (4 * tx + k)); }
+      }
     }
   }
   __syncthreads();

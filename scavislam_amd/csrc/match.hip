@@ -142,10 +142,17 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
     if (status == SVS_MATCH_OK) {
       const int ui = (int)uv0, vi = (int)uv1;
       // ---- warpAffinve: 10x10 patch, lanes take pixels lane and lane+64 -------------------
+      // f(uv), f(uv + e_x), f(uv + e_y) (matcher.cpp:411-413) evaluated once, in lanes 0/1/2 side by
+      // side (x + 0.0 is exact, so lane 0 still computes f at uv itself), then broadcast
       double f0[2], fu[2], fv[2];
-      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0], ap.anchor_obs_pyr[1], f0);
-      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + 1, ap.anchor_obs_pyr[1], fu);
-      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0], ap.anchor_obs_pyr[1] + 1, fv);
+      {
+        double fl[2];
+        d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + (lane == 1 ? 1.0 : 0.0),
+                 ap.anchor_obs_pyr[1] + (lane == 2 ? 1.0 : 0.0), fl);
+        f0[0] = __shfl(fl[0], 0, 64); f0[1] = __shfl(fl[1], 0, 64);
+        fu[0] = __shfl(fl[0], 1, 64); fu[1] = __shfl(fl[1], 1, 64);
+        fv[0] = __shfl(fl[0], 2, 64); fv[1] = __shfl(fl[1], 2, 64);
+      }
       const double a00 = fu[0] - f0[0], a01 = fu[1] - f0[1], a10 = fv[0] - f0[0], a11 = fv[1] - f0[1];
       const double invdet = 1.0 / (a00 * a11 - a01 * a10);
       const double i00 = a11 * invdet, i01 = -a01 * invdet, i10 = -a10 * invdet, i11 = a00 * invdet;
