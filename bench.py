@@ -332,6 +332,7 @@ def main():
         }
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()          # ranks > 0 wait here while rank 0 times the CPU baseline
         dist.destroy_process_group()
 
 

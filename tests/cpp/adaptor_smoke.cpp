@@ -1,0 +1,70 @@
+// Drives the C++ adaptor classes (include/scavislam_hip.hpp, the reference-named call surfaces) on the
+// GPU and prints results as text; tests/test_gpu_cpp_adaptor.py compares them with the CPU oracle.
+// Input: a raw u8 image file (w h then pixels) and a BA problem dump written by the test.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "scavislam_hip.hpp"
+
+using namespace scavislam_hip;
+
+template <class T>
+static bool read_vec(FILE *f, std::vector<T> *v, size_t n) { v->resize(n); return n == 0 || std::fread(v->data(), sizeof(T), n, f) == n; }
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  Context ctx(0);
+  if (!ctx.ok()) { std::puts("NODEVICE"); return 3; }
+  // ---- FastGrid::detectAdaptively on a pyramid built by FrameDev::preprocessing --------------------
+  FILE *f = std::fopen(argv[1], "rb");
+  int wh[2];
+  if (!f || std::fread(wh, sizeof(int), 2, f) != 2) return 4;
+  std::vector<uint8_t> img;
+  if (!read_vec(f, &img, (size_t)wh[0] * wh[1])) return 4;
+  std::fclose(f);
+  FrameDev fr(ctx, wh[0], wh[1]);
+  Image8 view = {img.data(), wh[0], wh[1], wh[0]};
+  if (!fr.preprocessing(view)) return 5;
+  int32_t w[3], h[3];
+  svs_fastgrid grids[3];
+  for (int l = 0; l < 3; ++l) {
+    w[l] = wh[0] >> l; h[l] = wh[1] >> l;
+    int dim = 3 - (int)(l * 0.5); if (dim < 1) dim = 1;                 // stereo_frontend.cpp:73-88
+    double inv = 1.0 / (1 << l);
+    int total = (int)(2000 * inv * inv), per_cell = total / (dim * dim), bound = per_cell / 3 > 10 ? per_cell / 3 : 10;
+    grids[l] = makeFastGrid(w[l], h[l], per_cell, bound, 25, dim, dim);
+  }
+  FastGrid fg(ctx, 3, w, h, grids);
+  std::vector<Corner> corners[3];
+  for (int it = 0; it < 3; ++it)
+    if (!fg.detectAdaptively(fr, 6, corners)) return 6;
+  for (int l = 0; l < 3; ++l) {
+    std::printf("CORNERS %d %zu", l, corners[l].size());
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < corners[l].size(); ++i) sum = sum * 1000003ull + (unsigned long long)(corners[l][i].x * 4096 + corners[l][i].y);
+    std::printf(" %llu", sum);
+    std::vector<int32_t> thr = fg.cell_grid2d(l);
+    for (size_t i = 0; i < thr.size(); ++i) std::printf(" %d", thr[i]);
+    std::printf("\n");
+  }
+  // ---- SlamGraphBA::optimize ------------------------------------------------------------------------
+  f = std::fopen(argv[2], "rb");
+  int hdr[4];
+  double camd[6];
+  if (!f || std::fread(hdr, sizeof(int), 4, f) != 4 || std::fread(camd, sizeof(double), 6, f) != 6) return 7;
+  std::vector<double> poses, psi;
+  std::vector<svs_ba_edge> edges;
+  std::vector<svs_ba_constraint> cons;
+  if (!read_vec(f, &poses, (size_t)hdr[0] * 12) || !read_vec(f, &psi, (size_t)hdr[1] * 3) || !read_vec(f, &edges, (size_t)hdr[2]) ||
+      !read_vec(f, &cons, (size_t)hdr[3])) return 7;
+  std::fclose(f);
+  svs_cam cam = {camd[0], camd[1], camd[2], camd[3], (int32_t)camd[4], (int32_t)camd[5]};
+  SlamGraphBA ba(ctx);
+  svs_ba_stats st;
+  if (!ba.optimize(OptParams(2, true, 3), cam, &poses, &psi, edges, cons, &st)) return 8;
+  std::printf("BA %d %d %d %.17g %.17g\n", st.iterations, st.trials, st.accepted, st.chi2_init, st.chi2_final);
+  for (size_t i = 0; i < poses.size(); ++i) std::printf("P %.17g\n", poses[i]);
+  for (size_t i = 0; i < psi.size(); ++i) std::printf("S %.17g\n", psi[i]);
+  return 0;
+}

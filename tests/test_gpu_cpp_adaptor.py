@@ -1,0 +1,62 @@
+"""The C++ adaptor classes of include/scavislam_hip.hpp (reference-named call surfaces over the C ABI),
+compiled with g++ and run on the GPU: FastGrid::detectAdaptively + cell_grid2d and SlamGraphBA::optimize
+must agree with the CPU oracle exactly like the Python path does."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_adaptor_matches_oracle(tmp_path):
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import BaParams, Cam
+    exe = tmp_path / "adaptor_smoke"
+    libdir = os.path.join(ROOT, "scavislam_amd")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adaptor_smoke.cpp"),
+                           "-o", str(exe), "-L", libdir, "-lscavislam_hip", f"-Wl,-rpath,{libdir}"])
+    w, h = 640, 480
+    img = synth.noise_image(w, h, 321)
+    with open(tmp_path / "img.bin", "wb") as f:
+        f.write(np.array([w, h], np.int32).tobytes())
+        f.write(img.tobytes())
+    prob = synth.ba_window(9, 500, seed=8, n_outer=2)
+    c = prob["cam"]
+    with open(tmp_path / "ba.bin", "wb") as f:
+        f.write(np.array([len(prob["poses"]), len(prob["psi"]), len(prob["edges"]), len(prob["cons"])], np.int32).tobytes())
+        f.write(np.array([c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"]], np.float64).tobytes())
+        f.write(prob["poses"].astype(np.float64).tobytes())
+        f.write(prob["psi"].astype(np.float64).tobytes())
+        f.write(prob["edges"].tobytes())
+        f.write(prob["cons"].tobytes())
+    out = subprocess.check_output([str(exe), str(tmp_path / "img.bin"), str(tmp_path / "ba.bin")]).decode().splitlines()
+    # FAST
+    pyr = O.build_pyramid(img)
+    grids = [O.fastgrid_for_level(pyr[l].shape[1], pyr[l].shape[0], l) for l in range(3)]
+    for it in range(3):
+        ref = [O.fastgrid_detect_adaptively(grids[l], pyr[l], 6) for l in range(3)]
+    for l in range(3):
+        tok = out[l].split()
+        assert tok[0] == "CORNERS" and int(tok[1]) == l
+        xy = ref[l][0]
+        s = 0
+        for x, y in xy.tolist():
+            s = (s * 1000003 + (x * 4096 + y)) % (1 << 64)
+        assert int(tok[2]) == len(xy) and int(tok[3]) == s, f"level {l} corner list differs"
+        nc = grids[l].gx * grids[l].gy
+        assert [int(t) for t in tok[4:4 + nc]] == list(grids[l].thr[:nc])
+    # BA
+    cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
+    prm = BaParams.reference_defaults()
+    poses_ref, psi_ref, st = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    ba = out[3].split()
+    assert ba[0] == "BA" and (int(ba[1]), int(ba[2]), int(ba[3])) == (st.iterations, st.trials, st.accepted)
+    np.testing.assert_allclose(float(ba[5]), st.chi2_final, rtol=1e-9)
+    P = np.array([float(l.split()[1]) for l in out if l.startswith("P ")]).reshape(-1, 12)
+    S = np.array([float(l.split()[1]) for l in out if l.startswith("S ")]).reshape(-1, 3)
+    assert np.abs(P - poses_ref).max() < 1e-6 * np.abs(poses_ref - prob["poses"]).max()
+    assert np.abs(S - psi_ref).max() < 1e-6 * np.abs(psi_ref - prob["psi"]).max()
