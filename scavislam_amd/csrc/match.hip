@@ -286,9 +286,10 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
 }  // namespace
 
 extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out) {
-  SVS_REQUIRE(ctx, ctx && a && f && d_out);
+  SVS_REQUIRE(ctx, ctx && a && f);
   SVS_REQUIRE(ctx, a->n_pts >= 0 && a->n_batch >= 1 && a->search_radius >= 0 && a->search_radius <= 31);
-  if (a->n_pts == 0) return SVS_OK;
+  if (a->n_pts == 0) return SVS_OK;                 // empty ap_map: nothing to append (matcher.cpp:332)
+  SVS_REQUIRE(ctx, d_out && a->d_pts && a->d_kfs);
   MatchParams M;
   M.a = *a;
   M.fv = svs_fast_view_internal(f);

@@ -243,7 +243,7 @@ class DenseTracker:
     def _set_T(self, T):
         T = np.broadcast_to(np.asarray(T, np.float64).reshape(-1, 12), (self.frame.batch, 12))
         with torch.cuda.stream(self.frame.stream):
-            self.d_T.copy_(torch.as_tensor(np.ascontiguousarray(T)))
+            self.d_T.copy_(torch.as_tensor(np.array(T, dtype=np.float64)))
 
     def computeDensePointCloudCpu(self, T_cur_from_actkey):
         fr = self.frame
