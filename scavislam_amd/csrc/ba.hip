@@ -35,8 +35,12 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 // of the WIN x WIN pose window (plus b_p / b_s rows) lives in LDS; contributions whose poses fall
 // outside the window go straight to global atomics.  Landmarks are processed sorted by anchor,
 // so a workgroup's landmarks touch a narrow band of poses and nearly everything lands in LDS.
+constexpr int DBG_N = 12;   // phase stamps per wave of the Schur kernel timeline (SVS_BA_DEBUG=2)
 constexpr int WIN = 16;
 constexpr int WIN_BLOCKS = WIN * (WIN + 1) / 2;
+// LDS stride of one 6x6 window block in doubles: 37 (not 36) spreads the same element of different
+// blocks over all banks -- measured 11 vs 32 cycles per ds_add_f64 wave instruction (tools/ubench.hip)
+constexpr int WBLK = 37;
 __device__ __forceinline__ int win_blk(int wi, int wj) { return wi * WIN - wi * (wi - 1) / 2 + (wj - wi); }
 
 template <int N>
@@ -181,27 +185,31 @@ struct BaDev {
   svs_cam cam;
   double delta, lambda;
   int robust, self_mode;
+  long long *dbg;                       // SVS_BA_DEBUG=2: per-wave phase stamps (100 MHz ticks), DBG_N per chunk
 };
 
 // MODE 0: accumulate reduced system + chi2 at the current state.
 // MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
 template <int MODE>
-__global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
+__global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   const int lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
   if (MODE == 1 && !wave_valid) return;
   const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
   const bool active = lane < len;
+#define SVS_STAMP(k) do { if (B.dbg && lane == 0 && wave_valid) B.dbg[DBG_N * (size_t)chunk + (k)] = (long long)wall_clock64(); } while (0)
+  SVS_STAMP(0);
   svs_ba_edge ed;
   if (active) ed = B.edges[e0 + lane];
   else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
-  __shared__ double s_win[MODE == 0 ? WIN_BLOCKS * 36 : 1];
+  __shared__ double s_win[MODE == 0 ? WIN_BLOCKS * WBLK : 1];
   __shared__ double s_vec[MODE == 0 ? 2 * WIN * 6 : 1];
+  __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? 4 * 64 * 18 : 1];   // W_obs of every edge lane
   __shared__ int s_pmin;
   int pmin = 0;
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) s_win[i] = 0.0;
+    for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += 256) s_win[i] = 0.0;
     for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) s_vec[i] = 0.0;
     if (threadIdx.x == 0) s_pmin = 0x7fffffff;
     __syncthreads();
@@ -212,17 +220,6 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
     __syncthreads();
     pmin = s_pmin;
   }
-  // add v to element rc of upper block (pi <= pj) of the reduced system
-  auto add_blk = [&](int pi, int pj, int rc, double v) {
-    const int wi = pi - pmin, wj = pj - pmin;
-    if (wj < WIN) lds_add_f64(&s_win[win_blk(wi, wj) * 36 + rc], v);
-    else atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v);
-  };
-  auto add_vec = [&](int which, int p, int r, double v) {     // which: 0 = b_p, 1 = b_s
-    const int wp = p - pmin;
-    if (wp < WIN) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + r], v);
-    else atomic_add_f64((which ? B.bs : B.bp) + 6 * p + r, v);
-  };
   // segment (= landmark) bounds inside the wave
   const int prev_point = __shfl_up(ed.point, 1, 64);
   const bool head = lane == 0 || prev_point != ed.point;
@@ -244,6 +241,7 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
     for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)ed.anchor + i]; }
+    SVS_STAMP(1);
     linearize_edge(psi, To, Ta, ed, B.cam, B.delta, B.robust, lin);
   } else {
 #pragma unroll
@@ -277,7 +275,9 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) hl[6 + i] = -(lin.D[i] * lin.g[0] + lin.D[3 + i] * lin.g[1] + lin.D[6 + i] * lin.g[2]);
   }
+  SVS_STAMP(2);
   seg_allreduce<9>(hl, lane, seg_begin, seg_end, maxlen);
+  SVS_STAMP(3);
   double Di[9], bl[3] = {hl[6], hl[7], hl[8]};
   {
     const double a00 = hl[0] + B.lambda, a01 = hl[1], a02 = hl[2], a11 = hl[3] + B.lambda, a12 = hl[4], a22 = hl[5] + B.lambda;
@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
       WA[i] = self ? (self_lit ? wo[i] + wa[i] : 0.0) : wa[i];
     }
   }
+  SVS_STAMP(4);
   seg_allreduce<18>(WA, lane, seg_begin, seg_end, maxlen);
+  SVS_STAMP(5);
   const int anchor = ed.anchor;
 
   if (MODE == 1) {
@@ -359,121 +361,176 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
   }
 
   // ---- MODE 0: reduced camera system -------------------------------------------------------
-  // pose blocks of this edge: M_oo = Eo^T A Eo, M_oa = -Eo^T (A R) Ea, M_aa = Ea^T (R^T A R) Ea
-  double AR[9], RAR[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) RAR[3 * i + j] = lin.R[i] * AR[j] + lin.R[3 + i] * AR[3 + j] + lin.R[6 + i] * AR[6 + j];
-  double Rg[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) Rg[i] = lin.R[i] * lin.g[0] + lin.R[3 + i] * lin.g[1] + lin.R[6 + i] * lin.g[2];
-  double bo[6], ba[6];
-  bo[0] = -lin.g[0]; bo[1] = -lin.g[1]; bo[2] = -lin.g[2];
+  // add v to element rc of upper block (pi <= pj) of the reduced system
+  auto add_blk = [&](int pi, int pj, int rc, double v) {
+    const int wi = pi - pmin, wj = pj - pmin;
+    if (wj < WIN) lds_add_f64(&s_win[win_blk(wi, wj) * WBLK + rc], v);
+    else atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v);
+  };
+  auto add_vec = [&](int which, int p, int r, double v) {     // which: 0 = b_p, 1 = b_s
+    const int wp = p - pmin;
+    if (wp < WIN) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + r], v);
+    else atomic_add_f64((which ? B.bs : B.bp) + 6 * p + r, v);
+  };
+  // Phases are ordered so that few values are live at a time (two waves per SIMD need <= 256 VGPRs).
+  // (1) anchor diagonal terms that do not involve W: sum over the landmark of
+  //     M_aa = Ea^T (R^T A R) Ea and b_anc = Ea^T R^T g  (+ the slot-1 terms of a literal self edge)
   {
-    double t0, t1, t2;
-    cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], t0, t1, t2);
-    bo[3] = -t0; bo[4] = -t1; bo[5] = -t2;
-  }
-  ba[0] = Rg[0]; ba[1] = Rg[1]; ba[2] = Rg[2];
-  cross3(lin.xa, Rg[0], Rg[1], Rg[2], ba[3], ba[4], ba[5]);
-
-  // observer part: blocks (i,i), (i,A), b_i
-  double WoD[18];
+    double AR[9], RAR[9];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) WoD[3 * i + j] = Wo[3 * i] * Di[j] + Wo[3 * i + 1] * Di[3 + j] + Wo[3 * i + 2] * Di[6 + j];
-  double Moo[36], Noa[36];
-  sym_block(lin.A, lin.y, Moo);
-  cross_block(AR, lin.y, lin.xa, Noa);                  // M_oa = -Noa
-  if (obs_role) {
-    const int pi = ed.pose;
+      for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int c = r; c < 6; ++c)
-        add_blk(pi, pi, 6 * r + c, Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]));
-    const bool up = pi < anchor;
+      for (int j = 0; j < 3; ++j) RAR[3 * i + j] = lin.R[i] * AR[j] + lin.R[3 + i] * AR[3 + j] + lin.R[6 + i] * AR[6 + j];
+    double Rg[3];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double m = -Noa[6 * r + c] - (WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2]);
-        if (up) add_blk(pi, anchor, 6 * r + c, m); else add_blk(anchor, pi, 6 * c + r, m);
-      }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      add_vec(0, pi, r, bo[r]);
-      add_vec(1, pi, r, Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
-    }
-  }
-  // observer-observer pairs of the same landmark: partner = lane + t (edges sorted by observer)
-  for (int t = 1; t < maxlen; ++t) {
-    double Wj[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) Wj[i] = __shfl_down(Wo[i], t, 64);
-    const int pj = __shfl_down(ed.pose, t, 64);
-    const int rolej = __shfl_down((int)obs_role, t, 64);
-    if (obs_role && lane + t <= seg_end && rolej) {
+    for (int i = 0; i < 3; ++i) Rg[i] = lin.R[i] * lin.g[0] + lin.R[3 + i] * lin.g[1] + lin.R[6 + i] * lin.g[2];
+    double ma[27];   // 21 unique of sum M_aa, 6 of sum b_anc
+    {
+      double Maa[36];
+      sym_block(RAR, lin.xa, Maa);
+      int k = 0;
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          add_blk(ed.pose, pj, 6 * r + c, -(WoD[3 * r] * Wj[3 * c] + WoD[3 * r + 1] * Wj[3 * c + 1] + WoD[3 * r + 2] * Wj[3 * c + 2]));
+        for (int c = r; c < 6; ++c) ma[k++] = self ? 0.0 : Maa[6 * r + c];
+      double t0, t1, t2;
+      cross3(lin.xa, Rg[0], Rg[1], Rg[2], t0, t1, t2);
+      ma[21] = self ? 0.0 : Rg[0]; ma[22] = self ? 0.0 : Rg[1]; ma[23] = self ? 0.0 : Rg[2];
+      ma[24] = self ? 0.0 : t0; ma[25] = self ? 0.0 : t1; ma[26] = self ? 0.0 : t2;
+      if (__any(self_lit)) {
+        // both slots of a self edge are the anchor vertex, so slot-1 and slot-2 diagonal terms
+        // and the symmetrised (1,2) pair all land on its diagonal block: M_oo + M_aa + sym(M_oa), b_obs + b_anc
+        double Moo[36], Noa[36];
+        sym_block(lin.A, lin.y, Moo);
+        cross_block(AR, lin.y, lin.xa, Noa);                // M_oa = -Noa
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) { if (self_lit) ma[q] = Moo[6 * r + c] + Maa[6 * r + c] - 0.5 * (Noa[6 * r + c] + Noa[6 * c + r]); ++q; }
+        double u0, u1, u2;
+        cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], u0, u1, u2);
+        if (self_lit) { ma[21] = Rg[0] - lin.g[0]; ma[22] = Rg[1] - lin.g[1]; ma[23] = Rg[2] - lin.g[2]; ma[24] = t0 - u0; ma[25] = t1 - u1; ma[26] = t2 - u2; }
+      }
+    }
+    seg_allreduce<27>(ma, lane, seg_begin, seg_end, maxlen);
+    if (active && head) {
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) add_blk(anchor, anchor, 6 * r + c, ma[k++]);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) add_vec(0, anchor, r, ma[21 + r]);
     }
   }
-  // anchor part: (A,A) block and b_A, from segment sums; written by the head lane
-  double ma[27];   // 21 unique of sum M_aa (+ self-literal terms), 6 of sum b_anc
-  {
-    double Maa[36];
-    sym_block(RAR, lin.xa, Maa);
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = r; c < 6; ++c) {
-        double maa = Maa[6 * r + c];
-        // for a self edge slot-1 + slot-2 diagonal terms and the (1,2) pair all land on the
-        // anchor's diagonal block: M_oo + M_aa + M_oa (symmetrised: M_oa = -M up to rounding)
-        if (self) maa = self_lit ? Moo[6 * r + c] + maa - 0.5 * (Noa[6 * r + c] + Noa[6 * c + r]) : 0.0;
-        ma[k++] = maa;
-      }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) ma[21 + r] = self ? (self_lit ? ba[r] + bo[r] : 0.0) : ba[r];
-  }
-  seg_allreduce<27>(ma, lane, seg_begin, seg_end, maxlen);
+  SVS_STAMP(6);
+  // (2) Schur terms of the anchor: -(W_A D^-1) W_A^T and W_A D^-1 b_l, once per landmark
   if (active && head) {
     double WAD[18];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) WAD[3 * i + j] = WA[3 * i] * Di[j] + WA[3 * i + 1] * Di[3 + j] + WA[3 * i + 2] * Di[6 + j];
-    int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = r; c < 6; ++c) {
-        const double m = ma[k++] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]);
-        add_blk(anchor, anchor, 6 * r + c, m);
-      }
+      for (int c = r; c < 6; ++c)
+        add_blk(anchor, anchor, 6 * r + c, -(WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]));
+#pragma unroll
+    for (int r = 0; r < 6; ++r) add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+  }
+  SVS_STAMP(7);
+  // (3) observer part: blocks (i,i), (i,A), b_i;  W_obs is parked in LDS for the pair phase
+  double *my_wo = s_wo + ((threadIdx.x >> 6) * 64 + lane) * 18;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) my_wo[i] = Wo[i];
+  double WoD[18];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) WoD[3 * i + j] = Wo[3 * i] * Di[j] + Wo[3 * i + 1] * Di[3 + j] + Wo[3 * i + 2] * Di[6 + j];
+  if (obs_role) {
+    const int pi = ed.pose;
+    {
+      double Moo[36];
+      sym_block(lin.A, lin.y, Moo);                           // M_oo = Eo^T A Eo
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c)
+          add_blk(pi, pi, 6 * r + c, Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]));
+    }
+    {
+      double AR[9], Noa[36];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
+      cross_block(AR, lin.y, lin.xa, Noa);                    // M_oa = -Eo^T (A R) Ea
+      const bool up = pi < anchor;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double m = -Noa[6 * r + c] - (WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2]);
+          if (up) add_blk(pi, anchor, 6 * r + c, m); else add_blk(anchor, pi, 6 * c + r, m);
+        }
+    }
+    double u0, u1, u2;
+    cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], u0, u1, u2);
+    const double bo[6] = {-lin.g[0], -lin.g[1], -lin.g[2], -u0, -u1, -u2};    // b_obs = -Eo^T g
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      add_vec(0, anchor, r, ma[21 + r]);
-      add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+      add_vec(0, pi, r, bo[r]);
+      add_vec(1, pi, r, Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
     }
   }
+  SVS_STAMP(8);
+  // (4) observer-observer pairs of a landmark, circulant schedule: in round r the edge with local index a
+  //     pairs with (a + r) mod m, so all m lanes of a landmark work for floor(m/2) rounds (instead of one
+  //     lane-partner distance per round over m-1 rounds).  -(W_a D^-1) W_b^T goes to block (min, max).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int m = seg_end - seg_begin + 1, a_loc = lane - seg_begin;
+    const double *wave_wo = s_wo + (threadIdx.x >> 6) * 64 * 18;
+    for (int r = 1; r <= (maxlen >> 1); ++r) {
+      int b_loc = a_loc + r;
+      if (b_loc >= m) b_loc -= m;
+      const int lane_b = seg_begin + b_loc;
+      const int pj = __shfl(ed.pose, lane_b, 64);
+      const int rolej = __shfl((int)obs_role, lane_b, 64);
+      const bool on = obs_role && rolej && 2 * r <= m && !(2 * r == m && a_loc >= r);
+      if (on) {
+        const double *wj = wave_wo + lane_b * 18;
+        double Wj[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) Wj[i] = wj[i];
+        const bool up = ed.pose < pj;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double v = -(WoD[3 * rr] * Wj[3 * c] + WoD[3 * rr + 1] * Wj[3 * c + 1] + WoD[3 * rr + 2] * Wj[3 * c + 2]);
+            if (up) add_blk(ed.pose, pj, 6 * rr + c, v); else add_blk(pj, ed.pose, 6 * c + rr, v);
+          }
+      }
+    }
+  }
+  SVS_STAMP(9);
   // flush the LDS window: one global atomic per touched element per workgroup
   __syncthreads();
+  SVS_STAMP(10);
   if (pmin != 0x7fffffff) {
     for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) {
-      const double v = s_win[i];
+      const int wb = i / 36, rc = i - wb * 36;
+      const double v = s_win[wb * WBLK + rc];
       if (v != 0.0) {
-        const int wb = i / 36, rc = i - wb * 36;
         int wi = 0, rem = wb;
         while (rem >= WIN - wi) { rem -= WIN - wi; ++wi; }
         const int pi = pmin + wi, pj = pmin + wi + rem;
@@ -488,6 +545,7 @@ __global__ __launch_bounds__(256) void ba_landmark_kernel(BaDev B) {
       }
     }
   }
+  SVS_STAMP(DBG_N - 1);
 }
 
 // ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
@@ -803,19 +861,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
 
 // ---- LDS-window variant of the solve -------------------------------------------------------------
 // When the filled block envelope is narrow (R = max_k(rowmax[k]-k)+1 rows fit in LDS) the active
-// R x R block window of the elimination lives entirely in LDS: no global round trip sits on the
-// P-step critical path.  Row k+R is prefetched into registers at the start of step k and dropped
-// into the ring slot row k vacates.  The panel rows U_kj go to a separate global buffer (written
-// once, read once in the back substitution, prefetched one step ahead).  Forward substitution is
-// fused; the panel is obtained by per-column forward substitution against U_kk (no explicit inverse).
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would put
-// the latency of the prefetch loads (global, ~1 us) back on the critical path of every step.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-constexpr int WSOLVE_PRE = 4;   // prefetch registers per lane: R*36 <= 256*WSOLVE_PRE  => R <= 28
+// R x R block window of the elimination lives entirely in LDS as a ring of envelope rows, and the
+// P-step elimination runs as a software pipeline with ONE workgroup barrier per step:
+//   wave 0 (pivot wave)   stage k: applies panel k to block row k+1 and to b_{k+1}, then factors the
+//                         pivot block k+1 and forms panel k+1 (Z, Y; fused forward substitution)
+//   waves 1-4 (update)    stage k: applies panel k to block rows k+2.. and to the rest of b
+//   wave 5 (loader)       stage k: drops envelope row k+R (loaded two stages earlier) into the ring
+//                         slot row k vacated, issues the loads of row k+R+2
+// Panels are double-buffered, so panel k+1 is written while panel k is still being applied.  The
+// panel rows Y_kj also go to a global buffer (written once, read once by the back substitution).
+// The back substitution is run by wave 0 alone -- no workgroup barriers on its P-step chain.
+// Measured (tools/ubench.hip): an f64 FMA issues every ~5 cycles per wave, dependent or not; what is
+// expensive on the critical path is LDS round trips and workgroup barriers, so those are minimised.
 
-// reciprocal by hardware estimate + 2 Newton steps.  A dependent f64 op costs ~36 cycles on one
-// wave (measured, tools/clock_probe.hip), so the elimination below is written for SHORT dependency
-// chains: LDL^T instead of Cholesky (no sqrt, one reciprocal per pivot), right-looking updates.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would put
+// the latency of the loader's global loads (~1 us) back on the critical path of every step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// orders LDS traffic between the lanes of one wave (LDS executes a wave's operations in order)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+constexpr int PIPE_THREADS = 384;
+constexpr int PIPE_LD = 16;     // loader registers per lane and buffer: R*36 <= 64*PIPE_LD  => R <= 28
+
+// reciprocal by hardware estimate + 2 Newton steps
 __device__ __forceinline__ double rcp_nr(double d) {
   double x = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, x, 1.0);
@@ -823,53 +890,74 @@ __device__ __forceinline__ double rcp_nr(double d) {
   e = __builtin_fma(-d, x, 1.0);
   return __builtin_fma(x, e, x);
 }
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 
 // H + lambda I = U^T D U (U unit upper, D diagonal), organised in 6x6 block rows inside the envelope.
 //   row k:  U_kk (unit upper), Y_kj = D_k^-1 U_kk^-T A~_kj  (j > k);   Z_kj = D_k Y_kj
 //   trailing: A~_ij -= Z_ki^T Y_kj;  forward: z_k = U_kk^-T b~_k, b~_j -= Y_kj^T z_k;  w = D^-1 z
 //   backward: x_k = U_kk^-1 (w_k - sum_j Y_kj x_j)
-__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
-                                                                     const int *__restrict__ rowmax_g, int R) {
+__global__ __launch_bounds__(PIPE_THREADS) void ba_solve_lds_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
+                                                                    const int *__restrict__ rowmax_g, int R) {
   extern __shared__ double smem[];
-  const int P = B.P, n = 6 * P, tid = threadIdx.x;
+  const int P = B.P, n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double *s_b = smem;                          // [n]
   double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
-  double *s_pz = s_win + (size_t)R * R * 36;   // [R][36] Z_kj of the current step
-  double *s_py = s_pz + (size_t)R * 36;        // [R][36] Y_kj
-  double *s_ud = s_py + (size_t)R * 36;        // [P][36] U_kk (unit upper; strict upper part used)
+  double *s_pz = s_win + (size_t)R * R * 36;   // [2][R][36] Z_kj
+  double *s_py = s_pz + 2 * (size_t)R * 36;    // [2][R][36] Y_kj
+  double *s_ud = s_py + 2 * (size_t)R * 36;    // [P][36] U_kk (unit upper; strict upper part used)
   double *s_rd = s_ud + (size_t)P * 36;        // [P][6]  1/D_k
-  double *s_y = s_rd + (size_t)P * 6;          // [8]  z_k
-  double *s_part = s_y + 8;                    // [R][6]
-  int *rowmax = reinterpret_cast<int *>(s_part + (size_t)R * 6);   // [P] envelope, staged in LDS (off the critical path)
+  double *s_y = s_rd + (size_t)P * 6;          // [2][8]  z_k
+  double *s_part = s_y + 16;                   // [R][6]
+  int *rowmax = reinterpret_cast<int *>(s_part + (size_t)R * 6);         // [P] envelope
+  unsigned char *lut = reinterpret_cast<unsigned char *>(rowmax + P);     // [(R-1)(R-2)/2 + ..][2] (ii, jj) of trailing block t, 1 <= ii <= jj
   __shared__ int s_fail;
   const long long t_begin = wall_clock64();
   if (tid == 0) s_fail = 0;
-  for (int i = tid; i < P; i += SOLVE_THREADS) rowmax[i] = rowmax_g[i];
-  for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  for (int i = tid; i < P; i += PIPE_THREADS) rowmax[i] = rowmax_g[i];
+  for (int i = tid; i < n; i += PIPE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  for (int t = tid; t < R * (R - 1) / 2; t += PIPE_THREADS) {   // t = jj (jj - 1) / 2 + (ii - 1)
+    int jj = 1;
+    while ((jj + 1) * jj / 2 <= t) ++jj;
+    lut[2 * t] = (unsigned char)(t - jj * (jj - 1) / 2 + 1);
+    lut[2 * t + 1] = (unsigned char)jj;
+  }
   for (int r = 0; r < R && r < P; ++r) {
     const long rb = blk_index(r, r, P);
-    for (int e = tid; e < R * 36; e += SOLVE_THREADS) {
+    for (int e = tid; e < R * 36; e += PIPE_THREADS) {
       const int c = e / 36;
       s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
     }
   }
-  __syncthreads();
-  const long long t_loop = wall_clock64();
-  for (int k = 0; k < P; ++k) {
-    double *row = s_win + ((size_t)(k % R) * R) * 36;
-    double pre[WSOLVE_PRE];
-    const int rn = k + R;
+  // loader wave: envelope rows R and R+1 are in flight before the pipeline starts
+  double ra[PIPE_LD], rb_[PIPE_LD];
+  auto load_row = [&](double (&reg)[PIPE_LD], int rn) {
     if (rn < P) {
       const long rb = blk_index(rn, rn, P);
 #pragma unroll
-      for (int i = 0; i < WSOLVE_PRE; ++i) {
-        const int e = tid + i * SOLVE_THREADS;
+      for (int i = 0; i < PIPE_LD; ++i) {
+        const int e = lane + 64 * i;
         const int c = e / 36;
-        pre[i] = (e < R * 36 && rn + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+        reg[i] = (e < R * 36 && rn + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
       }
     }
-    if (tid == 0) {
-      // right-looking LDL^T of the 6x6 pivot block: dependency chain = 6 x (rcp, scale, update)
+  };
+  auto store_row = [&](const double (&reg)[PIPE_LD], int k) {
+    if (k + R < P) {
+      double *row = s_win + ((size_t)(k % R) * R) * 36;
+#pragma unroll
+      for (int i = 0; i < PIPE_LD; ++i) { const int e = lane + 64 * i; if (e < R * 36) row[e] = reg[i]; }
+    }
+  };
+  if (wave == 5) { load_row(ra, R); load_row(rb_, R + 1); }
+  __syncthreads();
+  // pivot block k -> U_kk, 1/D_k; panel k -> Z, Y (buffer k & 1), z_k, w_k.  Run by wave 0.
+  long long t_mid = 0;
+  auto factor_panel = [&](int k) {
+    double *row = s_win + ((size_t)(k % R) * R) * 36;
+    if (lane == 0) {
+      // right-looking LDL^T of the 6x6 pivot block, in registers
       double A[36];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
@@ -878,8 +966,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, do
       int fail = 0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const double d = A[6 * j + j];
-        if (!(d > 0) || !isfinite(d)) fail = 1;
+        double d = A[6 * j + j];
+        if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1.0; }      // keep going (uniform control flow); x is zeroed at the end
         const double rj = rcp_nr(d);
         s_rd[(size_t)k * 6 + j] = rj;
         double u[6];
@@ -892,12 +980,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, do
       }
       if (fail) s_fail = 1;
     }
-    lds_barrier();
-    if (s_fail) break;
+    wave_lds_fence();
+    t_mid = wall_clock64();
     const int nj = rowmax[k] - k;
     const double *U = s_ud + (size_t)k * 36, *rd = s_rd + (size_t)k * 6;
-    // panel columns (+ the rhs as one more column): unit-lower forward substitution, right-looking
-    for (int e = tid; e <= nj * 6; e += SOLVE_THREADS) {
+    double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
+    // panel columns (+ the rhs as one more column): unit-lower forward substitution
+    for (int e = lane; e <= nj * 6; e += 64) {
       double a[6];
       const bool is_rhs = e == nj * 6;
       const int jj = e / 6, c = e - jj * 6;
@@ -909,119 +998,146 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, do
         for (int r = q + 1; r < 6; ++r) a[r] = __builtin_fma(-U[6 * q + r], a[q], a[r]);
       if (is_rhs) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s_y[q] = a[q];
+        for (int q = 0; q < 6; ++q) { zk[q] = a[q]; s_b[6 * k + q] = a[q] * rd[q]; }      // z_k, w_k
       } else {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           const double y = a[q] * rd[q];
-          s_pz[(size_t)jj * 36 + 6 * q + c] = a[q];
-          s_py[(size_t)jj * 36 + 6 * q + c] = y;
+          pz[(size_t)jj * 36 + 6 * q + c] = a[q];
+          py[(size_t)jj * 36 + 6 * q + c] = y;
           upanel[((size_t)k * R + jj) * 36 + 6 * q + c] = y;
         }
       }
     }
-    lds_barrier();
-    if (tid < 6) s_b[6 * k + tid] = s_y[tid] * rd[tid];        // w_k
-    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {        // b~_j -= Y_kj^T z_k
-      const int jj = e / 6, c = e - jj * 6;
+    wave_lds_fence();
+  };
+  // A~_(k+1+ii),(k+1+jj) row r -= Z_k,ii(:,r)^T Y_k,jj
+  auto update_block_row = [&](int k, const double *pz, const double *py, int ii, int jj, int r) {
+    double zi[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) zi[q] = pz[(size_t)ii * 36 + 6 * q + r];
+    double *Aij = s_win + (((size_t)((k + 1 + ii) % R) * R) + (jj - ii)) * 36 + 6 * r;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
       double s0 = 0, s1 = 0;
 #pragma unroll
       for (int q = 0; q < 6; q += 2) {
-        s0 = __builtin_fma(s_py[(size_t)jj * 36 + 6 * q + c], s_y[q], s0);
-        s1 = __builtin_fma(s_py[(size_t)jj * 36 + 6 * (q + 1) + c], s_y[q + 1], s1);
+        s0 = __builtin_fma(zi[q], py[(size_t)jj * 36 + 6 * q + c], s0);
+        s1 = __builtin_fma(zi[q + 1], py[(size_t)jj * 36 + 6 * (q + 1) + c], s1);
       }
-      s_b[6 * (k + 1 + jj) + c] -= s0 + s1;
+      Aij[c] -= s0 + s1;
     }
-    const int nblk = nj * (nj + 1) / 2;
-    for (int e = tid; e < nblk * 6; e += SOLVE_THREADS) {      // A~_ij -= Z_ki^T Y_kj
-      const int bidx = e / 6, r = e - bidx * 6;
-      int ii = 0, rem = bidx;
-      while (rem >= nj - ii) { rem -= nj - ii; ++ii; }
-      const int jj = ii + rem;
-      double zi[6];
+  };
+  auto update_rhs = [&](int k, const double *py, const double *zk, int jj, int c) {     // b~_(k+1+jj)[c] -= Y_k,jj(:,c)^T z_k
+    double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) zi[q] = s_pz[(size_t)ii * 36 + 6 * q + r];
-      double *Aij = s_win + (((size_t)((k + 1 + ii) % R) * R) + (jj - ii)) * 36 + 6 * r;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int q = 0; q < 6; q += 2) {
-          s0 = __builtin_fma(zi[q], s_py[(size_t)jj * 36 + 6 * q + c], s0);
-          s1 = __builtin_fma(zi[q + 1], s_py[(size_t)jj * 36 + 6 * (q + 1) + c], s1);
-        }
-        Aij[c] -= s0 + s1;
+    for (int q = 0; q < 6; q += 2) {
+      s0 = __builtin_fma(py[(size_t)jj * 36 + 6 * q + c], zk[q], s0);
+      s1 = __builtin_fma(py[(size_t)jj * 36 + 6 * (q + 1) + c], zk[q + 1], s1);
+    }
+    s_b[6 * (k + 1 + jj) + c] -= s0 + s1;
+  };
+  if (wave == 0) factor_panel(0);
+  lds_barrier();
+  const long long t_loop = wall_clock64();
+  long long acc_upd = 0, acc_piv = 0, acc_pan = 0, acc_bar = 0;      // pivot-wave stage breakdown (debug)
+  for (int k = 0; k < P; ++k) {
+    const int nj = rowmax[k] - k;
+    const long long ts0 = wall_clock64();
+    const double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
+    if (wave == 0) {
+      for (int e = lane; e < nj * 6; e += 64) update_block_row(k, pz, py, 0, e / 6, e % 6);
+      if (lane < 6 && nj > 0) update_rhs(k, py, zk, 0, lane);
+      wave_lds_fence();
+      const long long ts1 = wall_clock64();
+      if (k + 1 < P) factor_panel(k + 1);
+      const long long ts2 = wall_clock64();
+      acc_upd += ts1 - ts0; acc_piv += t_mid - ts1; acc_pan += ts2 - t_mid;
+    } else if (wave <= 4) {
+      const int ul = tid - 64;
+      for (int e = ul; e < (nj - 1) * 6; e += 256) update_rhs(k, py, zk, 1 + e / 6, e % 6);
+      const int nb = nj * (nj - 1) / 2;
+      for (int e = ul; e < nb * 6; e += 256) {
+        const int t = e / 6;
+        update_block_row(k, pz, py, lut[2 * t], lut[2 * t + 1], e - t * 6);
       }
+    } else {
+      if (k & 1) { store_row(rb_, k); load_row(rb_, k + R + 2); }
+      else { store_row(ra, k); load_row(ra, k + R + 2); }
     }
-    if (rn < P) {
-#pragma unroll
-      for (int i = 0; i < WSOLVE_PRE; ++i) { const int e = tid + i * SOLVE_THREADS; if (e < R * 36) row[e] = pre[i]; }
-    }
+    const long long ts3 = wall_clock64();
     lds_barrier();
+    acc_bar += (long long)wall_clock64() - ts3;
   }
   const int fail = s_fail;
-  lds_barrier();
   const long long t_fwd = wall_clock64();
-  if (!fail) {
-    double un[6];
-    int njn = rowmax[P - 1] - (P - 1);
-    if (tid < njn * 6) {
+  if (wave == 0) {
+    if (!fail) {
+      double un[6];
+      int njn = rowmax[P - 1] - (P - 1);
+      if (lane < njn * 6) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(P - 1) * R + tid / 6) * 36 + 6 * (tid % 6) + c];
-    }
-    for (int k = P - 1; k >= 0; --k) {
-      const int nj = njn;
-      double u[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) u[c] = un[c];
-      if (k > 0) {
-        njn = rowmax[k - 1] - (k - 1);
-        if (tid < njn * 6) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(k - 1) * R + tid / 6) * 36 + 6 * (tid % 6) + c];
-        }
+        for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(P - 1) * R + lane / 6) * 36 + 6 * (lane % 6) + c];
       }
-      if (tid < nj * 6) {
-        const int jj = tid / 6, r = tid - jj * 6;
-        double s0 = 0, s1 = 0;
+      for (int k = P - 1; k >= 0; --k) {
+        const int nj = njn;
+        double u[6];
 #pragma unroll
-        for (int c = 0; c < 6; c += 2) {
-          s0 = __builtin_fma(u[c], s_b[6 * (k + 1 + jj) + c], s0);
-          s1 = __builtin_fma(u[c + 1], s_b[6 * (k + 1 + jj) + c + 1], s1);
+        for (int c = 0; c < 6; ++c) u[c] = un[c];
+        if (k > 0) {
+          njn = rowmax[k - 1] - (k - 1);
+          if (lane < njn * 6) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) un[c] = upanel[((size_t)(k - 1) * R + lane / 6) * 36 + 6 * (lane % 6) + c];
+          }
         }
-        s_part[jj * 6 + r] = s0 + s1;
-      }
-      lds_barrier();
-      if (tid == 0) {
-        double x[6];
-        const double *U = s_ud + (size_t)k * 36;
+        for (int e = lane; e < nj * 6; e += 64) {
+          const int jj = e / 6, r = e - jj * 6;
+          if (e >= 64) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            for (int c = 0; c < 6; ++c) u[c] = upanel[((size_t)k * R + jj) * 36 + 6 * r + c];
+          }
+          double s0 = 0, s1 = 0;
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            s0 = __builtin_fma(u[c], s_b[6 * (k + 1 + jj) + c], s0);
+            s1 = __builtin_fma(u[c + 1], s_b[6 * (k + 1 + jj) + c + 1], s1);
+          }
+          s_part[jj * 6 + r] = s0 + s1;
+        }
+        wave_lds_fence();
+        double x = 0;
+        if (lane < 6) {
+          double p0 = 0, p1 = 0;
           int jj = 0;
-          for (; jj + 3 < nj; jj += 4) { p0 += s_part[jj * 6 + r]; p1 += s_part[(jj + 1) * 6 + r]; p2 += s_part[(jj + 2) * 6 + r]; p3 += s_part[(jj + 3) * 6 + r]; }
-          for (; jj < nj; ++jj) p0 += s_part[jj * 6 + r];
-          x[r] = s_b[6 * k + r] - ((p0 + p1) + (p2 + p3));
+          for (; jj + 1 < nj; jj += 2) { p0 += s_part[jj * 6 + lane]; p1 += s_part[(jj + 1) * 6 + lane]; }
+          if (jj < nj) p0 += s_part[jj * 6 + lane];
+          x = s_b[6 * k + lane] - (p0 + p1);
         }
+        // unit-upper back substitution across lanes 0..5
+        const double *U = s_ud + (size_t)k * 36;
+        double ucol[6];
 #pragma unroll
-        for (int r = 5; r >= 1; --r)
+        for (int r = 1; r < 6; ++r) ucol[r] = (lane < 6) ? U[6 * (lane < 6 ? lane : 0) + r] : 0.0;
 #pragma unroll
-          for (int q = 0; q < r; ++q) x[q] = __builtin_fma(-U[6 * q + r], x[r], x[q]);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) s_b[6 * k + r] = x[r];
+        for (int r = 5; r >= 1; --r) {
+          const double xr = readlane_f64(x, r);
+          if (lane < r) x = __builtin_fma(-ucol[r], xr, x);
+        }
+        if (lane < 6) s_b[6 * k + lane] = x;
+        wave_lds_fence();
       }
-      lds_barrier();
+    } else {
+      for (int i = lane; i < n; i += 64) s_b[i] = 0;
     }
-  } else {
-    for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = 0;
-    lds_barrier();
   }
+  __syncthreads();
   const long long t_back = wall_clock64();
   double sc = 0;
-  for (int i = tid; i < n; i += SOLVE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  for (int i = tid; i < n; i += PIPE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
   sc = wave_sum_f64(sc);
   if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
-  for (int p = tid; p < P; p += SOLVE_THREADS) {
+  for (int p = tid; p < P; p += PIPE_THREADS) {
     double Tn[12];
     d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
     for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
@@ -1030,6 +1146,295 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_lds_kernel(BaDev B, do
     B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
     // phase timing (100 MHz wall clock ticks -> us), read by SVS_BA_DEBUG=1
     B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
+    B.scal[8] = acc_upd * 0.01; B.scal[9] = acc_piv * 0.01; B.scal[10] = acc_pan * 0.01; B.scal[11] = acc_bar * 0.01;
+  }
+}
+
+// ---- register-resident variant for narrow envelopes (R <= 10 block rows) ------------------------------
+// Same U^T D U elimination and the same pipeline as ba_solve_lds_kernel, but the pivot wave never
+// round-trips through LDS inside a stage: lane (slot, c) of wave 0 owns column c of the block column
+// j with j % 10 == slot for as long as j is inside the sliding window.  It keeps that column of the
+// current panel (Y_k) in registers, applies panel k to its column of block row k+1, and the 6 pivots
+// of block k+1 are eliminated on ALL columns of the row at once (panel columns and the rhs ride along
+// as extra columns, multipliers broadcast with v_readlane) -- factorisation, panel and forward
+// substitution are one pass.  Trailing blocks are updated by waves 1-3 (two block columns per lane,
+// 128-bit LDS accesses), wave 4 streams envelope rows into the LDS ring.
+// The back substitution is column-oriented: lane (slot, r) carries the running value of component r of
+// one row, every solved x_k is broadcast from the pivot lanes and applied with 6 FMAs, panel rows are
+// prefetched FUSE_PRE steps ahead into registers -- no LDS access and no barrier on its chain.
+constexpr int FUSE_THREADS = 320;
+constexpr int FUSE_SLOTS = 10;
+constexpr int FUSE_PRE = 8;
+__global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
+                                                                      const int *__restrict__ rowmax_g, int R) {
+  extern __shared__ double smem[];
+  const int P = B.P, n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double *s_b = smem;                          // [n]
+  double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
+  double *s_pz = s_win + (size_t)R * R * 36;   // [2][R][36] Z_kj
+  double *s_py = s_pz + 2 * (size_t)R * 36;    // [2][R][36] Y_kj
+  double *s_ud = s_py + 2 * (size_t)R * 36;    // [P][36] U_kk (strict upper part)
+  double *s_y = s_ud + (size_t)P * 36;         // [2][8]  z_k
+  double *s_trash = s_y + 16;                  // [48] sink of the Z stores of the pivot block lanes
+  int *rowmax = reinterpret_cast<int *>(s_trash + 48);                    // [P] envelope
+  unsigned char *lut = reinterpret_cast<unsigned char *>(rowmax + P);     // (ii, jj) of trailing block t, 1 <= ii <= jj
+  __shared__ int s_fail;
+  const long long t_begin = wall_clock64();
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < P; i += FUSE_THREADS) rowmax[i] = rowmax_g[i];
+  for (int i = tid; i < n; i += FUSE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  for (int t = tid; t < R * (R - 1) / 2; t += FUSE_THREADS) {   // t = jj (jj - 1) / 2 + (ii - 1)
+    int jj = 1;
+    while ((jj + 1) * jj / 2 <= t) ++jj;
+    lut[2 * t] = (unsigned char)(t - jj * (jj - 1) / 2 + 1);
+    lut[2 * t + 1] = (unsigned char)jj;
+  }
+  for (int r = 0; r < R && r < P; ++r) {
+    const long rb = blk_index(r, r, P);
+    for (int e = tid; e < R * 36; e += FUSE_THREADS) {
+      const int c = e / 36;
+      s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+    }
+  }
+  constexpr int LDN = (FUSE_SLOTS * 36 + 63) / 64;     // loader registers per lane and buffer
+  double ra[LDN], rb_[LDN];
+  auto load_row = [&](double (&reg)[LDN], int rn) {
+    if (rn < P) {
+      const long rb = blk_index(rn, rn, P);
+#pragma unroll
+      for (int i = 0; i < LDN; ++i) {
+        const int e = lane + 64 * i;
+        const int c = e / 36;
+        reg[i] = (e < R * 36 && rn + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+      }
+    }
+  };
+  auto store_row = [&](const double (&reg)[LDN], int k) {
+    if (k + R < P) {
+      double *row = s_win + ((size_t)(k % R) * R) * 36;
+#pragma unroll
+      for (int i = 0; i < LDN; ++i) { const int e = lane + 64 * i; if (e < R * 36) row[e] = reg[i]; }
+    }
+  };
+  if (wave == 4) { load_row(ra, R); load_row(rb_, R + 1); }
+  __syncthreads();
+
+  // ---- pivot wave state: lane (slot, c) <-> column c of block column j, j % 10 == slot; lane 60 <-> rhs
+  const int slot = lane / 6, cc = lane - slot * 6;
+  const bool col_lane = lane < 6 * FUSE_SLOTS, rhs_lane = lane == 6 * FUSE_SLOTS;
+  double ycol[6] = {0, 0, 0, 0, 0, 0};          // this lane's column of Y_k (rhs lane: w_k); 0 outside panel k
+  int failed = 0;
+  long long t_ld = 0;
+  double *const g_trash = upanel + (size_t)P * FUSE_SLOTS * 36;      // 64 spare doubles behind the panel rows
+  // stage for pivot row p: apply panel p-1 (nj_prev blocks), eliminate, emit panel p
+  auto pivot_stage = [&](int p, int nj_prev) {
+    const int jp = p % FUSE_SLOTS, pl = jp * 6;
+    int off = slot - jp;                                            // block column j = p + off
+    off += off < 0 ? FUSE_SLOTS : 0;
+    const int njp = rowmax[p] - p;
+    const bool in_env = col_lane && off <= njp, act = in_env || rhs_lane;
+    double a[6];
+    {
+      const double *src = rhs_lane ? (s_b + 6 * p) : (s_win + (((size_t)(p % R) * R) + off) * 36 + cc);
+      const int stride = rhs_lane ? 1 : 6;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a[r] = act ? src[stride * r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] += (in_env && off == 0 && r == cc) ? B.lambda : 0.0;
+    if (nj_prev > 0) {
+      // block row p gets panel p-1:  a[r] -= sum_q Z_(p-1),p [q][r] * Y_(p-1),j [q][c]
+      const double *z0 = s_pz + (size_t)((p - 1) & 1) * R * 36;      // block 0 of panel p-1 is block column p
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q += 2) { s0 = __builtin_fma(z0[6 * q + r], ycol[q], s0); s1 = __builtin_fma(z0[6 * (q + 1) + r], ycol[q + 1], s1); }
+        a[r] -= s0 + s1;
+      }
+    }
+    t_ld = wall_clock64();
+    // eliminate the 6 pivots of block (p,p) on every column of the row (multipliers broadcast from the pivot lanes)
+    double rd[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double rj = rcp_nr(readlane_f64(a[q], pl + q));
+      rd[q] = rj;
+#pragma unroll
+      for (int r = q + 1; r < 6; ++r) {
+        const double u = readlane_f64(a[q], pl + r) * rj;            // U_pp[q][r]
+        a[r] = __builtin_fma(-u, a[q], a[r]);
+      }
+    }
+    // a non-positive / non-finite pivot shows in its reciprocal; elimination continues (uniform control flow), x is zeroed at the end
+#pragma unroll
+    for (int q = 0; q < 6; ++q) failed |= !(rd[q] > 0.0 && rd[q] < 1.7976931348623157e308);
+    // emit: Z = a, Y = D^-1 a.  Panel columns -> panel buffers + global row; pivot block columns -> U_pp = D^-1 (D U);
+    // rhs -> z_p, w_p.  One exec mask for all 18 stores: every lane gets its own destinations and strides.
+    const bool in_panel = in_env && off >= 1;
+    double *dZ, *dY, *dG = g_trash + lane % 6;
+    int sZ = 6, sY = 6;
+    if (rhs_lane) { dZ = s_y + (p & 1) * 8; dY = s_b + 6 * p; sZ = 1; sY = 1; }
+    else if (off == 0) { dZ = s_trash + cc; dY = s_ud + (size_t)p * 36 + cc; }
+    else {
+      dZ = s_pz + ((size_t)(p & 1) * R + (off - 1)) * 36 + cc;
+      dY = s_py + ((size_t)(p & 1) * R + (off - 1)) * 36 + cc;
+      dG = upanel + ((size_t)p * FUSE_SLOTS + (off - 1)) * 36 + cc;
+    }
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double y = a[q] * rd[q];
+        ycol[q] = y;
+        dZ[sZ * q] = a[q];
+        dY[sY * q] = y;
+        dG[6 * q] = y;
+      }
+    } else if (col_lane) {      // outside the envelope of row p: zero block for the unconditional loads of the back substitution
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dG[6 * q] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ycol[q] = (in_panel || rhs_lane) ? ycol[q] : 0.0;
+    wave_lds_fence();
+  };
+  if (wave == 0) pivot_stage(0, 0);
+  lds_barrier();
+  const long long t_loop = wall_clock64();
+  long long acc_piv = 0, acc_bar = 0, acc_ld = 0;      // pivot-wave stage breakdown (SVS_BA_DEBUG)
+  for (int k = 0; k < P; ++k) {
+    const int nj = rowmax[k] - k;
+    const long long ts0 = wall_clock64();
+    const double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
+    if (wave == 0) {
+      if (k + 1 < P) pivot_stage(k + 1, nj);
+    } else if (wave <= 3) {
+      const int ul = tid - 64;
+      // trailing blocks (ii >= 1): lane = (block, column pair)
+      const int nb = nj * (nj - 1) / 2;
+      for (int e = ul; e < nb * 3; e += 192) {
+        const int t = e / 3, c2 = 2 * (e - t * 3);
+        const int ii = lut[2 * t], jj = lut[2 * t + 1];
+        double y0[6], y1[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { y0[q] = py[(size_t)jj * 36 + 6 * q + c2]; y1[q] = py[(size_t)jj * 36 + 6 * q + c2 + 1]; }
+        double *Aij = s_win + (((size_t)((k + 1 + ii) % R) * R) + (jj - ii)) * 36 + c2;
+        const double *zi = pz + (size_t)ii * 36;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double s0 = 0, s1 = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { s0 = __builtin_fma(zi[6 * q + r], y0[q], s0); s1 = __builtin_fma(zi[6 * q + r], y1[q], s1); }
+          Aij[6 * r] -= s0; Aij[6 * r + 1] -= s1;
+        }
+      }
+      // b~_(k+1+jj) -= Y_k,jj^T z_k  for jj >= 1 (block row k+1 is the pivot wave's)
+      for (int e = ul; e < (nj - 1) * 6; e += 192) {
+        const int jj = 1 + e / 6, c = e % 6;
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q += 2) {
+          s0 = __builtin_fma(py[(size_t)jj * 36 + 6 * q + c], zk[q], s0);
+          s1 = __builtin_fma(py[(size_t)jj * 36 + 6 * (q + 1) + c], zk[q + 1], s1);
+        }
+        s_b[6 * (k + 1 + jj) + c] -= s0 + s1;
+      }
+    } else {
+      if (k & 1) { store_row(rb_, k); load_row(rb_, k + R + 2); }
+      else { store_row(ra, k); load_row(ra, k + R + 2); }
+    }
+    const long long ts3 = wall_clock64();
+    lds_barrier();
+    acc_piv += ts3 - ts0; acc_bar += (long long)wall_clock64() - ts3; acc_ld += t_ld - ts0;
+  }
+  if (wave == 0 && __any(failed)) s_fail = 1;
+  __syncthreads();
+  const int fail = s_fail;
+  const long long t_fwd = wall_clock64();
+  if (wave == 0) {
+    if (!fail) {
+      // ---- back substitution: lane (slot, r) carries component r of row i, i % 10 == slot
+      const int r = cc;
+      // lane state: dist = (k - slot) mod 10 for the step being prefetched (row i = k - dist; dist == 0: pivot lane)
+      auto load_row_state = [&](int i, double &w, double (&u)[6]) {      // w_i[r], U_ii[r][r+1..5]
+        const bool ok = i >= 0 && col_lane;
+        w = ok ? s_b[6 * i + r] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 6; ++rr) u[rr] = (ok && rr > r) ? s_ud[(size_t)i * 36 + 6 * r + rr] : 0.0;
+      };
+      int kp = P - 1;                                              // step whose panel row is fetched next
+      int distp = (kp % FUSE_SLOTS) - slot;
+      distp += distp < 0 ? FUSE_SLOTS : 0;
+      auto load_y = [&](double (&y)[6]) {                          // Y_(i,kp)[r][:], i = kp - distp;  0 on the pivot lanes
+        const int i = kp - distp;
+        const bool ok = col_lane && distp > 0 && i >= 0;
+        const double *src = upanel + ((size_t)(ok ? i : 0) * FUSE_SLOTS + (ok ? distp - 1 : 0)) * 36 + 6 * r;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) y[c] = ok ? src[c] : 0.0;
+        --kp;
+        distp = distp == 0 ? FUSE_SLOTS - 1 : distp - 1;
+      };
+      double yq[FUSE_PRE][6];
+#pragma unroll
+      for (int d = 0; d < FUSE_PRE; ++d) load_y(yq[d]);
+      double acc, wnext, ucol[6], ucolnext[6];
+      int dist = ((P - 1) % FUSE_SLOTS) - slot;
+      dist += dist < 0 ? FUSE_SLOTS : 0;
+      load_row_state(P - 1 - dist, acc, ucol);
+      load_row_state(P - 1 - dist - FUSE_SLOTS, wnext, ucolnext);
+      int sk = (P - 1) % FUSE_SLOTS;
+      for (int kb = P - 1; kb >= 0; kb -= FUSE_PRE) {
+#pragma unroll
+        for (int d = 0; d < FUSE_PRE; ++d) {
+          const int k = kb - d;
+          if (k >= 0) {
+            const int pl = sk * 6;
+            const bool piv = col_lane && dist == 0;
+            double cm[6], xs[6];
+#pragma unroll
+            for (int rr = 1; rr < 6; ++rr) cm[rr] = piv ? ucol[rr] : 0.0;
+#pragma unroll
+            for (int rr = 5; rr >= 1; --rr) {
+              xs[rr] = readlane_f64(acc, pl + rr);
+              acc = __builtin_fma(-cm[rr], xs[rr], acc);
+            }
+            xs[0] = readlane_f64(acc, pl);
+            if (piv) {
+              s_b[6 * k + r] = acc;                                   // x_k
+              acc = wnext;
+#pragma unroll
+              for (int rr = 1; rr < 6; ++rr) ucol[rr] = ucolnext[rr];
+              load_row_state(k - 2 * FUSE_SLOTS, wnext, ucolnext);
+            }
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c += 2) { s0 = __builtin_fma(yq[d][c], xs[c], s0); s1 = __builtin_fma(yq[d][c + 1], xs[c + 1], s1); }
+            acc -= s0 + s1;
+            load_y(yq[d]);
+            sk = sk == 0 ? FUSE_SLOTS - 1 : sk - 1;
+            dist = dist == 0 ? FUSE_SLOTS - 1 : dist - 1;
+          }
+        }
+      }
+    } else {
+      for (int i = lane; i < n; i += 64) s_b[i] = 0;
+    }
+  }
+  __syncthreads();
+  const long long t_back = wall_clock64();
+  double sc = 0;
+  for (int i = tid; i < n; i += FUSE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  sc = wave_sum_f64(sc);
+  if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
+  for (int p = tid; p < P; p += FUSE_THREADS) {
+    double Tn[12];
+    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
+  }
+  if (tid == 0) {
+    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+    B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
+    B.scal[8] = acc_ld * 0.01; B.scal[9] = (acc_piv - acc_ld) * 0.01; B.scal[10] = 0; B.scal[11] = acc_bar * 0.01;
   }
 }
 
@@ -1068,7 +1473,7 @@ struct svs_ba {
   int *d_rowmax = nullptr, *d_colmin = nullptr;
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
-  bool use_lds_solve = false; size_t lds_solve_smem = 0;
+  bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
   bool profile_ready = false;
@@ -1127,24 +1532,39 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ba->free_all();
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
-  // sort edges by (anchor, landmark, observer) -- copyDataToG2o iterates hash sets, so the reference
-  // has no meaningful edge order to preserve -- and pack whole landmarks into <=64-edge wave chunks.
-  // Anchor-major order keeps the poses a workgroup touches inside its LDS accumulation window.
+  // Edge order (copyDataToG2o iterates hash sets, so the reference has no meaningful edge order to
+  // preserve): landmarks are grouped by anchor so that the poses a workgroup touches stay inside its
+  // LDS accumulation window, but inside a group of G consecutive anchors the landmarks are dealt
+  // round-robin over the anchors -- neighbouring lanes then hit different pose blocks and the LDS
+  // atomics of one instruction rarely collide on an address.  Whole landmarks are packed into
+  // <=64-edge wave chunks, observers ascending inside a landmark.
   std::vector<int> order(E);
   for (int i = 0; i < E; ++i) {
     order[i] = i;
     SVS_REQUIRE(ctx, h_edges[i].point >= 0 && h_edges[i].point < L && h_edges[i].pose >= 0 && h_edges[i].pose < P && h_edges[i].anchor >= 0 && h_edges[i].anchor < P);
   }
+  std::vector<long long> lm_key(L, 0);
   {
     std::vector<int> anchor_of(L, -1);
+    int span = 1;
     for (int i = 0; i < E; ++i) {
       int &a = anchor_of[h_edges[i].point];
       if (a < 0) a = h_edges[i].anchor;
       SVS_REQUIRE(ctx, a == h_edges[i].anchor);                          // one anchor per point (slam_graph.hpp:121-133)
+      span = std::max(span, std::abs(h_edges[i].pose - a) + 1);
+    }
+    const int G = std::max(1, std::min(8, WIN - span));                  // anchors interleaved per group
+    std::vector<int> seen(P, 0);
+    for (int l = 0; l < L; ++l) {
+      const int a = anchor_of[l];
+      if (a < 0) continue;
+      const int rank = seen[a]++;
+      lm_key[l] = ((long long)(a / G) << 40) | ((long long)rank << 8) | (long long)(a % G);
     }
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (h_edges[a].anchor != h_edges[b].anchor) return h_edges[a].anchor < h_edges[b].anchor;
+    const long long ka = lm_key[h_edges[a].point], kb = lm_key[h_edges[b].point];
+    if (ka != kb) return ka < kb;
     if (h_edges[a].point != h_edges[b].point) return h_edges[a].point < h_edges[b].point;
     return h_edges[a].pose < h_edges[b].pose;
   });
@@ -1200,7 +1620,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, hipMalloc(&ba->d_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
   SVS_HIP(ctx, hipMalloc(&ba->d_red, sizeof(double) * ba->red_count));
   SVS_HIP(ctx, hipMalloc(&ba->d_x, sizeof(double) * 6 * (size_t)P));
-  SVS_HIP(ctx, hipMalloc(&ba->d_scal, sizeof(double) * 8));
+  SVS_HIP(ctx, hipMalloc(&ba->d_scal, sizeof(double) * 16));
   SVS_HIP(ctx, hipMalloc(&ba->d_linv, sizeof(double) * 36 * (size_t)P));
   SVS_HIP(ctx, hipMalloc(&ba->d_rowmax, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, hipMalloc(&ba->d_colmin, sizeof(int) * (size_t)P));
@@ -1257,14 +1677,19 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   int R = 1;
   for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
   ba->env_R = R;
-  // LDS budget of the window solve: rhs + R*R window + panel + U_kk + 1/diag + scratch
-  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 2 * (size_t)R * 36 + (size_t)P * 42 + 8 + (size_t)R * 6) + sizeof(int) * (size_t)(P + 2);
-  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= SOLVE_THREADS * WSOLVE_PRE && (R - 1) * 6 + 1 <= SOLVE_THREADS;
+  // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
+  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 64 + (size_t)R * 6) +
+                      sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
+  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD;
   ba->lds_solve_smem = need;
+  ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
   if (ba->use_lds_solve) {
     if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; }
-    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * 36 * (size_t)P * R));
-    if (need > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * (36 * (size_t)P * std::max(R, FUSE_SLOTS) + 64)));
+    if (need > 64 * 1024) {
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    }
   }
   ba->profile_ready = true;
   return SVS_OK;
@@ -1277,8 +1702,32 @@ static int launch_reduce(svs_ba *ba, double lambda) {
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
   if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   SVS_HIP(ctx, hipEventRecord(ba->ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
+  const char *dbg_env = getenv("SVS_BA_DEBUG");
+  const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
+  if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
   if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   SVS_HIP(ctx, hipEventRecord(ba->ev[1], ctx->stream));
+  if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
+    std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
+    SVS_HIP(ctx, hipMemcpyAsync(h.data(), B.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(B.dbg);
+    long long t0 = h[0], t1 = h[DBG_N - 1];
+    for (int c = 0; c < B.n_chunks; ++c) { t0 = std::min(t0, h[(size_t)DBG_N * c]); t1 = std::max(t1, h[(size_t)DBG_N * c + DBG_N - 1]); }
+    double ph[DBG_N] = {}, s_start = 0, mx_start = 0, mx_dur = 0;
+    for (int c = 0; c < B.n_chunks; ++c) {
+      const long long *d = &h[(size_t)DBG_N * c];
+      const double st = (d[0] - t0) * 0.01, dur = (d[DBG_N - 1] - d[0]) * 0.01;
+      s_start += st; mx_start = std::max(mx_start, st); mx_dur = std::max(mx_dur, dur);
+      for (int k = 1; k < DBG_N; ++k) ph[k] += (d[k] - d[k - 1]) * 0.01;
+    }
+    const double n = B.n_chunks;
+    static const char *names[DBG_N] = {"", "load", "linearize+Hll", "reduce Hll", "Dinv+W", "reduce W_A", "anchor M_aa", "anchor Schur", "observer blocks", "pairs", "barrier", "flush"};
+    fprintf(stderr, "[svs_ba] schur kernel timeline: span %.1f us, %d waves, start avg %.1f max %.1f us, wave duration max %.1f us; phases (us avg):",
+            (t1 - t0) * 0.01, B.n_chunks, s_start / n, mx_start, mx_dur);
+    for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f |", names[k], ph[k] / n);
+    fprintf(stderr, "\n");
+  }
   return SVS_OK;
 }
 
@@ -1325,10 +1774,12 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       if (rc) return rc;
       if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
       BaDev B = make_dev(ba, lambda);
-      SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 8, ctx->stream));
+      SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));
       SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
-      if (ba->use_lds_solve)
-        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(SOLVE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+      if (ba->use_fused_solve)
+        hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+      else if (ba->use_lds_solve)
+        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
       else
         hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
       SVS_LAUNCH_CHECK(ctx);
@@ -1338,14 +1789,16 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
       SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
       if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
-      double h[8];
+      double h[16];
       SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       float ms;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[0], ba->ev[1])); ba->t_reduce += ms; ba->n_reduce++;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[2], ba->ev[3])); ba->t_solve += ms;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[5], ba->ev[4])); ba->t_backsub += ms;
-      if (getenv("SVS_BA_DEBUG")) fprintf(stderr, "[svs_ba] solve phases: init %.1f us, forward %.1f us, backward %.1f us\n", h[5], h[6], h[7]);
+      if (getenv("SVS_BA_DEBUG"))
+        fprintf(stderr, "[svs_ba] solve phases: init %.1f us, forward %.1f us (pivot wave: load+row update %.1f, eliminate+emit %.1f, - %.1f, barrier wait %.1f), backward %.1f us\n",
+                h[5], h[6], h[8], h[9], h[10], h[11], h[7]);
       const bool fail = h[3] != 0.0;
       if (qmax == 0) { currentChi = h[4]; if (it == 0) st.chi2_init = currentChi; }
       double tempChi = fail ? 1.7976931348623157e308 : h[0];
