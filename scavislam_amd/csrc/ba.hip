@@ -1176,11 +1176,13 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   double *s_ud = s_py + 2 * (size_t)R * 36;    // [P][36] U_kk (strict upper part)
   double *s_y = s_ud + (size_t)P * 36;         // [2][8]  z_k
   double *s_trash = s_y + 16;                  // [48] sink of the Z stores of the pivot block lanes
-  int *rowmax = reinterpret_cast<int *>(s_trash + 48);                    // [P] envelope
+  double *s_zero = s_trash + 48;               // [48] zeros: source of the lanes outside the envelope (keeps the LDS loads unconditional)
+  int *rowmax = reinterpret_cast<int *>(s_zero + 48);                     // [P] envelope
   unsigned char *lut = reinterpret_cast<unsigned char *>(rowmax + P);     // (ii, jj) of trailing block t, 1 <= ii <= jj
   __shared__ int s_fail;
   const long long t_begin = wall_clock64();
   if (tid == 0) s_fail = 0;
+  if (tid < 48) s_zero[tid] = 0.0;
   for (int i = tid; i < P; i += FUSE_THREADS) rowmax[i] = rowmax_g[i];
   for (int i = tid; i < n; i += FUSE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
   for (int t = tid; t < R * (R - 1) / 2; t += FUSE_THREADS) {   // t = jj (jj - 1) / 2 + (ii - 1)
@@ -1209,9 +1211,9 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
       }
     }
   };
-  auto store_row = [&](const double (&reg)[LDN], int k) {
+  auto store_row = [&](const double (&reg)[LDN], int k, int ringk) {      // ringk = k % R
     if (k + R < P) {
-      double *row = s_win + ((size_t)(k % R) * R) * 36;
+      double *row = s_win + (ringk * R) * 36;
 #pragma unroll
       for (int i = 0; i < LDN; ++i) { const int e = lane + 64 * i; if (e < R * 36) row[e] = reg[i]; }
     }
@@ -1225,33 +1227,34 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   double ycol[6] = {0, 0, 0, 0, 0, 0};          // this lane's column of Y_k (rhs lane: w_k); 0 outside panel k
   int failed = 0;
   long long t_ld = 0;
-  double *const g_trash = upanel + (size_t)P * FUSE_SLOTS * 36;      // 64 spare doubles behind the panel rows
+  double *const g_trash = upanel + (size_t)P * FUSE_SLOTS * 36;      // 64 spare doubles behind the panel rows (write sink)
+  const double *const g_zero = g_trash + 64;                         // 64 zeros (never written)
   // stage for pivot row p: apply panel p-1 (nj_prev blocks), eliminate, emit panel p
-  auto pivot_stage = [&](int p, int nj_prev) {
-    const int jp = p % FUSE_SLOTS, pl = jp * 6;
+  auto pivot_stage = [&](int p, int nj_prev, int njp, int jp, int ringp) {      // jp = p % 10, ringp = p % R (kept as counters)
+    const int pl = jp * 6;
     int off = slot - jp;                                            // block column j = p + off
     off += off < 0 ? FUSE_SLOTS : 0;
-    const int njp = rowmax[p] - p;
     const bool in_env = col_lane && off <= njp, act = in_env || rhs_lane;
     double a[6];
     {
-      const double *src = rhs_lane ? (s_b + 6 * p) : (s_win + (((size_t)(p % R) * R) + off) * 36 + cc);
+      const double *src = rhs_lane ? (s_b + 6 * p) : in_env ? (s_win + ((ringp * R) + off) * 36 + cc) : s_zero;
       const int stride = rhs_lane ? 1 : 6;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) a[r] = act ? src[stride * r] : 0.0;
+      for (int r = 0; r < 6; ++r) a[r] = src[stride * r];
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) a[r] += (in_env && off == 0 && r == cc) ? B.lambda : 0.0;
     if (nj_prev > 0) {
       // block row p gets panel p-1:  a[r] -= sum_q Z_(p-1),p [q][r] * Y_(p-1),j [q][c]
       const double *z0 = s_pz + (size_t)((p - 1) & 1) * R * 36;      // block 0 of panel p-1 is block column p
+      double z[36];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double s0 = 0, s1 = 0;
+      for (int i = 0; i < 36; ++i) z[i] = z0[i];
+      __builtin_amdgcn_sched_barrier(0);                            // all 18 LDS loads in flight before the first FMA waits
 #pragma unroll
-        for (int q = 0; q < 6; q += 2) { s0 = __builtin_fma(z0[6 * q + r], ycol[q], s0); s1 = __builtin_fma(z0[6 * (q + 1) + r], ycol[q + 1], s1); }
-        a[r] -= s0 + s1;
-      }
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[r] = __builtin_fma(-z[6 * q + r], ycol[q], a[r]);
     }
     t_ld = wall_clock64();
     // eliminate the 6 pivots of block (p,p) on every column of the row (multipliers broadcast from the pivot lanes)
@@ -1298,18 +1301,36 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     for (int q = 0; q < 6; ++q) ycol[q] = (in_panel || rhs_lane) ? ycol[q] : 0.0;
     wave_lds_fence();
   };
-  if (wave == 0) pivot_stage(0, 0);
+  auto env_len = [&](int k) { return k < P ? rowmax[k] - k : 0; };
+  if (wave == 0) pivot_stage(0, 0, env_len(0), 0, 0);
   lds_barrier();
   const long long t_loop = wall_clock64();
   long long acc_piv = 0, acc_bar = 0, acc_ld = 0;      // pivot-wave stage breakdown (SVS_BA_DEBUG)
-  for (int k = 0; k < P; ++k) {
-    const int nj = rowmax[k] - k;
-    const long long ts0 = wall_clock64();
-    const double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
-    if (wave == 0) {
-      if (k + 1 < P) pivot_stage(k + 1, nj);
-    } else if (wave <= 3) {
-      const int ul = tid - 64;
+  // One loop per role (P stages, one lds_barrier each).  Separate loops keep the compiler's wait-count
+  // bookkeeping apart: in a shared loop body the pivot wave waited every stage for vmcnt(0) -- the round
+  // trip of its own panel stores -- because the loader's loads were pending on the merged path.
+  if (wave == 0) {
+    int nj_a = env_len(0), nj_b = env_len(1), nj_c = env_len(2);      // envelope lengths of rows k, k+1, k+2 (read ahead of use)
+    int ring1 = 1 % R, slot1 = 1 % FUSE_SLOTS;                         // (k + 1) % R and (k + 1) % 10
+    for (int k = 0; k < P; ++k) {
+      const int nj = nj_a, nj_nx = nj_b;
+      nj_a = nj_b; nj_b = nj_c; nj_c = env_len(k + 3);
+      const long long ts0 = wall_clock64();
+      if (k + 1 < P) pivot_stage(k + 1, nj, nj_nx, slot1, ring1);
+      ring1 = ring1 + 1 == R ? 0 : ring1 + 1;
+      slot1 = slot1 + 1 == FUSE_SLOTS ? 0 : slot1 + 1;
+      const long long ts3 = wall_clock64();
+      lds_barrier();
+      acc_piv += ts3 - ts0; acc_bar += (long long)wall_clock64() - ts3; acc_ld += t_ld - ts0;
+    }
+  } else if (wave <= 3) {
+    const int ul = tid - 64;
+    int nj_a = env_len(0), nj_b = env_len(1);
+    int ring1 = 1 % R;
+    for (int k = 0; k < P; ++k) {
+      const int nj = nj_a;
+      nj_a = nj_b; nj_b = env_len(k + 2);
+      const double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
       // trailing blocks (ii >= 1): lane = (block, column pair)
       const int nb = nj * (nj - 1) / 2;
       for (int e = ul; e < nb * 3; e += 192) {
@@ -1318,7 +1339,9 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
         double y0[6], y1[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) { y0[q] = py[(size_t)jj * 36 + 6 * q + c2]; y1[q] = py[(size_t)jj * 36 + 6 * q + c2 + 1]; }
-        double *Aij = s_win + (((size_t)((k + 1 + ii) % R) * R) + (jj - ii)) * 36 + c2;
+        int ring = ring1 + ii;
+        ring -= ring >= R ? R : 0;
+        double *Aij = s_win + ((ring * R) + (jj - ii)) * 36 + c2;
         const double *zi = pz + (size_t)ii * 36;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -1339,13 +1362,17 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
         }
         s_b[6 * (k + 1 + jj) + c] -= s0 + s1;
       }
-    } else {
-      if (k & 1) { store_row(rb_, k); load_row(rb_, k + R + 2); }
-      else { store_row(ra, k); load_row(ra, k + R + 2); }
+      ring1 = ring1 + 1 == R ? 0 : ring1 + 1;
+      lds_barrier();
     }
-    const long long ts3 = wall_clock64();
-    lds_barrier();
-    acc_piv += ts3 - ts0; acc_bar += (long long)wall_clock64() - ts3; acc_ld += t_ld - ts0;
+  } else {
+    int ringk = 0;
+    for (int k = 0; k < P; ++k) {
+      if (k & 1) { store_row(rb_, k, ringk); load_row(rb_, k + R + 2); }
+      else { store_row(ra, k, ringk); load_row(ra, k + R + 2); }
+      ringk = ringk + 1 == R ? 0 : ringk + 1;
+      lds_barrier();
+    }
   }
   if (wave == 0 && __any(failed)) s_fail = 1;
   __syncthreads();
@@ -1368,9 +1395,11 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
       auto load_y = [&](double (&y)[6]) {                          // Y_(i,kp)[r][:], i = kp - distp;  0 on the pivot lanes
         const int i = kp - distp;
         const bool ok = col_lane && distp > 0 && i >= 0;
-        const double *src = upanel + ((size_t)(ok ? i : 0) * FUSE_SLOTS + (ok ? distp - 1 : 0)) * 36 + 6 * r;
+        // unconditional loads (lanes without a block read a zero block): predicated loads would make the compiler drain
+        // vmcnt to 0 every step and put a full global round trip on the chain
+        const double *src = ok ? upanel + ((size_t)i * FUSE_SLOTS + (distp - 1)) * 36 + 6 * r : g_zero;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) y[c] = ok ? src[c] : 0.0;
+        for (int c = 0; c < 6; ++c) y[c] = src[c];
         --kp;
         distp = distp == 0 ? FUSE_SLOTS - 1 : distp - 1;
       };
@@ -1678,14 +1707,16 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
   ba->env_R = R;
   // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
-  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 64 + (size_t)R * 6) +
+  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 128 + (size_t)R * 6) +
                       sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
   ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD;
   ba->lds_solve_smem = need;
   ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
   if (ba->use_lds_solve) {
     if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; }
-    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * (36 * (size_t)P * std::max(R, FUSE_SLOTS) + 64)));
+    const size_t up_count = 36 * (size_t)P * std::max(R, FUSE_SLOTS) + 128;      // + write sink + zero block of the fused kernel
+    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * up_count));
+    SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel, 0, sizeof(double) * up_count, ctx->stream));
     if (need > 64 * 1024) {
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
