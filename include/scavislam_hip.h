@@ -130,6 +130,29 @@ int svs_convert_sobel_f32(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int 
                           size_t s_bstride, float *d_img, float *d_dx, float *d_dy, int fstride,
                           size_t f_bstride, int batch);
 
+/* ---- stereo block matching: replaces StereoFrontend::calcDisparityCpu (stereo_frontend.cpp:620-653),
+   i.e. cv::StereoBM(left pyr level 0, right, disp, CV_32F) with the state set there.  [cv::StereoBM is
+   OpenCV 2.4.2, external; semantics as restated in oracle/stereo.c incl. its definitions D1/D2.] ---------*/
+typedef struct {
+  int32_t prefilter_cap;      /* stereo_frontend.cpp:626  (31)  */
+  int32_t sad_window;         /* :627  (7; only 7 supported)    */
+  int32_t min_disparity;      /* :628  (0; only 0 supported)    */
+  int32_t num_disparities;    /* :636  (num_disp16*16 = 32; only 32 supported) */
+  int32_t texture_threshold;  /* :630  (10) */
+  int32_t uniqueness_ratio;   /* :631  (15) */
+  int32_t speckle_window;     /* :632  (100; 0 = no speckle filter) */
+  int32_t speckle_range;      /* :633  (32)  */
+  int32_t disp12_max_diff;    /* :634  (1; < 0 = no left-right check) */
+} svs_stereo_params;
+typedef struct svs_stereo svs_stereo;
+/* scratch for `max_batch` independent w x h frames (prefiltered images, 16-bit disparity, cost, labels) */
+int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out);
+int svs_stereo_destroy(svs_stereo *s);
+/* d_disp[b][y*dstride + x] = disparity in pixels, (min_disparity - 1) where filtered (all device pointers;
+   strides in elements, batch strides in elements of the respective type) */
+int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstride, size_t l_bstride, const uint8_t *d_right,
+                       int rstride, size_t r_bstride, float *d_disp, int dstride, size_t d_bstride, int n_batch);
+
 /* ---- grid FAST: replaces FastGrid (fast_grid.h:27-63) ----------------------------------------*/
 typedef struct svs_fast svs_fast;
 /* one FastGrid per level (stereo_frontend.cpp:73-88); `batch` independent threshold states */

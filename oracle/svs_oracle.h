@@ -237,6 +237,24 @@ int svs_ref_ba_optimize(int P, double *poses, int L, double *psi, int E,
                         const svs_ba_edge *edges, int C, const svs_ba_constraint *cons,
                         const svs_cam *cam, const svs_ba_params *prm, svs_ba_stats *stats);
 
+/* ---- stereo block matching: cv::StereoBM as configured at stereo_frontend.cpp:620-653 (oracle/stereo.c) ---- */
+typedef struct {
+  int32_t prefilter_cap;      /* 31 */
+  int32_t sad_window;         /* 7 */
+  int32_t min_disparity;      /* 0 */
+  int32_t num_disparities;    /* 32 (num_disp16 * 16) */
+  int32_t texture_threshold;  /* 10 */
+  int32_t uniqueness_ratio;   /* 15 */
+  int32_t speckle_window;     /* 100 */
+  int32_t speckle_range;      /* 32 */
+  int32_t disp12_max_diff;    /* 1 */
+} svs_stereo_params;
+void svs_ref_stereo_prefilter_xsobel(const uint8_t *src, int w, int h, int stride, int cap, uint8_t *dst);
+void svs_ref_stereo_bm_core(const uint8_t *lp, const uint8_t *rp, int w, int h, const svs_stereo_params *p, int16_t *disp16, int32_t *cost);
+void svs_ref_stereo_validate(int16_t *disp16, const int32_t *cost, int w, int h, const svs_stereo_params *p);
+void svs_ref_stereo_filter_speckles(int16_t *disp16, int w, int h, int new_val, int max_size, int max_diff);
+void svs_ref_stereo_bm(const uint8_t *left, const uint8_t *right, int w, int h, int stride, const svs_stereo_params *p, float *disp, int dstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,3 +81,14 @@ def level_cams(f, cx, cy, b, w, h, levels=3):
         s = float(1 << l)
         out[l] = Cam(f / s, cx / s, cy / s, b * (1 << l), int(w / s), int(h / s))
     return out
+
+
+class StereoParams(C.Structure):
+    """svs_stereo_params: cv::StereoBM state as set at stereo_frontend.cpp:620-653."""
+    _fields_ = [("prefilter_cap", C.c_int32), ("sad_window", C.c_int32), ("min_disparity", C.c_int32),
+                ("num_disparities", C.c_int32), ("texture_threshold", C.c_int32), ("uniqueness_ratio", C.c_int32),
+                ("speckle_window", C.c_int32), ("speckle_range", C.c_int32), ("disp12_max_diff", C.c_int32)]
+
+    @classmethod
+    def reference(cls, num_disp16=2):
+        return cls(31, 7, 0, 16 * num_disp16, 10, 15, 100, 32, 1)

@@ -8,6 +8,7 @@ stereo_frontend.cpp), device memory held in torch tensors:
   GuidedMatcher.match                    <- GuidedMatcher<StereoCamera>   matcher.hpp:67-83
   DenseTracker.denseTrackingCpu / computeDensePointCloudCpu               dense_tracking.h:59-79
   GpuTracker.jacobianReduction / chi2 / computePointCloud                 gpu/dense_tracking.cuh:281-342
+  StereoMatcher.calcDisparityCpu         <- StereoFrontend::calcDisparityCpu  stereo_frontend.cpp:620-653
 
 The HIP library does all the arithmetic; nothing here computes on the CPU.
 """
@@ -18,7 +19,7 @@ import torch
 
 from . import capi
 from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, Cam,
-                           FastGrid as FastGridPOD, level_cams)
+                           FastGrid as FastGridPOD, StereoParams, level_cams)
 
 NUM_PYR_LEVELS = 3  # global.h:107
 
@@ -325,3 +326,43 @@ class GpuTracker:
         TQ = np.ascontiguousarray(TQ_colmajor, np.float32).reshape(16)
         self.ctx.call("svs_pointcloud_full", TQ.ctypes.data, disp.data_ptr(), w, h, stride_in, stride_out, factor,
                       cloud.data_ptr())
+
+
+class StereoMatcher:
+    """StereoFrontend::calcDisparityCpu (stereo_frontend.cpp:620-653): cv::StereoBM on the level-0 left image
+    and the right image, float disparity written into the frame's `disp` (-1 where filtered)."""
+
+    def __init__(self, ctx, frame, params=None):
+        self.ctx, self.frame = ctx, frame
+        self.params = params or StereoParams.reference()
+        self.h = C.c_void_p()
+        ctx.call("svs_stereo_create", frame.w[0], frame.h[0], frame.batch, C.byref(self.params), C.byref(self.h))
+        ctx.children.add(self)
+        with torch.cuda.stream(frame.stream):
+            self.right = torch.zeros_like(frame.pyr[0])
+
+    def upload_right(self, images):
+        with torch.cuda.stream(self.frame.stream):
+            img = torch.as_tensor(np.ascontiguousarray(images)).to(self.right.device)
+            self.right[:, :, :self.frame.w[0]] = img.reshape(self.frame.batch, self.frame.h[0], self.frame.w[0])
+
+    def calcDisparityCpu(self, n_batch=None):
+        f = self.frame
+        self.ctx.check(self.ctx.lib.svs_stereo_compute(self.h, f.pyr[0].data_ptr(), f.stride[0], f.bstride(0),
+                                                       self.right.data_ptr(), f.stride[0], f.bstride(0), f.disp.data_ptr(),
+                                                       f.stride[0], f.bstride(0), n_batch or f.batch))
+
+    def disparity_host(self, slot=0):
+        self.ctx.sync()
+        return self.frame.disp[slot, :, :self.frame.w[0]].cpu().numpy()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.svs_stereo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

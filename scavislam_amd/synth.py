@@ -96,8 +96,8 @@ class Scene:
             ts = self.tex[k].shape[0]
             a = (p[..., ax[0]] * self.tex_scale) % (ts - 1)
             b = (p[..., ax[1]] * self.tex_scale) % (ts - 1)
-            a0 = np.floor(a).astype(int)
-            b0 = np.floor(b).astype(int)
+            a0 = np.minimum(np.floor(a).astype(int), ts - 2)      # a % (ts-1) can round up to ts-1 itself
+            b0 = np.minimum(np.floor(b).astype(int), ts - 2)
             fa, fb = a - a0, b - b0
             tx = self.tex[k]
             val = (tx[b0, a0] * (1 - fa) * (1 - fb) + tx[b0, a0 + 1] * fa * (1 - fb) +
@@ -109,6 +109,14 @@ class Scene:
         nrng = np.random.default_rng(seed + 77)
         img = img + nrng.normal(0, noise_sigma, img.shape)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8), disp
+
+
+def render_stereo(scene, cam, T_cam_from_world, noise_sigma=2.0, seed=0):
+    """(left u8, right u8, true left disparity f32): the right camera sits `b` along the left camera's x axis."""
+    left, disp = scene.render(cam, T_cam_from_world, noise_sigma, seed)
+    T_right_from_left = pose(np.eye(3), np.array([-cam["b"], 0.0, 0.0]))
+    right, _ = scene.render(cam, pose_mul(T_right_from_left, T_cam_from_world), noise_sigma, seed + 1000)
+    return left, right, disp
 
 
 def trajectory(n, step=0.05, yaw_deg=0.2):

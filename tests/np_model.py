@@ -179,3 +179,120 @@ def ba_dense_step(poses, psi, edges, cons, cam, lam, delta=1.0, robust=True, eps
     x = np.zeros(n)
     x[used] = np.linalg.solve(Hd[np.ix_(used, used)], b[used])
     return x[:6 * P].reshape(P, 6), x[6 * P:].reshape(L, 3), H, b
+
+
+# ---- stereo block matching: independent vectorised model of cv::StereoBM as used at stereo_frontend.cpp:620-653 ----
+def stereo_prefilter(img, cap=31):
+    """XSOBEL prefilter: 3x3 x-Sobel (reflect-101 rows), saturated to [0, 2 cap]; border columns / odd last row = cap."""
+    a = img.astype(np.int32)
+    h, w = a.shape
+    p = np.pad(a, ((1, 1), (0, 0)), mode="reflect")
+    gx = np.zeros_like(a)
+    gx[:, 1:-1] = (p[:-2, 2:] - p[:-2, :-2]) + 2 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])
+    out = np.clip(gx, -cap, cap) + cap
+    out[:, 0] = out[:, -1] = cap
+    if h % 2:
+        out[-1, :] = cap
+    return out.astype(np.uint8)
+
+
+def stereo_bm_core(lp, rp, ndisp=32, wsz=7, cap=31, texthr=10, uniq=15):
+    """(disp16, cost) of findStereoCorrespondenceBM on prefiltered images, via an explicit cost volume."""
+    h, w = lp.shape
+    r = wsz // 2
+    lofs, width1 = ndisp - 1, w - ndisp + 1
+    L, R = lp.astype(np.int32), rp.astype(np.int32)
+    disp16 = np.full((h, w), -16, np.int16)
+    cost = np.zeros((h, w), np.int32)
+    if width1 <= 0:
+        return disp16, cost
+    xs = np.arange(-r, width1 + r)                       # window columns relative to the output index x
+    lcol = np.clip(xs, -lofs, w - lofs - 1) + lofs
+    rcol = np.clip(xs, 0, w - 1)
+    vol = np.empty((ndisp, h, len(xs)), np.int32)
+    for d in range(ndisp):
+        vol[d] = np.abs(L[:, lcol] - R[:, np.minimum(rcol + d, w - 1)])
+    tex = np.abs(L[:, lcol] - cap)
+
+    def box(a):                                          # 7x7 window sum, rows replicated, columns already extended
+        a = np.pad(a, [(0, 0)] * (a.ndim - 2) + [(r, r), (0, 0)], mode="edge")
+        c = np.cumsum(np.pad(a, [(0, 0)] * (a.ndim - 2) + [(1, 0), (1, 0)]), axis=-2).cumsum(axis=-1)
+        return c[..., wsz:, wsz:] - c[..., :-wsz, wsz:] - c[..., wsz:, :-wsz] + c[..., :-wsz, :-wsz]
+
+    sad = box(vol)                                       # [ndisp, h, width1]
+    tsum = box(tex)
+    mind = np.argmin(sad, axis=0)                        # first minimum
+    minsad = np.take_along_axis(sad, mind[None], 0)[0]
+    ok = tsum >= texthr
+    if uniq > 0:
+        thresh = minsad + minsad * uniq // 100
+        dd = np.arange(ndisp)[:, None, None]
+        rival = (sad <= thresh[None]) & ((dd < mind[None] - 1) | (dd > mind[None] + 1))
+        ok &= ~rival.any(axis=0)
+    ip = np.where(mind == ndisp - 1, ndisp - 2, mind + 1)
+    im = np.where(mind == 0, 1, mind - 1)
+    p = np.take_along_axis(sad, ip[None], 0)[0]
+    n = np.take_along_axis(sad, im[None], 0)[0]
+    den = p + n - 2 * minsad + np.abs(p - n)
+    num = (p - n) * 256
+    frac = np.where(den != 0, np.sign(num) * (np.abs(num) // np.maximum(den, 1)), 0)      # C division truncates toward zero
+    val = ((ndisp - mind - 1) * 256 + frac + 15) >> 4
+    disp16[:, lofs:lofs + width1] = np.where(ok, val, -16).astype(np.int16)
+    cost[:, lofs:lofs + width1] = np.where(ok, minsad, 0)
+    return disp16, cost
+
+
+def stereo_validate(disp16, cost, ndisp=32, maxdiff=1):
+    d16 = disp16.astype(np.int32).copy()
+    h, w = d16.shape
+    INV = -16
+    for y in range(h):
+        d = d16[y]
+        d2 = np.full(w, INV, np.int64)
+        c2 = np.full(w, np.iinfo(np.int64).max, np.int64)
+        for x in range(ndisp, w):
+            if d[x] == INV:
+                continue
+            x2 = x - ((d[x] + 8) >> 4)
+            if 0 <= x2 < w and c2[x2] > cost[y, x]:
+                c2[x2], d2[x2] = cost[y, x], d[x]
+        out = d.copy()
+        for x in range(ndisp, w):
+            if d[x] == INV:
+                continue
+            bad = []
+            for xx in (x - (d[x] >> 4), x - ((d[x] + 15) >> 4)):
+                bad.append(0 <= xx < w and d2[xx] > INV and abs(d2[xx] - d[x]) > maxdiff * 16)
+            if all(bad):
+                out[x] = INV
+        d16[y] = out
+    return d16.astype(np.int16)
+
+
+def stereo_filter_speckles(disp16, max_size=100, max_diff=32, new_val=-16):
+    """Components of the pixel graph (4-neighbours whose values differ by <= max_diff); small ones -> new_val."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    d = disp16.astype(np.int32)
+    h, w = d.shape
+    idx = np.arange(h * w).reshape(h, w)
+    valid = d != new_val
+    eh = valid[:, :-1] & valid[:, 1:] & (np.abs(d[:, :-1] - d[:, 1:]) <= max_diff)
+    ev = valid[:-1, :] & valid[1:, :] & (np.abs(d[:-1, :] - d[1:, :]) <= max_diff)
+    rows = np.concatenate([idx[:, :-1][eh], idx[:-1, :][ev]])
+    cols = np.concatenate([idx[:, 1:][eh], idx[1:, :][ev]])
+    g = coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(h * w, h * w))
+    _, lab = connected_components(g, directed=False)
+    sizes = np.bincount(lab)
+    small = (sizes[lab] <= max_size).reshape(h, w) & valid
+    out = disp16.copy()
+    out[small] = new_val
+    return out
+
+
+def stereo_bm(left, right):
+    lp, rp = stereo_prefilter(left), stereo_prefilter(right)
+    d16, cost = stereo_bm_core(lp, rp)
+    d16 = stereo_validate(d16, cost)
+    d16 = stereo_filter_speckles(d16)
+    return d16.astype(np.float32) / 16.0
