@@ -27,4 +27,14 @@ xp, xl, H, b = M.ba_dense_step(prob["poses"], prob["psi"], prob["edges"], prob["
 np.savez_compressed(os.path.join(HERE, "ba_small.npz"), poses=prob["poses"], psi=prob["psi"],
                     edges=prob["edges"].view(np.uint8), cons=prob["cons"].view(np.uint8),
                     cam=np.array([c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"]]), xp_dense_model=xp, xl_dense_model=xl)
+# stereo block matching: 128 x 65 pair (odd height) through the NumPy model of cv::StereoBM
+sc = synth.Scene(11)
+scam = dict(synth.CAM_DEFAULT)
+scam.update(w=128, h=65, cx=64.0, cy=32.0, f=120.0, b=0.25)
+sl, sr, _ = synth.render_stereo(sc, scam, synth.trajectory(2)[1], seed=5)
+slp, srp = M.stereo_prefilter(sl), M.stereo_prefilter(sr)
+sd16, scost = M.stereo_bm_core(slp, srp)
+sval = M.stereo_validate(sd16, scost)
+np.savez_compressed(os.path.join(HERE, "stereo_small.npz"), left=sl, right=sr, lp=slp, rp=srp, disp16_raw=sd16, cost=scost,
+                    disp16_validated=sval, disp16_final=M.stereo_filter_speckles(sval))
 print("golden written")
