@@ -44,7 +44,7 @@ def main():
     from scavislam_amd import capi, synth
     from scavislam_amd.backend import SlamGraphOptimizer, make_allreduce, shard_problem
     from scavislam_amd.ctypes_types import BaParams, Cam
-    from scavislam_amd.frontend import DenseTracker, FastGrid, FramePyramid, GuidedMatcher
+    from scavislam_amd.frontend import DenseTracker, FastGrid, FramePyramid, GuidedMatcher, StereoMatcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,6 +82,8 @@ def main():
     NPAIR = 2
     kf_id = 0
     rend = {i: scene.render(cam, traj[i], seed=i) for i in [kf_id] + [4 + p for p in range(NPAIR + 1)]}
+    T_right = synth.pose(np.eye(3), np.array([-cam["b"], 0.0, 0.0]))      # right camera of the stereo rig (for the block matcher)
+    rend_right = {i: scene.render(cam, synth.pose_mul(T_right, traj[i]), seed=1000 + i)[0] for i in [5 + p for p in range(NPAIR)]}
     I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
     def build_frontend(B):
         prev_imgs = np.stack([rend[4 + (b % NPAIR)][0] for b in range(B)])
@@ -187,6 +189,20 @@ def main():
     time_stage("fast", lambda: fast.detectAdaptively(trials=6))
     time_stage("match", lambda: matcher.launch(margs))
     time_stage("pointcloud", _pc_dev)
+    # "stereo" stage of processFrame (calcDisparityCpu = cv::StereoBM): SURVEY 8f rank 1.  Timed on its own; the
+    # headline step uses the have_disp_img path (disparity given), as BASELINE's configs do.
+    stereo = StereoMatcher(ctx, cur)
+    stereo.upload_right(np.stack([rend_right[5 + (b % NPAIR)] for b in range(B)]))
+    disp_given = cur.disp.clone()
+    time_stage("stereo_bm", stereo.calcDisparityCpu, reps=5)
+    with torch.cuda.stream(stream):
+        d_bm = cur.disp[0, :, :cur.w[0]].cpu().numpy()
+        d_gt = disp_given[0, :, :cur.w[0]].cpu().numpy()
+        cur.disp.copy_(disp_given)
+    bm_valid = d_bm >= 0
+    stereo_info = {"valid_fraction": round(float(bm_valid.mean()), 4),
+                   "median_abs_err_px_vs_true_disparity": round(float(np.median(np.abs(d_bm - d_gt)[bm_valid])), 4)}
+    stereo.close()
     px = sum(cur.w[l] * cur.h[l] for l in range(3))
     n_corners = sum(len(fast.corners(0, l)[0]) for l in range(3))
     passes = int(dtrack.d_passes.cpu().numpy().mean())
@@ -198,6 +214,7 @@ def main():
         "match": args.points * (60 + 121 + 20) + args.points * 10 * 64,
         "dense_tracking": passes * (px // 16) * (16 + 1 + 16) // 3,     # cloud float4 + prev u8 + 4x4 u8 taps; passes spread over 3 levels
         "pointcloud": (px // 16) * 20,
+        "stereo_bm": cur.w[0] * cur.h[0] * (2 + 4),     # left + right u8 in, f32 disparity out
     }
     roofline_frontend = {k: {"ms": round(stage_ms[k], 4), "alg_bytes_per_frame": int(alg[k]),
                              "achieved_GBs": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 2),
@@ -297,10 +314,16 @@ def main():
             O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
             nba += 1
         cpu_schur_ms = (time.perf_counter() - t0) / nba * 1e3
+        t0 = time.perf_counter()
+        nst = 0
+        while nst < 2 or (time.perf_counter() - t0 < 3.0 and nst < 6):      # "stereo" (cv::StereoBM restatement), timed on its own like the GPU stage
+            O.stereo_bm(rend[5 + nst % NPAIR][0], rend_right[5 + nst % NPAIR])
+            nst += 1
+        cpu_stereo_ms = (time.perf_counter() - t0) / nst * 1e3
         cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{nfr} frames 640x480 through the CPU oracle (same stages, same inputs)"
                          f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
-               "schur_ms_per_optimize": round(cpu_schur_ms, 2)}
+               "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1)}
 
     if rank == 0:
         out = {
@@ -325,6 +348,8 @@ def main():
                          "dense_passes_per_frame": passes, "corners_per_frame": n_corners, "matches_per_frame": n_matched,
                          "dense_track_pose_err": track_err,
                          "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
+                         "stereo_bm": dict(stereo_info, ms_per_batch=round(stage_ms["stereo_bm"], 4),
+                                           frames_per_s_if_block_matching_is_added_to_the_step=round(world * B / ((t_front / K) + stage_ms["stereo_bm"] * 1e-3), 1)),
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
             "roofline": roofline,
             "roofline_frontend": roofline_frontend,

@@ -12,8 +12,8 @@
 //                            argmin / uniqueness / parabola per pixel
 //   stereo_bm_edge_kernel    the 3 leftmost output columns, whose right-image window clamps before the shift
 //   stereo_validate_kernel   validateDisparity, one workgroup per row
-//   stereo_ccl_*             speckle filter = connected components (union-find with atomicMin) + size test,
-//                            fused with the 1/16 float conversion
+//   stereo_ccl_*             speckle filter = connected components (horizontal runs, then union-find with atomicMin
+//                            across rows) + saturating size count; the size test is fused with the 1/16 float conversion
 #include "common.h"
 
 namespace {
@@ -62,26 +62,58 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 union Pk { uint64_t q; us2 h[2]; uint32_t u[2]; };
 
-// winner selection of one pixel from its 32 window SADs (findStereoCorrespondenceBM inner loop)
-__device__ __forceinline__ void bm_select(const uint32_t (&sad)[NDISP], int tsum, const StereoDev &S, int16_t &disp, uint16_t &cost) {
+// the window bytes one lane needs from one image row: 7 left bytes (8th masked) and 44 right bytes
+struct RowWin { uint32_t l0, l1, r[11]; };
+__device__ __forceinline__ RowWin load_rowwin(const uint8_t *lrow, const uint8_t *rrow) {
+  RowWin wv;
+  wv.l0 = load_u32_unaligned(lrow);
+  wv.l1 = load_u32_unaligned(lrow + 4);
+#pragma unroll
+  for (int k = 0; k < 11; ++k) wv.r[k] = load_u32_unaligned(rrow + 4 * k);
+  return wv;
+}
+// horizontal 7-tap SADs of one row for the 32 disparity indices (4 per V_QSAD/V_MQSAD pair) + texture term
+__device__ __forceinline__ void row_sads(const RowWin &wv, uint32_t ft4, Pk (&hh)[8], int &t) {
+  const uint32_t l1 = wv.l1 & 0x00ffffffu;      // byte 7 = 0 = masked out by MQSAD
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const uint64_t hq = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)wv.r[g] | ((uint64_t)wv.r[g + 1] << 32), wv.l0, 0ull);
+    hh[g].q = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)wv.r[g + 1] | ((uint64_t)wv.r[g + 2] << 32), l1, hq);
+  }
+  t = (int)__builtin_amdgcn_sad_u8(l1 | (ft4 & 0xff000000u), ft4, __builtin_amdgcn_sad_u8(wv.l0, ft4, 0u));
+}
+
+// per-lane LDS scratch of bm_select; a union, so that the halfword and dword views may alias
+union SelScr { uint32_t u[17]; unsigned short s[34]; };
+// winner selection of one pixel from its 32 window SADs (findStereoCorrespondenceBM inner loop).  Dynamic indexing
+// (sad[mind +- 1], masking the winner's neighbourhood) goes through the per-lane LDS scratch.
+__device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const StereoDev &S, SelScr &scr, int16_t &disp, uint16_t &cost) {
   disp = (int16_t)FILTERED16; cost = 0;
   uint32_t best = 0xffffffffu;
 #pragma unroll
-  for (int d = 0; d < NDISP; ++d) best = min(best, (sad[d] << 5) | (uint32_t)d);      // first minimum wins
+  for (int g = 0; g < 8; ++g) {      // first minimum wins: key = sad * 32 + d
+    best = min(best, ((sad[g].u[0] & 0xffffu) << 5) | (uint32_t)(4 * g));
+    best = min(best, ((sad[g].u[0] >> 16) << 5) | (uint32_t)(4 * g + 1));
+    best = min(best, ((sad[g].u[1] & 0xffffu) << 5) | (uint32_t)(4 * g + 2));
+    best = min(best, ((sad[g].u[1] >> 16) << 5) | (uint32_t)(4 * g + 3));
+  }
   const int minsad = (int)(best >> 5), mind = (int)(best & 31);
   if (tsum < S.texthr) return;
-  int p = 0, n = 0;      // sad[mind + 1], sad[mind - 1] with the mirrored ends sad[-1] = sad[1], sad[32] = sad[30]
-  const int ip = mind == NDISP - 1 ? NDISP - 2 : mind + 1, in = mind == 0 ? 1 : mind - 1;
 #pragma unroll
-  for (int d = 0; d < NDISP; ++d) { p = d == ip ? (int)sad[d] : p; n = d == in ? (int)sad[d] : n; }
+  for (int g = 0; g < 8; ++g) { scr.u[2 * g] = sad[g].u[0]; scr.u[2 * g + 1] = sad[g].u[1]; }
+  unsigned short *s16 = scr.s;
+  // sad[mind + 1], sad[mind - 1] with the mirrored ends sad[-1] = sad[1], sad[32] = sad[30]
+  const int p = s16[mind == NDISP - 1 ? NDISP - 2 : mind + 1], n = s16[mind == 0 ? 1 : mind - 1];
   if (S.uniq > 0) {
+    // the scan of the original stops at a d outside [mind-1, mind+1] with sad[d] <= thresh: mask those three, take the min
     const int thresh = minsad + (minsad * S.uniq / 100);
-    int cnt = 0;
+    s16[mind] = 0xffff;
+    s16[mind == 0 ? 32 : mind - 1] = 0xffff;            // slots 32/33 = spare halfword pair
+    s16[mind == NDISP - 1 ? 33 : mind + 1] = 0xffff;
+    us2 m = {0xffff, 0xffff};
 #pragma unroll
-    for (int d = 0; d < NDISP; ++d) cnt += (int)sad[d] <= thresh;
-    // the scan of the original stops at a d outside [mind-1, mind+1] with sad[d] <= thresh
-    cnt -= 1 + (mind > 0 && n <= thresh) + (mind < NDISP - 1 && p <= thresh);
-    if (cnt > 0) return;
+    for (int k = 0; k < 16; ++k) { Pk t; t.u[0] = scr.u[k]; m = __builtin_elementwise_min(m, t.h[0]); }
+    if ((int)min(m.x, m.y) <= thresh) return;
   }
   const int dd = p + n - 2 * minsad + abs(p - n);
   disp = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
@@ -89,8 +121,11 @@ __device__ __forceinline__ void bm_select(const uint32_t (&sad)[NDISP], int tsum
 }
 
 // grid: (ceil((width1-3)/64), ceil(h/BM_STRIP), batch), block 64.  Output columns x in [3, width1), X = x + 31.
+// The vertical 7-row sum slides down the strip: the entering row's SADs are added, the leaving row's are recomputed and
+// subtracted (cheaper than keeping a ring of 7 rows x 32 SADs: no LDS traffic, and occupancy is not LDS-bound); the
+// next step's two row windows are loaded before the current step's arithmetic.
 __global__ __launch_bounds__(64) void stereo_bm_kernel(StereoDev S) {
-  __shared__ uint64_t s_ring[7][9][64];      // [row slot][8 x packed h(d) + texture][lane]
+  __shared__ SelScr s_scr[64];
   const int lane = threadIdx.x, b = blockIdx.z;
   const int w = S.w, h = S.h, width1 = w - NDISP + 1;
   const int x = min(3 + blockIdx.x * 64 + lane, width1 - 1);      // lanes past the end redo the last column (no store)
@@ -99,74 +134,83 @@ __global__ __launch_bounds__(64) void stereo_bm_kernel(StereoDev S) {
   const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL + x + (NDISP - 1) - WSZ2;
   const uint8_t *rp = S.rp + (size_t)b * h * S.pitch + PADL + x - WSZ2;
   const uint32_t ft4 = 0x01010101u * (uint32_t)(S.cap + 1);
-  Pk sad[8];
+  auto win = [&](int r) { const size_t o = (size_t)min(max(r, 0), h - 1) * S.pitch; return load_rowwin(lp + o, rp + o); };
+  Pk sad[8], hh[8];
 #pragma unroll
   for (int g = 0; g < 8; ++g) sad[g].q = 0;
-  int tsum = 0, slot = 0;
-  for (int r = y0 - WSZ2; r < y1 + WSZ2; ++r) {
-    const int yy = min(max(r, 0), h - 1);
-    const uint8_t *lrow = lp + (size_t)yy * S.pitch, *rrow = rp + (size_t)yy * S.pitch;
-    const uint32_t l0 = load_u32_unaligned(lrow), l1 = load_u32_unaligned(lrow + 4) & 0x00ffffffu;      // 7 window bytes, 8th = mask
-    uint32_t rw[11];
+  int tsum = 0, t;
+  for (int r = y0 - WSZ2; r < y0 + WSZ2; ++r) {      // rows y0-3 .. y0+2 of the first window
+    const RowWin wv = win(r);
+    row_sads(wv, ft4, hh, t);
 #pragma unroll
-    for (int k = 0; k < 11; ++k) rw[k] = load_u32_unaligned(rrow + 4 * k);
-    const bool full = r - (y0 - WSZ2) >= 7;
+    for (int g = 0; g < 8; ++g) { sad[g].h[0] += hh[g].h[0]; sad[g].h[1] += hh[g].h[1]; }
+    tsum += t;
+  }
+  RowWin wa = win(y0 + WSZ2), ws = win(y0 - WSZ2);
+  for (int y = y0; y < y1; ++y) {
+    const RowWin na = win(y + WSZ2 + 1), ns = win(y - WSZ2 + 1);      // next step's rows, in flight during this step
+    row_sads(wa, ft4, hh, t);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      uint64_t hq = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)rw[g] | ((uint64_t)rw[g + 1] << 32), l0, 0ull);
-      hq = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[g + 1] | ((uint64_t)rw[g + 2] << 32), l1, hq);
-      Pk hn, ho;
-      hn.q = hq;
-      ho.q = full ? s_ring[slot][g][lane] : 0ull;
-      s_ring[slot][g][lane] = hq;
-      sad[g].h[0] = sad[g].h[0] + hn.h[0] - ho.h[0];
-      sad[g].h[1] = sad[g].h[1] + hn.h[1] - ho.h[1];
-    }
-    {
-      const int t = (int)__builtin_amdgcn_sad_u8(l1 | (ft4 & 0xff000000u), ft4, __builtin_amdgcn_sad_u8(l0, ft4, 0u));
-      const int to = full ? (int)s_ring[slot][8][lane] : 0;
-      s_ring[slot][8][lane] = (uint64_t)t;
-      tsum += t - to;
-    }
-    const int y = r - WSZ2;
-    if (y >= y0 && store) {
-      uint32_t s32[NDISP];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) { s32[4 * g] = sad[g].u[0] & 0xffff; s32[4 * g + 1] = sad[g].u[0] >> 16; s32[4 * g + 2] = sad[g].u[1] & 0xffff; s32[4 * g + 3] = sad[g].u[1] >> 16; }
-      int16_t d16; uint16_t c16;
-      bm_select(s32, tsum, S, d16, c16);
+    for (int g = 0; g < 8; ++g) { sad[g].h[0] += hh[g].h[0]; sad[g].h[1] += hh[g].h[1]; }
+    tsum += t;
+    int16_t d16; uint16_t c16;
+    bm_select(sad, tsum, S, s_scr[lane], d16, c16);
+    if (store) {
       const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
       S.disp16[o] = d16; S.cost[o] = c16;
     }
-    slot = slot == 6 ? 0 : slot + 1;
+    row_sads(ws, ft4, hh, t);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { sad[g].h[0] -= hh[g].h[0]; sad[g].h[1] -= hh[g].h[1]; }
+    tsum -= t;
+    wa = na; ws = ns;
   }
 }
 
-// columns X < 31 (never searched) and x in [0,3): generic clamped evaluation.  grid: (h, batch), block 64
+// columns X < 31 (never searched) and x in [0,3), whose right-image window clamps at column 0 BEFORE the disparity
+// shift (so it is not a contiguous byte window).  Half a wave per pixel: lane = disparity index d.
+// grid: (ceil(3*h/2), batch), block 64
 __global__ __launch_bounds__(64) void stereo_bm_edge_kernel(StereoDev S) {
-  const int y = blockIdx.x, b = blockIdx.y, w = S.w, h = S.h, lane = threadIdx.x;
-  const int16_t FILTERED = (int16_t)FILTERED16;
-  for (int c = lane; c < NDISP - 1 && c < w; c += 64) { S.disp16[((size_t)b * h + y) * w + c] = FILTERED; S.cost[((size_t)b * h + y) * w + c] = 0; }
-  const int width1 = w - NDISP + 1;
-  if (lane >= 3 || lane >= width1) return;
-  const int x = lane;
+  const int b = blockIdx.y, w = S.w, h = S.h, lane = threadIdx.x, d = lane & 31;
+  const int width1 = w - NDISP + 1, ncol = min(3, width1);
+  {   // the never-searched left border, FILTERED
+    const int n = (NDISP - 1) * h;
+    for (int i = blockIdx.x * 64 + lane; i < n; i += gridDim.x * 64) {
+      const size_t o = ((size_t)b * h + i / (NDISP - 1)) * w + i % (NDISP - 1);
+      S.disp16[o] = (int16_t)FILTERED16; S.cost[o] = 0;
+    }
+  }
+  const int pix = blockIdx.x * 2 + (lane >> 5);
+  const bool act = pix < ncol * h;
+  const int y = act ? pix / ncol : 0, x = act ? pix % ncol : 0;
   const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL, *rp = S.rp + (size_t)b * h * S.pitch + PADL;
-  uint32_t sad[NDISP];
-#pragma unroll
-  for (int d = 0; d < NDISP; ++d) sad[d] = 0;
-  int tsum = 0;
+  int sad = 0, tsum = 0;
   for (int dy = -WSZ2; dy <= WSZ2; ++dy) {
     const int yy = min(max(y + dy, 0), h - 1);
+#pragma unroll
     for (int dx = -WSZ2; dx <= WSZ2; ++dx) {
       const int lval = lp[(size_t)yy * S.pitch + x + dx + NDISP - 1];      // x + dx + 31 >= 28: no clamp on the left image here
-      const int rc = max(x + dx, 0);
-#pragma unroll
-      for (int d = 0; d < NDISP; ++d) sad[d] += (uint32_t)abs(lval - (int)rp[(size_t)yy * S.pitch + min(rc + d, w - 1)]);
+      sad += abs(lval - (int)rp[(size_t)yy * S.pitch + min(max(x + dx, 0) + d, w - 1)]);
       tsum += abs(lval - (S.cap + 1));
     }
   }
-  int16_t d16; uint16_t c16;
-  bm_select(sad, tsum, S, d16, c16);
+  // selection across the 32 lanes of the pixel (same rules as bm_select)
+  uint32_t key = ((uint32_t)sad << 5) | (uint32_t)d;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 64));
+  const int minsad = (int)(key >> 5), mind = (int)(key & 31), base = lane & 32;
+  const int ip = mind == NDISP - 1 ? NDISP - 2 : mind + 1, in = mind == 0 ? 1 : mind - 1;
+  const int p = __shfl(sad, base + ip, 64), n = __shfl(sad, base + in, 64);
+  const int thresh = minsad + (minsad * S.uniq / 100);
+  const unsigned long long rivals = __ballot(sad <= thresh && (d < mind - 1 || d > mind + 1));
+  const bool rival = ((rivals >> base) & 0xffffffffull) != 0;
+  if (!act || d != 0) return;
+  int16_t d16 = (int16_t)FILTERED16; uint16_t c16 = 0;
+  if (tsum >= S.texthr && !(S.uniq > 0 && rival)) {
+    const int dd = p + n - 2 * minsad + abs(p - n);
+    d16 = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+    c16 = (uint16_t)minsad;
+  }
   const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
   S.disp16[o] = d16; S.cost[o] = c16;
 }
@@ -220,34 +264,61 @@ __device__ __forceinline__ void ccl_union(int32_t *label, int a, int b) {
     a = old;
   }
 }
-// grid: (ceil(w*h/256), batch)
-__global__ __launch_bounds__(256) void stereo_ccl_init_kernel(StereoDev S) {
-  const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h;
-  if (i >= n) return;
-  const size_t o = (size_t)blockIdx.y * n + i;
-  S.label[o] = S.disp16[o] == (int16_t)FILTERED16 ? -1 : i;
-  S.count[o] = 0;
+__device__ __forceinline__ bool ccl_linked(int a, int b, int range) { return a != FILTERED16 && b != FILTERED16 && abs(a - b) <= range; }
+
+// Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels (a prefix max
+// over "run starts here" along the row), so the union-find only has to stitch rows together and its chains stay
+// short.  One workgroup per image row.  grid: (h, batch), block 256, dynamic LDS = 2 * w ints
+__global__ __launch_bounds__(256) void stereo_ccl_runs_kernel(StereoDev S) {
+  extern __shared__ int s_mem[];
+  const int w = S.w, y = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.y * w * S.h;
+  const int16_t *d = S.disp16 + base + (size_t)y * w;
+  int *s_a = s_mem, *s_b = s_mem + w;
+  for (int x = tid; x < w; x += 256) {
+    const int dv = d[x];
+    const bool start = dv != FILTERED16 && !(x > 0 && ccl_linked(dv, d[x - 1], S.speckle_range));
+    s_a[x] = dv == FILTERED16 ? -2 : (start ? x : -1);      // -2: filtered (also stops a run), -1: continues the run to its left
+    S.count[base + (size_t)y * w + x] = 0;
+  }
+  __syncthreads();
+  for (int o = 1; o < w; o <<= 1) {      // prefix "last run start / filtered marker to the left" (Hillis-Steele)
+    for (int x = tid; x < w; x += 256) { int v = s_a[x]; if (v == -1 && x >= o) v = s_a[x - o]; s_b[x] = v; }
+    __syncthreads();
+    int *t = s_a; s_a = s_b; s_b = t;
+  }
+  for (int x = tid; x < w; x += 256) S.label[base + (size_t)y * w + x] = s_a[x] < 0 ? -1 : y * w + s_a[x];
 }
+// stitch vertically linked pixels; one union per pair of overlapping runs (the leftmost linked column of the overlap).
+// grid: (ceil(w*h/256), batch)
 __global__ __launch_bounds__(256) void stereo_ccl_merge_kernel(StereoDev S) {
   const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h, w = S.w;
-  if (i >= n) return;
+  if (i + w >= n) return;
   const size_t base = (size_t)blockIdx.y * n;
   const int16_t *d = S.disp16 + base;
   int32_t *label = S.label + base;
-  const int FILTERED = FILTERED16, dv = d[i];
-  if (dv == FILTERED) return;
-  const int x = i % w;
-  if (x + 1 < w) { const int dn = d[i + 1]; if (dn != FILTERED && abs(dv - dn) <= S.speckle_range) ccl_union(label, i, i + 1); }
-  if (i + w < n) { const int dn = d[i + w]; if (dn != FILTERED && abs(dv - dn) <= S.speckle_range) ccl_union(label, i, i + w); }
+  if (!ccl_linked(d[i], d[i + w], S.speckle_range)) return;
+  if (i % w > 0 && label[i - 1] == label[i] && label[i + w - 1] == label[i + w] && ccl_linked(d[i - 1], d[i + w - 1], S.speckle_range)) return;
+  ccl_union(label, label[i], label[i + w]);      // run labels are only ever replaced by other members of the same set
 }
+// component sizes, saturating: the test is "size <= speckle_window", so a root that is already beyond the window
+// is left alone, and the lanes of a wave that share a root (runs!) add once.
 __global__ __launch_bounds__(256) void stereo_ccl_count_kernel(StereoDev S) {
-  const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h;
-  if (i >= n) return;
+  const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h, lane = threadIdx.x & 63;
   const size_t base = (size_t)blockIdx.y * n;
-  if (S.label[base + i] < 0) return;
-  const int root = ccl_find(S.label + base, i);
-  S.label[base + i] = root;      // flatten (roots stay roots, so concurrent finds remain valid)
-  atomicAdd(&S.count[base + root], 1);
+  int root = -1;
+  if (i < n && S.label[base + i] >= 0) {
+    root = ccl_find(S.label + base, i);
+    S.label[base + i] = root;      // flatten (roots stay roots, so concurrent finds remain valid)
+  }
+  const int prev = __shfl_up(root, 1, 64);
+  const bool head = root >= 0 && (lane == 0 || prev != root);
+  const unsigned long long heads = __ballot(head || root < 0);      // run boundaries inside the wave
+  if (head) {
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int len = above ? __ffsll((long long)above) : 64 - lane;
+    if (S.count[base + root] <= S.speckle_window) atomicAdd(&S.count[base + root], len);
+  }
 }
 // disparity in pixels; components of <= speckle_window pixels are filtered.  use_ccl == 0: plain conversion
 __global__ __launch_bounds__(256) void stereo_finish_kernel(StereoDev S, int use_ccl, float *__restrict__ out, int dstride, size_t d_bstride) {
@@ -314,7 +385,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 64), h, 2 * n_batch), dim3(64), 0, ctx->stream, S, d_left, lstride, l_bstride,
                      d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(h, n_batch), dim3(64), 0, ctx->stream, S);
+  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, 2), n_batch), dim3(64), 0, ctx->stream, S);
   SVS_LAUNCH_CHECK(ctx);
   if (width1 > 3) {
     hipLaunchKernelGGL(stereo_bm_kernel, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
@@ -327,7 +398,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
   const dim3 gp(div_up(n, 256), n_batch);
   if (ccl) {
-    hipLaunchKernelGGL(stereo_ccl_init_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 2 * (size_t)w, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(stereo_ccl_merge_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(stereo_ccl_count_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
   }
