@@ -4,7 +4,7 @@
 // Semantics as restated in oracle/stereo.c; results are bit-identical to it (integer pipeline).
 //
 // Kernels (all HBM/LDS-bound u8/u16 integer work, no MFMA):
-//   stereo_prefilter_kernel  3x3 x-Sobel -> saturating table, written +1 (so 0 can act as the MQSAD mask) into
+//   stereo_prefilter_kernel  3x3 x-Sobel -> saturating table (4 pixels per thread), written +1 (so 0 can act as the MQSAD mask) into
 //                            column-padded rows (replicated borders = the MIN/MAX clamps of the original)
 //   stereo_bm_kernel         one wave = 64 output columns x a strip of rows.  Per image row a lane forms the 32
 //                            horizontal 7-tap SADs with 16 V_QSAD/V_MQSAD_PK_U16_U8 (4 disparities each), keeps
@@ -35,29 +35,57 @@ struct StereoDev {
 
 __device__ __forceinline__ int xsobel_tab(int v, int cap) { return v < -cap ? 0 : v > cap ? 2 * cap : v + cap; }
 
-// grid: (ceil(pitch/64), h, 2*batch)   z = 2*b + (0 left | 1 right)
-__global__ __launch_bounds__(64) void stereo_prefilter_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
-                                                              const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
-  const int pc = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, b = blockIdx.z >> 1, side = blockIdx.z & 1;
-  if (pc >= S.pitch) return;
-  const uint8_t *src = side ? right + (size_t)b * r_bstride : left + (size_t)b * l_bstride;
-  const int stride = side ? rstride : lstride;
-  const int w = S.w, h = S.h, cap = S.cap;
-  const int x = min(max(pc - PADL, 0), w - 1);
-  int v = cap;
-  if (!((h & 1) && y == h - 1) && x > 0 && x < w - 1) {
-    const int yp = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yn = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-    const uint8_t *r0 = src + (size_t)yp * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yn * stride;
-    v = xsobel_tab((r0[x + 1] - r0[x - 1]) + 2 * (r1[x + 1] - r1[x - 1]) + (r2[x + 1] - r2[x - 1]), cap);
-  }
-  (side ? S.rp : S.lp)[((size_t)b * h + y) * S.pitch + pc] = (uint8_t)(v + 1);
-}
-
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
   uint32_t v;
   __builtin_memcpy(&v, p, 4);
   return v;
 }
+__device__ __forceinline__ int byte_of(uint32_t lo, uint32_t hi, int i) { return (int)((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4))) & 0xffu); }
+
+// 4 padded columns per thread.  grid: (ceil(pitch/256), h, 2*batch), block 64;  z = 2*b + (0 left | 1 right)
+__global__ __launch_bounds__(64) void stereo_prefilter_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
+                                                              const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
+  const int pc0 = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y, b = blockIdx.z >> 1, side = blockIdx.z & 1;
+  if (pc0 >= S.pitch) return;      // pitch is a multiple of 4
+  const uint8_t *src = side ? right + (size_t)b * r_bstride : left + (size_t)b * l_bstride;
+  const int stride = side ? rstride : lstride;
+  const int w = S.w, h = S.h, cap = S.cap;
+  const int x0 = pc0 - PADL;
+  uint32_t out = 0x01010101u * (uint32_t)(cap + 1);      // pads, border columns, odd last row
+  if (!((h & 1) && y == h - 1) && x0 + 3 >= 1 && x0 <= w - 2) {
+    const int yp = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yn = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    const uint8_t *r0 = src + (size_t)yp * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yn * stride;
+    if (x0 >= 1 && x0 + 4 <= w - 1) {      // all four interior: bytes x0-1 .. x0+4 are needed
+      uint32_t a0, a1, b0, b1, c0, c1;
+      a0 = load_u32_unaligned(r0 + x0 - 1); b0 = load_u32_unaligned(r1 + x0 - 1); c0 = load_u32_unaligned(r2 + x0 - 1);
+      if (x0 + 6 < w) {
+        a1 = load_u32_unaligned(r0 + x0 + 3); b1 = load_u32_unaligned(r1 + x0 + 3); c1 = load_u32_unaligned(r2 + x0 + 3);
+      } else {                              // end of the row: read only the two bytes that exist
+        a1 = (uint32_t)r0[x0 + 3] | ((uint32_t)r0[x0 + 4] << 8);
+        b1 = (uint32_t)r1[x0 + 3] | ((uint32_t)r1[x0 + 4] << 8);
+        c1 = (uint32_t)r2[x0 + 3] | ((uint32_t)r2[x0 + 4] << 8);
+      }
+      out = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = (byte_of(a0, a1, j + 2) - byte_of(a0, a1, j)) + 2 * (byte_of(b0, b1, j + 2) - byte_of(b0, b1, j)) +
+                      (byte_of(c0, c1, j + 2) - byte_of(c0, c1, j));
+        out |= (uint32_t)(xsobel_tab(v, cap) + 1) << (8 * j);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 + j;
+        if (x >= 1 && x <= w - 2) {
+          const int v = (r0[x + 1] - r0[x - 1]) + 2 * (r1[x + 1] - r1[x - 1]) + (r2[x + 1] - r2[x - 1]);
+          out = (out & ~(0xffu << (8 * j))) | ((uint32_t)(xsobel_tab(v, cap) + 1) << (8 * j));
+        }
+      }
+    }
+  }
+  *reinterpret_cast<uint32_t *>((side ? S.rp : S.lp) + ((size_t)b * h + y) * S.pitch + pc0) = out;
+}
+
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 union Pk { uint64_t q; us2 h[2]; uint32_t u[2]; };
@@ -350,7 +378,7 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
     return SVS_ERR_UNSUPPORTED;
   }
   svs_stereo *s = new svs_stereo();
-  s->ctx = ctx; s->w = w; s->h = h; s->max_batch = max_batch; s->pitch = w + PADL + PADR; s->prm = *prm;
+  s->ctx = ctx; s->w = w; s->h = h; s->max_batch = max_batch; s->pitch = (w + PADL + PADR + 3) & ~3; s->prm = *prm;
   const size_t n = (size_t)w * h * max_batch, np = (size_t)s->pitch * h * max_batch + 64;
   SVS_HIP(ctx, hipMalloc(&s->d_lp, np));
   SVS_HIP(ctx, hipMalloc(&s->d_rp, np));
@@ -382,7 +410,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   S.speckle_window = s->prm.speckle_window; S.speckle_range = s->prm.speckle_range; S.disp12 = s->prm.disp12_max_diff;
   S.lp = s->d_lp; S.rp = s->d_rp; S.disp16 = s->d_disp16; S.cost = s->d_cost; S.label = s->d_label; S.count = s->d_count;
   const int w = s->w, h = s->h, width1 = w - NDISP + 1, n = w * h;
-  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 64), h, 2 * n_batch), dim3(64), 0, ctx->stream, S, d_left, lstride, l_bstride,
+  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), h, 2 * n_batch), dim3(64), 0, ctx->stream, S, d_left, lstride, l_bstride,
                      d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, 2), n_batch), dim3(64), 0, ctx->stream, S);
