@@ -191,6 +191,25 @@ typedef struct {
    tie-break order are those of QuadTree::query. d_out: [n_batch][n_pts] */
 int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out);
 
+/* ---- motion-only refinement: replaces BA_SE3_XYZ_STEREO::calcFastMotionOnly (pose_optimizer.h:134-298) as
+   called behind the matcher at stereo_frontend.cpp:1058-1063 ------------------------------------------------*/
+typedef struct {
+  int32_t robust_kernel;   /* PoseOptimizerParams(true, 2, 15): pose_optimizer.h:36-58 */
+  int32_t num_iter;
+  double kernel_param;
+  double initial_mu;       /* -1 => tau * max diag(J^T J) (pose_optimizer.h:187-190) */
+  double tau;              /* 1e-5 */
+} svs_pose_opt_params;
+typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
+  double initial_chi2, chi2, max_err;
+  int32_t num_obs;
+  int32_t status;          /* 0 ok; 1 empty observation list (the reference asserts); 2 residual became NaN (the reference throws) */
+} svs_pose_opt_stats;
+/* obs_list / point_list = the SVS_MATCH_OK entries of d_results[b][0..n) in order (several svs_match outputs may be
+   concatenated, as matchAndTrack appends into one TrackData); d_T_io[b][12] = T_cur_from_actkey in/out */
+int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
+                    const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch);
+
 /* ---- dense tracker: replaces DenseTracker / GpuTracker ---------------------------------------*/
 /* computeDensePointCloudCpu (dense_tracking.cpp:393-423): quarter-grid cloud of one level */
 int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride,

@@ -11,7 +11,7 @@ import numpy as np
 
 from scavislam_amd.ctypes_types import (BA_CONSTRAINT_DTYPE, BA_EDGE_DTYPE, CANDIDATE_DTYPE,
                                         DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
-                                        BaParams, BaStats, Cam, FastGrid, StereoParams)
+                                        BaParams, BaStats, Cam, FastGrid, PoseOptParams, PoseOptStats, StereoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -402,3 +402,14 @@ def stereo_bm(left, right, prm=None):
     disp = np.empty((h, w), np.float32)
     lib().svs_ref_stereo_bm(_p(left), _p(right), w, h, w, C.byref(prm), _p(disp), w)
     return disp
+
+
+# ---- motion-only refinement (oracle/vision.c: svs_ref_motion_only) ----------------------------------
+def motion_only(results, cam, T, prm=None):
+    """calcFastMotionOnly over the status-OK entries of a MATCH_RESULT_DTYPE array; returns (T_new 3x4, PoseOptStats)."""
+    prm = prm or PoseOptParams.reference()
+    res = np.ascontiguousarray(results, MATCH_RESULT_DTYPE)
+    Tio = np.array(T, np.float64).reshape(12).copy()
+    st = PoseOptStats()
+    lib().svs_ref_motion_only(_p(res), len(res), C.byref(cam), C.byref(prm), _p(Tio), C.byref(st))
+    return Tio.reshape(3, 4), st

@@ -237,6 +237,22 @@ int svs_ref_ba_optimize(int P, double *poses, int L, double *psi, int E,
                         const svs_ba_edge *edges, int C, const svs_ba_constraint *cons,
                         const svs_cam *cam, const svs_ba_params *prm, svs_ba_stats *stats);
 
+/* ---- motion-only pose refinement: PoseOptimizer::calcFastMotionOnly, pose_optimizer.h:134-298 -------------- */
+typedef struct {
+  int32_t robust_kernel;   /* PoseOptimizerParams(true, 2, 15) at stereo_frontend.cpp:1061 */
+  int32_t num_iter;
+  double kernel_param;
+  double initial_mu;       /* -1 => tau * max diag(J^T J) */
+  double tau;              /* 1e-5 (pose_optimizer.h:50) */
+} svs_pose_opt_params;
+typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
+  double initial_chi2, chi2, max_err;
+  int32_t num_obs;
+  int32_t status;          /* 0 ok, 1 empty observation list (the reference asserts), 2 residual became NaN (the reference throws) */
+} svs_pose_opt_stats;
+int svs_ref_motion_only(const svs_match_result *res, int n, const svs_cam *cam, const svs_pose_opt_params *prm, double *T_io,
+                        svs_pose_opt_stats *st);
+
 /* ---- stereo block matching: cv::StereoBM as configured at stereo_frontend.cpp:620-653 (oracle/stereo.c) ---- */
 typedef struct {
   int32_t prefilter_cap;      /* 31 */

@@ -600,3 +600,111 @@ void svs_ref_se3_exp(const double *x, double *T) { se3_exp(x, T); }
 void svs_ref_se3_log(const double *T, double *x) { se3_log(T, x); }
 void svs_ref_se3_mul(const double *A, const double *B, double *C) { pose_mul(A, B, C); }
 void svs_ref_se3_inv(const double *A, double *B) { pose_inv(A, B); }
+
+/* ---- PoseOptimizer<SE3,6,IdObs<3>,3>::calcFastMotionOnly (pose_optimizer.h:134-298) -------------------
+ * with the SE3XYZ_STEREO prediction (transformations.h:414-464): f = obs - map_uvu(T xyz), J_c = frameJac
+ * (= d f / d delta), unweighted normal equations A = mu I + sum J^T J, B = -sum J^T (w f) with the
+ * pseudo-Huber weight applied to f only (:169-175, :213-222), delta = A.ldlt().solve(B), T_new = exp(delta) T,
+ * gain test on rho = chi2 - new_chi2 (:266), mu update mu *= max(1/3, 1 - (2 rho - 1)^3) (sic, rho is not
+ * a ratio, :272), 5 consecutive rejections stop, stop also when |B|_max <= EPS (1e-10, global.h:106).
+ * The observation list is the matcher's TrackData (status OK entries of `res`, in order):
+ * stereo_frontend.cpp:1058-1063 calls it with PoseOptimizerParams(true, 2, 15). */
+static double mo_kernel(double delta, double b) {          /* pose_optimizer.h:426-435 */
+  const double a = fabs(delta);
+  return a < b ? delta * delta : 2 * b * a - b * b;
+}
+static void mo_residual(const double *T, const double *xyz, const double *obs, const svs_cam *cam, double *f, double *J) {
+  double p[3];
+  pose_act(T, xyz, p);
+  const double x = p[0], y = p[1], z = p[2], fl = cam->f;
+  f[0] = obs[0] - (x / z * fl + cam->cx);                  /* StereoCamera::map_uvu, stereo_camera.cpp:37-44 */
+  f[1] = obs[1] - (y / z * fl + cam->cy);
+  f[2] = obs[2] - ((x - cam->b) / z * fl + cam->cx);
+  if (J) {                                                  /* SE3XYZ_STEREO::frameJac, transformations.h:424-447 */
+    const double ibz = 1. / z, ibz2 = 1. / (z * z);
+    const double A = -fl * ibz, B = -fl * ibz, C = fl * x * ibz2, D = fl * y * ibz2, E = fl * (x - cam->b) * ibz2;
+    const double Jv[18] = {A, 0, C, y * C, z * A - x * C, -y * A,
+                           0, B, D, -z * B + y * D, -x * D, x * B,
+                           A, 0, E, y * E, z * A - x * E, -y * A};
+    memcpy(J, Jv, sizeof Jv);
+  }
+}
+static double mo_weighted_sq(double *f, int robust, double b) {      /* f *= w; returns sqrW(f) after weighting */
+  if (robust) {
+    double nrm = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    if (nrm < 1e-10) nrm = 1e-10;
+    const double w = sqrt(mo_kernel(nrm, b)) / nrm;
+    f[0] *= w; f[1] *= w; f[2] *= w;
+  }
+  return f[0] * f[0] + f[1] * f[1] + f[2] * f[2];
+}
+int svs_ref_motion_only(const svs_match_result *res, int n, const svs_cam *cam, const svs_pose_opt_params *prm, double *T_io,
+                        svs_pose_opt_stats *st) {
+  const double EPS = 1e-10;
+  double T[12], Tn[12], chi2 = 0, max_err = 0, norm_max_A = 0, nu = 2;
+  int num_obs = 0, stop = 0, trial = 0;
+  memcpy(T, T_io, sizeof T);
+  for (int i = 0; i < n; ++i) {
+    if (res[i].status != SVS_MATCH_OK) continue;
+    double f[3], J[18];
+    mo_residual(T, res[i].xyz_actkey, res[i].obs, cam, f, J);
+    for (int c = 0; c < 6; ++c) {
+      const double dgl = fabs(J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c]);
+      if (dgl > norm_max_A) norm_max_A = dgl;
+    }
+    chi2 += mo_weighted_sq(f, prm->robust_kernel, prm->kernel_param);
+    ++num_obs;
+    for (int k = 0; k < 3; ++k) if (fabs(f[k]) > max_err) max_err = fabs(f[k]);
+  }
+  st->initial_chi2 = chi2; st->num_obs = num_obs; st->status = 0;
+  if (num_obs == 0) { st->chi2 = 0; st->max_err = 0; st->status = 1; return 1; }      /* assert(obs_list.size()>0) */
+  double mu = prm->initial_mu == -1 ? prm->tau * norm_max_A : prm->initial_mu;
+  for (int ig = 0; ig < prm->num_iter; ++ig) {
+    double rho = 0;
+    do {
+      double A[36] = {0}, B[6] = {0}, delta[6];
+      for (int c = 0; c < 6; ++c) A[7 * c] = mu;
+      for (int i = 0; i < n; ++i) {
+        if (res[i].status != SVS_MATCH_OK) continue;
+        double f[3], J[18];
+        mo_residual(T, res[i].xyz_actkey, res[i].obs, cam, f, J);
+        mo_weighted_sq(f, prm->robust_kernel, prm->kernel_param);
+        for (int r = 0; r < 6; ++r) {
+          for (int c = 0; c < 6; ++c) A[6 * r + c] += J[r] * J[c] + J[6 + r] * J[6 + c] + J[12 + r] * J[12 + c];
+          B[r] -= J[r] * f[0] + J[6 + r] * f[1] + J[12 + r] * f[2];
+        }
+      }
+      solve_small(6, A, B, delta);
+      double E[12];
+      se3_exp(delta, E);
+      pose_mul(E, T, Tn);
+      double new_chi2 = 0, new_max_err = 0;
+      for (int i = 0; i < n; ++i) {
+        if (res[i].status != SVS_MATCH_OK) continue;
+        double f[3];
+        mo_residual(Tn, res[i].xyz_actkey, res[i].obs, cam, f, NULL);
+        new_chi2 += mo_weighted_sq(f, prm->robust_kernel, prm->kernel_param);
+        for (int k = 0; k < 3; ++k) if (fabs(f[k]) > new_max_err) new_max_err = fabs(f[k]);
+      }
+      if (isnan(new_chi2)) { st->status = 2; st->chi2 = chi2; st->max_err = max_err; return 2; }      /* throw runtime_error("Res is NaN!") */
+      rho = chi2 - new_chi2;
+      if (rho > 0) {
+        memcpy(T, Tn, sizeof T);
+        chi2 = new_chi2; max_err = new_max_err;
+        double bm = -1;
+        for (int c = 0; c < 6; ++c) if (fabs(B[c]) > bm) bm = fabs(B[c]);
+        stop = bm <= EPS;
+        const double q = 2 * rho - 1, sc = 1 - q * q * q;
+        mu *= sc > 1. / 3. ? sc : 1. / 3.;
+        nu = 2.; trial = 0;
+      } else {
+        mu *= nu; nu *= 2.; ++trial;
+        if (trial == 5) stop = 1;
+      }
+    } while (!(rho > 0 || stop));
+    if (stop) break;
+  }
+  memcpy(T_io, T, sizeof T);
+  st->chi2 = chi2; st->max_err = max_err;
+  return 0;
+}

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import weakref
 
-from .ctypes_types import BaParams, BaStats, Cam, FastGrid, StereoParams
+from .ctypes_types import BaParams, BaStats, Cam, FastGrid, PoseOptParams, StereoParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVS_LIB_PATH") or os.path.join(_HERE, "libscavislam_hip.so")   # override = kernel A/B experiments only
@@ -76,6 +76,8 @@ _SIGS = {
                             C.c_int, C.c_void_p],
     "svs_pointcloud_full": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_void_p],
+    "svs_motion_only": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam), C.POINTER(PoseOptParams), C.c_void_p, C.c_void_p,
+                        C.c_int],
     "svs_stereo_create": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StereoParams), C.POINTER(C.c_void_p)],
     "svs_stereo_destroy": [C.c_void_p],
     "svs_stereo_compute": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int,

@@ -544,3 +544,175 @@ extern "C" int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ, const float 
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
+
+// ---- motion-only pose refinement: PoseOptimizer<SE3,6,IdObs<3>,3>::calcFastMotionOnly ---------------------------
+// (pose_optimizer.h:134-298, called at stereo_frontend.cpp:1058-1063 right behind the guided matcher).  One workgroup
+// per camera stream runs the whole LM loop on the device: observations are the status-OK entries of the matcher's
+// result array (= TrackData::obs_list / point_list, in list order); every pass is a strided sweep over them with a
+// wave-shuffle + LDS reduction of the 21 + 6 normal-equation sums (or chi2 / max error); one lane solves the 6x6 system.
+namespace {
+
+__device__ __forceinline__ double mo_kernel(double delta, double b) {      // pseudo-Huber cost, pose_optimizer.h:426-435
+  const double a = fabs(delta);
+  return a < b ? delta * delta : 2 * b * a - b * b;
+}
+// f = obs - map_uvu(T xyz) (stereo_camera.cpp:37-44); J = SE3XYZ_STEREO::frameJac (transformations.h:424-447) if wanted
+template <bool JAC>
+__device__ __forceinline__ void mo_residual(const double *T, const svs_match_result &o, const svs_cam &cam, double *f, double *J) {
+  const double *q = o.xyz_actkey;
+  const double x = T[0] * q[0] + T[1] * q[1] + T[2] * q[2] + T[3];
+  const double y = T[4] * q[0] + T[5] * q[1] + T[6] * q[2] + T[7];
+  const double z = T[8] * q[0] + T[9] * q[1] + T[10] * q[2] + T[11];
+  const double fl = cam.f;
+  f[0] = o.obs[0] - (x / z * fl + cam.cx);
+  f[1] = o.obs[1] - (y / z * fl + cam.cy);
+  f[2] = o.obs[2] - ((x - cam.b) / z * fl + cam.cx);
+  if (JAC) {
+    const double ibz = 1. / z, ibz2 = 1. / (z * z);
+    const double A = -fl * ibz, B = -fl * ibz, C = fl * x * ibz2, D = fl * y * ibz2, E = fl * (x - cam.b) * ibz2;
+    J[0] = A; J[1] = 0; J[2] = C; J[3] = y * C; J[4] = z * A - x * C; J[5] = -y * A;
+    J[6] = 0; J[7] = B; J[8] = D; J[9] = -z * B + y * D; J[10] = -x * D; J[11] = x * B;
+    J[12] = A; J[13] = 0; J[14] = E; J[15] = y * E; J[16] = z * A - x * E; J[17] = -y * A;
+  }
+}
+__device__ __forceinline__ double mo_weighted_sq(double *f, int robust, double b) {
+  if (robust) {
+    const double nrm = fmax(1e-10, sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]));
+    const double w = sqrt(mo_kernel(nrm, b)) / nrm;
+    f[0] *= w; f[1] *= w; f[2] *= w;
+  }
+  return f[0] * f[0] + f[1] * f[1] + f[2] * f[2];
+}
+
+constexpr int MO_THREADS = 256;
+// block reduction of N doubles per thread: sums for k < n_sum, maxima for the rest.  Result in s_red[0..N) (all threads may read)
+template <int N>
+__device__ __forceinline__ void mo_reduce(double (&v)[N], int n_sum, double *s_red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = k < n_sum ? x + y : fmax(x, y); }
+    if (lane == 0) s_red[wave * N + k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int k = threadIdx.x;
+    double x = s_red[k];
+    for (int w = 1; w < MO_THREADS / 64; ++w) x = k < n_sum ? x + s_red[w * N + k] : fmax(x, s_red[w * N + k]);
+    s_red[(MO_THREADS / 64) * N + k] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = s_red[(MO_THREADS / 64) * N + k];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
+                                                                 svs_pose_opt_params prm, double *__restrict__ T_io, svs_pose_opt_stats *__restrict__ stats) {
+  __shared__ double s_red[(MO_THREADS / 64 + 1) * 28];
+  __shared__ double s_T[12], s_Tn[12], s_B[6];
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  res += (size_t)slot * res_bstride;
+  if (tid < 12) s_T[tid] = T_io[12 * slot + tid];
+  __syncthreads();
+  // initial residuals: chi2, max error, number of observations, max diag(J^T J)
+  double chi2, max_err, mu, nu = 2;
+  int num_obs;
+  {
+    double v[4] = {0, 0, 0, 0};      // chi2, num_obs | max_err, norm_max_A
+    for (int i = tid; i < n; i += MO_THREADS) {
+      if (res[i].status != 0) continue;
+      double f[3], J[18];
+      mo_residual<true>(s_T, res[i], cam, f, J);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[3] = fmax(v[3], fabs(J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c]));
+      v[0] += mo_weighted_sq(f, prm.robust_kernel, prm.kernel_param);
+      v[1] += 1.0;
+      v[2] = fmax(v[2], fmax(fabs(f[0]), fmax(fabs(f[1]), fabs(f[2]))));
+    }
+    mo_reduce<4>(v, 2, s_red);
+    chi2 = v[0]; num_obs = (int)v[1]; max_err = v[2];
+    mu = prm.initial_mu == -1 ? prm.tau * v[3] : prm.initial_mu;
+  }
+  const double initial_chi2 = chi2;
+  int status = num_obs == 0 ? 1 : 0, trial = 0;
+  bool stop = num_obs == 0;
+  for (int ig = 0; ig < prm.num_iter && !stop; ++ig) {
+    double rho = 0;
+    do {
+      double v[27];      // 21 unique of sum J^T J (upper, row-major), 6 of sum J^T (w f)
+#pragma unroll
+      for (int k = 0; k < 27; ++k) v[k] = 0;
+      for (int i = tid; i < n; i += MO_THREADS) {
+        if (res[i].status != 0) continue;
+        double f[3], J[18];
+        mo_residual<true>(s_T, res[i], cam, f, J);
+        mo_weighted_sq(f, prm.robust_kernel, prm.kernel_param);
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = r; c < 6; ++c) v[k++] += J[r] * J[c] + J[6 + r] * J[6 + c] + J[12 + r] * J[12 + c];
+          v[21 + r] += J[r] * f[0] + J[6 + r] * f[1] + J[12 + r] * f[2];
+        }
+      }
+      mo_reduce<27>(v, 27, s_red);
+      if (tid == 0) {
+        double A[36], B[6], delta[6];
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+          for (int c = r; c < 6; ++c) { A[6 * r + c] = A[6 * c + r] = v[k++]; }
+        for (int r = 0; r < 6; ++r) { A[7 * r] += mu; B[r] = -v[21 + r]; s_B[r] = B[r]; }
+        d_solve6(A, B, delta);                                 // A.ldlt().solve(B)
+        double Tn[12];
+        d_se3_exp_mul(delta, s_T, Tn);                         // prediction.add: exp(delta) * T
+        for (int i = 0; i < 12; ++i) s_Tn[i] = Tn[i];
+      }
+      __syncthreads();
+      double w[2] = {0, 0};      // new chi2 | new max error
+      for (int i = tid; i < n; i += MO_THREADS) {
+        if (res[i].status != 0) continue;
+        double f[3];
+        mo_residual<false>(s_Tn, res[i], cam, f, nullptr);
+        w[0] += mo_weighted_sq(f, prm.robust_kernel, prm.kernel_param);
+        w[1] = fmax(w[1], fmax(fabs(f[0]), fmax(fabs(f[1]), fabs(f[2]))));
+      }
+      mo_reduce<2>(w, 1, s_red);
+      const double new_chi2 = w[0];
+      if (isnan(new_chi2)) { status = 2; stop = true; break; }      // the reference throws here
+      rho = chi2 - new_chi2;
+      if (rho > 0) {
+        if (tid < 12) s_T[tid] = s_Tn[tid];
+        chi2 = new_chi2; max_err = w[1];
+        double bm = -1;
+        for (int c = 0; c < 6; ++c) bm = fmax(bm, fabs(s_B[c]));
+        stop = bm <= 1e-10;
+        const double q = 2 * rho - 1, sc = 1 - q * q * q;
+        mu *= fmax(1. / 3., sc);
+        nu = 2.; trial = 0;
+      } else {
+        mu *= nu; nu *= 2.; ++trial;
+        if (trial == 5) stop = true;
+      }
+      __syncthreads();
+    } while (!(rho > 0 || stop));
+  }
+  if (tid < 12) T_io[12 * slot + tid] = s_T[tid];
+  if (tid == 0) {
+    svs_pose_opt_stats st;
+    st.initial_chi2 = initial_chi2; st.chi2 = chi2; st.max_err = max_err; st.num_obs = num_obs; st.status = status;
+    stats[slot] = st;
+  }
+}
+
+}  // namespace
+
+extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
+                               const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch) {
+  SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && batch >= 1 && n >= 0 && (n == 0 || d_results));
+  hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}

@@ -92,3 +92,19 @@ class StereoParams(C.Structure):
     @classmethod
     def reference(cls, num_disp16=2):
         return cls(31, 7, 0, 16 * num_disp16, 10, 15, 100, 32, 1)
+
+
+class PoseOptParams(C.Structure):
+    """svs_pose_opt_params: PoseOptimizerParams (pose_optimizer.h:36-58)."""
+    _fields_ = [("robust_kernel", C.c_int32), ("num_iter", C.c_int32), ("kernel_param", C.c_double),
+                ("initial_mu", C.c_double), ("tau", C.c_double)]
+
+    @classmethod
+    def reference(cls):
+        """PoseOptimizerParams(true, 2, 15) as passed at stereo_frontend.cpp:1061"""
+        return cls(1, 15, 2.0, -1.0, 1e-5)
+
+
+class PoseOptStats(C.Structure):
+    _fields_ = [("initial_chi2", C.c_double), ("chi2", C.c_double), ("max_err", C.c_double),
+                ("num_obs", C.c_int32), ("status", C.c_int32)]

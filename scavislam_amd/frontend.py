@@ -9,6 +9,7 @@ stereo_frontend.cpp), device memory held in torch tensors:
   DenseTracker.denseTrackingCpu / computeDensePointCloudCpu               dense_tracking.h:59-79
   GpuTracker.jacobianReduction / chi2 / computePointCloud                 gpu/dense_tracking.cuh:281-342
   StereoMatcher.calcDisparityCpu         <- StereoFrontend::calcDisparityCpu  stereo_frontend.cpp:620-653
+  PoseOptimizer.calcFastMotionOnly       <- BA_SE3_XYZ_STEREO::calcFastMotionOnly  pose_optimizer.h:134-298
 
 The HIP library does all the arithmetic; nothing here computes on the CPU.
 """
@@ -19,7 +20,7 @@ import torch
 
 from . import capi
 from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, Cam,
-                           FastGrid as FastGridPOD, StereoParams, level_cams)
+                           FastGrid as FastGridPOD, PoseOptParams, PoseOptStats, StereoParams, level_cams)
 
 NUM_PYR_LEVELS = 3  # global.h:107
 
@@ -226,6 +227,41 @@ class GuidedMatcher:
     def download(self):
         self.ctx.sync()
         return self._keep[4].cpu().numpy().view(MATCH_RESULT_DTYPE).reshape(self.frame.batch, self._n)
+
+
+class PoseOptimizer:
+    """BA_SE3_XYZ_STEREO (PoseOptimizer<SE3,6,IdObs<3>,3>, pose_optimizer.h:486): motion-only refinement of
+    T_cur_from_actkey over the matcher's TrackData, device resident (stereo_frontend.cpp:1058-1063)."""
+
+    def __init__(self, ctx, frame):
+        self.ctx, self.frame = ctx, frame
+        dev = frame.pyr[0].device
+        with torch.cuda.stream(frame.stream):
+            self.d_T = torch.zeros((frame.batch, 12), dtype=torch.float64, device=dev)
+            self.d_stats = torch.zeros(frame.batch * C.sizeof(PoseOptStats), dtype=torch.uint8, device=dev)
+
+    def calcFastMotionOnly(self, matcher, T_cur_from_actkey, params=None, download=True):
+        """obs_list / point_list = the status-OK results of `matcher` (device resident).  T: [batch,12] or [12]."""
+        fr = self.frame
+        prm = params or PoseOptParams.reference()
+        T = np.broadcast_to(np.asarray(T_cur_from_actkey, np.float64).reshape(-1, 12), (fr.batch, 12))
+        with torch.cuda.stream(fr.stream):
+            self.d_T.copy_(torch.as_tensor(np.array(T, np.float64)))
+        self.launch(matcher, prm)
+        return self.download() if download else None
+
+    def launch(self, matcher, prm):
+        fr = self.frame
+        self.ctx.call("svs_motion_only", matcher._keep[4].data_ptr(), matcher._n, matcher._n, C.byref(fr.cams[0]), C.byref(prm),
+                      self.d_T.data_ptr(), self.d_stats.data_ptr(), fr.batch)
+
+    def download(self):
+        self.ctx.sync()
+        T = self.d_T.cpu().numpy().reshape(self.frame.batch, 3, 4)
+        raw = self.d_stats.cpu().numpy()
+        stats = [PoseOptStats.from_buffer_copy(raw[i * C.sizeof(PoseOptStats):(i + 1) * C.sizeof(PoseOptStats)].tobytes())
+                 for i in range(self.frame.batch)]
+        return T, stats
 
 
 class DenseTracker:

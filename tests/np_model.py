@@ -296,3 +296,63 @@ def stereo_bm(left, right):
     d16 = stereo_validate(d16, cost)
     d16 = stereo_filter_speckles(d16)
     return d16.astype(np.float32) / 16.0
+
+
+# ---- motion-only refinement: vectorised model of PoseOptimizer::calcFastMotionOnly (pose_optimizer.h:134-298) ----
+def motion_only(xyz, obs, cam, T, robust=True, b=2.0, num_iter=15, tau=1e-5):
+    """xyz [n,3] points in the active keyframe frame, obs [n,3] (u,v,u_right); cam = (f,cx,cy,baseline)."""
+    f_, cx, cy, bl = cam
+
+    def resid(T):
+        p = xyz @ T[:, :3].T + T[:, 3]
+        pred = np.stack([p[:, 0] / p[:, 2] * f_ + cx, p[:, 1] / p[:, 2] * f_ + cy, (p[:, 0] - bl) / p[:, 2] * f_ + cx], 1)
+        return obs - pred, p
+
+    def weighted(r):
+        if not robust:
+            return r
+        nrm = np.maximum(1e-10, np.linalg.norm(r, axis=1))
+        k = np.where(nrm < b, nrm * nrm, 2 * b * nrm - b * b)
+        return r * (np.sqrt(k) / nrm)[:, None]
+
+    def jac(p):
+        x, y, z = p[:, 0], p[:, 1], p[:, 2]
+        A = -f_ / z
+        Cc, D, E = f_ * x / z ** 2, f_ * y / z ** 2, f_ * (x - bl) / z ** 2
+        zero = np.zeros_like(x)
+        J = np.stack([np.stack([A, zero, Cc, y * Cc, z * A - x * Cc, -y * A], 1),
+                      np.stack([zero, A, D, -z * A + y * D, -x * D, x * A], 1),
+                      np.stack([A, zero, E, y * E, z * A - x * E, -y * A], 1)], 1)
+        return J      # [n,3,6]
+
+    r, p = resid(T)
+    J = jac(p)
+    mu = tau * np.abs(np.einsum("nij,nij->nj", J, J)).max()
+    chi2 = float((weighted(r) ** 2).sum())
+    init = chi2
+    nu, trial, stop = 2.0, 0, False
+    for _ in range(num_iter):
+        while True:
+            r, p = resid(T)
+            J = jac(p)
+            A = mu * np.eye(6) + np.einsum("nij,nik->jk", J, J)
+            B = -np.einsum("nij,ni->j", J, weighted(r))
+            delta = linalg.solve(A, B, assume_a="sym")
+            Tn = pose_mul(se3_exp(delta), T)
+            new = float((weighted(resid(Tn)[0]) ** 2).sum())
+            rho = chi2 - new
+            if rho > 0:
+                T, chi2 = Tn, new
+                stop = np.abs(B).max() <= 1e-10
+                mu *= max(1 / 3, 1 - (2 * rho - 1) ** 3)
+                nu, trial = 2.0, 0
+            else:
+                mu *= nu
+                nu *= 2
+                trial += 1
+                stop = trial == 5
+            if rho > 0 or stop:
+                break
+        if stop:
+            break
+    return T, init, chi2
