@@ -97,6 +97,13 @@ class FrameDev {
     for (int y = 0; y < h_[0]; ++y) std::memcpy(&tmp[(size_t)y * stride_[0]], d.data + (size_t)y * d.stride, sizeof(float) * (size_t)w_[0]);
     return disp_.upload(tmp.data(), tmp.size());
   }
+  bool getDisparity(std::vector<float> *d) const {      // row-major w x h, stride removed
+    std::vector<float> tmp((size_t)stride_[0] * h_[0]);
+    if (!disp_.download(tmp.data(), tmp.size())) return false;
+    d->resize((size_t)w_[0] * h_[0]);
+    for (int y = 0; y < h_[0]; ++y) std::memcpy(&(*d)[(size_t)y * w_[0]], &tmp[(size_t)y * stride_[0]], sizeof(float) * (size_t)w_[0]);
+    return true;
+  }
   const uint8_t *pyr(int l) const { return pyr_[l].get(); }
   const float *disp() const { return disp_.get(); }
   const float *f32(int l) const { return f32_[l].get(); }
@@ -217,6 +224,65 @@ class GuidedMatcher {
     for (int i = 0; i < 3; ++i) B[4 * i + 3] = -(B[4 * i] * A[3] + B[4 * i + 1] * A[7] + B[4 * i + 2] * A[11]);
   }
   const Context &ctx_;
+};
+
+// PoseOptimizer<SE3,6,IdObs<3>,3> (BA_SE3_XYZ_STEREO, pose_optimizer.h:486): calcFastMotionOnly over the matcher's
+// TrackData (stereo_frontend.cpp:1058-1063).  `track` = the result records of one or more GuidedMatcher::match calls
+// (entries with status != SVS_MATCH_OK are skipped, as they never reach obs_list).
+struct PoseOptimizerParams {             // pose_optimizer.h:36-58
+  PoseOptimizerParams(bool robust_kernel = true, double kernel_param = 1, int num_iter = 50, double initial_mu = -1)
+      : robust_kernel(robust_kernel), kernel_param(kernel_param), num_iter(num_iter), initial_mu(initial_mu), tau(0.00001) {}
+  bool robust_kernel; double kernel_param; int num_iter; double initial_mu; double tau;
+};
+class BA_SE3_XYZ_STEREO {
+ public:
+  explicit BA_SE3_XYZ_STEREO(const Context &c) : ctx_(c) {}
+  bool calcFastMotionOnly(const std::vector<svs_match_result> &track, const svs_cam &cam, const PoseOptimizerParams &ba_params,
+                          double T_cur_from_actkey[12], svs_pose_opt_stats *stats) {
+    DeviceBuffer<svs_match_result> d_res(ctx_, track.size() ? track.size() : 1);
+    DeviceBuffer<double> d_T(ctx_, 12);
+    DeviceBuffer<svs_pose_opt_stats> d_st(ctx_, 1);
+    if ((track.size() && !d_res.upload(track.data(), track.size())) || !d_T.upload(T_cur_from_actkey, 12)) return false;
+    svs_pose_opt_params p;
+    p.robust_kernel = ba_params.robust_kernel; p.num_iter = ba_params.num_iter; p.kernel_param = ba_params.kernel_param;
+    p.initial_mu = ba_params.initial_mu; p.tau = ba_params.tau;
+    if (!ctx_.check(svs_motion_only(ctx_.get(), d_res.get(), (int)track.size(), track.size(), &cam, &p, d_T.get(), d_st.get(), 1))) return false;
+    svs_pose_opt_stats st;
+    if (!d_T.download(T_cur_from_actkey, 12) || !d_st.download(&st, 1)) return false;
+    if (stats) *stats = st;
+    return st.status == 0;      // 1: empty list (assert in the reference), 2: NaN residual (throw in the reference)
+  }
+
+ private:
+  const Context &ctx_;
+};
+
+// StereoFrontend::calcDisparityCpu (stereo_frontend.cpp:620-653): cv::StereoBM on the level-0 left image and the
+// right image; the float disparity lands in the frame's disparity image (FrameDev::disp, -1 where filtered).
+class StereoBM {
+ public:
+  StereoBM(const Context &c, int w, int h, int num_disp16 = 2) : ctx_(c), s_(0), w_(w), h_(h), right_(c, (size_t)((w + 63) / 64 * 64) * h) {
+    svs_stereo_params p = {31, 7, 0, 16 * num_disp16, 10, 15, 100, 32, 1};      // state set at stereo_frontend.cpp:626-636
+    ok_ = c.check(svs_stereo_create(c.get(), w, h, 1, &p, &s_));
+  }
+  ~StereoBM() { if (s_) svs_stereo_destroy(s_); }
+  bool ok() const { return ok_; }
+  bool operator()(const FrameDev &left, const Image8 &right, FrameDev *out) {
+    const int stride = left.stride(0);
+    std::vector<uint8_t> tmp((size_t)stride * h_);
+    for (int y = 0; y < h_; ++y) std::memcpy(&tmp[(size_t)y * stride], right.data + (size_t)y * right.stride, (size_t)w_);
+    if (!ok_ || !right_.upload(tmp.data(), tmp.size())) return false;
+    return ctx_.check(svs_stereo_compute(s_, left.pyr(0), stride, 0, right_.get(), stride, 0, const_cast<float *>(out->disp()), stride, 0, 1));
+  }
+
+ private:
+  StereoBM(const StereoBM &);
+  StereoBM &operator=(const StereoBM &);
+  const Context &ctx_;
+  svs_stereo *s_;
+  int w_, h_;
+  bool ok_;
+  DeviceBuffer<uint8_t> right_;
 };
 
 // DenseTracker, CPU-path semantics (dense_tracking.h:53-97, dense_tracking.cpp:222-423).

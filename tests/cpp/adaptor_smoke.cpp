@@ -66,5 +66,33 @@ int main(int argc, char **argv) {
   std::printf("BA %d %d %d %.17g %.17g\n", st.iterations, st.trials, st.accepted, st.chi2_init, st.chi2_final);
   for (size_t i = 0; i < poses.size(); ++i) std::printf("P %.17g\n", poses[i]);
   for (size_t i = 0; i < psi.size(); ++i) std::printf("S %.17g\n", psi[i]);
+  // ---- StereoBM (calcDisparityCpu) + BA_SE3_XYZ_STEREO::calcFastMotionOnly: optional third / fourth input files ------
+  if (argc >= 4) {
+    f = std::fopen(argv[3], "rb");
+    std::vector<uint8_t> right;
+    if (!f || !read_vec(f, &right, (size_t)wh[0] * wh[1])) return 9;
+    std::fclose(f);
+    StereoBM bm(ctx, wh[0], wh[1]);
+    Image8 rview = {right.data(), wh[0], wh[1], wh[0]};
+    std::vector<float> disp;
+    if (!bm.ok() || !bm(fr, rview, &fr) || !fr.getDisparity(&disp)) return 9;
+    double sum = 0; size_t valid = 0;
+    for (size_t i = 0; i < disp.size(); ++i) if (disp[i] >= 0) { sum += disp[i]; ++valid; }
+    std::printf("DISP %zu %.17g\n", valid, sum);
+  }
+  if (argc >= 5) {
+    f = std::fopen(argv[4], "rb");
+    int n;
+    double T[12];
+    std::vector<svs_match_result> track;
+    if (!f || std::fread(&n, sizeof(int), 1, f) != 1 || std::fread(T, sizeof(double), 12, f) != 12 || !read_vec(f, &track, (size_t)n)) return 10;
+    std::fclose(f);
+    BA_SE3_XYZ_STEREO ba2(ctx);
+    svs_pose_opt_stats ps;
+    if (!ba2.calcFastMotionOnly(track, cam, PoseOptimizerParams(true, 2, 15), T, &ps)) return 10;
+    std::printf("MOTION %d %.17g %.17g", ps.num_obs, ps.initial_chi2, ps.chi2);
+    for (int i = 0; i < 12; ++i) std::printf(" %.17g", T[i]);
+    std::printf("\n");
+  }
   return 0;
 }

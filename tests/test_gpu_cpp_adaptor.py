@@ -1,6 +1,6 @@
 """The C++ adaptor classes of include/scavislam_hip.hpp (reference-named call surfaces over the C ABI),
-compiled with g++ and run on the GPU: FastGrid::detectAdaptively + cell_grid2d and SlamGraphBA::optimize
-must agree with the CPU oracle exactly like the Python path does."""
+compiled with g++ and run on the GPU: FastGrid::detectAdaptively + cell_grid2d, SlamGraphBA::optimize, StereoBM and
+BA_SE3_XYZ_STEREO::calcFastMotionOnly must agree with the CPU oracle exactly like the Python path does."""
 import os
 import subprocess
 
@@ -33,7 +33,26 @@ def test_cpp_adaptor_matches_oracle(tmp_path):
         f.write(prob["psi"].astype(np.float64).tobytes())
         f.write(prob["edges"].tobytes())
         f.write(prob["cons"].tobytes())
-    out = subprocess.check_output([str(exe), str(tmp_path / "img.bin"), str(tmp_path / "ba.bin")]).decode().splitlines()
+    # right image = left shifted by 6 px (a constant-disparity pair) for StereoBM; synthetic track for calcFastMotionOnly
+    right = np.roll(img, -6, axis=1)
+    (tmp_path / "right.bin").write_bytes(right.tobytes())
+    from scavislam_amd.ctypes_types import MATCH_RESULT_DTYPE
+    rng = np.random.default_rng(2)
+    T_true = synth.pose(synth.so3_exp(np.array([0.01, 0.02, -0.01])), np.array([0.02, -0.03, 0.06]))
+    n_tr = 150
+    xyz = np.stack([rng.uniform(-3, 3, n_tr), rng.uniform(-1.5, 1.5, n_tr), rng.uniform(2.5, 12, n_tr)], 1)
+    pc = xyz @ T_true[:, :3].T + T_true[:, 3]
+    track = np.zeros(n_tr, MATCH_RESULT_DTYPE)
+    track["obs"] = np.stack([pc[:, 0] / pc[:, 2] * c["f"] + c["cx"], pc[:, 1] / pc[:, 2] * c["f"] + c["cy"],
+                             (pc[:, 0] - c["b"]) / pc[:, 2] * c["f"] + c["cx"]], 1) + rng.normal(0, 0.3, (n_tr, 3))
+    track["xyz_actkey"] = xyz
+    track["status"][::9] = 5
+    with open(tmp_path / "track.bin", "wb") as f:
+        f.write(np.array([n_tr], np.int32).tobytes())
+        f.write(np.eye(3, 4).astype(np.float64).tobytes())
+        f.write(track.tobytes())
+    out = subprocess.check_output([str(exe), str(tmp_path / "img.bin"), str(tmp_path / "ba.bin"), str(tmp_path / "right.bin"),
+                                   str(tmp_path / "track.bin")]).decode().splitlines()
     # FAST
     pyr = O.build_pyramid(img)
     grids = [O.fastgrid_for_level(pyr[l].shape[1], pyr[l].shape[0], l) for l in range(3)]
@@ -60,3 +79,13 @@ def test_cpp_adaptor_matches_oracle(tmp_path):
     S = np.array([float(l.split()[1]) for l in out if l.startswith("S ")]).reshape(-1, 3)
     assert np.abs(P - poses_ref).max() < 1e-6 * np.abs(poses_ref - prob["poses"]).max()
     assert np.abs(S - psi_ref).max() < 1e-6 * np.abs(psi_ref - prob["psi"]).max()
+    # StereoBM
+    dl = [l for l in out if l.startswith("DISP ")][0].split()
+    dref = O.stereo_bm(img, right)
+    assert int(dl[1]) == int((dref >= 0).sum()) and float(dl[2]) == float(dref[dref >= 0].astype(np.float64).sum())
+    # calcFastMotionOnly
+    ml = [l for l in out if l.startswith("MOTION ")][0].split()
+    Tr, sr = O.motion_only(track, cam, np.eye(3, 4))
+    assert int(ml[1]) == sr.num_obs
+    np.testing.assert_allclose([float(ml[2]), float(ml[3])], [sr.initial_chi2, sr.chi2], rtol=1e-9)
+    np.testing.assert_allclose(np.array([float(t) for t in ml[4:16]]).reshape(3, 4), Tr, rtol=0, atol=1e-9)
