@@ -76,9 +76,17 @@ __device__ __forceinline__ void taps_u8(const uint8_t *__restrict__ img, int str
 // Branch-free (invalid samples are predicated to zero contributions and a safe address) so that the
 // unrolled caller can keep the cloud load and the 12 bilinear taps of several samples in flight:
 // the pass is bound by gather latency, not by bytes.
+// the two T-independent loads of a sample (stored 3D point, previous-frame intensity): issued one trip ahead by track_pass
+struct SampleIn { float4 c4; uint8_t prev; };
+__device__ __forceinline__ SampleIn sample_load(const LevelArgs &L, int u, int v, int cw, bool in_range) {
+  SampleIn s;
+  s.c4 = in_range ? reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u] : make_float4(0.f, 0.f, 1.f, -1.f);
+  s.prev = L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4];
+  return s;
+}
 template <bool JAC, bool U8SRC = false>
-__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, int u, int v, int cw, bool in_range, Acc &a) {
-  const float4 c4 = in_range ? reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u] : make_float4(0.f, 0.f, 1.f, -1.f);
+__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a) {
+  const float4 c4 = in.c4;
   bool ok = in_range && (c4.w > 0);
   const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
   const double x = T[0] * xp0 + T[1] * xp1 + T[2] * xp2 + T[3];
@@ -90,7 +98,7 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   const int ui = ok ? (int)uvx : 0, vi = ok ? (int)uvy : 0;
   ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
   if (!ok) { uvx = 2.f; uvy = 2.f; }                       // safe tap position, contribution masked below
-  const float ip = (float)((1. / 255.) * L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4]);
+  const float ip = (float)((1. / 255.) * in.prev);
   float ic, g8x = 0.f, g8y = 0.f;
   if (U8SRC) taps_u8(L.cur8, L.c8stride, uvx, uvy, ic, g8x, g8y);
   else ic = interp32f(L.cur, L.fstride, uvx, uvy);
@@ -127,18 +135,33 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   }
 }
 
-// block reduction: wave shuffles then LDS; result valid in threads [0, NSUM] (index = value id)
+// block reduction; result valid in threads [0, NSUM] (index = value id).  Inside a wave the 29 sums are reduced by
+// recursive halving: in step s a lane keeps one half of its partial vector and hands the other half to its partner
+// (lane ^ 2^s), so 16+8+4+2+1(+1) = 32 f64 exchanges replace 29 x 6 butterflies -- the pass is short, this tail is not.
 template <int NWAVES>
 __device__ __forceinline__ void block_reduce(Acc &a, double (*s_part)[NSUM + 1], double *out_vals /* NSUM+1 in LDS */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double x[32];
 #pragma unroll
-  for (int i = 0; i < NSUM; ++i) a.v[i] = wave_sum_f64(a.v[i]);
-  double nn = wave_sum_f64((double)a.n);
-  if (lane == 0) {
+  for (int i = 0; i < NSUM; ++i) x[i] = a.v[i];
+  x[NSUM] = (double)a.n;
 #pragma unroll
-    for (int i = 0; i < NSUM; ++i) s_part[wave][i] = a.v[i];
-    s_part[wave][NSUM] = nn;
+  for (int i = NSUM + 1; i < 32; ++i) x[i] = 0.0;
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const int half = 16 >> step, bit = 1 << step;
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double send = up ? x[k] : x[k + half];
+      const double keep = up ? x[k + half] : x[k];
+      x[k] = keep + __shfl_xor(send, bit, 64);
+    }
   }
+  x[0] += __shfl_xor(x[0], 32, 64);
+  // lanes 0..31 now hold the wave sum of value id = bit-reversed lane index (5 bits)
+  const int idx = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+  if (lane < 32 && idx <= NSUM) s_part[wave][idx] = x[0];
   __syncthreads();
   if (threadIdx.x <= NSUM) {
     double s = 0;
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(256) void dense_pass_cpu_sem_kernel(LevelArgs L, si
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sample_cpu_sem<JAC>(L, T, i % cw, i / cw, cw, true, a);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sample_cpu_sem<JAC>(L, T, sample_load(L, i % cw, i / cw, cw, true), true, a);
   block_reduce<4>(a, s_part, s_out);
   if (threadIdx.x <= NSUM) partials[((size_t)slot * gridDim.x + blockIdx.x) * (NSUM + 1) + threadIdx.x] = s_out[threadIdx.x];
 }
@@ -234,15 +257,15 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
-  // TRK_UNROLL samples per lane per trip, predicated tail: several samples' gathers in flight per lane
-  for (int i0 = threadIdx.x; i0 < n; i0 += TRK_UNROLL * TRK_THREADS) {
-#pragma unroll
-    for (int q = 0; q < TRK_UNROLL; ++q) {
-      const int i = i0 + q * TRK_THREADS;
-      const bool in_range = i < n;
-      const int ii = in_range ? i : 0;
-      sample_cpu_sem<JAC, U8SRC>(L, T, ii % cw, ii / cw, cw, in_range, a);
-    }
+  // one sample per lane per trip; the next trip's stored point and previous-frame intensity (independent of T) are loaded
+  // before this trip's arithmetic, so only the bilinear taps -- whose addresses depend on the projection -- are exposed
+  int i = threadIdx.x;
+  SampleIn nxt = sample_load(L, (i < n ? i : 0) % cw, (i < n ? i : 0) / cw, cw, i < n);
+  for (; i < n; i += TRK_THREADS) {
+    const SampleIn cur = nxt;
+    const int j = i + TRK_THREADS;
+    nxt = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
+    sample_cpu_sem<JAC, U8SRC>(L, T, cur, true, a);
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
