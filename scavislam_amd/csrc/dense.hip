@@ -244,7 +244,7 @@ struct TrackArgs {
 };
 
 #ifndef SVS_TRK_THREADS
-#define SVS_TRK_THREADS 1024
+#define SVS_TRK_THREADS 512
 #endif
 #ifndef SVS_TRK_UNROLL
 #define SVS_TRK_UNROLL 1
@@ -257,15 +257,25 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
-  // one sample per lane per trip; the next trip's stored point and previous-frame intensity (independent of T) are loaded
-  // before this trip's arithmetic, so only the bilinear taps -- whose addresses depend on the projection -- are exposed
-  int i = threadIdx.x;
-  SampleIn nxt = sample_load(L, (i < n ? i : 0) % cw, (i < n ? i : 0) / cw, cw, i < n);
-  for (; i < n; i += TRK_THREADS) {
-    const SampleIn cur = nxt;
-    const int j = i + TRK_THREADS;
-    nxt = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
-    sample_cpu_sem<JAC, U8SRC>(L, T, cur, true, a);
+  // TRK_UNROLL samples per lane per trip (independent gather chains in flight); the next trip's stored points and
+  // previous-frame intensities (independent of T) are loaded before this trip's arithmetic, so only the bilinear
+  // taps -- whose addresses depend on the projection -- are exposed
+  SampleIn nxt[TRK_UNROLL];
+#pragma unroll
+  for (int q = 0; q < TRK_UNROLL; ++q) {
+    const int j = threadIdx.x + q * TRK_THREADS;
+    nxt[q] = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
+  }
+  for (int i = threadIdx.x; i < n; i += TRK_UNROLL * TRK_THREADS) {
+    SampleIn cur[TRK_UNROLL];
+#pragma unroll
+    for (int q = 0; q < TRK_UNROLL; ++q) {
+      cur[q] = nxt[q];
+      const int j = i + (TRK_UNROLL + q) * TRK_THREADS;
+      nxt[q] = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
+    }
+#pragma unroll
+    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS < n, a);
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
