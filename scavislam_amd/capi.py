@@ -103,6 +103,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise SvsError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # torch bundles its own libamdhip64; importing it first makes the loader bind this library to that same HIP
+        # runtime instance (two runtimes in one process do not share devices, streams or allocations)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             fn = getattr(lib, name)
