@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   const int lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
-  if (MODE == 1 && !wave_valid) return;
   const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
   const bool active = lane < len;
 #define SVS_STAMP(k) do { if (B.dbg && lane == 0 && wave_valid) B.dbg[DBG_N * (size_t)chunk + (k)] = (long long)wall_clock64(); } while (0)
@@ -208,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? 4 * 64 * 18 : 1];   // W_obs of every edge lane
   __shared__ int s_pmin;
   int pmin = 0;
+  __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
+  if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
   if (MODE == 0) {
     for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += 256) s_win[i] = 0.0;
     for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) s_vec[i] = 0.0;
@@ -250,37 +251,62 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     for (int i = 0; i < 3; ++i) { lin.xa[i] = 0; lin.y[i] = 0; lin.g[i] = 0; }
     lin.rho0 = 0;
   }
+  // one global atomic per WORKGROUP for the scalar sums: same-address f64 atomics serialise in L2 (~20 ns each), and one
+  // per wave cost more than the rest of the back-substitution kernel
   if (MODE == 0) {
     const double c = wave_sum_f64(lin.rho0);
-    if (lane == 0) atomic_add_f64(B.chi2_cur, c);
+    if (lane == 0 && c != 0.0) lds_add_f64(&s_scal[0], c);      // window init barrier above ordered the zeroing
   }
-  // observer role: this lane owns pose ed.pose of its landmark; a self edge (observer == anchor)
-  // has no observer role: G2O_LITERAL folds its slot-1 terms into the anchor, EXACT drops them.
+  // observer role: this lane owns pose ed.pose of its landmark.  A self edge (observer == anchor: R = I, y = x_a up to
+  // rounding) has J_obs + J_anc = 0: it contributes to H_ll / b_l only, plus -- in G2O_LITERAL mode, SURVEY.md B-7 --
+  // the slot terms M_oo + M_aa + sym(M_oa) on the anchor's diagonal block, which collapse to M_aa = Ea^T A Ea
+  // (differences are O(eps |M|)); its b and W slot terms cancel.
   const bool obs_role = active && !self;
   const bool self_lit = self && B.self_mode == 0;
 
-  // ---- Bm = A D;  H_ll = D^T Bm,  b_l = -D^T g  -> segment sums -> D^-1 ---------------------------
+  // ---- per landmark sums, one segmented reduction: H_ll = sum D^T A D, b_l = -sum D^T g, and -- because x_a is common
+  //      to all edges of a landmark -- W_anc = -Ea^T (sum R^T A D), M_aa = Ea^T (sum R^T A R) Ea, b_anc = Ea^T (sum R^T g)
   double Bm[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) Bm[3 * i + j] = lin.A[3 * i] * lin.D[j] + lin.A[3 * i + 1] * lin.D[3 + j] + lin.A[3 * i + 2] * lin.D[6 + j];
-  double hl[9];   // 6 unique H_ll + 3 b_l
+  constexpr int NRED = MODE == 0 ? 27 : 18;
+  double red[NRED];      // [0..5] H_ll upper, [6..8] b_l, [9..17] S_RB = sum R^T Bm, (MODE 0:) [18..23] S_RAR upper, [24..26] S_Rg
   {
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = i; j < 3; ++j) hl[k++] = lin.D[i] * Bm[j] + lin.D[3 + i] * Bm[3 + j] + lin.D[6 + i] * Bm[6 + j];
+      for (int j = i; j < 3; ++j) red[k++] = lin.D[i] * Bm[j] + lin.D[3 + i] * Bm[3 + j] + lin.D[6 + i] * Bm[6 + j];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) hl[6 + i] = -(lin.D[i] * lin.g[0] + lin.D[3 + i] * lin.g[1] + lin.D[6 + i] * lin.g[2]);
+    for (int i = 0; i < 3; ++i) red[6 + i] = -(lin.D[i] * lin.g[0] + lin.D[3 + i] * lin.g[1] + lin.D[6 + i] * lin.g[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) red[9 + 3 * i + j] = obs_role ? lin.R[i] * Bm[j] + lin.R[3 + i] * Bm[3 + j] + lin.R[6 + i] * Bm[6 + j] : 0.0;
+    if (MODE == 0) {
+      double AR[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
+      const bool in_maa = obs_role || self_lit;
+      k = 18;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) red[k++] = in_maa ? lin.R[i] * AR[j] + lin.R[3 + i] * AR[3 + j] + lin.R[6 + i] * AR[6 + j] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) red[24 + i] = obs_role ? lin.R[i] * lin.g[0] + lin.R[3 + i] * lin.g[1] + lin.R[6 + i] * lin.g[2] : 0.0;
+    }
   }
   SVS_STAMP(2);
-  seg_allreduce<9>(hl, lane, seg_begin, seg_end, maxlen);
+  seg_allreduce<NRED>(red, lane, seg_begin, seg_end, maxlen);
   SVS_STAMP(3);
-  double Di[9], bl[3] = {hl[6], hl[7], hl[8]};
+  double Di[9], bl[3] = {red[6], red[7], red[8]};
   {
-    const double a00 = hl[0] + B.lambda, a01 = hl[1], a02 = hl[2], a11 = hl[3] + B.lambda, a12 = hl[4], a22 = hl[5] + B.lambda;
+    const double a00 = red[0] + B.lambda, a01 = red[1], a02 = red[2], a11 = red[3] + B.lambda, a12 = red[4], a22 = red[5] + B.lambda;
     // closed-form inverse of the symmetric 3x3 (Eigen fixed-size inverse = cofactors / det)
     const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
     const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
@@ -291,32 +317,24 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   double Db[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) Db[i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
-
-  // ---- W blocks: W_obs = [Bm ; y x Bm(:,c)],  W_anc = -[R^T Bm ; x_a x (R^T Bm)(:,c)] -----------------
-  double Wo[18], WA[18];
-  {
-    double wo[18], wa[18], RB[9];
+  // W_obs = Eo^T Bm = [Bm ; y x Bm(:,c)]  (0 for a self edge);  W_anc = -Ea^T S_RB = -[S_RB ; x_a x S_RB(:,c)], rebuilt where needed
+  double Wo[18];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) RB[3 * i + j] = lin.R[i] * Bm[j] + lin.R[3 + i] * Bm[3 + j] + lin.R[6 + i] * Bm[6 + j];
+  for (int c = 0; c < 3; ++c) {
+    double t0, t1, t2;
+    cross3(lin.y, Bm[c], Bm[3 + c], Bm[6 + c], t0, t1, t2);
+    Wo[c] = obs_role ? Bm[c] : 0.0; Wo[3 + c] = obs_role ? Bm[3 + c] : 0.0; Wo[6 + c] = obs_role ? Bm[6 + c] : 0.0;
+    Wo[9 + c] = obs_role ? t0 : 0.0; Wo[12 + c] = obs_role ? t1 : 0.0; Wo[15 + c] = obs_role ? t2 : 0.0;
+  }
+  auto make_WA = [&](double (&WA)[18]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      wo[c] = Bm[c]; wo[3 + c] = Bm[3 + c]; wo[6 + c] = Bm[6 + c];
-      cross3(lin.y, Bm[c], Bm[3 + c], Bm[6 + c], wo[9 + c], wo[12 + c], wo[15 + c]);
-      wa[c] = -RB[c]; wa[3 + c] = -RB[3 + c]; wa[6 + c] = -RB[6 + c];
       double t0, t1, t2;
-      cross3(lin.xa, RB[c], RB[3 + c], RB[6 + c], t0, t1, t2);
-      wa[9 + c] = -t0; wa[12 + c] = -t1; wa[15 + c] = -t2;
+      cross3(lin.xa, red[9 + c], red[12 + c], red[15 + c], t0, t1, t2);
+      WA[c] = -red[9 + c]; WA[3 + c] = -red[12 + c]; WA[6 + c] = -red[15 + c];
+      WA[9 + c] = -t0; WA[12 + c] = -t1; WA[15 + c] = -t2;
     }
-#pragma unroll
-    for (int i = 0; i < 18; ++i) {
-      Wo[i] = obs_role ? wo[i] : 0.0;
-      WA[i] = self ? (self_lit ? wo[i] + wa[i] : 0.0) : wa[i];
-    }
-  }
-  SVS_STAMP(4);
-  seg_allreduce<18>(WA, lane, seg_begin, seg_end, maxlen);
+  };
   SVS_STAMP(5);
   const int anchor = ed.anchor;
 
@@ -332,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     seg_allreduce<3>(c, lane, seg_begin, seg_end, maxlen);
     double xl[3] = {0, 0, 0};
     if (active) {
+      double WA[18];
+      make_WA(WA);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         double s = bl[j] - c[j];
@@ -356,7 +376,10 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     }
     sc = wave_sum_f64(sc);
     chi = wave_sum_f64(chi);
-    if (lane == 0) { atomic_add_f64(&B.scal[0], chi); atomic_add_f64(&B.scal[1], sc); }
+    __syncthreads();                                   // s_scal zeroed
+    if (lane == 0) { lds_add_f64(&s_scal[0], chi); lds_add_f64(&s_scal[1], sc); }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomic_add_f64(&B.scal[0], s_scal[0]); atomic_add_f64(&B.scal[1], s_scal[1]); }
     return;
   }
 
@@ -372,66 +395,12 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     if (wp < WIN) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + r], v);
     else atomic_add_f64((which ? B.bs : B.bp) + 6 * p + r, v);
   };
-  // Phases are ordered so that few values are live at a time (two waves per SIMD need <= 256 VGPRs).
-  // (1) anchor diagonal terms that do not involve W: sum over the landmark of
-  //     M_aa = Ea^T (R^T A R) Ea and b_anc = Ea^T R^T g  (+ the slot-1 terms of a literal self edge)
-  {
-    double AR[9], RAR[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) RAR[3 * i + j] = lin.R[i] * AR[j] + lin.R[3 + i] * AR[3 + j] + lin.R[6 + i] * AR[6 + j];
-    double Rg[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Rg[i] = lin.R[i] * lin.g[0] + lin.R[3 + i] * lin.g[1] + lin.R[6 + i] * lin.g[2];
-    double ma[27];   // 21 unique of sum M_aa, 6 of sum b_anc
-    {
-      double Maa[36];
-      sym_block(RAR, lin.xa, Maa);
-      int k = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c) ma[k++] = self ? 0.0 : Maa[6 * r + c];
-      double t0, t1, t2;
-      cross3(lin.xa, Rg[0], Rg[1], Rg[2], t0, t1, t2);
-      ma[21] = self ? 0.0 : Rg[0]; ma[22] = self ? 0.0 : Rg[1]; ma[23] = self ? 0.0 : Rg[2];
-      ma[24] = self ? 0.0 : t0; ma[25] = self ? 0.0 : t1; ma[26] = self ? 0.0 : t2;
-      if (__any(self_lit)) {
-        // both slots of a self edge are the anchor vertex, so slot-1 and slot-2 diagonal terms
-        // and the symmetrised (1,2) pair all land on its diagonal block: M_oo + M_aa + sym(M_oa), b_obs + b_anc
-        double Moo[36], Noa[36];
-        sym_block(lin.A, lin.y, Moo);
-        cross_block(AR, lin.y, lin.xa, Noa);                // M_oa = -Noa
-        int q = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = r; c < 6; ++c) { if (self_lit) ma[q] = Moo[6 * r + c] + Maa[6 * r + c] - 0.5 * (Noa[6 * r + c] + Noa[6 * c + r]); ++q; }
-        double u0, u1, u2;
-        cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], u0, u1, u2);
-        if (self_lit) { ma[21] = Rg[0] - lin.g[0]; ma[22] = Rg[1] - lin.g[1]; ma[23] = Rg[2] - lin.g[2]; ma[24] = t0 - u0; ma[25] = t1 - u1; ma[26] = t2 - u2; }
-      }
-    }
-    seg_allreduce<27>(ma, lane, seg_begin, seg_end, maxlen);
-    if (active && head) {
-      int k = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c) add_blk(anchor, anchor, 6 * r + c, ma[k++]);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) add_vec(0, anchor, r, ma[21 + r]);
-    }
-  }
-  SVS_STAMP(6);
-  // (2) Schur terms of the anchor: -(W_A D^-1) W_A^T and W_A D^-1 b_l, once per landmark
+  // (1) anchor block, once per landmark: Ea^T S_RAR Ea - (W_A D^-1) W_A^T,  b_anc = Ea^T S_Rg,  Schur rhs W_A D^-1 b_l
   if (active && head) {
-    double WAD[18];
+    double WA[18], WAD[18], SR[9], Maa[36];
+    make_WA(WA);
+    SR[0] = red[18]; SR[1] = red[19]; SR[2] = red[20]; SR[3] = red[19]; SR[4] = red[21]; SR[5] = red[22]; SR[6] = red[20]; SR[7] = red[22]; SR[8] = red[23];
+    sym_block(SR, lin.xa, Maa);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -440,12 +409,18 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = r; c < 6; ++c)
-        add_blk(anchor, anchor, 6 * r + c, -(WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]));
+        add_blk(anchor, anchor, 6 * r + c, Maa[6 * r + c] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]));
+    double t0, t1, t2;
+    cross3(lin.xa, red[24], red[25], red[26], t0, t1, t2);
+    const double ba[6] = {red[24], red[25], red[26], t0, t1, t2};
 #pragma unroll
-    for (int r = 0; r < 6; ++r) add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+    for (int r = 0; r < 6; ++r) {
+      add_vec(0, anchor, r, ba[r]);
+      add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+    }
   }
   SVS_STAMP(7);
-  // (3) observer part: blocks (i,i), (i,A), b_i;  W_obs is parked in LDS for the pair phase
+  // (2) observer part: blocks (i,i), (i,A), b_i;  W_obs is parked in LDS for the pair phase
   double *my_wo = s_wo + ((threadIdx.x >> 6) * 64 + lane) * 18;
 #pragma unroll
   for (int i = 0; i < 18; ++i) my_wo[i] = Wo[i];
@@ -466,7 +441,8 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
           add_blk(pi, pi, 6 * r + c, Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]));
     }
     {
-      double AR[9], Noa[36];
+      double AR[9], Noa[36], WA[18];
+      make_WA(WA);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -491,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
     }
   }
   SVS_STAMP(8);
-  // (4) observer-observer pairs of a landmark, circulant schedule: in round r the edge with local index a
+  // (3) observer-observer pairs of a landmark, circulant schedule: in round r the edge with local index a
   //     pairs with (a + r) mod m, so all m lanes of a landmark work for floor(m/2) rounds (instead of one
   //     lane-partner distance per round over m-1 rounds).  -(W_a D^-1) W_b^T goes to block (min, max).
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -526,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   // flush the LDS window: one global atomic per touched element per workgroup
   __syncthreads();
   SVS_STAMP(10);
+  if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur, s_scal[0]);
   if (pmin != 0x7fffffff) {
     for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) {
       const int wb = i / 36, rc = i - wb * 36;
@@ -1753,7 +1730,7 @@ static int launch_reduce(svs_ba *ba, double lambda) {
       for (int k = 1; k < DBG_N; ++k) ph[k] += (d[k] - d[k - 1]) * 0.01;
     }
     const double n = B.n_chunks;
-    static const char *names[DBG_N] = {"", "load", "linearize+Hll", "reduce Hll", "Dinv+W", "reduce W_A", "anchor M_aa", "anchor Schur", "observer blocks", "pairs", "barrier", "flush"};
+    static const char *names[DBG_N] = {"", "load", "linearize + landmark sums", "segment reduce", "-", "D^-1, W", "-", "anchor block", "observer blocks", "pairs", "barrier", "flush"};
     fprintf(stderr, "[svs_ba] schur kernel timeline: span %.1f us, %d waves, start avg %.1f max %.1f us, wave duration max %.1f us; phases (us avg):",
             (t1 - t0) * 0.01, B.n_chunks, s_start / n, mx_start, mx_dur);
     for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f |", names[k], ph[k] / n);
