@@ -1559,7 +1559,8 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
       SVS_REQUIRE(ctx, a == h_edges[i].anchor);                          // one anchor per point (slam_graph.hpp:121-133)
       span = std::max(span, std::abs(h_edges[i].pose - a) + 1);
     }
-    const int G = std::max(1, std::min(8, WIN - span));                  // anchors interleaved per group
+    int G = std::max(1, std::min(8, WIN - span));                        // anchors interleaved per group
+    if (const char *e = getenv("SVS_BA_GROUP")) G = std::max(1, atoi(e));   // experiments only
     std::vector<int> seen(P, 0);
     for (int l = 0; l < L; ++l) {
       const int a = anchor_of[l];
