@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   int pmin = 0;
   __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
   if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
+  if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 16) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
   if (MODE == 0) {
     for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += 256) s_win[i] = 0.0;
     for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) s_vec[i] = 0.0;
@@ -1480,6 +1481,7 @@ struct svs_ba {
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
+  double *h_scal = nullptr;             // pinned host mirror of d_scal (the per-trial read-back must not go through a pageable staging copy)
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
   bool profile_ready = false;
@@ -1522,6 +1524,7 @@ extern "C" int svs_ba_create(svs_ctx *ctx, svs_ba **out) {
 extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (!ba) return SVS_OK;
   (void)hipStreamSynchronize(ba->ctx->stream);
+  if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
   ba->free_all();
   for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
   delete ba;
@@ -1783,7 +1786,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       if (rc) return rc;
       if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
       BaDev B = make_dev(ba, lambda);
-      SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));
+      if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
       SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
       if (ba->use_fused_solve)
         hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
@@ -1798,8 +1801,9 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
       SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
       if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
-      double h[16];
-      SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+      if (!ba->h_scal) SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_scal, sizeof(double) * 16, hipHostMallocDefault));
+      double *h = ba->h_scal;
+      SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       float ms;
       SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[0], ba->ev[1])); ba->t_reduce += ms; ba->n_reduce++;
