@@ -232,6 +232,22 @@ def main():
         ctx.sync()
         lat_ms = (time.perf_counter() - t0) / 20 * 1e3
     del fe1
+    # batched modes in between (B in {1, 8, 64}): same step, B independent streams per launch
+    batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
+    for Bs in (8, 64):
+        if Bs >= B:
+            continue
+        fes = build_frontend(Bs)
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                fes["step"]()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fes["step"]()
+            ctx.sync()
+            batch_sweep[str(Bs)] = round(Bs * 10 / (time.perf_counter() - t0), 1)
+        del fes
 
     # ------------------------------------------------------------------ back-end (Schur) region
     P_, L_ = 50, 20000
@@ -369,6 +385,7 @@ def main():
                          "dense_passes_per_frame": passes, "corners_per_frame": n_corners, "matches_per_frame": n_matched,
                          "dense_track_pose_err": track_err,
                          "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
+                         "frames_per_s_per_gpu_by_batch": batch_sweep,
                          "stereo_bm": dict(stereo_info, ms_per_batch=round(stage_ms["stereo_bm"], 4),
                                            frames_per_s_if_block_matching_is_added_to_the_step=round(world * B / ((t_front / K) + stage_ms["stereo_bm"] * 1e-3), 1)),
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
