@@ -325,3 +325,53 @@ def test_dense_full_resolution_variant(gpu_ctx, scene_frames):
     np.testing.assert_allclose(got["b"], ref["b"], rtol=1e-5, atol=1e-5 * np.abs(ref["b"]).max())
     chi2 = gt.chi2(prev.f32[l][0], cloud, T34, c.f, c.cx, c.cy, w, h, cur.stride[l], w)
     np.testing.assert_allclose(chi2, ref["chi2"], rtol=1e-6)
+
+
+def test_dense_tracking_rgbd_config_with_invalid_depth(gpu_ctx):
+    """RGB-D intrinsics (data/rgbd_example.cfg), disparity from u16 depth with the depthToDisp
+    semantics (frame_grabber-impl.cpp:136-151: depth * 1/5000 m -> f / (depth * b), 0 where the sensor has no depth),
+    10 % invalid pixels in blobs.  Cloud bit-exact (w = -1 entries included), pass sums and tracked pose as usual."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker
+    ctx, stream = gpu_ctx
+    cam = synth.CAM_RGBD
+    sc = synth.Scene(2013)
+    traj = synth.trajectory(3, step=0.03, yaw_deg=0.15)
+    rng = np.random.default_rng(2013)
+    frames = []
+    for i in (0, 1):
+        img, disp = sc.render(cam, traj[i], seed=40 + i)
+        depth_u16 = np.where(disp > 0, np.rint(cam["f"] * cam["b"] / np.maximum(disp, 1e-6) * 5000.0), 0).astype(np.uint16)
+        for _ in range(60):                                     # blobs of missing depth, about 10 % of the image
+            x0, y0 = rng.integers(0, cam["w"] - 40), rng.integers(0, cam["h"] - 40)
+            depth_u16[y0:y0 + rng.integers(8, 40), x0:x0 + rng.integers(8, 40)] = 0
+        depth = depth_u16.astype(np.float32) * np.float32(1.0 / 5000.0)
+        with np.errstate(divide="ignore"):
+            d = np.where(depth_u16 > 0, np.float32(cam["f"]) / (depth * np.float32(cam["b"])) , np.float32(0)).astype(np.float32)
+        frames.append((img, d))
+    assert 0.05 < (frames[0][1] == 0).mean() < 0.25
+    prev = _frame(ctx, stream, cam, [frames[0][0]], [frames[0][1]])
+    cur = _frame(ctx, stream, cam, [frames[1][0]], [frames[1][1]])
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    ctx.sync()
+    clouds = [O.pointcloud_cpu(frames[0][1], prev.cams[l], l, I) for l in range(3)]
+    for l in range(3):
+        got = dtp.ref_dense_points[l][0].cpu().numpy()
+        assert np.array_equal(got, clouds[l]) and (got[..., 3] == -1).any()
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dtp.ref_dense_points
+    pyr_p, pyr_c = O.build_pyramid(frames[0][0]), O.build_pyramid(frames[1][0])
+    fl = [O.convert_sobel(p) for p in pyr_c]
+    for l in range(3):
+        ref = O.dense_pass_cpu(clouds[l], pyr_p[l], fl[l][0], fl[l][1], fl[l][2], cur.cams[l], I, True)
+        got = dt.pass_sums(l, prev.pyr, I.reshape(12), True)[0]
+        assert got["n_valid"] == ref["n_valid"]
+        np.testing.assert_allclose(got["H"], ref["H"], rtol=0, atol=1e-9 * np.abs(ref["H"]).max())
+    T_gpu, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+    T_ref, _ = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cur.cams, I)
+    T_true = synth.pose_mul(traj[1], synth.pose_inv(traj[0]))
+    np.testing.assert_allclose(T_gpu[0], T_ref, rtol=0, atol=1e-4)
+    assert np.abs(T_gpu[0][:, :3] - T_true[:, :3]).max() < 2e-3      # rotation recovered (the 3 cm translation is below what this scene constrains)
