@@ -105,7 +105,7 @@ constexpr int WAVES_PER_BLOCK = 4;
 
 __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_result *__restrict__ out) {
   __shared__ uint8_t s_patch[WAVES_PER_BLOCK][104];
-  __shared__ int s_cand[WAVES_PER_BLOCK][64][2];   // per-wave list of the window chunk's hits: packed (x,y), key
+  __shared__ int s_cand[WAVES_PER_BLOCK][128];      // per-wave list of window hits waiting to be scored: packed (y << 16) | x
   const svs_match_args &A = M.a;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ip = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -193,14 +193,21 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
         const int cstride = A.cur_stride[lvl];
         const int side = 2 * R + 1, npos = side * side;
         const float inv_side = 1.0f / (float)side;
-        // 16 lanes per candidate (lane = patch row x half-row, 4 pixels each): four candidates are
-        // scored per trip, sums reduced inside the 16-lane group
-        const int sub = lane & 15, grp = lane >> 4, prow = sub >> 1, phalf = sub & 1;
-        int k4[4];
+        // key patch as 16 packed dwords (8 rows x 2), wave-uniform: lane l < 16 packs dword l, broadcast with readlane
+        uint32_t kd = 0;
+        if (lane < 16) {
+          const uint8_t *kp = &s_patch[wave][((lane >> 1) + 1) * 10 + (lane & 1) * 4 + 1];
+          kd = (uint32_t)kp[0] | ((uint32_t)kp[1] << 8) | ((uint32_t)kp[2] << 16) | ((uint32_t)kp[3] << 24);
+        }
+        uint32_t key4[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k4[j] = s_patch[wave][(prow + 1) * 10 + phalf * 4 + j + 1];
-        int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-group running best
+        for (int i = 0; i < 16; ++i) key4[i] = (uint32_t)__builtin_amdgcn_readlane((int)kd, i);
+        // window scan: hits are compacted into a per-wave LDS list; whenever it holds >= 64 corners (and at the end) they
+        // are scored one lane per candidate: 8 rows x 2 unaligned dwords of the current image, sums with V_SAD_U8 /
+        // V_DOT4_U32_U8 against the wave-uniform key dwords -- no cross-lane reduction per candidate
+        int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-lane running best
         unsigned gkey = 0xffffffffu;
+        int ncand = 0;                                 // wave-uniform fill of s_cand
         for (int p0 = 0; p0 < npos; p0 += 64) {
           const int pos = p0 + lane;
           int cx = 0, cy = 0;
@@ -218,38 +225,44 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
             }
           }
           const unsigned long long m = __ballot(hit);
-          const int nhit = __popcll(m);
-          if (nhit == 0) continue;                                   // wave-uniform
-          if (hit) {
-            const int r = __popcll(m & ((1ull << lane) - 1ull));
-            s_cand[wave][r][0] = (cy << 16) | cx;
-            s_cand[wave][r][1] = (int)quad_key(cx, cy, cam.w, cam.h);
-          }
+          if (hit) s_cand[wave][ncand + __popcll(m & ((1ull << lane) - 1ull))] = (cy << 16) | cx;
+          ncand += __popcll(m);
+          const bool last = p0 + 64 >= npos;
+          if (ncand < 64 && !last) continue;                           // wave-uniform
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_s_waitcnt(0xc07f);
-          for (int t = 0; t < nhit; t += 4) {
-            const int ci = t + grp;
-            const bool valid = ci < nhit;
-            const int packed = s_cand[wave][valid ? ci : 0][0];
-            const unsigned hk = (unsigned)s_cand[wave][valid ? ci : 0][1];
-            const int hx = packed & 0xffff, hy = packed >> 16;
-            const uint8_t *p = cimg + (size_t)(hy - 4 + prow) * cstride + (hx - 4 + phalf * 4);
-            uint32_t v4;
-            __builtin_memcpy(&v4, p, 4);                             // 4 consecutive pixels of the patch row
-            int sB = 0, sBB = 0, sAB = 0;
+          for (int base = 0; base < ncand; base += 64) {
+            if (base + lane < ncand) {
+              const int packed = s_cand[wave][base + lane];
+              const int hx = packed & 0xffff, hy = packed >> 16;
+              const uint8_t *p = cimg + (size_t)(hy - 4) * cstride + (hx - 4);
+              uint32_t sB = 0, sBB = 0, sAB = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int bj = (v4 >> (8 * j)) & 0xff; sB += bj; sBB += bj * bj; sAB += bj * k4[j]; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) { sB += __shfl_xor(sB, o, 64); sBB += __shfl_xor(sBB, o, 64); sAB += __shfl_xor(sAB, o, 64); }
-            const int z = sumAA - 2 * sAB - sBB - (sumA * sumA - 2 * sumA * sB - sB * sB) / 64;
-            // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, key); z must also beat thr_mean
-            if (valid && z < init_dist && (z < gbest || (z == gbest && hk < gkey))) { gbest = z; gkey = hk; gx_ = hx; gy_ = hy; }
+              for (int r = 0; r < 8; ++r) {
+                uint32_t v0, v1;
+                __builtin_memcpy(&v0, p + (size_t)r * cstride, 4);
+                __builtin_memcpy(&v1, p + (size_t)r * cstride + 4, 4);
+                sB = __builtin_amdgcn_sad_u8(v0, 0u, sB); sB = __builtin_amdgcn_sad_u8(v1, 0u, sB);
+                sBB = __builtin_amdgcn_udot4(v0, v0, sBB, false); sBB = __builtin_amdgcn_udot4(v1, v1, sBB, false);
+                sAB = __builtin_amdgcn_udot4(v0, key4[2 * r], sAB, false); sAB = __builtin_amdgcn_udot4(v1, key4[2 * r + 1], sAB, false);
+              }
+              const int iB = (int)sB;
+              const int z = sumAA - 2 * (int)sAB - (int)sBB - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
+              // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, key); z must also beat thr_mean.
+              // The quadrant key is only needed to break ties, so it is computed lazily (ties are rare).
+              if (z < init_dist) {
+                if (z < gbest) { gbest = z; gx_ = hx; gy_ = hy; }
+                else if (z == gbest && quad_key(hx, hy, cam.w, cam.h) < quad_key(gx_, gy_, cam.w, cam.h)) { gx_ = hx; gy_ = hy; }
+              }
+            }
           }
+          ncand = 0;
           __builtin_amdgcn_wave_barrier();
         }
-        // lexicographic min across the four groups
+        // lexicographic min across the wave
+        gkey = gbest != 0x7fffffff ? quad_key(gx_, gy_, cam.w, cam.h) : 0xffffffffu;
 #pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
+        for (int o = 1; o < 64; o <<= 1) {
           const int oz = __shfl_xor(gbest, o, 64), ox = __shfl_xor(gx_, o, 64), oy = __shfl_xor(gy_, o, 64);
           const unsigned ok = __shfl_xor(gkey, o, 64);
           if (oz < gbest || (oz == gbest && ok < gkey)) { gbest = oz; gkey = ok; gx_ = ox; gy_ = oy; }
