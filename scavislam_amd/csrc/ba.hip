@@ -1484,6 +1484,11 @@ struct svs_ba {
   double *h_scal = nullptr;             // pinned host mirror of d_scal (the per-trial read-back must not go through a pageable staging copy)
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
+  // persistent host work arrays / pinned staging of set_problem, device capacities (grow-only)
+  std::vector<int> w_anchor, w_nobs, w_pos, w_off, w_aoff, w_alist, w_order, w_fill, w_cs, w_cl;
+  svs_ba_edge *h_edges = nullptr; size_t h_edges_cap = 0;
+  size_t cap_poses[2] = {0, 0}, cap_psi[2] = {0, 0}, cap_edges = 0, cap_cs = 0, cap_cl = 0, cap_cons = 0, cap_red = 0, cap_x = 0, cap_scal = 0,
+         cap_linv = 0, cap_rowmax = 0, cap_colmin = 0, cap_pattern = 0, cap_upanel = 0;
   bool profile_ready = false;
   hipEvent_t ev[6] = {};
   float t_reduce = 0, t_solve = 0, t_backsub = 0;
@@ -1497,6 +1502,9 @@ struct svs_ba {
     if (d_upanel) (void)hipFree(d_upanel); d_upanel = nullptr; env_R = 0; use_lds_solve = false;
     d_rowmax = d_colmin = nullptr; d_pattern = nullptr; profile_ready = false;
     d_edges = nullptr; d_chunk_start = d_chunk_len = nullptr; d_cons = nullptr; d_red = d_x = d_scal = d_linv = nullptr;
+    cap_poses[0] = cap_poses[1] = cap_psi[0] = cap_psi[1] = cap_edges = cap_cs = cap_cl = cap_cons = cap_red = cap_x = cap_scal = cap_linv = cap_rowmax =
+        cap_colmin = cap_pattern = cap_upanel = 0;
+    if (h_edges) { (void)hipHostFree(h_edges); h_edges = nullptr; h_edges_cap = 0; }
   }
 };
 
@@ -1539,77 +1547,89 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
   if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ba->free_all();
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
+  ba->profile_ready = false; ba->env_R = 0; ba->use_lds_solve = ba->use_fused_solve = false;
   // Edge order (copyDataToG2o iterates hash sets, so the reference has no meaningful edge order to
   // preserve): landmarks are grouped by anchor so that the poses a workgroup touches stay inside its
   // LDS accumulation window, but inside a group of G consecutive anchors the landmarks are dealt
   // round-robin over the anchors -- neighbouring lanes then hit different pose blocks and the LDS
   // atomics of one instruction rarely collide on an address.  Whole landmarks are packed into
   // <=64-edge wave chunks, observers ascending inside a landmark.
-  std::vector<int> order(E);
+  // All of it is linear time (bucket passes, no comparison sort of the edge list): this marshalling is what a caller
+  // pays per optimize() once the kernels take a fraction of a millisecond.
+  std::vector<int> &anchor_of = ba->w_anchor, &n_obs = ba->w_nobs, &lm_pos = ba->w_pos, &lm_off = ba->w_off;
+  anchor_of.assign(L, -1); n_obs.assign(L, 0);
+  int span = 1;
   for (int i = 0; i < E; ++i) {
-    order[i] = i;
-    SVS_REQUIRE(ctx, h_edges[i].point >= 0 && h_edges[i].point < L && h_edges[i].pose >= 0 && h_edges[i].pose < P && h_edges[i].anchor >= 0 && h_edges[i].anchor < P);
+    const svs_ba_edge &e = h_edges[i];
+    SVS_REQUIRE(ctx, e.point >= 0 && e.point < L && e.pose >= 0 && e.pose < P && e.anchor >= 0 && e.anchor < P);
+    int &a = anchor_of[e.point];
+    if (a < 0) a = e.anchor;
+    SVS_REQUIRE(ctx, a == e.anchor);                                     // one anchor per point (slam_graph.hpp:121-133)
+    span = std::max(span, std::abs(e.pose - a) + 1);
+    if (++n_obs[e.point] > 64) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
   }
-  std::vector<long long> lm_key(L, 0);
+  int G = std::max(1, std::min(8, WIN - span));                          // anchors interleaved per group
+  if (const char *e = getenv("SVS_BA_GROUP")) G = std::max(1, atoi(e));     // experiments only
+  // landmark order: per anchor the landmarks in index order; per group of G anchors deal them round-robin
+  std::vector<int> &by_anchor_off = ba->w_aoff, &by_anchor = ba->w_alist, &lm_order = ba->w_order;
+  by_anchor_off.assign(P + 1, 0);
+  for (int l = 0; l < L; ++l) if (anchor_of[l] >= 0) ++by_anchor_off[anchor_of[l] + 1];
+  for (int a = 0; a < P; ++a) by_anchor_off[a + 1] += by_anchor_off[a];
+  by_anchor.resize(by_anchor_off[P]);
   {
-    std::vector<int> anchor_of(L, -1);
-    int span = 1;
+    std::vector<int> fill(by_anchor_off.begin(), by_anchor_off.end() - 1);
+    for (int l = 0; l < L; ++l) if (anchor_of[l] >= 0) by_anchor[fill[anchor_of[l]]++] = l;
+  }
+  lm_order.clear(); lm_order.reserve(by_anchor.size());
+  for (int g0 = 0; g0 < P; g0 += G) {
+    const int g1 = std::min(P, g0 + G);
+    int longest = 0;
+    for (int a = g0; a < g1; ++a) longest = std::max(longest, by_anchor_off[a + 1] - by_anchor_off[a]);
+    for (int r = 0; r < longest; ++r)
+      for (int a = g0; a < g1; ++a)
+        if (r < by_anchor_off[a + 1] - by_anchor_off[a]) lm_order.push_back(by_anchor[by_anchor_off[a] + r]);
+  }
+  // edge slots: landmarks in that order, each with its observers ascending (insertion into <= 64 slots)
+  lm_pos.assign(L, -1); lm_off.assign(lm_order.size() + 1, 0);
+  for (size_t k = 0; k < lm_order.size(); ++k) { lm_pos[lm_order[k]] = (int)k; lm_off[k + 1] = lm_off[k] + n_obs[lm_order[k]]; }
+  if ((size_t)E > ba->h_edges_cap) {
+    if (ba->h_edges) (void)hipHostFree(ba->h_edges);
+    ba->h_edges_cap = (size_t)E + (size_t)E / 4 + 64;
+    SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_edges, sizeof(svs_ba_edge) * ba->h_edges_cap, hipHostMallocDefault));
+  }
+  svs_ba_edge *sorted = ba->h_edges;      // pinned: the upload is a plain DMA, no pageable staging copy
+  {
+    std::vector<int> &filled = ba->w_fill;
+    filled.assign(lm_order.size(), 0);
     for (int i = 0; i < E; ++i) {
-      int &a = anchor_of[h_edges[i].point];
-      if (a < 0) a = h_edges[i].anchor;
-      SVS_REQUIRE(ctx, a == h_edges[i].anchor);                          // one anchor per point (slam_graph.hpp:121-133)
-      span = std::max(span, std::abs(h_edges[i].pose - a) + 1);
-    }
-    int G = std::max(1, std::min(8, WIN - span));                        // anchors interleaved per group
-    if (const char *e = getenv("SVS_BA_GROUP")) G = std::max(1, atoi(e));   // experiments only
-    std::vector<int> seen(P, 0);
-    for (int l = 0; l < L; ++l) {
-      const int a = anchor_of[l];
-      if (a < 0) continue;
-      const int rank = seen[a]++;
-      lm_key[l] = ((long long)(a / G) << 40) | ((long long)rank << 8) | (long long)(a % G);
+      const svs_ba_edge &e = h_edges[i];
+      const int k = lm_pos[e.point], base = lm_off[k];
+      int j = filled[k]++;
+      while (j > 0 && sorted[base + j - 1].pose > e.pose) { sorted[base + j] = sorted[base + j - 1]; --j; }
+      SVS_REQUIRE(ctx, j == 0 || sorted[base + j - 1].pose != e.pose);     // one observation per (point, keyframe)
+      sorted[base + j] = e;
     }
   }
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const long long ka = lm_key[h_edges[a].point], kb = lm_key[h_edges[b].point];
-    if (ka != kb) return ka < kb;
-    if (h_edges[a].point != h_edges[b].point) return h_edges[a].point < h_edges[b].point;
-    return h_edges[a].pose < h_edges[b].pose;
-  });
-  std::vector<svs_ba_edge> sorted(E);
-  for (int i = 0; i < E; ++i) sorted[i] = h_edges[order[i]];
-  std::vector<int> cs, cl;
-  int i = 0;
-  while (i < E) {
-    int start = i, len = 0;
-    while (i < E) {
-      int j = i;
-      while (j < E && sorted[j].point == sorted[i].point) ++j;
-      int m = j - i;
-      if (m > 64) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
-      for (int a = i + 1; a < j; ++a) {
-        SVS_REQUIRE(ctx, sorted[a].anchor == sorted[i].anchor);          // one anchor per point (slam_graph.hpp:121-133)
-        SVS_REQUIRE(ctx, sorted[a].pose != sorted[a - 1].pose);          // one observation per (point, keyframe)
-      }
-      if (len + m > 64) break;
-      len += m; i = j;
-    }
+  std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
+  cs.clear(); cl.clear();
+  for (size_t k = 0; k < lm_order.size();) {
+    const int start = lm_off[k];
+    int len = 0;
+    while (k < lm_order.size() && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
     cs.push_back(start); cl.push_back(len);
   }
   ba->n_chunks = (int)cs.size();
   // structural pattern of the reduced camera system: poses sharing a landmark, and constraints
   ba->h_pattern.assign((size_t)P * P, 0.0);
-  for (int a = 0; a < E;) {
-    int b = a;
-    int lo = std::min(sorted[a].pose, sorted[a].anchor), hi = std::max(sorted[a].pose, sorted[a].anchor);
-    while (b < E && sorted[b].point == sorted[a].point) { lo = std::min(lo, sorted[b].pose); hi = std::max(hi, sorted[b].pose); ++b; }
+  for (size_t k = 0; k < lm_order.size(); ++k) {
+    const int a = lm_off[k], b = lm_off[k + 1];
+    int lo = std::min(sorted[a].pose, sorted[a].anchor), hi = std::max(sorted[b - 1].pose, sorted[a].anchor);
+    lo = std::min(lo, sorted[a].pose);
     // envelope only needs, per pose, the farthest co-visible pose: mark (p, hi) for every pose of the landmark
     for (int e = a; e < b; ++e) ba->h_pattern[(size_t)sorted[e].pose * P + hi] = 1.0;
     ba->h_pattern[(size_t)sorted[a].anchor * P + hi] = 1.0;
     ba->h_pattern[(size_t)lo * P + hi] = 1.0;
-    a = b;
   }
   if (add_pose_terms)
     for (int c = 0; c < C; ++c) {
@@ -1618,25 +1638,34 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     }
   const size_t nblk = (size_t)P * (P + 1) / 2;
   ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
+  // device buffers persist across calls and only grow (the window changes by about one keyframe per call)
+  auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
+    if (bytes <= *cap && *ptr) return hipSuccess;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(ptr, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+  };
   for (int k = 0; k < 2; ++k) {
-    SVS_HIP(ctx, hipMalloc(&ba->d_poses[k], sizeof(double) * 12 * (size_t)P));
-    SVS_HIP(ctx, hipMalloc(&ba->d_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
+    SVS_HIP(ctx, ensure((void **)&ba->d_poses[k], &ba->cap_poses[k], sizeof(double) * 12 * (size_t)P));
+    SVS_HIP(ctx, ensure((void **)&ba->d_psi[k], &ba->cap_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
     if (L) SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[k], h_psi, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
   }
-  SVS_HIP(ctx, hipMalloc(&ba->d_edges, sizeof(svs_ba_edge) * (size_t)std::max(E, 1)));
-  SVS_HIP(ctx, hipMalloc(&ba->d_chunk_start, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
-  SVS_HIP(ctx, hipMalloc(&ba->d_chunk_len, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
-  SVS_HIP(ctx, hipMalloc(&ba->d_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
-  SVS_HIP(ctx, hipMalloc(&ba->d_red, sizeof(double) * ba->red_count));
-  SVS_HIP(ctx, hipMalloc(&ba->d_x, sizeof(double) * 6 * (size_t)P));
-  SVS_HIP(ctx, hipMalloc(&ba->d_scal, sizeof(double) * 16));
-  SVS_HIP(ctx, hipMalloc(&ba->d_linv, sizeof(double) * 36 * (size_t)P));
-  SVS_HIP(ctx, hipMalloc(&ba->d_rowmax, sizeof(int) * (size_t)P));
-  SVS_HIP(ctx, hipMalloc(&ba->d_colmin, sizeof(int) * (size_t)P));
-  SVS_HIP(ctx, hipMalloc(&ba->d_pattern, sizeof(double) * (size_t)P * P));
-  ba->profile_ready = false;
-  if (E) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges, sorted.data(), sizeof(svs_ba_edge) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, ensure((void **)&ba->d_edges, &ba->cap_edges, sizeof(svs_ba_edge) * (size_t)std::max(E, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_red, &ba->cap_red, sizeof(double) * ba->red_count));
+  SVS_HIP(ctx, ensure((void **)&ba->d_x, &ba->cap_x, sizeof(double) * 6 * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * 16));
+  SVS_HIP(ctx, ensure((void **)&ba->d_linv, &ba->cap_linv, sizeof(double) * 36 * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_pattern, &ba->cap_pattern, sizeof(double) * (size_t)P * P));
+  if (E) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges, sorted, sizeof(svs_ba_edge) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
   if (ba->n_chunks) {
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_start, cs.data(), sizeof(int) * cs.size(), hipMemcpyHostToDevice, ctx->stream));
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_len, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -1694,10 +1723,15 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   ba->lds_solve_smem = need;
   ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
   if (ba->use_lds_solve) {
-    if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; }
     const size_t up_count = 36 * (size_t)P * std::max(R, FUSE_SLOTS) + 128;      // + write sink + zero block of the fused kernel
-    SVS_HIP(ctx, hipMalloc(&ba->d_upanel, sizeof(double) * up_count));
-    SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel, 0, sizeof(double) * up_count, ctx->stream));
+    if (sizeof(double) * up_count > ba->cap_upanel || !ba->d_upanel) {
+      if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; ba->cap_upanel = 0; }
+      const size_t want = sizeof(double) * (up_count + up_count / 4);
+      SVS_HIP(ctx, hipMalloc(&ba->d_upanel, want));
+      ba->cap_upanel = want;
+    }
+    // the fused kernel's zero block sits right behind the P x 10 panel rows (position depends on P): clear sink + zero block
+    SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel + (up_count - 128), 0, sizeof(double) * 128, ctx->stream));
     if (need > 64 * 1024) {
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
