@@ -68,36 +68,90 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
-// One pyrDown step.  Block = 32x8 output pixels; source footprint 67x19 staged in LDS, then the
-// separable [1 4 6 4 1] passes run out of LDS (horizontal into u16, vertical into the output).
-constexpr int PD_TX = 32, PD_TY = 8, PD_SW = 2 * PD_TX + 3, PD_SH = 2 * PD_TY + 3;
+// One pyrDown step, no LDS: a lane produces a 4 x 2 patch of output pixels from a 7-row x 11-byte source footprint
+// held in registers (three unaligned dword loads per row), horizontal [1 4 6 4 1] per row with V_DOT4_U32_U8, the two
+// vertical combinations on packed u16 pairs; `(s+128)>>8`; one dword store per output row.
+__device__ __forceinline__ uint32_t ld_u32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restrict__ src, int w, int h, int ss,
-                                                          size_t sb, uint8_t *__restrict__ dst, int dw, int dh,
-                                                          int ds, size_t db) {
-  __shared__ uint8_t s_src[PD_SH][PD_SW + 1];
-  __shared__ uint16_t s_h[PD_SH][PD_TX];
-  const int tid = threadIdx.y * PD_TX + threadIdx.x;
-  const int ox0 = blockIdx.x * PD_TX, oy0 = blockIdx.y * PD_TY;
+                                                         size_t sb, uint8_t *__restrict__ dst, int dw, int dh,
+                                                         int ds, size_t db) {
+  const int ox = 4 * (blockIdx.x * 64 + threadIdx.x), oy = 2 * (blockIdx.y * 4 + threadIdx.y);      // 4 waves = 4 output row pairs
+  if (ox >= dw || oy >= dh) return;
   src += (size_t)blockIdx.z * sb;
   dst += (size_t)blockIdx.z * db;
-  const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
-  for (int i = tid; i < PD_SH * PD_SW; i += 256) {
-    int r = i / PD_SW, c = i - r * PD_SW;
-    int y = reflect101(sy0 + r, h), x = reflect101(sx0 + c, w);
-    s_src[r][c] = src[(size_t)y * ss + x];
+  const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+  // Column borders without divergence: the leftmost lane (sx0 = -2) and the lane whose third dword crosses the right
+  // edge load from a clamped in-row address and rebuild their bytes with V_PERM (BORDER_REFLECT_101); rows are reflected
+  // per wave (uniform).  Only footprints whose first two dwords cross the right edge (widths not a multiple of 8) take
+  // the per-byte path.
+  const bool left = sx0 < 0, cross2 = sx0 + 12 > w;
+  const bool fast = w >= 16 && sx0 + 8 <= w;
+  uint32_t sel0 = 0x03020100u, sel2 = 0x03020100u;
+  int off2 = sx0 + 8;
+  if (left) sel0 = 0x01000102u;                                 // cols -2,-1,0,1 -> 2,1,0,1 of the dword loaded at col 0
+  if (cross2) {
+    off2 = w - 4;
+    sel2 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = sx0 + 8 + k, cr = c < w ? c : 2 * w - 2 - c;
+      sel2 |= (uint32_t)max(min(cr - (w - 4), 3), 0) << (8 * k);
+    }
   }
-  __syncthreads();
-  for (int i = tid; i < PD_SH * PD_TX; i += 256) {
-    int r = i / PD_TX, c = i - r * PD_TX;
-    const uint8_t *p = &s_src[r][2 * c];
-    s_h[r][c] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+  union Pk2 { uint32_t u; us2_t h; };
+  Pk2 hp[7][2];      // hsum[r][0..1], hsum[r][2..3] as packed u16 (max 16 * 255 = 4080)
+  const uint32_t W4 = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint8_t *p = src + (size_t)reflect101(sy0 + r, h) * ss;
+    uint32_t d0, d1, d2;
+    if (fast) {
+      d0 = __builtin_amdgcn_perm(0u, ld_u32u(p + (left ? 0 : sx0)), sel0);
+      d1 = ld_u32u(p + sx0 + 4);
+      d2 = __builtin_amdgcn_perm(0u, ld_u32u(p + off2), sel2);
+    } else {
+      uint32_t bt[12];
+#pragma unroll
+      for (int k = 0; k < 11; ++k) bt[k] = p[reflect101(sx0 + k, w)];
+      bt[11] = 0;
+      d0 = bt[0] | (bt[1] << 8) | (bt[2] << 16) | (bt[3] << 24);
+      d1 = bt[4] | (bt[5] << 8) | (bt[6] << 16) | (bt[7] << 24);
+      d2 = bt[8] | (bt[9] << 8) | (bt[10] << 16);
+    }
+    // horizontal pass: out_j = [1 4 6 4] . bytes[2j..2j+3] + bytes[2j+4]  -> V_DOT4_U32_U8 on byte-aligned dwords
+    const uint32_t d01 = __builtin_amdgcn_alignbyte(d1, d0, 2);      // bytes 2..5
+    const uint32_t d12 = __builtin_amdgcn_alignbyte(d2, d1, 2);      // bytes 6..9
+    const uint32_t h0 = __builtin_amdgcn_udot4(d0, W4, d1 & 0xffu, false);              // + byte 4
+    const uint32_t h1 = __builtin_amdgcn_udot4(d01, W4, d12 & 0xffu, false);            // + byte 6
+    const uint32_t h2 = __builtin_amdgcn_udot4(d1, W4, d2 & 0xffu, false);              // + byte 8
+    const uint32_t h3 = __builtin_amdgcn_udot4(d12, W4, (d2 >> 16) & 0xffu, false);     // + byte 10
+    hp[r][0].u = h0 | (h1 << 16);
+    hp[r][1].u = h2 | (h3 << 16);
   }
-  __syncthreads();
-  const int ox = ox0 + threadIdx.x, oy = oy0 + threadIdx.y;
-  if (ox < dw && oy < dh) {
-    int r = 2 * threadIdx.y, c = threadIdx.x;
-    int acc = s_h[r][c] + 4 * s_h[r + 1][c] + 6 * s_h[r + 2][c] + 4 * s_h[r + 3][c] + s_h[r + 4][c];
-    dst[(size_t)oy * ds + ox] = (uint8_t)((acc + 128) >> 8);
+  // vertical pass on packed pairs: (h0 + h4) + 4 (h1 + h3) + 6 h2 <= 16 * 4080 = 65280 fits u16; (s + 128) >> 8
+  const us2_t c4 = {4, 4}, c6 = {6, 6}, c128 = {128, 128};
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    if (oy + o >= dh) break;
+    uint32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const us2_t acc = (hp[2 * o][q].h + hp[2 * o + 4][q].h) + c4 * (hp[2 * o + 1][q].h + hp[2 * o + 3][q].h) + c6 * hp[2 * o + 2][q].h;
+      // the 17-bit sum of the last +128 cannot be formed in u16: (acc >> 8) + ((acc & 255) >= 128)
+      Pk2 t;
+      t.h = acc;
+      v[2 * q] = ((t.u & 0xffffu) + 128u) >> 8;
+      v[2 * q + 1] = ((t.u >> 16) + 128u) >> 8;
+    }
+    (void)c128;
+    const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    uint8_t *q = dst + (size_t)(oy + o) * ds + ox;
+    if (ox + 3 < dw && ((ds | (int)(db & 3)) & 3) == 0 && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t *>(q) = packed;
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (ox + j < dw) q[j] = (uint8_t)v[j];
+    }
   }
 }
 
@@ -105,7 +159,7 @@ extern "C" int svs_pyr_down_u8(svs_ctx *ctx, const uint8_t *d_src, int w, int h,
                                uint8_t *d_dst, int dstride, size_t d_bstride, int batch) {
   SVS_REQUIRE(ctx, ctx && d_src && d_dst && w >= 3 && h >= 3 && batch >= 1);
   int dw = (w + 1) / 2, dh = (h + 1) / 2;
-  dim3 grid(div_up(dw, PD_TX), div_up(dh, PD_TY), batch), block(PD_TX, PD_TY);
+  dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
   hipLaunchKernelGGL(pyr_down_u8_kernel, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw,
                      dh, dstride, d_bstride);
   SVS_LAUNCH_CHECK(ctx);
