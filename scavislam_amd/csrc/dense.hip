@@ -203,17 +203,44 @@ __global__ void dense_finalize_kernel(const double *__restrict__ partials, int n
 }
 
 // ---- device-resident LM (whole denseTrackingCpu) ---------------------------------------------
-__device__ void d_solve6(const double *A, const double *b, double *x) {   // Gaussian elimination, partial pivoting
+// 6x6 solve by Gaussian elimination with partial pivoting (stands in for Eigen's ldlt(), as in the oracle).  Fully unrolled
+// with compile-time indices: the row exchange is a chain of predicated swaps, so the augmented matrix lives in registers
+// (a dynamically indexed copy would sit in scratch memory, and this runs on one lane while the workgroup waits).
+__device__ void d_solve6(const double *A, const double *b, double *x) {
   double M[6][7];
-  for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) M[i][j] = A[i * 6 + j]; M[i][6] = b[i]; }
-  for (int k = 0; k < 6; ++k) {
-    int p = k; double best = fabs(M[k][k]);
-    for (int i = k + 1; i < 6; ++i) if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); p = i; }
-    if (p != k) for (int j = 0; j < 7; ++j) { double t = M[k][j]; M[k][j] = M[p][j]; M[p][j] = t; }
-    double piv = M[k][k];
-    for (int i = k + 1; i < 6; ++i) { double f = M[i][k] / piv; for (int j = k; j < 7; ++j) M[i][j] -= f * M[k][j]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) M[i][j] = A[i * 6 + j];
+    M[i][6] = b[i];
   }
-  for (int i = 5; i >= 0; --i) { double s = M[i][6]; for (int j = i + 1; j < 6; ++j) s -= M[i][j] * x[j]; x[i] = s / M[i][i]; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(M[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; p = i; } }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool sw = p == i;
+#pragma unroll
+      for (int j = k; j < 7; ++j) { const double a = M[k][j], c = M[i][j]; M[k][j] = sw ? c : a; M[i][j] = sw ? a : c; }
+    }
+    const double piv = M[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = M[i][k] / piv;
+#pragma unroll
+      for (int j = k; j < 7; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s_ = M[i][6];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s_ -= M[i][j] * x[j];
+    x[i] = s_ / M[i][i];
+  }
 }
 __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   // Tn = exp(x) * T
   const double *w = x + 3;
