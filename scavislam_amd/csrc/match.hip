@@ -259,13 +259,25 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
           ncand = 0;
           __builtin_amdgcn_wave_barrier();
         }
-        // lexicographic min across the wave
-        gkey = gbest != 0x7fffffff ? quad_key(gx_, gy_, cam.w, cam.h) : 0xffffffffu;
+        // lexicographic min of (z, quadrant key) across the wave: minimum z first (6 shuffle steps); only if several lanes
+        // tie on it -- rare -- are their keys computed and compared; the winner's corner is read with readlane
+        int zmin = gbest;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int oz = __shfl_xor(gbest, o, 64), ox = __shfl_xor(gx_, o, 64), oy = __shfl_xor(gy_, o, 64);
-          const unsigned ok = __shfl_xor(gkey, o, 64);
-          if (oz < gbest || (oz == gbest && ok < gkey)) { gbest = oz; gkey = ok; gx_ = ox; gy_ = oy; }
+        for (int o = 1; o < 64; o <<= 1) zmin = min(zmin, __shfl_xor(zmin, o, 64));
+        if (zmin != 0x7fffffff) {
+          unsigned long long tie = __ballot(gbest == zmin);
+          if (__popcll(tie) > 1) {
+            unsigned k = gbest == zmin ? quad_key(gx_, gy_, cam.w, cam.h) : 0xffffffffu;
+            unsigned kmin = k;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+            tie = __ballot(gbest == zmin && k == kmin);
+          }
+          const int win = __ffsll((long long)tie) - 1;
+          gbest = zmin;
+          gx_ = __builtin_amdgcn_readlane(gx_, win);
+          gy_ = __builtin_amdgcn_readlane(gy_, win);
+          gkey = 0;
         }
         unsigned bestkey = gkey;
         if (bestkey != 0xffffffffu) { best = gbest; bu = gx_; bv = gy_; }
