@@ -77,10 +77,19 @@ __device__ __forceinline__ unsigned quad_key(int px, int py, int W, int H) {
   return key;
 }
 
+// per-point result of computePrediction + the local affine of warpAffinve (everything that is one scalar evaluation per
+// point): produced one LANE per point by match_predict_kernel, consumed one WAVE per point by match_kernel
+struct PointPred {
+  int32_t status, ui, vi, lvl, kfi, pad_;
+  double inv[4];          // inverse of the local affine A (matcher.cpp:415-426)
+  double key_uv[2];       // anchor_obs_pyr
+  double xyz_actkey[3];
+};
 struct MatchParams {
   svs_match_args a;
   FastView fv;
   const double *kf_T;     // [n_batch][n_kf][24]: T_cur_from_anchor, T_actkey_from_anchor (match_pose_kernel)
+  PointPred *pred;        // [n_batch][n_pts]
 };
 
 // The two relative poses a candidate needs depend only on (camera stream, anchor keyframe), not on
@@ -101,6 +110,51 @@ __global__ void match_pose_kernel(svs_match_args A, double *__restrict__ out) {
   for (int i = 0; i < 12; ++i) o[12 + i] = t1[i];
 }
 
+// computePrediction (matcher.cpp:98-142) and the affine set-up of warpAffinve (:403-426), one lane per candidate point.
+// The same f64 expressions as before, evaluated once per point instead of redundantly by the 64 lanes of its wave.
+__global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
+  const svs_match_args &A = M.a;
+  const int ip = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
+  if (ip >= A.n_pts) return;
+  const svs_candidate_point ap = A.d_pts[(size_t)slot * A.n_pts + ip];
+  PointPred pr;
+  pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0;
+  pr.inv[0] = pr.inv[1] = pr.inv[2] = pr.inv[3] = 0; pr.key_uv[0] = ap.anchor_obs_pyr[0]; pr.key_uv[1] = ap.anchor_obs_pyr[1];
+  pr.xyz_actkey[0] = pr.xyz_actkey[1] = pr.xyz_actkey[2] = 0;
+  if (ap.kf_index < 0 || ap.kf_index >= A.n_kf) pr.status = SVS_MATCH_NO_ANCHOR;
+  else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) pr.status = SVS_MATCH_NONE;  // no feature_tree for that level
+  if (pr.status == SVS_MATCH_OK) {
+    const svs_cam cam = A.cam_vec[ap.anchor_level];
+    const double *kfT = M.kf_T + ((size_t)slot * A.n_kf + ap.kf_index) * 24;
+    double T_cur_from_anchor[12], xyz_cur[3];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T_cur_from_anchor[i] = kfT[i];
+    d_pose_act(T_cur_from_anchor, ap.xyz_anchor, xyz_cur);
+    const double uv0 = cam.f * (xyz_cur[0] / xyz_cur[2]) + cam.cx;
+    const double uv1 = cam.f * (xyz_cur[1] / xyz_cur[2]) + cam.cy;
+    const double depth_cur = 1. / xyz_cur[2], depth_anchor = 1. / ap.xyz_anchor[2];
+    if (!d_in_frame(cam, (int)ap.anchor_obs_pyr[0], (int)ap.anchor_obs_pyr[1], 4)) pr.status = SVS_MATCH_BORDER;
+    else if (depth_cur > depth_anchor * 3 || depth_anchor > depth_cur * 3) pr.status = SVS_MATCH_DEPTH;
+    else if (!(fabs(uv0) < 1e9) || !(fabs(uv1) < 1e9)) pr.status = SVS_MATCH_NONE;
+    if (pr.status == SVS_MATCH_OK) {
+      pr.ui = (int)uv0; pr.vi = (int)uv1;
+      // f(uv), f(uv + e_x), f(uv + e_y) (matcher.cpp:411-413); x + 0.0 is exact
+      double f0[2], fu[2], fv[2];
+      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + 0.0, ap.anchor_obs_pyr[1] + 0.0, f0);
+      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + 1.0, ap.anchor_obs_pyr[1] + 0.0, fu);
+      d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + 0.0, ap.anchor_obs_pyr[1] + 1.0, fv);
+      const double a00 = fu[0] - f0[0], a01 = fu[1] - f0[1], a10 = fv[0] - f0[0], a11 = fv[1] - f0[1];
+      const double invdet = 1.0 / (a00 * a11 - a01 * a10);
+      pr.inv[0] = a11 * invdet; pr.inv[1] = -a01 * invdet; pr.inv[2] = -a10 * invdet; pr.inv[3] = a00 * invdet;
+      double T_actkey_from_anchor[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T_actkey_from_anchor[i] = kfT[12 + i];
+      d_pose_act(T_actkey_from_anchor, ap.xyz_anchor, pr.xyz_actkey);
+    }
+  }
+  M.pred[(size_t)slot * A.n_pts + ip] = pr;
+}
+
 constexpr int WAVES_PER_BLOCK = 4;
 
 __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_result *__restrict__ out) {
@@ -111,58 +165,32 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
   const int ip = blockIdx.x * WAVES_PER_BLOCK + wave;
   const int slot = blockIdx.y;
   if (ip >= A.n_pts) return;                       // wave-uniform
-  const svs_candidate_point ap = A.d_pts[(size_t)slot * A.n_pts + ip];
+  const PointPred pp = M.pred[(size_t)slot * A.n_pts + __builtin_amdgcn_readfirstlane(ip)];      // wave-uniform record
   svs_match_result *o = &out[(size_t)slot * A.n_pts + ip];
   const int R = A.search_radius;
   const int init_dist = A.thr_mean * A.thr_mean * 64;
-  int status = SVS_MATCH_OK;
+  int status = pp.status;
   double xyz_actkey[3] = {0, 0, 0}, obs[3] = {0, 0, 0};
   int best = init_dist, bu = 0, bv = 0;
-
-  if (ap.kf_index < 0 || ap.kf_index >= A.n_kf) status = SVS_MATCH_NO_ANCHOR;
-  else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) status = SVS_MATCH_NONE;  // no feature_tree for that level
   if (status == SVS_MATCH_OK) {
-    // all 64 lanes work on the same point: make the indices wave-uniform (scalar) so the keyframe
-    // record and the per-level tables are read with scalar loads instead of a per-lane scratch copy
-    const int kfi = __builtin_amdgcn_readfirstlane(ap.kf_index);
-    const int lvl = __builtin_amdgcn_readfirstlane(ap.anchor_level);
-    const svs_keyframe *kfp = A.d_kfs + kfi;
-    const svs_cam cam = A.cam_vec[lvl];
-    double T_cur_from_anchor[12], xyz_cur[3];
-    const double *kfT = M.kf_T + ((size_t)slot * A.n_kf + kfi) * 24;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T_cur_from_anchor[i] = kfT[i];
-    d_pose_act(T_cur_from_anchor, ap.xyz_anchor, xyz_cur);
-    const double uv0 = cam.f * (xyz_cur[0] / xyz_cur[2]) + cam.cx;
-    const double uv1 = cam.f * (xyz_cur[1] / xyz_cur[2]) + cam.cy;
-    const double depth_cur = 1. / xyz_cur[2], depth_anchor = 1. / ap.xyz_anchor[2];
-    if (!d_in_frame(cam, (int)ap.anchor_obs_pyr[0], (int)ap.anchor_obs_pyr[1], 4)) status = SVS_MATCH_BORDER;
-    else if (depth_cur > depth_anchor * 3 || depth_anchor > depth_cur * 3) status = SVS_MATCH_DEPTH;
-    else if (!(fabs(uv0) < 1e9) || !(fabs(uv1) < 1e9)) status = SVS_MATCH_NONE;
-    if (status == SVS_MATCH_OK) {
-      const int ui = (int)uv0, vi = (int)uv1;
+    {
+      // all 64 lanes work on the same point: wave-uniform (scalar) indices, the keyframe record and the per-level tables
+      // are read with scalar loads
+      const int kfi = __builtin_amdgcn_readfirstlane(pp.kfi);
+      const int lvl = __builtin_amdgcn_readfirstlane(pp.lvl);
+      const svs_keyframe *kfp = A.d_kfs + kfi;
+      const svs_cam cam = A.cam_vec[lvl];
+      const int ui = pp.ui, vi = pp.vi;
       // ---- warpAffinve: 10x10 patch, lanes take pixels lane and lane+64 -------------------
-      // f(uv), f(uv + e_x), f(uv + e_y) (matcher.cpp:411-413) evaluated once, in lanes 0/1/2 side by
-      // side (x + 0.0 is exact, so lane 0 still computes f at uv itself), then broadcast
-      double f0[2], fu[2], fv[2];
-      {
-        double fl[2];
-        d_warp_f(T_cur_from_anchor, ap.xyz_anchor[2], cam, ap.anchor_obs_pyr[0] + (lane == 1 ? 1.0 : 0.0),
-                 ap.anchor_obs_pyr[1] + (lane == 2 ? 1.0 : 0.0), fl);
-        f0[0] = __shfl(fl[0], 0, 64); f0[1] = __shfl(fl[1], 0, 64);
-        fu[0] = __shfl(fl[0], 1, 64); fu[1] = __shfl(fl[1], 1, 64);
-        fv[0] = __shfl(fl[0], 2, 64); fv[1] = __shfl(fl[1], 2, 64);
-      }
-      const double a00 = fu[0] - f0[0], a01 = fu[1] - f0[1], a10 = fv[0] - f0[0], a11 = fv[1] - f0[1];
-      const double invdet = 1.0 / (a00 * a11 - a01 * a10);
-      const double i00 = a11 * invdet, i01 = -a01 * invdet, i10 = -a10 * invdet, i11 = a00 * invdet;
+      const double i00 = pp.inv[0], i01 = pp.inv[1], i10 = pp.inv[2], i11 = pp.inv[3];
+      const double key_u = pp.key_uv[0], key_v = pp.key_uv[1];
       const uint8_t *kimg = kfp->pyr[lvl];
       const int kstride = kfp->stride[lvl];
       for (int q = lane; q < 100; q += 64) {
         const int iy = q / 10, ix = q - iy * 10;
         const double dx = ix - 5, dy = iy - 5;
-        const double r0 = (i00 * dx + i01 * dy) + ap.anchor_obs_pyr[0];
-        const double r1 = (i10 * dx + i11 * dy) + ap.anchor_obs_pyr[1];
+        const double r0 = (i00 * dx + i01 * dy) + key_u;
+        const double r1 = (i10 * dx + i11 * dy) + key_v;
         const double x = floor(r0), y = floor(r1);
         uint8_t val;
         if (!(x >= 0) || !(y >= 0) || x + 1 >= cam.w || y + 1 >= cam.h) val = 0;
@@ -281,10 +309,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
         }
         unsigned bestkey = gkey;
         if (bestkey != 0xffffffffu) { best = gbest; bu = gx_; bv = gy_; }
-        double T_actkey_from_anchor[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T_actkey_from_anchor[i] = kfT[12 + i];
-        d_pose_act(T_actkey_from_anchor, ap.xyz_anchor, xyz_actkey);
+        xyz_actkey[0] = pp.xyz_actkey[0]; xyz_actkey[1] = pp.xyz_actkey[1]; xyz_actkey[2] = pp.xyz_actkey[2];      // point in the active keyframe (match_predict_kernel)
         if (bestkey == 0xffffffffu) { status = SVS_MATCH_NONE; best = init_dist; }
         else {
           const double inv_factor = 1.0 / (double)(1 << lvl);
@@ -330,7 +355,19 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
     kf_T_n = need; owner = ctx;
   }
   M.kf_T = kf_T;
+  static thread_local svs_ctx *owner_p = nullptr;
+  static thread_local PointPred *pred = nullptr;
+  static thread_local size_t pred_n = 0;
+  const size_t need_p = (size_t)a->n_batch * a->n_pts;
+  if (owner_p != ctx || pred_n < need_p) {
+    if (pred) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(pred); pred = nullptr; pred_n = 0; }
+    SVS_HIP(ctx, hipMalloc(&pred, need_p * sizeof(PointPred)));
+    pred_n = need_p; owner_p = ctx;
+  }
+  M.pred = pred;
   hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, *a, kf_T);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
   SVS_LAUNCH_CHECK(ctx);
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
   hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
