@@ -158,8 +158,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
 constexpr int WAVES_PER_BLOCK = 4;
 
 __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_result *__restrict__ out) {
-  __shared__ uint8_t s_patch[WAVES_PER_BLOCK][104];
-  __shared__ int s_cand[WAVES_PER_BLOCK][128];      // per-wave list of window hits waiting to be scored: packed (y << 16) | x
+  __shared__ int s_cand[WAVES_PER_BLOCK][320];      // per-wave list of window hits waiting to be scored ((y << 16) | x): < 64 carried + <= 256 per trip
   const svs_match_args &A = M.a;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ip = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -186,8 +185,12 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
       const double key_u = pp.key_uv[0], key_v = pp.key_uv[1];
       const uint8_t *kimg = kfp->pyr[lvl];
       const int kstride = kfp->stride[lvl];
-      for (int q = lane; q < 100; q += 64) {
-        const int iy = q / 10, ix = q - iy * 10;
+      // Only the centre 8x8 of the reference's 10x10 warp is ever read (KEY_PATCH, matcher.cpp:376-381) and every warped
+      // pixel depends on its own coordinates alone: lane = pixel (row lane>>3, column lane&7) of that centre, one pass,
+      // the value stays in a register.
+      int keyv;
+      {
+        const int iy = (lane >> 3) + 1, ix = (lane & 7) + 1;
         const double dx = ix - 5, dy = iy - 5;
         const double r0 = (i00 * dx + i01 * dy) + key_u;
         const double r1 = (i10 * dx + i11 * dy) + key_v;
@@ -203,12 +206,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
           const double s = (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
           val = (uint8_t)(s < 255. ? s : 255.);
         }
-        s_patch[wave][q] = val;
+        keyv = val;
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave landed
-      const int pr = lane >> 3, pc = lane & 7;
-      const int keyv = s_patch[wave][(pr + 1) * 10 + pc + 1];
       const int sumA = wave_sum_i32(keyv), sumAA = wave_sum_i32(keyv * keyv);
       if (sumA * sumA - sumAA < A.thr_std * A.thr_std * 64) status = SVS_MATCH_TEXTURE;
       else {
@@ -219,43 +218,64 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
         const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
         const uint8_t *cimg = A.d_cur_pyr[lvl] + (size_t)slot * A.cur_bstride[lvl];
         const int cstride = A.cur_stride[lvl];
-        const int side = 2 * R + 1, npos = side * side;
-        const float inv_side = 1.0f / (float)side;
-        // key patch as 16 packed dwords (8 rows x 2), wave-uniform: lane l < 16 packs dword l, broadcast with readlane
-        uint32_t kd = 0;
-        if (lane < 16) {
-          const uint8_t *kp = &s_patch[wave][((lane >> 1) + 1) * 10 + (lane & 1) * 4 + 1];
-          kd = (uint32_t)kp[0] | ((uint32_t)kp[1] << 8) | ((uint32_t)kp[2] << 16) | ((uint32_t)kp[3] << 24);
-        }
+        const int side = 2 * R + 1;
+        // key patch as 16 packed dwords (8 rows x 2), wave-uniform: the four bytes of a dword sit in four adjacent lanes
+        // (quad shuffles), lane 4i then holds dword i
+        const uint32_t kd = (uint32_t)keyv | ((uint32_t)__shfl_down(keyv, 1, 64) << 8) | ((uint32_t)__shfl_down(keyv, 2, 64) << 16) |
+                            ((uint32_t)__shfl_down(keyv, 3, 64) << 24);
         uint32_t key4[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) key4[i] = (uint32_t)__builtin_amdgcn_readlane((int)kd, i);
+        for (int i = 0; i < 16; ++i) key4[i] = (uint32_t)__builtin_amdgcn_readlane((int)kd, 4 * i);
         // window scan: hits are compacted into a per-wave LDS list; whenever it holds >= 64 corners (and at the end) they
         // are scored one lane per candidate: 8 rows x 2 unaligned dwords of the current image, sums with V_SAD_U8 /
         // V_DOT4_U32_U8 against the wave-uniform key dwords -- no cross-lane reduction per candidate
         int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-lane running best
         unsigned gkey = 0xffffffffu;
         int ncand = 0;                                 // wave-uniform fill of s_cand
-        for (int p0 = 0; p0 < npos; p0 += 64) {
-          const int pos = p0 + lane;
-          int cx = 0, cy = 0;
-          bool hit = false;
-          if (pos < npos) {
-            const int wy = (int)(((float)pos + 0.5f) * inv_side), wx = pos - wy * side;   // exact for pos < 2^12
-            cx = ui - R + wx; cy = vi - R + wy;
-            if (cx >= 0 && cy >= 0 && cx < gx * cw && cy < gy * chh && d_in_frame(cam, cx, cy, 6)) {
-              int cellx = 0, celly = 0;                   // grids are at most a few cells wide: compares beat divides
-              for (int q = 1; q < gx; ++q) cellx += cx >= q * cw;
-              for (int q = 1; q < gy; ++q) celly += cy >= q * chh;
-              const int cell = celly * gx + cellx;
-              const int thr1 = min(max(emit[cell], 0), 255) + 1;
-              hit = score[(size_t)cy * sstride + cx] >= thr1;
+        // a lane tests four horizontally adjacent window positions from one (unaligned) dword of the score map
+        const int ngrp = (side + 3) >> 2, ntask = side * ngrp;
+        const float inv_ngrp = 1.0f / (float)ngrp;
+        const int xlo = 6, xhi = min(gx * cw, cam.w - 6), ylo = 6, yhi = min(gy * chh, cam.h - 6);      // isInFrame(uv, 6) and inside the cell grid
+        for (int p0 = 0; p0 < ntask; p0 += 64) {
+          const int task = p0 + lane;
+          const bool valid = task < ntask;
+          const int wy = (int)(((float)task + 0.5f) * inv_ngrp), g4 = 4 * (task - wy * ngrp);      // exact for task < 2^12
+          const int cy = vi - R + wy, cx0 = ui - R + g4;
+          const bool row_ok = valid && cy >= ylo && cy < yhi;
+          uint32_t sc4 = 0;
+          int thrA = 256, thrB = 256, xb = 0x7fffffff;
+          if (row_ok) {
+            const uint8_t *srow = score + (size_t)cy * sstride;
+            if (cx0 >= 0 && cx0 + 3 < cam.w) __builtin_memcpy(&sc4, srow + cx0, 4);
+            else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) if (cx0 + k >= 0 && cx0 + k < cam.w) sc4 |= (uint32_t)srow[cx0 + k] << (8 * k);
             }
+            int cellx = 0, celly = 0;                   // grids are at most a few cells wide: compares beat divides
+            const int cxc = max(cx0, 0);
+            for (int q = 1; q < gx; ++q) cellx += cxc >= q * cw;
+            for (int q = 1; q < gy; ++q) celly += cy >= q * chh;
+            thrA = min(max(emit[celly * gx + cellx], 0), 255) + 1;
+            thrB = min(max(emit[celly * gx + min(cellx + 1, gx - 1)], 0), 255) + 1;
+            xb = (cellx + 1) * cw;                      // a 4-pixel group straddles at most one cell boundary (cells are >= 4 wide)
           }
-          const unsigned long long m = __ballot(hit);
-          if (hit) s_cand[wave][ncand + __popcll(m & ((1ull << lane) - 1ull))] = (cy << 16) | cx;
-          ncand += __popcll(m);
-          const bool last = p0 + 64 >= npos;
+          int nh = 0;
+          unsigned long long mk[4];
+          bool hk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int cx = cx0 + k, sc = (int)((sc4 >> (8 * k)) & 0xffu);
+            hk[k] = row_ok && g4 + k < side && cx >= xlo && cx < xhi && sc >= (cx >= xb ? thrB : thrA);
+            mk[k] = __ballot(hk[k]);
+          }
+          const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (hk[k]) s_cand[wave][ncand + nh + __popcll(mk[k] & lt)] = (cy << 16) | (cx0 + k);
+            nh += __popcll(mk[k]);
+          }
+          ncand += nh;
+          const bool last = p0 + 64 >= ntask;
           if (ncand < 64 && !last) continue;                           // wave-uniform
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_s_waitcnt(0xc07f);
