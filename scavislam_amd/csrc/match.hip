@@ -4,13 +4,18 @@
 // matchCandidates (:144-181), returnBestMatch (:183-214), createObervation
 // (matcher-impl.cpp:33-51).
 //
-// MI355X-first design: ONE WAVEFRONT PER CANDIDATE POINT, 64 lanes = the 64 pixels of the 8x8
-// patch.  The affine key-patch warp (100 f64 bilinear taps) is spread over the lanes, the three
-// ZNSSD sums are wave reductions, and the quadtree of the reference is replaced by a direct scan
-// of the (2R+1)^2 search window in the FAST score map produced by fast.hip: a pixel is a
-// candidate iff its score clears the emit threshold of its cell.  The reference's tie-break
-// (first hit in QuadTree::query DFS order wins, strict '<') is reproduced with a per-candidate
-// quadrant key, so results are bit-exact without building a tree.
+// MI355X-first design, three kernels:
+//   match_pose_kernel     relative poses per (stream, keyframe)
+//   match_predict_kernel  ONE LANE per candidate point: computePrediction and the local affine of warpAffinve -- the
+//                         scalar f64 part (10 exact divisions) is evaluated once per point, not by 64 lanes redundantly
+//   match_kernel          ONE WAVEFRONT per candidate point: lane = pixel of the 8x8 key patch (only the used centre of the
+//                         reference's 10x10 warp is formed; the patch never leaves registers), texture sums by wave
+//                         reduction; the quadtree of the reference is replaced by a scan of the (2R+1)^2 search window in
+//                         the FAST score map of fast.hip (four positions per lane from one dword; a pixel is a candidate iff
+//                         its score clears the emit threshold of its cell); hits are compacted in LDS and scored one lane
+//                         per candidate with V_SAD_U8 / V_DOT4_U32_U8; the winner is the minimum ZNSSD, and the reference's
+//                         tie-break (first hit in QuadTree::query DFS order, strict '<') is reproduced with a quadrant key
+//                         computed only on ties -- bit-exact without building a tree.
 // f64 geometry is compiled with -ffp-contract=off so it rounds like the host oracle.
 #include "common.h"
 
