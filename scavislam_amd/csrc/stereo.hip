@@ -277,32 +277,40 @@ __global__ __launch_bounds__(256) void stereo_validate_kernel(StereoDev S) {
 }
 
 // ---- speckle filter: connected components by union-find (labels = linear pixel index inside the frame) ----------
+// Labels: -1 = filtered pixel, CCL_BIG = member of a component already known to exceed the speckle window (any
+// component containing a horizontal run longer than the window), otherwise the index of a pixel of the same set
+// (roots point at themselves).  CCL_BIG is smaller than every index, so "hang the larger root under the smaller"
+// (atomicMin) makes it absorb whatever gets connected to it.
+constexpr int CCL_BIG = -2;
 __device__ __forceinline__ int ccl_find(const int32_t *label, int x) {
   int p = label[x];
-  while (p != x) { x = p; p = label[x]; }
-  return x;
+  while (p != x && p >= 0) { x = p; p = label[x]; }
+  return p < 0 ? CCL_BIG : x;
 }
-__device__ __forceinline__ void ccl_union(int32_t *label, int a, int b) {
+__device__ __forceinline__ void ccl_union(int32_t *label, int a, int b) {      // a, b: node indices or CCL_BIG
   while (true) {
-    a = ccl_find(label, a); b = ccl_find(label, b);
+    if (a >= 0) a = ccl_find(label, a);
+    if (b >= 0) b = ccl_find(label, b);
     if (a == b) return;
-    if (a < b) { const int t = a; a = b; b = t; }      // a > b: hang the larger root under the smaller
+    if (a < b) { const int t = a; a = b; b = t; }      // a > b >= CCL_BIG: hang the larger root under the smaller
     const int old = atomicMin(&label[a], b);
     if (old == a) return;
-    a = old;
+    a = old;                                            // a was no longer a root: continue from its new parent
   }
 }
 __device__ __forceinline__ bool ccl_linked(int a, int b, int range) { return a != FILTERED16 && b != FILTERED16 && abs(a - b) <= range; }
 
-// Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels (a prefix max
+// Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels (a prefix scan
 // over "run starts here" along the row), so the union-find only has to stitch rows together and its chains stay
-// short.  One workgroup per image row.  grid: (h, batch), block 256, dynamic LDS = 2 * w ints
+// short; runs longer than the speckle window are labelled CCL_BIG right away -- in a real disparity map that is most
+// valid pixels, and their vertical links cost nothing later.  One workgroup per image row.
+// grid: (h, batch), block 256, dynamic LDS = 3 * w ints
 __global__ __launch_bounds__(256) void stereo_ccl_runs_kernel(StereoDev S) {
   extern __shared__ int s_mem[];
   const int w = S.w, y = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.y * w * S.h;
   const int16_t *d = S.disp16 + base + (size_t)y * w;
-  int *s_a = s_mem, *s_b = s_mem + w;
+  int *s_a = s_mem, *s_b = s_mem + w, *s_len = s_mem + 2 * w;
   for (int x = tid; x < w; x += 256) {
     const int dv = d[x];
     const bool start = dv != FILTERED16 && !(x > 0 && ccl_linked(dv, d[x - 1], S.speckle_range));
@@ -315,7 +323,15 @@ __global__ __launch_bounds__(256) void stereo_ccl_runs_kernel(StereoDev S) {
     __syncthreads();
     int *t = s_a; s_a = s_b; s_b = t;
   }
-  for (int x = tid; x < w; x += 256) S.label[base + (size_t)y * w + x] = s_a[x] < 0 ? -1 : y * w + s_a[x];
+  for (int x = tid; x < w; x += 256) {      // the last pixel of a run publishes the run length at the run start
+    const int st = s_a[x];
+    if (st >= 0 && (x == w - 1 || s_a[x + 1] != st)) s_len[st] = x - st + 1;
+  }
+  __syncthreads();
+  for (int x = tid; x < w; x += 256) {
+    const int st = s_a[x];
+    S.label[base + (size_t)y * w + x] = st < 0 ? -1 : (s_len[st] > S.speckle_window ? CCL_BIG : y * w + st);
+  }
 }
 // stitch vertically linked pixels; one union per pair of overlapping runs (the leftmost linked column of the overlap).
 // grid: (ceil(w*h/256), batch)
@@ -325,19 +341,24 @@ __global__ __launch_bounds__(256) void stereo_ccl_merge_kernel(StereoDev S) {
   const size_t base = (size_t)blockIdx.y * n;
   const int16_t *d = S.disp16 + base;
   int32_t *label = S.label + base;
+  const int la = label[i], lb = label[i + w];
+  if (la == -1 || lb == -1 || (la == CCL_BIG && lb == CCL_BIG)) return;      // filtered, or both sides already known to be big
   if (!ccl_linked(d[i], d[i + w], S.speckle_range)) return;
-  if (i % w > 0 && label[i - 1] == label[i] && label[i + w - 1] == label[i + w] && ccl_linked(d[i - 1], d[i + w - 1], S.speckle_range)) return;
-  ccl_union(label, label[i], label[i + w]);      // run labels are only ever replaced by other members of the same set
+  if (i % w > 0 && label[i - 1] == la && label[i + w - 1] == lb && ccl_linked(d[i - 1], d[i + w - 1], S.speckle_range)) return;
+  ccl_union(label, la, lb);      // run labels are only ever replaced by other members of the same set (or CCL_BIG)
 }
 // component sizes, saturating: the test is "size <= speckle_window", so a root that is already beyond the window
-// is left alone, and the lanes of a wave that share a root (runs!) add once.
+// is left alone, and the lanes of a wave that share a root (runs!) add once.  Members of CCL_BIG need no count.
 __global__ __launch_bounds__(256) void stereo_ccl_count_kernel(StereoDev S) {
   const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h, lane = threadIdx.x & 63;
   const size_t base = (size_t)blockIdx.y * n;
   int root = -1;
-  if (i < n && S.label[base + i] >= 0) {
-    root = ccl_find(S.label + base, i);
-    S.label[base + i] = root;      // flatten (roots stay roots, so concurrent finds remain valid)
+  if (i < n) {
+    const int l = S.label[base + i];
+    if (l >= 0) {
+      root = ccl_find(S.label + base, i);
+      if (root != l) S.label[base + i] = root;      // flatten (roots stay roots, so concurrent finds remain valid)
+    }
   }
   const int prev = __shfl_up(root, 1, 64);
   const bool head = root >= 0 && (lane == 0 || prev != root);
@@ -354,7 +375,7 @@ __global__ __launch_bounds__(256) void stereo_finish_kernel(StereoDev S, int use
   if (i >= n) return;
   const size_t base = (size_t)blockIdx.y * n;
   int d = S.disp16[base + i];
-  if (use_ccl && d != FILTERED16 && S.count[base + S.label[base + i]] <= S.speckle_window) d = FILTERED16;
+  if (use_ccl && d != FILTERED16) { const int l = S.label[base + i]; if (l != CCL_BIG && S.count[base + l] <= S.speckle_window) d = FILTERED16; }
   out[(size_t)blockIdx.y * d_bstride + (size_t)(i / S.w) * dstride + (i % S.w)] = (float)d * (1.f / (1 << DISP_SHIFT));
 }
 
@@ -426,7 +447,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
   const dim3 gp(div_up(n, 256), n_batch);
   if (ccl) {
-    hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 2 * (size_t)w, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 3 * (size_t)w, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(stereo_ccl_merge_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(stereo_ccl_count_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
   }
