@@ -11,7 +11,7 @@
 //                            the last 7 rows in an LDS ring and slides the vertical sum with packed-u16 adds;
 //                            argmin / uniqueness / parabola per pixel
 //   stereo_bm_edge_kernel    the 3 leftmost output columns, whose right-image window clamps before the shift
-//   stereo_validate_kernel   validateDisparity, one workgroup per row
+//   stereo_validate_kernel   validateDisparity, one workgroup per row (one LDS atomicMin of (cost, x) per source pixel)
 //   stereo_ccl_*             speckle filter = connected components (horizontal runs, then union-find with atomicMin
 //                            across rows) + saturating size count; the size test is fused with the 1/16 float conversion
 #include "common.h"
@@ -243,35 +243,34 @@ __global__ __launch_bounds__(64) void stereo_bm_edge_kernel(StereoDev S) {
   S.disp16[o] = d16; S.cost[o] = c16;
 }
 
-// validateDisparity (with D2): one workgroup per image row.  grid: (h, batch), block 256
+// validateDisparity (with D2): one workgroup per image row.  The reference's sequential first pass ("a strictly smaller
+// cost wins", ascending x => first x on ties) is a minimum over (cost, x): every valid source pixel does one LDS atomicMin
+// of the packed key (cost << 16 | x) on its target column.  grid: (h, batch), block 256, dynamic LDS = 2 * w ints
 __global__ __launch_bounds__(256) void stereo_validate_kernel(StereoDev S) {
   extern __shared__ int s_mem[];
   const int w = S.w, y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  int *s_d = s_mem, *s_c = s_mem + w, *s_d2 = s_mem + 2 * w;
+  int *s_d = s_mem;
+  unsigned *s_key = reinterpret_cast<unsigned *>(s_mem + w);
   const int SCALE = 1 << DISP_SHIFT, INVALID = -SCALE, maxdiff = S.disp12 * SCALE;
   int16_t *dp = S.disp16 + ((size_t)b * S.h + y) * w;
   const uint16_t *cp = S.cost + ((size_t)b * S.h + y) * w;
-  for (int x = tid; x < w; x += 256) { s_d[x] = dp[x]; s_c[x] = cp[x]; }
+  for (int x = tid; x < w; x += 256) { s_d[x] = dp[x]; s_key[x] = 0xffffffffu; }
   __syncthreads();
   const int minX1 = NDISP;
-  for (int x2 = tid; x2 < w; x2 += 256) {
-    int bc = 0x7fffffff, bd = INVALID;
-    for (int k = 0; k <= NDISP; ++k) {      // sources x = x2 + round(d): ascending x, strictly smaller cost wins
-      const int x = x2 + k;
-      if (x < minX1 || x >= w) continue;
-      const int d = s_d[x];
-      if (d == INVALID || ((d + SCALE / 2) >> DISP_SHIFT) != k) continue;
-      if (s_c[x] < bc) { bc = s_c[x]; bd = d; }
-    }
-    s_d2[x2] = bd;
+  for (int x = minX1 + tid; x < w; x += 256) {
+    const int d = s_d[x];
+    if (d == INVALID) continue;
+    const int x2 = x - ((d + SCALE / 2) >> DISP_SHIFT);
+    if (x2 >= 0 && x2 < w) atomicMin(&s_key[x2], ((unsigned)cp[x] << 16) | (unsigned)x);
   }
   __syncthreads();
   for (int x = minX1 + tid; x < w; x += 256) {
     const int d = s_d[x];
     if (d == INVALID) continue;
     const int x0 = x - (d >> DISP_SHIFT), x1 = x - ((d + SCALE - 1) >> DISP_SHIFT);
-    const bool bad0 = x0 >= 0 && x0 < w && s_d2[x0] > INVALID && abs(s_d2[x0] - d) > maxdiff;
-    const bool bad1 = x1 >= 0 && x1 < w && s_d2[x1] > INVALID && abs(s_d2[x1] - d) > maxdiff;
+    bool bad0 = false, bad1 = false;
+    if (x0 >= 0 && x0 < w) { const unsigned k = s_key[x0]; bad0 = k != 0xffffffffu && abs(s_d[k & 0xffffu] - d) > maxdiff; }
+    if (x1 >= 0 && x1 < w) { const unsigned k = s_key[x1]; bad1 = k != 0xffffffffu && abs(s_d[k & 0xffffu] - d) > maxdiff; }
     if (bad0 && bad1) dp[x] = (int16_t)INVALID;
   }
 }
@@ -394,7 +393,7 @@ struct svs_stereo {
 extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out) {
   SVS_REQUIRE(ctx, ctx && prm && out && w > 0 && h > 0 && max_batch > 0);
   if (prm->sad_window != 7 || prm->min_disparity != 0 || prm->num_disparities != NDISP || prm->prefilter_cap < 1 || prm->prefilter_cap > 63 ||
-      w < NDISP + 2 * WSZ2 || h < 2) {
+      w < NDISP + 2 * WSZ2 || w > 65535 || h < 2) {
     ctx->err = "svs_stereo: only SADWindowSize 7, minDisparity 0, numberOfDisparities 32, preFilterCap 1..63, w >= 38 are supported";
     return SVS_ERR_UNSUPPORTED;
   }
@@ -441,7 +440,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
     SVS_LAUNCH_CHECK(ctx);
   }
   if (s->prm.disp12_max_diff >= 0) {
-    hipLaunchKernelGGL(stereo_validate_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 3 * (size_t)w, ctx->stream, S);
+    hipLaunchKernelGGL(stereo_validate_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 2 * (size_t)w, ctx->stream, S);
     SVS_LAUNCH_CHECK(ctx);
   }
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
