@@ -186,12 +186,14 @@ struct BaDev {
   double delta, lambda;
   int robust, self_mode;
   long long *dbg;                       // SVS_BA_DEBUG=2: per-wave phase stamps (100 MHz ticks), DBG_N per chunk
+  double *ctl;                          // device-side LM control (speculative trials): [0] lambda, [1] abort flag, [8 + 8 it ..] trial records
 };
 
 // MODE 0: accumulate reduced system + chi2 at the current state.
 // MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
@@ -574,6 +576,7 @@ __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_wave_barrier(
 
 template <int MODE>
 __global__ __launch_bounds__(64) void ba_constraint_kernel(BaDev B) {
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   __shared__ double s_m[8][36];      // 0 Adj(T21) 1 dl(e) 2 t1 3 J1 4 dl(-e) 5 J2 6 O*J1 7 O*J2
   const int c = blockIdx.x, lane = threadIdx.x;
   const svs_ba_constraint &cc = B.cons[c];
@@ -685,6 +688,7 @@ __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws,
                                                                  const int *__restrict__ rowmax, const int *__restrict__ colmin) {
   extern __shared__ double smem[];
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int P = B.P, n = 6 * P, tid = threadIdx.x;
   double *s_b = smem;                 // [n] rhs -> y -> x
   double *s_panel = smem + n;         // [P*36] current panel row U_kj, j>k
@@ -879,6 +883,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 __global__ __launch_bounds__(PIPE_THREADS) void ba_solve_lds_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
                                                                     const int *__restrict__ rowmax_g, int R) {
   extern __shared__ double smem[];
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int P = B.P, n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double *s_b = smem;                          // [n]
   double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
@@ -1146,6 +1151,7 @@ constexpr int FUSE_PRE = 8;
 __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
                                                                       const int *__restrict__ rowmax_g, int R) {
   extern __shared__ double smem[];
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int P = B.P, n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double *s_b = smem;                          // [n]
   double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
@@ -1462,6 +1468,32 @@ __global__ void ba_expand_kernel(BaDev B, double *__restrict__ Hfull, double *__
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bred[i] = B.bp[i] - B.bs[i];
 }
 
+// Accept / reject of one LM trial on the device (OptimizationAlgorithmLevenberg::solve), used by the
+// speculative enqueue of svs_ba_optimize: on acceptance the next trial's lambda is published in ctl[0]; anything else
+// (rejection, rho == 0, non-finite chi2) raises the abort flag, the already enqueued kernels of later trials return
+// immediately and the host takes over with its ordinary loop.  Record per iteration: chi2 at the current state, trial
+// chi2, scale, rho, accepted, lambda after the update, solver failure, done marker.
+__global__ void ba_lm_kernel(BaDev B, int it) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || B.ctl[1] != 0.0) return;
+  double *rec = B.ctl + 8 + 8 * it;
+  const double chi_cur = B.scal[4], fail = B.scal[3];
+  const double tempChi = fail != 0.0 ? 1.7976931348623157e308 : B.scal[0];
+  const double scale = B.scal[1] + B.scal[2] + 1e-3;
+  const double rho = (chi_cur - tempChi) / scale;
+  double lambda = B.ctl[0];
+  const bool accept = rho > 0 && isfinite(tempChi);
+  if (accept) {
+    const double q = 2 * rho - 1;
+    double alpha = 1. - q * q * q;
+    alpha = fmin(alpha, 2. / 3.);
+    lambda *= fmax(1. / 3., alpha);
+    B.ctl[0] = lambda;
+  } else {
+    B.ctl[1] = 1.0;
+  }
+  rec[0] = chi_cur; rec[1] = tempChi; rec[2] = scale; rec[3] = rho; rec[4] = accept ? 1.0 : 0.0; rec[5] = lambda; rec[6] = fail; rec[7] = 1.0;
+}
+
 }  // namespace
 
 struct svs_ba {
@@ -1481,6 +1513,9 @@ struct svs_ba {
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
+  double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
+  int ctl_iters = 0;
+  std::vector<hipEvent_t> spec_ev;      // 6 events per speculative trial
   double *h_scal = nullptr;             // pinned host mirror of d_scal (the per-trial read-back must not go through a pageable staging copy)
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
@@ -1508,11 +1543,13 @@ struct svs_ba {
   }
 };
 
-static BaDev make_dev(const svs_ba *ba, double lambda) {
+static BaDev make_dev(const svs_ba *ba, double lambda, int cur = -1, double *ctl = nullptr) {
   BaDev B{};
+  if (cur < 0) cur = ba->cur;
+  B.ctl = ctl;
   B.P = ba->P; B.L = ba->L; B.E = ba->E; B.C = ba->add_pose_terms ? ba->C : 0; B.n_chunks = ba->n_chunks;
-  B.poses = ba->d_poses[ba->cur]; B.psi = ba->d_psi[ba->cur];
-  B.poses_trial = ba->d_poses[1 - ba->cur]; B.psi_trial = ba->d_psi[1 - ba->cur];
+  B.poses = ba->d_poses[cur]; B.psi = ba->d_psi[cur];
+  B.poses_trial = ba->d_poses[1 - cur]; B.psi_trial = ba->d_psi[1 - cur];
   B.edges = ba->d_edges; B.chunk_start = ba->d_chunk_start; B.chunk_len = ba->d_chunk_len; B.cons = ba->d_cons;
   const size_t nblk = (size_t)ba->P * (ba->P + 1) / 2;
   B.H = ba->d_red; B.bp = ba->d_red + nblk * 36; B.bs = B.bp + 6 * (size_t)ba->P; B.chi2_cur = B.bs + 6 * (size_t)ba->P;
@@ -1533,6 +1570,10 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (!ba) return SVS_OK;
   (void)hipStreamSynchronize(ba->ctx->stream);
   if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
+  if (ba->h_ctl) { (void)hipHostFree(ba->h_ctl); ba->h_ctl = nullptr; }
+  if (ba->d_ctl) { (void)hipFree(ba->d_ctl); ba->d_ctl = nullptr; }
+  for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
+  ba->spec_ev.clear();
   ba->free_all();
   for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
   delete ba;
@@ -1742,17 +1783,18 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
 }
 
 // buildSystem + Schur reduction at the current state (MODE 0 kernels)
-static int launch_reduce(svs_ba *ba, double lambda) {
+static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = nullptr, hipEvent_t *ev = nullptr) {
   svs_ctx *ctx = ba->ctx;
-  BaDev B = make_dev(ba, lambda);
+  BaDev B = make_dev(ba, lambda, cur, ctl);
+  if (!ev) ev = ba->ev;
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
   if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ba->ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
+  SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
   const char *dbg_env = getenv("SVS_BA_DEBUG");
   const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
   if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
   if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ba->ev[1], ctx->stream));
+  SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
     std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
     SVS_HIP(ctx, hipMemcpyAsync(h.data(), B.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -1797,7 +1839,46 @@ extern "C" int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred, 
   return SVS_OK;
 }
 
-// OptimizationAlgorithmLevenberg::solve x num_iters, host control flow, device math.
+// enqueue one LM trial on the ctx stream: system at the current state, solve, trial state, trial chi2 + scale
+static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEvent_t *ev, size_t smem_fallback, svs_allreduce_fn allreduce, void *user) {
+  svs_ctx *ctx = ba->ctx;
+  // (re)build at the current state with this lambda; the state only changes on accept, so a
+  // rebuilt system equals g2o's "restore diagonal + add new lambda"
+  int rc = launch_reduce(ba, lambda, cur, ctl, ev);
+  if (rc) return rc;
+  if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
+  BaDev B = make_dev(ba, lambda, cur, ctl);
+  if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
+  SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  if (ba->use_fused_solve)
+    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+  else if (ba->use_lds_solve)
+    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+  else
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
+  SVS_LAUNCH_CHECK(ctx);
+  SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
+  if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
+  if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
+  return SVS_OK;
+}
+static int add_trial_times(svs_ba *ba, hipEvent_t *ev) {
+  svs_ctx *ctx = ba->ctx;
+  float ms;
+  SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1])); ba->t_reduce += ms; ba->n_reduce++;
+  SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[2], ev[3])); ba->t_solve += ms;
+  SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[5], ev[4])); ba->t_backsub += ms;
+  return SVS_OK;
+}
+
+// OptimizationAlgorithmLevenberg::solve x num_iters, device math.  Control flow: the common path -- the
+// first trial of every iteration is accepted -- is enqueued speculatively for all iterations at once with the
+// accept/reject decision and the lambda update on the device (ba_lm_kernel), one host synchronisation in total; the first
+// rejection (or terminate condition) turns the remaining enqueued kernels into no-ops and the host loop below resumes
+// from exactly that point.
 extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->d_red);
@@ -1809,40 +1890,71 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
   { int rc = ensure_profile(ba, allreduce, user); if (rc) return rc; }
   const size_t smem = sizeof(double) * ((size_t)6 * ba->P + (size_t)ba->P * 36 + 36);
   if (smem > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  for (int it = 0; it < prm.num_iters && ok; ++it) {
-    if (it == 0) { lambda = prm.lambda_init; ni = 2; }
+  int it = 0;
+  bool resume = false;                 // the first trial of iteration `it` was already run (and rejected) by the speculative phase
+  double r_rho = 0, r_chi = 0;
+  const bool speculate = prm.num_iters >= 1 && prm.max_trials > 1 && !getenv("SVS_BA_DEBUG") && !getenv("SVS_BA_NO_SPECULATION");
+  if (speculate) {
+    const int n_it = prm.num_iters;
+    const size_t n_ctl = 8 + 8 * (size_t)n_it;
+    if (ba->ctl_iters < n_it) {
+      if (ba->d_ctl) (void)hipFree(ba->d_ctl);
+      if (ba->h_ctl) (void)hipHostFree(ba->h_ctl);
+      ba->d_ctl = ba->h_ctl = nullptr;
+      SVS_HIP(ctx, hipMalloc(&ba->d_ctl, sizeof(double) * n_ctl));
+      SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_ctl, sizeof(double) * n_ctl, hipHostMallocDefault));
+      ba->ctl_iters = n_it;
+    }
+    while (ba->spec_ev.size() < 6 * (size_t)n_it) { hipEvent_t e; SVS_HIP(ctx, hipEventCreate(&e)); ba->spec_ev.push_back(e); }
+    for (size_t i = 0; i < n_ctl; ++i) ba->h_ctl[i] = 0.0;
+    ba->h_ctl[0] = lambda;
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_ctl, ba->h_ctl, sizeof(double) * n_ctl, hipMemcpyHostToDevice, ctx->stream));
+    int cur = ba->cur;
+    for (int j = 0; j < n_it; ++j) {
+      int rc = enqueue_trial(ba, lambda, cur, ba->d_ctl, &ba->spec_ev[6 * j], smem, allreduce, user);
+      if (rc) return rc;
+      BaDev B = make_dev(ba, lambda, cur, ba->d_ctl);
+      hipLaunchKernelGGL(ba_lm_kernel, dim3(1), dim3(64), 0, ctx->stream, B, j);
+      SVS_LAUNCH_CHECK(ctx);
+      cur = 1 - cur;                   // as if accepted
+    }
+    SVS_HIP(ctx, hipMemcpyAsync(ba->h_ctl, ba->d_ctl, sizeof(double) * n_ctl, hipMemcpyDeviceToHost, ctx->stream));
+    SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n_it; ++j) {
+      const double *rec = ba->h_ctl + 8 + 8 * j;
+      if (rec[7] == 0.0) break;        // not executed: an earlier trial raised the abort flag
+      { int rc = add_trial_times(ba, &ba->spec_ev[6 * j]); if (rc) return rc; }
+      ++st.trials;
+      if (j == 0) st.chi2_init = rec[0];
+      if (rec[4] != 0.0) {             // accepted on the device: this iteration is complete
+        lambda = rec[5]; ni = 2; ++st.accepted;
+        ba->cur = 1 - ba->cur;
+        ++st.iterations;
+        st.chi2_final = rec[1];
+        it = j + 1;
+      } else {                         // rejected (or rho == 0 / not finite): same bookkeeping as the host path, then resume there
+        lambda *= ni; ni *= 2;
+        resume = true; r_rho = rec[3]; r_chi = rec[0];
+        it = j;
+        break;
+      }
+    }
+  }
+  for (; it < prm.num_iters && ok; ++it) {
+    if (it == 0 && !resume) { lambda = prm.lambda_init; ni = 2; }
     double rho = 0, currentChi = 0;
     int qmax = 0;
+    bool skip = resume;
+    if (resume) { rho = r_rho; currentChi = r_chi; qmax = 1; resume = false; }
     do {
-      // (re)build at the current state with this lambda; the state only changes on accept, so a
-      // rebuilt system equals g2o's "restore diagonal + add new lambda"
-      int rc = launch_reduce(ba, lambda);
+      if (skip) { skip = false; continue; }      // `continue` in a do-while jumps to the condition: the speculative phase ran this trial
+      int rc = enqueue_trial(ba, lambda, -1, nullptr, ba->ev, smem, allreduce, user);
       if (rc) return rc;
-      if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
-      BaDev B = make_dev(ba, lambda);
-      if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
-      SVS_HIP(ctx, hipEventRecord(ba->ev[2], ctx->stream));
-      if (ba->use_fused_solve)
-        hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
-      else if (ba->use_lds_solve)
-        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
-      else
-        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
-      SVS_LAUNCH_CHECK(ctx);
-      SVS_HIP(ctx, hipEventRecord(ba->ev[3], ctx->stream));
-      if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-      SVS_HIP(ctx, hipEventRecord(ba->ev[5], ctx->stream));
-      if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-      SVS_HIP(ctx, hipEventRecord(ba->ev[4], ctx->stream));
-      if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
       if (!ba->h_scal) SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_scal, sizeof(double) * 16, hipHostMallocDefault));
       double *h = ba->h_scal;
       SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      float ms;
-      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[0], ba->ev[1])); ba->t_reduce += ms; ba->n_reduce++;
-      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[2], ba->ev[3])); ba->t_solve += ms;
-      SVS_HIP(ctx, hipEventElapsedTime(&ms, ba->ev[5], ba->ev[4])); ba->t_backsub += ms;
+      { int rc2 = add_trial_times(ba, ba->ev); if (rc2) return rc2; }
       if (getenv("SVS_BA_DEBUG"))
         fprintf(stderr, "[svs_ba] solve phases: init %.1f us, forward %.1f us (pivot wave: load+row update %.1f, eliminate+emit %.1f, - %.1f, barrier wait %.1f), backward %.1f us\n",
                 h[5], h[6], h[8], h[9], h[10], h[11], h[7]);
@@ -1854,7 +1966,8 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       rho /= scale;
       ++st.trials;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        const double q = 2 * rho - 1;
+        double alpha = 1. - q * q * q;                // same expression as ba_lm_kernel (g2o: pow(2 rho - 1, 3), <= 1 ulp apart)
         alpha = std::min(alpha, 2. / 3.);
         lambda *= std::max(1. / 3., alpha);
         ni = 2; currentChi = tempChi; ++st.accepted;

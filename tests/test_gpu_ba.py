@@ -211,3 +211,38 @@ def test_sharded_optimize_single_process(gpu_ctx):
         assert _rel_update_err(psi[mine], psi0[mine], prob["psi"][mine]) < 1e-6
     for c, _ in ctxs:
         c.close()
+
+
+def test_speculative_lm_equals_host_driven_lm(gpu_ctx, monkeypatch):
+    """The device-side accept/reject path (all iterations enqueued at once, ba_lm_kernel decides) and the
+    host-driven loop (SVS_BA_NO_SPECULATION=1: one synchronisation per trial) are the same arithmetic in
+    the same order up to the order of the f64 atomics (not reproducible run to run either): identical LM
+    trajectory, states and statistics equal to ~1e-8, also when trials are rejected mid-way."""
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prob = synth.ba_window(8, 300, seed=77, n_outer=0, pose_sigma_t=0.4, pose_sigma_r_deg=8.0, outlier_frac=0.2)
+    cam = _cam(prob["cam"])
+    for lam0, iters in ((1e-9, 3), (1e-3, 6), (50.0, 4)):
+        out = []
+        for no_spec in (False, True):
+            if no_spec:
+                monkeypatch.setenv("SVS_BA_NO_SPECULATION", "1")
+            else:
+                monkeypatch.delenv("SVS_BA_NO_SPECULATION", raising=False)
+            prm = BaParams.reference_defaults()
+            prm.lambda_init, prm.num_iters = lam0, iters
+            opt = SlamGraphOptimizer(ctx, stream)
+            opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+            st = opt.optimize()
+            out.append((st, *opt.restoreDataFromG2o()))
+            opt.close()
+        (a, pa, sa), (b, pb, sb) = out
+        assert (a.iterations, a.trials, a.accepted, a.terminated) == (b.iterations, b.trials, b.accepted, b.terminated)
+        for x, y in ((a.chi2_init, b.chi2_init), (a.chi2_final, b.chi2_final), (a.lambda_final, b.lambda_final)):
+            assert abs(x - y) <= 1e-7 * abs(y)
+        if a.accepted:
+            assert _rel_update_err(pa, pb, prob["poses"]) < 1e-7 and _rel_update_err(sa, sb, prob["psi"]) < 1e-7
+        else:
+            assert np.array_equal(pa, pb) and np.array_equal(sa, sb)
