@@ -234,15 +234,32 @@ typedef struct {
      taps are formed on the fly from it (bit-identical values, ~1/8 of the HBM traffic) and
      d_cur/d_dx/d_dy are ignored, i.e. the convertTo/Sobel part of preprocessing can be skipped. */
   const uint8_t *d_cur_u8[3]; int32_t c8stride[3]; size_t c8_bstride[3];
+  /* optional output [batch][3][12]: the pose the LAST H,b pass of each level ran at, i.e. the pose
+     DenseTracker::residual_img[level] shows (dense_tracking.cpp:279-329); feed it to
+     svs_dense_residual_image_cpu_sem.  NULL = not wanted. */
+  double *d_T_jac_out;
 } svs_dense_track_args;
 int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io,
                             int32_t *d_passes_out, int batch);
+/* DenseTracker::residual_img[level] (dense_tracking.cpp:52-54,279-329): float4 per quarter-grid sample as left by an
+   H,b pass at pose d_T[b * T_bstride .. +12): (0,1,0,1) no depth, (1,0,0,1) out of frame, else grey 1 - 50 res^2.
+   Either d_cur (f32 level image) or d_cur_u8 (fused source, as in svs_dense_track_args) must be given. */
+int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t cloud_bstride,
+                                     const uint8_t *d_prev_u8, int pstride, size_t p_bstride,
+                                     const float *d_cur, int fstride, size_t f_bstride,
+                                     const uint8_t *d_cur_u8, int c8stride, size_t c8_bstride,
+                                     const svs_cam *cam, const double *d_T, size_t T_bstride,
+                                     float *d_res_img4, size_t res_bstride, int batch);
 /* GpuTracker::jacobianReduction / chi2 (gpu/dense_tracking.cuh:291-342, .cu:172-263,376-453):
    full resolution, f32, no clamp; T is GpuMatrix34 (12 floats column-major) by value */
 int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4,
                         const float *d_prev, const float *d_cur, const float *d_dx,
                         const float *d_dy, int stride_f, float f, float cx, float cy,
                         const float *h_T34_colmajor, int do_jac, svs_dense_sums *d_out);
+/* GpuTracker::residualImage (gpu/dense_tracking.cuh:329-337, .cu:495-569); d_res_img4 has the cloud's stride */
+int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4,
+                                  const float *d_prev, const float *d_cur, int stride_f, float f,
+                                  float cx, float cy, const float *h_T34_colmajor, float *d_res_img4);
 /* computePointCloud (gpu/dense_tracking.cu:82-148) */
 int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ_colmajor, const float *d_disp, int w, int h,
                         int stride_in, int stride_out, int factor, float *d_cloud4);

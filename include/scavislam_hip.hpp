@@ -288,9 +288,17 @@ class StereoBM {
 // DenseTracker, CPU-path semantics (dense_tracking.h:53-97, dense_tracking.cpp:222-423).
 class DenseTracker {
  public:
-  DenseTracker(const Context &c, const svs_cam cam_vec[SVS_NUM_PYR_LEVELS]) : ctx_(c), d_T_(c, 12), d_passes_(c, 1) {
-    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) { cam_[l] = cam_vec[l]; cloud_[l] = DeviceBuffer<float>(c, (size_t)(cam_vec[l].w / 4) * (cam_vec[l].h / 4) * 4); }
+  DenseTracker(const Context &c, const svs_cam cam_vec[SVS_NUM_PYR_LEVELS]) : ctx_(c), d_T_(c, 12), d_T_jac_(c, 36), d_passes_(c, 1) {
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {
+      cam_[l] = cam_vec[l];
+      const size_t n4 = (size_t)(cam_vec[l].w / 4) * (cam_vec[l].h / 4) * 4;
+      cloud_[l] = DeviceBuffer<float>(c, n4);
+      d_rimg_[l] = DeviceBuffer<float>(c, n4);
+      residual_img[l].assign(n4, 0.f);                                   // setTo(cv::Scalar(0,0,0,1)), dense_tracking.cpp:54
+      for (size_t i = 3; i < n4; i += 4) residual_img[l][i] = 1.f;
+    }
   }
+  std::vector<float> residual_img[SVS_NUM_PYR_LEVELS];                   // public member of the reference (dense_tracking.h:66), float4 per sample
   // void computeDensePointCloudCpu(const SE3& T_cur_from_actkey): ref_dense_points_ from the frame's disparity
   bool computeDensePointCloudCpu(const FrameDev &fr, const double T_cur_from_actkey[12]) {
     if (!d_T_.upload(T_cur_from_actkey, 12)) return false;
@@ -306,16 +314,25 @@ class DenseTracker {
       a.d_cloud[l] = cloud_[l].get(); a.d_prev_u8[l] = prev.pyr(l); a.pstride[l] = prev.stride(l);
       a.d_cur[l] = cur.f32(l); a.d_dx[l] = cur.dx(l); a.d_dy[l] = cur.dy(l); a.fstride[l] = cur.stride(l); a.cam_vec[l] = cam_[l];
     }
+    a.d_T_jac_out = d_T_jac_.get();
     if (!d_T_.upload(T_cur_from_actkey, 12)) return false;
     if (!ctx_.check(svs_dense_track_cpu_sem(ctx_.get(), &a, d_T_.get(), d_passes_.get(), 1))) return false;
+    if (want_residual_img) {                                             // the reference always writes it; here it is opt-in (GUI only)
+      for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {
+        if (!ctx_.check(svs_dense_residual_image_cpu_sem(ctx_.get(), cloud_[l].get(), 0, prev.pyr(l), prev.stride(l), 0, cur.f32(l), cur.stride(l), 0,
+                                                         nullptr, 0, 0, &cam_[l], d_T_jac_.get() + 12 * l, 36, d_rimg_[l].get(), 0, 1))) return false;
+        if (!d_rimg_[l].download(residual_img[l].data(), residual_img[l].size())) return false;
+      }
+    }
     return d_T_.download(T_cur_from_actkey, 12);
   }
+  bool want_residual_img = false;
 
  private:
   const Context &ctx_;
   svs_cam cam_[SVS_NUM_PYR_LEVELS];
-  DeviceBuffer<float> cloud_[SVS_NUM_PYR_LEVELS];
-  DeviceBuffer<double> d_T_;
+  DeviceBuffer<float> cloud_[SVS_NUM_PYR_LEVELS], d_rimg_[SVS_NUM_PYR_LEVELS];
+  DeviceBuffer<double> d_T_, d_T_jac_;
   DeviceBuffer<int32_t> d_passes_;
 };
 

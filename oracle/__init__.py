@@ -217,7 +217,7 @@ def dense_pass_cpu(cloud, prev_u8, cur, dx, dy, cam, T, do_jac, want_rimg=False)
     return (out[0], rimg) if want_rimg else out[0]
 
 
-def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T):
+def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T, want_rimg=False):
     clouds = [np.ascontiguousarray(a, np.float32) for a in clouds]
     prev = [np.ascontiguousarray(a) for a in prev_pyr]
     cur = [np.ascontiguousarray(a, np.float32) for a in cur_f]
@@ -226,14 +226,19 @@ def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T):
     P3 = C.c_void_p * 3
     I3 = C.c_int * 3
     T = np.array(T, np.float64).reshape(12).copy()
+    # DenseTracker's constructor fills residual_img with (0,0,0,1) (dense_tracking.cpp:54)
+    rimg = [np.tile(np.array([0, 0, 0, 1], np.float32), (*c.shape[:2], 1)) for c in clouds]
     L = lib()
-    L.svs_ref_dense_tracking_cpu.argtypes = [C.c_void_p] * 2 + [C.c_void_p] + [C.c_void_p] * 3 + \
-        [C.c_void_p, C.c_void_p, C.c_void_p]
-    passes = L.svs_ref_dense_tracking_cpu(
+    L.svs_ref_dense_tracking_cpu_rimg.argtypes = [C.c_void_p] * 2 + [C.c_void_p] + [C.c_void_p] * 3 + \
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    passes = L.svs_ref_dense_tracking_cpu_rimg(
         P3(*[a.ctypes.data for a in clouds]), P3(*[a.ctypes.data for a in prev]),
         I3(*[a.strides[0] for a in prev]), P3(*[a.ctypes.data for a in cur]),
         P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]),
-        I3(*[a.strides[0] // 4 for a in cur]), cams, _p(T))
+        I3(*[a.strides[0] // 4 for a in cur]), cams, _p(T),
+        P3(*[a.ctypes.data for a in rimg]) if want_rimg else None)
+    if want_rimg:
+        return T.reshape(3, 4), passes, rimg
     return T.reshape(3, 4), passes
 
 
@@ -259,6 +264,19 @@ def dense_pass_full(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor, do_jac):
     L.svs_ref_dense_pass_full(_p(cloud), w, h, w, _p(prev), _p(cur), _p(dx), _p(dy), w, f, cx, cy,
                               _p(T), int(do_jac), _p(out))
     return out[0]
+
+
+def residual_image_full(cloud, prev, cur, f, cx, cy, T34_colmajor):
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    h, w = cloud.shape[:2]
+    prev, cur = [np.ascontiguousarray(a, np.float32) for a in (prev, cur)]
+    T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+    out = np.zeros((h, w, 4), np.float32)
+    L = lib()
+    L.svs_ref_residual_image_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.svs_ref_residual_image_full(_p(cloud), w, h, w, _p(prev), _p(cur), w, f, cx, cy, _p(T), _p(out))
+    return out
 
 
 def pointcloud_full(TQ_colmajor, disp, w, h, factor):

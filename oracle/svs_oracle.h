@@ -195,6 +195,16 @@ int svs_ref_dense_tracking_cpu(const float *const cloud[3],
                                const float *const cur[3], const float *const dx[3],
                                const float *const dy[3], const int fstride[3],
                                const svs_cam cam_vec[3], double T[12]);
+/* same + residual_img[level] (cw*ch*4 floats each) as left behind by the last H,b pass of every level */
+int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *const prev_u8[3],
+                                    const int pstride[3], const float *const cur[3],
+                                    const float *const dx[3], const float *const dy[3],
+                                    const int fstride[3], const svs_cam cam_vec[3], double *T,
+                                    float *const rimg[3]);
+/* gpu/dense_tracking.cu:495-541 residualImage_kernel; rimg has the cloud's stride */
+void svs_ref_residual_image_full(const float *cloud, int w, int h, int stride4, const float *prev,
+                                 const float *cur, int stride_f, float f, float cx, float cy,
+                                 const float T34_colmajor[12], float *rimg);
 /* dense_tracking.cpp:393-423 computeDensePointCloudCpu for one level */
 void svs_ref_pointcloud_cpu(const float *disp, int disp_stride, const svs_cam *cam, int level,
                             const double T_cur_from_actkey[12], float *cloud /* (w/4)*(h/4)*4 */);

@@ -470,6 +470,15 @@ int svs_ref_dense_tracking_cpu(const float *const cloud[3], const uint8_t *const
                                const int pstride[3], const float *const cur[3],
                                const float *const dx[3], const float *const dy[3],
                                const int fstride[3], const svs_cam cam_vec[3], double *T) {
+  return svs_ref_dense_tracking_cpu_rimg(cloud, prev_u8, pstride, cur, dx, dy, fstride, cam_vec, T, 0);
+}
+/* same, also leaving DenseTracker::residual_img[level] as the reference does: every H,b pass rewrites it
+   (dense_tracking.cpp:319-329), so it ends as the image of the LAST H,b pass of each level */
+int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *const prev_u8[3],
+                                    const int pstride[3], const float *const cur[3],
+                                    const float *const dx[3], const float *const dy[3],
+                                    const int fstride[3], const svs_cam cam_vec[3], double *T,
+                                    float *const rimg[3]) {
   int passes = 0;
   for (int level = 2; level >= 0; --level) {
     const svs_cam *cam = &cam_vec[level];
@@ -483,7 +492,7 @@ int svs_ref_dense_tracking_cpu(const float *const cloud[3], const uint8_t *const
     for (int i = 0; i < 15; ++i) {
       double rho = 0;
       do {
-        svs_ref_dense_pass_cpu(cloud[level], cw, ch, prev_u8[level], pstride[level], cur[level], dx[level], dy[level], fstride[level], cam, T, 1, &s, 0);
+        svs_ref_dense_pass_cpu(cloud[level], cw, ch, prev_u8[level], pstride[level], cur[level], dx[level], dy[level], fstride[level], cam, T, 1, &s, rimg ? rimg[level] : 0);
         ++passes;
         double Hf[36], nb[6], x[6], E[12], Tn[12];
         int k = 0;
@@ -582,6 +591,26 @@ void svs_ref_dense_pass_full(const float *cloud, int w, int h, int s4, const flo
       }
     }
   memcpy(out->H, H, sizeof H); memcpy(out->b, b, sizeof b); out->chi2 = chi2; out->n_valid = nv;
+}
+/* gpu/dense_tracking.cu:495-541 residualImage_kernel (manual bilinear in place of the texture unit, as in
+   svs_ref_dense_pass_full) */
+void svs_ref_residual_image_full(const float *cloud, int w, int h, int s4, const float *prev,
+                                 const float *cur, int fs, float f, float cx, float cy, const float *T,
+                                 float *rimg) {
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      const float *p = cloud + 4 * ((size_t)v * s4 + u);
+      float *o = rimg + 4 * ((size_t)v * s4 + u);
+      if (!(p[3] > 0)) { o[0] = 0.f; o[1] = 1.f; o[2] = 0.f; o[3] = 1.f; continue; }
+      float x = p[0] * T[0] + p[1] * T[3] + p[2] * T[6] + p[3] * T[9];
+      float y = p[0] * T[1] + p[1] * T[4] + p[2] * T[7] + p[3] * T[10];
+      float z = p[0] * T[2] + p[1] * T[5] + p[2] * T[8] + p[3] * T[11];
+      float uu = f * x / z + cx, vv = f * y / z + cy;
+      if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; o[3] = 1.f; continue; }
+      float res = prev[(size_t)v * fs + u] - interp32f(cur, fs, uu, vv);
+      float g = 1 - 50.f * res * res; if (g < 0.f) g = 0.f;
+      o[0] = o[1] = o[2] = g; o[3] = 1.f;
+    }
 }
 void svs_ref_pointcloud_full(const float *TQ, const float *disp, int w, int h, int si, int so,
                              int factor, float *cloud) {

@@ -26,7 +26,8 @@ class DenseTrackArgs(C.Structure):
                 ("d_prev_u8", C.c_void_p * 3), ("pstride", C.c_int32 * 3), ("p_bstride", C.c_size_t * 3),
                 ("d_cur", C.c_void_p * 3), ("d_dx", C.c_void_p * 3), ("d_dy", C.c_void_p * 3),
                 ("fstride", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3), ("cam_vec", Cam * 3),
-                ("d_cur_u8", C.c_void_p * 3), ("c8stride", C.c_int32 * 3), ("c8_bstride", C.c_size_t * 3)]
+                ("d_cur_u8", C.c_void_p * 3), ("c8stride", C.c_int32 * 3), ("c8_bstride", C.c_size_t * 3),
+                ("d_T_jac_out", C.c_void_p)]
 
 
 class MatchArgs(C.Structure):
@@ -71,6 +72,11 @@ _SIGS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam),
                                C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "svs_dense_track_cpu_sem": [C.c_void_p, C.POINTER(DenseTrackArgs), C.c_void_p, C.c_void_p, C.c_int],
+    "svs_dense_residual_image_cpu_sem": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
+                                         C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
+                                         C.POINTER(Cam), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int],
+    "svs_dense_residual_image_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "svs_dense_pass_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                             C.c_int, C.c_void_p],

@@ -268,6 +268,7 @@ __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   
 struct TrackArgs {
   LevelArgs lv[3];
   size_t cloud_b[3], prev_b[3], f_b[3], c8_b[3];
+  double *T_jac;     // optional [batch][3][12]: pose of the last H,b pass of each level (what residual_img[level] shows)
 };
 
 #ifndef SVS_TRK_THREADS
@@ -311,7 +312,7 @@ template <bool U8SRC>
 __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
-  __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27];
+  __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
   const int slot = blockIdx.x;
   if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
   __syncthreads();
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
     __syncthreads();
     bool stop = false;
     for (int it = 0; it < 15 && !stop; ++it) {
+      if (threadIdx.x >= 64 && threadIdx.x < 76) s_Tj[level][threadIdx.x - 64] = s_T[threadIdx.x - 64];   // the reference's H,b pass of this iteration ran at s_T
       if (threadIdx.x == 0) {
         double H[36], nb[6], x[6];
         int k = 0;
@@ -370,6 +372,53 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
   }
   if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];
   if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
+  __syncthreads();
+  if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
+}
+
+// DenseTracker::residual_img[level] (dense_tracking.cpp:279-329): the GUI image an H,b pass at pose T leaves behind.
+// Green = no depth, red = projects out of frame, grey = 1 - 50 res^2 of the clamped residual.
+template <bool U8SRC>
+__global__ __launch_bounds__(256) void residual_image_cpu_sem_kernel(LevelArgs L, size_t cloud_b, size_t prev_b, size_t f_b, size_t c8_b,
+                                                                     const double *__restrict__ Tarr, size_t T_b,
+                                                                     float *__restrict__ rimg, size_t rimg_b) {
+  const int slot = blockIdx.y;
+  const int cw = L.cam.w / 4, ch = L.cam.h / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cw * ch) return;
+  L.cloud += slot * cloud_b; L.prev += slot * prev_b;
+  if (U8SRC) L.cur8 += slot * c8_b; else L.cur += slot * f_b;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * T_b + k];
+  const int u = i % cw, v = i / cw;
+  const float4 c4 = reinterpret_cast<const float4 *>(L.cloud)[i];
+  float4 o = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (c4.w > 0) {
+    const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
+    const double x = T[0] * xp0 + T[1] * xp1 + T[2] * xp2 + T[3];
+    const double y = T[4] * xp0 + T[5] * xp1 + T[6] * xp2 + T[7];
+    const double z = T[8] * xp0 + T[9] * xp1 + T[10] * xp2 + T[11];
+    const float uvx = (float)(L.cam.f * (x / z) + L.cam.cx);
+    const float uvy = (float)(L.cam.f * (y / z) + L.cam.cy);
+    bool ok = fabsf(uvx) < 1e9f && fabsf(uvy) < 1e9f;
+    const int ui = ok ? (int)uvx : 0, vi = ok ? (int)uvy : 0;
+    ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
+    o = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (ok) {
+      const float ip = (float)((1. / 255.) * L.prev[(size_t)(v * 4) * L.pstride + u * 4]);
+      float ic, gx, gy;
+      if (U8SRC) taps_u8(L.cur8, L.c8stride, uvx, uvy, ic, gx, gy);
+      else ic = interp32f(L.cur, L.fstride, uvx, uvy);
+      float res = ip - ic;
+      if (res > 0.1) res = 0.1;
+      if (res < -0.1) res = -0.1;
+      float g = 1 - 50.f * res * res;
+      if (g < 0.f) g = 0.f;
+      o = make_float4(g, g, g, 1.f);
+    }
+  }
+  reinterpret_cast<float4 *>(rimg + slot * rimg_b)[i] = o;
 }
 
 // computeDensePointCloudCpu (dense_tracking.cpp:393-423)
@@ -482,6 +531,30 @@ __global__ void dense_finalize_full_kernel(const double *__restrict__ partials, 
   else out->n_valid = (long long)s;
 }
 
+// residualImage_kernel (gpu/dense_tracking.cu:495-541)
+__global__ __launch_bounds__(256) void residual_image_full_kernel(const float *__restrict__ cloud, int w, int h, int s4,
+                                                                  const float *__restrict__ prev, const float *__restrict__ cur, int fs,
+                                                                  float f, float cx, float cy, T34 T, float *__restrict__ rimg) {
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= w || v >= h) return;
+  const float4 p = reinterpret_cast<const float4 *>(cloud)[(size_t)v * s4 + u];
+  float4 o = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (p.w > 0) {
+    const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];
+    const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
+    const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
+    const float uu = f * x / z + cx, vv = f * y / z + cy;
+    o = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2)) {
+      const float res = prev[(size_t)v * fs + u] - interp32f(cur, fs, uu, vv);
+      float g = 1 - 50.f * res * res;
+      if (g < 0.f) g = 0.f;
+      o = make_float4(g, g, g, 1.f);
+    }
+  }
+  reinterpret_cast<float4 *>(rimg)[(size_t)v * s4 + u] = o;
+}
+
 __global__ __launch_bounds__(256) void pointcloud_full_kernel(T44 TQ, const float *__restrict__ disp, int w, int h, int si, int so,
                                                               int factor, float *__restrict__ cloud) {
   const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -566,8 +639,39 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
                         a->d_cur_u8[l], a->c8stride[l]};
     A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l]; A.c8_b[l] = a->c8_bstride[l];
   }
+  A.T_jac = a->d_T_jac_out;
   if (u8src) hipLaunchKernelGGL(dense_track_cpu_sem_kernel<true>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
   else hipLaunchKernelGGL(dense_track_cpu_sem_kernel<false>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t cloud_bstride, const uint8_t *d_prev_u8,
+                                                int pstride, size_t p_bstride, const float *d_cur, int fstride, size_t f_bstride,
+                                                const uint8_t *d_cur_u8, int c8stride, size_t c8_bstride, const svs_cam *cam,
+                                                const double *d_T, size_t T_bstride, float *d_res_img4, size_t res_bstride, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_cloud && d_prev_u8 && (d_cur || d_cur_u8) && cam && d_T && d_res_img4 && batch >= 1);
+  SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);
+  LevelArgs L{d_cloud, d_prev_u8, d_cur, nullptr, nullptr, pstride, fstride, *cam, d_cur_u8, c8stride};
+  const int n = (cam->w / 4) * (cam->h / 4);
+  if (d_cur_u8)
+    hipLaunchKernelGGL(residual_image_cpu_sem_kernel<true>, dim3(div_up(n, 256), batch), dim3(256), 0, ctx->stream, L, cloud_bstride, p_bstride,
+                       f_bstride, c8_bstride, d_T, T_bstride, d_res_img4, res_bstride);
+  else
+    hipLaunchKernelGGL(residual_image_cpu_sem_kernel<false>, dim3(div_up(n, 256), batch), dim3(256), 0, ctx->stream, L, cloud_bstride, p_bstride,
+                       f_bstride, c8_bstride, d_T, T_bstride, d_res_img4, res_bstride);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                                             const float *d_cur, int stride_f, float f, float cx, float cy, const float *h_T,
+                                             float *d_res_img4) {
+  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_res_img4 && w > 0 && h > 0);
+  T34 T;
+  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
+  hipLaunchKernelGGL(residual_image_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4,
+                     d_prev, d_cur, stride_f, f, cx, cy, T, d_res_img4);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -276,6 +276,11 @@ class DenseTracker:
             self.d_T = torch.zeros((frame.batch, 12), dtype=torch.float64, device=dev)
             self.d_passes = torch.zeros(frame.batch, dtype=torch.int32, device=dev)
             self.d_sums = torch.zeros(frame.batch * DENSE_SUMS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.d_T_jac = torch.zeros((frame.batch, NUM_PYR_LEVELS, 12), dtype=torch.float64, device=dev)
+            # DenseTracker's constructor: residual_img[level].setTo((0,0,0,1)) (dense_tracking.cpp:52-54)
+            self.residual_img = [torch.zeros_like(c) for c in self.ref_dense_points]
+            for r in self.residual_img:
+                r[..., 3] = 1.0
 
     def _set_T(self, T):
         T = np.broadcast_to(np.asarray(T, np.float64).reshape(-1, 12), (self.frame.batch, 12))
@@ -316,7 +321,23 @@ class DenseTracker:
                 a.d_cur[l], a.d_dx[l], a.d_dy[l] = fr.f32[l].data_ptr(), fr.dx[l].data_ptr(), fr.dy[l].data_ptr()
             a.fstride[l], a.f_bstride[l] = fr.stride[l], fr.bstride(l)
             a.cam_vec[l] = fr.cams[l]
+        a.d_T_jac_out = self.d_T_jac.data_ptr()
         return a
+
+    def computeResidualImages(self, prev_pyr, from_u8=False):
+        """Fill the public residual_img[level] member as denseTrackingCpu leaves it (dense_tracking.cpp:279-329):
+        the image of the last H,b pass of each level, whose pose the tracker recorded in d_T_jac."""
+        fr = self.frame
+        for l in range(NUM_PYR_LEVELS):
+            cb = (fr.h[l] // 4) * (fr.w[l] // 4) * 4
+            self.ctx.call("svs_dense_residual_image_cpu_sem", self.ref_dense_points[l].data_ptr(), cb,
+                          prev_pyr[l].data_ptr(), fr.stride[l], fr.bstride(l),
+                          None if from_u8 else fr.f32[l].data_ptr(), fr.stride[l], fr.bstride(l),
+                          fr.pyr[l].data_ptr() if from_u8 else None, fr.stride[l], fr.bstride(l),
+                          C.byref(fr.cams[l]), self.d_T_jac.data_ptr() + 96 * l, 36,
+                          self.residual_img[l].data_ptr(), cb, fr.batch)
+        self.ctx.sync()
+        return [r.cpu().numpy() for r in self.residual_img]
 
     def denseTrackingCpu(self, prev_pyr, T_cur_from_actkey, args=None, download=True, from_u8=False):
         """DenseTracker::denseTrackingCpu(SE3*): in/out pose; whole LM loop in one launch."""
@@ -357,6 +378,13 @@ class GpuTracker:
 
     def chi2(self, I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4):
         return float(self._pass(I_prev, cloud, T, f, cx, cy, w, h, stride_f, stride_f4, False)["chi2"])
+
+    def residualImage(self, I_prev, cloud, T34_colmajor, f, cx, cy, w, h, stride_f, stride_f4, res_img):
+        I_cur = self._tex[0]
+        T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+        self.ctx.call("svs_dense_residual_image_full", cloud.data_ptr(), w, h, stride_f4, I_prev.data_ptr(), I_cur.data_ptr(),
+                      stride_f, float(f), float(cx), float(cy), T.ctypes.data, res_img.data_ptr())
+        self.ctx.sync()
 
     def computePointCloud(self, TQ_colmajor, disp, w, h, stride_in, stride_out, factor, cloud):
         TQ = np.ascontiguousarray(TQ_colmajor, np.float32).reshape(16)
