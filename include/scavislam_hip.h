@@ -210,6 +210,33 @@ typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
 int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
                     const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch);
 
+/* ---- gating of the matched points: the data-parallel part of StereoFrontend::processMatchedPoints
+   (stereo_frontend.cpp:834-974), which runs right behind calcFastMotionOnly on the same TrackData ----------*/
+typedef struct {           /* per matcher record; only meaningful where status == SVS_MATCH_OK */
+  int32_t accepted;        /* |uvu - map_uvu(T xyz)| < max_reproj_error * 2^level (u, v), < 3 max_reproj_error (u_right): :869-871 */
+  int32_t is_new;          /* id_obs.point_id < num_new_feat_matched (:920): goes to new_point_list, else track_point_list */
+  double uv_pyr[2];        /* pyrFromZero_2d(uvu.head(2), anchor_level): point_tree insert position (:918), draw line start */
+  double curkey_uv_pyr[2]; /* pyrFromZero_2d(se3xyz.map(SE3(), point), anchor_level) (:896-898) */
+} svs_gated_point;
+typedef struct {           /* PointStatistics (stereo_frontend.h) + the track-length accumulators (:857-858,925-926,966) */
+  int32_t num_points_grid2x2[4];   /* [i * 2 + j], i from u, j from v (:875-880) */
+  int32_t num_points_grid3x3[9];   /* [i * 3 + j] (:882-892) */
+  int32_t num_matched_points[3];   /* per anchor level (:895) */
+  int32_t num_track_points;
+  int32_t num_obs;                 /* obs_list.size() */
+  int32_t pad_[2];
+  double sum_track_length;         /* av_track_length_ = sum_track_length / num_track_points (:966) */
+} svs_point_stats;
+/* d_results [batch][n] (res_bstride records apart) and d_pts [batch][n] (pts_bstride apart) are the arrays svs_match was
+   called with / produced (concatenated calls allowed, as in matchAndTrack); records with index < n_new_records stem from
+   the "new feature" match calls (stereo_frontend.cpp:989-1030), so an OK record is "new" iff its index is below that --
+   the same split as point_id < num_new_feat_matched.  d_T [batch][12] = T_cur_from_actkey after calcFastMotionOnly.
+   cam = level-0 stereo camera.  max_reproj_error: ui.max_reproj_error, default 2 (:845-846). */
+int svs_process_matched_points(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n,
+                               size_t res_bstride, size_t pts_bstride, int n_new_records, const svs_cam *cam,
+                               const double *d_T, float max_reproj_error, svs_gated_point *d_gated, size_t gated_bstride,
+                               svs_point_stats *d_stats, int batch);
+
 /* ---- dense tracker: replaces DenseTracker / GpuTracker ---------------------------------------*/
 /* computeDensePointCloudCpu (dense_tracking.cpp:393-423): quarter-grid cloud of one level */
 int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride,

@@ -252,6 +252,28 @@ class BA_SE3_XYZ_STEREO {
     if (stats) *stats = st;
     return st.status == 0;      // 1: empty list (assert in the reference), 2: NaN residual (throw in the reference)
   }
+  // StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974), numeric part: reprojection gate at
+  // T_cur_from_actkey, PointStatistics counters, level positions.  `points[i]` is the candidate point record i of
+  // `track` was matched from; records below n_new_records stem from the new-feature match calls (:989-1030).
+  // The caller then walks `gated` to fill new_point_list / track_point_list / point_tree (host containers).
+  bool processMatchedPoints(const std::vector<svs_match_result> &track, const std::vector<svs_candidate_point> &points, int n_new_records,
+                            const svs_cam &cam, const double T_cur_from_actkey[12], float max_reproj_error,
+                            std::vector<svs_gated_point> *gated, svs_point_stats *stats) {
+    if (track.size() != points.size() || !gated || !stats) return false;
+    const size_t n = track.size();
+    DeviceBuffer<svs_match_result> d_res(ctx_, n ? n : 1);
+    DeviceBuffer<svs_candidate_point> d_pts(ctx_, n ? n : 1);
+    DeviceBuffer<svs_gated_point> d_g(ctx_, n ? n : 1);
+    DeviceBuffer<double> d_T(ctx_, 12);
+    DeviceBuffer<svs_point_stats> d_st(ctx_, 1);
+    if (n && (!d_res.upload(track.data(), n) || !d_pts.upload(points.data(), n))) return false;
+    if (!d_T.upload(T_cur_from_actkey, 12)) return false;
+    if (!ctx_.check(svs_process_matched_points(ctx_.get(), d_res.get(), d_pts.get(), (int)n, n, n, n_new_records, &cam, d_T.get(), max_reproj_error,
+                                               d_g.get(), n, d_st.get(), 1))) return false;
+    gated->resize(n);
+    if (n && !d_g.download(gated->data(), n)) return false;
+    return d_st.download(stats, 1);
+  }
 
  private:
   const Context &ctx_;

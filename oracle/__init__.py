@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 from scavislam_amd.ctypes_types import (BA_CONSTRAINT_DTYPE, BA_EDGE_DTYPE, CANDIDATE_DTYPE,
-                                        DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
+                                        DENSE_SUMS_DTYPE, GATED_POINT_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
+                                        POINT_STATS_DTYPE,
                                         BaParams, BaStats, Cam, FastGrid, PoseOptParams, PoseOptStats, StereoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -431,3 +432,21 @@ def motion_only(results, cam, T, prm=None):
     st = PoseOptStats()
     lib().svs_ref_motion_only(_p(res), len(res), C.byref(cam), C.byref(prm), _p(Tio), C.byref(st))
     return Tio.reshape(3, 4), st
+
+
+def process_matched_points(results, pts, n_new_records, cam, T, max_reproj_error=2.0):
+    """StereoFrontend::processMatchedPoints over a MATCH_RESULT_DTYPE array and its CANDIDATE_DTYPE points;
+    returns (GATED_POINT_DTYPE[n], POINT_STATS_DTYPE scalar)."""
+    res = np.ascontiguousarray(results, MATCH_RESULT_DTYPE)
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    assert len(res) == len(pts)
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    gated = np.zeros(len(res), GATED_POINT_DTYPE)
+    stats = np.zeros(1, POINT_STATS_DTYPE)
+    L = lib()
+    L.svs_ref_process_matched_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                                 C.c_void_p, C.c_void_p]
+    L.svs_ref_process_matched_points.restype = None
+    L.svs_ref_process_matched_points(_p(res), _p(pts), len(res), int(n_new_records), C.byref(cam), _p(T),
+                                     C.c_float(max_reproj_error), _p(gated), _p(stats))
+    return gated, stats[0]

@@ -263,6 +263,26 @@ typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
 int svs_ref_motion_only(const svs_match_result *res, int n, const svs_cam *cam, const svs_pose_opt_params *prm, double *T_io,
                         svs_pose_opt_stats *st);
 
+/* ---- StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974): reprojection gate at the refined pose,
+   PointStatistics counters, pyramid-level positions, track-length sum; serial, in obs_list order ---------------- */
+typedef struct {
+  int32_t accepted, is_new;
+  double uv_pyr[2];
+  double curkey_uv_pyr[2];
+} svs_gated_point;
+typedef struct {
+  int32_t num_points_grid2x2[4];
+  int32_t num_points_grid3x3[9];
+  int32_t num_matched_points[3];
+  int32_t num_track_points;
+  int32_t num_obs;
+  int32_t pad_[2];
+  double sum_track_length;
+} svs_point_stats;
+void svs_ref_process_matched_points(const svs_match_result *res, const svs_candidate_point *pts, int n, int n_new_records,
+                                    const svs_cam *cam, const double *T, float max_reproj_error, svs_gated_point *gated,
+                                    svs_point_stats *stats);
+
 /* ---- stereo block matching: cv::StereoBM as configured at stereo_frontend.cpp:620-653 (oracle/stereo.c) ---- */
 typedef struct {
   int32_t prefilter_cap;      /* 31 */

@@ -737,3 +737,51 @@ int svs_ref_motion_only(const svs_match_result *res, int n, const svs_cam *cam, 
   st->chi2 = chi2; st->max_err = max_err;
   return 0;
 }
+
+/* StereoFrontend::processMatchedPoints, stereo_frontend.cpp:834-974.  The list/hash-map/draw bookkeeping of the original
+   is replaced by one flag record per matcher result; everything numeric follows the source line by line. */
+void svs_ref_process_matched_points(const svs_match_result *res, const svs_candidate_point *pts, int n, int n_new_records,
+                                    const svs_cam *cam, const double *T, float max_reproj_error, svs_gated_point *gated,
+                                    svs_point_stats *stats) {
+  memset(stats, 0, sizeof *stats);
+  int half_width = (int)(cam->w * 0.5);                       /* :848-854 */
+  int half_height = (int)(cam->h * 0.5);
+  float third = 1. / 3.;
+  int third_width = (int)(cam->w * third);
+  int third_height = (int)(cam->h * third);
+  int twothird_width = (int)(cam->w * 2 * third);
+  int twothird_height = (int)(cam->h * 2 * third);
+  double sum_track_length = 0.f;
+  for (int k = 0; k < n; ++k) {
+    memset(&gated[k], 0, sizeof gated[k]);
+    if (res[k].status != 0) continue;                         /* not in obs_list */
+    ++stats->num_obs;
+    double diff[3];
+    mo_residual(T, res[k].xyz_actkey, res[k].obs, cam, diff, 0);       /* uvu - se3xyz_stereo_.map(T, point), :863-866 */
+    const double *uvu = res[k].obs;
+    int level = pts[k].anchor_level;
+    int factor = 1 << level;                                  /* zeroFromPyr_i(1, anchor_level) */
+    if (fabs(diff[0]) < max_reproj_error * factor && fabs(diff[1]) < max_reproj_error * factor
+        && fabs(diff[2]) < 3. * max_reproj_error) {           /* :869-871 */
+      int i = 1, j = 1;
+      if (uvu[0] < half_width) i = 0;
+      if (uvu[1] < half_height) j = 0;
+      ++stats->num_points_grid2x2[i * 2 + j];
+      i = 2; j = 2;
+      if (uvu[0] < third_width) i = 0; else if (uvu[0] < twothird_width) i = 1;
+      if (uvu[1] < third_height) j = 0; else if (uvu[1] < twothird_height) j = 1;
+      ++stats->num_points_grid3x3[i * 3 + j];
+      ++stats->num_matched_points[level];
+      const double *q = res[k].xyz_actkey;                    /* se3xyz.map(SE3(), point) = cam.map(project2d(point)) */
+      double cu = q[0] / q[2] * cam->f + cam->cx, cv = q[1] / q[2] * cam->f + cam->cy;
+      gated[k].accepted = 1;
+      gated[k].is_new = k < n_new_records;                    /* id_obs.point_id < num_new_feat_matched, :920 */
+      gated[k].curkey_uv_pyr[0] = cu / factor; gated[k].curkey_uv_pyr[1] = cv / factor;    /* pyrFromZero_2d */
+      gated[k].uv_pyr[0] = uvu[0] / factor; gated[k].uv_pyr[1] = uvu[1] / factor;
+      double dx = gated[k].uv_pyr[0] - gated[k].curkey_uv_pyr[0], dy = gated[k].uv_pyr[1] - gated[k].curkey_uv_pyr[1];
+      sum_track_length += sqrt(dx * dx + dy * dy);            /* :925 / :955 */
+      ++stats->num_track_points;
+    }
+  }
+  stats->sum_track_length = sum_track_length;
+}

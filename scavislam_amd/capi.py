@@ -84,6 +84,8 @@ _SIGS = {
                             C.c_void_p],
     "svs_motion_only": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam), C.POINTER(PoseOptParams), C.c_void_p, C.c_void_p,
                         C.c_int],
+    "svs_process_matched_points": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(Cam),
+                                   C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int],
     "svs_stereo_create": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StereoParams), C.POINTER(C.c_void_p)],
     "svs_stereo_destroy": [C.c_void_p],
     "svs_stereo_compute": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int,

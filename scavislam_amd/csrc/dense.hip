@@ -873,6 +873,81 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
 
 }  // namespace
 
+// ---- StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974), data-parallel part ---------------------------
+// One workgroup per stream sweeps the matcher records: reprojection gate at the refined pose, the 2x2 / 3x3 / per-level
+// counters (LDS atomics), the pyramid-level positions the host needs for point_tree and the draw lists, and the
+// track-length sum.  The host-side remainder (building new_point_list / track_point_list) walks the flags.
+namespace {
+__global__ __launch_bounds__(256) void gate_matched_kernel(const svs_match_result *__restrict__ res, const svs_candidate_point *__restrict__ pts, int n,
+                                                           size_t res_b, size_t pts_b, int n_new, svs_cam cam, const double *__restrict__ Tarr,
+                                                           float mre, svs_gated_point *__restrict__ out, size_t out_b, svs_point_stats *__restrict__ stats) {
+  __shared__ int s_cnt[18];          // 4 + 9 + 3 + num_track + num_obs
+  __shared__ double s_sum[4];
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  res += slot * res_b; pts += slot * pts_b; out += slot * out_b;
+  if (tid < 18) s_cnt[tid] = 0;
+  __syncthreads();
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[12 * slot + k];
+  const int half_w = (int)(cam.w * 0.5), half_h = (int)(cam.h * 0.5);
+  const float third = (float)(1. / 3.);
+  const int third_w = (int)(cam.w * third), third_h = (int)(cam.h * third);
+  const int tt_w = (int)(cam.w * 2 * third), tt_h = (int)(cam.h * 2 * third);
+  double len = 0;
+  for (int i = tid; i < n; i += 256) {
+    svs_gated_point g{};
+    if (res[i].status == 0) {
+      atomicAdd(&s_cnt[17], 1);
+      double d[3];
+      mo_residual<false>(T, res[i], cam, d, nullptr);          // uvu - se3xyz_stereo_.map(T_cur_from_actkey_, point)
+      const int level = pts[i].anchor_level;
+      const int factor = 1 << level;                             // zeroFromPyr_i(1, anchor_level)
+      if (fabs(d[0]) < mre * factor && fabs(d[1]) < mre * factor && fabs(d[2]) < 3. * mre) {
+        const double *uvu = res[i].obs, *q = res[i].xyz_actkey;
+        const int i2 = uvu[0] < half_w ? 0 : 1, j2 = uvu[1] < half_h ? 0 : 1;
+        const int i3 = uvu[0] < third_w ? 0 : (uvu[0] < tt_w ? 1 : 2), j3 = uvu[1] < third_h ? 0 : (uvu[1] < tt_h ? 1 : 2);
+        atomicAdd(&s_cnt[i2 * 2 + j2], 1);
+        atomicAdd(&s_cnt[4 + i3 * 3 + j3], 1);
+        atomicAdd(&s_cnt[13 + level], 1);
+        atomicAdd(&s_cnt[16], 1);
+        const double inv = 1.0 / (double)factor;                 // exact power of two: x * inv == x / factor
+        g.accepted = 1;
+        g.is_new = i < n_new ? 1 : 0;
+        g.uv_pyr[0] = uvu[0] * inv; g.uv_pyr[1] = uvu[1] * inv;
+        g.curkey_uv_pyr[0] = (q[0] / q[2] * cam.f + cam.cx) * inv;
+        g.curkey_uv_pyr[1] = (q[1] / q[2] * cam.f + cam.cy) * inv;
+        const double dx = g.uv_pyr[0] - g.curkey_uv_pyr[0], dy = g.uv_pyr[1] - g.curkey_uv_pyr[1];
+        len += sqrt(dx * dx + dy * dy);
+      }
+    }
+    out[i] = g;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = len;
+  __syncthreads();
+  svs_point_stats *st = stats + slot;
+  if (tid < 4) st->num_points_grid2x2[tid] = s_cnt[tid];
+  else if (tid < 13) st->num_points_grid3x3[tid - 4] = s_cnt[tid];
+  else if (tid < 16) st->num_matched_points[tid - 13] = s_cnt[tid];
+  else if (tid == 16) st->num_track_points = s_cnt[16];
+  else if (tid == 17) st->num_obs = s_cnt[17];
+  else if (tid == 18) { st->pad_[0] = st->pad_[1] = 0; st->sum_track_length = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]); }
+}
+}  // namespace
+
+extern "C" int svs_process_matched_points(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n,
+                                          size_t res_bstride, size_t pts_bstride, int n_new_records, const svs_cam *cam, const double *d_T,
+                                          float max_reproj_error, svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats,
+                                          int batch) {
+  SVS_REQUIRE(ctx, ctx && cam && d_T && d_stats && batch >= 1 && n >= 0 && (n == 0 || (d_results && d_pts && d_gated)));
+  hipLaunchKernelGGL(gate_matched_kernel, dim3(batch), dim3(256), 0, ctx->stream, d_results, d_pts, n, res_bstride, pts_bstride, n_new_records,
+                     *cam, d_T, max_reproj_error, d_gated, gated_bstride, d_stats);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
 extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
                                const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch) {
   SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && batch >= 1 && n >= 0 && (n == 0 || d_results));

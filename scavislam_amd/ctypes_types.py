@@ -108,3 +108,11 @@ class PoseOptParams(C.Structure):
 class PoseOptStats(C.Structure):
     _fields_ = [("initial_chi2", C.c_double), ("chi2", C.c_double), ("max_err", C.c_double),
                 ("num_obs", C.c_int32), ("status", C.c_int32)]
+
+
+# svs_gated_point / svs_point_stats: StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974)
+GATED_POINT_DTYPE = np.dtype([("accepted", "<i4"), ("is_new", "<i4"), ("uv_pyr", "<f8", 2), ("curkey_uv_pyr", "<f8", 2)])
+assert GATED_POINT_DTYPE.itemsize == 40
+POINT_STATS_DTYPE = np.dtype([("num_points_grid2x2", "<i4", 4), ("num_points_grid3x3", "<i4", 9), ("num_matched_points", "<i4", 3),
+                              ("num_track_points", "<i4"), ("num_obs", "<i4"), ("pad_", "<i4", 2), ("sum_track_length", "<f8")])
+assert POINT_STATS_DTYPE.itemsize == 88

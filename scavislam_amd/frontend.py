@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from . import capi
-from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, Cam,
+from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, GATED_POINT_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
+                           POINT_STATS_DTYPE, Cam,
                            FastGrid as FastGridPOD, PoseOptParams, PoseOptStats, StereoParams, level_cams)
 
 NUM_PYR_LEVELS = 3  # global.h:107
@@ -262,6 +263,25 @@ class PoseOptimizer:
         stats = [PoseOptStats.from_buffer_copy(raw[i * C.sizeof(PoseOptStats):(i + 1) * C.sizeof(PoseOptStats)].tobytes())
                  for i in range(self.frame.batch)]
         return T, stats
+
+    def processMatchedPoints(self, matcher, n_new_records, max_reproj_error=2.0, download=True):
+        """StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974), data-parallel part, at the pose this
+        optimiser holds (i.e. right behind calcFastMotionOnly, no host round trip): per-record gate flags and
+        pyramid-level positions + PointStatistics.  Returns (GATED_POINT_DTYPE[batch, n], POINT_STATS_DTYPE[batch])."""
+        fr = self.frame
+        n = matcher._n
+        dev = fr.pyr[0].device
+        with torch.cuda.stream(fr.stream):
+            self.d_gated = torch.zeros(fr.batch * max(n, 1) * GATED_POINT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.d_pstats = torch.zeros(fr.batch * POINT_STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.ctx.call("svs_process_matched_points", matcher._keep[4].data_ptr(), matcher._keep[1].data_ptr(), n, n, n,
+                      int(n_new_records), C.byref(fr.cams[0]), self.d_T.data_ptr(), float(max_reproj_error),
+                      self.d_gated.data_ptr(), n, self.d_pstats.data_ptr(), fr.batch)
+        if not download:
+            return None
+        self.ctx.sync()
+        gated = self.d_gated.cpu().numpy().view(GATED_POINT_DTYPE)[:fr.batch * n].reshape(fr.batch, n)
+        return gated, self.d_pstats.cpu().numpy().view(POINT_STATS_DTYPE)
 
 
 class DenseTracker:

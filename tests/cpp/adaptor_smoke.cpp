@@ -93,6 +93,16 @@ int main(int argc, char **argv) {
     std::printf("MOTION %d %.17g %.17g", ps.num_obs, ps.initial_chi2, ps.chi2);
     for (int i = 0; i < 12; ++i) std::printf(" %.17g", T[i]);
     std::printf("\n");
+    // processMatchedPoints at the refined pose: every 3rd point on level 1, first third of the records "new"
+    std::vector<svs_candidate_point> points(track.size());
+    std::memset(points.data(), 0, points.size() * sizeof(svs_candidate_point));
+    for (size_t i = 0; i < points.size(); ++i) points[i].anchor_level = (i % 3 == 0) ? 1 : 0;
+    std::vector<svs_gated_point> gated;
+    svs_point_stats pst;
+    if (!ba2.processMatchedPoints(track, points, (int)(track.size() / 3), cam, T, 2.f, &gated, &pst)) return 11;
+    int n_acc = 0, n_new = 0;
+    for (size_t i = 0; i < gated.size(); ++i) { n_acc += gated[i].accepted; n_new += gated[i].is_new; }
+    std::printf("GATE %d %d %d %d %.17g\n", pst.num_obs, pst.num_track_points, n_acc, n_new, pst.sum_track_length);
   }
   return 0;
 }

@@ -45,19 +45,21 @@ def test_pod_layouts_match_the_c_header(tmp_path):
     """sizeof/offsetof of every POD struct, compiled from the header with gcc, against ctypes/numpy."""
     from scavislam_amd import capi
     from scavislam_amd.ctypes_types import (BA_CONSTRAINT_DTYPE, BA_EDGE_DTYPE, CANDIDATE_DTYPE, DENSE_SUMS_DTYPE,
-                                            KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, BaParams, BaStats, Cam, FastGrid, PoseOptParams, PoseOptStats,
-                                            StereoParams)
+                                            GATED_POINT_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE, POINT_STATS_DTYPE, BaParams, BaStats, Cam,
+                                            FastGrid, PoseOptParams, PoseOptStats, StereoParams)
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "scavislam_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "scavislam_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(svs_cam),sizeof(svs_fastgrid),sizeof(svs_candidate_point),sizeof(svs_keyframe),sizeof(svs_match_result),"
                    "sizeof(svs_dense_sums),sizeof(svs_ba_edge),sizeof(svs_ba_constraint),sizeof(svs_ba_params),sizeof(svs_ba_stats),"
-                   "sizeof(svs_match_args),sizeof(svs_dense_track_args),sizeof(svs_stereo_params),sizeof(svs_pose_opt_params),sizeof(svs_pose_opt_stats));return 0;}\n")
+                   "sizeof(svs_match_args),sizeof(svs_dense_track_args),sizeof(svs_stereo_params),sizeof(svs_pose_opt_params),sizeof(svs_pose_opt_stats),"
+                   "sizeof(svs_gated_point),sizeof(svs_point_stats));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(Cam), C.sizeof(FastGrid), CANDIDATE_DTYPE.itemsize, KEYFRAME_DTYPE.itemsize, MATCH_RESULT_DTYPE.itemsize,
             DENSE_SUMS_DTYPE.itemsize, BA_EDGE_DTYPE.itemsize, BA_CONSTRAINT_DTYPE.itemsize, C.sizeof(BaParams), C.sizeof(BaStats),
-            C.sizeof(capi.MatchArgs), C.sizeof(capi.DenseTrackArgs), C.sizeof(StereoParams), C.sizeof(PoseOptParams), C.sizeof(PoseOptStats)]
+            C.sizeof(capi.MatchArgs), C.sizeof(capi.DenseTrackArgs), C.sizeof(StereoParams), C.sizeof(PoseOptParams), C.sizeof(PoseOptStats),
+            GATED_POINT_DTYPE.itemsize, POINT_STATS_DTYPE.itemsize]
     assert got == want
     # the oracle header shares the POD definitions
     src2 = tmp_path / "sz2.c"

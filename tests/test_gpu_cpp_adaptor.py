@@ -89,3 +89,12 @@ def test_cpp_adaptor_matches_oracle(tmp_path):
     assert int(ml[1]) == sr.num_obs
     np.testing.assert_allclose([float(ml[2]), float(ml[3])], [sr.initial_chi2, sr.chi2], rtol=1e-9)
     np.testing.assert_allclose(np.array([float(t) for t in ml[4:16]]).reshape(3, 4), Tr, rtol=0, atol=1e-9)
+    # processMatchedPoints
+    from scavislam_amd.ctypes_types import CANDIDATE_DTYPE
+    gl = [l for l in out if l.startswith("GATE ")][0].split()
+    pts = np.zeros(len(track), CANDIDATE_DTYPE)
+    pts["anchor_level"][::3] = 1
+    T_cpp = np.array([float(t) for t in ml[4:16]])
+    g_ref, s_ref = O.process_matched_points(track, pts, len(track) // 3, cam, T_cpp, 2.0)
+    assert [int(x) for x in gl[1:5]] == [s_ref["num_obs"], s_ref["num_track_points"], g_ref["accepted"].sum(), g_ref["is_new"].sum()]
+    np.testing.assert_allclose(float(gl[5]), s_ref["sum_track_length"], rtol=1e-12)

@@ -118,3 +118,60 @@ def test_motion_only_behind_the_matcher(gpu_ctx, scene_frames):
     np.testing.assert_allclose(T[0], Tr, rtol=0, atol=1e-9)
     assert stats[0].num_obs == sr.num_obs and stats[0].chi2 <= stats[0].initial_chi2
     assert np.abs(T[0] - T_true).max() < 0.05      # stays near the truth (the candidate points carry a few px of noise)
+    # processMatchedPoints right behind it, at the refined pose that never left the device
+    po = PoseOptimizer(ctx, cur)
+    T2, _ = po.calcFastMotionOnly(m, T_guess.reshape(12))
+    gated, pstats = po.processMatchedPoints(m, n_new_records=600)
+    g_ref, s_ref = O.process_matched_points(res, pts, 600, cur.cams[0], T2[0])
+    _check_gate(gated[0], pstats[0], g_ref, s_ref)
+    assert pstats[0]["num_track_points"] >= 20
+
+
+def _check_gate(gated, stats, gated_ref, stats_ref):
+    for k in ("accepted", "is_new", "uv_pyr", "curkey_uv_pyr"):
+        assert np.array_equal(gated[k], gated_ref[k]), k
+    for k in ("num_points_grid2x2", "num_points_grid3x3", "num_matched_points", "num_track_points", "num_obs"):
+        assert np.array_equal(stats[k], stats_ref[k]), k
+    np.testing.assert_allclose(stats["sum_track_length"], stats_ref["sum_track_length"], rtol=1e-12)
+
+
+def test_process_matched_points_matches_oracle(gpu_ctx):
+    """StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974): gate flags, level positions and integer
+    statistics bit-exact; the track-length sum within 1e-12 (parallel summation order)."""
+    import torch
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import CANDIDATE_DTYPE, GATED_POINT_DTYPE, POINT_STATS_DTYPE, Cam
+    ctx, stream = gpu_ctx
+    rng = np.random.default_rng(5)
+    cam = synth.CAM_DEFAULT
+    camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+    T = synth.pose(synth.so3_exp(np.array([0.01, -0.02, 0.005])), np.array([0.03, -0.01, 0.08]))
+    B, n, n_new = 3, 700, 260
+    res = np.stack([_synthetic_results(rng, cam, T, n, outliers=0.25) for _ in range(B)])
+    # residuals straddling the three thresholds (2 * 2^level px in u and v, 6 px in u_right)
+    res["obs"] += rng.choice([0.0, 1.9, 2.1, 3.9, 4.1, 5.9, 6.1, 7.9, 8.1], size=res["obs"].shape) * rng.choice([-1, 1], size=res["obs"].shape)
+    pts = np.zeros((B, n), CANDIDATE_DTYPE)
+    pts["anchor_level"] = rng.integers(0, 3, (B, n))
+    with torch.cuda.stream(stream):
+        d_res = torch.as_tensor(res.view(np.uint8).reshape(-1)).cuda()
+        d_pts = torch.as_tensor(pts.view(np.uint8).reshape(-1)).cuda()
+        d_T = torch.as_tensor(np.tile(T.reshape(12), (B, 1))).cuda()
+        d_g = torch.zeros(B * n * GATED_POINT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        d_s = torch.zeros(B * POINT_STATS_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    for mre in (2.0, 0.75, 5.0):
+        ctx.call("svs_process_matched_points", d_res.data_ptr(), d_pts.data_ptr(), n, n, n, n_new, C.byref(camc), d_T.data_ptr(), mre,
+                 d_g.data_ptr(), n, d_s.data_ptr(), B)
+        ctx.sync()
+        gated = d_g.cpu().numpy().view(GATED_POINT_DTYPE).reshape(B, n)
+        stats = d_s.cpu().numpy().view(POINT_STATS_DTYPE)
+        for b in range(B):
+            g_ref, s_ref = O.process_matched_points(res[b], pts[b], n_new, camc, T, mre)
+            _check_gate(gated[b], stats[b], g_ref, s_ref)
+            assert 0 < s_ref["num_track_points"] < s_ref["num_obs"] and s_ref["num_points_grid3x3"].sum() == s_ref["num_track_points"]
+            assert g_ref["is_new"].sum() == g_ref["accepted"][:n_new].sum()
+    # empty list
+    ctx.call("svs_process_matched_points", None, None, 0, 0, 0, 0, C.byref(camc), d_T.data_ptr(), 2.0, None, 0, d_s.data_ptr(), B)
+    ctx.sync()
+    stats = d_s.cpu().numpy().view(POINT_STATS_DTYPE)
+    assert (stats["num_obs"] == 0).all() and (stats["sum_track_length"] == 0).all()
