@@ -1148,11 +1148,43 @@ __global__ __launch_bounds__(PIPE_THREADS) void ba_solve_lds_kernel(BaDev B, dou
 constexpr int FUSE_THREADS = 320;
 constexpr int FUSE_SLOTS = 10;
 constexpr int FUSE_PRE = 8;
+// Two fronts ("burn at both ends"): with P1 > 0 the kernel runs as TWO workgroups.  Front 0 eliminates the block rows
+// 0 .. P_top-1 in natural order; front 1 eliminates the last P1 rows (P_top = P - P1) in REVERSED block order -- the same
+// code on the block-reversed matrix (blocks fetched transposed from the packed upper storage, envelope = the reversed
+// profile).  The band structure decouples the two eliminations except for the R-1 rows just above front 1's set: front 1
+// leaves their Schur-complement deltas (matrix corner + rhs) in `xfer`, raises flag 0, and front 0 adds them to its LDS
+// window right before it consumes the first of those rows.  Back substitution mirrors it: front 0 publishes x of those
+// R-1 rows as soon as they are solved (flag 1), front 1 treats them as known rows of its own (reversed) system.
+// Flags hold the launch epoch (no reset needed); waits are bounded and fall into the solve's failure path.
+struct FuseFronts { int P_top, P1; double *xfer; unsigned *flags; unsigned epoch; };
+__device__ __forceinline__ bool fuse_wait_flag(const unsigned *flag, unsigned epoch) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
 __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ upanel,
-                                                                      const int *__restrict__ rowmax_g, int R) {
+                                                                      const int *__restrict__ rowmax_g, int R, FuseFronts F) {
   extern __shared__ double smem[];
   if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
-  const int P = B.P, n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int front = blockIdx.x, PN = B.P;                                // PN: poses of the whole (natural) system
+  const int Pe = front ? F.P1 : F.P_top;                                 // block rows this front eliminates
+  const int P = front ? F.P1 + R - 1 : F.P_top;                          // block rows in its view (front 1: + the R-1 shared rows, kept symbolic)
+  const int m0 = F.P_top - (R - 1);                                      // first shared row (natural index); shared rows = m0 .. P_top-1
+  const bool two = F.P1 > 0;
+  rowmax_g += front * PN;
+  upanel += (size_t)front * ((size_t)PN * FUSE_SLOTS * 36 + 128);
+  const int n = 6 * P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // element e = 6 r + c of local block (rl, rl + cb) of this front's matrix
+  auto hval = [&](int rl, int cb, int e) -> double {
+    if (!front) return B.H[(blk_index(rl, rl, PN) + cb) * 36 + e];
+    if (rl >= Pe) return 0.0;                                            // shared rows start from zero: they end up holding the deltas
+    const int i = PN - 1 - rl, j = i - cb;                               // natural block (j, i), j <= i; off-diagonal blocks transposed
+    const int r = e / 6, c = e - 6 * r;
+    return B.H[blk_index(j, i, PN) * 36 + (cb == 0 ? e : 6 * c + r)];
+  };
+  auto nat = [&](int rl) { return front ? PN - 1 - rl : rl; };
   double *s_b = smem;                          // [n]
   double *s_win = s_b + n;                     // [R][R][36] ring of envelope rows
   double *s_pz = s_win + (size_t)R * R * 36;   // [2][R][36] Z_kj
@@ -1168,7 +1200,14 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   if (tid == 0) s_fail = 0;
   if (tid < 48) s_zero[tid] = 0.0;
   for (int i = tid; i < P; i += FUSE_THREADS) rowmax[i] = rowmax_g[i];
-  for (int i = tid; i < n; i += FUSE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  for (int i = tid; i < n; i += FUSE_THREADS) {
+    const int rl = i / 6, g = 6 * nat(rl) + (i - 6 * rl);
+    s_b[i] = rl < Pe ? B.bp[g] - B.bs[g] : 0.0;
+  }
+  if (front) {      // shared rows take no part in the elimination: identity U_kk and zero panel rows for the back substitution
+    for (int e = tid; e < (P - Pe) * 36; e += FUSE_THREADS) s_ud[(size_t)Pe * 36 + e] = 0.0;
+    for (int e = tid; e < (P - Pe) * FUSE_SLOTS * 36; e += FUSE_THREADS) upanel[(size_t)Pe * FUSE_SLOTS * 36 + e] = 0.0;
+  }
   for (int t = tid; t < R * (R - 1) / 2; t += FUSE_THREADS) {   // t = jj (jj - 1) / 2 + (ii - 1)
     int jj = 1;
     while ((jj + 1) * jj / 2 <= t) ++jj;
@@ -1176,22 +1215,20 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     lut[2 * t + 1] = (unsigned char)jj;
   }
   for (int r = 0; r < R && r < P; ++r) {
-    const long rb = blk_index(r, r, P);
     for (int e = tid; e < R * 36; e += FUSE_THREADS) {
       const int c = e / 36;
-      s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+      s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? hval(r, c, e - c * 36) : 0.0;
     }
   }
   constexpr int LDN = (FUSE_SLOTS * 36 + 63) / 64;     // loader registers per lane and buffer
   double ra[LDN], rb_[LDN];
   auto load_row = [&](double (&reg)[LDN], int rn) {
     if (rn < P) {
-      const long rb = blk_index(rn, rn, P);
 #pragma unroll
       for (int i = 0; i < LDN; ++i) {
         const int e = lane + 64 * i;
         const int c = e / 36;
-        reg[i] = (e < R * 36 && rn + c < P) ? B.H[(rb + c) * 36 + (e - c * 36)] : 0.0;
+        reg[i] = (e < R * 36 && rn + c < P) ? hval(rn, c, e - c * 36) : 0.0;
       }
     }
   };
@@ -1211,10 +1248,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   double ycol[6] = {0, 0, 0, 0, 0, 0};          // this lane's column of Y_k (rhs lane: w_k); 0 outside panel k
   int failed = 0;
   long long t_ld = 0;
-  double *const g_trash = upanel + (size_t)P * FUSE_SLOTS * 36;      // 64 spare doubles behind the panel rows (write sink)
+  double *const g_trash = upanel + (size_t)PN * FUSE_SLOTS * 36;     // 64 spare doubles behind this front's panel rows (write sink)
   const double *const g_zero = g_trash + 64;                         // 64 zeros (never written)
   // stage for pivot row p: apply panel p-1 (nj_prev blocks), eliminate, emit panel p
-  auto pivot_stage = [&](int p, int nj_prev, int njp, int jp, int ringp) {      // jp = p % 10, ringp = p % R (kept as counters)
+  auto pivot_stage = [&](int p, int nj_prev, int njp, int jp, int ringp, bool apply_only = false) {      // jp = p % 10, ringp = p % R (kept as counters)
     const int pl = jp * 6;
     int off = slot - jp;                                            // block column j = p + off
     off += off < 0 ? FUSE_SLOTS : 0;
@@ -1227,7 +1264,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
       for (int r = 0; r < 6; ++r) a[r] = src[stride * r];
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) a[r] += (in_env && off == 0 && r == cc) ? B.lambda : 0.0;
+    for (int r = 0; r < 6; ++r) a[r] += (in_env && off == 0 && r == cc && !apply_only) ? B.lambda : 0.0;
     if (nj_prev > 0) {
       // block row p gets panel p-1:  a[r] -= sum_q Z_(p-1),p [q][r] * Y_(p-1),j [q][c]
       const double *z0 = s_pz + (size_t)((p - 1) & 1) * R * 36;      // block 0 of panel p-1 is block column p
@@ -1239,6 +1276,17 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
       for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int r = 0; r < 6; ++r) a[r] = __builtin_fma(-z[6 * q + r], ycol[q], a[r]);
+    }
+    if (apply_only) {      // first shared row of front 1: it only receives panel p-1 (the update waves cover rows >= p+1), then rests
+      if (rhs_lane) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_b[6 * p + r] = a[r];
+      } else if (in_env) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_win[((ringp * R) + off) * 36 + 6 * r + cc] = a[r];
+      }
+      wave_lds_fence();
+      return;
     }
     t_ld = wall_clock64();
     // eliminate the 6 pivots of block (p,p) on every column of the row (multipliers broadcast from the pivot lanes)
@@ -1293,14 +1341,36 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   // One loop per role (P stages, one lds_barrier each).  Separate loops keep the compiler's wait-count
   // bookkeeping apart: in a shared loop body the pivot wave waited every stage for vmcnt(0) -- the round
   // trip of its own panel stores -- because the loader's loads were pending on the merged path.
+  // front 0, entering stage inj_k: the shared rows m0 .. P_top-1 are all inside the LDS window and none has been consumed
+  // yet -- wait for front 1, add its deltas (update waves), one extra barrier for every role
+  const int inj_k = (two && !front) ? m0 - 1 : -1;
+  bool wait_failed = false;
+  auto inject = [&]() {
+    if (wave >= 1 && wave <= 3) {
+      if (!fuse_wait_flag(F.flags, F.epoch)) wait_failed = true;
+      const int ul = tid - 64, nsh = R - 1;
+      // front 1's local block (P1 + a, P1 + a + d) is natural block (j, i), i = P_top-1-a, j = i-d, transposed
+      for (int e = ul; e < nsh * R * 36; e += 192) {
+        const int a = e / (R * 36), rem = e - a * R * 36, d = rem / 36, q = rem - d * 36, r = q / 6, c = q - 6 * r;
+        if (a + d < nsh) {
+          const int i = F.P_top - 1 - a, j = i - d;
+          s_win[(((j % R) * R) + d) * 36 + 6 * c + r] += F.xfer[e];
+        }
+      }
+      for (int e = ul; e < nsh * 6; e += 192) { const int a = e / 6; s_b[6 * (F.P_top - 1 - a) + (e - 6 * a)] += F.xfer[nsh * R * 36 + e]; }
+    }
+    lds_barrier();
+  };
   if (wave == 0) {
     int nj_a = env_len(0), nj_b = env_len(1), nj_c = env_len(2);      // envelope lengths of rows k, k+1, k+2 (read ahead of use)
     int ring1 = 1 % R, slot1 = 1 % FUSE_SLOTS;                         // (k + 1) % R and (k + 1) % 10
-    for (int k = 0; k < P; ++k) {
+    for (int k = 0; k < Pe; ++k) {
+      if (k == inj_k) inject();
       const int nj = nj_a, nj_nx = nj_b;
       nj_a = nj_b; nj_b = nj_c; nj_c = env_len(k + 3);
       const long long ts0 = wall_clock64();
-      if (k + 1 < P) pivot_stage(k + 1, nj, nj_nx, slot1, ring1);
+      if (k + 1 < Pe) pivot_stage(k + 1, nj, nj_nx, slot1, ring1);
+      else if (k + 1 < P) pivot_stage(k + 1, nj, nj_nx, slot1, ring1, true);
       ring1 = ring1 + 1 == R ? 0 : ring1 + 1;
       slot1 = slot1 + 1 == FUSE_SLOTS ? 0 : slot1 + 1;
       const long long ts3 = wall_clock64();
@@ -1311,7 +1381,8 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     const int ul = tid - 64;
     int nj_a = env_len(0), nj_b = env_len(1);
     int ring1 = 1 % R;
-    for (int k = 0; k < P; ++k) {
+    for (int k = 0; k < Pe; ++k) {
+      if (k == inj_k) inject();
       const int nj = nj_a;
       nj_a = nj_b; nj_b = env_len(k + 2);
       const double *pz = s_pz + (size_t)(k & 1) * R * 36, *py = s_py + (size_t)(k & 1) * R * 36, *zk = s_y + (k & 1) * 8;
@@ -1351,7 +1422,8 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     }
   } else {
     int ringk = 0;
-    for (int k = 0; k < P; ++k) {
+    for (int k = 0; k < Pe; ++k) {
+      if (k == inj_k) inject();
       if (k & 1) { store_row(rb_, k, ringk); load_row(rb_, k + R + 2); }
       else { store_row(ra, k, ringk); load_row(ra, k + R + 2); }
       ringk = ringk + 1 == R ? 0 : ringk + 1;
@@ -1359,9 +1431,30 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     }
   }
   if (wave == 0 && __any(failed)) s_fail = 1;
+  if (__any(wait_failed) && lane == 0) s_fail = 1;
   __syncthreads();
+  if (front) {
+    // hand the deltas of the shared rows to front 0, then wait for their solution
+    const int nsh = R - 1;
+    for (int e = tid; e < nsh * R * 36; e += FUSE_THREADS) {
+      const int a = e / (R * 36), rem = e - a * R * 36;
+      F.xfer[e] = s_win[(((Pe + a) % R) * R) * 36 + rem];
+    }
+    for (int e = tid; e < nsh * 6; e += FUSE_THREADS) F.xfer[nsh * R * 36 + e] = s_b[6 * Pe + e];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(F.flags, F.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      if (!fuse_wait_flag(F.flags + 1, F.epoch)) { if (lane == 0) s_fail = 1; }
+      const double *xs = F.xfer + nsh * R * 36 + nsh * 6;              // x of natural rows m0 .. P_top-1
+      for (int e = lane; e < nsh * 6; e += 64) { const int a = e / 6; s_b[6 * (Pe + a) + (e - 6 * a)] = xs[6 * (nsh - 1 - a) + (e - 6 * a)]; }
+    }
+    __syncthreads();
+  }
   const int fail = s_fail;
   const long long t_fwd = wall_clock64();
+  const bool publish = two && !front;
+  double *const xpub = F.xfer + (R - 1) * R * 36 + (R - 1) * 6;
   if (wave == 0) {
     if (!fail) {
       // ---- back substitution: lane (slot, r) carries component r of row i, i % 10 == slot
@@ -1414,6 +1507,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
             xs[0] = readlane_f64(acc, pl);
             if (piv) {
               s_b[6 * k + r] = acc;                                   // x_k
+              if (publish && k >= m0) xpub[6 * (k - m0) + r] = acc;
               acc = wnext;
 #pragma unroll
               for (int rr = 1; rr < 6; ++rr) ucol[rr] = ucolnext[rr];
@@ -1423,6 +1517,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
 #pragma unroll
             for (int c = 0; c < 6; c += 2) { s0 = __builtin_fma(yq[d][c], xs[c], s0); s1 = __builtin_fma(yq[d][c + 1], xs[c + 1], s1); }
             acc -= s0 + s1;
+            if (publish && k == m0) {                                 // the shared rows are solved: release front 1
+              __threadfence();
+              if (lane == 0) __hip_atomic_store(F.flags + 1, F.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
             load_y(yq[d]);
             sk = sk == 0 ? FUSE_SLOTS - 1 : sk - 1;
             dist = dist == 0 ? FUSE_SLOTS - 1 : dist - 1;
@@ -1431,21 +1529,33 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
       }
     } else {
       for (int i = lane; i < n; i += 64) s_b[i] = 0;
+      if (publish) {                                                   // a failed factorisation still releases front 1 (the step is rejected anyway)
+        for (int i = lane; i < (R - 1) * 6; i += 64) xpub[i] = 0.0;
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(F.flags + 1, F.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   __syncthreads();
   const long long t_back = wall_clock64();
   double sc = 0;
-  for (int i = tid; i < n; i += FUSE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  for (int i = tid; i < 6 * Pe; i += FUSE_THREADS) {
+    const int rl = i / 6, g = 6 * nat(rl) + (i - 6 * rl);
+    const double xv = s_b[i];
+    x_out[g] = xv;
+    sc += xv * (B.lambda * xv + B.bp[g]);
+  }
   sc = wave_sum_f64(sc);
   if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
-  for (int p = tid; p < P; p += FUSE_THREADS) {
+  for (int p = tid; p < Pe; p += FUSE_THREADS) {
     double Tn[12];
-    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
-    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
+    const int g = nat(p);
+    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)g, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)g + i] = Tn[i];
   }
-  if (tid == 0) {
-    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+  if (tid == 0 && fail) B.scal[3] = 1.0;                               // zeroed before every trial by the Schur kernel / the host memset
+  if (tid == 0 && !front) {
+    B.scal[4] = *B.chi2_cur;
     B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
     B.scal[8] = acc_ld * 0.01; B.scal[9] = (acc_piv - acc_ld) * 0.01; B.scal[10] = 0; B.scal[11] = acc_bar * 0.01;
   }
@@ -1513,6 +1623,8 @@ struct svs_ba {
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
+  int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
+  int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
   int ctl_iters = 0;
   std::vector<hipEvent_t> spec_ev;      // 6 events per speculative trial
@@ -1572,6 +1684,9 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
   if (ba->h_ctl) { (void)hipHostFree(ba->h_ctl); ba->h_ctl = nullptr; }
   if (ba->d_ctl) { (void)hipFree(ba->d_ctl); ba->d_ctl = nullptr; }
+  if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
+  if (ba->d_xfer) (void)hipFree(ba->d_xfer);
+  if (ba->d_flags) (void)hipFree(ba->d_flags);
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
   ba->free_all();
@@ -1671,6 +1786,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     for (int e = a; e < b; ++e) ba->h_pattern[(size_t)sorted[e].pose * P + hi] = 1.0;
     ba->h_pattern[(size_t)sorted[a].anchor * P + hi] = 1.0;
     ba->h_pattern[(size_t)lo * P + hi] = 1.0;
+    // ... and, for the reversed front of the two-front solve, per pose the FIRST co-visible pose: mark (lo, p)
+    for (int e = a; e < b; ++e) ba->h_pattern[(size_t)lo * P + sorted[e].pose] = 1.0;
+    ba->h_pattern[(size_t)lo * P + sorted[a].anchor] = 1.0;
   }
   if (add_pose_terms)
     for (int c = 0; c < C; ++c) {
@@ -1763,15 +1881,57 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD;
   ba->lds_solve_smem = need;
   ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
+  // two-front elimination (fused kernel only): front 1 takes the last P1 block rows in reversed order.  Balance: front 0
+  // needs front 1's deltas when it reaches row P_top-(R-1), i.e. after P - P1 - (R-1) stages; front 1 needs P1 stages + the hand-over.
+  ba->fuse_P1 = 0;
+  if (ba->use_fused_solve && !getenv("SVS_BA_ONE_FRONT")) {
+    int P1 = (P - (R - 1) - 2) / 2;
+    if (const char *e = getenv("SVS_BA_P1")) P1 = atoi(e);               // experiments only
+    if (P1 >= 4 && P - P1 - (R - 1) >= 2) ba->fuse_P1 = P1;
+  }
+  std::vector<int> rm2(2 * (size_t)P, 0);
+  if (ba->fuse_P1 > 0) {
+    const int P1 = ba->fuse_P1, P_top = P - P1, Pv = P1 + R - 1;
+    for (int k = 0; k < P_top; ++k) rm2[k] = std::min(rowmax[k], P_top - 1);
+    // reversed profile: local row k' <-> natural P-1-k'; its reach = the topmost natural row coupled to it, with the same fill closure
+    std::vector<int> rr(P);
+    for (int kk = 0; kk < P; ++kk) {
+      const int i = P - 1 - kk;
+      int top = i;
+      for (int j = 0; j < i; ++j) if (pat[(size_t)j * P + i] != 0.0) { top = j; break; }
+      rr[kk] = P - 1 - top;
+    }
+    for (int kk = 0; kk < P; ++kk) for (int i = kk + 1; i <= rr[kk]; ++i) rr[i] = std::max(rr[i], rr[kk]);
+    bool ok = true;
+    for (int kk = 0; kk < P; ++kk) if (rr[kk] - kk + 1 > R) ok = false;      // (a symmetric band: same width both ways)
+    for (int kk = 0; kk < Pv; ++kk) rm2[P + kk] = std::min(rr[kk], Pv - 1);
+    if (!ok) ba->fuse_P1 = 0;
+  }
+  if (ba->fuse_P1 == 0) for (int k = 0; k < P; ++k) rm2[k] = rowmax[k];
+  if (ba->use_fused_solve) {
+    if (!ba->d_rowmax2 || ba->cap_rowmax2 < sizeof(int) * rm2.size()) {
+      if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
+      ba->cap_rowmax2 = sizeof(int) * rm2.size() + 256;
+      SVS_HIP(ctx, hipMalloc(&ba->d_rowmax2, ba->cap_rowmax2));
+    }
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_rowmax2, rm2.data(), sizeof(int) * rm2.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!ba->d_xfer) {
+      SVS_HIP(ctx, hipMalloc(&ba->d_xfer, sizeof(double) * (FUSE_SLOTS * FUSE_SLOTS * 36 + 2 * FUSE_SLOTS * 6)));
+      SVS_HIP(ctx, hipMalloc(&ba->d_flags, sizeof(unsigned) * 4));
+      SVS_HIP(ctx, hipMemsetAsync(ba->d_flags, 0, sizeof(unsigned) * 4, ctx->stream));
+    }
+    SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));                       // rm2 is a local
+  }
   if (ba->use_lds_solve) {
-    const size_t up_count = 36 * (size_t)P * std::max(R, FUSE_SLOTS) + 128;      // + write sink + zero block of the fused kernel
+    const size_t up_count = 2 * (36 * (size_t)P * std::max(R, FUSE_SLOTS) + 128);      // per front: panel rows + write sink + zero block of the fused kernel
     if (sizeof(double) * up_count > ba->cap_upanel || !ba->d_upanel) {
       if (ba->d_upanel) { (void)hipFree(ba->d_upanel); ba->d_upanel = nullptr; ba->cap_upanel = 0; }
       const size_t want = sizeof(double) * (up_count + up_count / 4);
       SVS_HIP(ctx, hipMalloc(&ba->d_upanel, want));
       ba->cap_upanel = want;
     }
-    // the fused kernel's zero block sits right behind the P x 10 panel rows (position depends on P): clear sink + zero block
+    // the fused kernel's zero block sits right behind the P x 10 panel rows of each front (position depends on P): clear sink + zero block
+    SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel + (up_count / 2 - 128), 0, sizeof(double) * 128, ctx->stream));
     SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel + (up_count - 128), 0, sizeof(double) * 128, ctx->stream));
     if (need > 64 * 1024) {
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -1851,7 +2011,11 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
   SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   if (ba->use_fused_solve)
-    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+  {
+    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch};
+    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(ba->fuse_P1 > 0 ? 2 : 1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel,
+                       ba->d_rowmax2, ba->env_R, F);
+  }
   else if (ba->use_lds_solve)
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
   else

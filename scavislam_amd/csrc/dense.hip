@@ -84,6 +84,24 @@ __device__ __forceinline__ SampleIn sample_load(const LevelArgs &L, int u, int v
   s.prev = L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4];
   return s;
 }
+// x / z and y / z share their denominator, and the Jacobian needs 1 / z again: one refined reciprocal serves all three.
+// r = RN(1 / b) after two Newton steps on v_rcp_f64 (what the compiler's own division expansion does per quotient), then
+// q = a r, e = a - q b (exact in an FMA), q + e r is the correctly rounded a / b by Markstein's theorem whenever r is the
+// correctly rounded reciprocal -- 3 f64 instructions per quotient instead of 11.  The pass is f64-issue bound
+// (~200 VALU instructions per sample, profiles/r1_notes.md), so this is ~10 % of its time.  Non-finite / zero b give
+// NaN or inf exactly where the IEEE quotient would be inf or NaN: those samples fail the |uv| < 1e9 gate either way.
+__device__ __forceinline__ double rcp_rn(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(e, r, r);
+}
+__device__ __forceinline__ double div_rn(double a, double b, double r) {
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-q, b, a), r, q);
+}
+
 template <bool JAC, bool U8SRC = false>
 __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a) {
   const float4 c4 = in.c4;
@@ -92,8 +110,9 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   const double x = T[0] * xp0 + T[1] * xp1 + T[2] * xp2 + T[3];
   const double y = T[4] * xp0 + T[5] * xp1 + T[6] * xp2 + T[7];
   const double z = T[8] * xp0 + T[9] * xp1 + T[10] * xp2 + T[11];
-  float uvx = (float)(L.cam.f * (x / z) + L.cam.cx);
-  float uvy = (float)(L.cam.f * (y / z) + L.cam.cy);
+  const double rz = rcp_rn(z);
+  float uvx = (float)(L.cam.f * div_rn(x, z, rz) + L.cam.cx);
+  float uvy = (float)(L.cam.f * div_rn(y, z, rz) + L.cam.cy);
   ok = ok && (fabsf(uvx) < 1e9f && fabsf(uvy) < 1e9f);
   const int ui = ok ? (int)uvx : 0, vi = ok ? (int)uvy : 0;
   ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
@@ -118,7 +137,7 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
     // in-frame test and the tap addresses must match bit for bit).
     {
 #pragma clang fp contract(fast)
-      const double f = L.cam.f, iz = 1.0 / zs, iz2 = iz * iz, fx = f * iz, xz = xs * iz2 * f, yz = ys * iz2 * f;
+      const double f = L.cam.f, iz = ok ? rz : 1.0, iz2 = iz * iz, fx = f * iz, xz = xs * iz2 * f, yz = ys * iz2 * f;
       const double r0[6] = {-fx, 0, xz, xz * ys, -(f + xz * xs), ys * fx};
       const double r1[6] = {0, -fx, yz, f + yz * ys, -(yz * xs), -(xs * fx)};
       double J[6];
