@@ -315,7 +315,10 @@ int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
 int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
 int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,
                           double *h_bred /* 6P */, double *h_chi2);
-/* last-call timing of the dominant kernels, ms (hipEvents on the ctx stream) */
+/* profiling: bracket the Schur, solve and back-substitution kernels of every LM trial with hipEvents on the ctx stream.
+   Off by default: each event record costs ~4 us of stream time (12 per optimize() = 15 % of it at 50 KF / 20k). */
+int svs_ba_set_timing(svs_ba *ba, int on);
+/* last-call timing of the dominant kernels, ms (zeros unless svs_ba_set_timing(ba, 1)) */
 int svs_ba_kernel_times(svs_ba *ba, float *reduce_ms, float *solve_ms, float *backsub_ms,
                         int32_t *n_reduce_launches);
 

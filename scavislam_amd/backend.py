@@ -103,6 +103,10 @@ class SlamGraphOptimizer:
         self.ctx.check(self.ctx.lib.svs_ba_reduced_system(self.h, float(lam), H.ctypes.data, b.ctypes.data, chi2.ctypes.data))
         return H, b, float(chi2[0])
 
+    def set_timing(self, on):
+        """hipEvent brackets around the dominant kernels of every LM trial (profiling; ~4 us per event)."""
+        self.ctx.check(self.ctx.lib.svs_ba_set_timing(self.h, int(bool(on))))
+
     def kernel_times(self):
         r, s, b, n = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
         self.ctx.lib.svs_ba_kernel_times(self.h, C.byref(r), C.byref(s), C.byref(b), C.byref(n))

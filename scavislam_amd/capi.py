@@ -98,6 +98,7 @@ _SIGS = {
     "svs_ba_get_state": [C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_reset_state": [C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_reduced_system": [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_ba_set_timing": [C.c_void_p, C.c_int],
     "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_int32)],
 }

@@ -1623,6 +1623,7 @@ struct svs_ba {
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
+  bool timing = false;                         // hipEvent brackets around the three dominant kernels of every trial (svs_ba_set_timing / svs_ba_kernel_times)
   int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
@@ -1949,12 +1950,12 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   if (!ev) ev = ba->ev;
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
   if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
   const char *dbg_env = getenv("SVS_BA_DEBUG");
   const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
   if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
   if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
     std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
     SVS_HIP(ctx, hipMemcpyAsync(h.data(), B.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -2009,7 +2010,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   BaDev B = make_dev(ba, lambda, cur, ctl);
   if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
-  SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   if (ba->use_fused_solve)
   {
     FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch};
@@ -2021,17 +2022,18 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   else
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
   SVS_LAUNCH_CHECK(ctx);
-  SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
   if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
   if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
-  SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
+  if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
   if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   return SVS_OK;
 }
 static int add_trial_times(svs_ba *ba, hipEvent_t *ev) {
   svs_ctx *ctx = ba->ctx;
   float ms;
+  if (!ba->timing) return SVS_OK;
   SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1])); ba->t_reduce += ms; ba->n_reduce++;
   SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[2], ev[3])); ba->t_solve += ms;
   SVS_HIP(ctx, hipEventElapsedTime(&ms, ev[5], ev[4])); ba->t_backsub += ms;
@@ -2159,6 +2161,12 @@ extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {
   if (h_poses) SVS_HIP(ctx, hipMemcpyAsync(h_poses, ba->d_poses[ba->cur], sizeof(double) * 12 * (size_t)ba->P, hipMemcpyDeviceToHost, ctx->stream));
   if (h_psi && ba->L) SVS_HIP(ctx, hipMemcpyAsync(h_psi, ba->d_psi[ba->cur], sizeof(double) * 3 * (size_t)ba->L, hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_set_timing(svs_ba *ba, int on) {
+  if (!ba) return SVS_ERR_INVALID;
+  ba->timing = on != 0;
   return SVS_OK;
 }
 
