@@ -21,6 +21,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1606,6 +1612,57 @@ __global__ void ba_lm_kernel(BaDev B, int it) {
 
 }  // namespace
 
+// Small host-side worker pool for the per-call marshalling (svs_ba_set_problem): the phases are passes over the 64-byte
+// edge records and are memory-bound on one core (~0.25 ms per pass at 100k edges).  Workers spin briefly between the
+// back-to-back phases of one call and sleep on a condition variable between calls.
+class HostPool {
+ public:
+  explicit HostPool(int n) : n_(std::max(1, n)) {
+    for (int t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_.store(true); gen_fast_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  int size() const { return n_; }
+  // fn(t, n) on every worker t in [0, n); returns when all are done
+  void run(const std::function<void(int, int)> &fn) {
+    if (n_ == 1) { fn(0, 1); return; }
+    job_ = &fn;
+    pending_.store(n_ - 1, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lk(m_); gen_fast_.fetch_add(1, std::memory_order_release); }      // under the lock: no lost wake-up
+    cv_.notify_all();
+    fn(0, n_);
+    while (pending_.load(std::memory_order_acquire) != 0) { /* phases are sub-millisecond: spin */ }
+  }
+
+ private:
+  void loop(int t) {
+    unsigned seen = 0;
+    for (;;) {
+      bool got = false;
+      for (int spin = 0; spin < 20000 && !got; ++spin) got = gen_fast_.load(std::memory_order_acquire) != seen;     // ~100 us of polling
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_.load() || gen_fast_.load(std::memory_order_acquire) != seen; });
+      }
+      if (stop_.load()) return;
+      seen = gen_fast_.load(std::memory_order_acquire);
+      (*job_)(t, n_);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  const std::function<void(int, int)> *job_ = nullptr;
+  std::atomic<unsigned> gen_fast_{0};
+  std::atomic<int> pending_{0};
+  std::atomic<bool> stop_{false};
+};
+
 struct svs_ba {
   svs_ctx *ctx = nullptr;
   int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, add_pose_terms = 1;
@@ -1634,6 +1691,10 @@ struct svs_ba {
   std::vector<double> h_pattern;
   // persistent host work arrays / pinned staging of set_problem, device capacities (grow-only)
   std::vector<int> w_anchor, w_nobs, w_pos, w_off, w_aoff, w_alist, w_order, w_fill, w_cs, w_cl;
+  std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
+  std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
+  HostPool *pool = nullptr;                    // marshalling workers (created on first use, SVS_HOST_THREADS overrides the count)
+  std::vector<double> w_pat_local;
   svs_ba_edge *h_edges = nullptr; size_t h_edges_cap = 0;
   size_t cap_poses[2] = {0, 0}, cap_psi[2] = {0, 0}, cap_edges = 0, cap_cs = 0, cap_cl = 0, cap_cons = 0, cap_red = 0, cap_x = 0, cap_scal = 0,
          cap_linv = 0, cap_rowmax = 0, cap_colmin = 0, cap_pattern = 0, cap_upanel = 0;
@@ -1691,6 +1752,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
   ba->free_all();
+  delete ba->pool; ba->pool = nullptr;
   for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
   delete ba;
   return SVS_OK;
@@ -1704,6 +1766,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
   if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const bool dbg_t = getenv("SVS_BA_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_0 = now(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0, t_5 = t_0;
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
   ba->profile_ready = false; ba->env_R = 0; ba->use_lds_solve = ba->use_fused_solve = false;
   // Edge order (copyDataToG2o iterates hash sets, so the reference has no meaningful edge order to
@@ -1717,15 +1782,70 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   std::vector<int> &anchor_of = ba->w_anchor, &n_obs = ba->w_nobs, &lm_pos = ba->w_pos, &lm_off = ba->w_off;
   anchor_of.assign(L, -1); n_obs.assign(L, 0);
   int span = 1;
-  for (int i = 0; i < E; ++i) {
-    const svs_ba_edge &e = h_edges[i];
-    SVS_REQUIRE(ctx, e.point >= 0 && e.point < L && e.pose >= 0 && e.pose < P && e.anchor >= 0 && e.anchor < P);
-    int &a = anchor_of[e.point];
-    if (a < 0) a = e.anchor;
-    SVS_REQUIRE(ctx, a == e.anchor);                                     // one anchor per point (slam_graph.hpp:121-133)
-    span = std::max(span, std::abs(e.pose - a) + 1);
-    if (++n_obs[e.point] > 64) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
+  // worker pool: one pass over the edge records is memory-bound on one core
+  if (!ba->pool) {
+    int nt = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("SVS_HOST_THREADS")) nt = std::max(1, atoi(e));
+    ba->pool = new HostPool(nt);
   }
+  HostPool &pool = *ba->pool;
+  const bool par = pool.size() > 1 && E >= 16384 && (size_t)L * pool.size() <= ((size_t)1 << 24);
+  auto for_range = [&](int total, const std::function<void(int, int, int)> &body) {      // body(t, begin, end)
+    if (!par) { body(0, 0, total); return; }
+    pool.run([&](int t, int n) { const long long a = (long long)total * t / n, b = (long long)total * (t + 1) / n; body(t, (int)a, (int)b); });
+  };
+  std::vector<uint64_t> &keys = ba->w_keys, &ent = ba->w_ent;
+  keys.resize((size_t)std::max(E, 1)); ent.resize((size_t)std::max(E, 1));
+  // Pass 1 over the edge records, no shared writes: every worker keeps, per landmark, the count of its own edges and the
+  // anchor it saw ((anchor + 1) << 8 | count in one word), and leaves a compact (point, pose) key per edge.  The merge
+  // turns the per-worker counts into per-worker start offsets inside the landmark (a counting sort without atomics whose
+  // result -- input order inside a landmark -- does not depend on the number of workers).
+  const int T = par ? pool.size() : 1;
+  std::vector<int> &cnt = ba->w_cnt;
+  cnt.assign((size_t)T * std::max(L, 1), 0);
+  {
+    std::atomic<int> err{0};
+    std::vector<int> span_t(T, 1);
+    for_range(E, [&](int t, int i0, int i1) {
+      int sp = 1;
+      int *c = cnt.data() + (size_t)t * L;
+      for (int i = i0; i < i1; ++i) {
+        const svs_ba_edge &e = h_edges[i];
+        if (!(e.point >= 0 && e.point < L && e.pose >= 0 && e.pose < P && e.anchor >= 0 && e.anchor < P)) { err.store(1); return; }
+        const int w = c[e.point];
+        if (w != 0 && (w >> 8) != e.anchor + 1) { err.store(2); return; }         // one anchor per point (slam_graph.hpp:121-133)
+        if ((w & 0xff) >= 64) { err.store(3); return; }
+        c[e.point] = ((e.anchor + 1) << 8) | ((w & 0xff) + 1);
+        sp = std::max(sp, std::abs(e.pose - e.anchor) + 1);
+        keys[i] = ((uint64_t)(uint32_t)e.point << 32) | (uint32_t)e.pose;           // all the later passes need of the record
+      }
+      span_t[t] = sp;
+    });
+    if (err.load() == 0)
+      for_range(L, [&](int, int l0, int l1) {
+        for (int l = l0; l < l1; ++l) {
+          int total = 0, anc = -1;
+          for (int t = 0; t < T; ++t) {
+            int &w = cnt[(size_t)t * L + l];
+            if (w != 0) {
+              const int a = (w >> 8) - 1;
+              if (anc >= 0 && a != anc) err.store(2);
+              anc = a;
+            }
+            const int n = w & 0xff;
+            w = total;                                                              // start offset of worker t inside landmark l
+            total += n;
+          }
+          if (total > 64) err.store(3);
+          anchor_of[l] = anc; n_obs[l] = total;
+        }
+      });
+    if (err.load() == 3) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
+    if (err.load() == 1) { ctx->err = "svs_ba_set_problem: edge index out of range"; return SVS_ERR_INVALID; }
+    if (err.load() == 2) { ctx->err = "svs_ba_set_problem: a point is observed with two different anchors"; return SVS_ERR_INVALID; }
+    for (int v : span_t) span = std::max(span, v);
+  }
+  t_1 = now();
   int G = std::max(1, std::min(8, WIN - span));                          // anchors interleaved per group
   if (const char *e = getenv("SVS_BA_GROUP")) G = std::max(1, atoi(e));     // experiments only
   // landmark order: per anchor the landmarks in index order; per group of G anchors deal them round-robin
@@ -1755,49 +1875,6 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     ba->h_edges_cap = (size_t)E + (size_t)E / 4 + 64;
     SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_edges, sizeof(svs_ba_edge) * ba->h_edges_cap, hipHostMallocDefault));
   }
-  svs_ba_edge *sorted = ba->h_edges;      // pinned: the upload is a plain DMA, no pageable staging copy
-  {
-    std::vector<int> &filled = ba->w_fill;
-    filled.assign(lm_order.size(), 0);
-    for (int i = 0; i < E; ++i) {
-      const svs_ba_edge &e = h_edges[i];
-      const int k = lm_pos[e.point], base = lm_off[k];
-      int j = filled[k]++;
-      while (j > 0 && sorted[base + j - 1].pose > e.pose) { sorted[base + j] = sorted[base + j - 1]; --j; }
-      SVS_REQUIRE(ctx, j == 0 || sorted[base + j - 1].pose != e.pose);     // one observation per (point, keyframe)
-      sorted[base + j] = e;
-    }
-  }
-  std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
-  cs.clear(); cl.clear();
-  for (size_t k = 0; k < lm_order.size();) {
-    const int start = lm_off[k];
-    int len = 0;
-    while (k < lm_order.size() && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
-    cs.push_back(start); cl.push_back(len);
-  }
-  ba->n_chunks = (int)cs.size();
-  // structural pattern of the reduced camera system: poses sharing a landmark, and constraints
-  ba->h_pattern.assign((size_t)P * P, 0.0);
-  for (size_t k = 0; k < lm_order.size(); ++k) {
-    const int a = lm_off[k], b = lm_off[k + 1];
-    int lo = std::min(sorted[a].pose, sorted[a].anchor), hi = std::max(sorted[b - 1].pose, sorted[a].anchor);
-    lo = std::min(lo, sorted[a].pose);
-    // envelope only needs, per pose, the farthest co-visible pose: mark (p, hi) for every pose of the landmark
-    for (int e = a; e < b; ++e) ba->h_pattern[(size_t)sorted[e].pose * P + hi] = 1.0;
-    ba->h_pattern[(size_t)sorted[a].anchor * P + hi] = 1.0;
-    ba->h_pattern[(size_t)lo * P + hi] = 1.0;
-    // ... and, for the reversed front of the two-front solve, per pose the FIRST co-visible pose: mark (lo, p)
-    for (int e = a; e < b; ++e) ba->h_pattern[(size_t)lo * P + sorted[e].pose] = 1.0;
-    ba->h_pattern[(size_t)lo * P + sorted[a].anchor] = 1.0;
-  }
-  if (add_pose_terms)
-    for (int c = 0; c < C; ++c) {
-      SVS_REQUIRE(ctx, h_cons[c].pose1 >= 0 && h_cons[c].pose1 < P && h_cons[c].pose2 >= 0 && h_cons[c].pose2 < P);
-      ba->h_pattern[(size_t)std::min(h_cons[c].pose1, h_cons[c].pose2) * P + std::max(h_cons[c].pose1, h_cons[c].pose2)] = 1.0;
-    }
-  const size_t nblk = (size_t)P * (P + 1) / 2;
-  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
   // device buffers persist across calls and only grow (the window changes by about one keyframe per call)
   auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
     if (bytes <= *cap && *ptr) return hipSuccess;
@@ -1808,13 +1885,88 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     if (e == hipSuccess) *cap = want;
     return e;
   };
+  t_2 = now();
+  svs_ba_edge *sorted = ba->h_edges;      // pinned: the upload is a plain DMA, no pageable staging copy
+  for_range(E, [&](int t, int i0, int i1) {            // pass 2, compact arrays only: every edge takes its slot (same worker ranges as pass 1)
+    int *c = cnt.data() + (size_t)t * L;
+    for (int i = i0; i < i1; ++i) {
+      const int pt = (int)(keys[i] >> 32);
+      ent[lm_off[lm_pos[pt]] + c[pt]++] = ((keys[i] & 0xffffffffull) << 32) | (uint32_t)i;      // (pose, source index)
+    }
+  });
+  // ... then each landmark is put in observer order (<= 64 entries, insertion sort on the (pose, index) words; the result
+  // does not depend on the slot order above because (point, keyframe) pairs are unique), and the structural pattern of
+  // the reduced camera system is marked: poses sharing a landmark, and constraints
+  const size_t n_lm = lm_order.size();
+  ba->h_pattern.assign((size_t)P * P, 0.0);
+  std::vector<double> &pat_local = ba->w_pat_local;
+  pat_local.assign((size_t)P * P * (par ? pool.size() : 0), 0.0);
+  {
+    std::atomic<int> dup{0};
+    for_range((int)n_lm, [&](int t, int k0, int k1) {
+      double *pat = par ? pat_local.data() + (size_t)t * P * P : ba->h_pattern.data();
+      for (int k = k0; k < k1; ++k) {
+        const int a = lm_off[k], b = lm_off[k + 1];
+        for (int i = a + 1; i < b; ++i) {
+          const uint64_t e = ent[i];
+          int j = i;
+          while (j > a && ent[j - 1] > e) { ent[j] = ent[j - 1]; --j; }
+          ent[j] = e;
+        }
+        for (int i = a + 1; i < b; ++i) if ((ent[i] >> 32) == (ent[i - 1] >> 32)) dup.store(1);      // one observation per (point, keyframe)
+        const int anc = anchor_of[lm_order[k]], p_first = (int)(ent[a] >> 32), p_last = (int)(ent[b - 1] >> 32);
+        const int lo = std::min(p_first, anc), hi = std::max(p_last, anc);
+        // envelope only needs, per pose, the farthest co-visible pose: mark (p, hi) for every pose of the landmark
+        for (int e = a; e < b; ++e) pat[(size_t)(ent[e] >> 32) * P + hi] = 1.0;
+        pat[(size_t)anc * P + hi] = 1.0;
+        pat[(size_t)lo * P + hi] = 1.0;
+        // ... and, for the reversed front of the two-front solve, per pose the FIRST co-visible pose: mark (lo, p)
+        for (int e = a; e < b; ++e) pat[(size_t)lo * P + (ent[e] >> 32)] = 1.0;
+        pat[(size_t)lo * P + anc] = 1.0;
+      }
+    });
+    if (dup.load()) { ctx->err = "svs_ba_set_problem: two observations of one point in one keyframe"; return SVS_ERR_INVALID; }
+    if (par)
+      for (int t = 0; t < pool.size(); ++t)
+        for (size_t i = 0; i < (size_t)P * P; ++i) if (pat_local[(size_t)t * P * P + i] != 0.0) ba->h_pattern[i] = 1.0;
+  }
+  t_3 = now();
+  // gather the records into slot order (sequential writes into the pinned buffer, each record read once) in a few
+  // sub-ranges, each uploaded as soon as it is complete: the DMA of one overlaps the gather of the next
+  SVS_HIP(ctx, ensure((void **)&ba->d_edges, &ba->cap_edges, sizeof(svs_ba_edge) * (size_t)std::max(E, 1)));
+  {
+    const int n_sub = par ? 4 : 1;
+    for (int sb = 0; sb < n_sub; ++sb) {
+      const int s0 = (int)((long long)E * sb / n_sub), s1 = (int)((long long)E * (sb + 1) / n_sub);
+      for_range(s1 - s0, [&](int, int i0, int i1) {
+        for (int i = s0 + i0; i < s0 + i1; ++i) sorted[i] = h_edges[(uint32_t)ent[i]];
+      });
+      if (s1 > s0) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges + s0, sorted + s0, sizeof(svs_ba_edge) * (size_t)(s1 - s0), hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
+  cs.clear(); cl.clear();
+  for (size_t k = 0; k < n_lm;) {
+    const int start = lm_off[k];
+    int len = 0;
+    while (k < n_lm && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
+    cs.push_back(start); cl.push_back(len);
+  }
+  ba->n_chunks = (int)cs.size();
+  if (add_pose_terms)
+    for (int c = 0; c < C; ++c) {
+      SVS_REQUIRE(ctx, h_cons[c].pose1 >= 0 && h_cons[c].pose1 < P && h_cons[c].pose2 >= 0 && h_cons[c].pose2 < P);
+      ba->h_pattern[(size_t)std::min(h_cons[c].pose1, h_cons[c].pose2) * P + std::max(h_cons[c].pose1, h_cons[c].pose2)] = 1.0;
+    }
+  t_4 = now();
+  const size_t nblk = (size_t)P * (P + 1) / 2;
+  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
   for (int k = 0; k < 2; ++k) {
     SVS_HIP(ctx, ensure((void **)&ba->d_poses[k], &ba->cap_poses[k], sizeof(double) * 12 * (size_t)P));
     SVS_HIP(ctx, ensure((void **)&ba->d_psi[k], &ba->cap_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
     if (L) SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[k], h_psi, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
   }
-  SVS_HIP(ctx, ensure((void **)&ba->d_edges, &ba->cap_edges, sizeof(svs_ba_edge) * (size_t)std::max(E, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
@@ -1825,14 +1977,19 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_pattern, &ba->cap_pattern, sizeof(double) * (size_t)P * P));
-  if (E) SVS_HIP(ctx, hipMemcpyAsync(ba->d_edges, sorted, sizeof(svs_ba_edge) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
   if (ba->n_chunks) {
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_start, cs.data(), sizeof(int) * cs.size(), hipMemcpyHostToDevice, ctx->stream));
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_len, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice, ctx->stream));
   }
   if (C) SVS_HIP(ctx, hipMemcpyAsync(ba->d_cons, h_cons, sizeof(svs_ba_constraint) * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)P, ctx->stream));
+  t_5 = now();
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (dbg_t) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[svs_ba] set_problem: validate+count %.0f us, landmark order %.0f us, slots+sort+pattern %.0f us, gather+upload+chunks %.0f us, enqueue copies %.0f us, wait %.0f us\n",
+            us(t_0, t_1), us(t_1, t_2), us(t_2, t_3), us(t_3, t_4), us(t_4, t_5), us(t_5, now()));
+  }
   return SVS_OK;
 }
 
