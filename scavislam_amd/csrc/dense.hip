@@ -103,7 +103,8 @@ __device__ __forceinline__ double div_rn(double a, double b, double r) {
 }
 
 template <bool JAC, bool U8SRC = false>
-__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a) {
+__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a,
+                                               const float *ip_lut = nullptr) {
   const float4 c4 = in.c4;
   bool ok = in_range && (c4.w > 0);
   const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
@@ -117,7 +118,9 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   const int ui = ok ? (int)uvx : 0, vi = ok ? (int)uvy : 0;
   ok = ok && (ui >= 2 && vi >= 2 && ui < L.cam.w - 2 && vi < L.cam.h - 2);
   if (!ok) { uvx = 2.f; uvy = 2.f; }                       // safe tap position, contribution masked below
-  const float ip = (float)((1. / 255.) * in.prev);
+  // (float)((1./255.) * u8): a double product rounded once (dense_tracking.cpp:290-293), NOT the f32 product convertTo
+  // uses for the current image -- the tracker kernel keeps the 256 possible values in LDS (3 f64-rate instructions less)
+  const float ip = ip_lut ? ip_lut[in.prev] : (float)((1. / 255.) * in.prev);
   float ic, g8x = 0.f, g8y = 0.f;
   if (U8SRC) taps_u8(L.cur8, L.c8stride, uvx, uvy, ic, g8x, g8y);
   else ic = interp32f(L.cur, L.fstride, uvx, uvy);
@@ -300,29 +303,37 @@ constexpr int TRK_THREADS = SVS_TRK_THREADS;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
 template <bool JAC, bool U8SRC>
-__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out) {
+__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut) {
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
   // TRK_UNROLL samples per lane per trip (independent gather chains in flight); the next trip's stored points and
   // previous-frame intensities (independent of T) are loaded before this trip's arithmetic, so only the bilinear
-  // taps -- whose addresses depend on the projection -- are exposed
+  // taps -- whose addresses depend on the projection -- are exposed.  The grid position of the prefetched sample is
+  // carried incrementally (one division per pass instead of one per sample: the pass is VALU-issue bound).
+  constexpr int STEP = TRK_UNROLL * TRK_THREADS;
+  const int su = STEP % cw, sv = STEP / cw;
   SampleIn nxt[TRK_UNROLL];
+  int pu[TRK_UNROLL], pv[TRK_UNROLL];
 #pragma unroll
   for (int q = 0; q < TRK_UNROLL; ++q) {
     const int j = threadIdx.x + q * TRK_THREADS;
-    nxt[q] = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
+    pu[q] = j % cw; pv[q] = j / cw;
+    const bool in = pv[q] < ch;
+    nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
   }
-  for (int i = threadIdx.x; i < n; i += TRK_UNROLL * TRK_THREADS) {
+  for (int i = threadIdx.x; i < n; i += STEP) {
     SampleIn cur[TRK_UNROLL];
 #pragma unroll
     for (int q = 0; q < TRK_UNROLL; ++q) {
       cur[q] = nxt[q];
-      const int j = i + (TRK_UNROLL + q) * TRK_THREADS;
-      nxt[q] = sample_load(L, (j < n ? j : 0) % cw, (j < n ? j : 0) / cw, cw, j < n);
+      pu[q] += su; pv[q] += sv;
+      if (pu[q] >= cw) { pu[q] -= cw; ++pv[q]; }
+      const bool in = pv[q] < ch;
+      nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
     }
 #pragma unroll
-    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS < n, a);
+    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS < n, a, ip_lut);
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
@@ -332,8 +343,10 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
+  __shared__ float s_iplut[256];
   const int slot = blockIdx.x;
   if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
+  for (int i = threadIdx.x; i < 256; i += TRK_THREADS) s_iplut[i] = (float)((1. / 255.) * i);
   __syncthreads();
   int passes = 0;
   // One fused pass per LM iteration.  The reference runs, per iteration, an H,b pass at T and a
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<true, U8SRC>(L, T, s_part, s_out);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     ++passes;
     float chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC>(L, T, s_part, s_out);        // new_chi2 (:335-367) + H,b for the next iteration
+      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut);        // new_chi2 (:335-367) + H,b for the next iteration
       ++passes;
       const float new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
