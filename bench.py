@@ -338,7 +338,7 @@ def main():
                 # HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the
                 # gfx950 note in MI355X_MICROARCH.md), measured on this kernel at this size in profiles/r1_summary.md;
                 # it cannot be collected inside this process, so it is only reported for the profiled configuration
-                "traffic": 17212300 if (world == 1 and E_local == 99587) else None,
+                "traffic": 17221600 if (world == 1 and E_local == 99587) else None,
                 "traffic_source": "profiles/r1_summary.md section 3 (2*FETCH_SIZE + WRITE_SIZE)"}
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
@@ -354,7 +354,7 @@ def main():
         kf_pyr = O.build_pyramid(rend[kf_id][0])
         t0 = time.perf_counter()
         nfr = 0
-        while nfr < 3 or (time.perf_counter() - t0 < 8.0 and nfr < 40):
+        while nfr < 3 or (time.perf_counter() - t0 < 8.0 and nfr < 200):      # BASELINE configs[0]: 200 frames
             p = nfr % NPAIR
             img_c, disp_c = rend[5 + p]
             pyr_c = O.build_pyramid(img_c)                                      # "preprocess"
@@ -372,13 +372,13 @@ def main():
         cpu_fps = nfr / t_cpu
         t0 = time.perf_counter()
         nba = 0
-        while nba < 2 or (time.perf_counter() - t0 < 6.0 and nba < 20):
+        while nba < 2 or (time.perf_counter() - t0 < 6.0 and nba < 100):
             O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
             nba += 1
         cpu_schur_ms = (time.perf_counter() - t0) / nba * 1e3
         t0 = time.perf_counter()
         nst = 0
-        while nst < 2 or (time.perf_counter() - t0 < 3.0 and nst < 6):      # "stereo" (cv::StereoBM restatement), timed on its own like the GPU stage
+        while nst < 2 or (time.perf_counter() - t0 < 4.0 and nst < 12):     # "stereo" (cv::StereoBM restatement), timed on its own like the GPU stage
             O.stereo_bm(rend[5 + nst % NPAIR][0], rend_right[5 + nst % NPAIR])
             nst += 1
         cpu_stereo_ms = (time.perf_counter() - t0) / nst * 1e3
