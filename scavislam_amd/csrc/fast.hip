@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void fast_compact_2sweep_kernel(FastParams P) 
 // with the row count; after the row scan the corners are emitted from the LDS masks alone.
 // Order inside a row: x = 4*lane + j  =>  rank = sum_j popc(ballot_j & lanes_below) + popc(own bits < j).
 constexpr int CMP_MAXROWS = 1024;
-__global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
+// CMP_WAVES waves per cell: the sweep is a chain of global round trips per wave, so 16 waves (fewer trips each) win when
+// few cells are in flight (latency mode), 4 waves when the batch fills the device anyway.
+template <int CMP_WAVES>
+__global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams P) {
   extern __shared__ unsigned long long s_mask[];      // [rows][chunks][4]
   __shared__ int s_row[CMP_MAXROWS];
   const int slot = blockIdx.y;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
   // 8 rows in flight per wave: the loads of a batch are issued back to back, so the sweep pays one
   // global round trip per 8 rows instead of one per row
   constexpr int RB = 8;
-  for (int r0 = wave * RB; r0 < rows; r0 += 4 * RB) {
+  for (int r0 = wave * RB; r0 < rows; r0 += CMP_WAVES * RB) {
     for (int ch = 0; ch < chunks; ++ch) {
       const int x = ch * 256 + 4 * lane;
       uint32_t v[RB];
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) void fast_compact_kernel(FastParams P) {
   __syncthreads();
   int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int r = wave; r < rows; r += 4) {
+  for (int r = wave; r < rows; r += CMP_WAVES) {
     int o = base + s_row[r];
     const int y = v0 + 3 + r;
     for (int ch = 0; ch < chunks; ++ch) {
@@ -511,7 +514,12 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
     mask_bytes = std::max(mask_bytes, (size_t)std::max(L.cell_h - 6, 0) * (size_t)((std::max(L.cell_w - 6, 1) + 255) / 256) * 32);
   }
   if (mask_bytes <= 56 * 1024)
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P);
+  {
+    if ((long)f->P.ncell_total * n_batch <= 1024)
+      hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P);
+    else
+      hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P);
+  }
   else
     hipLaunchKernelGGL(fast_compact_2sweep_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P);
   SVS_LAUNCH_CHECK(ctx);
