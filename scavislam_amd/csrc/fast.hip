@@ -17,6 +17,7 @@
 #include "common.h"
 #include "fast_view.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -358,15 +359,28 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams
     for (int ch = 0; ch < chunks; ++ch) {
       const int x = ch * 256 + 4 * lane;
       uint32_t v[RB];
+      if (cols >= 4) {
+        // branch-free: every lane loads a dword from a clamped position (the lane straddling the ROI edge shifts the
+        // out-of-ROI bytes away).  With a per-byte tail path the compiler put a full wait behind every row's load and
+        // the 8 loads of a batch were 16 serial round trips.
+        const int xs = min(x, cols - 4), sh = 8 * (x - xs);
+        const bool lane_in = x < cols;
 #pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int r = r0 + i;
-        v[i] = 0;
-        if (r < rows) {
-          const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
-          if (x + 3 < cols) __builtin_memcpy(&v[i], p + x, 4);
-          else
+        for (int i = 0; i < RB; ++i) {
+          const int r = min(r0 + i, rows - 1);
+          uint32_t raw;
+          __builtin_memcpy(&raw, score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3 + xs, 4);
+          v[i] = (lane_in && r0 + i < rows) ? (raw >> (sh & 31)) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int r = r0 + i;
+          v[i] = 0;
+          if (r < rows) {
+            const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
             for (int j = 0; j < 4; ++j) if (x + j < cols) v[i] |= (uint32_t)p[x + j] << (8 * j);
+          }
         }
       }
 #pragma unroll
@@ -410,7 +424,10 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if ((b[j] >> lane) & 1ull) {
-          if (pos < P.cap) { xy[2 * pos] = (int16_t)(u0 + 3 + ch * 256 + 4 * lane + j); xy[2 * pos + 1] = (int16_t)y; }
+          if (pos < P.cap) {      // (x, y) as one dword store
+            const uint32_t pk = (uint32_t)(uint16_t)(u0 + 3 + ch * 256 + 4 * lane + j) | ((uint32_t)(uint16_t)y << 16);
+            __builtin_memcpy(xy + 2 * pos, &pk, 4);
+          }
           ++pos;
         }
       }
@@ -515,7 +532,7 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
   }
   if (mask_bytes <= 56 * 1024)
   {
-    if ((long)f->P.ncell_total * n_batch <= 1024)
+    if ((long)f->P.ncell_total * n_batch <= 1024 || getenv("SVS_FAST_CMP16"))
       hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P);
     else
       hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P);
