@@ -104,13 +104,13 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I
     const int r = i / 18, c = i - r * 18;
     const int y = min(max(gy0 + r, 0), L.h - 1), x = gx0 + 4 * c;
     const uint8_t *row = img + (size_t)y * istride;
-    uint32_t v;
-    if (x >= 0 && x + 3 < L.w) __builtin_memcpy(&v, row + x, 4);
-    else {
-      v = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v |= (uint32_t)row[min(max(x + q, 0), L.w - 1)] << (8 * q);
-    }
+    // branch-free: a dword from the clamped position, shifted so that the in-image bytes land where they belong; the bytes
+    // outside the image become 0 and are never used (only ROI-interior pixels are scored and their ring stays inside the
+    // ROI).  A per-byte border path would put a wait behind every iteration's load.
+    const int xs = min(max(x, 0), L.w - 4), d = x - xs;
+    uint32_t raw;
+    __builtin_memcpy(&raw, row + xs, 4);
+    const uint32_t v = d == 0 ? raw : d >= 4 || d <= -4 ? 0u : d > 0 ? raw >> (8 * d) : raw << (-8 * d);
     s_img[r * LROW + c] = v;
   }
   __syncthreads();
