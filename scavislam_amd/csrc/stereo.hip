@@ -299,41 +299,66 @@ __device__ __forceinline__ void ccl_union(int32_t *label, int a, int b) {      /
 }
 __device__ __forceinline__ bool ccl_linked(int a, int b, int range) { return a != FILTERED16 && b != FILTERED16 && abs(a - b) <= range; }
 
-// Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels (a prefix scan
-// over "run starts here" along the row), so the union-find only has to stitch rows together and its chains stay
-// short; runs longer than the speckle window are labelled CCL_BIG right away -- in a real disparity map that is most
-// valid pixels, and their vertical links cost nothing later.  One workgroup per image row.
-// grid: (h, batch), block 256, dynamic LDS = 3 * w ints
+// Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels, so the union-find
+// only has to stitch rows together and its chains stay short; runs longer than the speckle window are labelled CCL_BIG
+// right away -- in a real disparity map that is most valid pixels, and their vertical links cost nothing later.
+// One workgroup per image row, one wave per 64-pixel segment: "last run start at or left of me" and "next run boundary
+// right of me" come from two ballots per segment plus a carry over the (few) segments of the row -- three barriers per
+// row.  The start pixel of every small run gets count = 0 and its length in `rlen` (the cost plane, free after the
+// LR check; 0 everywhere else): the later passes find the small runs through it and nothing else needs clearing.
+// grid: (h, batch), block 256, dynamic LDS = (2 w + 2 nseg) ints
 __global__ __launch_bounds__(256) void stereo_ccl_runs_kernel(StereoDev S) {
   extern __shared__ int s_mem[];
-  const int w = S.w, y = blockIdx.x, tid = threadIdx.x;
-  const size_t base = (size_t)blockIdx.y * w * S.h;
-  const int16_t *d = S.disp16 + base + (size_t)y * w;
-  int *s_a = s_mem, *s_b = s_mem + w, *s_len = s_mem + 2 * w;
-  for (int x = tid; x < w; x += 256) {
-    const int dv = d[x];
-    const bool start = dv != FILTERED16 && !(x > 0 && ccl_linked(dv, d[x - 1], S.speckle_range));
-    s_a[x] = dv == FILTERED16 ? -2 : (start ? x : -1);      // -2: filtered (also stops a run), -1: continues the run to its left
-    S.count[base + (size_t)y * w + x] = 0;
+  const int w = S.w, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t base = (size_t)blockIdx.y * w * S.h + (size_t)y * w;
+  const int16_t *d = S.disp16 + base;
+  const int nseg = (w + 63) >> 6;
+  int *s_st = s_mem, *s_len = s_mem + w, *s_segl = s_len + w, *s_segf = s_segl + nseg;
+  for (int seg = wave; seg < nseg; seg += 4) {
+    const int x = seg * 64 + lane;
+    const bool in = x < w;
+    const int dv = in ? d[x] : FILTERED16, dl = (in && x > 0) ? d[x - 1] : FILTERED16;
+    const bool filt = dv == FILTERED16;                                        // lanes beyond the row end act as a boundary
+    const bool start = !filt && !(x > 0 && ccl_linked(dv, dl, S.speckle_range));
+    const unsigned long long sb = __ballot(start), bb = __ballot(start || filt);
+    const unsigned long long lower = sb & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    if (in) {
+      s_st[x] = filt ? -2 : (lower ? seg * 64 + 63 - __clzll((long long)lower) : -1);      // -1: the run started in an earlier segment
+      const unsigned long long above = lane == 63 ? 0ull : (bb >> (lane + 1));
+      s_len[x] = above ? x + __ffsll((long long)above) : -1;                               // next boundary; -1: in a later segment
+    }
+    if (lane == 0) {
+      s_segl[seg] = sb ? seg * 64 + 63 - __clzll((long long)sb) : -1;
+      s_segf[seg] = bb ? seg * 64 + __ffsll((long long)bb) - 1 : 0x7fffffff;
+    }
   }
   __syncthreads();
-  for (int o = 1; o < w; o <<= 1) {      // prefix "last run start / filtered marker to the left" (Hillis-Steele)
-    for (int x = tid; x < w; x += 256) { int v = s_a[x]; if (v == -1 && x >= o) v = s_a[x - o]; s_b[x] = v; }
-    __syncthreads();
-    int *t = s_a; s_a = s_b; s_b = t;
-  }
-  for (int x = tid; x < w; x += 256) {      // the last pixel of a run publishes the run length at the run start
-    const int st = s_a[x];
-    if (st >= 0 && (x == w - 1 || s_a[x + 1] != st)) s_len[st] = x - st + 1;
-  }
+  if (tid == 0) { int run = -1; for (int k = 0; k < nseg; ++k) { const int v = s_segl[k]; s_segl[k] = run; run = max(run, v); } }              // exclusive prefix max
+  if (tid == 64) { int run = w; for (int k = nseg - 1; k >= 0; --k) { const int v = s_segf[k]; s_segf[k] = run; run = min(run, v); } }          // exclusive suffix min
   __syncthreads();
   for (int x = tid; x < w; x += 256) {
-    const int st = s_a[x];
-    S.label[base + (size_t)y * w + x] = st < 0 ? -1 : (s_len[st] > S.speckle_window ? CCL_BIG : y * w + st);
+    const int seg = x >> 6;
+    int st = s_st[x];
+    if (st == -1) { st = s_segl[seg]; s_st[x] = st; }
+    if (st == x) { int nb = s_len[x]; if (nb < 0) nb = s_segf[seg]; s_len[x] = min(nb, w) - x; }
+  }
+  __syncthreads();
+  uint16_t *rlen = S.cost + base;
+  for (int x = tid; x < w; x += 256) {
+    const int st = s_st[x];
+    int lab = -1, rl = 0;
+    if (st >= 0) {
+      const int len = s_len[st];
+      const bool big = len > S.speckle_window;
+      lab = big ? CCL_BIG : y * w + st;
+      if (!big && st == x) { rl = len; S.count[base + x] = 0; }
+    }
+    S.label[base + x] = lab;
+    rlen[x] = (uint16_t)rl;
   }
 }
 // stitch vertically linked pixels; one union per pair of overlapping runs (the leftmost linked column of the overlap).
-// grid: (ceil(w*h/256), batch)
+// grid: (ceil(w*h/256), batch) -- scalar variant for widths that are not a multiple of 4
 __global__ __launch_bounds__(256) void stereo_ccl_merge_kernel(StereoDev S) {
   const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h, w = S.w;
   if (i + w >= n) return;
@@ -346,26 +371,57 @@ __global__ __launch_bounds__(256) void stereo_ccl_merge_kernel(StereoDev S) {
   if (i % w > 0 && label[i - 1] == la && label[i + w - 1] == lb && ccl_linked(d[i - 1], d[i + w - 1], S.speckle_range)) return;
   ccl_union(label, la, lb);      // run labels are only ever replaced by other members of the same set (or CCL_BIG)
 }
-// component sizes, saturating: the test is "size <= speckle_window", so a root that is already beyond the window
-// is left alone, and the lanes of a wave that share a root (runs!) add once.  Members of CCL_BIG need no count.
-__global__ __launch_bounds__(256) void stereo_ccl_count_kernel(StereoDev S) {
-  const int i = blockIdx.x * 256 + threadIdx.x, n = S.w * S.h, lane = threadIdx.x & 63;
+// same, four horizontally adjacent pixels per lane (w % 4 == 0): the labels of both rows arrive as two 16-byte loads and
+// most lanes leave right there (filtered, or big above big); grid: (ceil(w*h/1024), batch)
+__global__ __launch_bounds__(256) void stereo_ccl_merge4_kernel(StereoDev S) {
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4, n = S.w * S.h, w = S.w;
+  if (i0 + w >= n) return;
   const size_t base = (size_t)blockIdx.y * n;
-  int root = -1;
-  if (i < n) {
-    const int l = S.label[base + i];
-    if (l >= 0) {
-      root = ccl_find(S.label + base, i);
-      if (root != l) S.label[base + i] = root;      // flatten (roots stay roots, so concurrent finds remain valid)
-    }
+  const int16_t *d = S.disp16 + base;
+  int32_t *label = S.label + base;
+  const int4 a4 = *reinterpret_cast<const int4 *>(label + i0), b4 = *reinterpret_cast<const int4 *>(label + i0 + w);
+  const int la[4] = {a4.x, a4.y, a4.z, a4.w}, lb[4] = {b4.x, b4.y, b4.z, b4.w};
+  bool cand[4], any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { cand[k] = !(la[k] == -1 || lb[k] == -1 || (la[k] == CCL_BIG && lb[k] == CCL_BIG)); any |= cand[k]; }
+  if (!any) return;
+  const uint2 da2 = *reinterpret_cast<const uint2 *>(d + i0), db2 = *reinterpret_cast<const uint2 *>(d + i0 + w);
+  const int da[4] = {(int16_t)(da2.x & 0xffff), (int16_t)(da2.x >> 16), (int16_t)(da2.y & 0xffff), (int16_t)(da2.y >> 16)};
+  const int db[4] = {(int16_t)(db2.x & 0xffff), (int16_t)(db2.x >> 16), (int16_t)(db2.y & 0xffff), (int16_t)(db2.y >> 16)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!cand[k] || !ccl_linked(da[k], db[k], S.speckle_range)) continue;
+    bool covered;
+    if (k > 0) covered = la[k - 1] == la[k] && lb[k - 1] == lb[k] && ccl_linked(da[k - 1], db[k - 1], S.speckle_range);
+    else covered = i0 % w > 0 && label[i0 - 1] == la[0] && label[i0 + w - 1] == lb[0] && ccl_linked(d[i0 - 1], d[i0 + w - 1], S.speckle_range);
+    if (!covered) ccl_union(label, la[k], lb[k]);
   }
-  const int prev = __shfl_up(root, 1, 64);
-  const bool head = root >= 0 && (lane == 0 || prev != root);
-  const unsigned long long heads = __ballot(head || root < 0);      // run boundaries inside the wave
-  if (head) {
-    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const int len = above ? __ffsll((long long)above) : 64 - lane;
-    if (S.count[base + root] <= S.speckle_window) atomicAdd(&S.count[base + root], len);
+}
+// component sizes, saturating: the test is "size <= speckle_window", so a root that is already beyond the window is left
+// alone.  Only the start pixels of small runs carry a length (rlen != 0): eight pixels per lane, most lanes see zeros.
+// Members of CCL_BIG need no count.  grid: (ceil(w*h/2048), batch)
+__global__ __launch_bounds__(256) void stereo_ccl_count_kernel(StereoDev S) {
+  const int n = S.w * S.h, i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 >= n) return;
+  const size_t base = (size_t)blockIdx.y * n;
+  const uint16_t *rlen = S.cost + base;
+  int len[8];
+  if (((base | (size_t)i0) & 7) == 0 && i0 + 8 <= n) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(rlen + i0);
+    if ((r.x | r.y | r.z | r.w) == 0) return;
+    len[0] = r.x & 0xffff; len[1] = r.x >> 16; len[2] = r.y & 0xffff; len[3] = r.y >> 16;
+    len[4] = r.z & 0xffff; len[5] = r.z >> 16; len[6] = r.w & 0xffff; len[7] = r.w >> 16;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) len[k] = i0 + k < n ? rlen[i0 + k] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (len[k] == 0) continue;
+    const int root = ccl_find(S.label + base, i0 + k);
+    if (root != i0 + k) S.label[base + i0 + k] = root;      // flatten: the pixels of this run reach the root (or CCL_BIG) in one hop;
+                                                            // roots stay roots, so concurrent finds through this node remain valid
+    if (root >= 0 && S.count[base + root] <= S.speckle_window) atomicAdd(&S.count[base + root], len[k]);
   }
 }
 // disparity in pixels; components of <= speckle_window pixels are filtered.  use_ccl == 0: plain conversion
@@ -374,7 +430,13 @@ __global__ __launch_bounds__(256) void stereo_finish_kernel(StereoDev S, int use
   if (i >= n) return;
   const size_t base = (size_t)blockIdx.y * n;
   int d = S.disp16[base + i];
-  if (use_ccl && d != FILTERED16) { const int l = S.label[base + i]; if (l != CCL_BIG && S.count[base + l] <= S.speckle_window) d = FILTERED16; }
+  if (use_ccl && d != FILTERED16) {
+    const int l = S.label[base + i];                     // start pixel of the pixel's run, or CCL_BIG
+    if (l >= 0) {
+      const int root = S.label[base + l];                // flattened by the count pass
+      if (root >= 0 && S.count[base + root] <= S.speckle_window) d = FILTERED16;
+    }
+  }
   out[(size_t)blockIdx.y * d_bstride + (size_t)(i / S.w) * dstride + (i % S.w)] = (float)d * (1.f / (1 << DISP_SHIFT));
 }
 
@@ -393,7 +455,7 @@ struct svs_stereo {
 extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out) {
   SVS_REQUIRE(ctx, ctx && prm && out && w > 0 && h > 0 && max_batch > 0);
   if (prm->sad_window != 7 || prm->min_disparity != 0 || prm->num_disparities != NDISP || prm->prefilter_cap < 1 || prm->prefilter_cap > 63 ||
-      w < NDISP + 2 * WSZ2 || w > 65535 || h < 2) {
+      w < NDISP + 2 * WSZ2 || w > 65535 || h < 2 || prm->speckle_window > 65535) {
     ctx->err = "svs_stereo: only SADWindowSize 7, minDisparity 0, numberOfDisparities 32, preFilterCap 1..63, w >= 38 are supported";
     return SVS_ERR_UNSUPPORTED;
   }
@@ -446,9 +508,12 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
   const dim3 gp(div_up(n, 256), n_batch);
   if (ccl) {
-    hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 3 * (size_t)w, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(stereo_ccl_merge_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(stereo_ccl_count_kernel, gp, dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * (2 * (size_t)w + 2 * (size_t)((w + 63) / 64)), ctx->stream, S);
+    SVS_LAUNCH_CHECK(ctx);
+    if (w % 4 == 0) hipLaunchKernelGGL(stereo_ccl_merge4_kernel, dim3(div_up(n, 1024), n_batch), dim3(256), 0, ctx->stream, S);
+    else hipLaunchKernelGGL(stereo_ccl_merge_kernel, gp, dim3(256), 0, ctx->stream, S);
+    SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(stereo_ccl_count_kernel, dim3(div_up(n, 2048), n_batch), dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
   }
   hipLaunchKernelGGL(stereo_finish_kernel, gp, dim3(256), 0, ctx->stream, S, ccl ? 1 : 0, d_disp, dstride, d_bstride);
   SVS_LAUNCH_CHECK(ctx);
