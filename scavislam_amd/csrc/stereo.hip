@@ -42,45 +42,41 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 }
 __device__ __forceinline__ int byte_of(uint32_t lo, uint32_t hi, int i) { return (int)((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4))) & 0xffu); }
 
-// 4 padded columns per thread.  grid: (ceil(pitch/256), h, 2*batch), block 64;  z = 2*b + (0 left | 1 right)
-__global__ __launch_bounds__(64) void stereo_prefilter_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
-                                                              const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
-  const int pc0 = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y, b = blockIdx.z >> 1, side = blockIdx.z & 1;
-  if (pc0 >= S.pitch) return;      // pitch is a multiple of 4
+// dword at byte position q of a row of w bytes, read from the clamped position and shifted into place: bytes that fall
+// outside the row come back as 0 (they only ever feed border columns, which are overwritten).  Branch-free on purpose:
+// a per-byte border path makes every wave that holds an edge lane walk it, with a wait behind each load.
+__device__ __forceinline__ uint32_t load_u32_clamped(const uint8_t *row, int q, int w) {
+  const int qs = min(max(q, 0), w - 4), d = q - qs;
+  const uint32_t raw = load_u32_unaligned(row + qs);
+  return d == 0 ? raw : (d >= 4 || d <= -4) ? 0u : d > 0 ? raw >> (8 * d) : raw << (-8 * d);
+}
+// 4 padded columns per thread, 4 rows per workgroup.  grid: (ceil(pitch/256), ceil(h/4), 2*batch), block (64, 4);
+// z = 2*b + (0 left | 1 right)
+__global__ __launch_bounds__(256) void stereo_prefilter_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
+                                                               const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
+  const int pc0 = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int w = S.w, h = S.h, cap = S.cap;
+  if (pc0 >= S.pitch || y >= h) return;      // pitch is a multiple of 4
   const uint8_t *src = side ? right + (size_t)b * r_bstride : left + (size_t)b * l_bstride;
   const int stride = side ? rstride : lstride;
-  const int w = S.w, h = S.h, cap = S.cap;
   const int x0 = pc0 - PADL;
-  uint32_t out = 0x01010101u * (uint32_t)(cap + 1);      // pads, border columns, odd last row
-  if (!((h & 1) && y == h - 1) && x0 + 3 >= 1 && x0 <= w - 2) {
+  const uint32_t fill = 0x01010101u * (uint32_t)(cap + 1);      // pads, border columns, odd last row
+  uint32_t out = fill;
+  if (!((h & 1) && y == h - 1)) {
     const int yp = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yn = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
     const uint8_t *r0 = src + (size_t)yp * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yn * stride;
-    if (x0 >= 1 && x0 + 4 <= w - 1) {      // all four interior: bytes x0-1 .. x0+4 are needed
-      uint32_t a0, a1, b0, b1, c0, c1;
-      a0 = load_u32_unaligned(r0 + x0 - 1); b0 = load_u32_unaligned(r1 + x0 - 1); c0 = load_u32_unaligned(r2 + x0 - 1);
-      if (x0 + 6 < w) {
-        a1 = load_u32_unaligned(r0 + x0 + 3); b1 = load_u32_unaligned(r1 + x0 + 3); c1 = load_u32_unaligned(r2 + x0 + 3);
-      } else {                              // end of the row: read only the two bytes that exist
-        a1 = (uint32_t)r0[x0 + 3] | ((uint32_t)r0[x0 + 4] << 8);
-        b1 = (uint32_t)r1[x0 + 3] | ((uint32_t)r1[x0 + 4] << 8);
-        c1 = (uint32_t)r2[x0 + 3] | ((uint32_t)r2[x0 + 4] << 8);
-      }
-      out = 0;
+    // bytes x0-1 .. x0+4 of the three rows (w >= 38, checked at create)
+    const uint32_t a0 = load_u32_clamped(r0, x0 - 1, w), a1 = load_u32_clamped(r0, x0 + 3, w);
+    const uint32_t b0 = load_u32_clamped(r1, x0 - 1, w), b1 = load_u32_clamped(r1, x0 + 3, w);
+    const uint32_t c0 = load_u32_clamped(r2, x0 - 1, w), c1 = load_u32_clamped(r2, x0 + 3, w);
+    out = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int v = (byte_of(a0, a1, j + 2) - byte_of(a0, a1, j)) + 2 * (byte_of(b0, b1, j + 2) - byte_of(b0, b1, j)) +
-                      (byte_of(c0, c1, j + 2) - byte_of(c0, c1, j));
-        out |= (uint32_t)(xsobel_tab(v, cap) + 1) << (8 * j);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int x = x0 + j;
-        if (x >= 1 && x <= w - 2) {
-          const int v = (r0[x + 1] - r0[x - 1]) + 2 * (r1[x + 1] - r1[x - 1]) + (r2[x + 1] - r2[x - 1]);
-          out = (out & ~(0xffu << (8 * j))) | ((uint32_t)(xsobel_tab(v, cap) + 1) << (8 * j));
-        }
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int x = x0 + j;
+      const int v = (byte_of(a0, a1, j + 2) - byte_of(a0, a1, j)) + 2 * (byte_of(b0, b1, j + 2) - byte_of(b0, b1, j)) +
+                    (byte_of(c0, c1, j + 2) - byte_of(c0, c1, j));
+      const uint32_t o = (x >= 1 && x <= w - 2) ? (uint32_t)(xsobel_tab(v, cap) + 1) : (uint32_t)(cap + 1);
+      out |= o << (8 * j);
     }
   }
   *reinterpret_cast<uint32_t *>((side ? S.rp : S.lp) + ((size_t)b * h + y) * S.pitch + pc0) = out;
@@ -492,8 +488,8 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   S.speckle_window = s->prm.speckle_window; S.speckle_range = s->prm.speckle_range; S.disp12 = s->prm.disp12_max_diff;
   S.lp = s->d_lp; S.rp = s->d_rp; S.disp16 = s->d_disp16; S.cost = s->d_cost; S.label = s->d_label; S.count = s->d_count;
   const int w = s->w, h = s->h, width1 = w - NDISP + 1, n = w * h;
-  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), h, 2 * n_batch), dim3(64), 0, ctx->stream, S, d_left, lstride, l_bstride,
-                     d_right, rstride, r_bstride);
+  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 4), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
+                     l_bstride, d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, 2), n_batch), dim3(64), 0, ctx->stream, S);
   SVS_LAUNCH_CHECK(ctx);
