@@ -303,7 +303,8 @@ constexpr int TRK_THREADS = SVS_TRK_THREADS;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
 template <bool JAC, bool U8SRC>
-__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut) {
+__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut,
+                                           int first, int nwg) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
@@ -311,18 +312,18 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
   // previous-frame intensities (independent of T) are loaded before this trip's arithmetic, so only the bilinear
   // taps -- whose addresses depend on the projection -- are exposed.  The grid position of the prefetched sample is
   // carried incrementally (one division per pass instead of one per sample: the pass is VALU-issue bound).
-  constexpr int STEP = TRK_UNROLL * TRK_THREADS;
+  const int STEP = TRK_UNROLL * TRK_THREADS * nwg;
   const int su = STEP % cw, sv = STEP / cw;
   SampleIn nxt[TRK_UNROLL];
   int pu[TRK_UNROLL], pv[TRK_UNROLL];
 #pragma unroll
   for (int q = 0; q < TRK_UNROLL; ++q) {
-    const int j = threadIdx.x + q * TRK_THREADS;
+    const int j = first + q * TRK_THREADS * nwg;
     pu[q] = j % cw; pv[q] = j / cw;
     const bool in = pv[q] < ch;
     nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
   }
-  for (int i = threadIdx.x; i < n; i += STEP) {
+  for (int i = first; i < n; i += STEP) {
     SampleIn cur[TRK_UNROLL];
 #pragma unroll
     for (int q = 0; q < TRK_UNROLL; ++q) {
@@ -333,18 +334,47 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
       nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
     }
 #pragma unroll
-    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS < n, a, ip_lut);
+    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
 }
 
-template <bool U8SRC>
-__global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out) {
+// MULTI: a few streams only (latency mode) -- gridDim.x workgroups share every sweep of one stream.  Each leaves its 29 partial
+// sums in global memory, a device-scope counter barrier (all workgroups of the launch are resident: NW * batch <= #CUs) lets
+// every workgroup add the partials up in the same fixed order, and each then runs the identical LM bookkeeping redundantly,
+// so no pose has to be broadcast.  Partials are double-buffered by pass parity: a workgroup can only overwrite a buffer after
+// everyone has passed the barrier of the pass in between, i.e. after everyone has read it.
+struct TrackMulti { double *part; unsigned *bar; };      // [batch][2][nwg][32], [batch] (zeroed before the launch)
+template <bool U8SRC, bool MULTI>
+__global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
   __shared__ float s_iplut[256];
-  const int slot = blockIdx.x;
+  const int slot = MULTI ? blockIdx.y : blockIdx.x, wg = MULTI ? blockIdx.x : 0, nwg = MULTI ? gridDim.x : 1;
+  const int first = wg * TRK_THREADS + threadIdx.x;
+  int sweep = 0;
+  auto all_workgroups = [&]() {      // s_out[0..NSUM] <- sum over the workgroups of this stream
+    if (!MULTI) return;
+    double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * nwg * 32;
+    if (threadIdx.x <= NSUM) buf[wg * 32 + threadIdx.x] = s_out[threadIdx.x];
+    __threadfence();
+    __syncthreads();
+    ++sweep;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(G.bar + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)sweep * (unsigned)nwg;
+      for (long spin = 0; spin < (1l << 26) && __hip_atomic_load(G.bar + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x <= NSUM) {
+      double acc = 0;
+      for (int w = 0; w < nwg; ++w) acc += buf[w * 32 + threadIdx.x];
+      s_out[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  };
   if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
   for (int i = threadIdx.x; i < 256; i += TRK_THREADS) s_iplut[i] = (float)((1. / 255.) * i);
   __syncthreads();
@@ -363,7 +393,8 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    all_workgroups();
     ++passes;
     float chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
@@ -385,7 +416,8 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut);        // new_chi2 (:335-367) + H,b for the next iteration
+      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);        // new_chi2 (:335-367) + H,b for the next iteration
+      all_workgroups();
       ++passes;
       const float new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
@@ -402,9 +434,10 @@ __global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackA
       }
     }
   }
+  __syncthreads();
+  if (wg != 0) return;
   if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];
   if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
-  __syncthreads();
   if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
 }
 
@@ -672,8 +705,25 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l]; A.c8_b[l] = a->c8_bstride[l];
   }
   A.T_jac = a->d_T_jac_out;
-  if (u8src) hipLaunchKernelGGL(dense_track_cpu_sem_kernel<true>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
-  else hipLaunchKernelGGL(dense_track_cpu_sem_kernel<false>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  // latency mode: with few streams, NW workgroups share each stream's sweeps (they must all be resident: NW * batch <= 128 CUs)
+  int nwg = batch <= 32 ? 4 : 1;      // measured (B = 1 / 8): 4 workgroups 0.26 ms / 19.4k fps, 8: 0.26 / 15.6k, 16: 0.28 / 10.4k, 1: 0.34 / 14.4k;
+                                      // 2 per stream at 64 streams lose to one (barrier + redundant LM tails)
+  if (const char *e = getenv("SVS_TRK_NWG")) nwg = std::max(1, atoi(e));
+  TrackMulti G{nullptr, nullptr};
+  if (nwg >= 2) {
+    double *scratch = nullptr;
+    const size_t n_part = (size_t)batch * 2 * nwg * 32;
+    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch);          // + one counter word (8 bytes) per stream
+    if (rc) return rc;
+    G.part = scratch;
+    G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
+    SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (size_t)batch, ctx->stream));
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  } else {
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  }
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
