@@ -426,3 +426,42 @@ def test_dense_tracking_rgbd_config_with_invalid_depth(gpu_ctx):
     T_true = synth.pose_mul(traj[1], synth.pose_inv(traj[0]))
     np.testing.assert_allclose(T_gpu[0], T_ref, rtol=0, atol=1e-4)
     assert np.abs(T_gpu[0][:, :3] - T_true[:, :3]).max() < 2e-3      # rotation recovered (the 3 cm translation is below what this scene constrains)
+
+
+def test_dense_tracking_multi_workgroup_variant(gpu_ctx, scene_frames, monkeypatch):
+    """Latency-mode tracker (<= 32 streams: 4 workgroups share every sweep of a stream, partial sums added in a fixed order
+    behind a device-scope barrier) against the one-workgroup-per-stream kernel on a small batch of DIFFERENT streams:
+    same passes, poses equal to 1e-9 (only the order of the f64 partial sums differs), per-level Jacobian poses too."""
+    import torch
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    ctx, stream = gpu_ctx
+    cam = scene_frames["cam"]
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8, step=0.04, yaw_deg=0.3)
+    B = 5
+    prev_f = [sc.render(cam, traj[i], seed=50 + i) for i in range(B)]
+    cur_f = [sc.render(cam, traj[i + 1], seed=60 + i) for i in range(B)]
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    prev.upload(np.stack([f[0] for f in prev_f]), np.stack([f[1] for f in prev_f]))
+    cur.upload(np.stack([f[0] for f in cur_f]), np.stack([f[1] for f in cur_f]))
+    prev.preprocessing(); cur.preprocessing()
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    out = {}
+    for nwg in ("1", "4"):
+        monkeypatch.setenv("SVS_TRK_NWG", nwg)
+        dt = DenseTracker(ctx, cur)
+        dt.ref_dense_points = dtp.ref_dense_points
+        T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+        out[nwg] = (T.copy(), passes.copy(), dt.d_T_jac.cpu().numpy().copy())
+    monkeypatch.delenv("SVS_TRK_NWG")
+    (T1, p1, j1), (T4, p4, j4) = out["1"], out["4"]
+    assert np.array_equal(p1, p4) and len(set(p1.tolist())) >= 1
+    np.testing.assert_allclose(T4, T1, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(j4, j1, rtol=0, atol=1e-9)
+    for b in range(B):                                       # every stream moved towards its own true motion
+        T_true = synth.pose_mul(traj[b + 1], synth.pose_inv(traj[b]))
+        assert np.abs(T4[b] - T_true).max() < 0.5 * np.abs(I - T_true).max()
