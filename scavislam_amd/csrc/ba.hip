@@ -197,11 +197,14 @@ struct BaDev {
 
 // MODE 0: accumulate reduced system + chi2 at the current state.
 // MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
+// NW waves (chunks) per workgroup: 4 by default; the host picks more when that brings the number of workgroups down to
+// one per CU (at 50 KF / 20k: 1 612 chunks -> 231 workgroups of 7 waves instead of 403 of 4 that load the CUs unevenly).
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(BaDev B) {
+  constexpr int NT = NW * 64;
   if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int chunk = blockIdx.x * NW + (threadIdx.x >> 6);
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
   const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
   const bool active = lane < len;
@@ -212,15 +215,15 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
   __shared__ double s_win[MODE == 0 ? WIN_BLOCKS * WBLK : 1];
   __shared__ double s_vec[MODE == 0 ? 2 * WIN * 6 : 1];
-  __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? 4 * 64 * 18 : 1];   // W_obs of every edge lane
+  __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? NW * 64 * 18 : 1];   // W_obs of every edge lane
   __shared__ int s_pmin;
   int pmin = 0;
   __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
   if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
   if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 16) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += 256) s_win[i] = 0.0;
-    for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) s_vec[i] = 0.0;
+    for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += NT) s_win[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * WIN * 6; i += NT) s_vec[i] = 0.0;
     if (threadIdx.x == 0) s_pmin = 0x7fffffff;
     __syncthreads();
     int mn = active ? min(ed.pose, ed.anchor) : 0x7fffffff;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
   SVS_STAMP(10);
   if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur, s_scal[0]);
   if (pmin != 0x7fffffff) {
-    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += 256) {
+    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += NT) {
       const int wb = i / 36, rc = i - wb * 36;
       const double v = s_win[wb * WBLK + rc];
       if (v != 0.0) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void ba_landmark_kernel(BaDev B) {
         if (pj < P) atomic_add_f64(&B.H[blk_index(pi, pj, P) * 36 + rc], v);
       }
     }
-    for (int i = threadIdx.x; i < 2 * WIN * 6; i += 256) {
+    for (int i = threadIdx.x; i < 2 * WIN * 6; i += NT) {
       const double v = s_vec[i];
       if (v != 0.0) {
         const int which = i / (WIN * 6), rest = i - which * WIN * 6, wp = rest / 6, r = rest - wp * 6;
@@ -2111,7 +2114,20 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   const char *dbg_env = getenv("SVS_BA_DEBUG");
   const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
   if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
-  if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<0>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.n_chunks > 0) {
+    // waves per workgroup: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
+    int nw = 4;
+    if (!getenv("SVS_BA_NW4")) for (int c = 5; c <= 8 && div_up(B.n_chunks, nw) > ctx->n_cu; ++c) if (div_up(B.n_chunks, c) <= ctx->n_cu) nw = c;
+    if (const char *e = getenv("SVS_BA_NW")) nw = atoi(e);
+    switch (nw) {
+      case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5>), dim3(div_up(B.n_chunks, 5)), dim3(320), 0, ctx->stream, B); break;
+      case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6>), dim3(div_up(B.n_chunks, 6)), dim3(384), 0, ctx->stream, B); break;
+      case 7: hipLaunchKernelGGL((ba_landmark_kernel<0, 7>), dim3(div_up(B.n_chunks, 7)), dim3(448), 0, ctx->stream, B); break;
+      case 8: hipLaunchKernelGGL((ba_landmark_kernel<0, 8>), dim3(div_up(B.n_chunks, 8)), dim3(512), 0, ctx->stream, B); break;
+      default: hipLaunchKernelGGL((ba_landmark_kernel<0, 4>), dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); break;
+    }
+    SVS_LAUNCH_CHECK(ctx);
+  }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
     std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
@@ -2182,7 +2198,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
   if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
-  if (B.n_chunks > 0) { hipLaunchKernelGGL(ba_landmark_kernel<1>, dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.n_chunks > 0) { hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
   if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   return SVS_OK;

@@ -10,6 +10,7 @@
 
 struct svs_ctx {
   int device = 0;
+  int n_cu = 256;                 // compute units of the device (MI355X: 256)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

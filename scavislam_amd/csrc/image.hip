@@ -12,6 +12,7 @@ extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
   svs_ctx *c = new svs_ctx();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return SVS_ERR_NO_DEVICE; }
+  { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu; }
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SVS_ERR_HIP; }
