@@ -2039,7 +2039,7 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
   const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 128 + (size_t)R * 6) +
                       sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
-  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD;
+  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD && !getenv("SVS_BA_NO_LDS_SOLVE");
   ba->lds_solve_smem = need;
   ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
   // two-front elimination (fused kernel only): front 1 takes the last P1 block rows in reversed order.  Balance: front 0

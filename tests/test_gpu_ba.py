@@ -246,3 +246,61 @@ def test_speculative_lm_equals_host_driven_lm(gpu_ctx, monkeypatch):
             assert _rel_update_err(pa, pb, prob["poses"]) < 1e-7 and _rel_update_err(sa, sb, prob["psi"]) < 1e-7
         else:
             assert np.array_equal(pa, pb) and np.array_equal(sa, sb)
+
+
+def _with_loop_closure(prob, i, j, rng):
+    """Adds a relative-pose constraint between the far-apart poses i < j (a loop-closure style edge, slam_graph.cpp:937-981
+    builds the same kind for outer-window poses): the block envelope of the reduced system then spans j - i + 1 rows."""
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import BA_CONSTRAINT_DTYPE
+    gt = prob["poses_gt"].reshape(-1, 3, 4)
+    T_ji = synth.pose_mul(gt[j], synth.pose_inv(gt[i]))
+    dn = np.concatenate([rng.normal(0, 0.005, 3), rng.normal(0, 0.002, 3)])
+    T_ji = synth.pose_mul(synth.pose(synth.so3_exp(dn[3:]), dn[:3]), T_ji)
+    Lam = np.eye(6) * 30.0
+    Lam[:3, :3] *= (350 * np.linalg.norm(T_ji[:, 3]) / 8.0) ** 2
+    Lam[3:, 3:] *= 100.0 ** 2
+    c = np.zeros(1, BA_CONSTRAINT_DTYPE)
+    c[0]["T_21"], c[0]["info"], c[0]["pose1"], c[0]["pose2"] = T_ji.reshape(12), Lam.reshape(36), i, j
+    return dict(prob, cons=np.concatenate([prob["cons"], c]))
+
+
+@pytest.mark.parametrize("case", ["fused_two_fronts", "fused_one_front", "lds_forced", "global_forced", "lds_wide_envelope",
+                                  "global_wide_envelope"])
+def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
+    """The reduced camera system is solved by one of three kernels depending on the width of its block envelope: the fused
+    register-resident elimination (<= 10 block rows; two fronts when the window is long enough), the LDS-window pipeline
+    (<= 28), the global-memory blocked Cholesky (anything).  Each must give the oracle's update to 1e-6."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    rng = np.random.default_rng(3)
+    for k in ("SVS_BA_ONE_FRONT", "SVS_BA_NO_FUSED_SOLVE", "SVS_BA_NO_LDS_SOLVE"):
+        monkeypatch.delenv(k, raising=False)
+    P = 40
+    prob = synth.ba_window(P, 4000, seed=11, n_outer=2)
+    if case == "fused_one_front":
+        monkeypatch.setenv("SVS_BA_ONE_FRONT", "1")
+    elif case == "lds_forced":
+        monkeypatch.setenv("SVS_BA_NO_FUSED_SOLVE", "1")
+    elif case == "global_forced":
+        monkeypatch.setenv("SVS_BA_NO_LDS_SOLVE", "1")
+    elif case == "lds_wide_envelope":
+        prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows
+    elif case == "global_wide_envelope":
+        prob = _with_loop_closure(prob, 0, P - 1, rng)       # full envelope: 40 block rows
+    cam = _cam(prob["cam"])
+    prm = BaParams.reference_defaults()
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
+    assert st_ref.accepted >= 1
+    np.testing.assert_allclose(st.chi2_final, st_ref.chi2_final, rtol=1e-8)      # wide envelopes: longer elimination chains
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
+    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    opt.close()
