@@ -465,3 +465,28 @@ def test_dense_tracking_multi_workgroup_variant(gpu_ctx, scene_frames, monkeypat
     for b in range(B):                                       # every stream moved towards its own true motion
         T_true = synth.pose_mul(traj[b + 1], synth.pose_inv(traj[b]))
         assert np.abs(T4[b] - T_true).max() < 0.5 * np.abs(I - T_true).max()
+
+
+def test_fastgrid_large_frame_two_sweep_compaction(gpu_ctx):
+    """A 2560x1440 frame: level-0 cells are 853x480 pixels, so the per-cell corner masks no longer fit the one-sweep
+    compaction's LDS budget and the two-sweep kernel emits the corners; lists stay bit-exact (order included)."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FastGrid
+    ctx, stream = gpu_ctx
+    w, h = 2560, 1440
+    cam = dict(synth.CAM_DEFAULT, w=w, h=h, cx=w / 2, cy=h / 2)
+    imgs = [synth.noise_image(w, h, 900 + i) for i in range(2)]
+    fr = _frame(ctx, stream, cam, [imgs[0]], with_float=False)
+    fg = FastGrid(ctx, fr, corner_cap=60000)
+    grids = [O.fastgrid_for_level(fr.w[l], fr.h[l], l) for l in range(3)]
+    for i in range(2):
+        fr.upload(imgs[i][None])
+        fr.preprocessing()
+        fg.detectAdaptively(trials=6)
+        pyr = O.build_pyramid(imgs[i])
+        for l in range(3):
+            xy_ref, cc_ref, et_ref = O.fastgrid_detect_adaptively(grids[l], pyr[l], 6)
+            xy, cc, et, ts = fg.corners(0, l)
+            assert np.array_equal(cc, cc_ref) and np.array_equal(et, et_ref), (i, l)
+            assert np.array_equal(xy, xy_ref), (i, l)
