@@ -26,6 +26,29 @@ from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, GATED_POINT_DTYPE,
 NUM_PYR_LEVELS = 3  # global.h:107
 
 
+def _pose_mul(A, B):
+    """3x4 pose product with the operation order of the C code on both sides of the boundary ((a0 b0 + a1 b1) + a2 b2,
+    then + t; no BLAS, no FMA): the matcher's truncating warp makes the last bit of the pose visible once in ~10^3 points."""
+    A, B = [float(v) for v in np.asarray(A, np.float64).reshape(12)], [float(v) for v in np.asarray(B, np.float64).reshape(12)]
+    out = [0.0] * 12
+    for i in range(3):
+        for j in range(4):
+            out[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j]
+        out[4 * i + 3] += A[4 * i + 3]
+    return np.array(out)
+
+
+def _pose_inv(A):
+    A = [float(v) for v in np.asarray(A, np.float64).reshape(12)]
+    out = [0.0] * 12
+    for i in range(3):
+        for j in range(3):
+            out[4 * i + j] = A[4 * j + i]
+    for i in range(3):
+        out[4 * i + 3] = -(out[4 * i] * A[3] + out[4 * i + 1] * A[7] + out[4 * i + 2] * A[11])
+    return np.array(out)
+
+
 def _round_up(a, b):
     return (a + b - 1) // b * b
 
@@ -201,9 +224,8 @@ class GuidedMatcher:
         T_cur_from_w = np.zeros((B, 12))
         T_w_from_actkey = np.zeros((B, 12))
         for b in range(B):  # two 3x4 pose products per frame: host bookkeeping (matcher.cpp:326-330)
-            A, Bm = Tc[b].reshape(3, 4), Ta[b].reshape(3, 4)
-            T_cur_from_w[b, :] = np.hstack([A[:, :3] @ Bm[:, :3], (A[:, :3] @ Bm[:, 3] + A[:, 3])[:, None]]).reshape(12)
-            T_w_from_actkey[b, :] = np.hstack([Bm[:, :3].T, (-Bm[:, :3].T @ Bm[:, 3])[:, None]]).reshape(12)
+            T_cur_from_w[b, :] = _pose_mul(Tc[b], Ta[b])
+            T_w_from_actkey[b, :] = _pose_inv(Ta[b])
         with torch.cuda.stream(fr.stream):
             d_kfs = torch.as_tensor(kfs.view(np.uint8)).to(dev)
             d_pts = torch.as_tensor(pts.view(np.uint8).reshape(-1)).to(dev)

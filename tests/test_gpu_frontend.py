@@ -490,3 +490,66 @@ def test_fastgrid_large_frame_two_sweep_compaction(gpu_ctx):
             xy, cc, et, ts = fg.corners(0, l)
             assert np.array_equal(cc, cc_ref) and np.array_equal(et, et_ref), (i, l)
             assert np.array_equal(xy, xy_ref), (i, l)
+
+
+def test_matcher_two_keyframes_two_streams(gpu_ctx, scene_frames):
+    """Candidate points anchored in two different keyframes (keyframe_map lookup by anchor id, matcher.cpp:326-345), the
+    active keyframe being the second one, for a batch of two current frames with different pose guesses: every record of
+    both streams bit-exact against the oracle."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import FastGrid, FramePyramid, GuidedMatcher
+    ctx, stream = gpu_ctx
+    cam = scene_frames["cam"]
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8)
+    k0, k1, c0, c1 = 0, 2, 5, 6
+    img_k0, disp_k0 = sc.render(cam, traj[k0], seed=k0)
+    img_k1, disp_k1 = sc.render(cam, traj[k1], seed=k1)
+    curs = [sc.render(cam, traj[i], seed=i) for i in (c0, c1)]
+    fr = _frame(ctx, stream, cam, [c[0] for c in curs], [c[1] for c in curs])
+    fg = FastGrid(ctx, fr)
+    for _ in range(2):
+        fg.detectAdaptively(trials=6)
+    kfs = []
+    for img in (img_k0, img_k1):
+        kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
+        kf.upload(img[None])
+        kf.preprocessing()
+        kfs.append(kf)
+    rng = np.random.default_rng(21)
+    pts = np.concatenate([synth.candidate_points(rng, cam, disp_k0, traj[k0], (200, 100, 40), kf_index=0),
+                          synth.candidate_points(rng, cam, disp_k1, traj[k1], (200, 100, 40), kf_index=1)])
+    pts["point_id"] = np.arange(len(pts))
+    rng.shuffle(pts)
+    T_act = traj[k1]                                                     # active keyframe = keyframe 1
+    T_guess = []
+    for i, ci in enumerate((c0, c1)):
+        T = synth.pose_mul(traj[ci], synth.pose_inv(T_act))
+        T[:, 3] += np.array([0.003, -0.002, 0.004]) * (i + 1)
+        T_guess.append(T)
+    gm = GuidedMatcher(ctx, fr, fg)
+    res = gm.match([(kfs[0].pyr, 0, traj[k0].reshape(12)), (kfs[1].pyr, 0, traj[k1].reshape(12))],
+                   np.stack([T.reshape(12) for T in T_guess]), T_act.reshape(12), pts)
+    pyr_k = [O.build_pyramid(img_k0), O.build_pyramid(img_k1)]
+    n_ok = 0
+    for s in range(2):
+        pyr_c = O.build_pyramid(curs[s][0])
+        trees = []
+        for l in range(3):
+            xy, cc, et, ts = fg.corners(s, l)
+            trees.append(O.quadtree_from_corners(xy, cc, pyr_c[l].shape[1], pyr_c[l].shape[0]))
+        ref = O.match(pyr_k, [traj[k0].reshape(12), traj[k1].reshape(12)], T_guess[s], T_act, pyr_c, curs[s][1], trees, fr.cams, pts)
+        for k in ("status", "znssd"):
+            bad = np.nonzero(res[s][k] != ref[k])[0]
+            assert bad.size == 0, (s, k, bad[:8], res[s][k][bad[:8]], ref[k][bad[:8]], pts["kf_index"][bad[:8]], pts["anchor_level"][bad[:8]],
+                                   res[s]["u"][bad[:8]], ref["u"][bad[:8]], res[s]["v"][bad[:8]], ref["v"][bad[:8]])
+        found = (ref["status"] == 0) | (ref["status"] == 6)
+        assert np.array_equal(res[s]["u"][found], ref["u"][found]) and np.array_equal(res[s]["v"][found], ref["v"][found])
+        ok = ref["status"] == 0
+        assert np.array_equal(res[s]["obs"][ok], ref["obs"][ok])
+        np.testing.assert_allclose(res[s]["xyz_actkey"][found], ref["xyz_actkey"][found], rtol=1e-12, atol=1e-12)
+        for kfi in (0, 1):
+            assert (ok & (pts["kf_index"] == kfi)).sum() > 20, (s, kfi)
+        n_ok += ok.sum()
+    assert n_ok > 200
