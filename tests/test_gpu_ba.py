@@ -304,3 +304,55 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
     assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
     opt.close()
+
+
+def test_landmarks_with_64_observations(gpu_ctx):
+    """Landmarks seen by 64 keyframes (the supported maximum: one landmark fills a whole wave chunk, 32 circulant pair rounds)
+    next to ordinary ones; anchors in the middle of their runs as well as at the start.  The reduced system spans 64 block
+    rows, so this also runs the global-memory solve on a real (not forced) wide envelope.  65 observations are refused."""
+    import oracle as O
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BA_EDGE_DTYPE, BaParams
+    ctx, stream = gpu_ctx
+    P = 70
+    prob = synth.ba_window(P, 600, seed=31, n_outer=0)
+    c = prob["cam"]
+    gt = prob["poses_gt"].reshape(-1, 3, 4)
+    rng = np.random.default_rng(9)
+    e = prob["edges"]
+    extra = []
+    for l, (first, anchor) in zip((5, 77, 300), ((0, 0), (3, 40), (6, 69))):        # runs [first, first + 64), anchor inside
+        e = e[e["point"] != l]
+        pg = prob["psi_gt"][l]
+        xa = np.array([pg[0] / pg[2], pg[1] / pg[2], 1.0 / pg[2]])
+        Tw = synth.pose_inv(gt[anchor])
+        xw = Tw[:, :3] @ xa + Tw[:, 3]
+        for i in range(first, first + 64):
+            y = gt[i][:, :3] @ xw + gt[i][:, 3]
+            obs = np.array([c["f"] * y[0] / y[2] + c["cx"], c["f"] * y[1] / y[2] + c["cy"], c["f"] * (y[0] - c["b"]) / y[2] + c["cx"]])
+            rec = np.zeros(1, BA_EDGE_DTYPE)
+            rec["obs"], rec["info"], rec["point"], rec["pose"], rec["anchor"] = obs + rng.normal(0, 0.5, 3), (1.0, 1.0, 0.333 ** 2), l, i, anchor
+            extra.append(rec)
+    edges = np.concatenate([e] + extra)
+    rng.shuffle(edges)                                                               # the reference iterates hash sets: any input order
+    assert np.bincount(edges["point"]).max() == 64
+    cam = _cam(c)
+    prm = BaParams.reference_defaults()
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], edges, prob["cons"], cam, prm)
+    H, b, chi2 = opt.reduced_system(50.0)
+    H_ref, b_ref = O.ba_reduced_system(prob["poses"], prob["psi"], edges, prob["cons"], cam, prm, 50.0)
+    np.testing.assert_allclose(H, H_ref, rtol=0, atol=1e-10 * np.abs(H_ref).max())
+    np.testing.assert_allclose(b, b_ref, rtol=0, atol=1e-10 * np.abs(b_ref).max())
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], edges, prob["cons"], cam, prm)
+    assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
+    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    one_more = edges[edges["point"] == 5][:1].copy()
+    one_more["pose"] = 64
+    with pytest.raises(capi.SvsError, match="status 5"):
+        opt.copyDataToG2o(prob["poses"], prob["psi"], np.concatenate([edges, one_more]), prob["cons"], cam, prm)
+    opt.close()
