@@ -356,3 +356,28 @@ def test_landmarks_with_64_observations(gpu_ctx):
     with pytest.raises(capi.SvsError, match="status 5"):
         opt.copyDataToG2o(prob["poses"], prob["psi"], np.concatenate([edges, one_more]), prob["cons"], cam, prm)
     opt.close()
+
+
+def test_largest_supported_window_256_poses(gpu_ctx):
+    """P = 256 keyframes (the documented maximum of the single-workgroup solves): long two-front elimination
+    (front 1 takes ~120 block rows), everything else as usual; 257 poses are refused with SVS_ERR_UNSUPPORTED."""
+    import oracle as O
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prob = synth.ba_window(256, 6000, seed=77, n_outer=3)
+    cam = _cam(prob["cam"])
+    prm = BaParams.reference_defaults()
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
+    assert st_ref.accepted >= 1
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
+    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    with pytest.raises(capi.SvsError, match="status 5"):
+        opt.copyDataToG2o(np.tile(prob["poses"][:1], (257, 1)), prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    opt.close()
