@@ -338,7 +338,7 @@ def main():
                 # HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the
                 # gfx950 note in MI355X_MICROARCH.md), measured on this kernel at this size in profiles/r1_summary.md;
                 # it cannot be collected inside this process, so it is only reported for the profiled configuration
-                "traffic": 17221600 if (world == 1 and E_local == 99587) else None,
+                "traffic": 14113400 if (world == 1 and E_local == 99587) else None,
                 "traffic_source": "profiles/r1_summary.md section 3 (2*FETCH_SIZE + WRITE_SIZE)"}
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
