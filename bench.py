@@ -344,7 +344,7 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
     cpu = None
     cpu_schur_ms = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the contract: rank 0 at N=1 only
         import oracle as O
         grids = [O.fastgrid_for_level(cur.w[l], cur.h[l], l) for l in range(3)]
         # state the reference also carries over from the previous frame (not timed)
