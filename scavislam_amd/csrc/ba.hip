@@ -1693,7 +1693,7 @@ struct svs_ba {
   double *d_pattern = nullptr;          // [P*P] structural indicator (all-reduced in sharded runs)
   std::vector<double> h_pattern;
   // persistent host work arrays / pinned staging of set_problem, device capacities (grow-only)
-  std::vector<int> w_anchor, w_nobs, w_pos, w_off, w_aoff, w_alist, w_order, w_fill, w_cs, w_cl;
+  std::vector<int> w_anchor, w_nobs, w_pos, w_off, w_aoff, w_alist, w_order, w_cs, w_cl;
   std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
   std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
   HostPool *pool = nullptr;                    // marshalling workers (created on first use, SVS_HOST_THREADS overrides the count)
