@@ -38,7 +38,14 @@ struct FastParams {
   unsigned *hist;         // [batch][ncell_total][256]
   int *thr, *emit, *count, *offset;   // [batch][ncell_total]
   int *level_total;       // [batch][n_levels]
+  // corner candidates (score >= t_lo) of every tile, written by the score kernel: the compaction sorts these few records
+  // instead of sweeping the score map again.  cand [batch][n_tiles][CAND_CAP] = score8 << 24 | cell-local y << 12 | x
+  uint32_t *cand; int *cand_n;      // cand_n [batch][n_tiles] (may exceed CAND_CAP: then the cell falls back to the sweep)
+  int *cell_tile0, *cell_ntile;     // [ncell_total]: tiles of a cell are contiguous in the tile list
+  int n_tiles;
 };
+constexpr int CAND_CAP = 512;       // per 64x32 tile (2048 pixels)
+constexpr int CAND_CELL_CAP = 4096; // sorted in LDS per cell
 struct ImgPtrs {
   const uint8_t *img[SVS_NUM_PYR_LEVELS];
   int stride[SVS_NUM_PYR_LEVELS];
@@ -185,6 +192,14 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I
     atomicAdd(&s_hist[s8], 1u);
   }
   __syncthreads();
+  {
+    uint32_t *cand = P.cand + ((size_t)slot * P.n_tiles + blockIdx.x) * CAND_CAP;
+    for (int i = tid; i < min(ncorn, CAND_CAP); i += 256) {
+      const int code = s_list[i], py = code >> 8, px = code & 0xff;
+      cand[i] = ((uint32_t)reinterpret_cast<const uint8_t *>(s_sc)[py * 64 + px] << 24) | ((uint32_t)(td.y0 + py) << 12) | (uint32_t)(td.x0 + px);
+    }
+    if (tid == 0) P.cand_n[(size_t)slot * P.n_tiles + blockIdx.x] = ncorn;
+  }
   for (int ty = tid >> 4; ty < TH; ty += 16) {
     const int cy = td.y0 + ty;
     if (cy < L.cell_h && cx0 < L.cell_w) {
@@ -269,7 +284,8 @@ __global__ __launch_bounds__(256) void fast_adapt_kernel(FastParams P, int trial
 
 // K3: ordered compaction of one cell.  Sweep 1 counts per ROI row (one wave per row), an LDS scan
 // turns counts into offsets, sweep 2 writes (x,y) with a ballot prefix.
-__global__ __launch_bounds__(256) void fast_compact_2sweep_kernel(FastParams P) {
+__global__ __launch_bounds__(256) void fast_compact_2sweep_kernel(FastParams P, const int *__restrict__ ovf) {
+  if (ovf && !ovf[(size_t)blockIdx.y * P.ncell_total + blockIdx.x]) return;      // done by fast_compact_list_kernel
   __shared__ int s_row[1024];
   const int slot = blockIdx.y;
   int c = blockIdx.x, lvl = 0;
@@ -336,7 +352,8 @@ constexpr int CMP_MAXROWS = 1024;
 // CMP_WAVES waves per cell: the sweep is a chain of global round trips per wave, so 16 waves (fewer trips each) win when
 // few cells are in flight (latency mode), 4 waves when the batch fills the device anyway.
 template <int CMP_WAVES>
-__global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams P) {
+__global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams P, const int *__restrict__ ovf) {
+  if (ovf && !ovf[(size_t)blockIdx.y * P.ncell_total + blockIdx.x]) return;      // done by fast_compact_list_kernel
   extern __shared__ unsigned long long s_mask[];      // [rows][chunks][4]
   __shared__ int s_row[CMP_MAXROWS];
   const int slot = blockIdx.y;
@@ -436,6 +453,83 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams
   }
 }
 
+// K3 from the candidate lists: the cell's candidates at or above its emit threshold are collected in LDS (one wave per
+// tile list, 16 waves), ordered by (y, x) -- the row-major order of the reference -- and written out.  Up to 1024 corners
+// are ordered by counting ("my rank = number of smaller keys": n broadcast LDS reads per lane, no barrier), more by a
+// bitonic network.  A cell whose tiles or whose own list overflowed is left to the sweep kernels (ovf[cell] = 1).
+// grid: (ncell_total, batch), block 256 or 1024.
+constexpr int LST_MAXTILES = 1024;
+template <int LST_THREADS>      // 1024 when few cells are in flight (latency mode), 256 when the batch fills the device
+__global__ __launch_bounds__(LST_THREADS) void fast_compact_list_kernel(FastParams P, int *__restrict__ ovf) {
+  __shared__ uint32_t s_key[CAND_CELL_CAP];
+  __shared__ int s_tn[LST_MAXTILES];
+  __shared__ int s_n, s_ovf;
+  const int slot = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lvl = 0;
+  while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
+  const LevelDev &L = P.lv[lvl];
+  const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
+  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
+  const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
+  const int base = P.offset[(size_t)slot * P.ncell_total + c];
+  const int t0 = P.cell_tile0[c], nt = P.cell_ntile[c];
+  if (tid == 0) { s_n = 0; s_ovf = nt > LST_MAXTILES ? 1 : 0; }
+  for (int t = tid; t < min(nt, LST_MAXTILES); t += LST_THREADS) s_tn[t] = P.cand_n[(size_t)slot * P.n_tiles + t0 + t];
+  __syncthreads();
+  if (thr1 <= 255 && !s_ovf)
+    for (int t = wave; t < nt; t += LST_THREADS / 64) {
+      const int n = s_tn[t];
+      if (n > CAND_CAP) { if (lane == 0) s_ovf = 1; continue; }
+      const uint32_t *cand = P.cand + ((size_t)slot * P.n_tiles + t0 + t) * CAND_CAP;
+      for (int i = lane; i < n; i += 64) {
+        const uint32_t r = cand[i];
+        if ((int)(r >> 24) >= thr1) {
+          const int k = atomicAdd(&s_n, 1);
+          if (k < CAND_CELL_CAP) s_key[k] = ((r >> 12) & 0xfffu) << 16 | (r & 0xfffu);
+        }
+      }
+    }
+  __syncthreads();
+  const int n = s_n;
+  const bool over = s_ovf != 0 || n > CAND_CELL_CAP;
+  if (tid == 0) ovf[(size_t)slot * P.ncell_total + c] = over ? 1 : 0;
+  if (over || n == 0) return;
+  int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
+  auto emit = [&](int rank, uint32_t key) {
+    const int pos = base + rank;
+    if (pos < P.cap) {
+      const uint32_t pk = (uint32_t)(uint16_t)(u0 + (int)(key & 0xffffu)) | ((uint32_t)(uint16_t)(v0 + (int)(key >> 16)) << 16);
+      __builtin_memcpy(xy + 2 * pos, &pk, 4);
+    }
+  };
+  if (n <= 1024) {
+    for (int i = tid; i < n; i += LST_THREADS) {
+      const uint32_t key = s_key[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += s_key[j] < key;      // keys are distinct pixel positions
+      emit(rank, key);
+    }
+    return;
+  }
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = n + tid; i < m; i += LST_THREADS) s_key[i] = 0xffffffffu;
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += LST_THREADS) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t a = s_key[i], b = s_key[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { s_key[i] = b; s_key[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += LST_THREADS) emit(i, s_key[i]);
+}
+
 }  // namespace
 
 struct svs_fast {
@@ -444,6 +538,8 @@ struct svs_fast {
   int batch;
   TileDesc *d_tiles; int n_tiles;
   std::vector<int> t_lo_src;
+  int *d_ovf = nullptr;       // [batch][ncell_total] cells the list compaction left to the sweep
+  bool use_lists = false;
 };
 
 extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
@@ -455,6 +551,8 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
   P = FastParams{};
   P.n_levels = n_levels; P.cap = cap;
   std::vector<TileDesc> tiles;
+  std::vector<int> cell_tile0, cell_ntile;
+  bool lists_ok = true;
   int cell_base = 0, t_lo = 255;
   for (int l = 0; l < n_levels; ++l) {
     const svs_fastgrid &g = grids[l];
@@ -471,9 +569,12 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
     SVS_HIP(ctx, hipMalloc(&L.xy, sizeof(int16_t) * 2 * (size_t)cap * batch));
     for (int c = 0; c < g.gx * g.gy; ++c) {
       t_lo = std::min(t_lo, std::min(g.fast_min, g.thr[c]));
+      cell_tile0.push_back((int)tiles.size());
       for (int y0 = 0; y0 < g.cell_h; y0 += TH)
         for (int x0 = 0; x0 < g.cell_w; x0 += TW) tiles.push_back(TileDesc{(int16_t)l, (int16_t)c, (int16_t)x0, (int16_t)y0});
+      cell_ntile.push_back((int)tiles.size() - cell_tile0.back());
     }
+    lists_ok = lists_ok && g.cell_w <= 4096 && g.cell_h <= 4096;
     cell_base += g.gx * g.gy;
   }
   P.ncell_total = cell_base;
@@ -497,6 +598,15 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
       for (int c = 0; c < grids[l].gx * grids[l].gy; ++c) thr0[(size_t)b * P.ncell_total + P.lv[l].cell_base + c] = grids[l].thr[c];
   SVS_HIP(ctx, hipMemcpyAsync(P.thr, thr0.data(), nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   f->n_tiles = (int)tiles.size();
+  P.n_tiles = f->n_tiles;
+  f->use_lists = lists_ok;
+  SVS_HIP(ctx, hipMalloc(&P.cand, sizeof(uint32_t) * (size_t)batch * tiles.size() * CAND_CAP));
+  SVS_HIP(ctx, hipMalloc(&P.cand_n, sizeof(int) * (size_t)batch * tiles.size()));
+  SVS_HIP(ctx, hipMalloc(&P.cell_tile0, sizeof(int) * cell_tile0.size()));
+  SVS_HIP(ctx, hipMalloc(&P.cell_ntile, sizeof(int) * cell_ntile.size()));
+  SVS_HIP(ctx, hipMalloc(&f->d_ovf, sizeof(int) * nc));
+  SVS_HIP(ctx, hipMemcpyAsync(P.cell_tile0, cell_tile0.data(), sizeof(int) * cell_tile0.size(), hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(P.cell_ntile, cell_ntile.data(), sizeof(int) * cell_ntile.size(), hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMalloc(&f->d_tiles, sizeof(TileDesc) * tiles.size()));
   SVS_HIP(ctx, hipMemcpyAsync(f->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -510,6 +620,7 @@ extern "C" int svs_fast_destroy(svs_fast *f) {
   for (int l = 0; l < f->P.n_levels; ++l) { hipFree(f->P.lv[l].score); hipFree(f->P.lv[l].xy); }
   hipFree(f->P.hist); hipFree(f->P.thr); hipFree(f->P.emit); hipFree(f->P.count); hipFree(f->P.offset);
   hipFree(f->P.level_total); hipFree(f->d_tiles);
+  hipFree(f->P.cand); hipFree(f->P.cand_n); hipFree(f->P.cell_tile0); hipFree(f->P.cell_ntile); hipFree(f->d_ovf);
   delete f;
   return SVS_OK;
 }
@@ -530,15 +641,24 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
     const LevelDev &L = f->P.lv[l];
     mask_bytes = std::max(mask_bytes, (size_t)std::max(L.cell_h - 6, 0) * (size_t)((std::max(L.cell_w - 6, 1) + 255) / 256) * 32);
   }
+  // compaction from the score kernel's candidate lists; cells whose lists overflowed (and everything, if the lists are
+  // switched off) go through the score-map sweep
+  const int *ovf = nullptr;
+  if (f->use_lists && !getenv("SVS_FAST_NO_LISTS")) {
+    if ((long)f->P.ncell_total * n_batch <= 1024) hipLaunchKernelGGL(fast_compact_list_kernel<1024>, dim3(f->P.ncell_total, n_batch), dim3(1024), 0, ctx->stream, f->P, f->d_ovf);
+    else hipLaunchKernelGGL(fast_compact_list_kernel<256>, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P, f->d_ovf);
+    SVS_LAUNCH_CHECK(ctx);
+    ovf = f->d_ovf;
+  }
   if (mask_bytes <= 56 * 1024)
   {
     if ((long)f->P.ncell_total * n_batch <= 1024 || getenv("SVS_FAST_CMP16"))
-      hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P);
+      hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P, ovf);
     else
-      hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P);
+      hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P, ovf);
   }
   else
-    hipLaunchKernelGGL(fast_compact_2sweep_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P);
+    hipLaunchKernelGGL(fast_compact_2sweep_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P, ovf);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
