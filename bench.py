@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="independent camera streams per rank per step")
+    ap.add_argument("--batch", type=int, default=512, help="independent camera streams per rank per step")
     ap.add_argument("--points", type=int, default=2000, help="candidate points per frame (SURVEY 8d config 2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -234,7 +234,7 @@ def main():
     del fe1
     # batched modes in between (B in {1, 8, 64}): same step, B independent streams per launch
     batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
-    for Bs in (8, 64):
+    for Bs in (8, 64, 256):
         if Bs >= B:
             continue
         fes = build_frontend(Bs)

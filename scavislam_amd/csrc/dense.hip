@@ -345,8 +345,11 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 // so no pose has to be broadcast.  Partials are double-buffered by pass parity: a workgroup can only overwrite a buffer after
 // everyone has passed the barrier of the pass in between, i.e. after everyone has read it.
 struct TrackMulti { double *part; unsigned *bar; };      // [batch][2][nwg][32], [batch] (zeroed before the launch)
-template <bool U8SRC, bool MULTI>
-__global__ __launch_bounds__(TRK_THREADS) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
+// MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
+// workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
+// bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
+template <bool U8SRC, bool MULTI, int MINW>
+__global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
@@ -718,11 +721,14 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     G.part = scratch;
     G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
     SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (size_t)batch, ctx->stream));
-    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  } else if ((batch > ctx->n_cu && !getenv("SVS_TRK_ONE_PER_CU")) || getenv("SVS_TRK_TWO_PER_CU")) {      // env: tests / experiments
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else {
-    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   }
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
