@@ -193,7 +193,159 @@ struct BaDev {
   int robust, self_mode;
   long long *dbg;                       // SVS_BA_DEBUG=2: per-wave phase stamps (100 MHz ticks), DBG_N per chunk
   double *ctl;                          // device-side LM control (speculative trials): [0] lambda, [1] abort flag, [8 + 8 it ..] trial records
+  int fuse_cons;                        // constraints ride in extra workgroups of the landmark kernels
 };
+
+// ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
+__device__ void d_so3_log(const double *R, double *w, double &theta) {
+  double q[4];
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { double s = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s; }
+  else { double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s; }
+  const double n = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), ww = q[0];
+  double two_atan;
+  if (n < 1e-10) two_atan = 2.0 / ww - 2.0 * (n * n) / (ww * ww * ww);
+  else if (fabs(ww) < 1e-10) two_atan = (ww > 0 ? M_PI : -M_PI) / n;
+  else two_atan = 2.0 * atan(n / ww) / n;
+  w[0] = two_atan * q[1]; w[1] = two_atan * q[2]; w[2] = two_atan * q[3];
+  theta = two_atan * n;
+}
+__device__ void d_pose_mul(const double *A, const double *Bm, double *Cm) {
+  double t[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) t[4 * i + j] = A[4 * i] * Bm[j] + A[4 * i + 1] * Bm[4 + j] + A[4 * i + 2] * Bm[8 + j];
+    t[4 * i + 3] += A[4 * i + 3];
+  }
+  for (int i = 0; i < 12; ++i) Cm[i] = t[i];
+}
+__device__ void d_pose_inv(const double *A, double *Bm) {
+  double t[12];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[4 * i + j] = A[4 * j + i];
+  for (int i = 0; i < 3; ++i) t[4 * i + 3] = -(t[4 * i] * A[3] + t[4 * i + 1] * A[7] + t[4 * i + 2] * A[11]);
+  for (int i = 0; i < 12; ++i) Bm[i] = t[i];
+}
+__device__ void d_se3_log(const double *T, double *x) {
+  double R[9], W[9], W2[9], Vi[9], th;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T[4 * i + j];
+  d_so3_log(R, x + 3, th);
+  const double *w = x + 3;
+  W[0] = 0; W[1] = -w[2]; W[2] = w[1]; W[3] = w[2]; W[4] = 0; W[5] = -w[0]; W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  const double c = fabs(th) < 1e-10 ? 1.0 / 12.0 : (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
+  for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * W[i] + c * W2[i];
+  Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
+  for (int i = 0; i < 3; ++i) x[i] = Vi[3 * i] * T[3] + Vi[3 * i + 1] * T[7] + Vi[3 * i + 2] * T[11];
+}
+// One wavefront per constraint; lane (i,j) = element of the 6x6 products, operands staged in LDS.
+// (A one-thread-per-constraint version spent 60 us in scratch-spilled serial 6x6x6 products.)
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+
+// one wave per constraint (lanes 0..63 of the calling workgroup); s_m: 8 x 36 doubles of LDS
+// 0 Adj(T21) 1 dl(e) 2 t1 3 J1 4 dl(-e) 5 J2 6 O*J1 7 O*J2
+template <int MODE>
+__device__ __forceinline__ void ba_constraint_body(const BaDev &B, int c, double (*s_m)[36]) {
+  const int lane = threadIdx.x;
+  const svs_ba_constraint &cc = B.cons[c];
+  const double *poses = MODE == 0 ? B.poses : B.poses_trial;
+  double T2i[12], t[12], err[6];
+  d_pose_inv(poses + 12 * cc.pose2, T2i);
+  d_pose_mul(cc.T_21, poses + 12 * cc.pose1, t);
+  d_pose_mul(t, T2i, t);
+  d_se3_log(t, err);                                    // redundant per lane: ~300 flop
+  double oe[6], e2 = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { oe[i] = 0; for (int j = 0; j < 6; ++j) oe[i] += cc.info[6 * i + j] * err[j]; e2 += err[i] * oe[i]; }
+  if (MODE == 1) { if (lane == 0) atomic_add_f64(&B.scal[0], e2); return; }
+  if (lane == 0) atomic_add_f64(B.chi2_cur, e2);
+  const int i = lane / 6, j = lane - 6 * i;             // lanes 0..35 own element (i,j)
+  const bool on = lane < 36;
+  // Adj(T21) = [[R, t^R],[0, R]];  d_lieBracketab_by_d_a(d) = -ad_d   (SURVEY.md A.4)
+  if (on) {
+    const double *A = cc.T_21;
+    const double tt[3] = {A[3], A[7], A[11]};
+    const int bi = i % 3, bj = j % 3;
+    const double Rij = A[4 * bi + bj];
+    // (t^ R)[bi][bj]
+    const double th[9] = {0, -tt[2], tt[1], tt[2], 0, -tt[0], -tt[1], tt[0], 0};
+    const double tR = th[3 * bi] * A[bj] + th[3 * bi + 1] * A[4 + bj] + th[3 * bi + 2] * A[8 + bj];
+    double adj = 0, dlp = 0, dlm = 0;
+    const double hu[9] = {0, -err[2], err[1], err[2], 0, -err[0], -err[1], err[0], 0};
+    const double hw[9] = {0, -err[5], err[4], err[5], 0, -err[3], -err[4], err[3], 0};
+    if (i < 3 && j < 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
+    else if (i < 3 && j >= 3) { adj = tR; dlp = -hu[3 * bi + bj]; }
+    else if (i >= 3 && j >= 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
+    dlm = -dlp;                                         // dl(-e)
+    s_m[0][lane] = adj; s_m[1][lane] = dlp; s_m[4][lane] = dlm;
+  }
+  wave_lds_sync();
+  auto mm = [&](int a, int b) { double s = 0; for (int k = 0; k < 6; ++k) s += s_m[a][6 * i + k] * s_m[b][6 * k + j]; return s; };
+  // J1 = third(T21, e) = Adj + 1/2 dl Adj + 1/12 dl dl Adj
+  double t1 = on ? mm(1, 0) : 0.0;
+  if (on) s_m[2][lane] = t1;
+  wave_lds_sync();
+  double t2 = on ? mm(1, 2) : 0.0;
+  const double J1 = on ? s_m[0][lane] + 0.5 * t1 + (1. / 12.) * t2 : 0.0;
+  // J2 = -third(I, -e) = -(I + 1/2 dl(-e) + 1/12 dl(-e)^2)
+  double u2 = on ? mm(4, 4) : 0.0;
+  const double J2 = on ? -((i == j ? 1.0 : 0.0) + 0.5 * s_m[4][lane] + (1. / 12.) * u2) : 0.0;
+  wave_lds_sync();
+  if (on) { s_m[3][lane] = J1; s_m[5][lane] = J2; }
+  wave_lds_sync();
+  // O*J1, O*J2
+  if (on) {
+    double a1 = 0, a2 = 0;
+    for (int k = 0; k < 6; ++k) { a1 += cc.info[6 * i + k] * s_m[3][6 * k + j]; a2 += cc.info[6 * i + k] * s_m[5][6 * k + j]; }
+    s_m[6][lane] = a1; s_m[7][lane] = a2;
+  }
+  wave_lds_sync();
+  const int p1 = cc.pose1, p2 = cc.pose2, P = B.P;
+  if (on) {
+    double s11 = 0, s22 = 0, s12 = 0;
+    for (int k = 0; k < 6; ++k) { s11 += s_m[3][6 * k + i] * s_m[6][6 * k + j]; s22 += s_m[5][6 * k + i] * s_m[7][6 * k + j]; s12 += s_m[3][6 * k + i] * s_m[7][6 * k + j]; }
+    if (j >= i) { atomic_add_f64(&B.H[blk_index(p1, p1, P) * 36 + lane], s11); atomic_add_f64(&B.H[blk_index(p2, p2, P) * 36 + lane], s22); }
+    if (p1 != p2) {
+      const bool up = p1 < p2;
+      atomic_add_f64(&B.H[(up ? blk_index(p1, p2, P) : blk_index(p2, p1, P)) * 36 + (up ? 6 * i + j : 6 * j + i)], s12);
+    }
+  }
+  if (lane < 6) {
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < 6; ++k) { s1 += s_m[3][6 * k + lane] * oe[k]; s2 += s_m[5][6 * k + lane] * oe[k]; }
+    atomic_add_f64(&B.bp[6 * p1 + lane], -s1);
+    atomic_add_f64(&B.bp[6 * p2 + lane], -s2);
+  }
+}
+// stand-alone launch (windows without landmarks on this rank; otherwise the constraints ride in extra workgroups of
+// the landmark kernels)
+template <int MODE>
+__global__ __launch_bounds__(64) void ba_constraint_kernel(BaDev B) {
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
+  __shared__ double s_m[8][36];
+  ba_constraint_body<MODE>(B, blockIdx.x, s_m);
+}
+
+// Levenberg accept / reject of one speculative trial (OptimizationAlgorithmLevenberg::solve), on one lane
+__device__ __forceinline__ void ba_lm_decide(const BaDev &B, int it) {
+  double *rec = B.ctl + 8 + 8 * it;
+  const double chi_cur = B.scal[4], fail = B.scal[3];
+  const double tempChi = fail != 0.0 ? 1.7976931348623157e308 : B.scal[0];
+  const double scale = B.scal[1] + B.scal[2] + 1e-3;
+  const double rho = (chi_cur - tempChi) / scale;
+  double lambda = B.ctl[0];
+  const bool accept = rho > 0 && isfinite(tempChi);
+  if (accept) {
+    const double q = 2 * rho - 1;
+    double alpha = 1. - q * q * q;
+    alpha = fmin(alpha, 2. / 3.);
+    lambda *= fmax(1. / 3., alpha);
+    B.ctl[0] = lambda;
+  } else {
+    B.ctl[1] = 1.0;
+  }
+  rec[0] = chi_cur; rec[1] = tempChi; rec[2] = scale; rec[3] = rho; rec[4] = accept ? 1.0 : 0.0; rec[5] = lambda; rec[6] = fail; rec[7] = 1.0;
+}
 
 // MODE 0: accumulate reduced system + chi2 at the current state.
 // MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
@@ -204,6 +356,12 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
   constexpr int NT = NW * 64;
   if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int lane = threadIdx.x & 63;
+  __shared__ double s_cons[8][36];
+  const int n_lm_blocks = (B.n_chunks + NW - 1) / NW;
+  if (B.fuse_cons && (int)blockIdx.x >= n_lm_blocks) {                      // pose-pose constraints: one wave each
+    if (threadIdx.x < 64) ba_constraint_body<MODE>(B, blockIdx.x - n_lm_blocks, s_cons);
+    return;
+  }
   const int chunk = blockIdx.x * NW + (threadIdx.x >> 6);
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
   const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
@@ -535,128 +693,6 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     }
   }
   SVS_STAMP(DBG_N - 1);
-}
-
-// ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
-__device__ void d_so3_log(const double *R, double *w, double &theta) {
-  double q[4];
-  const double tr = R[0] + R[4] + R[8];
-  if (tr > 0) { double s = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s; }
-  else if (R[0] > R[4] && R[0] > R[8]) { double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s; }
-  else if (R[4] > R[8]) { double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s; }
-  else { double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s; }
-  const double n = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), ww = q[0];
-  double two_atan;
-  if (n < 1e-10) two_atan = 2.0 / ww - 2.0 * (n * n) / (ww * ww * ww);
-  else if (fabs(ww) < 1e-10) two_atan = (ww > 0 ? M_PI : -M_PI) / n;
-  else two_atan = 2.0 * atan(n / ww) / n;
-  w[0] = two_atan * q[1]; w[1] = two_atan * q[2]; w[2] = two_atan * q[3];
-  theta = two_atan * n;
-}
-__device__ void d_pose_mul(const double *A, const double *Bm, double *Cm) {
-  double t[12];
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 4; ++j) t[4 * i + j] = A[4 * i] * Bm[j] + A[4 * i + 1] * Bm[4 + j] + A[4 * i + 2] * Bm[8 + j];
-    t[4 * i + 3] += A[4 * i + 3];
-  }
-  for (int i = 0; i < 12; ++i) Cm[i] = t[i];
-}
-__device__ void d_pose_inv(const double *A, double *Bm) {
-  double t[12];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[4 * i + j] = A[4 * j + i];
-  for (int i = 0; i < 3; ++i) t[4 * i + 3] = -(t[4 * i] * A[3] + t[4 * i + 1] * A[7] + t[4 * i + 2] * A[11]);
-  for (int i = 0; i < 12; ++i) Bm[i] = t[i];
-}
-__device__ void d_se3_log(const double *T, double *x) {
-  double R[9], W[9], W2[9], Vi[9], th;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T[4 * i + j];
-  d_so3_log(R, x + 3, th);
-  const double *w = x + 3;
-  W[0] = 0; W[1] = -w[2]; W[2] = w[1]; W[3] = w[2]; W[4] = 0; W[5] = -w[0]; W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-  const double c = fabs(th) < 1e-10 ? 1.0 / 12.0 : (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
-  for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * W[i] + c * W2[i];
-  Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
-  for (int i = 0; i < 3; ++i) x[i] = Vi[3 * i] * T[3] + Vi[3 * i + 1] * T[7] + Vi[3 * i + 2] * T[11];
-}
-// One wavefront per constraint; lane (i,j) = element of the 6x6 products, operands staged in LDS.
-// (A one-thread-per-constraint version spent 60 us in scratch-spilled serial 6x6x6 products.)
-__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
-
-template <int MODE>
-__global__ __launch_bounds__(64) void ba_constraint_kernel(BaDev B) {
-  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
-  __shared__ double s_m[8][36];      // 0 Adj(T21) 1 dl(e) 2 t1 3 J1 4 dl(-e) 5 J2 6 O*J1 7 O*J2
-  const int c = blockIdx.x, lane = threadIdx.x;
-  const svs_ba_constraint &cc = B.cons[c];
-  const double *poses = MODE == 0 ? B.poses : B.poses_trial;
-  double T2i[12], t[12], err[6];
-  d_pose_inv(poses + 12 * cc.pose2, T2i);
-  d_pose_mul(cc.T_21, poses + 12 * cc.pose1, t);
-  d_pose_mul(t, T2i, t);
-  d_se3_log(t, err);                                    // redundant per lane: ~300 flop
-  double oe[6], e2 = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { oe[i] = 0; for (int j = 0; j < 6; ++j) oe[i] += cc.info[6 * i + j] * err[j]; e2 += err[i] * oe[i]; }
-  if (MODE == 1) { if (lane == 0) atomic_add_f64(&B.scal[0], e2); return; }
-  if (lane == 0) atomic_add_f64(B.chi2_cur, e2);
-  const int i = lane / 6, j = lane - 6 * i;             // lanes 0..35 own element (i,j)
-  const bool on = lane < 36;
-  // Adj(T21) = [[R, t^R],[0, R]];  d_lieBracketab_by_d_a(d) = -ad_d   (SURVEY.md A.4)
-  if (on) {
-    const double *A = cc.T_21;
-    const double tt[3] = {A[3], A[7], A[11]};
-    const int bi = i % 3, bj = j % 3;
-    const double Rij = A[4 * bi + bj];
-    // (t^ R)[bi][bj]
-    const double th[9] = {0, -tt[2], tt[1], tt[2], 0, -tt[0], -tt[1], tt[0], 0};
-    const double tR = th[3 * bi] * A[bj] + th[3 * bi + 1] * A[4 + bj] + th[3 * bi + 2] * A[8 + bj];
-    double adj = 0, dlp = 0, dlm = 0;
-    const double hu[9] = {0, -err[2], err[1], err[2], 0, -err[0], -err[1], err[0], 0};
-    const double hw[9] = {0, -err[5], err[4], err[5], 0, -err[3], -err[4], err[3], 0};
-    if (i < 3 && j < 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
-    else if (i < 3 && j >= 3) { adj = tR; dlp = -hu[3 * bi + bj]; }
-    else if (i >= 3 && j >= 3) { adj = Rij; dlp = -hw[3 * bi + bj]; }
-    dlm = -dlp;                                         // dl(-e)
-    s_m[0][lane] = adj; s_m[1][lane] = dlp; s_m[4][lane] = dlm;
-  }
-  wave_lds_sync();
-  auto mm = [&](int a, int b) { double s = 0; for (int k = 0; k < 6; ++k) s += s_m[a][6 * i + k] * s_m[b][6 * k + j]; return s; };
-  // J1 = third(T21, e) = Adj + 1/2 dl Adj + 1/12 dl dl Adj
-  double t1 = on ? mm(1, 0) : 0.0;
-  if (on) s_m[2][lane] = t1;
-  wave_lds_sync();
-  double t2 = on ? mm(1, 2) : 0.0;
-  const double J1 = on ? s_m[0][lane] + 0.5 * t1 + (1. / 12.) * t2 : 0.0;
-  // J2 = -third(I, -e) = -(I + 1/2 dl(-e) + 1/12 dl(-e)^2)
-  double u2 = on ? mm(4, 4) : 0.0;
-  const double J2 = on ? -((i == j ? 1.0 : 0.0) + 0.5 * s_m[4][lane] + (1. / 12.) * u2) : 0.0;
-  wave_lds_sync();
-  if (on) { s_m[3][lane] = J1; s_m[5][lane] = J2; }
-  wave_lds_sync();
-  // O*J1, O*J2
-  if (on) {
-    double a1 = 0, a2 = 0;
-    for (int k = 0; k < 6; ++k) { a1 += cc.info[6 * i + k] * s_m[3][6 * k + j]; a2 += cc.info[6 * i + k] * s_m[5][6 * k + j]; }
-    s_m[6][lane] = a1; s_m[7][lane] = a2;
-  }
-  wave_lds_sync();
-  const int p1 = cc.pose1, p2 = cc.pose2, P = B.P;
-  if (on) {
-    double s11 = 0, s22 = 0, s12 = 0;
-    for (int k = 0; k < 6; ++k) { s11 += s_m[3][6 * k + i] * s_m[6][6 * k + j]; s22 += s_m[5][6 * k + i] * s_m[7][6 * k + j]; s12 += s_m[3][6 * k + i] * s_m[7][6 * k + j]; }
-    if (j >= i) { atomic_add_f64(&B.H[blk_index(p1, p1, P) * 36 + lane], s11); atomic_add_f64(&B.H[blk_index(p2, p2, P) * 36 + lane], s22); }
-    if (p1 != p2) {
-      const bool up = p1 < p2;
-      atomic_add_f64(&B.H[(up ? blk_index(p1, p2, P) : blk_index(p2, p1, P)) * 36 + (up ? 6 * i + j : 6 * j + i)], s12);
-    }
-  }
-  if (lane < 6) {
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < 6; ++k) { s1 += s_m[3][6 * k + lane] * oe[k]; s2 += s_m[5][6 * k + lane] * oe[k]; }
-    atomic_add_f64(&B.bp[6 * p1 + lane], -s1);
-    atomic_add_f64(&B.bp[6 * p2 + lane], -s2);
-  }
 }
 
 // ---- reduced-system solve: blocked right-looking Cholesky on the packed upper 6x6 blocks -------
@@ -1594,23 +1630,7 @@ __global__ void ba_expand_kernel(BaDev B, double *__restrict__ Hfull, double *__
 // chi2, scale, rho, accepted, lambda after the update, solver failure, done marker.
 __global__ void ba_lm_kernel(BaDev B, int it) {
   if (threadIdx.x != 0 || blockIdx.x != 0 || B.ctl[1] != 0.0) return;
-  double *rec = B.ctl + 8 + 8 * it;
-  const double chi_cur = B.scal[4], fail = B.scal[3];
-  const double tempChi = fail != 0.0 ? 1.7976931348623157e308 : B.scal[0];
-  const double scale = B.scal[1] + B.scal[2] + 1e-3;
-  const double rho = (chi_cur - tempChi) / scale;
-  double lambda = B.ctl[0];
-  const bool accept = rho > 0 && isfinite(tempChi);
-  if (accept) {
-    const double q = 2 * rho - 1;
-    double alpha = 1. - q * q * q;
-    alpha = fmin(alpha, 2. / 3.);
-    lambda *= fmax(1. / 3., alpha);
-    B.ctl[0] = lambda;
-  } else {
-    B.ctl[1] = 1.0;
-  }
-  rec[0] = chi_cur; rec[1] = tempChi; rec[2] = scale; rec[3] = rho; rec[4] = accept ? 1.0 : 0.0; rec[5] = lambda; rec[6] = fail; rec[7] = 1.0;
+  ba_lm_decide(B, it);
 }
 
 }  // namespace
@@ -1732,6 +1752,7 @@ static BaDev make_dev(const svs_ba *ba, double lambda, int cur = -1, double *ctl
   B.H = ba->d_red; B.bp = ba->d_red + nblk * 36; B.bs = B.bp + 6 * (size_t)ba->P; B.chi2_cur = B.bs + 6 * (size_t)ba->P;
   B.x = ba->d_x; B.scal = ba->d_scal;
   B.cam = ba->cam; B.delta = ba->prm.huber_delta; B.lambda = lambda; B.robust = ba->prm.use_robust; B.self_mode = ba->prm.self_edge_mode;
+  B.fuse_cons = (B.C > 0 && B.n_chunks > 0 && !getenv("SVS_BA_NO_FUSED_CONS")) ? 1 : 0;
   return B;
 }
 
@@ -2109,7 +2130,7 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   BaDev B = make_dev(ba, lambda, cur, ctl);
   if (!ev) ev = ba->ev;
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
-  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
   const char *dbg_env = getenv("SVS_BA_DEBUG");
   const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
@@ -2119,12 +2140,13 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
     int nw = 4;
     if (!getenv("SVS_BA_NW4")) for (int c = 5; c <= 8 && div_up(B.n_chunks, nw) > ctx->n_cu; ++c) if (div_up(B.n_chunks, c) <= ctx->n_cu) nw = c;
     if (const char *e = getenv("SVS_BA_NW")) nw = atoi(e);
+    const int xc = B.fuse_cons ? B.C : 0;      // pose-pose constraints in extra workgroups of the same launch
     switch (nw) {
-      case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5>), dim3(div_up(B.n_chunks, 5)), dim3(320), 0, ctx->stream, B); break;
-      case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6>), dim3(div_up(B.n_chunks, 6)), dim3(384), 0, ctx->stream, B); break;
-      case 7: hipLaunchKernelGGL((ba_landmark_kernel<0, 7>), dim3(div_up(B.n_chunks, 7)), dim3(448), 0, ctx->stream, B); break;
-      case 8: hipLaunchKernelGGL((ba_landmark_kernel<0, 8>), dim3(div_up(B.n_chunks, 8)), dim3(512), 0, ctx->stream, B); break;
-      default: hipLaunchKernelGGL((ba_landmark_kernel<0, 4>), dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); break;
+      case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5>), dim3(div_up(B.n_chunks, 5) + xc), dim3(320), 0, ctx->stream, B); break;
+      case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6>), dim3(div_up(B.n_chunks, 6) + xc), dim3(384), 0, ctx->stream, B); break;
+      case 7: hipLaunchKernelGGL((ba_landmark_kernel<0, 7>), dim3(div_up(B.n_chunks, 7) + xc), dim3(448), 0, ctx->stream, B); break;
+      case 8: hipLaunchKernelGGL((ba_landmark_kernel<0, 8>), dim3(div_up(B.n_chunks, 8) + xc), dim3(512), 0, ctx->stream, B); break;
+      default: hipLaunchKernelGGL((ba_landmark_kernel<0, 4>), dim3(div_up(B.n_chunks, 4) + xc), dim3(256), 0, ctx->stream, B); break;
     }
     SVS_LAUNCH_CHECK(ctx);
   }
@@ -2196,9 +2218,12 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
   SVS_LAUNCH_CHECK(ctx);
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
-  if (B.C > 0) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
-  if (B.n_chunks > 0) { hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4)), dim3(256), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
+  if (B.n_chunks > 0) {
+    hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4) + (B.fuse_cons ? B.C : 0)), dim3(256), 0, ctx->stream, B);
+    SVS_LAUNCH_CHECK(ctx);
+  }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
   if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   return SVS_OK;
@@ -2253,8 +2278,8 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       int rc = enqueue_trial(ba, lambda, cur, ba->d_ctl, &ba->spec_ev[6 * j], smem, allreduce, user);
       if (rc) return rc;
       BaDev B = make_dev(ba, lambda, cur, ba->d_ctl);
-      hipLaunchKernelGGL(ba_lm_kernel, dim3(1), dim3(64), 0, ctx->stream, B, j);
-      SVS_LAUNCH_CHECK(ctx);
+      hipLaunchKernelGGL(ba_lm_kernel, dim3(1), dim3(64), 0, ctx->stream, B, j);      // (taking this decision in the last workgroup of the
+      SVS_LAUNCH_CHECK(ctx);                                                           //  previous kernel costs more than the launch: 400 same-address tickets)
       cur = 1 - cur;                   // as if accepted
     }
     SVS_HIP(ctx, hipMemcpyAsync(ba->h_ctl, ba->d_ctl, sizeof(double) * n_ctl, hipMemcpyDeviceToHost, ctx->stream));

