@@ -356,3 +356,34 @@ def motion_only(xyz, obs, cam, T, robust=True, b=2.0, num_iter=15, tau=1e-5):
         if stop:
             break
     return T, init, chi2
+
+
+# ---- StereoFrontend::processMatchedPoints, numeric part (independent vectorised restatement) ----------------------------
+def process_matched_points(xyz, obs, level, is_ok, n_new_records, cam, T, max_reproj_error=2.0):
+    """xyz [n,3] points in the active keyframe, obs [n,3] (u, v, u_right) in level-0 pixels, level [n], is_ok [n] bool.
+    Returns dict(accepted, is_new, uv_pyr, curkey_uv_pyr, grid2x2 [2,2], grid3x3 [3,3], per_level [3], n_track, sum_len)."""
+    f, cx, cy, b, w, h = cam
+    T = np.asarray(T, np.float64).reshape(3, 4)
+    p = xyz @ T[:, :3].T + T[:, 3]
+    pred = np.stack([p[:, 0] / p[:, 2] * f + cx, p[:, 1] / p[:, 2] * f + cy, (p[:, 0] - b) / p[:, 2] * f + cx], 1)
+    d = np.abs(obs - pred)
+    fac = (2.0 ** level).astype(np.float64)
+    mre = np.float32(max_reproj_error)
+    acc = is_ok & (d[:, 0] < np.float64(mre) * fac) & (d[:, 1] < np.float64(mre) * fac) & (d[:, 2] < 3.0 * np.float64(mre))
+    third = np.float32(1.0 / 3.0)
+    half_w, half_h = int(w * 0.5), int(h * 0.5)
+    tw, th = int(np.float32(w) * third), int(np.float32(h) * third)
+    ttw, tth = int(np.float32(w * 2) * third), int(np.float32(h * 2) * third)
+    i2 = (obs[:, 0] >= half_w).astype(int); j2 = (obs[:, 1] >= half_h).astype(int)
+    i3 = (obs[:, 0] >= tw).astype(int) + (obs[:, 0] >= ttw).astype(int)
+    j3 = (obs[:, 1] >= th).astype(int) + (obs[:, 1] >= tth).astype(int)
+    g2 = np.zeros((2, 2), int); g3 = np.zeros((3, 3), int); per = np.zeros(3, int)
+    np.add.at(g2, (i2[acc], j2[acc]), 1)
+    np.add.at(g3, (i3[acc], j3[acc]), 1)
+    np.add.at(per, level[acc], 1)
+    uv = obs[:, :2] / fac[:, None]
+    ck = np.stack([xyz[:, 0] / xyz[:, 2] * f + cx, xyz[:, 1] / xyz[:, 2] * f + cy], 1) / fac[:, None]
+    length = np.hypot(*(uv - ck).T)
+    return dict(accepted=acc, is_new=acc & (np.arange(len(obs)) < n_new_records), uv_pyr=np.where(acc[:, None], uv, 0.0),
+                curkey_uv_pyr=np.where(acc[:, None], ck, 0.0), grid2x2=g2, grid3x3=g3, per_level=per, n_track=int(acc.sum()),
+                sum_len=float(length[acc].sum()))
