@@ -387,3 +387,72 @@ def process_matched_points(xyz, obs, level, is_ok, n_new_records, cam, T, max_re
     return dict(accepted=acc, is_new=acc & (np.arange(len(obs)) < n_new_records), uv_pyr=np.where(acc[:, None], uv, 0.0),
                 curkey_uv_pyr=np.where(acc[:, None], ck, 0.0), grid2x2=g2, grid3x3=g3, per_level=per, n_track=int(acc.sum()),
                 sum_len=float(length[acc].sum()))
+
+
+# ---- dense tracker (dense_tracking.cpp:222-423), vectorised and independent of the C oracle -------------------------------
+def _bilinear_f32(img, u, v):
+    """maths_utils.cpp:46-65 interpolateMat_32f: float weights, 4 taps."""
+    x, y = np.floor(u), np.floor(v)
+    sx, sy = (u - x).astype(np.float32), (v - y).astype(np.float32)
+    xi, yi = x.astype(int), y.astype(int)
+    wx0, wy0 = np.float32(1) - sx, np.float32(1) - sy
+    return (wx0 * wy0) * img[yi, xi] + (wx0 * sy) * img[yi + 1, xi] + (sx * wy0) * img[yi, xi + 1] + (sx * sy) * img[yi + 1, xi + 1]
+
+
+def pointcloud_cpu(disp, cam, level, T_cur_from_actkey):
+    """computeDensePointCloudCpu: quarter-grid cloud of one level; cam = (f, cx, cy, b, w, h) of THAT level."""
+    f, cx, cy, b, w, h = cam
+    cw, ch = w // 4, h // 4
+    u, v = np.meshgrid(np.arange(cw) * 4, np.arange(ch) * 4)
+    d = (disp[(v << level), (u << level)].astype(np.float64) * (1.0 / (1 << level))).astype(np.float32)
+    Q = np.array([[1, 0, 0, -cx], [0, 1, 0, -cy], [0, 0, 0, f], [0, 0, 1.0 / b, 0]])
+    T = np.vstack([np.asarray(T_cur_from_actkey, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+    TQ = np.linalg.inv(T) @ Q
+    uvd = np.stack([u, v, d.astype(np.float64), np.ones_like(u, float)], -1)
+    r = uvd @ TQ.T
+    out = np.zeros((ch, cw, 4), np.float32)
+    ok = d > 0
+    with np.errstate(all="ignore"):
+        out[..., :3] = np.where(ok[..., None], (r[..., :3] / r[..., 3:4]), 0.0).astype(np.float32)
+    out[..., 3] = np.where(ok, 1.0, -1.0)
+    return out
+
+
+def dense_pass(cloud, prev_u8, cur, dx, dy, cam, T):
+    """One H,b pass of denseTrackingCpu's loop body; returns H (6x6), b (6), chi2, n_valid, residual image."""
+    f, cx, cy, b_, w, h = cam
+    T = np.asarray(T, np.float64).reshape(3, 4)
+    ch, cw = cloud.shape[:2]
+    P = cloud[..., :3].astype(np.float64)
+    has = cloud[..., 3] > 0
+    X = P @ T[:, :3].T + T[:, 3]
+    with np.errstate(all="ignore"):
+        uv = np.stack([f * (X[..., 0] / X[..., 2]) + cx, f * (X[..., 1] / X[..., 2]) + cy], -1).astype(np.float32)
+    ui, vi = np.trunc(uv[..., 0]), np.trunc(uv[..., 1])
+    inside = has & np.isfinite(uv).all(-1) & (ui >= 2) & (vi >= 2) & (ui < w - 2) & (vi < h - 2)
+    u = np.where(inside, uv[..., 0], np.float32(2)); v = np.where(inside, uv[..., 1], np.float32(2))
+    vv, uu = np.meshgrid(np.arange(ch) * 4, np.arange(cw) * 4, indexing="ij")
+    ip = ((1.0 / 255.0) * prev_u8[vv, uu].astype(np.float64)).astype(np.float32)
+    ic = _bilinear_f32(cur, u, v)
+    res = np.clip((ip - ic).astype(np.float32), np.float32(-0.1), np.float32(0.1))      # clamp +-0.1 (double constants, f32 values)
+    res = np.where(res > 0.1, np.float32(0.1), np.where(res < -0.1, np.float32(-0.1), res)).astype(np.float32)
+    gx = (0.5 * _bilinear_f32(dx, u, v).astype(np.float64)).astype(np.float32).astype(np.float64)
+    gy = (0.5 * _bilinear_f32(dy, u, v).astype(np.float64)).astype(np.float32).astype(np.float64)
+    x, y, z = X[..., 0], X[..., 1], np.where(inside, X[..., 2], 1.0)
+    z2 = z * z
+    r0 = np.stack([-1.0 / z * f, 0 * z, x / z2 * f, x * y / z2 * f, -(1 + x * x / z2) * f, y / z * f], -1)      # transformations.h:117-139
+    r1 = np.stack([0 * z, -1.0 / z * f, y / z2 * f, (1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f], -1)
+    J = gx[..., None] * r0 + gy[..., None] * r1
+    J = np.where(inside[..., None], J, 0.0)
+    rr = np.where(inside, res, np.float32(0)).astype(np.float64)
+    Jf = J.reshape(-1, 6)
+    H = Jf.T @ Jf
+    bvec = Jf.T @ rr.reshape(-1)
+    chi2 = float((rr.astype(np.float32) ** 2).astype(np.float64).sum())
+    g = np.maximum(np.float32(0), np.float32(1) - np.float32(50) * res * res)
+    rimg = np.zeros((ch, cw, 4), np.float32)
+    rimg[..., 3] = 1
+    rimg[~has, 1] = 1
+    rimg[has & ~inside, 0] = 1
+    rimg[inside, 0] = rimg[inside, 1] = rimg[inside, 2] = g[inside]
+    return H, bvec, chi2, int(inside.sum()), rimg
