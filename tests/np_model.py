@@ -456,3 +456,99 @@ def dense_pass(cloud, prev_u8, cur, dx, dy, cam, T):
     rimg[has & ~inside, 0] = 1
     rimg[inside, 0] = rimg[inside, 1] = rimg[inside, 2] = g[inside]
     return H, bvec, chi2, int(inside.sum()), rimg
+
+
+# ---- GuidedMatcher<StereoCamera>::match (matcher.cpp:98-181, 312-458; matcher-impl.cpp:33-51), written from the reference
+#      source independently of the C oracle.  Tie-breaking uses the quadrant-key order the quadtree's DFS induces
+#      (quadtree.h:515-540, 636-708; proven equivalent to the oracle's tree walk by test_quadtree_order_*).
+def quad_key(px, py, W, H, depth=16):
+    x0 = y0 = 0.0
+    w, h = float(W), float(H)
+    key = 0
+    for _ in range(depth):
+        bx = 0 if (1.0 - (x0 + w - px) / w) < 0.5 else 1
+        by = 0 if (1.0 - (y0 + h - py) / h) < 0.5 else 1
+        key = key * 4 + bx * 2 + by
+        w *= 0.5; h *= 0.5
+        x0 += w * bx; y0 += h * by
+    return key
+
+
+def _trunc_div(a, b):
+    q = abs(a) // b
+    return q if a >= 0 else -q
+
+
+def match_point(pt, kf_pyr, T_anchor_from_w, T_cur_from_actkey, T_actkey_from_w, cur_pyr, disp, corners, cams,
+                radius=8, thr_mean=22, thr_std=10):
+    """One candidate point.  pt: CANDIDATE_DTYPE record; kf_pyr / cur_pyr: 3 u8 levels; corners[l]: (n,2) int array of the
+    current frame's FAST corners; cams[l] = (f, cx, cy, w, h) of level l.  Returns (status, u, v, znssd, obs, xyz_actkey)
+    with the oracle's status codes (0 ok, 2 border, 3 depth, 4 texture, 5 no candidate, 6 no disparity)."""
+    l = int(pt["anchor_level"])
+    f, cx, cy, W, H = cams[l]
+    T_cur_from_w = pose_mul(T_cur_from_actkey, T_actkey_from_w)
+    T_c2_from_c1 = pose_mul(T_cur_from_w, pose_inv(T_anchor_from_w))
+    act = lambda T, p: T[:, :3] @ p + T[:, 3]
+    xyz_a = np.asarray(pt["xyz_anchor"], np.float64)
+    xyz_cur = act(T_c2_from_c1, xyz_a)
+    uv_pyr = np.array([f * (xyz_cur[0] / xyz_cur[2]) + cx, f * (xyz_cur[1] / xyz_cur[2]) + cy])
+    key_uv = np.asarray(pt["anchor_obs_pyr"][:2], np.float64)
+    ku, kv = int(key_uv[0]), int(key_uv[1])
+    none = (0, 0, thr_mean * thr_mean * 64, np.zeros(3), np.zeros(3))
+    if not (4 <= ku < W - 4 and 4 <= kv < H - 4):
+        return (2,) + none
+    d_cur, d_anc = 1.0 / xyz_cur[2], 1.0 / xyz_a[2]
+    if d_cur > d_anc * 3 or d_anc > d_cur * 3:
+        return (3,) + none
+    # warpAffinve
+    def fwd(uv):
+        p = np.array([(uv[0] - cx) / f, (uv[1] - cy) / f, 1.0]) * xyz_a[2]
+        q = act(T_c2_from_c1, p)
+        return np.array([f * (q[0] / q[2]) + cx, f * (q[1] / q[2]) + cy])
+    f0, fu, fv = fwd(key_uv), fwd(key_uv + np.array([1.0, 0.0])), fwd(key_uv + np.array([0.0, 1.0]))
+    A = np.array([fu - f0, fv - f0])
+    det = A[0, 0] * A[1, 1] - A[1, 0] * A[0, 1]
+    inv = np.array([[A[1, 1], -A[0, 1]], [-A[1, 0], A[0, 0]]]) * (1.0 / det)
+    img = kf_pyr[l]
+    patch = np.zeros((10, 10), np.uint8)
+    for ix in range(10):
+        for iy in range(10):
+            r0 = (inv[0, 0] * (ix - 5) + inv[0, 1] * (iy - 5)) + key_uv[0]
+            r1 = (inv[1, 0] * (ix - 5) + inv[1, 1] * (iy - 5)) + key_uv[1]
+            x, y = np.floor(r0), np.floor(r1)
+            if x < 0 or y < 0 or x + 1 >= W or y + 1 >= H or not np.isfinite(x + y):
+                val = 0
+            else:
+                sx, sy = r0 - x, r1 - y
+                xi, yi = int(x), int(y)
+                s = ((1 - sx) * (1 - sy)) * float(img[yi, xi]) + ((1 - sx) * sy) * float(img[yi + 1, xi]) + \
+                    (sx * (1 - sy)) * float(img[yi, xi + 1]) + (sx * sy) * float(img[yi + 1, xi + 1])
+                val = int(min(255.0, s))
+            patch[iy, ix] = val
+    key = patch[1:9, 1:9].astype(np.int64)
+    sumA, sumAA = int(key.sum()), int((key * key).sum())
+    xyz_actkey = act(pose_inv(pose_mul(T_anchor_from_w, pose_inv(T_actkey_from_w))), xyz_a)
+    if sumA * sumA - sumAA < thr_std * thr_std * 64:
+        return (4, 0, 0, thr_mean * thr_mean * 64, np.zeros(3), xyz_actkey)
+    ui, vi = int(uv_pyr[0]), int(uv_pyr[1])
+    c = corners[l]
+    inwin = c[(c[:, 0] >= ui - radius) & (c[:, 0] <= ui + radius) & (c[:, 1] >= vi - radius) & (c[:, 1] <= vi + radius)]
+    order = sorted(range(len(inwin)), key=lambda i: quad_key(float(inwin[i, 0]), float(inwin[i, 1]), W, H))
+    best, bu, bv = thr_mean * thr_mean * 64, -1, -1
+    cur = cur_pyr[l].astype(np.int64)
+    for i in order:
+        u, v = int(inwin[i, 0]), int(inwin[i, 1])
+        if not (6 <= u < W - 6 and 6 <= v < H - 6):
+            continue
+        Bp = cur[v - 4:v + 4, u - 4:u + 4]
+        sumB, sumBB, sumAB = int(Bp.sum()), int((Bp * Bp).sum()), int((Bp * key).sum())
+        z = sumAA - 2 * sumAB - sumBB - _trunc_div(sumA * sumA - 2 * sumA * sumB - sumB * sumB, 64)
+        if z < best:
+            best, bu, bv = z, u, v
+    if bu < 0:
+        return (5, 0, 0, thr_mean * thr_mean * 64, np.zeros(3), xyz_actkey)
+    d = float(disp[bv << l, bu << l]) * (1.0 / (1 << l))
+    if d > 0:
+        s = float(1 << l)
+        return (0, bu, bv, best, np.array([float(np.float32(bu)) * s, float(np.float32(bv)) * s, (float(np.float32(bu)) - d) * s]), xyz_actkey)
+    return (6, bu, bv, best, np.zeros(3), xyz_actkey)
