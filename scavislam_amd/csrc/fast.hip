@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t pair_of(const uint32_t (&w)[3], int b) {
   return __builtin_amdgcn_perm(w[j1], w[j], i0 | (0x0cu << 8) | (i1 << 16) | (0x0cu << 24));
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
+__global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
   __shared__ uint32_t s_img[(TH + 2 * HALO) * LROW];
   __shared__ unsigned s_hist[256];
   __shared__ uint32_t s_sc[TH * 16];      // scores of the tile, one dword per 4 pixels
