@@ -436,6 +436,29 @@ __global__ __launch_bounds__(256) void stereo_finish_kernel(StereoDev S, int use
   out[(size_t)blockIdx.y * d_bstride + (size_t)(i / S.w) * dstride + (i % S.w)] = (float)d * (1.f / (1 << DISP_SHIFT));
 }
 
+// same, four pixels per lane (w % 4 == 0, so the four share a row): one 8-byte disparity load, one 16-byte label load;
+// grid: (ceil(w*h/1024), batch)
+__global__ __launch_bounds__(256) void stereo_finish4_kernel(StereoDev S, int use_ccl, float *__restrict__ out, int dstride, size_t d_bstride) {
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4, n = S.w * S.h;
+  if (i0 >= n) return;
+  const size_t base = (size_t)blockIdx.y * n;
+  const uint2 d2 = *reinterpret_cast<const uint2 *>(S.disp16 + base + i0);
+  int d[4] = {(int16_t)(d2.x & 0xffff), (int16_t)(d2.x >> 16), (int16_t)(d2.y & 0xffff), (int16_t)(d2.y >> 16)};
+  if (use_ccl) {
+    const int4 l4 = *reinterpret_cast<const int4 *>(S.label + base + i0);
+    const int l[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (d[k] != FILTERED16 && l[k] >= 0) {
+        const int root = S.label[base + l[k]];           // flattened by the count pass
+        if (root >= 0 && S.count[base + root] <= S.speckle_window) d[k] = FILTERED16;
+      }
+  }
+  float *o = out + (size_t)blockIdx.y * d_bstride + (size_t)(i0 / S.w) * dstride + (i0 % S.w);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)d[k] * (1.f / (1 << DISP_SHIFT));
+}
+
 }  // namespace
 
 struct svs_stereo {
@@ -511,7 +534,8 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
     SVS_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(stereo_ccl_count_kernel, dim3(div_up(n, 2048), n_batch), dim3(256), 0, ctx->stream, S); SVS_LAUNCH_CHECK(ctx);
   }
-  hipLaunchKernelGGL(stereo_finish_kernel, gp, dim3(256), 0, ctx->stream, S, ccl ? 1 : 0, d_disp, dstride, d_bstride);
+  if (w % 4 == 0) hipLaunchKernelGGL(stereo_finish4_kernel, dim3(div_up(n, 1024), n_batch), dim3(256), 0, ctx->stream, S, ccl ? 1 : 0, d_disp, dstride, d_bstride);
+  else hipLaunchKernelGGL(stereo_finish_kernel, gp, dim3(256), 0, ctx->stream, S, ccl ? 1 : 0, d_disp, dstride, d_bstride);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
