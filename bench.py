@@ -376,6 +376,14 @@ def main():
             O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
             nba += 1
         cpu_schur_ms = (time.perf_counter() - t0) / nba * 1e3
+        # context: one build + Schur accumulation of the same window from 1 and from 8 host threads
+        acc_ms = {}
+        for nthr in (1, 8):
+            O.ba_reduced_system_mt(nthr, prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm, 50.0)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                O.ba_reduced_system_mt(nthr, prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm, 50.0)
+            acc_ms[str(nthr)] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
         t0 = time.perf_counter()
         nst = 0
         while nst < 2 or (time.perf_counter() - t0 < 4.0 and nst < 12):     # "stereo" (cv::StereoBM restatement), timed on its own like the GPU stage
@@ -385,7 +393,8 @@ def main():
         cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{nfr} frames 640x480 through the CPU oracle (same stages, same inputs)"
                          f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
-               "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1)}
+               "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1),
+               "schur_accumulate_ms_by_host_threads": acc_ms}
 
     if rank == 0:
         out = {

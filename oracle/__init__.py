@@ -366,6 +366,20 @@ def ba_reduced_system(poses, psi, edges, cons, cam, prm, lam):
     return H, b
 
 
+def ba_reduced_system_mt(threads, poses, psi, edges, cons, cam, prm, lam):
+    """The reduced camera system from `threads` host threads (benchmark context only)."""
+    poses, psi, edges, cons = _ba_args(poses, psi, edges, cons)
+    n = 6 * len(poses)
+    H = np.zeros((n, n))
+    b = np.zeros(n)
+    L = lib()
+    L.svs_ref_ba_reduced_system_mt.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    L.svs_ref_ba_reduced_system_mt(int(threads), len(poses), _p(poses), len(psi), _p(psi), len(edges), _p(edges), len(cons), _p(cons),
+                                   C.byref(cam), C.byref(prm), float(lam), _p(H), _p(b))
+    return H, b
+
+
 def ba_optimize(poses, psi, edges, cons, cam, prm):
     poses, psi, edges, cons = _ba_args(poses, psi, edges, cons)
     poses = poses.copy()

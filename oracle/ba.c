@@ -371,6 +371,58 @@ int svs_ref_ba_reduced_system(int P, const double *poses, int L, const double *p
   return 0;
 }
 
+/* The same accumulation (build + Schur reduction of one LM trial) spread over `threads` host threads -- context for the
+   GPU numbers only (upstream g2o guards its landmark loop with an OpenMP pragma).  Landmarks are dealt to the
+   threads in contiguous ranges; every thread builds and reduces the system of its own edges into a private dense
+   (6P)^2 matrix, the matrices are summed at the end.  Same result as svs_ref_ba_reduced_system up to summation order. */
+#include <pthread.h>
+typedef struct {
+  int P, L, E, C, t, T;
+  const double *poses, *psi; const svs_ba_edge *edges; const svs_ba_constraint *cons; const svs_cam *cam; const svs_ba_params *prm;
+  double lambda, *Hred, *bred;
+} mt_job;
+static void *mt_worker(void *arg) {
+  mt_job *J = (mt_job *)arg;
+  const int l0 = (int)((long long)J->L * J->t / J->T), l1 = (int)((long long)J->L * (J->t + 1) / J->T), n = 6 * J->P;
+  int Es = 0;
+  for (int e = 0; e < J->E; ++e) Es += J->edges[e].point >= l0 && J->edges[e].point < l1;
+  svs_ba_edge *sub = (svs_ba_edge *)malloc(sizeof(svs_ba_edge) * (size_t)(Es ? Es : 1));
+  for (int e = 0, k = 0; e < J->E; ++e) if (J->edges[e].point >= l0 && J->edges[e].point < l1) sub[k++] = J->edges[e];
+  ba_sys S = sys_alloc(J->P, J->L, Es);
+  int *start = (int *)malloc(sizeof(int) * ((size_t)J->L + 1)), *idx = (int *)malloc(sizeof(int) * (size_t)(Es ? Es : 1));
+  landmark_csr(J->L, Es, sub, start, idx);
+  build_system(&S, J->poses, J->psi, sub, J->t == 0 ? J->C : 0, J->cons, J->cam, J->prm);      /* constraints once */
+  schur_reduce(&S, sub, start, idx, J->lambda, J->Hred, J->bred, 0);
+  if (J->t != 0) for (int i = 0; i < n; ++i) J->Hred[(size_t)i * n + i] -= J->lambda;          /* pose damping once */
+  free(start); free(idx); free(sub); sys_free(&S);
+  return 0;
+}
+int svs_ref_ba_reduced_system_mt(int threads, int P, const double *poses, int L, const double *psi, int E,
+                                 const svs_ba_edge *edges, int C, const svs_ba_constraint *cons,
+                                 const svs_cam *cam, const svs_ba_params *prm, double lambda,
+                                 double *Hred, double *bred) {
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  const int n = 6 * P;
+  pthread_t th[64];
+  mt_job jobs[64];
+  double *Hs = (double *)malloc(sizeof(double) * (size_t)n * n * threads), *bs = (double *)malloc(sizeof(double) * (size_t)n * threads);
+  for (int t = 0; t < threads; ++t) {
+    mt_job j = {P, L, E, C, t, threads, poses, psi, edges, cons, cam, prm, lambda, Hs + (size_t)t * n * n, bs + (size_t)t * n};
+    jobs[t] = j;
+    pthread_create(&th[t], 0, mt_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], 0);
+  memcpy(Hred, Hs, sizeof(double) * (size_t)n * n);
+  memcpy(bred, bs, sizeof(double) * n);
+  for (int t = 1; t < threads; ++t) {
+    for (size_t i = 0; i < (size_t)n * n; ++i) Hred[i] += Hs[(size_t)t * n * n + i];
+    for (int i = 0; i < n; ++i) bred[i] += bs[(size_t)t * n + i];
+  }
+  free(Hs); free(bs);
+  return 0;
+}
+
 int svs_ref_ba_optimize(int P, double *poses, int L, double *psi, int E, const svs_ba_edge *edges,
                         int C, const svs_ba_constraint *cons, const svs_cam *cam,
                         const svs_ba_params *prm, svs_ba_stats *stats) {

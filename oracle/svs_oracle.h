@@ -243,6 +243,11 @@ int svs_ref_ba_reduced_system(int P, const double *poses, int L, const double *p
                               const svs_cam *cam, const svs_ba_params *prm, double lambda,
                               double *Hred, double *bred);
 /* full optimize: poses [P][12] and psi [L][3] in/out */
+/* same system from `threads` host threads (context number for the benchmark only; landmark ranges per thread) */
+int svs_ref_ba_reduced_system_mt(int threads, int P, const double *poses, int L, const double *psi, int E,
+                                 const svs_ba_edge *edges, int C, const svs_ba_constraint *cons,
+                                 const svs_cam *cam, const svs_ba_params *prm, double lambda,
+                                 double *Hred, double *bred);
 int svs_ref_ba_optimize(int P, double *poses, int L, double *psi, int E,
                         const svs_ba_edge *edges, int C, const svs_ba_constraint *cons,
                         const svs_cam *cam, const svs_ba_params *prm, svs_ba_stats *stats);
