@@ -383,3 +383,31 @@ def test_largest_supported_window_256_poses(gpu_ctx):
     with pytest.raises(capi.SvsError, match="status 5"):
         opt.copyDataToG2o(np.tile(prob["poses"][:1], (257, 1)), prob["psi"], prob["edges"], prob["cons"], cam, prm)
     opt.close()
+
+
+def test_kernel_timing_brackets_are_opt_in(gpu_ctx):
+    """svs_ba_set_timing: the hipEvent brackets around the three big kernels are off by default (kernel_times() = 0) and
+    report plausible per-trial durations when switched on; results do not depend on them."""
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prob = synth.ba_window(15, 3000, seed=2012)
+    cam = _cam(prob["cam"])
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, BaParams.reference_defaults())
+    st0 = opt.optimize()
+    kt = opt.kernel_times()
+    assert kt["reduce_ms"] == 0 and kt["solve_ms"] == 0 and kt["backsub_ms"] == 0
+    p0, s0 = opt.restoreDataFromG2o()
+    opt.reset_state(prob["poses"], prob["psi"])
+    opt.set_timing(True)
+    st1 = opt.optimize()
+    kt = opt.kernel_times()
+    assert kt["n_trials"] == st1.trials == st0.trials
+    for k in ("reduce_ms", "solve_ms", "backsub_ms"):
+        assert 0.001 < kt[k] / kt["n_trials"] < 5.0, (k, kt)
+    p1, s1 = opt.restoreDataFromG2o()
+    assert _rel_update_err(p1, p0, prob["poses"]) < 1e-9
+    opt.set_timing(False)
+    opt.close()
