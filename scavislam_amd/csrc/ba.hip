@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1716,6 +1717,7 @@ struct svs_ba {
   std::vector<int> w_anchor, w_nobs, w_pos, w_off, w_aoff, w_alist, w_order, w_cs, w_cl;
   std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
   std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
+  unsigned char *h_stage = nullptr; size_t h_stage_cap = 0, h_stage_used = 0;      // pinned staging of the small per-call uploads
   HostPool *pool = nullptr;                    // marshalling workers (created on first use, SVS_HOST_THREADS overrides the count)
   std::vector<double> w_pat_local;
   svs_ba_edge *h_edges = nullptr; size_t h_edges_cap = 0;
@@ -1756,6 +1758,34 @@ static BaDev make_dev(const svs_ba *ba, double lambda, int cur = -1, double *ctl
   return B;
 }
 
+// Small uploads go through one pinned staging area: an asynchronous copy from pageable memory makes the runtime wait for
+// the stream (it has to reuse its own bounce buffer), which would serialise the host behind the big edge DMA.  The area is
+// reset by svs_ba_set_problem after its initial stream synchronisation.
+static int stage_reserve(svs_ba *ba, size_t bytes) {
+  svs_ctx *ctx = ba->ctx;
+  if (bytes <= ba->h_stage_cap) return SVS_OK;
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ba->h_stage) (void)hipHostFree(ba->h_stage);
+  ba->h_stage = nullptr; ba->h_stage_cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_stage, want, hipHostMallocDefault));
+  ba->h_stage_cap = want;
+  return SVS_OK;
+}
+static int stage_upload(svs_ba *ba, void *d_dst, const void *h_src, size_t bytes) {
+  svs_ctx *ctx = ba->ctx;
+  if (bytes == 0) return SVS_OK;
+  const size_t off = (ba->h_stage_used + 63) & ~(size_t)63;
+  if (off + bytes > ba->h_stage_cap) {      // should not happen (reserved up front): fall back to the pageable copy
+    SVS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SVS_OK;
+  }
+  std::memcpy(ba->h_stage + off, h_src, bytes);
+  ba->h_stage_used = off + bytes;
+  SVS_HIP(ctx, hipMemcpyAsync(d_dst, ba->h_stage + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return SVS_OK;
+}
+
 extern "C" int svs_ba_create(svs_ctx *ctx, svs_ba **out) {
   SVS_REQUIRE(ctx, ctx && out);
   svs_ba *ba = new svs_ba();
@@ -1769,6 +1799,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   (void)hipStreamSynchronize(ba->ctx->stream);
   if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
   if (ba->h_ctl) { (void)hipHostFree(ba->h_ctl); ba->h_ctl = nullptr; }
+  if (ba->h_stage) { (void)hipHostFree(ba->h_stage); ba->h_stage = nullptr; ba->h_stage_cap = 0; }
   if (ba->d_ctl) { (void)hipFree(ba->d_ctl); ba->d_ctl = nullptr; }
   if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
   if (ba->d_xfer) (void)hipFree(ba->d_xfer);
@@ -1790,6 +1821,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
   if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ba->h_stage_used = 0;
+  { int rc = stage_reserve(ba, sizeof(double) * (12 * (size_t)P + 3 * (size_t)L) + sizeof(svs_ba_constraint) * (size_t)C + sizeof(int) * ((size_t)E / 8 + 6 * (size_t)P) + 8192);
+    if (rc) return rc; }
   const bool dbg_t = getenv("SVS_BA_DEBUG") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t_0 = now(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0, t_5 = t_0;
@@ -1988,8 +2022,12 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   for (int k = 0; k < 2; ++k) {
     SVS_HIP(ctx, ensure((void **)&ba->d_poses[k], &ba->cap_poses[k], sizeof(double) * 12 * (size_t)P));
     SVS_HIP(ctx, ensure((void **)&ba->d_psi[k], &ba->cap_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
-    SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
-    if (L) SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[k], h_psi, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+  }
+  { int rc = stage_upload(ba, ba->d_poses[0], h_poses, sizeof(double) * 12 * (size_t)P); if (rc) return rc; }
+  SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[1], ba->d_poses[0], sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToDevice, ctx->stream));
+  if (L) {
+    int rc = stage_upload(ba, ba->d_psi[0], h_psi, sizeof(double) * 3 * (size_t)L); if (rc) return rc;
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[1], ba->d_psi[0], sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToDevice, ctx->stream));
   }
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
@@ -2002,13 +2040,16 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_pattern, &ba->cap_pattern, sizeof(double) * (size_t)P * P));
   if (ba->n_chunks) {
-    SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_start, cs.data(), sizeof(int) * cs.size(), hipMemcpyHostToDevice, ctx->stream));
-    SVS_HIP(ctx, hipMemcpyAsync(ba->d_chunk_len, cl.data(), sizeof(int) * cl.size(), hipMemcpyHostToDevice, ctx->stream));
+    int rc = stage_upload(ba, ba->d_chunk_start, cs.data(), sizeof(int) * cs.size()); if (rc) return rc;
+    rc = stage_upload(ba, ba->d_chunk_len, cl.data(), sizeof(int) * cl.size()); if (rc) return rc;
   }
-  if (C) SVS_HIP(ctx, hipMemcpyAsync(ba->d_cons, h_cons, sizeof(svs_ba_constraint) * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
+  if (C) { int rc = stage_upload(ba, ba->d_cons, h_cons, sizeof(svs_ba_constraint) * (size_t)C); if (rc) return rc; }
   SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)P, ctx->stream));
   t_5 = now();
-  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // No synchronisation here: everything above is ordered on the ctx stream in front of whatever the caller enqueues next;
+  // the caller's (pageable) arrays have been staged by the runtime when hipMemcpyAsync returns, the pinned edge buffer and
+  // the work vectors are only touched again by the next set_problem, which starts with a stream synchronisation.
+  if (dbg_t) SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (dbg_t) {
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     fprintf(stderr, "[svs_ba] set_problem: validate+count %.0f us, landmark order %.0f us, slots+sort+pattern %.0f us, gather+upload+chunks %.0f us, enqueue copies %.0f us, wait %.0f us\n",
@@ -2051,9 +2092,8 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   for (int k = 0; k < P; ++k)                       // fill: row k spreads its reach to rows k+1..rowmax[k]
     for (int i = k + 1; i <= rowmax[k]; ++i) rowmax[i] = std::max(rowmax[i], rowmax[k]);
   for (int k = 0; k < P; ++k) { colmin[k] = k; for (int i = 0; i < k; ++i) if (rowmax[i] >= k) { colmin[k] = i; break; } }
-  SVS_HIP(ctx, hipMemcpyAsync(ba->d_rowmax, rowmax.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
-  SVS_HIP(ctx, hipMemcpyAsync(ba->d_colmin, colmin.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
-  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int rc = stage_upload(ba, ba->d_rowmax, rowmax.data(), sizeof(int) * P); if (rc) return rc; }
+  { int rc = stage_upload(ba, ba->d_colmin, colmin.data(), sizeof(int) * P); if (rc) return rc; }
   int R = 1;
   for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
   ba->env_R = R;
@@ -2096,13 +2136,12 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
       ba->cap_rowmax2 = sizeof(int) * rm2.size() + 256;
       SVS_HIP(ctx, hipMalloc(&ba->d_rowmax2, ba->cap_rowmax2));
     }
-    SVS_HIP(ctx, hipMemcpyAsync(ba->d_rowmax2, rm2.data(), sizeof(int) * rm2.size(), hipMemcpyHostToDevice, ctx->stream));
+    { int rc = stage_upload(ba, ba->d_rowmax2, rm2.data(), sizeof(int) * rm2.size()); if (rc) return rc; }
     if (!ba->d_xfer) {
       SVS_HIP(ctx, hipMalloc(&ba->d_xfer, sizeof(double) * (FUSE_SLOTS * FUSE_SLOTS * 36 + 2 * FUSE_SLOTS * 6)));
       SVS_HIP(ctx, hipMalloc(&ba->d_flags, sizeof(unsigned) * 4));
       SVS_HIP(ctx, hipMemsetAsync(ba->d_flags, 0, sizeof(unsigned) * 4, ctx->stream));
     }
-    SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));                       // rm2 is a local
   }
   if (ba->use_lds_solve) {
     const size_t up_count = 2 * (36 * (size_t)P * std::max(R, FUSE_SLOTS) + 128);      // per front: panel rows + write sink + zero block of the fused kernel
