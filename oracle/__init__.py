@@ -464,3 +464,191 @@ def process_matched_points(results, pts, n_new_records, cam, T, max_reproj_error
     L.svs_ref_process_matched_points(_p(res), _p(pts), len(res), int(n_new_records), C.byref(cam), _p(T),
                                      C.c_float(max_reproj_error), _p(gated), _p(stats))
     return gated, stats[0]
+
+
+# ---- full-resolution (CUDA-build) dense tracker: restatement + the reference-compiled pin -----------------
+SUM_F64, SUM_F32_TREE = 0, 1
+
+
+def dense_pass_full_ex(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor, do_jac, sum_mode=SUM_F64):
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    h, w = cloud.shape[:2]
+    prev, cur, dx, dy = [np.ascontiguousarray(a, np.float32) for a in (prev, cur, dx, dy)]
+    T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+    out = np.zeros(1, DENSE_SUMS_DTYPE)
+    L = lib()
+    L.svs_ref_dense_pass_full_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + \
+        [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.svs_ref_dense_pass_full_ex(_p(cloud), w, h, w, _p(prev), _p(cur), _p(dx), _p(dy), w, f, cx, cy,
+                                 _p(T), int(do_jac), int(sum_mode), _p(out))
+    return out[0]
+
+
+def dense_tracking_gpu(cloud, prev, cur, dx, dy, f, cx, cy, T, sum_mode=SUM_F64):
+    """DenseTracker::denseTrackingGpu restated (dense_tracking.cpp:60-193).  cloud/prev/cur/dx/dy: lists of 3 level
+    arrays; f, cx, cy: per-level intrinsics.  Returns (T 3x4, passes, records [n][4], T_jac [3][3][4])."""
+    cloud = [np.ascontiguousarray(a, np.float32) for a in cloud]
+    prev, cur, dx, dy = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (prev, cur, dx, dy)]
+    w = (C.c_int * 3)(*[c.shape[1] for c in cloud])
+    h = (C.c_int * 3)(*[c.shape[0] for c in cloud])
+    P3 = C.c_void_p * 3
+    D3 = C.c_double * 3
+    T = np.ascontiguousarray(T, np.float64).reshape(12).copy()
+    rec = np.zeros((256, 4))
+    nrec = C.c_int(0)
+    Tj = np.zeros((3, 12))
+    L = lib()
+    L.svs_ref_dense_tracking_gpu.restype = C.c_int
+    L.svs_ref_dense_tracking_gpu.argtypes = None
+    passes = L.svs_ref_dense_tracking_gpu(
+        P3(*[a.ctypes.data for a in cloud]), w, P3(*[a.ctypes.data for a in prev]), P3(*[a.ctypes.data for a in cur]),
+        P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]), w, w, h,
+        D3(*[float(v) for v in f]), D3(*[float(v) for v in cx]), D3(*[float(v) for v in cy]), _p(T), C.c_int(int(sum_mode)),
+        _p(rec), C.c_int(256), C.byref(nrec), _p(Tj))
+    return T.reshape(3, 4), passes, rec[:nrec.value].copy(), Tj.reshape(3, 3, 4)
+
+
+def preprocess_gpu_sem(img_u8, levels=3):
+    """FrameGrabber::preprocessing of the CUDA build: f32 pyramid by pyrDown on f32 + REPLICATE derivatives."""
+    img_u8 = np.ascontiguousarray(img_u8, np.uint8)
+    L = lib()
+    h, w = img_u8.shape
+    f0 = np.zeros((h, w), np.float32)
+    L.svs_ref_convert_f32(_p(img_u8), w, h, img_u8.strides[0], _p(f0), w)
+    pyr = [f0]
+    for _ in range(levels - 1):
+        s = pyr[-1]
+        sh, sw = s.shape
+        d = np.zeros(((sh + 1) // 2, (sw + 1) // 2), np.float32)
+        L.svs_ref_pyr_down_f32(_p(s), sw, sh, sw, _p(d), d.shape[1])
+        pyr.append(d)
+    dxs, dys = [], []
+    for s in pyr:
+        sh, sw = s.shape
+        dx = np.zeros_like(s)
+        dy = np.zeros_like(s)
+        L.svs_ref_deriv_replicate(_p(s), sw, sh, sw, _p(dx), _p(dy), sw)
+        dxs.append(dx)
+        dys.append(dy)
+    return pyr, dxs, dys
+
+
+class RefGpu:
+    """oracle/_ref/libsvs_ref_gpu.so: the reference's gpu/dense_tracking.{cuh,cu} compiled on the host (oracle/Makefile,
+    ref_shim/).  Test infrastructure; built only where /root/reference exists, prebuilt file travels to the GPU box."""
+
+    def __init__(self):
+        so = os.path.join(_HERE, "_ref", "libsvs_ref_gpu.so")
+        if os.path.isdir("/root/reference/scavislam/gpu"):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        self.L = L = C.CDLL(so)
+        L.svsref_tracker_create.restype = C.c_void_p
+        L.svsref_tracker_chi2.restype = C.c_float
+        L.svsref_tracker_chi2.argtypes = [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_int] * 4
+        L.svsref_tracker_jacobian_reduction.argtypes = [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
+        L.svsref_tracker_residual_image.argtypes = [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_int] * 4 + [C.c_void_p]
+        L.svsref_tracker_bind_texture.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+        L.svsref_tracker_destroy.argtypes = [C.c_void_p]
+        L.svsref_camera_project.argtypes = [C.c_double] * 3 + [C.c_void_p] * 2
+        L.svsref_frame_jacobian.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.svsref_accumulate.argtypes = [C.c_void_p] * 3 + [C.c_float]
+        L.svsref_compute_point_cloud.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+
+    def set_tex_frac_bits(self, bits):
+        self.L.svsref_set_tex_frac_bits(int(bits))
+
+    def mat34_times_vec(self, T_colmajor, v):
+        T = np.ascontiguousarray(T_colmajor, np.float64).reshape(12)
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.zeros(4, np.float32)
+        self.L.svsref_mat34_times_vec(_p(T), _p(v), _p(out))
+        return out
+
+    def mat4_times_vec(self, M_colmajor, v):
+        M = np.ascontiguousarray(M_colmajor, np.float64).reshape(16)
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.zeros(4, np.float32)
+        self.L.svsref_mat4_times_vec(_p(M), _p(v), _p(out))
+        return out
+
+    def camera_project(self, f, cx, cy, p):
+        p = np.ascontiguousarray(p, np.float32)
+        out = np.zeros(2, np.float32)
+        self.L.svsref_camera_project(f, cx, cy, _p(p), _p(out))
+        return out
+
+    def frame_jacobian(self, p, f, dx, dy):
+        p = np.ascontiguousarray(p, np.float32)
+        out = np.zeros(6, np.float32)
+        self.L.svsref_frame_jacobian(_p(p), f, dx, dy, _p(out))
+        return out
+
+    def accumulate(self, H21, b6, v6, s):
+        H21 = np.ascontiguousarray(H21, np.float32).copy()
+        b6 = np.ascontiguousarray(b6, np.float32).copy()
+        v6 = np.ascontiguousarray(v6, np.float32)
+        self.L.svsref_accumulate(_p(H21), _p(b6), _p(v6), float(s))
+        return H21, b6
+
+    def sym_copy_to(self, H21):
+        H21 = np.ascontiguousarray(H21, np.float32)
+        out = np.zeros(36)
+        self.L.svsref_sym_copy_to(_p(H21), _p(out))
+        return out.reshape(6, 6).T        # column-major storage
+
+    def compute_point_cloud(self, TQ_colmajor, disp, w, h, factor):
+        TQ = np.ascontiguousarray(TQ_colmajor, np.float64).reshape(16)
+        disp = np.ascontiguousarray(disp, np.float32)
+        out = np.zeros((h, w, 4), np.float32)
+        self.L.svsref_compute_point_cloud(_p(TQ), _p(disp), w, h, disp.strides[0] // 4, w, factor, _p(out))
+        return out
+
+    class Tracker:
+        def __init__(self, ref, w, h):
+            self.ref, self.w, self.h = ref, w, h
+            self.t = ref.L.svsref_tracker_create(w, h)
+
+        def close(self):
+            if self.t:
+                self.ref.L.svsref_tracker_destroy(self.t)
+                self.t = None
+
+        def bind(self, cur, dx, dy):
+            self.cur, self.dx, self.dy = [np.ascontiguousarray(a, np.float32) for a in (cur, dx, dy)]
+            self.ref.L.svsref_tracker_bind_texture(self.t, _p(self.cur), _p(self.dx), _p(self.dy), self.w, self.h, self.w)
+
+        def _common(self, prev, cloud, T34_colmajor):
+            prev = np.ascontiguousarray(prev, np.float32)
+            cloud = np.ascontiguousarray(cloud, np.float32)
+            T = np.ascontiguousarray(T34_colmajor, np.float64).reshape(12)
+            return prev, cloud, T
+
+        def jacobian_reduction(self, prev, cloud, T34_colmajor, f, cx, cy):
+            prev, cloud, T = self._common(prev, cloud, T34_colmajor)
+            H = np.zeros(21, np.float32)
+            b = np.zeros(6, np.float32)
+            self.ref.L.svsref_tracker_jacobian_reduction(self.t, _p(prev), _p(cloud), _p(T), f, cx, cy, self.w, self.h, self.w, self.w,
+                                                         _p(H), _p(b))
+            return H, b
+
+        def chi2(self, prev, cloud, T34_colmajor, f, cx, cy):
+            prev, cloud, T = self._common(prev, cloud, T34_colmajor)
+            return float(self.ref.L.svsref_tracker_chi2(self.t, _p(prev), _p(cloud), _p(T), f, cx, cy, self.w, self.h, self.w, self.w))
+
+        def residual_image(self, prev, cloud, T34_colmajor, f, cx, cy):
+            prev, cloud, T = self._common(prev, cloud, T34_colmajor)
+            out = np.zeros((self.h, self.w, 4), np.float32)
+            self.ref.L.svsref_tracker_residual_image(self.t, _p(prev), _p(cloud), _p(T), f, cx, cy, self.w, self.h, self.w, self.w, _p(out))
+            return out
+
+
+_REF = None
+
+
+def ref_gpu():
+    global _REF
+    if _REF is None:
+        _REF = RefGpu()
+    return _REF

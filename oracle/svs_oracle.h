@@ -214,6 +214,22 @@ void svs_ref_dense_pass_full(const float *cloud, int w, int h, int stride4,
                              const float *prev, const float *cur, const float *dx,
                              const float *dy, int fstride, float f, float cx, float cy,
                              const float T34_colmajor[12], int do_jac, svs_dense_sums *out);
+/* same with the summation mode explicit: 0 = f64 sums (SVS_SUM_F64), 1 = the reference's f32 block-tree + sequential host
+   sum, bit-comparable with oracle/_ref (SVS_SUM_F32_TREE) */
+void svs_ref_dense_pass_full_ex(const float *cloud, int w, int h, int stride4,
+                                const float *prev, const float *cur, const float *dx,
+                                const float *dy, int fstride, float f, float cx, float cy,
+                                const float T34_colmajor[12], int do_jac, int sum_mode, svs_dense_sums *out);
+/* DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193); see vision.c */
+int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3], const float *const prev[3],
+                               const float *const cur[3], const float *const dx[3], const float *const dy[3],
+                               const int fstride[3], const int w[3], const int h[3], const double f[3],
+                               const double cx[3], const double cy[3], double T[12], int sum_mode, double *rec, int rec_cap,
+                               int *n_rec, double *T_jac);
+/* FrameGrabber::preprocessing, CUDA build (frame_grabber.cpp:291-313,102-115); OpenCV gpu semantics ASSUMED, see vision.c */
+void svs_ref_pyr_down_f32(const float *src, int w, int h, int sstride, float *dst, int dstride);
+void svs_ref_deriv_replicate(const float *img, int w, int h, int stride, float *dx, float *dy, int dstride);
+void svs_ref_convert_f32(const uint8_t *src, int w, int h, int sstride, float *dst, int dstride);
 /* gpu/dense_tracking.cu:82-122 pointcloud_kernel semantics (incl. the unscaled-row quirk) */
 void svs_ref_pointcloud_full(const float TQ_colmajor[16], const float *disp, int w, int h,
                              int stride_in, int stride_out, int factor, float *cloud);

@@ -552,48 +552,126 @@ void svs_ref_pointcloud_cpu(const float *disp, int ds, const svs_cam *cam, int l
 }
 
 /* ------------------------------------------------------------------------------------------
- * Full-resolution f32 variant: gpu/dense_tracking.cu:24-80 (helpers), :172-263, :376-453.
- * The texture fetch tex2D(u+.5,v+.5) with linear filtering is restated as the 4-tap f32
- * bilinear of maths_utils.cpp:46-65 (NVIDIA's 9-bit fixed-point texture weights are not
- * reproduced: that is hardware behaviour, not the reference's arithmetic). */
+ * Full-resolution f32 variant (the CUDA build): gpu/dense_tracking.cu:24-80 (helpers), :172-263
+ * (jacobianReduction_kernel), :376-453 (chi2_kernel), :495-541 (residualImage_kernel) and the host loop
+ * DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193).
+ *
+ * PINNED against the reference itself: oracle/_ref/libsvs_ref_gpu.so is compiled from those two reference files
+ * (oracle/Makefile) and tests/test_ref_pin_cpu.py checks this restatement against it bit for bit -- per pixel, per
+ * 8x8 block and for whole images in SVS_SUM_F32_TREE mode (the reference's own f32 reduction order).
+ *
+ * Texture fetch: the reference samples tex2D(tex, uv.x + 0.5f, uv.y + 0.5f) with linear filtering (.cu:206-215).
+ * The texture unit subtracts the 0.5 again (CUDA C Programming Guide, linear filtering: xB = x - 0.5), so the
+ * sampling position is RN(uv + 0.5f) - 0.5f -- NOT always uv: the f32 addition rounds when uv + 0.5 crosses a binade
+ * (uv in [2^k - 0.5, 2^k)).  That rounding is the reference's own arithmetic and is reproduced; the four taps are
+ * combined as in the reference's software bilinear (maths_utils.cpp:46-65).  NVIDIA's 9-bit fixed-point weights are
+ * device behaviour and are not reproduced (oracle/_ref can switch them on to measure their effect). */
+static inline float tex2d_lin(const float *m, int stride, int w, int h, float x, float y) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fi = floorf(xb), fj = floorf(yb);
+  const float sx = xb - fi, sy = yb - fj;
+  const float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+  int i0 = (int)fi, j0 = (int)fj, i1 = i0 + 1, j1 = j0 + 1;
+  i0 = i0 < 0 ? 0 : (i0 >= w ? w - 1 : i0); i1 = i1 < 0 ? 0 : (i1 >= w ? w - 1 : i1);   /* clamp addressing */
+  j0 = j0 < 0 ? 0 : (j0 >= h ? h - 1 : j0); j1 = j1 < 0 ? 0 : (j1 >= h ? h - 1 : j1);
+  const float v00 = m[(size_t)j0 * stride + i0], v01 = m[(size_t)j1 * stride + i0];
+  const float v10 = m[(size_t)j0 * stride + i1], v11 = m[(size_t)j1 * stride + i1];
+  return (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
+}
+/* one thread of jacobianReduction_kernel / chi2_kernel up to the reduction: returns 1 and fills res (and J if do_jac)
+   when the pixel contributes (.cu:193-221 / :395-411) */
+static inline int full_pixel(const float *cloud, int w, int h, int s4, const float *prev, const float *cur,
+                             const float *dxi, const float *dyi, int fs, float f, float cx, float cy, const float *T,
+                             int u, int v, int do_jac, float *res_out, float *J) {
+  const float *p = cloud + 4 * ((size_t)v * s4 + u);
+  if (!(p[3] > 0)) return 0;
+  const float x = p[0] * T[0] + p[1] * T[3] + p[2] * T[6] + p[3] * T[9];       /* matTimesVec / dotStride3 */
+  const float y = p[0] * T[1] + p[1] * T[4] + p[2] * T[7] + p[3] * T[10];
+  const float z = p[0] * T[2] + p[1] * T[5] + p[2] * T[8] + p[3] * T[11];
+  const float uu = f * x / z + cx, vv = f * y / z + cy;                        /* cameraProject */
+  if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) return 0;
+  const float ut = uu + 0.5f, vt = vv + 0.5f;                                  /* uv_cur_texoffset */
+  const float ip = prev[(size_t)v * fs + u];
+  const float ic = tex2d_lin(cur, fs, w, h, ut, vt);
+  const float res = ip - ic;
+  *res_out = res;
+  if (do_jac) {
+    float gx = 0.5f * tex2d_lin(dxi, fs, w, h, ut, vt), gy = 0.5f * tex2d_lin(dyi, fs, w, h, ut, vt);
+    const float zsq = z * z;                                                   /* frameJacobian, .cu:65-80 */
+    gx *= f; gy *= f;
+    J[0] = (float)(-gx * (1. / z));
+    J[1] = (float)(-gy * 1. / z);
+    J[2] = (gx * x / zsq + gy * y / zsq);
+    J[3] = (gx * (x * y) / zsq + gy * (1.f + y * y / zsq));
+    J[4] = (-gx * (1.f + (x * x / zsq)) - gy * (x * y) / zsq);
+    J[5] = (gx * y / z - gy * x / z);
+  }
+  return 1;
+}
+/* sum_mode SVS_SUM_F64 (0): f32 per-pixel products accumulated in f64, row-major (what the product is compared with);
+   sum_mode SVS_SUM_F32_TREE (1): the reference's arithmetic to the last bit -- per 8x8 block a 64-slot f32 array
+   reduced as `s[t] += s[t+off]`, off = 32,16,...,1, lanes t < 32 in lockstep and only lanes inside the image taking
+   part (.cu:153-168,224-261), then the block results added sequentially in f32 on the host in block order (.cu:343-355,
+   :480-485). */
+void svs_ref_dense_pass_full_ex(const float *cloud, int w, int h, int s4, const float *prev,
+                                const float *cur, const float *dxi, const float *dyi, int fs, float f,
+                                float cx, float cy, const float *T, int do_jac, int sum_mode, svs_dense_sums *out) {
+  int64_t nv = 0;
+  if (sum_mode == 0) {
+    double H[21] = {0}, b[6] = {0}, chi2 = 0;
+    for (int v = 0; v < h; ++v)
+      for (int u = 0; u < w; ++u) {
+        float res, J[6];
+        if (!full_pixel(cloud, w, h, s4, prev, cur, dxi, dyi, fs, f, cx, cy, T, u, v, do_jac, &res, J)) continue;
+        chi2 += (double)(res * res);
+        ++nv;
+        if (do_jac) {
+          int k = 0;
+          for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) H[k++] += (double)(J[c] * J[r]);
+          for (int i = 0; i < 6; ++i) b[i] += (double)(J[i] * res);
+        }
+      }
+    memcpy(out->H, H, sizeof H); memcpy(out->b, b, sizeof b); out->chi2 = chi2; out->n_valid = nv;
+    return;
+  }
+  float Ht[21] = {0}, bt[6] = {0}, chi2t = 0.f;
+  const int gx_ = (w + 7) / 8, gy_ = (h + 7) / 8;
+  for (int by = 0; by < gy_; ++by)
+    for (int bx = 0; bx < gx_; ++bx) {
+      float s[64][28];           /* 21 H, 6 b, chi2 per thread */
+      int active[64];
+      memset(s, 0, sizeof s);
+      for (int t = 0; t < 64; ++t) {
+        const int u = bx * 8 + (t & 7), v = by * 8 + (t >> 3);
+        active[t] = u < w && v < h;
+        if (!active[t]) continue;
+        float res, J[6];
+        if (!full_pixel(cloud, w, h, s4, prev, cur, dxi, dyi, fs, f, cx, cy, T, u, v, do_jac, &res, J)) continue;
+        ++nv;
+        s[t][27] += res * res;
+        if (do_jac) {
+          int k = 0;
+          for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) s[t][k++] += J[c] * J[r];   /* addOuter, .cuh:163-203 */
+          for (int i = 0; i < 6; ++i) s[t][21 + i] += J[i] * res;                              /* scaledAdd */
+        }
+      }
+      for (int off = 32; off >= 1; off >>= 1)
+        for (int t = 0; t < 32; ++t)            /* ascending t == lockstep: lane t reads slot t+off before lane t+off writes it */
+          if (active[t]) for (int k = 0; k < 28; ++k) s[t][k] += s[t + off][k];
+      for (int k = 0; k < 21; ++k) Ht[k] += s[0][k];
+      for (int k = 0; k < 6; ++k) bt[k] += s[0][21 + k];
+      chi2t += s[0][27];
+    }
+  for (int k = 0; k < 21; ++k) out->H[k] = Ht[k];
+  for (int k = 0; k < 6; ++k) out->b[k] = bt[k];
+  out->chi2 = chi2t; out->n_valid = nv;
+}
 void svs_ref_dense_pass_full(const float *cloud, int w, int h, int s4, const float *prev,
                              const float *cur, const float *dxi, const float *dyi, int fs, float f,
                              float cx, float cy, const float *T, int do_jac, svs_dense_sums *out) {
-  double H[21] = {0}, b[6] = {0}, chi2 = 0; int64_t nv = 0;
-  for (int v = 0; v < h; ++v)
-    for (int u = 0; u < w; ++u) {
-      const float *p = cloud + 4 * ((size_t)v * s4 + u);
-      if (!(p[3] > 0)) continue;
-      float x = p[0] * T[0] + p[1] * T[3] + p[2] * T[6] + p[3] * T[9];
-      float y = p[0] * T[1] + p[1] * T[4] + p[2] * T[7] + p[3] * T[10];
-      float z = p[0] * T[2] + p[1] * T[5] + p[2] * T[8] + p[3] * T[11];
-      float uu = f * x / z + cx, vv = f * y / z + cy;
-      if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) continue;
-      float ip = prev[(size_t)v * fs + u];
-      float ic = interp32f(cur, fs, uu, vv);
-      float res = ip - ic;
-      chi2 += (double)(res * res);
-      ++nv;
-      if (do_jac) {
-        float gx = 0.5f * interp32f(dxi, fs, uu, vv), gy = 0.5f * interp32f(dyi, fs, uu, vv);
-        float zsq = z * z;
-        gx *= f; gy *= f;
-        float J[6];
-        J[0] = (float)(-gx * (1. / z));
-        J[1] = (float)(-gy * 1. / z);
-        J[2] = (gx * x / zsq + gy * y / zsq);
-        J[3] = (gx * (x * y) / zsq + gy * (1.f + y * y / zsq));
-        J[4] = (-gx * (1.f + (x * x / zsq)) - gy * (x * y) / zsq);
-        J[5] = (gx * y / z - gy * x / z);
-        int k = 0;
-        for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) H[k++] += (double)(J[c] * J[r]);
-        for (int i = 0; i < 6; ++i) b[i] += (double)(J[i] * res);
-      }
-    }
-  memcpy(out->H, H, sizeof H); memcpy(out->b, b, sizeof b); out->chi2 = chi2; out->n_valid = nv;
+  svs_ref_dense_pass_full_ex(cloud, w, h, s4, prev, cur, dxi, dyi, fs, f, cx, cy, T, do_jac, 0, out);
 }
-/* gpu/dense_tracking.cu:495-541 residualImage_kernel (manual bilinear in place of the texture unit, as in
-   svs_ref_dense_pass_full) */
+/* gpu/dense_tracking.cu:495-541 residualImage_kernel */
 void svs_ref_residual_image_full(const float *cloud, int w, int h, int s4, const float *prev,
                                  const float *cur, int fs, float f, float cx, float cy, const float *T,
                                  float *rimg) {
@@ -602,15 +680,124 @@ void svs_ref_residual_image_full(const float *cloud, int w, int h, int s4, const
       const float *p = cloud + 4 * ((size_t)v * s4 + u);
       float *o = rimg + 4 * ((size_t)v * s4 + u);
       if (!(p[3] > 0)) { o[0] = 0.f; o[1] = 1.f; o[2] = 0.f; o[3] = 1.f; continue; }
-      float x = p[0] * T[0] + p[1] * T[3] + p[2] * T[6] + p[3] * T[9];
-      float y = p[0] * T[1] + p[1] * T[4] + p[2] * T[7] + p[3] * T[10];
-      float z = p[0] * T[2] + p[1] * T[5] + p[2] * T[8] + p[3] * T[11];
-      float uu = f * x / z + cx, vv = f * y / z + cy;
-      if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; o[3] = 1.f; continue; }
-      float res = prev[(size_t)v * fs + u] - interp32f(cur, fs, uu, vv);
+      float res, J[6];
+      if (!full_pixel(cloud, w, h, s4, prev, cur, 0, 0, fs, f, cx, cy, T, u, v, 0, &res, J)) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; o[3] = 1.f; continue; }
       float g = 1 - 50.f * res * res; if (g < 0.f) g = 0.f;
       o[0] = o[1] = o[2] = g; o[3] = 1.f;
     }
+}
+
+/* DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193): levels 2..0; chi2(); <= 15 iterations of
+   { jacobianReduction; H += mu diag(H); x = H.ldlt().solve(-b); T_new = exp(x) T; new_chi2 = chi2(T_new);
+     rho = chi2 - new_chi2 (float arithmetic); accept: stop = |b|_inf <= EPS, mu *= max(1/3, 1 - (2 rho - 1)^3), nu = 2,
+     trial = 0 | reject: mu *= nu, nu *= 2, two rejections in a row stop } while (!(rho > 0 || stop)).
+   Poses go to the kernels as GpuMatrix34 (f64 -> f32, column-major, :80-82,109-111,138-140).
+   rec (optional, cap records of 4 doubles): {level, accepted (1/0; 2 = the level's initial chi2), chi2 before, chi2 of
+   the trial}; T_jac (optional [3][12]): the pose of the last jacobianReduction of each level, which is the pose the
+   reference renders residualImage with (:177-186 pass gpuT_cur_from_prev, not the final pose).  Returns the number of
+   kernel passes the reference would have launched. */
+int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3], const float *const prev[3],
+                               const float *const cur[3], const float *const dx[3], const float *const dy[3],
+                               const int fstride[3], const int w[3], const int h[3], const double f[3],
+                               const double cx[3], const double cy[3], double *T, int sum_mode, double *rec, int rec_cap,
+                               int *n_rec, double *T_jac) {
+  int passes = 0, nr = 0;
+#define SVS_REC(l, a, c0, c1) do { if (rec && nr < rec_cap) { rec[4 * nr] = (l); rec[4 * nr + 1] = (a); rec[4 * nr + 2] = (c0); rec[4 * nr + 3] = (c1); } ++nr; } while (0)
+  for (int l = 2; l >= 0; --l) {
+    const float fl = (float)f[l], cxl = (float)cx[l], cyl = (float)cy[l];       /* GpuIntrinsics::set, .cuh:30-38 */
+    float Tf[12];
+    svs_dense_sums s;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) Tf[3 * c + r] = (float)T[4 * r + c];
+    svs_ref_dense_pass_full_ex(cloud[l], w[l], h[l], stride4[l], prev[l], cur[l], dx[l], dy[l], fstride[l], fl, cxl, cyl, Tf, 0, sum_mode, &s);
+    ++passes;
+    float chi2 = (float)s.chi2;
+    SVS_REC(l, 2, chi2, chi2);
+    double nu = 2, mu = 0.01f;
+    int stop = 0, trial = 0;
+    for (int i = 0; i < 15; ++i) {
+      double rho = 0;
+      do {
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) Tf[3 * c + r] = (float)T[4 * r + c];
+        if (T_jac) memcpy(T_jac + 12 * l, T, sizeof(double) * 12);
+        svs_ref_dense_pass_full_ex(cloud[l], w[l], h[l], stride4[l], prev[l], cur[l], dx[l], dy[l], fstride[l], fl, cxl, cyl, Tf, 1, sum_mode, &s);
+        ++passes;
+        double Hf[36], nb[6], x[6], E[12], Tn[12];
+        int k = 0;
+        for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { Hf[6 * r + c] = s.H[k]; Hf[6 * c + r] = s.H[k]; ++k; }   /* copyTo, .cuh:118-132 */
+        for (int q = 0; q < 6; ++q) Hf[7 * q] += mu * Hf[7 * q];                                                       /* H += mu diag(H) */
+        for (int q = 0; q < 6; ++q) nb[q] = -s.b[q];
+        solve_small(6, Hf, nb, x);
+        se3_exp(x, E);
+        pose_mul(E, T, Tn);
+        float Tnf[12];
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) Tnf[3 * c + r] = (float)Tn[4 * r + c];
+        svs_dense_sums s2;
+        svs_ref_dense_pass_full_ex(cloud[l], w[l], h[l], stride4[l], prev[l], cur[l], dx[l], dy[l], fstride[l], fl, cxl, cyl, Tnf, 0, sum_mode, &s2);
+        ++passes;
+        const float new_chi2 = (float)s2.chi2;
+        rho = chi2 - new_chi2;                      /* float - float, then widened (:142) */
+        SVS_REC(l, rho > 0 ? 1 : 0, chi2, new_chi2);
+        if (rho > 0) {
+          memcpy(T, Tn, sizeof(double) * 12);
+          chi2 = new_chi2;
+          double mx = 0; for (int q = 0; q < 6; ++q) if (fabs(s.b[q]) > mx) mx = fabs(s.b[q]);
+          stop = mx <= 1e-10;                       /* norm_max(b) <= EPS (global.h:106) */
+          const double t = 2 * rho - 1;
+          const double g = 1 - t * t * t;
+          mu *= (1. / 3. > g ? 1. / 3. : g);
+          nu = 2.;
+          trial = 0;
+        } else {
+          mu *= nu;
+          nu *= 2.;
+          ++trial;
+          if (trial == 2) stop = 1;
+        }
+      } while (!(rho > 0 || stop));
+      if (stop) break;
+    }
+    ++passes;                                       /* residualImage(gpuT_cur_from_prev) (:177-186) */
+  }
+#undef SVS_REC
+  if (n_rec) *n_rec = nr;
+  return passes;
+}
+
+/* FrameGrabber::preprocessing, CUDA build (frame_grabber.cpp:291-313): level 0 = gpu convertTo(CV_32F, 1/255.),
+   levels 1, 2 = cv::gpu::pyrDown of the f32 level above, and on every level dx / dy = the gpu derivative filters
+   created at :102-115 (ksize 1, cv::BORDER_REPLICATE).  OpenCV 2.4.2 gpu module is external -- ASSUMED semantics:
+   convertTo multiplies in float; pyrDown = separable [1 4 6 4 1]/16 in f32 (weights .0625 .25 .375 .25 .0625),
+   columns (vertical) first then rows, taps added in ascending order, BORDER_REFLECT_101, output ((w+1)/2, (h+1)/2)
+   sampled at (2x, 2y); derivative = I(x+1) - I(x-1) with clamped coordinates, no scaling. */
+static inline int refl101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; } return i; }
+void svs_ref_pyr_down_f32(const float *src, int w, int h, int ss, float *dst, int ds) {
+  const int ow = (w + 1) / 2, oh = (h + 1) / 2;
+  const float k0 = 0.0625f, k1 = 0.25f, k2 = 0.375f;
+  float *col = (float *)malloc(sizeof(float) * (size_t)w);
+  for (int y = 0; y < oh; ++y) {
+    const float *r0 = src + (size_t)refl101(2 * y - 2, h) * ss, *r1 = src + (size_t)refl101(2 * y - 1, h) * ss;
+    const float *r2 = src + (size_t)refl101(2 * y, h) * ss, *r3 = src + (size_t)refl101(2 * y + 1, h) * ss;
+    const float *r4 = src + (size_t)refl101(2 * y + 2, h) * ss;
+    for (int x = 0; x < w; ++x) { float a = k0 * r0[x]; a = a + k1 * r1[x]; a = a + k2 * r2[x]; a = a + k1 * r3[x]; a = a + k0 * r4[x]; col[x] = a; }
+    for (int x = 0; x < ow; ++x) {
+      float a = k0 * col[refl101(2 * x - 2, w)]; a = a + k1 * col[refl101(2 * x - 1, w)]; a = a + k2 * col[refl101(2 * x, w)];
+      a = a + k1 * col[refl101(2 * x + 1, w)]; a = a + k0 * col[refl101(2 * x + 2, w)];
+      dst[(size_t)y * ds + x] = a;
+    }
+  }
+  free(col);
+}
+void svs_ref_deriv_replicate(const float *img, int w, int h, int s, float *dx, float *dy, int ds) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1, ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+      dx[(size_t)y * ds + x] = img[(size_t)y * s + xp] - img[(size_t)y * s + xm];
+      dy[(size_t)y * ds + x] = img[(size_t)yp * s + x] - img[(size_t)ym * s + x];
+    }
+}
+void svs_ref_convert_f32(const uint8_t *src, int w, int h, int ss, float *dst, int ds) {
+  const float sc = (float)(1. / 255.);
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) dst[(size_t)y * ds + x] = (float)src[(size_t)y * ss + x] * sc;
 }
 void svs_ref_pointcloud_full(const float *TQ, const float *disp, int w, int h, int si, int so,
                              int factor, float *cloud) {

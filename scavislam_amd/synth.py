@@ -260,3 +260,55 @@ def shard_landmarks(edges, L, n_shards, chunk=64):
         mask = owner[edges["point"]] == s
         out.append((ids, mask))
     return out
+
+
+# ---- full-resolution dense tracking (BASELINE config 5: RGB-D 640x480 depth frames) -----------------------------
+def level_cams(cam, levels=3):
+    """cam_vec of frame_grabber-impl.cpp:48-60: f / 2^l, pp / 2^l, size / 2^l, baseline * 2^l."""
+    return [dict(f=cam["f"] / (1 << l), cx=cam["cx"] / (1 << l), cy=cam["cy"] / (1 << l), b=cam["b"] * (1 << l),
+                 w=cam["w"] >> l, h=cam["h"] >> l) for l in range(levels)]
+
+
+def cloud_full_level(disp0, cam, level):
+    """float4 cloud of one pyramid level at full level resolution from the level-0 disparity image: metrically correct
+    points (x, y, z, 1) in the frame's own coordinates, (0, 0, 0, -1) where there is no depth.  (The reference's
+    pointcloud_kernel has two indexing quirks on levels > 0; trackers take the cloud as an input.)"""
+    c = level_cams(cam)[level]
+    d = disp0[::1 << level, ::1 << level][:c["h"], :c["w"]].astype(np.float64)
+    u, v = np.meshgrid(np.arange(c["w"], dtype=np.float64), np.arange(c["h"], dtype=np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = cam["f"] * cam["b"] / d
+    ok = d > 0
+    out = np.zeros((c["h"], c["w"], 4), np.float32)
+    out[..., 0] = np.where(ok, (u - c["cx"]) * z / c["f"], 0)
+    out[..., 1] = np.where(ok, (v - c["cy"]) * z / c["f"], 0)
+    out[..., 2] = np.where(ok, z, 0)
+    out[..., 3] = np.where(ok, 1.0, -1.0)
+    return out
+
+
+def depth_holes(disp, rng, frac=0.10):
+    """invalid-depth blobs as an RGB-D sensor leaves them (10 % invalid pixels in blobs)"""
+    h, w = disp.shape
+    out = disp.copy()
+    area = 0
+    while area < frac * h * w:
+        x0, y0 = rng.integers(0, w), rng.integers(0, h)
+        sx, sy = rng.integers(4, max(5, w // 10)), rng.integers(4, max(5, h // 10))
+        out[y0:y0 + sy, x0:x0 + sx] = 0
+        area += sx * sy
+    return out
+
+
+def dense_full_case(cam=None, seed=2013, step=0.03, yaw_deg=0.3, holes=True, scene=None, frame=3):
+    """Two consecutive frames for the full-resolution tracker: previous image + its disparity (with holes), current image,
+    and the true T_cur_from_prev.  Returns dict(img_prev, img_cur, disp_prev, T_true, cam)."""
+    cam = dict(CAM_RGBD if cam is None else cam)
+    sc = scene or Scene(seed)
+    traj = trajectory(frame + 2, step=step, yaw_deg=yaw_deg)
+    T_p, T_c = traj[frame], traj[frame + 1]
+    img_p, disp_p = sc.render(cam, T_p, seed=seed)
+    img_c, _ = sc.render(cam, T_c, seed=seed + 1)
+    if holes:
+        disp_p = depth_holes(disp_p, np.random.default_rng(seed + 5))
+    return dict(img_prev=img_p, img_cur=img_c, disp_prev=disp_p, T_true=pose_mul(T_c, pose_inv(T_p)), cam=cam)
