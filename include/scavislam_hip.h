@@ -111,6 +111,11 @@ typedef struct svs_ctx svs_ctx;
 int svs_ctx_create(int device, void *hip_stream, svs_ctx **out);
 int svs_ctx_destroy(svs_ctx *ctx);
 int svs_ctx_sync(svs_ctx *ctx);
+/* experiment / test switches (0 = automatic choice): "trk_nwg" workgroups per stream of the latency-mode quarter-grid
+   tracker, "trk_regs" its register budget (1: one workgroup per CU, 2: two), "full_nwg" workgroups per stream of the
+   full-resolution tracker.  The environment (SVS_TRK_NWG, SVS_TRK_ONE_PER_CU / SVS_TRK_TWO_PER_CU, SVS_FULL_NWG) only
+   supplies the initial values, read once by svs_ctx_create. */
+int svs_ctx_set_option(svs_ctx *ctx, const char *name, int value);
 void *svs_ctx_stream(svs_ctx *ctx);
 const char *svs_last_error(svs_ctx *ctx);
 int svs_malloc(svs_ctx *ctx, size_t bytes, void **d_ptr);
@@ -277,6 +282,47 @@ int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t 
                                      const uint8_t *d_cur_u8, int c8stride, size_t c8_bstride,
                                      const svs_cam *cam, const double *d_T, size_t T_bstride,
                                      float *d_res_img4, size_t res_bstride, int batch);
+/* ---- full-resolution dense tracker: the CUDA build's DenseTracker / GpuTracker (dense_tracking.cpp:60-215,
+   gpu/dense_tracking.cuh:281-342).  Per-pixel arithmetic = the reference's f32 code (pinned against the reference-compiled
+   kernels, oracle/_ref); sums in f64.  The texture fetch tex2D(uv + 0.5f) is the exact-weight bilinear at
+   RN(uv + 0.5f) - 0.5f with clamp addressing. ------------------------------------------------------------------------*/
+/* FrameGrabber::preprocessing, CUDA branch (frame_grabber.cpp:291-313; filters :102-115): level 0 = convertTo(CV_32F, 1/255.),
+   level l = gpu::pyrDown(level l-1) on f32, dx / dy = ksize-1 derivative with BORDER_REPLICATE on every level.
+   d_img / d_dx / d_dy: `levels` device pointers each; level l has size ((w+1)/2.., (h+1)/2..). [cv::gpu is external: semantics
+   as restated in oracle/vision.c] */
+int svs_preprocess_gpu_sem(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride,
+                           float *const *d_img, float *const *d_dx, float *const *d_dy, const int32_t *fstride,
+                           const size_t *f_bstride, int levels, int batch);
+typedef struct {                       /* one entry per chi2 evaluation of denseTrackingGpu's loop */
+  int32_t level;
+  int32_t accepted;                    /* 1 / 0 = trial accepted / rejected (rho > 0, dense_tracking.cpp:142-144); 2 = the level's initial chi2 */
+  float chi2, new_chi2;                /* chi2 before the trial, chi2 at the trial pose (both `float` in the reference) */
+} svs_dense_lm_record;
+typedef struct {
+  const float *d_cloud4[3]; int32_t stride_f4[3]; size_t cloud_bstride[3];   /* dev_ref_dense_points_[l]: float4 per pixel, strides in float4 */
+  const float *d_prev[3];              /* prev_left().gpu_pyr_float32[l] */
+  const float *d_cur[3];               /* cur_left().gpu_pyr_float32[l] */
+  const float *d_dx[3], *d_dy[3];      /* gpu_pyr_float32_dx / _dy[l]; all NULL => the derivative taps are formed on the fly from d_cur
+                                          (I(x+1) - I(x-1), REPLICATE: bit-identical to the filters of frame_grabber.cpp:102-115, 8 B/px less) */
+  int32_t stride_f[3]; size_t f_bstride[3];
+  int32_t w[3], h[3];
+  double f[3], cx[3], cy[3];           /* cam_vec[l] intrinsics (narrowed to float as GpuIntrinsics::set does) */
+  double *d_T_jac_out;                 /* optional [batch][3][12]: pose of the last jacobianReduction of each level = the pose the reference
+                                          renders residualImage with (dense_tracking.cpp:177-186) */
+  svs_dense_lm_record *d_record_out;   /* optional [batch][record_cap] */
+  int32_t record_cap;
+  int32_t *d_n_record_out;             /* optional [batch]: records the loop produced (may exceed record_cap; only the first cap are stored) */
+} svs_dense_track_full_args;
+/* whole DenseTracker::denseTrackingGpu(SE3*) (dense_tracking.cpp:60-193) for `batch` independent streams in ONE launch: levels 2..0,
+   damped LM (H += mu diag(H), mu0 = 0.01f), <= 15 accepted steps per level, two rejections in a row stop.  d_T_io [batch][12] in/out.
+   d_passes_out [batch] (optional): fused sweeps executed (one per chi2 evaluation), or -1 if the stream's workgroups could not
+   synchronise (device oversubscribed; T is then unchanged garbage-free but NOT converged). */
+int svs_dense_track_full(svs_ctx *ctx, const svs_dense_track_full_args *a, double *d_T_io, int32_t *d_passes_out, int batch);
+/* parity probe: per-pixel terms of jacobianReduction_kernel before its reduction, d_terms8[v * w + u] = {J0..J5, res, valid};
+   d_dx == d_dy == NULL selects the on-the-fly derivative taps */
+int svs_dense_pixel_terms_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                               const float *d_cur, const float *d_dx, const float *d_dy, int stride_f, float f, float cx,
+                               float cy, const float *h_T34_colmajor, float *d_terms8);
 /* GpuTracker::jacobianReduction / chi2 (gpu/dense_tracking.cuh:291-342, .cu:172-263,376-453):
    full resolution, f32, no clamp; T is GpuMatrix34 (12 floats column-major) by value */
 int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4,

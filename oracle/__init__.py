@@ -484,6 +484,19 @@ def dense_pass_full_ex(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor, do_jac
     return out[0]
 
 
+def dense_pixel_terms_full(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor):
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    h, w = cloud.shape[:2]
+    prev, cur, dx, dy = [np.ascontiguousarray(a, np.float32) for a in (prev, cur, dx, dy)]
+    T = np.ascontiguousarray(T34_colmajor, np.float32).reshape(12)
+    out = np.zeros((h, w, 8), np.float32)
+    L = lib()
+    L.svs_ref_dense_pixel_terms_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + \
+        [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.svs_ref_dense_pixel_terms_full(_p(cloud), w, h, w, _p(prev), _p(cur), _p(dx), _p(dy), w, f, cx, cy, _p(T), _p(out))
+    return out
+
+
 def dense_tracking_gpu(cloud, prev, cur, dx, dy, f, cx, cy, T, sum_mode=SUM_F64):
     """DenseTracker::denseTrackingGpu restated (dense_tracking.cpp:60-193).  cloud/prev/cur/dx/dy: lists of 3 level
     arrays; f, cx, cy: per-level intrinsics.  Returns (T 3x4, passes, records [n][4], T_jac [3][3][4])."""

@@ -220,6 +220,9 @@ void svs_ref_dense_pass_full_ex(const float *cloud, int w, int h, int stride4,
                                 const float *prev, const float *cur, const float *dx,
                                 const float *dy, int fstride, float f, float cx, float cy,
                                 const float T34_colmajor[12], int do_jac, int sum_mode, svs_dense_sums *out);
+void svs_ref_dense_pixel_terms_full(const float *cloud, int w, int h, int stride4, const float *prev, const float *cur,
+                                    const float *dx, const float *dy, int fstride, float f, float cx, float cy,
+                                    const float T34_colmajor[12], float *out8);
 /* DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193); see vision.c */
 int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3], const float *const prev[3],
                                const float *const cur[3], const float *const dx[3], const float *const dy[3],

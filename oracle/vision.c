@@ -608,6 +608,20 @@ static inline int full_pixel(const float *cloud, int w, int h, int s4, const flo
   }
   return 1;
 }
+/* per-pixel terms of jacobianReduction_kernel before its reduction: out[v * w + u] = {J0..J5, res, valid} (zeros where the
+   pixel does not contribute) -- what the HIP path's svs_dense_pixel_terms_full must reproduce bit for bit */
+void svs_ref_dense_pixel_terms_full(const float *cloud, int w, int h, int s4, const float *prev, const float *cur,
+                                    const float *dxi, const float *dyi, int fs, float f, float cx, float cy, const float *T,
+                                    float *out) {
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      float res = 0, J[6] = {0, 0, 0, 0, 0, 0};
+      const int ok = full_pixel(cloud, w, h, s4, prev, cur, dxi, dyi, fs, f, cx, cy, T, u, v, 1, &res, J);
+      float *o = out + 8 * ((size_t)v * w + u);
+      for (int i = 0; i < 6; ++i) o[i] = ok ? J[i] : 0.f;
+      o[6] = ok ? res : 0.f; o[7] = ok ? 1.f : 0.f;
+    }
+}
 /* sum_mode SVS_SUM_F64 (0): f32 per-pixel products accumulated in f64, row-major (what the product is compared with);
    sum_mode SVS_SUM_F32_TREE (1): the reference's arithmetic to the last bit -- per 8x8 block a 64-slot f32 array
    reduced as `s[t] += s[t+off]`, off = 32,16,...,1, lanes t < 32 in lockstep and only lanes inside the image taking

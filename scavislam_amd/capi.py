@@ -30,6 +30,16 @@ class DenseTrackArgs(C.Structure):
                 ("d_T_jac_out", C.c_void_p)]
 
 
+class DenseTrackFullArgs(C.Structure):
+    _fields_ = [("d_cloud4", C.c_void_p * 3), ("stride_f4", C.c_int32 * 3), ("cloud_bstride", C.c_size_t * 3),
+                ("d_prev", C.c_void_p * 3), ("d_cur", C.c_void_p * 3), ("d_dx", C.c_void_p * 3), ("d_dy", C.c_void_p * 3),
+                ("stride_f", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3),
+                ("w", C.c_int32 * 3), ("h", C.c_int32 * 3),
+                ("f", C.c_double * 3), ("cx", C.c_double * 3), ("cy", C.c_double * 3),
+                ("d_T_jac_out", C.c_void_p), ("d_record_out", C.c_void_p), ("record_cap", C.c_int32),
+                ("d_n_record_out", C.c_void_p)]
+
+
 class MatchArgs(C.Structure):
     _fields_ = [("d_kfs", C.c_void_p), ("n_kf", C.c_int32),
                 ("d_pts", C.c_void_p), ("n_pts", C.c_int32),
@@ -45,6 +55,7 @@ _SIGS = {
     "svs_ctx_create": [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)],
     "svs_ctx_destroy": [C.c_void_p],
     "svs_ctx_sync": [C.c_void_p],
+    "svs_ctx_set_option": [C.c_void_p, C.c_char_p, C.c_int],
     "svs_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "svs_free": [C.c_void_p, C.c_void_p],
     "svs_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
@@ -77,6 +88,11 @@ _SIGS = {
                                          C.POINTER(Cam), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int],
     "svs_dense_residual_image_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "svs_preprocess_gpu_sem": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.c_int, C.c_int],
+    "svs_dense_track_full": [C.c_void_p, C.POINTER(DenseTrackFullArgs), C.c_void_p, C.c_void_p, C.c_int],
+    "svs_dense_pixel_terms_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "svs_dense_pass_full": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                             C.c_int, C.c_void_p],
@@ -150,6 +166,10 @@ class Context:
 
     def sync(self):
         self.check(self.lib.svs_ctx_sync(self.h))
+
+    def set_option(self, name, value):
+        """experiment / test switches of the context (see svs_ctx_set_option in the header)"""
+        self.call("svs_ctx_set_option", name.encode(), int(value))
 
     def timer_start(self):
         self.check(self.lib.svs_timer_start(self.h))

@@ -1,8 +1,7 @@
 // dense.hip -- dense (direct) SE3 tracking for gfx950.
 // Replaces DenseTracker::denseTrackingCpu / computeDensePointCloudCpu
-// (dense_tracking.cpp:222-423; the parity target, SURVEY.md section 0 last row) and the four
-// CUDA kernels of gpu/dense_tracking.cu (pointcloud :82-122, jacobianReduction :172-263,
-// chi2 :376-453) behind the GpuTracker call surface (gpu/dense_tracking.cuh:281-342).
+// (dense_tracking.cpp:222-423; the parity target, SURVEY.md section 0 last row).  The CUDA build's
+// full-resolution tracker (GpuTracker, denseTrackingGpu) lives in dense_full.hip.
 //
 // MI355X-first design:
 //  * per-sample work is a gather (cloud, 4-tap bilinear of cur/dx/dy) + 27 accumulators; the
@@ -534,129 +533,13 @@ __global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__
   reinterpret_cast<float4 *>(cloud + slot * cloud_b)[i] = o;
 }
 
-// ---- full-resolution f32 variant (gpu/dense_tracking.cu semantics) ---------------------------
-struct T34 { float m[12]; };
-struct T44 { float m[16]; };
-
-template <bool JAC>
-__global__ __launch_bounds__(256) void dense_pass_full_kernel(const float *__restrict__ cloud, int w, int h, int s4,
-                                                              const float *__restrict__ prev, const float *__restrict__ cur,
-                                                              const float *__restrict__ dxi, const float *__restrict__ dyi, int fs,
-                                                              float f, float cx, float cy, T34 T, double *__restrict__ partials) {
-  __shared__ double s_part[4][NSUM + 1];
-  __shared__ double s_out[NSUM + 1];
-  Acc a;
-  a.zero();
-  // 64x4 pixel tiles: a wavefront reads one contiguous 64-pixel row segment (1 KiB of float4)
-  const int tiles_x = div_up(w, 64), tiles_y = div_up(h, 4);
-  for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
-    const int u = (t % tiles_x) * 64 + (threadIdx.x & 63), v = (t / tiles_x) * 4 + (threadIdx.x >> 6);
-    if (u >= w || v >= h) continue;
-    const float4 p = reinterpret_cast<const float4 *>(cloud)[(size_t)v * s4 + u];
-    if (!(p.w > 0)) continue;
-    const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];
-    const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
-    const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
-    const float uu = f * x / z + cx, vv = f * y / z + cy;
-    if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2))) continue;
-    const float ip = prev[(size_t)v * fs + u];
-    const float ic = interp32f(cur, fs, uu, vv);
-    const float res = ip - ic;
-    a.v[27] += (double)(res * res);
-    a.n += 1;
-    if (JAC) {
-      float gx = 0.5f * interp32f(dxi, fs, uu, vv), gy = 0.5f * interp32f(dyi, fs, uu, vv);
-      const float zsq = z * z;
-      gx *= f; gy *= f;
-      float J[6];
-      J[0] = (float)(-gx * (1. / z));
-      J[1] = (float)(-gy * 1. / z);
-      J[2] = (gx * x / zsq + gy * y / zsq);
-      J[3] = (gx * (x * y) / zsq + gy * (1.f + y * y / zsq));
-      J[4] = (-gx * (1.f + (x * x / zsq)) - gy * (x * y) / zsq);
-      J[5] = (gx * y / z - gy * x / z);
-      int k = 0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int r = 0; r <= c; ++r) a.v[k++] += (double)(J[c] * J[r]);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) a.v[21 + i] += (double)(J[i] * res);
-    }
-  }
-  block_reduce<4>(a, s_part, s_out);
-  if (threadIdx.x <= NSUM) partials[(size_t)blockIdx.x * (NSUM + 1) + threadIdx.x] = s_out[threadIdx.x];
-}
-
-__global__ void dense_finalize_full_kernel(const double *__restrict__ partials, int nblocks, svs_dense_sums *__restrict__ out) {
-  const int t = threadIdx.x;
-  if (t > NSUM) return;
-  double s = 0;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * (NSUM + 1) + t];
-  if (t < 21) out->H[t] = s;
-  else if (t < 27) out->b[t - 21] = s;
-  else if (t == 27) out->chi2 = s;
-  else out->n_valid = (long long)s;
-}
-
-// residualImage_kernel (gpu/dense_tracking.cu:495-541)
-__global__ __launch_bounds__(256) void residual_image_full_kernel(const float *__restrict__ cloud, int w, int h, int s4,
-                                                                  const float *__restrict__ prev, const float *__restrict__ cur, int fs,
-                                                                  float f, float cx, float cy, T34 T, float *__restrict__ rimg) {
-  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (u >= w || v >= h) return;
-  const float4 p = reinterpret_cast<const float4 *>(cloud)[(size_t)v * s4 + u];
-  float4 o = make_float4(0.f, 1.f, 0.f, 1.f);
-  if (p.w > 0) {
-    const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];
-    const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
-    const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
-    const float uu = f * x / z + cx, vv = f * y / z + cy;
-    o = make_float4(1.f, 0.f, 0.f, 1.f);
-    if (uu >= 1.f && vv >= 1.f && uu <= (float)(w - 2) && vv <= (float)(h - 2)) {
-      const float res = prev[(size_t)v * fs + u] - interp32f(cur, fs, uu, vv);
-      float g = 1 - 50.f * res * res;
-      if (g < 0.f) g = 0.f;
-      o = make_float4(g, g, g, 1.f);
-    }
-  }
-  reinterpret_cast<float4 *>(rimg)[(size_t)v * s4 + u] = o;
-}
-
-__global__ __launch_bounds__(256) void pointcloud_full_kernel(T44 TQ, const float *__restrict__ disp, int w, int h, int si, int so,
-                                                              int factor, float *__restrict__ cloud) {
-  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (u >= w || v >= h) return;
-  const float d = disp[(size_t)v * si + u * factor] * factor;     // row not scaled: .cu:97-98 quirk kept
-  float4 o;
-  if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
-  else {
-    const float q[4] = {(float)u, (float)v, d, 1.f};
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = q[0] * TQ.m[i] + q[1] * TQ.m[4 + i] + q[2] * TQ.m[8 + i] + q[3] * TQ.m[12 + i];
-    o = make_float4(r[0] / r[3], r[1] / r[3], r[2] / r[3], 1.f);
-  }
-  reinterpret_cast<float4 *>(cloud)[(size_t)v * so + u] = o;
-}
-
-// per-ctx scratch for block partials (one allocation, grown on demand, owned by a static map-free
-// slot inside the ctx would need ctx changes; keep it simple: allocate per call size class)
-struct Scratch { double *p = nullptr; size_t n = 0; };
-
 }  // namespace
 
-static int ensure_scratch(svs_ctx *ctx, double **p, size_t count) {
-  // scratch lives in a thread-local cache keyed by ctx (one ctx per calling thread)
-  static thread_local svs_ctx *owner = nullptr;
-  static thread_local Scratch sc;
-  if (owner != ctx || sc.n < count) {
-    if (sc.p) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(sc.p); sc.p = nullptr; sc.n = 0; }
-    SVS_HIP(ctx, hipMalloc(&sc.p, count * sizeof(double)));
-    sc.n = count; owner = ctx;
-  }
-  *p = sc.p;
-  return SVS_OK;
+static int ensure_scratch(svs_ctx *ctx, double **p, size_t count) {      // ctx-owned (common.h)
+  void *v = nullptr;
+  const int rc = svs_ctx_scratch(ctx, count * sizeof(double), &v);
+  *p = static_cast<double *>(v);
+  return rc;
 }
 
 extern "C" int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride,
@@ -711,7 +594,7 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
   // latency mode: with few streams, NW workgroups share each stream's sweeps (they must all be resident: NW * batch <= 128 CUs)
   int nwg = batch <= 32 ? 4 : 1;      // measured (B = 1 / 8): 4 workgroups 0.26 ms / 19.4k fps, 8: 0.26 / 15.6k, 16: 0.28 / 10.4k, 1: 0.34 / 14.4k;
                                       // 2 per stream at 64 streams lose to one (barrier + redundant LM tails)
-  if (const char *e = getenv("SVS_TRK_NWG")) nwg = std::max(1, atoi(e));
+  if (ctx->trk_nwg) nwg = ctx->trk_nwg;
   TrackMulti G{nullptr, nullptr};
   if (nwg >= 2) {
     double *scratch = nullptr;
@@ -723,7 +606,7 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (size_t)batch, ctx->stream));
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-  } else if ((batch > ctx->n_cu && !getenv("SVS_TRK_ONE_PER_CU")) || getenv("SVS_TRK_TWO_PER_CU")) {      // env: tests / experiments
+  } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else {
@@ -748,51 +631,6 @@ extern "C" int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_clo
   else
     hipLaunchKernelGGL(residual_image_cpu_sem_kernel<false>, dim3(div_up(n, 256), batch), dim3(256), 0, ctx->stream, L, cloud_bstride, p_bstride,
                        f_bstride, c8_bstride, d_T, T_bstride, d_res_img4, res_bstride);
-  SVS_LAUNCH_CHECK(ctx);
-  return SVS_OK;
-}
-
-extern "C" int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
-                                             const float *d_cur, int stride_f, float f, float cx, float cy, const float *h_T,
-                                             float *d_res_img4) {
-  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_res_img4 && w > 0 && h > 0);
-  T34 T;
-  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
-  hipLaunchKernelGGL(residual_image_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4,
-                     d_prev, d_cur, stride_f, f, cx, cy, T, d_res_img4);
-  SVS_LAUNCH_CHECK(ctx);
-  return SVS_OK;
-}
-
-extern "C" int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
-                                   const float *d_cur, const float *d_dx, const float *d_dy, int stride_f, float f,
-                                   float cx, float cy, const float *h_T, int do_jac, svs_dense_sums *d_out) {
-  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_out && w > 0 && h > 0);
-  SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
-  T34 T;
-  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
-  int ntiles = div_up(w, 64) * div_up(h, 4);
-  int nblocks = std::min(ntiles, 1024);
-  double *part = nullptr;
-  int rc = ensure_scratch(ctx, &part, (size_t)nblocks * (NSUM + 1));
-  if (rc) return rc;
-  if (do_jac)
-    hipLaunchKernelGGL(dense_pass_full_kernel<true>, dim3(nblocks), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy, T, part);
-  else
-    hipLaunchKernelGGL(dense_pass_full_kernel<false>, dim3(nblocks), dim3(256), 0, ctx->stream, d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy, T, part);
-  SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(dense_finalize_full_kernel, dim3(1), dim3(64), 0, ctx->stream, part, nblocks, d_out);
-  SVS_LAUNCH_CHECK(ctx);
-  return SVS_OK;
-}
-
-extern "C" int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ, const float *d_disp, int w, int h, int stride_in,
-                                   int stride_out, int factor, float *d_cloud4) {
-  SVS_REQUIRE(ctx, ctx && h_TQ && d_disp && d_cloud4 && w > 0 && h > 0 && factor >= 1);
-  T44 TQ;
-  for (int i = 0; i < 16; ++i) TQ.m[i] = h_TQ[i];
-  hipLaunchKernelGGL(pointcloud_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, TQ, d_disp, w, h,
-                     stride_in, stride_out, factor, d_cloud4);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -1,0 +1,729 @@
+// dense_full.hip -- full-resolution dense SE3 tracking for gfx950: the CUDA build's tracker.
+// Replaces DenseTracker::denseTrackingGpu / computeDensePointCloudGpu (dense_tracking.cpp:60-215), the GpuTracker class
+// with its four kernels (gpu/dense_tracking.cuh:281-342, gpu/dense_tracking.cu:82-569) and the CUDA branch of
+// FrameGrabber::preprocessing (frame_grabber.cpp:291-313, filters :102-115).
+//
+// Arithmetic contract (oracle/vision.c, pinned bit for bit against the reference-compiled kernels in oracle/_ref):
+// every per-pixel quantity -- transformed point, projection, in-frame test, texture position RN(uv + 0.5f) - 0.5f,
+// bilinear taps, residual, the six Jacobian entries incl. the reference's `1./p.z` double promotions -- is the f32 value
+// the reference's code produces (no contraction; svs_dense_pixel_terms_full exposes them for the bit-exact test).
+// Only the accumulator differs: the reference adds 27 f32 numbers through an 8x8 shared-memory tree, per-block results on
+// the host; here they are f64 sums (more accurate than the reference, deterministic, fixed order).
+//
+// MI355X-first design:
+//  * ONE launch per frame batch runs the whole coarse-to-fine damped LM (3 levels x <= 15 accepted steps): the reference
+//    pays a launch + device synchronisation + D2H copy per pass, and two passes per trial.
+//  * ONE fused sweep per trial: chi2 at the trial pose and H,b at the same pose come from the same per-pixel terms, so the
+//    reference's chi2(T_new) pass and the jacobianReduction(T) pass that follows an accepted step are one read of the
+//    32 B/px (cloud 16, previous intensity 4, current image + two gradient images 12); after a rejected step the old H,b
+//    are re-damped without touching memory.
+//  * a stream's pixels are shared by NWG workgroups (NWG * streams ~ the chip's resident workgroups); partial sums meet at
+//    the stream's leader workgroup through write-through (sc1) 8-byte words + one arrival counter, the leader adds them in
+//    a fixed order, takes the LM step on one lane and publishes the next pose the same way: no grid-wide barrier, no fence
+//    that would flush an XCD's L2 (MI355X_MICROARCH.md, "inter-workgroup visibility").  With >= 1 stream per resident
+//    workgroup slot NWG is 1 and nothing leaves the workgroup.
+//  * divisions: one IEEE reciprocal per denominator + a 3-instruction correctly rounded quotient (Markstein) instead of
+//    twelve ~10-instruction IEEE divisions; the f64-promoted entries J0, J1 reduce to f32 quotients exactly (double
+//    rounding through f64 is innocuous for a quotient of two f32 numbers, and a 2^-52 perturbation cannot reach an f32
+//    rounding boundary, which a quotient of two 24-bit numbers misses by >= 2^-49 relative).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int NS = 28;                 // 21 H (packed upper by column) + 6 b + chi2; n_valid rides along as the 29th value
+constexpr int FULL_THREADS = 256;
+constexpr int FULL_WAVES = FULL_THREADS / 64;
+
+struct FullLevel {
+  const float4 *cloud; const float *prev, *cur, *dx, *dy;
+  int w, h, s4, fs;
+  float f, cx, cy;
+};
+struct M34 { float m[12]; };           // GpuMatrix34: column-major 3x4 (gpu/dense_tracking.cuh:219-237)
+struct M44 { float m[16]; };
+
+// ---- exact f32 quotients sharing a denominator ------------------------------------------------------------------
+// r = RN(1 / z) (IEEE division); q = RN(a r); e = a - q z exactly (FMA); RN(q + e r) = RN(a / z) (Markstein: r correctly
+// rounded, q faithful).  Outside the safe exponent range (where a r could overflow / underflow first) fall back to IEEE.
+struct Recip { float z, r; bool safe; };
+__device__ __forceinline__ Recip recip(float z) {
+  Recip R;
+  R.z = z; R.r = 1.0f / z;
+  const float az = fabsf(z);
+  R.safe = az > 1e-18f && az < 1e18f;
+  return R;
+}
+__device__ __forceinline__ float quot(float a, const Recip &R) {
+  const float q = a * R.r;
+  const float e = __builtin_fmaf(-q, R.z, a);
+  const float q2 = __builtin_fmaf(e, R.r, q);
+  const float aa = fabsf(a);
+  // a == +-0: q already carries the IEEE sign of the zero quotient (the correction step would turn -0 into +0)
+  return a == 0.f ? q : ((R.safe && aa < 1e18f && aa > 1e-18f) ? q2 : a / R.z);
+}
+
+// texture fetch of the reference: tex2D(tex, uv.x + 0.5f, uv.y + 0.5f), linear filter, clamp addressing
+// (gpu/dense_tracking.cu:206-215).  (xt, yt) = uv + 0.5f as the reference forms it; the unit samples at (xt, yt) - 0.5.
+struct TexPos { int i0, i1, j0, j1; float w00, w01, w10, w11; };
+__device__ __forceinline__ TexPos tex_pos(float xt, float yt, int w, int h) {
+  TexPos P;
+  const float xb = xt - 0.5f, yb = yt - 0.5f;
+  const float fi = floorf(xb), fj = floorf(yb);
+  const float sx = xb - fi, sy = yb - fj;
+  const float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+  const int i = (int)fi, j = (int)fj;
+  P.i0 = min(max(i, 0), w - 1); P.i1 = min(max(i + 1, 0), w - 1);
+  P.j0 = min(max(j, 0), h - 1); P.j1 = min(max(j + 1, 0), h - 1);
+  P.w00 = wx0 * wy0; P.w01 = wx0 * wy1; P.w10 = wx1 * wy0; P.w11 = wx1 * wy1;     // (x,y) (x,y+1) (x+1,y) (x+1,y+1)
+  return P;
+}
+__device__ __forceinline__ float tex_fetch(const float *__restrict__ m, int stride, const TexPos &P) {
+  const float v00 = m[(size_t)P.j0 * stride + P.i0], v01 = m[(size_t)P.j1 * stride + P.i0];
+  const float v10 = m[(size_t)P.j0 * stride + P.i1], v11 = m[(size_t)P.j1 * stride + P.i1];
+  return P.w00 * v00 + P.w01 * v01 + P.w10 * v10 + P.w11 * v11;
+}
+
+// One thread of jacobianReduction_kernel / chi2_kernel up to its reduction (gpu/dense_tracking.cu:193-221, :395-411).
+// Returns whether the pixel contributes; res and (JAC) J[6] are the reference's f32 values.
+// FUSE: dx / dy images are not read; their taps are formed from the current image as the reference's derivative filter
+// defines them (I(x+1) - I(x-1), I(y+1) - I(y-1), BORDER_REPLICATE: frame_grabber.cpp:102-115) -- bit-identical values.
+template <bool JAC, bool FUSE>
+__device__ __forceinline__ bool full_pixel(const FullLevel &L, const M34 &T, const float4 p, const float ip, float &res, float *J) {
+  if (!(p.w > 0)) return false;
+  const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];       // matTimesVec / dotStride3
+  const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
+  const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
+  const Recip Rz = recip(z);
+  const float uu = quot(L.f * x, Rz) + L.cx, vv = quot(L.f * y, Rz) + L.cy;          // cameraProject
+  if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(L.w - 2) && vv <= (float)(L.h - 2))) return false;
+  const TexPos P = tex_pos(uu + 0.5f, vv + 0.5f, L.w, L.h);
+  const float ic = tex_fetch(L.cur, L.fs, P);
+  res = ip - ic;
+  if (JAC) {
+    float gx, gy;
+    if (FUSE) {
+      // columns i0-1 .. i1+1 and rows j0-1 .. j1+1 of the current image, clamped (REPLICATE)
+      const int xm0 = max(P.i0 - 1, 0), xp0 = min(P.i0 + 1, L.w - 1), xm1 = max(P.i1 - 1, 0), xp1 = min(P.i1 + 1, L.w - 1);
+      const int ym0 = max(P.j0 - 1, 0), yp0 = min(P.j0 + 1, L.h - 1), ym1 = max(P.j1 - 1, 0), yp1 = min(P.j1 + 1, L.h - 1);
+      const float *r0 = L.cur + (size_t)P.j0 * L.fs, *r1 = L.cur + (size_t)P.j1 * L.fs;
+      const float dx00 = r0[xp0] - r0[xm0], dx01 = r1[xp0] - r1[xm0], dx10 = r0[xp1] - r0[xm1], dx11 = r1[xp1] - r1[xm1];
+      const float *c0m = L.cur + (size_t)ym0 * L.fs, *c0p = L.cur + (size_t)yp0 * L.fs, *c1m = L.cur + (size_t)ym1 * L.fs, *c1p = L.cur + (size_t)yp1 * L.fs;
+      const float dy00 = c0p[P.i0] - c0m[P.i0], dy01 = c1p[P.i0] - c1m[P.i0], dy10 = c0p[P.i1] - c0m[P.i1], dy11 = c1p[P.i1] - c1m[P.i1];
+      gx = 0.5f * (P.w00 * dx00 + P.w01 * dx01 + P.w10 * dx10 + P.w11 * dx11);
+      gy = 0.5f * (P.w00 * dy00 + P.w01 * dy01 + P.w10 * dy10 + P.w11 * dy11);
+    } else {
+      gx = 0.5f * tex_fetch(L.dx, L.fs, P);
+      gy = 0.5f * tex_fetch(L.dy, L.fs, P);
+    }
+    // frameJacobian (gpu/dense_tracking.cu:65-80)
+    const float zsq = z * z;
+    const Recip Rq = recip(zsq);
+    gx *= L.f; gy *= L.f;
+    J[0] = -quot(gx, Rz);                                   // (float)(-dx * (1. / p.z))
+    J[1] = -quot(gy, Rz);                                   // (float)(-dy * 1. / p.z)
+    J[2] = quot(gx * x, Rq) + quot(gy * y, Rq);
+    J[3] = quot(gx * (x * y), Rq) + gy * (1.f + quot(y * y, Rq));
+    J[4] = -gx * (1.f + quot(x * x, Rq)) - quot(gy * (x * y), Rq);
+    J[5] = quot(gx * y, Rz) - quot(gy * x, Rz);
+  }
+  return true;
+}
+
+struct AccF {
+  double v[NS];
+  int n;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) v[i] = 0;
+    n = 0;
+  }
+  // chi2 += (double)(res * res) as the restatement does; H and b take the exact products of the f32 terms (one f64 FMA each
+  // instead of an f32 product, a conversion and an f64 add: the sweep is issue-bound on its f64 instructions)
+  template <bool JAC> __device__ __forceinline__ void add(bool ok, float res, const float *J) {
+    const float r = ok ? res : 0.f;
+    v[27] += (double)(r * r);
+    n += ok ? 1 : 0;
+    if (JAC) {
+      double Jd[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Jd[i] = ok ? (double)J[i] : 0.0;
+      int k = 0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int q = 0; q <= c; ++q) { v[k] = __builtin_fma(Jd[c], Jd[q], v[k]); ++k; }
+      const double rd = (double)r;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[21 + i] = __builtin_fma(Jd[i], rd, v[21 + i]);
+    }
+  }
+};
+
+// workgroup reduction of the 29 values (recursive halving inside a wave: 32 f64 exchanges instead of 29 x 6 butterflies);
+// result in s_out[0..NS], valid for all threads after the trailing barrier
+__device__ __forceinline__ void full_block_reduce(const AccF &a, double (*s_part)[NS + 1], double *s_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double x[32];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) x[i] = a.v[i];
+  x[NS] = (double)a.n;
+#pragma unroll
+  for (int i = NS + 1; i < 32; ++i) x[i] = 0.0;
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const int half = 16 >> step, bit = 1 << step;
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double send = up ? x[k] : x[k + half];
+      const double keep = up ? x[k + half] : x[k];
+      x[k] = keep + __shfl_xor(send, bit, 64);
+    }
+  }
+  x[0] += __shfl_xor(x[0], 32, 64);
+  const int idx = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+  if (lane < 32 && idx <= NS) s_part[wave][idx] = x[0];
+  __syncthreads();
+  if (threadIdx.x <= NS) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < FULL_WAVES; ++w) s += s_part[w][threadIdx.x];
+    s_out[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// one sweep of this workgroup's share of a level: pixel groups of FULL_THREADS consecutive pixels (row-major over the
+// w x h image, so a wave reads 1 KiB of consecutive float4 cloud entries), groups dealt round-robin to the stream's
+// workgroups.  The T-independent loads of the next pixel (cloud entry, previous intensity) are issued before this
+// pixel's arithmetic; only the bilinear taps, whose addresses depend on the projection, are exposed.
+template <bool JAC, bool FUSE>
+__device__ __forceinline__ void full_sweep(const FullLevel &L, const M34 &T, int wg, int nwg, AccF &a) {
+  const int n = L.w * L.h;
+  const int step = FULL_THREADS * nwg;
+  const int su = step % L.w, sv = step / L.w;
+  int i = wg * FULL_THREADS + (int)threadIdx.x;
+  int u = i % L.w, v = i / L.w;
+  bool in = i < n;
+  float4 p = in ? L.cloud[(size_t)v * L.s4 + u] : make_float4(0.f, 0.f, 1.f, -1.f);
+  float ip = in ? L.prev[(size_t)v * L.fs + u] : 0.f;
+  for (; i < n; i += step) {
+    const float4 pc = p;
+    const float ipc = ip;
+    u += su; v += sv;
+    if (u >= L.w) { u -= L.w; ++v; }
+    in = i + step < n;
+    p = in ? L.cloud[(size_t)v * L.s4 + u] : make_float4(0.f, 0.f, 1.f, -1.f);
+    ip = in ? L.prev[(size_t)v * L.fs + u] : 0.f;
+    float res = 0.f, J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool ok = full_pixel<JAC, FUSE>(L, T, pc, ipc, res, J);
+    a.template add<JAC>(ok, res, J);
+  }
+}
+
+// ---- 6x6 solve + SE3 exp (as in dense.hip; the LM step runs on one lane) -----------------------------------------
+__device__ void f_solve6(const double *A, const double *b, double *x) {
+  double M[6][7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) M[i][j] = A[i * 6 + j];
+    M[i][6] = b[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(M[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; p = i; } }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool sw = p == i;
+#pragma unroll
+      for (int j = k; j < 7; ++j) { const double a = M[k][j], c = M[i][j]; M[k][j] = sw ? c : a; M[i][j] = sw ? a : c; }
+    }
+    const double piv = M[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = M[i][k] / piv;
+#pragma unroll
+      for (int j = k; j < 7; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s_ = M[i][6];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s_ -= M[i][j] * x[j];
+    x[i] = s_ / M[i][i];
+  }
+}
+__device__ void f_se3_exp_mul(const double *x, const double *T, double *Tn) {   // Tn = exp(x) * T
+  const double *w = x + 3;
+  double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+  double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, W2[9], R[9], V[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  double a, b;
+  if (th < 1e-10) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  for (int i = 0; i < 9; ++i) R[i] = a * W[i] + b * W2[i];
+  R[0] += 1; R[4] += 1; R[8] += 1;
+  if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
+  else {
+    double c = (1.0 - cos(th)) / th2, d = (th - sin(th)) / (th2 * th);
+    for (int i = 0; i < 9; ++i) V[i] = c * W[i] + d * W2[i];
+    V[0] += 1; V[4] += 1; V[8] += 1;
+  }
+  double t[3];
+  for (int i = 0; i < 3; ++i) t[i] = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+    Tn[4 * i + 3] += t[i];
+  }
+}
+
+// ---- cross-workgroup words: write-through stores / L1-bypassing loads, agent scope --------------------------------
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct TrackFullArgs {
+  FullLevel lv[3];
+  size_t cloud_b[3], f_b[3];
+  double *T_jac;                       // optional [batch][3][12]
+  svs_dense_lm_record *rec; int rec_cap;   // optional [batch][rec_cap]
+  int32_t *n_rec;                      // optional [batch]
+  // cross-workgroup hand-off area (nwg > 1): per stream [nwg][32] partial sums, 16 broadcast words, arrival counter, epoch
+  double *part; double *bcast; unsigned *count; unsigned *epoch;
+  int nwg;
+};
+
+enum { PH_INIT = 0, PH_TRIAL = 1 };
+constexpr long SPIN_LIMIT = 1l << 22;          // x s_sleep(2): seconds -- a sibling workgroup that never became resident
+
+// The whole DenseTracker::denseTrackingGpu loop of one stream (dense_tracking.cpp:60-193).
+template <bool FUSE, bool MULTI>
+__global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFullArgs A, double *__restrict__ T_io, int32_t *__restrict__ passes_out) {
+  __shared__ double s_part[FULL_WAVES][NS + 1];
+  __shared__ double s_out[NS + 1];
+  __shared__ double s_sum[NS + 1];
+  __shared__ double s_T[12], s_Teval[12], s_H[21], s_b[6], s_Tj[3][12];
+  __shared__ int s_ctl[2];             // level (or -1 when finished), failure flag
+  __shared__ double s_grp[8][32];      // leader: group sums of the other workgroups' partials
+  const int nwg = MULTI ? A.nwg : 1;
+  const int slot = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x % nwg : 0;
+  const int tid = threadIdx.x;
+  const bool leader = wg == 0;
+  double *part = MULTI ? A.part + (size_t)slot * nwg * 32 : nullptr;
+  double *bcast = MULTI ? A.bcast + (size_t)slot * 16 : nullptr;
+  unsigned *count = MULTI ? A.count + slot : nullptr, *epoch = MULTI ? A.epoch + slot : nullptr;
+  // LM state of the leader (lane 0 of workgroup 0)
+  float chi2 = 0.f;
+  double mu = 0.01f, nu = 2;           // `double mu = 0.01f` (dense_tracking.cpp:103)
+  int trial = 0, iter = 0, phase = PH_INIT, n_rec = 0;
+  if (tid < 12) { const double t = T_io[(size_t)slot * 12 + tid]; s_T[tid] = t; s_Teval[tid] = t; }
+  if (tid < 36) s_Tj[tid / 12][tid % 12] = T_io[(size_t)slot * 12 + tid % 12];
+  if (tid == 0) { s_ctl[0] = 2; s_ctl[1] = 0; }
+  __syncthreads();
+  int passes = 0;
+  for (;;) {
+    const int level = s_ctl[0];
+    if (level < 0) break;
+    FullLevel L = A.lv[level];
+    L.cloud += slot * A.cloud_b[level];
+    L.prev += slot * A.f_b[level]; L.cur += slot * A.f_b[level];
+    if (!FUSE) { L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level]; }
+    M34 T;                              // GpuMatrix34::set: f64 -> f32, column-major (dense_tracking.cpp:80-82)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) T.m[3 * c + r] = (float)s_Teval[4 * r + c];
+    AccF a;
+    a.zero();
+    full_sweep<true, FUSE>(L, T, wg, nwg, a);
+    full_block_reduce(a, s_part, s_out);
+    ++passes;
+    bool failed = false;
+    if (MULTI && !leader) {
+      if (tid <= NS) st_agent(part + wg * 32 + tid, s_out[tid]);
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spin = 0;
+        while (__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)passes && ++spin < SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+        if (spin >= SPIN_LIMIT) s_ctl[1] = 1;
+      }
+      __syncthreads();
+      if (s_ctl[1]) break;                                     // the leader never answered: give up (passes_out is the leader's)
+      if (tid < 12) s_Teval[tid] = ld_agent(bcast + tid);
+      if (tid == 12) { const double c = ld_agent(bcast + 12); s_ctl[0] = (int)c; }
+      __syncthreads();
+      continue;
+    }
+    // ---- leader: gather the stream's sums in a fixed order ----
+    if (MULTI) {
+      if (tid == 0) {
+        const unsigned want = (unsigned)(nwg - 1) * (unsigned)passes;
+        long spin = 0;
+        while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spin < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+        if (spin >= SPIN_LIMIT) s_ctl[1] = 1;
+      }
+      __syncthreads();
+      failed = s_ctl[1] != 0;
+      // 8 lanes per value, each adds every 8th workgroup's partial (8 loads in flight), then the 8 group sums in order
+      const int val = tid & 31, grp = tid >> 5;
+      double acc = 0;
+      if (!failed && val <= NS) {
+        for (int w0 = 1 + grp; w0 < nwg; w0 += 64) {
+          double t8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const int w = w0 + 8 * k; t8[k] = w < nwg ? ld_agent(part + w * 32 + val) : 0.0; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc += t8[k];
+        }
+      }
+      __syncthreads();
+      s_grp[grp][val] = acc;
+      __syncthreads();
+      if (tid <= NS) {
+        double s = s_out[tid];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += s_grp[g][tid];
+        s_sum[tid] = s;
+      }
+    } else if (tid <= NS) s_sum[tid] = s_out[tid];
+    __syncthreads();
+    // ---- leader, lane 0: one step of the reference's LM state machine ----
+    if (tid == 0) {
+      const float chi2_e = (float)s_sum[27];                      // GpuTracker::chi2 returns float
+      int lvl = level;
+      bool level_done = false;
+      if (failed) { lvl = -1; }
+      else if (phase == PH_INIT) {                                 // float chi2 = gpu_tracker_.chi2(...) (:84-92)
+        chi2 = chi2_e;
+        for (int k = 0; k < 21; ++k) s_H[k] = s_sum[k];
+        for (int k = 0; k < 6; ++k) s_b[k] = s_sum[21 + k];
+        mu = 0.01f; nu = 2; trial = 0; iter = 0;
+        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{lvl, 2, chi2, chi2};
+        ++n_rec;
+        phase = PH_TRIAL;
+      } else {
+        const float new_chi2 = chi2_e;
+        const double rho = chi2 - new_chi2;                       // float - float, widened (:142)
+        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{lvl, rho > 0 ? 1 : 0, chi2, new_chi2};
+        ++n_rec;
+        bool stop = false;
+        if (rho > 0) {
+          double mx = 0;
+          for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(s_b[k]));
+          stop = mx <= 1e-10;                                     // norm_max(b) <= EPS, b of the pass the step came from (:148)
+          for (int k = 0; k < 12; ++k) s_T[k] = s_Teval[k];
+          chi2 = new_chi2;
+          for (int k = 0; k < 21; ++k) s_H[k] = s_sum[k];         // = the next iteration's jacobianReduction at the accepted pose
+          for (int k = 0; k < 6; ++k) s_b[k] = s_sum[21 + k];
+          const double t = 2 * rho - 1;
+          mu *= fmax(1. / 3., 1 - t * t * t);
+          nu = 2.;
+          trial = 0;
+          ++iter;                                                 // leaves the do-while; next i of the for loop
+        } else {
+          mu *= nu;
+          nu *= 2.;
+          ++trial;
+          if (trial == 2) stop = true;
+        }
+        level_done = stop || iter >= 15;
+      }
+      if (lvl >= 0 && level_done) {
+        --lvl;
+        phase = PH_INIT;
+        for (int k = 0; k < 12; ++k) s_Teval[k] = s_T[k];         // next level starts with chi2 + H,b at the current pose
+      } else if (lvl >= 0) {
+        // jacobianReduction at s_T gave (s_H, s_b): damped solve and trial pose (:115-128)
+        for (int k = 0; k < 12; ++k) s_Tj[lvl][k] = s_T[k];
+        double H[36], nb[6], x[6], Tn[12];
+        int k = 0;
+        for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { H[6 * r + c] = s_H[k]; H[6 * c + r] = s_H[k]; ++k; }
+        for (int q = 0; q < 6; ++q) H[7 * q] += mu * H[7 * q];
+        for (int q = 0; q < 6; ++q) nb[q] = -s_b[q];
+        f_solve6(H, nb, x);
+        f_se3_exp_mul(x, s_T, Tn);
+        for (int q = 0; q < 12; ++q) s_Teval[q] = Tn[q];
+      }
+      s_ctl[0] = lvl;
+    }
+    __syncthreads();
+    if (MULTI) {
+      if (tid < 12) st_agent(bcast + tid, s_Teval[tid]);
+      if (tid == 12) st_agent(bcast + 12, (double)s_ctl[0]);
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(epoch, (unsigned)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!leader) return;
+  if (tid < 12) T_io[(size_t)slot * 12 + tid] = s_T[tid];
+  if (tid == 0) {
+    if (passes_out) passes_out[slot] = s_ctl[1] ? -1 : passes;
+    if (A.n_rec) A.n_rec[slot] = n_rec;
+  }
+  if (A.T_jac && tid < 36) A.T_jac[(size_t)slot * 36 + tid] = s_Tj[tid / 12][tid % 12];
+}
+
+// ---- single passes behind the GpuTracker call surface -------------------------------------------------------------
+template <bool JAC>
+__global__ __launch_bounds__(FULL_THREADS) void dense_pass_full_kernel(FullLevel L, M34 T, double *__restrict__ partials) {
+  __shared__ double s_part[FULL_WAVES][NS + 1];
+  __shared__ double s_out[NS + 1];
+  AccF a;
+  a.zero();
+  full_sweep<JAC, false>(L, T, blockIdx.x, gridDim.x, a);
+  full_block_reduce(a, s_part, s_out);
+  if (threadIdx.x <= NS) partials[(size_t)blockIdx.x * (NS + 1) + threadIdx.x] = s_out[threadIdx.x];
+}
+__global__ void dense_finalize_full_kernel(const double *__restrict__ partials, int nblocks, svs_dense_sums *__restrict__ out) {
+  const int t = threadIdx.x;
+  if (t > NS) return;
+  double s = 0;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * (NS + 1) + t];
+  if (t < 21) out->H[t] = s;
+  else if (t < 27) out->b[t - 21] = s;
+  else if (t == 27) out->chi2 = s;
+  else out->n_valid = (long long)s;
+}
+
+// residualImage_kernel (gpu/dense_tracking.cu:495-541)
+__global__ __launch_bounds__(256) void residual_image_full_kernel(FullLevel L, M34 T, float *__restrict__ rimg) {
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= L.w || v >= L.h) return;
+  const float4 p = L.cloud[(size_t)v * L.s4 + u];
+  float4 o = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (p.w > 0) {
+    float res, J[6];
+    o = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (full_pixel<false, false>(L, T, p, L.prev[(size_t)v * L.fs + u], res, J)) {
+      float g = 1 - 50.f * res * res;
+      if (g < 0.f) g = 0.f;
+      o = make_float4(g, g, g, 1.f);
+    }
+  }
+  reinterpret_cast<float4 *>(rimg)[(size_t)v * L.s4 + u] = o;
+}
+
+// parity probe: the per-pixel terms of jacobianReduction_kernel before its reduction: out[v][u] = {J0..J5, res, valid}
+template <bool FUSE>
+__global__ __launch_bounds__(256) void pixel_terms_full_kernel(FullLevel L, M34 T, float *__restrict__ out) {
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= L.w || v >= L.h) return;
+  float res = 0.f, J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool ok = full_pixel<true, FUSE>(L, T, L.cloud[(size_t)v * L.s4 + u], L.prev[(size_t)v * L.fs + u], res, J);
+  float *o = out + 8 * ((size_t)v * L.w + u);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o[i] = ok ? J[i] : 0.f;
+  o[6] = ok ? res : 0.f;
+  o[7] = ok ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void pointcloud_full_kernel(M44 TQ, const float *__restrict__ disp, int w, int h, int si, int so,
+                                                              int factor, float *__restrict__ cloud) {
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= w || v >= h) return;
+  const float d = disp[(size_t)v * si + u * factor] * factor;     // row not scaled: .cu:97-98 quirk kept
+  float4 o;
+  if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
+  else {
+    const float q[4] = {(float)u, (float)v, d, 1.f};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = q[0] * TQ.m[i] + q[1] * TQ.m[4 + i] + q[2] * TQ.m[8 + i] + q[3] * TQ.m[12 + i];
+    o = make_float4(r[0] / r[3], r[1] / r[3], r[2] / r[3], 1.f);
+  }
+  reinterpret_cast<float4 *>(cloud)[(size_t)v * so + u] = o;
+}
+
+// ---- CUDA-build preprocessing (frame_grabber.cpp:291-313): f32 level 0, f32 pyrDown, REPLICATE derivatives ---------
+__global__ __launch_bounds__(256) void convert_f32_kernel(const uint8_t *__restrict__ src, int w, int h, int ss, size_t s_b,
+                                                          float *__restrict__ dst, int ds, size_t d_b) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= w || y >= h) return;
+  dst[b * d_b + (size_t)y * ds + x] = (float)src[b * s_b + (size_t)y * ss + x] * (float)(1. / 255.);
+}
+__device__ __forceinline__ int refl101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+// cv::gpu::pyrDown on f32 (ASSUMED OpenCV 2.4.2 gpu semantics, see oracle/vision.c): columns first, then rows, taps in
+// ascending order, REFLECT_101.  One lane per output pixel: 25 taps from L1/L2 (the source row set of neighbouring lanes
+// overlaps 5/2-fold); the level images are 1.2 MB + 0.3 MB per frame, this is not where the time goes.
+__global__ __launch_bounds__(256) void pyr_down_f32_kernel(const float *__restrict__ src, int w, int h, int ss, size_t s_b,
+                                                           float *__restrict__ dst, int ow, int oh, int ds, size_t d_b) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= ow || y >= oh) return;
+  const float k0 = 0.0625f, k1 = 0.25f, k2 = 0.375f;
+  const float *s = src + b * s_b;
+  int xs[5], ys[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) { xs[t] = refl101(2 * x - 2 + t, w); ys[t] = refl101(2 * y - 2 + t, h); }
+  float col[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    float a = k0 * s[(size_t)ys[0] * ss + xs[t]];
+    a = a + k1 * s[(size_t)ys[1] * ss + xs[t]];
+    a = a + k2 * s[(size_t)ys[2] * ss + xs[t]];
+    a = a + k1 * s[(size_t)ys[3] * ss + xs[t]];
+    a = a + k0 * s[(size_t)ys[4] * ss + xs[t]];
+    col[t] = a;
+  }
+  float a = k0 * col[0];
+  a = a + k1 * col[1]; a = a + k2 * col[2]; a = a + k1 * col[3]; a = a + k0 * col[4];
+  dst[b * d_b + (size_t)y * ds + x] = a;
+}
+__global__ __launch_bounds__(256) void deriv_replicate_kernel(const float *__restrict__ img, int w, int h, int s, size_t i_b,
+                                                              float *__restrict__ dx, float *__restrict__ dy) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= w || y >= h) return;
+  const float *im = img + b * i_b;
+  const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+  dx[b * i_b + (size_t)y * s + x] = im[(size_t)y * s + xp] - im[(size_t)y * s + xm];
+  dy[b * i_b + (size_t)y * s + x] = im[(size_t)yp * s + x] - im[(size_t)ym * s + x];
+}
+
+static FullLevel make_level(const float *cloud4, int w, int h, int s4, const float *prev, const float *cur, const float *dx, const float *dy,
+                            int fs, float f, float cx, float cy) {
+  FullLevel L;
+  L.cloud = reinterpret_cast<const float4 *>(cloud4); L.prev = prev; L.cur = cur; L.dx = dx; L.dy = dy;
+  L.w = w; L.h = h; L.s4 = s4; L.fs = fs; L.f = f; L.cx = cx; L.cy = cy;
+  return L;
+}
+
+}  // namespace
+
+extern "C" int svs_preprocess_gpu_sem(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride,
+                                      float *const *d_img, float *const *d_dx, float *const *d_dy, const int32_t *fstride,
+                                      const size_t *f_bstride, int levels, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_src && d_img && d_dx && d_dy && fstride && f_bstride && w > 0 && h > 0 && levels >= 1 && levels <= 3 && batch >= 1);
+  SVS_DEVICE(ctx);
+  int lw = w, lh = h;
+  for (int l = 0; l < levels; ++l) {
+    SVS_REQUIRE(ctx, d_img[l] && d_dx[l] && d_dy[l] && fstride[l] >= lw);
+    const dim3 grid(div_up(lw, 64), div_up(lh, 4), batch);
+    if (l == 0)
+      hipLaunchKernelGGL(convert_f32_kernel, grid, dim3(256), 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_img[0], fstride[0], f_bstride[0]);
+    else {
+      const int pw = l == 1 ? w : (w + 1) / 2, ph = l == 1 ? h : (h + 1) / 2;
+      hipLaunchKernelGGL(pyr_down_f32_kernel, grid, dim3(256), 0, ctx->stream, (const float *)d_img[l - 1], pw, ph, fstride[l - 1], f_bstride[l - 1],
+                         d_img[l], lw, lh, fstride[l], f_bstride[l]);
+    }
+    SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(deriv_replicate_kernel, grid, dim3(256), 0, ctx->stream, (const float *)d_img[l], lw, lh, fstride[l], f_bstride[l], d_dx[l], d_dy[l]);
+    SVS_LAUNCH_CHECK(ctx);
+    lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+  }
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                                             const float *d_cur, int stride_f, float f, float cx, float cy, const float *h_T,
+                                             float *d_res_img4) {
+  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_res_img4 && w > 0 && h > 0);
+  SVS_DEVICE(ctx);
+  M34 T;
+  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
+  hipLaunchKernelGGL(residual_image_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream,
+                     make_level(d_cloud4, w, h, stride_f4, d_prev, d_cur, nullptr, nullptr, stride_f, f, cx, cy), T, d_res_img4);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_pixel_terms_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                                          const float *d_cur, const float *d_dx, const float *d_dy, int stride_f, float f, float cx,
+                                          float cy, const float *h_T, float *d_terms8) {
+  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_terms8 && w > 0 && h > 0 && (!d_dx == !d_dy));
+  SVS_DEVICE(ctx);
+  M34 T;
+  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
+  const FullLevel L = make_level(d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy);
+  if (d_dx) hipLaunchKernelGGL(pixel_terms_full_kernel<false>, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, L, T, d_terms8);
+  else hipLaunchKernelGGL(pixel_terms_full_kernel<true>, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, L, T, d_terms8);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_pass_full(svs_ctx *ctx, const float *d_cloud4, int w, int h, int stride_f4, const float *d_prev,
+                                   const float *d_cur, const float *d_dx, const float *d_dy, int stride_f, float f,
+                                   float cx, float cy, const float *h_T, int do_jac, svs_dense_sums *d_out) {
+  SVS_REQUIRE(ctx, ctx && d_cloud4 && d_prev && d_cur && h_T && d_out && w > 0 && h > 0);
+  SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
+  SVS_DEVICE(ctx);
+  M34 T;
+  for (int i = 0; i < 12; ++i) T.m[i] = h_T[i];
+  const int nblocks = std::min(div_up(w * h, FULL_THREADS), 4 * ctx->n_cu);
+  void *part = nullptr;
+  const int rc = svs_ctx_scratch(ctx, (size_t)nblocks * (NS + 1) * sizeof(double), &part);
+  if (rc) return rc;
+  const FullLevel L = make_level(d_cloud4, w, h, stride_f4, d_prev, d_cur, d_dx, d_dy, stride_f, f, cx, cy);
+  if (do_jac) hipLaunchKernelGGL(dense_pass_full_kernel<true>, dim3(nblocks), dim3(FULL_THREADS), 0, ctx->stream, L, T, (double *)part);
+  else hipLaunchKernelGGL(dense_pass_full_kernel<false>, dim3(nblocks), dim3(FULL_THREADS), 0, ctx->stream, L, T, (double *)part);
+  SVS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(dense_finalize_full_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)part, nblocks, d_out);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ, const float *d_disp, int w, int h, int stride_in,
+                                   int stride_out, int factor, float *d_cloud4) {
+  SVS_REQUIRE(ctx, ctx && h_TQ && d_disp && d_cloud4 && w > 0 && h > 0 && factor >= 1);
+  SVS_DEVICE(ctx);
+  M44 TQ;
+  for (int i = 0; i < 16; ++i) TQ.m[i] = h_TQ[i];
+  hipLaunchKernelGGL(pointcloud_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, TQ, d_disp, w, h,
+                     stride_in, stride_out, factor, d_cloud4);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_dense_track_full(svs_ctx *ctx, const svs_dense_track_full_args *a, double *d_T_io, int32_t *d_passes_out, int batch) {
+  SVS_REQUIRE(ctx, ctx && a && d_T_io && batch >= 1);
+  SVS_DEVICE(ctx);
+  TrackFullArgs A;
+  const bool fuse = a->d_dx[0] == nullptr;
+  for (int l = 0; l < 3; ++l) {
+    SVS_REQUIRE(ctx, a->d_cloud4[l] && a->d_prev[l] && a->d_cur[l] && a->w[l] >= 4 && a->h[l] >= 4);
+    SVS_REQUIRE(ctx, fuse ? (!a->d_dx[l] && !a->d_dy[l]) : (a->d_dx[l] && a->d_dy[l]));
+    SVS_REQUIRE(ctx, a->stride_f4[l] >= a->w[l] && a->stride_f[l] >= a->w[l]);
+    A.lv[l] = make_level(a->d_cloud4[l], a->w[l], a->h[l], a->stride_f4[l], a->d_prev[l], a->d_cur[l], a->d_dx[l], a->d_dy[l], a->stride_f[l],
+                         (float)a->f[l], (float)a->cx[l], (float)a->cy[l]);      // GpuIntrinsics::set (gpu/dense_tracking.cuh:30-38)
+    A.cloud_b[l] = a->cloud_bstride[l]; A.f_b[l] = a->f_bstride[l];
+  }
+  A.T_jac = a->d_T_jac_out;
+  A.rec = a->d_record_out; A.rec_cap = a->d_record_out ? a->record_cap : 0; A.n_rec = a->d_n_record_out;
+  SVS_REQUIRE(ctx, !a->d_record_out || a->record_cap > 0);
+  // workgroups per stream: fill the resident slots (4 workgroups of 256 threads per CU at <= 128 VGPRs; keep half of them free for
+  // whatever else shares the device), never more than the pixel groups of the smallest level are worth
+  const int slots = 2 * ctx->n_cu;
+  int nwg = ctx->full_nwg ? ctx->full_nwg : std::max(1, std::min(slots / batch, 64));
+  nwg = std::min(nwg, std::max(1, div_up(a->w[0] * a->h[0], FULL_THREADS)));
+  A.nwg = nwg;
+  A.part = nullptr; A.bcast = nullptr; A.count = nullptr; A.epoch = nullptr;
+  if (nwg > 1) {
+    void *scr = nullptr;
+    const size_t n_part = (size_t)batch * nwg * 32, n_bc = (size_t)batch * 16;
+    const int rc = svs_ctx_scratch(ctx, (n_part + n_bc + (size_t)batch) * sizeof(double), &scr);
+    if (rc) return rc;
+    A.part = static_cast<double *>(scr);
+    A.bcast = A.part + n_part;
+    A.count = reinterpret_cast<unsigned *>(A.bcast + n_bc);
+    A.epoch = A.count + batch;
+    SVS_HIP(ctx, hipMemsetAsync(A.count, 0, sizeof(double) * (size_t)batch, ctx->stream));
+    if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+    else hipLaunchKernelGGL((dense_track_full_kernel<false, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  } else {
+    if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+    else hipLaunchKernelGGL((dense_track_full_kernel<false, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
+  }
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}

@@ -3,6 +3,7 @@
 // the CPU path's convertTo(CV_32F,1/255.) + Sobel(ksize=1).  Integer path is bit-exact to the
 // OpenCV 2.4.2 semantics restated in SURVEY.md A.2; HBM-bound stencils, LDS-tiled.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
@@ -19,6 +20,10 @@ extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
     c->own_stream = true;
   }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return SVS_ERR_HIP; }
+  auto env_int = [](const char *name, int lo, int hi) { const char *e = getenv(name); if (!e) return 0; const int v = atoi(e); return v < lo ? lo : (v > hi ? hi : v); };
+  c->trk_nwg = env_int("SVS_TRK_NWG", 1, 64);
+  c->trk_regs = getenv("SVS_TRK_ONE_PER_CU") ? 1 : (getenv("SVS_TRK_TWO_PER_CU") ? 2 : 0);
+  c->full_nwg = env_int("SVS_FULL_NWG", 1, 1024);
   *out = c;
   return SVS_OK;
 }
@@ -27,8 +32,30 @@ extern "C" int svs_ctx_destroy(svs_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->scratch) (void)hipFree(c->scratch);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return SVS_OK;
+}
+int svs_ctx_scratch(svs_ctx *c, size_t bytes, void **out) {
+  SVS_REQUIRE(c, c && out);
+  if (c->scratch_bytes < bytes) {
+    SVS_DEVICE(c);
+    if (c->scratch) { SVS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    SVS_HIP(c, hipMalloc(&c->scratch, want));
+    c->scratch_bytes = want;
+  }
+  *out = c->scratch;
+  return SVS_OK;
+}
+extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
+  SVS_REQUIRE(c, c && name && value >= 0);
+  const std::string n(name);
+  if (n == "trk_nwg") c->trk_nwg = value > 64 ? 64 : value;
+  else if (n == "trk_regs") c->trk_regs = value > 2 ? 0 : value;
+  else if (n == "full_nwg") c->full_nwg = value > 1024 ? 1024 : value;
+  else SVS_REQUIRE(c, !"unknown option");
   return SVS_OK;
 }
 extern "C" int svs_ctx_sync(svs_ctx *c) { SVS_REQUIRE(c, c); SVS_HIP(c, hipStreamSynchronize(c->stream)); return SVS_OK; }

@@ -43,6 +43,10 @@ DENSE_SUMS_DTYPE = np.dtype([("H", "<f8", 21), ("b", "<f8", 6), ("chi2", "<f8"),
                              ("n_valid", "<i8")], align=True)
 assert DENSE_SUMS_DTYPE.itemsize == 232
 
+# svs_dense_lm_record: one entry per chi2 evaluation of DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193)
+DENSE_LM_RECORD_DTYPE = np.dtype([("level", "<i4"), ("accepted", "<i4"), ("chi2", "<f4"), ("new_chi2", "<f4")])
+assert DENSE_LM_RECORD_DTYPE.itemsize == 16
+
 BA_EDGE_DTYPE = np.dtype([("obs", "<f8", 3), ("info", "<f8", 3), ("point", "<i4"),
                           ("pose", "<i4"), ("anchor", "<i4"), ("pad_", "<i4")], align=True)
 assert BA_EDGE_DTYPE.itemsize == 64

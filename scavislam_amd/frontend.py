@@ -8,6 +8,8 @@ stereo_frontend.cpp), device memory held in torch tensors:
   GuidedMatcher.match                    <- GuidedMatcher<StereoCamera>   matcher.hpp:67-83
   DenseTracker.denseTrackingCpu / computeDensePointCloudCpu               dense_tracking.h:59-79
   GpuTracker.jacobianReduction / chi2 / computePointCloud                 gpu/dense_tracking.cuh:281-342
+  GpuFrameData.preprocessing()           <- FrameGrabber::preprocessing, CUDA branch  frame_grabber.cpp:291-313
+  DenseTrackerGpu.denseTrackingGpu / computeDensePointCloudGpu            dense_tracking.cpp:60-215
   StereoMatcher.calcDisparityCpu         <- StereoFrontend::calcDisparityCpu  stereo_frontend.cpp:620-653
   PoseOptimizer.calcFastMotionOnly       <- BA_SE3_XYZ_STEREO::calcFastMotionOnly  pose_optimizer.h:134-298
 
@@ -19,7 +21,7 @@ import numpy as np
 import torch
 
 from . import capi
-from .ctypes_types import (CANDIDATE_DTYPE, DENSE_SUMS_DTYPE, GATED_POINT_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
+from .ctypes_types import (CANDIDATE_DTYPE, DENSE_LM_RECORD_DTYPE, DENSE_SUMS_DTYPE, GATED_POINT_DTYPE, KEYFRAME_DTYPE, MATCH_RESULT_DTYPE,
                            POINT_STATS_DTYPE, Cam,
                            FastGrid as FastGridPOD, PoseOptParams, PoseOptStats, StereoParams, level_cams)
 
@@ -432,6 +434,130 @@ class GpuTracker:
         TQ = np.ascontiguousarray(TQ_colmajor, np.float32).reshape(16)
         self.ctx.call("svs_pointcloud_full", TQ.ctypes.data, disp.data_ptr(), w, h, stride_in, stride_out, factor,
                       cloud.data_ptr())
+
+
+class GpuFrameData:
+    """The CUDA build's per-frame device data (FrameData members gpu_pyr_float32 / gpu_pyr_float32_dx / _dy / gpu_disp_32f,
+    frame_grabber.hpp:139-150) for `batch` independent streams."""
+
+    def __init__(self, ctx, stream, cam, batch=1):
+        self.ctx, self.stream, self.cam, self.batch = ctx, stream, cam, batch
+        self.cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"], NUM_PYR_LEVELS)
+        dev = torch.device("cuda", ctx.device)
+        self.w = [self.cams[l].w for l in range(NUM_PYR_LEVELS)]
+        self.h = [self.cams[l].h for l in range(NUM_PYR_LEVELS)]
+        self.stride = [_round_up(w, 64) for w in self.w]
+        with torch.cuda.stream(stream):
+            self.uint8 = torch.zeros((batch, self.h[0], self.stride[0]), dtype=torch.uint8, device=dev)
+            self.disp = torch.zeros((batch, self.h[0], self.stride[0]), dtype=torch.float32, device=dev)
+            self.f32 = [torch.zeros((batch, self.h[l], self.stride[l]), dtype=torch.float32, device=dev) for l in range(NUM_PYR_LEVELS)]
+            self.dx = [torch.zeros_like(t) for t in self.f32]
+            self.dy = [torch.zeros_like(t) for t in self.f32]
+
+    def bstride(self, l):
+        return self.h[l] * self.stride[l]
+
+    def upload(self, images, disp=None):
+        with torch.cuda.stream(self.stream):
+            img = torch.as_tensor(np.ascontiguousarray(images)).to(self.uint8.device)
+            self.uint8[:, :, :self.w[0]] = img.reshape(self.batch, self.h[0], self.w[0])
+            if disp is not None:
+                d = torch.as_tensor(np.ascontiguousarray(disp, dtype=np.float32)).to(self.disp.device)
+                self.disp[:, :, :self.w[0]] = d.reshape(self.batch, self.h[0], self.w[0])
+
+    def preprocessing(self):
+        """gpu convertTo + gpu::pyrDown on f32 + the REPLICATE derivative filters (frame_grabber.cpp:291-313)."""
+        n = NUM_PYR_LEVELS
+        P = C.c_void_p * n
+        self.ctx.call("svs_preprocess_gpu_sem", self.uint8.data_ptr(), self.w[0], self.h[0], self.stride[0], self.bstride(0),
+                      P(*[t.data_ptr() for t in self.f32]), P(*[t.data_ptr() for t in self.dx]), P(*[t.data_ptr() for t in self.dy]),
+                      (C.c_int32 * n)(*self.stride), (C.c_size_t * n)(*[self.bstride(l) for l in range(n)]), n, self.batch)
+
+
+class DenseTrackerGpu:
+    """DenseTracker of the CUDA build (dense_tracking.cpp:25-215): full-resolution clouds dev_ref_dense_points_[l], damped LM."""
+    RECORD_CAP = 128
+
+    def __init__(self, ctx, frame):
+        self.ctx, self.frame = ctx, frame
+        dev = frame.f32[0].device
+        B = frame.batch
+        with torch.cuda.stream(frame.stream):
+            self.dev_ref_dense_points = [torch.zeros((B, frame.h[l], frame.w[l], 4), dtype=torch.float32, device=dev) for l in range(NUM_PYR_LEVELS)]
+            self.dev_residual_img = [torch.zeros_like(c) for c in self.dev_ref_dense_points]
+            for r in self.dev_residual_img:
+                r[..., 3] = 1.0                                   # setTo(Scalar(0,0,0,1)) (dense_tracking.cpp:40)
+            self.d_T = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+            self.d_passes = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.d_T_jac = torch.zeros((B, NUM_PYR_LEVELS, 12), dtype=torch.float64, device=dev)
+            self.d_rec = torch.zeros(B * self.RECORD_CAP * DENSE_LM_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.d_nrec = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def _set_T(self, T):
+        T = np.broadcast_to(np.asarray(T, np.float64).reshape(-1, 12), (self.frame.batch, 12))
+        with torch.cuda.stream(self.frame.stream):
+            self.d_T.copy_(torch.as_tensor(np.array(T, dtype=np.float64)))
+
+    def computeDensePointCloudGpu(self, T_cur_from_actkey):
+        """computePointCloud per level with TQ = T^-1 * cam_vec[level].Q() and factor 2^level (dense_tracking.cpp:195-215);
+        slot 0's pose for every slot (one launch per level and slot: the reference's call surface is per frame)."""
+        fr = self.frame
+        T = np.asarray(T_cur_from_actkey, np.float64).reshape(3, 4)
+        Ti = np.vstack([_pose_inv(T).reshape(3, 4), [0, 0, 0, 1]])
+        for l in range(NUM_PYR_LEVELS):
+            c = fr.cams[l]
+            Q = np.array([[1, 0, 0, -c.cx], [0, 1, 0, -c.cy], [0, 0, 0, c.f], [0, 0, 1.0 / c.b, 0]])
+            TQ = np.ascontiguousarray((Ti @ Q).T.reshape(16), np.float32)
+            for b in range(fr.batch):
+                self.ctx.call("svs_pointcloud_full", TQ.ctypes.data, fr.disp[b].data_ptr(), fr.w[l], fr.h[l], fr.stride[0], fr.w[l],
+                              1 << l, self.dev_ref_dense_points[l][b].data_ptr())
+
+    def track_args(self, prev, fuse_gradients=False, record=True):
+        fr = self.frame
+        a = capi.DenseTrackFullArgs()
+        for l in range(NUM_PYR_LEVELS):
+            a.d_cloud4[l], a.stride_f4[l], a.cloud_bstride[l] = self.dev_ref_dense_points[l].data_ptr(), fr.w[l], fr.w[l] * fr.h[l]
+            a.d_prev[l], a.d_cur[l] = prev.f32[l].data_ptr(), fr.f32[l].data_ptr()
+            if not fuse_gradients:
+                a.d_dx[l], a.d_dy[l] = fr.dx[l].data_ptr(), fr.dy[l].data_ptr()
+            a.stride_f[l], a.f_bstride[l] = fr.stride[l], fr.bstride(l)
+            a.w[l], a.h[l] = fr.w[l], fr.h[l]
+            a.f[l], a.cx[l], a.cy[l] = fr.cams[l].f, fr.cams[l].cx, fr.cams[l].cy
+        a.d_T_jac_out = self.d_T_jac.data_ptr()
+        if record:
+            a.d_record_out, a.record_cap, a.d_n_record_out = self.d_rec.data_ptr(), self.RECORD_CAP, self.d_nrec.data_ptr()
+        return a
+
+    def denseTrackingGpu(self, prev, T_cur_from_actkey, args=None, download=True, fuse_gradients=False):
+        """DenseTracker::denseTrackingGpu(SE3*): in/out pose, whole damped LM in one launch.  prev: the previous GpuFrameData.
+        Returns (T [batch,3,4], fused sweeps [batch], records: list of DENSE_LM_RECORD_DTYPE arrays)."""
+        fr = self.frame
+        if T_cur_from_actkey is not None:
+            self._set_T(T_cur_from_actkey)
+        a = args or self.track_args(prev, fuse_gradients)
+        self.ctx.check(self.ctx.lib.svs_dense_track_full(self.ctx.h, C.byref(a), self.d_T.data_ptr(), self.d_passes.data_ptr(), fr.batch))
+        if not download:
+            return None
+        self.ctx.sync()
+        n = self.d_nrec.cpu().numpy()
+        rec = self.d_rec.cpu().numpy().view(DENSE_LM_RECORD_DTYPE).reshape(fr.batch, self.RECORD_CAP)
+        return (self.d_T.cpu().numpy().reshape(fr.batch, 3, 4), self.d_passes.cpu().numpy(),
+                [rec[b, :min(int(n[b]), self.RECORD_CAP)].copy() for b in range(fr.batch)])
+
+    def residualImages(self, prev):
+        """dev_residual_img[l] as denseTrackingGpu leaves it: residualImage at the pose of the level's last jacobianReduction
+        (dense_tracking.cpp:177-186)."""
+        fr = self.frame
+        self.ctx.sync()
+        Tj = self.d_T_jac.cpu().numpy().reshape(fr.batch, NUM_PYR_LEVELS, 3, 4)
+        for l in range(NUM_PYR_LEVELS):
+            for b in range(fr.batch):
+                T34 = np.ascontiguousarray(Tj[b, l].T.reshape(12), np.float32)          # GpuMatrix34: column-major
+                self.ctx.call("svs_dense_residual_image_full", self.dev_ref_dense_points[l][b].data_ptr(), fr.w[l], fr.h[l], fr.w[l],
+                              prev.f32[l][b].data_ptr(), fr.f32[l][b].data_ptr(), fr.stride[l], float(fr.cams[l].f), float(fr.cams[l].cx),
+                              float(fr.cams[l].cy), T34.ctypes.data, self.dev_residual_img[l][b].data_ptr())
+        self.ctx.sync()
+        return [r.cpu().numpy() for r in self.dev_residual_img]
 
 
 class StereoMatcher:

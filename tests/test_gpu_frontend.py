@@ -452,20 +452,20 @@ def test_dense_tracking_multi_workgroup_variant(gpu_ctx, scene_frames, monkeypat
     dtp.computeDensePointCloudCpu(I.reshape(12))
     out = {}
     for nwg in ("1", "4"):
-        monkeypatch.setenv("SVS_TRK_NWG", nwg)
+        ctx.set_option("trk_nwg", int(nwg))
         dt = DenseTracker(ctx, cur)
         dt.ref_dense_points = dtp.ref_dense_points
         T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
         out[nwg] = (T.copy(), passes.copy(), dt.d_T_jac.cpu().numpy().copy())
     # the 128-register build of the one-workgroup kernel (used when there are more streams than CUs): same arithmetic
-    monkeypatch.setenv("SVS_TRK_NWG", "1")
-    monkeypatch.setenv("SVS_TRK_TWO_PER_CU", "1")
+    ctx.set_option("trk_nwg", 1)
+    ctx.set_option("trk_regs", 2)
     dt = DenseTracker(ctx, cur)
     dt.ref_dense_points = dtp.ref_dense_points
     T2, passes2 = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
     assert np.array_equal(T2, out["1"][0]) and np.array_equal(passes2, out["1"][1])
-    monkeypatch.delenv("SVS_TRK_TWO_PER_CU")
-    monkeypatch.delenv("SVS_TRK_NWG")
+    ctx.set_option("trk_regs", 0)
+    ctx.set_option("trk_nwg", 0)
     (T1, p1, j1), (T4, p4, j4) = out["1"], out["4"]
     assert np.array_equal(p1, p4) and len(set(p1.tolist())) >= 1
     np.testing.assert_allclose(T4, T1, rtol=0, atol=1e-9)
