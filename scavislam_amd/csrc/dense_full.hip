@@ -22,7 +22,7 @@
 //    a fixed order, takes the LM step on one lane and publishes the next pose the same way: no grid-wide barrier, no fence
 //    that would flush an XCD's L2 (MI355X_MICROARCH.md, "inter-workgroup visibility").  With >= 1 stream per resident
 //    workgroup slot NWG is 1 and nothing leaves the workgroup.
-//  * divisions: one IEEE reciprocal per denominator + a 3-instruction correctly rounded quotient (Markstein) instead of
+//  * divisions: one IEEE reciprocal per denominator + a 4-instruction correctly rounded quotient (Markstein) instead of
 //    twelve ~10-instruction IEEE divisions; the f64-promoted entries J0, J1 reduce to f32 quotients exactly (double
 //    rounding through f64 is innocuous for a quotient of two f32 numbers, and a 2^-52 perturbation cannot reach an f32
 //    rounding boundary, which a quotient of two 24-bit numbers misses by >= 2^-49 relative).
@@ -34,6 +34,11 @@ namespace {
 constexpr int NS = 28;                 // 21 H (packed upper by column) + 6 b + chi2; n_valid rides along as the 29th value
 constexpr int FULL_THREADS = 256;
 constexpr int FULL_WAVES = FULL_THREADS / 64;
+#ifndef SVS_FULL_MINW
+#define SVS_FULL_MINW 4
+#endif
+constexpr int FULL_MINW = SVS_FULL_MINW;   // waves per SIMD the tracker's register allocation must allow (= workgroups per CU): the sweep is
+                                           // gather-latency bound, the one-lane LM step may spill
 
 struct FullLevel {
   const float4 *cloud; const float *prev, *cur, *dx, *dy;
@@ -45,23 +50,20 @@ struct M44 { float m[16]; };
 
 // ---- exact f32 quotients sharing a denominator ------------------------------------------------------------------
 // r = RN(1 / z) (IEEE division); q = RN(a r); e = a - q z exactly (FMA); RN(q + e r) = RN(a / z) (Markstein: r correctly
-// rounded, q faithful).  Outside the safe exponent range (where a r could overflow / underflow first) fall back to IEEE.
-struct Recip { float z, r; bool safe; };
-__device__ __forceinline__ Recip recip(float z) {
-  Recip R;
-  R.z = z; R.r = 1.0f / z;
-  const float az = fabsf(z);
-  R.safe = az > 1e-18f && az < 1e18f;
-  return R;
-}
-__device__ __forceinline__ float quot(float a, const Recip &R) {
+// rounded, q faithful); q's sign bit is OR-ed in so that a = +-0 keeps the IEEE sign of the zero quotient (for a != 0 the two
+// signs agree anyway).  4 instructions instead of ~10.  Valid while nothing over- or underflows on the way: the callers use
+// it only for 1e-9 < |z| < 1e9 (then every numerator of an in-frame pixel is far inside the f32 range) and take the IEEE
+// path otherwise.
+struct Recip { float z, r; };
+__device__ __forceinline__ Recip recip(float z) { Recip R; R.z = z; R.r = 1.0f / z; return R; }
+template <bool FAST> __device__ __forceinline__ float quot(float a, const Recip &R) {
+  if (!FAST) return a / R.z;
   const float q = a * R.r;
   const float e = __builtin_fmaf(-q, R.z, a);
   const float q2 = __builtin_fmaf(e, R.r, q);
-  const float aa = fabsf(a);
-  // a == +-0: q already carries the IEEE sign of the zero quotient (the correction step would turn -0 into +0)
-  return a == 0.f ? q : ((R.safe && aa < 1e18f && aa > 1e-18f) ? q2 : a / R.z);
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, q) & 0x80000000u) | __builtin_bit_cast(unsigned, q2));
 }
+__device__ __forceinline__ bool z_is_tame(float z) { const float az = fabsf(z); return az > 1e-9f && az < 1e9f; }
 
 // texture fetch of the reference: tex2D(tex, uv.x + 0.5f, uv.y + 0.5f), linear filter, clamp addressing
 // (gpu/dense_tracking.cu:206-215).  (xt, yt) = uv + 0.5f as the reference forms it; the unit samples at (xt, yt) - 0.5.
@@ -78,56 +80,112 @@ __device__ __forceinline__ TexPos tex_pos(float xt, float yt, int w, int h) {
   P.w00 = wx0 * wy0; P.w01 = wx0 * wy1; P.w10 = wx1 * wy0; P.w11 = wx1 * wy1;     // (x,y) (x,y+1) (x+1,y) (x+1,y+1)
   return P;
 }
-__device__ __forceinline__ float tex_fetch(const float *__restrict__ m, int stride, const TexPos &P) {
-  const float v00 = m[(size_t)P.j0 * stride + P.i0], v01 = m[(size_t)P.j1 * stride + P.i0];
-  const float v10 = m[(size_t)P.j0 * stride + P.i1], v11 = m[(size_t)P.j1 * stride + P.i1];
-  return P.w00 * v00 + P.w01 * v01 + P.w10 * v10 + P.w11 * v11;
+struct Taps { float v00, v01, v10, v11; };
+// uniform base (SGPR pair) + 32-bit unsigned byte offset per lane: one address register per tap instead of a 64-bit add each
+template <class T> __device__ __forceinline__ T ld_at(const T *base, unsigned byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off); }
+struct TapOffs { unsigned o00, o01, o10, o11; };
+__device__ __forceinline__ TapOffs tap_offsets(const TexPos &P, int stride) {
+  TapOffs o;
+  const unsigned r0 = (unsigned)(P.j0 * stride), r1 = (unsigned)(P.j1 * stride);
+  o.o00 = (r0 + (unsigned)P.i0) * 4u; o.o01 = (r1 + (unsigned)P.i0) * 4u; o.o10 = (r0 + (unsigned)P.i1) * 4u; o.o11 = (r1 + (unsigned)P.i1) * 4u;
+  return o;
 }
+__device__ __forceinline__ Taps tex_load(const float *__restrict__ m, const TapOffs &o) {
+  Taps t;
+  t.v00 = ld_at(m, o.o00); t.v01 = ld_at(m, o.o01); t.v10 = ld_at(m, o.o10); t.v11 = ld_at(m, o.o11);
+  return t;
+}
+__device__ __forceinline__ float tex_mix(const TexPos &P, const Taps &t) { return P.w00 * t.v00 + P.w01 * t.v01 + P.w10 * t.v10 + P.w11 * t.v11; }
 
-// One thread of jacobianReduction_kernel / chi2_kernel up to its reduction (gpu/dense_tracking.cu:193-221, :395-411).
-// Returns whether the pixel contributes; res and (JAC) J[6] are the reference's f32 values.
+// One thread of jacobianReduction_kernel / chi2_kernel up to its reduction (gpu/dense_tracking.cu:193-221, :395-411), in two
+// stages so that a sweep can issue the taps of the next pixel before it does the arithmetic of this one.
 // FUSE: dx / dy images are not read; their taps are formed from the current image as the reference's derivative filter
 // defines them (I(x+1) - I(x-1), I(y+1) - I(y-1), BORDER_REPLICATE: frame_grabber.cpp:102-115) -- bit-identical values.
+template <bool JAC, bool FUSE> struct PixelA {
+  bool ok;
+  float x, y, z, ip;
+  Recip Rz;
+  TexPos P;
+  Taps c, gx, gy;                     // raw taps: current image, dx, dy  (FUSE: gx / gy hold the tap DIFFERENCES' operands)
+  Taps gxm, gym;                      // FUSE only: the "minus" neighbours (gx / gy hold the "plus" ones)
+};
+// stage A: transform, project, in-frame test, tap loads issued (not waited for)
 template <bool JAC, bool FUSE>
-__device__ __forceinline__ bool full_pixel(const FullLevel &L, const M34 &T, const float4 p, const float ip, float &res, float *J) {
-  if (!(p.w > 0)) return false;
+__device__ __forceinline__ void pixel_stage_a(const FullLevel &L, const M34 &T, const float4 p, const float ip, PixelA<JAC, FUSE> &A) {
   const float x = p.x * T.m[0] + p.y * T.m[3] + p.z * T.m[6] + p.w * T.m[9];       // matTimesVec / dotStride3
   const float y = p.x * T.m[1] + p.y * T.m[4] + p.z * T.m[7] + p.w * T.m[10];
   const float z = p.x * T.m[2] + p.y * T.m[5] + p.z * T.m[8] + p.w * T.m[11];
-  const Recip Rz = recip(z);
-  const float uu = quot(L.f * x, Rz) + L.cx, vv = quot(L.f * y, Rz) + L.cy;          // cameraProject
-  if (!(uu >= 1.f && vv >= 1.f && uu <= (float)(L.w - 2) && vv <= (float)(L.h - 2))) return false;
-  const TexPos P = tex_pos(uu + 0.5f, vv + 0.5f, L.w, L.h);
-  const float ic = tex_fetch(L.cur, L.fs, P);
-  res = ip - ic;
+  A.x = x; A.y = y; A.z = z; A.ip = ip;
+  A.Rz = recip(z);
+  float uu, vv;
+  if (__builtin_expect(z_is_tame(z), 1)) { uu = quot<true>(L.f * x, A.Rz) + L.cx; vv = quot<true>(L.f * y, A.Rz) + L.cy; }     // cameraProject
+  else { uu = L.f * x / z + L.cx; vv = L.f * y / z + L.cy; }
+  A.ok = (p.w > 0) && (uu >= 1.f && vv >= 1.f && uu <= (float)(L.w - 2) && vv <= (float)(L.h - 2));
+  // a pixel that does not contribute becomes a harmless one: tap position (1, 1), point (0, 0, 1); stage B zeroes its residual
+  // and gradients, so its Jacobian is +-0 and nothing has to be masked term by term
+  if (!A.ok) { uu = 1.f; vv = 1.f; A.x = 0.f; A.y = 0.f; A.z = 1.f; A.Rz.z = 1.f; A.Rz.r = 1.f; }
+  A.P = tex_pos(uu + 0.5f, vv + 0.5f, L.w, L.h);
+  const TapOffs O = tap_offsets(A.P, L.fs);
+  A.c = tex_load(L.cur, O);
   if (JAC) {
-    float gx, gy;
     if (FUSE) {
       // columns i0-1 .. i1+1 and rows j0-1 .. j1+1 of the current image, clamped (REPLICATE)
+      const TexPos &P = A.P;
       const int xm0 = max(P.i0 - 1, 0), xp0 = min(P.i0 + 1, L.w - 1), xm1 = max(P.i1 - 1, 0), xp1 = min(P.i1 + 1, L.w - 1);
       const int ym0 = max(P.j0 - 1, 0), yp0 = min(P.j0 + 1, L.h - 1), ym1 = max(P.j1 - 1, 0), yp1 = min(P.j1 + 1, L.h - 1);
       const float *r0 = L.cur + (size_t)P.j0 * L.fs, *r1 = L.cur + (size_t)P.j1 * L.fs;
-      const float dx00 = r0[xp0] - r0[xm0], dx01 = r1[xp0] - r1[xm0], dx10 = r0[xp1] - r0[xm1], dx11 = r1[xp1] - r1[xm1];
+      A.gx.v00 = r0[xp0]; A.gxm.v00 = r0[xm0]; A.gx.v01 = r1[xp0]; A.gxm.v01 = r1[xm0];
+      A.gx.v10 = r0[xp1]; A.gxm.v10 = r0[xm1]; A.gx.v11 = r1[xp1]; A.gxm.v11 = r1[xm1];
       const float *c0m = L.cur + (size_t)ym0 * L.fs, *c0p = L.cur + (size_t)yp0 * L.fs, *c1m = L.cur + (size_t)ym1 * L.fs, *c1p = L.cur + (size_t)yp1 * L.fs;
-      const float dy00 = c0p[P.i0] - c0m[P.i0], dy01 = c1p[P.i0] - c1m[P.i0], dy10 = c0p[P.i1] - c0m[P.i1], dy11 = c1p[P.i1] - c1m[P.i1];
-      gx = 0.5f * (P.w00 * dx00 + P.w01 * dx01 + P.w10 * dx10 + P.w11 * dx11);
-      gy = 0.5f * (P.w00 * dy00 + P.w01 * dy01 + P.w10 * dy10 + P.w11 * dy11);
+      A.gy.v00 = c0p[P.i0]; A.gym.v00 = c0m[P.i0]; A.gy.v01 = c1p[P.i0]; A.gym.v01 = c1m[P.i0];
+      A.gy.v10 = c0p[P.i1]; A.gym.v10 = c0m[P.i1]; A.gy.v11 = c1p[P.i1]; A.gym.v11 = c1m[P.i1];
     } else {
-      gx = 0.5f * tex_fetch(L.dx, L.fs, P);
-      gy = 0.5f * tex_fetch(L.dy, L.fs, P);
+      A.gx = tex_load(L.dx, O);
+      A.gy = tex_load(L.dy, O);
     }
-    // frameJacobian (gpu/dense_tracking.cu:65-80)
-    const float zsq = z * z;
-    const Recip Rq = recip(zsq);
-    gx *= L.f; gy *= L.f;
-    J[0] = -quot(gx, Rz);                                   // (float)(-dx * (1. / p.z))
-    J[1] = -quot(gy, Rz);                                   // (float)(-dy * 1. / p.z)
-    J[2] = quot(gx * x, Rq) + quot(gy * y, Rq);
-    J[3] = quot(gx * (x * y), Rq) + gy * (1.f + quot(y * y, Rq));
-    J[4] = -gx * (1.f + quot(x * x, Rq)) - quot(gy * (x * y), Rq);
-    J[5] = quot(gx * y, Rz) - quot(gy * x, Rz);
   }
-  return true;
+}
+// frameJacobian (gpu/dense_tracking.cu:65-80); the f64-promoted J0, J1 are exactly the f32 quotients (file header)
+template <bool FAST>
+__device__ __forceinline__ void frame_jacobian(float x, float y, float z, const Recip &Rz, float f, float gx, float gy, float *J) {
+  const float zsq = z * z;
+  const Recip Rq = recip(zsq);
+  gx *= f; gy *= f;
+  J[0] = -quot<FAST>(gx, Rz);                                   // (float)(-dx * (1. / p.z))
+  J[1] = -quot<FAST>(gy, Rz);                                   // (float)(-dy * 1. / p.z)
+  J[2] = quot<FAST>(gx * x, Rq) + quot<FAST>(gy * y, Rq);
+  J[3] = quot<FAST>(gx * (x * y), Rq) + gy * (1.f + quot<FAST>(y * y, Rq));
+  J[4] = -gx * (1.f + quot<FAST>(x * x, Rq)) - quot<FAST>(gy * (x * y), Rq);
+  J[5] = quot<FAST>(gx * y, Rz) - quot<FAST>(gy * x, Rz);
+}
+// stage B: residual and Jacobian from the landed taps.  Returns whether the pixel contributes.
+template <bool JAC, bool FUSE>
+__device__ __forceinline__ bool pixel_stage_b(const FullLevel &L, const PixelA<JAC, FUSE> &A, float &res, float *J) {
+  const float ic = tex_mix(A.P, A.c);
+  res = A.ok ? A.ip - ic : 0.f;
+  if (JAC) {
+    float gx, gy;
+    if (FUSE) {
+      Taps dx, dy;
+      dx.v00 = A.gx.v00 - A.gxm.v00; dx.v01 = A.gx.v01 - A.gxm.v01; dx.v10 = A.gx.v10 - A.gxm.v10; dx.v11 = A.gx.v11 - A.gxm.v11;
+      dy.v00 = A.gy.v00 - A.gym.v00; dy.v01 = A.gy.v01 - A.gym.v01; dy.v10 = A.gy.v10 - A.gym.v10; dy.v11 = A.gy.v11 - A.gym.v11;
+      gx = 0.5f * tex_mix(A.P, dx);
+      gy = 0.5f * tex_mix(A.P, dy);
+    } else {
+      gx = 0.5f * tex_mix(A.P, A.gx);
+      gy = 0.5f * tex_mix(A.P, A.gy);
+    }
+    if (!A.ok) { gx = 0.f; gy = 0.f; }
+    if (__builtin_expect(z_is_tame(A.z), 1)) frame_jacobian<true>(A.x, A.y, A.z, A.Rz, L.f, gx, gy, J);
+    else frame_jacobian<false>(A.x, A.y, A.z, A.Rz, L.f, gx, gy, J);
+  }
+  return A.ok;
+}
+template <bool JAC, bool FUSE>
+__device__ __forceinline__ bool full_pixel(const FullLevel &L, const M34 &T, const float4 p, const float ip, float &res, float *J) {
+  PixelA<JAC, FUSE> A;
+  pixel_stage_a<JAC, FUSE>(L, T, p, ip, A);
+  return pixel_stage_b<JAC, FUSE>(L, A, res, J);
 }
 
 struct AccF {
@@ -140,14 +198,15 @@ struct AccF {
   }
   // chi2 += (double)(res * res) as the restatement does; H and b take the exact products of the f32 terms (one f64 FMA each
   // instead of an f32 product, a conversion and an f64 add: the sweep is issue-bound on its f64 instructions)
+  // (a pixel that does not contribute arrives with res = 0 and J = +-0, see pixel_stage_a / _b)
   template <bool JAC> __device__ __forceinline__ void add(bool ok, float res, const float *J) {
-    const float r = ok ? res : 0.f;
+    const float r = res;
     v[27] += (double)(r * r);
     n += ok ? 1 : 0;
     if (JAC) {
       double Jd[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) Jd[i] = ok ? (double)J[i] : 0.0;
+      for (int i = 0; i < 6; ++i) Jd[i] = (double)J[i];
       int k = 0;
 #pragma unroll
       for (int c = 0; c < 6; ++c)
@@ -196,8 +255,9 @@ __device__ __forceinline__ void full_block_reduce(const AccF &a, double (*s_part
 
 // one sweep of this workgroup's share of a level: pixel groups of FULL_THREADS consecutive pixels (row-major over the
 // w x h image, so a wave reads 1 KiB of consecutive float4 cloud entries), groups dealt round-robin to the stream's
-// workgroups.  The T-independent loads of the next pixel (cloud entry, previous intensity) are issued before this
-// pixel's arithmetic; only the bilinear taps, whose addresses depend on the projection, are exposed.
+// workgroups.  The T-independent loads of the next pixel (cloud entry, previous intensity: the HBM stream) are issued before
+// this pixel's arithmetic.  Measured (profiles/r2_notes.md): the sweep is VALU-bound (75 % VALU-busy at 4 waves per SIMD), a
+// deeper software pipeline (taps of pixel k+1 in flight during the Jacobian of pixel k) costs 28 registers and buys nothing.
 template <bool JAC, bool FUSE>
 __device__ __forceinline__ void full_sweep(const FullLevel &L, const M34 &T, int wg, int nwg, AccF &a) {
   const int n = L.w * L.h;
@@ -205,17 +265,18 @@ __device__ __forceinline__ void full_sweep(const FullLevel &L, const M34 &T, int
   const int su = step % L.w, sv = step / L.w;
   int i = wg * FULL_THREADS + (int)threadIdx.x;
   int u = i % L.w, v = i / L.w;
+  const float4 none = make_float4(0.f, 0.f, 1.f, -1.f);
   bool in = i < n;
-  float4 p = in ? L.cloud[(size_t)v * L.s4 + u] : make_float4(0.f, 0.f, 1.f, -1.f);
-  float ip = in ? L.prev[(size_t)v * L.fs + u] : 0.f;
+  float4 p = in ? ld_at(L.cloud, (unsigned)(v * L.s4 + u) * 16u) : none;
+  float ip = in ? ld_at(L.prev, (unsigned)(v * L.fs + u) * 4u) : 0.f;
   for (; i < n; i += step) {
     const float4 pc = p;
     const float ipc = ip;
     u += su; v += sv;
     if (u >= L.w) { u -= L.w; ++v; }
     in = i + step < n;
-    p = in ? L.cloud[(size_t)v * L.s4 + u] : make_float4(0.f, 0.f, 1.f, -1.f);
-    ip = in ? L.prev[(size_t)v * L.fs + u] : 0.f;
+    p = in ? ld_at(L.cloud, (unsigned)(v * L.s4 + u) * 16u) : none;
+    ip = in ? ld_at(L.prev, (unsigned)(v * L.fs + u) * 4u) : 0.f;
     float res = 0.f, J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool ok = full_pixel<JAC, FUSE>(L, T, pc, ipc, res, J);
     a.template add<JAC>(ok, res, J);
@@ -303,7 +364,7 @@ constexpr long SPIN_LIMIT = 1l << 22;          // x s_sleep(2): seconds -- a sib
 
 // The whole DenseTracker::denseTrackingGpu loop of one stream (dense_tracking.cpp:60-193).
 template <bool FUSE, bool MULTI>
-__global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFullArgs A, double *__restrict__ T_io, int32_t *__restrict__ passes_out) {
+__global__ __launch_bounds__(FULL_THREADS, FULL_MINW) void dense_track_full_kernel(TrackFullArgs A, double *__restrict__ T_io, int32_t *__restrict__ passes_out) {
   __shared__ double s_part[FULL_WAVES][NS + 1];
   __shared__ double s_out[NS + 1];
   __shared__ double s_sum[NS + 1];
@@ -317,10 +378,9 @@ __global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFul
   double *part = MULTI ? A.part + (size_t)slot * nwg * 32 : nullptr;
   double *bcast = MULTI ? A.bcast + (size_t)slot * 16 : nullptr;
   unsigned *count = MULTI ? A.count + slot : nullptr, *epoch = MULTI ? A.epoch + slot : nullptr;
-  // LM state of the leader (lane 0 of workgroup 0)
-  float chi2 = 0.f;
-  double mu = 0.01f, nu = 2;           // `double mu = 0.01f` (dense_tracking.cpp:103)
-  int trial = 0, iter = 0, phase = PH_INIT, n_rec = 0;
+  // LM state of the leader (used by lane 0 of workgroup 0 only; kept in LDS so that nothing of it is live across the sweeps)
+  __shared__ struct { double mu, nu; float chi2; int trial, iter, phase, n_rec; } s_lm;
+  if (tid == 0) { s_lm.mu = 0.01f; s_lm.nu = 2; s_lm.chi2 = 0.f; s_lm.trial = 0; s_lm.iter = 0; s_lm.phase = PH_INIT; s_lm.n_rec = 0; }   // `double mu = 0.01f` (dense_tracking.cpp:103)
   if (tid < 12) { const double t = T_io[(size_t)slot * 12 + tid]; s_T[tid] = t; s_Teval[tid] = t; }
   if (tid < 36) s_Tj[tid / 12][tid % 12] = T_io[(size_t)slot * 12 + tid % 12];
   if (tid == 0) { s_ctl[0] = 2; s_ctl[1] = 0; }
@@ -337,7 +397,7 @@ __global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFul
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) T.m[3 * c + r] = (float)s_Teval[4 * r + c];
+      for (int r = 0; r < 3; ++r) T.m[3 * c + r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s_Teval[4 * r + c])));   // uniform: keep in SGPRs
     AccF a;
     a.zero();
     full_sweep<true, FUSE>(L, T, wg, nwg, a);
@@ -396,6 +456,9 @@ __global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFul
     __syncthreads();
     // ---- leader, lane 0: one step of the reference's LM state machine ----
     if (tid == 0) {
+      float chi2 = s_lm.chi2;
+      double mu = s_lm.mu, nu = s_lm.nu;
+      int trial = s_lm.trial, iter = s_lm.iter, phase = s_lm.phase, n_rec = s_lm.n_rec;
       const float chi2_e = (float)s_sum[27];                      // GpuTracker::chi2 returns float
       int lvl = level;
       bool level_done = false;
@@ -452,6 +515,7 @@ __global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFul
         for (int q = 0; q < 12; ++q) s_Teval[q] = Tn[q];
       }
       s_ctl[0] = lvl;
+      s_lm.chi2 = chi2; s_lm.mu = mu; s_lm.nu = nu; s_lm.trial = trial; s_lm.iter = iter; s_lm.phase = phase; s_lm.n_rec = n_rec;
     }
     __syncthreads();
     if (MULTI) {
@@ -467,7 +531,7 @@ __global__ __launch_bounds__(FULL_THREADS) void dense_track_full_kernel(TrackFul
   if (tid < 12) T_io[(size_t)slot * 12 + tid] = s_T[tid];
   if (tid == 0) {
     if (passes_out) passes_out[slot] = s_ctl[1] ? -1 : passes;
-    if (A.n_rec) A.n_rec[slot] = n_rec;
+    if (A.n_rec) A.n_rec[slot] = s_lm.n_rec;
   }
   if (A.T_jac && tid < 36) A.T_jac[(size_t)slot * 36 + tid] = s_Tj[tid / 12][tid % 12];
 }
@@ -701,9 +765,10 @@ extern "C" int svs_dense_track_full(svs_ctx *ctx, const svs_dense_track_full_arg
   A.T_jac = a->d_T_jac_out;
   A.rec = a->d_record_out; A.rec_cap = a->d_record_out ? a->record_cap : 0; A.n_rec = a->d_n_record_out;
   SVS_REQUIRE(ctx, !a->d_record_out || a->record_cap > 0);
-  // workgroups per stream: fill the resident slots (4 workgroups of 256 threads per CU at <= 128 VGPRs; keep half of them free for
-  // whatever else shares the device), never more than the pixel groups of the smallest level are worth
-  const int slots = 2 * ctx->n_cu;
+  // workgroups per stream: fill the resident slots (FULL_MINW workgroups of 256 threads per CU).  Workgroup ids are stream-major and
+  // dispatch is in id order, so on an oversubscribed device the resident set is a prefix of whole streams (+ one partial one that
+  // completes as soon as an earlier stream retires): co-residency is wanted for speed, not needed for progress.
+  const int slots = FULL_MINW * ctx->n_cu;
   int nwg = ctx->full_nwg ? ctx->full_nwg : std::max(1, std::min(slots / batch, 64));
   nwg = std::min(nwg, std::max(1, div_up(a->w[0] * a->h[0], FULL_THREADS)));
   A.nwg = nwg;
