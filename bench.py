@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="independent camera streams per rank per step")
     ap.add_argument("--points", type=int, default=2000, help="candidate points per frame (SURVEY 8d config 2)")
+    ap.add_argument("--pairs", type=int, default=32, help="distinct (previous, current) frame pairs with different motions dealt to the streams")
+    ap.add_argument("--full-batch", type=int, default=64, help="streams per launch of the full-resolution dense tracker row (BASELINE config 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -79,24 +81,38 @@ def main():
     cam = synth.CAM_DEFAULT
     scene = synth.Scene(2011)
     traj = synth.trajectory(8)
-    NPAIR = 2
+    # NPAIR distinct (previous, current) frame pairs with different inter-frame motions: forward step 2..8 cm, yaw 0.05..0.5 deg,
+    # a few mm of lateral drift -- so LM pass counts, FAST thresholds and candidate lists differ between the streams of a batch
+    NPAIR = args.pairs
     kf_id = 0
-    rend = {i: scene.render(cam, traj[i], seed=i) for i in [kf_id] + [4 + p for p in range(NPAIR + 1)]}
+    mrng = np.random.default_rng(77)
+    T_prev_list, T_cur_list = [], []
+    for p in range(NPAIR):
+        T_p = traj[4 + p % 4]
+        step, yaw = mrng.uniform(0.02, 0.08), np.deg2rad(mrng.uniform(0.05, 0.5)) * mrng.choice([-1, 1])
+        R_rel = synth.so3_exp(np.array([mrng.normal(0, 0.0005), yaw, mrng.normal(0, 0.0005)]))
+        T_rel_p = synth.pose(R_rel, np.array([mrng.normal(0, 0.003), mrng.normal(0, 0.002), -step]))     # camera moves forward: points come closer
+        T_prev_list.append(T_p)
+        T_cur_list.append(synth.pose_mul(T_rel_p, T_p))
+    rend_kf = scene.render(cam, traj[kf_id], seed=kf_id)
+    rend_prev = [scene.render(cam, T_prev_list[p], seed=100 + p) for p in range(NPAIR)]
+    rend_cur = [scene.render(cam, T_cur_list[p], seed=200 + p) for p in range(NPAIR)]
     T_right = synth.pose(np.eye(3), np.array([-cam["b"], 0.0, 0.0]))      # right camera of the stereo rig (for the block matcher)
-    rend_right = {i: scene.render(cam, synth.pose_mul(T_right, traj[i]), seed=1000 + i)[0] for i in [5 + p for p in range(NPAIR)]}
+    NRIGHT = min(NPAIR, 4)
+    rend_right = [scene.render(cam, synth.pose_mul(T_right, T_cur_list[p]), seed=1000 + p)[0] for p in range(NRIGHT)]
     I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
     def build_frontend(B):
-        prev_imgs = np.stack([rend[4 + (b % NPAIR)][0] for b in range(B)])
-        prev_disp = np.stack([rend[4 + (b % NPAIR)][1] for b in range(B)])
-        cur_imgs = np.stack([rend[5 + (b % NPAIR)][0] for b in range(B)])
-        cur_disp = np.stack([rend[5 + (b % NPAIR)][1] for b in range(B)])
+        prev_imgs = np.stack([rend_prev[b % NPAIR][0] for b in range(B)])
+        prev_disp = np.stack([rend_prev[b % NPAIR][1] for b in range(B)])
+        cur_imgs = np.stack([rend_cur[b % NPAIR][0] for b in range(B)])
+        cur_disp = np.stack([rend_cur[b % NPAIR][1] for b in range(B)])
 
         prev = FramePyramid(ctx, stream, cam, batch=B)
         cur = FramePyramid(ctx, stream, cam, batch=B)
         kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
         prev.upload(prev_imgs, prev_disp)
         cur.upload(cur_imgs, cur_disp)
-        kf.upload(rend[kf_id][0][None], rend[kf_id][1][None])
+        kf.upload(rend_kf[0][None], rend_kf[1][None])
         prev.preprocessing()
         kf.preprocessing()
         fast = FastGrid(ctx, cur)
@@ -108,12 +124,12 @@ def main():
             track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
         rng = np.random.default_rng(2011)
         n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
-        pts = synth.candidate_points(rng, cam, rend[kf_id][1], traj[kf_id], n_per_level)
+        pts = synth.candidate_points(rng, cam, rend_kf[1], traj[kf_id], n_per_level)
         T_kf = traj[kf_id]
-        Tc = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
+        Tc = np.stack([synth.pose_mul(T_cur_list[b % NPAIR], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
         matcher = GuidedMatcher(ctx, cur, fast)
         margs = matcher.prepare([(kf.pyr, 0, T_kf.reshape(12))], Tc, T_kf.reshape(12), pts)
-        T_rel = np.stack([synth.pose_mul(traj[5 + (b % NPAIR)], synth.pose_inv(traj[4 + (b % NPAIR)])).reshape(12) for b in range(B)])
+        T_rel = np.stack([synth.pose_mul(T_cur_list[b % NPAIR], synth.pose_inv(T_prev_list[b % NPAIR])).reshape(12) for b in range(B)])
         with torch.cuda.stream(stream):
             d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
 
@@ -155,7 +171,7 @@ def main():
     T_tracked = dtrack.d_T.cpu().numpy().reshape(B, 3, 4)
     mres = matcher.download()
     n_matched = int((mres["status"] == 0).sum(axis=1).mean())
-    track_err = float(np.abs(T_tracked[0] - T_rel[0].reshape(3, 4)).max())
+    track_err = float(max(np.abs(T_tracked[b] - T_rel[b].reshape(3, 4)).max() for b in range(min(B, NPAIR))))
 
     # per-stage / per-kernel timing with HIP events on the ctx stream (not part of the timed steps)
     stage_ms = {}
@@ -192,27 +208,34 @@ def main():
     # "stereo" stage of processFrame (calcDisparityCpu = cv::StereoBM): SURVEY 8f rank 1.  Timed on its own; the
     # headline step uses the have_disp_img path (disparity given), as BASELINE's configs do.
     stereo = StereoMatcher(ctx, cur)
-    stereo.upload_right(np.stack([rend_right[5 + (b % NPAIR)] for b in range(B)]))
+    stereo.upload_right(np.stack([rend_right[(b % NPAIR) % NRIGHT] for b in range(B)]))
+    if NPAIR > NRIGHT:      # only the first NRIGHT pairs have a rendered right image: give every stream a matching left image for this stage
+        with torch.cuda.stream(stream):
+            left_keep = cur.pyr[0].clone()
+            cur.pyr[0][:, :, :cur.w[0]] = torch.as_tensor(np.stack([rend_cur[(b % NPAIR) % NRIGHT][0] for b in range(B)])).to(dev)
     disp_given = cur.disp.clone()
     time_stage("stereo_bm", stereo.calcDisparityCpu, reps=5)
     with torch.cuda.stream(stream):
         d_bm = cur.disp[0, :, :cur.w[0]].cpu().numpy()
         d_gt = disp_given[0, :, :cur.w[0]].cpu().numpy()
         cur.disp.copy_(disp_given)
+        if NPAIR > NRIGHT:
+            cur.pyr[0].copy_(left_keep)
     bm_valid = d_bm >= 0
     stereo_info = {"valid_fraction": round(float(bm_valid.mean()), 4),
                    "median_abs_err_px_vs_true_disparity": round(float(np.median(np.abs(d_bm - d_gt)[bm_valid])), 4)}
     stereo.close()
     px = sum(cur.w[l] * cur.h[l] for l in range(3))
     n_corners = sum(len(fast.corners(0, l)[0]) for l in range(3))
-    passes = int(dtrack.d_passes.cpu().numpy().mean())
+    passes_all = dtrack.d_passes.cpu().numpy()
+    passes = float(passes_all.mean())
     # algorithmic bytes per frame, SURVEY.md 8d table
     alg = {
         "pyramid": cur.w[0] * cur.h[0] + cur.w[1] * cur.h[1] + cur.w[2] * cur.h[2],
         "convert_sobel": px * 13,      # stand-alone kernel, timed for reference; NOT part of the fused step
         "fast": px + 4 * n_corners + 22 * 4,
         "match": args.points * (60 + 121 + 20) + args.points * 10 * 64,
-        "dense_tracking": passes * (px // 16) * (16 + 1 + 16) // 3,     # cloud float4 + prev u8 + 4x4 u8 taps; passes spread over 3 levels
+        "dense_tracking": int(passes * (px // 16) * (16 + 1 + 16) / 3),     # cloud float4 + prev u8 + 4x4 u8 taps; passes spread over 3 levels
         "pointcloud": (px // 16) * 20,
         "stereo_bm": cur.w[0] * cur.h[0] * (2 + 4),     # left + right u8 in, f32 disparity out
     }
@@ -248,6 +271,71 @@ def main():
             ctx.sync()
             batch_sweep[str(Bs)] = round(Bs * 10 / (time.perf_counter() - t0), 1)
         del fes
+
+    # ------------------------------------------------------------------ BASELINE config 5: RGB-D full-resolution dense tracking
+    # DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193) for FB independent 640x480 RGB-D streams per launch: CUDA-branch
+    # preprocessing done, clouds resident; a step = the whole coarse-to-fine damped LM.  Algorithmic bytes per SURVEY 8d: 32 B per
+    # pixel per sweep of a level (the fused sweep yields chi2 AND H,b; the reference reads 24 + 32 B/px for the same pair).
+    from scavislam_amd.frontend import DenseTrackerGpu, GpuFrameData
+    FB = args.full_batch
+    camd = synth.CAM_RGBD
+    NFP = min(NPAIR, 8)
+    hrng = np.random.default_rng(2013)
+    fprev = GpuFrameData(ctx, stream, camd, FB)
+    fcur = GpuFrameData(ctx, stream, camd, FB)
+    fr_prev = [scene.render(camd, T_prev_list[p], seed=300 + p) for p in range(NFP)]
+    fr_cur = [scene.render(camd, T_cur_list[p], seed=400 + p) for p in range(NFP)]
+    disp_holes = [synth.depth_holes(fr_prev[p][1], hrng) for p in range(NFP)]          # 10 % invalid depth in blobs
+    fprev.upload(np.stack([fr_prev[b % NFP][0] for b in range(FB)]))
+    fcur.upload(np.stack([fr_cur[b % NFP][0] for b in range(FB)]))
+    fprev.preprocessing(); fcur.preprocessing()
+    dfull = DenseTrackerGpu(ctx, fcur)
+    clouds_full = [[synth.cloud_full_level(disp_holes[p], camd, l) for l in range(3)] for p in range(NFP)]
+    with torch.cuda.stream(stream):
+        for l in range(3):
+            dfull.dev_ref_dense_points[l].copy_(torch.as_tensor(np.stack([clouds_full[b % NFP][l] for b in range(FB)])))
+    fargs = dfull.track_args(fprev)
+    T_f, sweeps_f, rec_f = dfull.denseTrackingGpu(fprev, I34, args=fargs)
+    full_err = float(max(np.abs(T_f[b] - synth.pose_mul(T_cur_list[b % NFP], synth.pose_inv(T_prev_list[b % NFP]))).max() for b in range(min(FB, NFP))))
+    full_bytes = sum(32 * (camd["w"] >> l) * (camd["h"] >> l) * int((rec_f[b]["level"] == l).sum()) for b in range(FB) for l in range(3))
+    with torch.cuda.stream(stream):
+        d_T0f = torch.as_tensor(np.tile(I34, (FB, 1))).to(dev)
+        ms_full = []
+        for _ in range(2 + min(K, 10)):
+            dfull.d_T.copy_(d_T0f)
+            ctx.sync()
+            ctx.timer_start()
+            dfull.denseTrackingGpu(fprev, None, args=fargs, download=False)
+            ms_full.append(ctx.timer_stop_ms())
+        ms_full = float(np.median(ms_full[2:]))
+        # latency mode: one stream per launch
+        f1p, f1c = GpuFrameData(ctx, stream, camd, 1), GpuFrameData(ctx, stream, camd, 1)
+        f1p.upload(fr_prev[0][0][None]); f1c.upload(fr_cur[0][0][None])
+        f1p.preprocessing(); f1c.preprocessing()
+        d1 = DenseTrackerGpu(ctx, f1c)
+        for l in range(3):
+            d1.dev_ref_dense_points[l].copy_(torch.as_tensor(clouds_full[0][l][None]))
+        a1 = d1.track_args(f1p)
+        ms1 = []
+        for _ in range(12):
+            d1._set_T(I34)
+            ctx.sync()
+            ctx.timer_start()
+            d1.denseTrackingGpu(f1p, None, args=a1, download=False)
+            ms1.append(ctx.timer_stop_ms())
+        ms_full_b1 = float(np.median(ms1[2:]))
+    dense_full = {"workload": "configs[4]: RGB-D dense_tracking, 640x480 depth frames, full resolution, 3 levels, damped LM (denseTrackingGpu)",
+                  "streams_per_launch": FB, "ms_per_launch": round(ms_full, 4), "frames_per_s": round(world * FB / (ms_full * 1e-3), 1),
+                  "sweeps_per_frame": {"mean": round(float(sweeps_f.mean()), 2), "min": int(sweeps_f.min()), "max": int(sweeps_f.max())},
+                  "reference_kernel_passes_for_the_same_trajectories": round(float(np.mean([6 + 2 * int((r["accepted"] < 2).sum()) for r in rec_f])), 1),
+                  "pose_err_vs_true_motion": full_err,
+                  "latency_mode_B1_ms_per_frame": round(ms_full_b1, 4),
+                  "roofline": {"bound": "hbm", "kernel": "dense_track_full_kernel (whole LM in one launch; 32 B/px per fused chi2+H,b sweep)",
+                               "alg_bytes_per_launch": int(full_bytes), "avg_launch_ms": round(ms_full, 4),
+                               "achieved": round(full_bytes / (ms_full * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(full_bytes / (ms_full * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    del dfull, fprev, fcur, d1, f1p, f1c
+    torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ back-end (Schur) region
     P_, L_ = 50, 20000
@@ -348,15 +436,15 @@ def main():
         import oracle as O
         grids = [O.fastgrid_for_level(cur.w[l], cur.h[l], l) for l in range(3)]
         # state the reference also carries over from the previous frame (not timed)
-        pyr_p_cache = {p: O.build_pyramid(rend[4 + p][0]) for p in range(NPAIR)}
-        clouds_cache = {p: [O.pointcloud_cpu(rend[4 + p][1], cur.cams[l], l, I34.reshape(3, 4)) for l in range(3)]
+        pyr_p_cache = {p: O.build_pyramid(rend_prev[p][0]) for p in range(NPAIR)}
+        clouds_cache = {p: [O.pointcloud_cpu(rend_prev[p][1], cur.cams[l], l, I34.reshape(3, 4)) for l in range(3)]
                         for p in range(NPAIR)}
-        kf_pyr = O.build_pyramid(rend[kf_id][0])
+        kf_pyr = O.build_pyramid(rend_kf[0])
         t0 = time.perf_counter()
         nfr = 0
         while nfr < 3 or (time.perf_counter() - t0 < 8.0 and nfr < 200):      # BASELINE configs[0]: 200 frames
             p = nfr % NPAIR
-            img_c, disp_c = rend[5 + p]
+            img_c, disp_c = rend_cur[p]
             pyr_c = O.build_pyramid(img_c)                                      # "preprocess"
             fl = [O.convert_sobel(x) for x in pyr_c]
             Tt, _ = O.dense_tracking_cpu(clouds_cache[p], pyr_p_cache[p], [f[0] for f in fl], [f[1] for f in fl],
@@ -387,13 +475,14 @@ def main():
         t0 = time.perf_counter()
         nst = 0
         while nst < 2 or (time.perf_counter() - t0 < 4.0 and nst < 12):     # "stereo" (cv::StereoBM restatement), timed on its own like the GPU stage
-            O.stereo_bm(rend[5 + nst % NPAIR][0], rend_right[5 + nst % NPAIR])
+            O.stereo_bm(rend_cur[nst % NRIGHT][0], rend_right[nst % NRIGHT])
             nst += 1
         cpu_stereo_ms = (time.perf_counter() - t0) / nst * 1e3
         cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{nfr} frames 640x480 through the CPU oracle (same stages, same inputs)"
                          f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
                "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1),
+               "stereo_bm_note": "naive scalar restatement of cv::StereoBM, NOT OpenCV's SIMD implementation (30-50x faster): no speed-up claim for this stage",
                "schur_accumulate_ms_by_host_threads": acc_ms}
 
     if rank == 0:
@@ -419,13 +508,16 @@ def main():
                       "speedup_vs_cpu_port": round(cpu_schur_ms / ms_opt, 2) if cpu_schur_ms else None,
                       "weak_scaling": schur_weak},
             "frontend": {"stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-                         "dense_passes_per_frame": passes, "corners_per_frame": n_corners, "matches_per_frame": n_matched,
+                         "dense_passes_per_frame": round(passes, 2),
+                         "dense_passes_per_frame_spread": {"min": int(passes_all.min()), "max": int(passes_all.max()), "distinct_frame_pairs": NPAIR},
+                         "corners_per_frame": n_corners, "matches_per_frame": n_matched,
                          "dense_track_pose_err": track_err,
                          "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
                          "frames_per_s_per_gpu_by_batch": batch_sweep,
                          "stereo_bm": dict(stereo_info, ms_per_batch=round(stage_ms["stereo_bm"], 4),
                                            frames_per_s_if_block_matching_is_added_to_the_step=round(world * B / ((t_front / K) + stage_ms["stereo_bm"] * 1e-3), 1)),
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
+            "dense_full": dense_full,
             "roofline": roofline,
             "roofline_frontend": roofline_frontend,
             "cpu_baseline": cpu,
