@@ -254,6 +254,11 @@ int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t cloud_bstr
                            const float *d_cur, const float *d_dx, const float *d_dy, int fstride,
                            size_t f_bstride, const svs_cam *cam, const double *d_T, int do_jac,
                            svs_dense_sums *d_out, int batch);
+typedef struct {                       /* one entry per chi2 evaluation of the dense trackers' LM loops */
+  int32_t level;
+  int32_t accepted;                    /* 1 / 0 = trial accepted / rejected (rho > 0: dense_tracking.cpp:142-144 / :367-369); 2 = the level's initial chi2 */
+  float chi2, new_chi2;                /* chi2 before the trial, chi2 at the trial pose (both `float` in the reference) */
+} svs_dense_lm_record;
 /* whole DenseTracker::denseTrackingCpu(SE3*) (dense_tracking.cpp:222-391), device resident:
    3 levels x <=15 LM iterations with no host round trip. d_T_io [batch][12] in/out */
 typedef struct {
@@ -270,6 +275,12 @@ typedef struct {
      DenseTracker::residual_img[level] shows (dense_tracking.cpp:279-329); feed it to
      svs_dense_residual_image_cpu_sem.  NULL = not wanted. */
   double *d_T_jac_out;
+  /* optional accept / reject record of the loop, [batch][record_cap] (+ the number produced per stream).  The reference repeats a
+     rejected trial once (its undamped solve gives the identical step, so the identical rejection, then stops at trial == 2,
+     dense_tracking.cpp:379-384); the device loop stops at the first rejection and records it once. */
+  svs_dense_lm_record *d_record_out;
+  int32_t record_cap;
+  int32_t *d_n_record_out;
 } svs_dense_track_args;
 int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io,
                             int32_t *d_passes_out, int batch);
@@ -293,11 +304,6 @@ int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t 
 int svs_preprocess_gpu_sem(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride,
                            float *const *d_img, float *const *d_dx, float *const *d_dy, const int32_t *fstride,
                            const size_t *f_bstride, int levels, int batch);
-typedef struct {                       /* one entry per chi2 evaluation of denseTrackingGpu's loop */
-  int32_t level;
-  int32_t accepted;                    /* 1 / 0 = trial accepted / rejected (rho > 0, dense_tracking.cpp:142-144); 2 = the level's initial chi2 */
-  float chi2, new_chi2;                /* chi2 before the trial, chi2 at the trial pose (both `float` in the reference) */
-} svs_dense_lm_record;
 typedef struct {
   const float *d_cloud4[3]; int32_t stride_f4[3]; size_t cloud_bstride[3];   /* dev_ref_dense_points_[l]: float4 per pixel, strides in float4 */
   const float *d_prev[3];              /* prev_left().gpu_pyr_float32[l] */

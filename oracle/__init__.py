@@ -218,7 +218,7 @@ def dense_pass_cpu(cloud, prev_u8, cur, dx, dy, cam, T, do_jac, want_rimg=False)
     return (out[0], rimg) if want_rimg else out[0]
 
 
-def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T, want_rimg=False):
+def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T, want_rimg=False, want_rec=False):
     clouds = [np.ascontiguousarray(a, np.float32) for a in clouds]
     prev = [np.ascontiguousarray(a) for a in prev_pyr]
     cur = [np.ascontiguousarray(a, np.float32) for a in cur_f]
@@ -230,14 +230,18 @@ def dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T, want_rimg=F
     # DenseTracker's constructor fills residual_img with (0,0,0,1) (dense_tracking.cpp:54)
     rimg = [np.tile(np.array([0, 0, 0, 1], np.float32), (*c.shape[:2], 1)) for c in clouds]
     L = lib()
-    L.svs_ref_dense_tracking_cpu_rimg.argtypes = [C.c_void_p] * 2 + [C.c_void_p] + [C.c_void_p] * 3 + \
-        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    passes = L.svs_ref_dense_tracking_cpu_rimg(
+    L.svs_ref_dense_tracking_cpu_rec.argtypes = [C.c_void_p] * 2 + [C.c_void_p] + [C.c_void_p] * 3 + \
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rec = np.zeros((256, 4))
+    nrec = C.c_int(0)
+    passes = L.svs_ref_dense_tracking_cpu_rec(
         P3(*[a.ctypes.data for a in clouds]), P3(*[a.ctypes.data for a in prev]),
         I3(*[a.strides[0] for a in prev]), P3(*[a.ctypes.data for a in cur]),
         P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]),
         I3(*[a.strides[0] // 4 for a in cur]), cams, _p(T),
-        P3(*[a.ctypes.data for a in rimg]) if want_rimg else None)
+        P3(*[a.ctypes.data for a in rimg]) if want_rimg else None, _p(rec), 256, C.byref(nrec))
+    if want_rec:
+        return T.reshape(3, 4), passes, rec[:nrec.value].copy()
     if want_rimg:
         return T.reshape(3, 4), passes, rimg
     return T.reshape(3, 4), passes

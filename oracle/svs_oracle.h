@@ -201,6 +201,11 @@ int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *
                                     const float *const dx[3], const float *const dy[3],
                                     const int fstride[3], const svs_cam cam_vec[3], double *T,
                                     float *const rimg[3]);
+int svs_ref_dense_tracking_cpu_rec(const float *const cloud[3], const uint8_t *const prev_u8[3],
+                                   const int pstride[3], const float *const cur[3],
+                                   const float *const dx[3], const float *const dy[3],
+                                   const int fstride[3], const svs_cam cam_vec[3], double *T,
+                                   float *const rimg[3], double *rec, int rec_cap, int *n_rec);
 /* gpu/dense_tracking.cu:495-541 residualImage_kernel; rimg has the cloud's stride */
 void svs_ref_residual_image_full(const float *cloud, int w, int h, int stride4, const float *prev,
                                  const float *cur, int stride_f, float f, float cx, float cy,

@@ -479,7 +479,16 @@ int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *
                                     const float *const dx[3], const float *const dy[3],
                                     const int fstride[3], const svs_cam cam_vec[3], double *T,
                                     float *const rimg[3]) {
-  int passes = 0;
+  return svs_ref_dense_tracking_cpu_rec(cloud, prev_u8, pstride, cur, dx, dy, fstride, cam_vec, T, rimg, 0, 0, 0);
+}
+/* same + the accept / reject record: rec[4 k ..] = {level, accepted (1 / 0; 2 = the level's initial chi2), chi2, new_chi2} */
+int svs_ref_dense_tracking_cpu_rec(const float *const cloud[3], const uint8_t *const prev_u8[3],
+                                   const int pstride[3], const float *const cur[3],
+                                   const float *const dx[3], const float *const dy[3],
+                                   const int fstride[3], const svs_cam cam_vec[3], double *T,
+                                   float *const rimg[3], double *rec, int rec_cap, int *n_rec) {
+  int passes = 0, nr = 0;
+#define SVS_REC(l, a, c0, c1) do { if (rec && nr < rec_cap) { rec[4 * nr] = (l); rec[4 * nr + 1] = (a); rec[4 * nr + 2] = (c0); rec[4 * nr + 3] = (c1); } ++nr; } while (0)
   for (int level = 2; level >= 0; --level) {
     const svs_cam *cam = &cam_vec[level];
     int cw = cam->w / 4, ch = cam->h / 4;
@@ -487,6 +496,7 @@ int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *
     svs_ref_dense_pass_cpu(cloud[level], cw, ch, prev_u8[level], pstride[level], cur[level], dx[level], dy[level], fstride[level], cam, T, 0, &s, 0);
     ++passes;
     float chi2 = (float)s.chi2;
+    SVS_REC(level, 2, chi2, chi2);
     double nu = 2, mu = 0.01f; int stop = 0, trial = 0;
     (void)nu; (void)mu;
     for (int i = 0; i < 15; ++i) {
@@ -506,6 +516,7 @@ int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *
         ++passes;
         float new_chi2 = (float)s2.chi2;
         rho = chi2 - new_chi2;
+        SVS_REC(level, rho > 0 ? 1 : 0, chi2, new_chi2);
         if (rho > 0) {
           memcpy(T, Tn, sizeof(double) * 12);
           chi2 = new_chi2;
@@ -520,6 +531,8 @@ int svs_ref_dense_tracking_cpu_rimg(const float *const cloud[3], const uint8_t *
       if (stop) break;
     }
   }
+#undef SVS_REC
+  if (n_rec) *n_rec = nr;
   return passes;
 }
 

@@ -27,7 +27,7 @@ class DenseTrackArgs(C.Structure):
                 ("d_cur", C.c_void_p * 3), ("d_dx", C.c_void_p * 3), ("d_dy", C.c_void_p * 3),
                 ("fstride", C.c_int32 * 3), ("f_bstride", C.c_size_t * 3), ("cam_vec", Cam * 3),
                 ("d_cur_u8", C.c_void_p * 3), ("c8stride", C.c_int32 * 3), ("c8_bstride", C.c_size_t * 3),
-                ("d_T_jac_out", C.c_void_p)]
+                ("d_T_jac_out", C.c_void_p), ("d_record_out", C.c_void_p), ("record_cap", C.c_int32), ("d_n_record_out", C.c_void_p)]
 
 
 class DenseTrackFullArgs(C.Structure):

@@ -290,6 +290,7 @@ struct TrackArgs {
   LevelArgs lv[3];
   size_t cloud_b[3], prev_b[3], f_b[3], c8_b[3];
   double *T_jac;     // optional [batch][3][12]: pose of the last H,b pass of each level (what residual_img[level] shows)
+  svs_dense_lm_record *rec; int rec_cap; int32_t *n_rec;      // optional accept / reject record of the loop
 };
 
 #ifndef SVS_TRK_THREADS
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (threadIdx.x < 12) s_T[threadIdx.x] = T_io[(size_t)slot * 12 + threadIdx.x];
   for (int i = threadIdx.x; i < 256; i += TRK_THREADS) s_iplut[i] = (float)((1. / 255.) * i);
   __syncthreads();
-  int passes = 0;
+  int passes = 0, n_rec = 0;
   // One fused pass per LM iteration.  The reference runs, per iteration, an H,b pass at T and a
   // chi2 pass at T_new, and after an accepted step starts the next iteration with an H,b pass at
   // that same T_new.  Evaluating chi2 AND H,b together at T_new therefore serves both (identical
@@ -400,6 +401,8 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     ++passes;
     float chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
+    if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
+    ++n_rec;
     __syncthreads();
     bool stop = false;
     for (int it = 0; it < 15 && !stop; ++it) {
@@ -423,6 +426,8 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       ++passes;
       const float new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
+      if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, rho > 0 ? 1 : 0, chi2, new_chi2};
+      ++n_rec;
       if (rho > 0) {
         chi2 = new_chi2;
         double mx = -1;
@@ -440,6 +445,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (wg != 0) return;
   if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];
   if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
+  if (threadIdx.x == 0 && A.n_rec) A.n_rec[slot] = n_rec;
   if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
 }
 
@@ -591,6 +597,8 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     A.cloud_b[l] = a->cloud_bstride[l]; A.prev_b[l] = a->p_bstride[l]; A.f_b[l] = a->f_bstride[l]; A.c8_b[l] = a->c8_bstride[l];
   }
   A.T_jac = a->d_T_jac_out;
+  A.rec = a->d_record_out; A.rec_cap = a->d_record_out ? a->record_cap : 0; A.n_rec = a->d_n_record_out;
+  SVS_REQUIRE(ctx, !a->d_record_out || a->record_cap > 0);
   // latency mode: with few streams, NW workgroups share each stream's sweeps (they must all be resident: NW * batch <= 128 CUs)
   int nwg = batch <= 32 ? 4 : 1;      // measured (B = 1 / 8): 4 workgroups 0.26 ms / 19.4k fps, 8: 0.26 / 15.6k, 16: 0.28 / 10.4k, 1: 0.34 / 14.4k;
                                       // 2 per stream at 64 streams lose to one (barrier + redundant LM tails)

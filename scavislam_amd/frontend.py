@@ -321,6 +321,8 @@ class DenseTracker:
             self.d_passes = torch.zeros(frame.batch, dtype=torch.int32, device=dev)
             self.d_sums = torch.zeros(frame.batch * DENSE_SUMS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             self.d_T_jac = torch.zeros((frame.batch, NUM_PYR_LEVELS, 12), dtype=torch.float64, device=dev)
+            self.d_rec = torch.zeros(frame.batch * 128 * DENSE_LM_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.d_nrec = torch.zeros(frame.batch, dtype=torch.int32, device=dev)
             # DenseTracker's constructor: residual_img[level].setTo((0,0,0,1)) (dense_tracking.cpp:52-54)
             self.residual_img = [torch.zeros_like(c) for c in self.ref_dense_points]
             for r in self.residual_img:
@@ -366,7 +368,15 @@ class DenseTracker:
             a.fstride[l], a.f_bstride[l] = fr.stride[l], fr.bstride(l)
             a.cam_vec[l] = fr.cams[l]
         a.d_T_jac_out = self.d_T_jac.data_ptr()
+        a.d_record_out, a.record_cap, a.d_n_record_out = self.d_rec.data_ptr(), 128, self.d_nrec.data_ptr()
         return a
+
+    def lm_records(self):
+        """accept / reject record of the last denseTrackingCpu call: list (per stream) of DENSE_LM_RECORD_DTYPE arrays"""
+        self.ctx.sync()
+        n = self.d_nrec.cpu().numpy()
+        rec = self.d_rec.cpu().numpy().view(DENSE_LM_RECORD_DTYPE).reshape(self.frame.batch, 128)
+        return [rec[b, :min(int(n[b]), 128)].copy() for b in range(self.frame.batch)]
 
     def computeResidualImages(self, prev_pyr, from_u8=False):
         """Fill the public residual_img[level] member as denseTrackingCpu leaves it (dense_tracking.cpp:279-329):

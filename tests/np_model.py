@@ -552,3 +552,56 @@ def match_point(pt, kf_pyr, T_anchor_from_w, T_cur_from_actkey, T_actkey_from_w,
         s = float(1 << l)
         return (0, bu, bv, best, np.array([float(np.float32(bu)) * s, float(np.float32(bv)) * s, (float(np.float32(bu)) - d) * s]), xyz_actkey)
     return (6, bu, bv, best, np.zeros(3), xyz_actkey)
+
+
+# ---- sensitivity of the landmark back-substitution (vectorised over edges, numeric Jacobians) ---------------------------
+def _residual_vec(psi, T_obs, T_anc, obs, cam):
+    """stereo_residual for arrays: psi [E,3], T_* [E,3,4], obs [E,3] -> [E,3]"""
+    xa = np.stack([psi[:, 0], psi[:, 1], np.ones(len(psi))], 1) / psi[:, 2:3]
+    Ra, ta = T_anc[:, :, :3], T_anc[:, :, 3]
+    xw = np.einsum("eji,ej->ei", Ra, xa - ta)                 # T_anc^-1 x_a
+    y = np.einsum("eij,ej->ei", T_obs[:, :, :3], xw) + T_obs[:, :, 3]
+    f, cx, cy, b = cam
+    return obs - np.stack([f * y[:, 0] / y[:, 2] + cx, f * y[:, 1] / y[:, 2] + cy, f * (y[:, 0] - b) / y[:, 2] + cx], 1)
+
+
+def _exp_left(T, d):
+    """exp(d) * T for arrays T [E,3,4] and ONE tangent vector d (6)"""
+    E4 = np.vstack([se3_exp(d), [0, 0, 0, 1]])
+    T4 = np.concatenate([T, np.tile(np.array([[[0, 0, 0, 1.0]]]), (len(T), 1, 1))], 1)
+    return np.einsum("ij,ejk->eik", E4, T4)[:, :3]
+
+
+def landmark_amplification(poses, psi, edges, cam, lam, delta=1.0, eps=1e-6):
+    """Per landmark l: a_l = || (H_ll + lam I)^-1 ||_2 * || [W_1 .. W_m] ||_F, the factor by which a perturbation of the pose
+    update x_p is amplified in x_l = D^-1 (b_l - sum W_i^T x_i)  (BlockSolver::solve, SURVEY.md A.3).  Numeric Jacobians of
+    the stereo residual, Huber weights at the given state, self edges (observer == anchor) have no pose Jacobian."""
+    P = poses.reshape(-1, 3, 4)
+    To, Ta = P[edges["pose"]], P[edges["anchor"]]
+    ps = psi[edges["point"]]
+    r0 = _residual_vec(ps, To, Ta, edges["obs"], cam)
+    e2 = (r0 * r0 * edges["info"]).sum(1)
+    rho1 = np.where(e2 <= delta * delta, 1.0, delta / np.sqrt(np.maximum(e2, 1e-300)))
+    om = edges["info"] * rho1[:, None]
+    Jpsi = np.zeros((len(edges), 3, 3))
+    for k in range(3):
+        d = np.zeros(3); d[k] = eps
+        Jpsi[:, :, k] = (_residual_vec(ps + d, To, Ta, edges["obs"], cam) - _residual_vec(ps - d, To, Ta, edges["obs"], cam)) / (2 * eps)
+    Jo = np.zeros((len(edges), 3, 6)); Ja = np.zeros((len(edges), 3, 6))
+    for k in range(6):
+        d = np.zeros(6); d[k] = eps
+        Jo[:, :, k] = (_residual_vec(ps, _exp_left(To, d), Ta, edges["obs"], cam) - _residual_vec(ps, _exp_left(To, -d), Ta, edges["obs"], cam)) / (2 * eps)
+        Ja[:, :, k] = (_residual_vec(ps, To, _exp_left(Ta, d), edges["obs"], cam) - _residual_vec(ps, To, _exp_left(Ta, -d), edges["obs"], cam)) / (2 * eps)
+    self_edge = edges["pose"] == edges["anchor"]
+    Jo[self_edge] = 0; Ja[self_edge] = 0
+    L = len(psi)
+    Hll = np.zeros((L, 3, 3)); W2 = np.zeros(L)
+    np.add.at(Hll, edges["point"], np.einsum("eki,ek,ekj->eij", Jpsi, om, Jpsi))
+    Wo = np.einsum("eki,ek,ekj->eij", Jo, om, Jpsi)
+    Wa = np.einsum("eki,ek,ekj->eij", Ja, om, Jpsi)
+    np.add.at(W2, edges["point"], (Wo ** 2).sum((1, 2)) + (Wa ** 2).sum((1, 2)))     # upper bound: anchor blocks of a landmark add up coherently at most
+    seen = np.zeros(L, bool); seen[edges["point"]] = True
+    amp = np.zeros(L)
+    ev = np.linalg.eigvalsh(Hll[seen] + lam * np.eye(3))
+    amp[seen] = np.sqrt(W2[seen]) / ev[:, 0]
+    return amp

@@ -302,9 +302,21 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     assert st_ref.accepted >= 1
     np.testing.assert_allclose(st.chi2_final, st_ref.chi2_final, rtol=1e-8)      # wide envelopes: longer elimination chains
     assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6               # the parity bar (measured: 2e-9 .. 2e-8)
-    # landmarks: 1e-5 here.  One weakly constrained landmark of this window amplifies the run-to-run 1e-9 wobble of the
-    # pose update (f64 atomics order) by ~250x; every solve kernel shows the same 5e-7 .. 4e-6 on it (tools/dbg_wide.py)
-    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-5
+    # landmarks: the same 1e-6 bar.  x_l = D^-1 (b_l - sum W_i^T x_i) multiplies whatever the pose update carries (1e-9 relative:
+    # f64 atomics order) by a_l = |D^-1| |W|; a landmark whose a_l is far above the window's typical value (weak parallax: tiny
+    # smallest eigenvalue of H_ll) cannot meet a bar relative to the LARGEST update of the window.  Those are excluded by a stated,
+    # state-derived bound, and the test asserts how few they are.
+    import np_model as M
+    c = prob["cam"]
+    amp = M.landmark_amplification(prob["poses"], prob["psi"], prob["edges"], (c["f"], c["cx"], c["cy"], c["b"]), st_ref.lambda_final)
+    seen = amp > 0
+    bound = 50.0 * np.median(amp[seen])
+    keep = seen & (amp <= bound)
+    n_excluded = int((seen & ~keep).sum())
+    assert n_excluded <= 4, f"{n_excluded} landmarks above 50x the median amplification"
+    upd = np.abs(psi_ref - prob["psi"]).max()
+    assert np.abs(psi - psi_ref)[keep].max() / upd < 1e-6, f"excluded {n_excluded}"
+    assert np.abs(psi - psi_ref)[~keep & seen].max(initial=0.0) / upd < 1e-4     # and even those stay close
     opt.close()
 
 

@@ -278,8 +278,8 @@ def test_dense_tracking_device_resident_lm(gpu_ctx, scene_frames):
     clouds = [O.pointcloud_cpu(disp_p, prev.cams[l], l, I) for l in range(3)]
     pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
     fl = [O.convert_sobel(p) for p in pyr_c]
-    T_ref, passes_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl],
-                                             cur.cams, I)
+    T_ref, passes_ref, rec_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl],
+                                                      cur.cams, I, want_rec=True)
     T_true = synth.pose_mul(T_c, synth.pose_inv(T_p))
     err_gpu = np.abs(T_gpu[0] - T_true).max()
     err_ref = np.abs(T_ref - T_true).max()
@@ -287,6 +287,83 @@ def test_dense_tracking_device_resident_lm(gpu_ctx, scene_frames):
     assert err_ref < 0.5 * err_start and err_gpu < 0.5 * err_start
     np.testing.assert_allclose(T_gpu[0], T_ref, rtol=0, atol=1e-4)
     assert 3 <= passes[0] <= 3 * (1 + 15 * 2 * 3)
+    # the LM trajectory itself (dense_tracking.cpp:367-385)
+    n_strict = _check_cpu_sem_trajectory(dt.lm_records()[0], passes[0], rec_ref, passes_ref, "scene_frames")
+    print("strictly compared:", n_strict)
+
+
+def _check_cpu_sem_trajectory(rec, passes, rec_ref, passes_ref, label):
+    """Accept / reject sequence and the chi2 of every trial of the device-resident denseTrackingCpu loop vs the oracle's.
+    The reference keeps chi2 in a `float` accumulated serially over ~25k samples (dense_tracking.cpp:229,335): its own summation
+    noise is ~1e-5 relative, so a trial whose |chi2 - new_chi2| is below 1e-5 chi2 is decided by that noise and the
+    comparison is only made up to the first such trial.  The reference repeats a rejected trial (identical step, identical
+    rejection) before it stops at trial == 2; the device loop records it once.  Returns 1 if the whole trajectory was compared."""
+    ref = rec_ref.copy()
+    dup = np.zeros(len(ref), bool)
+    for k in range(1, len(ref)):
+        if ref[k, 1] == 0 and ref[k - 1, 1] == 0 and ref[k, 0] == ref[k - 1, 0]:
+            assert ref[k, 2] == ref[k - 1, 2] and ref[k, 3] == ref[k - 1, 3]      # the repeated trial really is identical
+            dup[k] = True
+    ref = ref[~dup]
+    is_trial = ref[:, 1] < 2
+    near_tie = is_trial & (np.abs(ref[:, 2] - ref[:, 3]) < 1e-5 * np.abs(ref[:, 2]))
+    assert passes == len(rec), label                   # one fused pass per chi2 evaluation
+    n_cmp = int(np.argmax(near_tie)) if near_tie.any() else len(ref)         # records before the first near-tie are comparable
+    print(f"{label}: {int(is_trial.sum())} trials, {int(near_tie.sum())} near-tie(s), comparing the first {n_cmp} of {len(ref)} records")
+    assert len(rec) >= n_cmp
+    assert np.array_equal(rec["level"][:n_cmp], ref[:n_cmp, 0].astype(np.int32)), label
+    assert np.array_equal(rec["accepted"][:n_cmp], ref[:n_cmp, 1].astype(np.int32)), label
+    np.testing.assert_allclose(rec["chi2"][:n_cmp], ref[:n_cmp, 2], rtol=2e-5)
+    np.testing.assert_allclose(rec["new_chi2"][:n_cmp], ref[:n_cmp, 3], rtol=2e-5)
+    if near_tie.any():
+        return 0
+    assert len(rec) == len(ref), label
+    # the reference's pass count for this trajectory: per level 1 chi2 pass, 2 passes per trial, rejected trials twice
+    assert passes_ref == 3 + 2 * (int(is_trial.sum()) + int(dup.sum())), label
+    return 1
+
+
+def test_dense_tracking_lm_trajectory_many_scenes(gpu_ctx):
+    """Eight streams with different scenes / motions: every stream's accept / reject record is compared with the oracle's up to its
+    first near-tie; at least three of them must be comparable to the end (no near-tie at all) and then equal record for record."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    ctx, stream = gpu_ctx
+    cam = synth.CAM_DEFAULT
+    B = 8
+    sc = synth.Scene(2011)
+    rng = np.random.default_rng(5)
+    base = synth.trajectory(6)
+    T_prev = [base[b % 6] for b in range(B)]
+    T_cur = [synth.pose_mul(synth.pose(synth.so3_exp([rng.normal(0, 5e-4), np.deg2rad(rng.uniform(0.05, 0.5)), rng.normal(0, 5e-4)]),
+                                       [rng.normal(0, 0.003), rng.normal(0, 0.002), -rng.uniform(0.02, 0.08)]), T_prev[b]) for b in range(B)]
+    prev_f = [sc.render(cam, T_prev[b], seed=500 + b) for b in range(B)]
+    cur_f = [sc.render(cam, T_cur[b], seed=600 + b) for b in range(B)]
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    prev.upload(np.stack([f[0] for f in prev_f]), np.stack([f[1] for f in prev_f]))
+    cur.upload(np.stack([f[0] for f in cur_f]), np.stack([f[1] for f in cur_f]))
+    prev.preprocessing(); cur.preprocessing()
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dtp.ref_dense_points
+    T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+    recs = dt.lm_records()
+    n_strict = 0
+    for b in range(B):
+        clouds = [O.pointcloud_cpu(prev_f[b][1], prev.cams[l], l, I) for l in range(3)]
+        pyr_p, pyr_c = O.build_pyramid(prev_f[b][0]), O.build_pyramid(cur_f[b][0])
+        fl = [O.convert_sobel(p) for p in pyr_c]
+        T_ref, passes_ref, rec_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cur.cams, I,
+                                                          want_rec=True)
+        strict = _check_cpu_sem_trajectory(recs[b], passes[b], rec_ref, passes_ref, f"stream {b}")
+        n_strict += strict
+        if strict:
+            np.testing.assert_allclose(T[b], T_ref, rtol=0, atol=1e-6)
+    assert n_strict >= 3, f"only {n_strict} of {B} streams without a near-tie"
 
 
 def test_dense_full_resolution_variant(gpu_ctx, scene_frames):
