@@ -343,6 +343,19 @@ int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, in
 int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ_colmajor, const float *d_disp, int w, int h,
                         int stride_in, int stride_out, int factor, float *d_cloud4);
 
+/* ---- multi-GPU: the library-owned collective of the landmark-sharded back-end.  The reference has no
+   distributed code; one process per GPU each creates a context and a communicator (RCCL, bound at run time) --------------*/
+typedef struct { char bytes[128]; } svs_unique_id;      /* = ncclUniqueId */
+typedef struct svs_comm svs_comm;
+/* rank 0 obtains the id and hands it to the other ranks out of band (MPI, a TCP store, a file) */
+int svs_comm_get_unique_id(svs_ctx *ctx, svs_unique_id *out);
+/* collective over all ranks: ncclCommInitRank on the context's device */
+int svs_comm_create(svs_ctx *ctx, const svs_unique_id *id, int rank, int world, svs_comm **out);
+int svs_comm_destroy(svs_comm *c);
+/* sum `count` doubles at d_buf in place across ranks, on the context's stream (asynchronous like every device entry point) */
+int svs_comm_allreduce_f64(svs_comm *c, void *d_buf, size_t count);
+int svs_comm_stats(svs_comm *c, int32_t *rank, int32_t *world, uint64_t *n_calls, uint64_t *n_doubles);
+
 /* ---- BA: replaces SlamGraph::optimize (slam_graph.hpp:457-462, slam_graph.cpp:312-355) -------*/
 typedef struct svs_ba svs_ba;
 /* all-reduce hook for landmark-sharded operation: sum `count` doubles at d_buf in place across
@@ -363,6 +376,16 @@ int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const do
 int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats);
 /* restoreDataFromG2o (slam_graph.cpp:1035-1058): poses [P][12], psi [L][3] */
 int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
+/* landmark-sharded operation over a library-owned communicator: svs_ba_optimize(ba, NULL, NULL, stats) then all-reduces the
+   packed reduced system and the two trial scalars of every LM trial (and, once per problem, the co-visibility pattern) with
+   ncclAllReduce on the ctx stream.  comm == NULL detaches.  A non-NULL `allreduce` argument of svs_ba_optimize takes precedence
+   (test hook). */
+int svs_ba_set_comm(svs_ba *ba, svs_comm *comm);
+/* experiment / test switches of one optimizer (0 = default behaviour): "no_speculation", "one_front", "no_fused_solve",
+   "no_lds_solve", "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
+   "p1" (rows of the reversed front), "group" (anchors dealt round-robin), "host_threads".  The environment (SVS_BA_*,
+   SVS_HOST_THREADS) only supplies the initial values, read once by svs_ba_create; values are clamped to their valid ranges. */
+int svs_ba_set_option(svs_ba *ba, const char *name, int value);
 /* building blocks exposed for parity tests and profiling */
 int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
 int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,

@@ -48,6 +48,47 @@ def make_allreduce(stream, device, group=None):
     return capi.ALLREDUCE_FN(_fn)
 
 
+class Communicator:
+    """svs_comm: the library-owned RCCL communicator of the landmark-sharded back-end.  The unique id travels from rank 0 to the
+    other ranks through torch.distributed (any backend; here only as the out-of-band channel a C++ host would replace by MPI or a
+    TCP store) -- the collectives of svs_ba_optimize themselves are ncclAllReduce calls made by the library on its own stream."""
+
+    def __init__(self, ctx, rank, world, device=None, group=None):
+        import torch.distributed as dist
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            ctx.call("svs_comm_get_unique_id", uid.ctypes.data)
+        if world > 1:
+            t = torch.as_tensor(uid)
+            if device is not None:
+                t = t.to(device)
+            dist.broadcast(t, src=0, group=group)
+            uid = t.cpu().numpy().copy()
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svs_comm_create(ctx.h, uid.ctypes.data, rank, world, C.byref(self.h)))
+        ctx.children.add(self)
+
+    def allreduce(self, d_ptr, count):
+        self.ctx.check(self.ctx.lib.svs_comm_allreduce_f64(self.h, d_ptr, count))
+
+    def stats(self):
+        r, w, n, d = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        self.ctx.lib.svs_comm_stats(self.h, C.byref(r), C.byref(w), C.byref(n), C.byref(d))
+        return dict(rank=r.value, world=w.value, n_calls=n.value, n_doubles=d.value)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.svs_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _CudaArray:
     def __init__(self, ptr, count):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
@@ -102,6 +143,14 @@ class SlamGraphOptimizer:
         H, b, chi2 = np.zeros((n, n)), np.zeros(n), np.zeros(1)
         self.ctx.check(self.ctx.lib.svs_ba_reduced_system(self.h, float(lam), H.ctypes.data, b.ctypes.data, chi2.ctypes.data))
         return H, b, float(chi2[0])
+
+    def set_option(self, name, value):
+        """experiment / test switches of this optimizer (svs_ba_set_option)"""
+        self.ctx.check(self.ctx.lib.svs_ba_set_option(self.h, name.encode(), int(value)))
+
+    def set_comm(self, comm):
+        """attach a library-owned communicator: optimize() then all-reduces with ncclAllReduce on the ctx stream"""
+        self.ctx.check(self.ctx.lib.svs_ba_set_comm(self.h, comm.h if comm is not None else None))
 
     def set_timing(self, on):
         """hipEvent brackets around the dominant kernels of every LM trial (profiling; ~4 us per event)."""

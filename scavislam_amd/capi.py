@@ -115,6 +115,13 @@ _SIGS = {
     "svs_ba_reset_state": [C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_reduced_system": [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_set_timing": [C.c_void_p, C.c_int],
+    "svs_ba_set_option": [C.c_void_p, C.c_char_p, C.c_int],
+    "svs_ba_set_comm": [C.c_void_p, C.c_void_p],
+    "svs_comm_get_unique_id": [C.c_void_p, C.c_void_p],
+    "svs_comm_create": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "svs_comm_destroy": [C.c_void_p],
+    "svs_comm_allreduce_f64": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "svs_comm_stats": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_int32)],
 }

@@ -1658,8 +1658,10 @@ class HostPool {
     { std::lock_guard<std::mutex> lk(m_); gen_fast_.fetch_add(1, std::memory_order_release); }      // under the lock: no lost wake-up
     cv_.notify_all();
     fn(0, n_);
-    while (pending_.load(std::memory_order_acquire) != 0) { /* phases are sub-millisecond: spin */ }
+    for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin)       // phases are sub-millisecond: spin briefly, then let go of the core
+      if (spin > 4096) std::this_thread::yield();
   }
+  std::mutex use_;                      // one caller at a time (the pool is shared by every optimizer of the process)
 
  private:
   void loop(int t) {
@@ -1687,8 +1689,17 @@ class HostPool {
   std::atomic<bool> stop_{false};
 };
 
+struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
+  int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, debug = 0;
+  int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0;
+};
+int svs_comm_allreduce_hook(void *d_buf, size_t count, void *user);      // comm.hip
+
 struct svs_ba {
   svs_ctx *ctx = nullptr;
+  BaOptions opt;
+  svs_comm *comm = nullptr;             // library-owned collective of sharded runs (svs_ba_set_comm)
+  bool problem_valid = false;           // set by a COMPLETED svs_ba_set_problem; every other entry point requires it
   int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, add_pose_terms = 1;
   svs_cam cam{};
   svs_ba_params prm{};
@@ -1718,7 +1729,7 @@ struct svs_ba {
   std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
   std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
   unsigned char *h_stage = nullptr; size_t h_stage_cap = 0, h_stage_used = 0;      // pinned staging of the small per-call uploads
-  HostPool *pool = nullptr;                    // marshalling workers (created on first use, SVS_HOST_THREADS overrides the count)
+  HostPool *pool = nullptr;                    // marshalling workers: ONE pool per process, shared by all optimizers (created on first use)
   std::vector<double> w_pat_local;
   svs_ba_edge *h_edges = nullptr; size_t h_edges_cap = 0;
   size_t cap_poses[2] = {0, 0}, cap_psi[2] = {0, 0}, cap_edges = 0, cap_cs = 0, cap_cl = 0, cap_cons = 0, cap_red = 0, cap_x = 0, cap_scal = 0,
@@ -1754,7 +1765,7 @@ static BaDev make_dev(const svs_ba *ba, double lambda, int cur = -1, double *ctl
   B.H = ba->d_red; B.bp = ba->d_red + nblk * 36; B.bs = B.bp + 6 * (size_t)ba->P; B.chi2_cur = B.bs + 6 * (size_t)ba->P;
   B.x = ba->d_x; B.scal = ba->d_scal;
   B.cam = ba->cam; B.delta = ba->prm.huber_delta; B.lambda = lambda; B.robust = ba->prm.use_robust; B.self_mode = ba->prm.self_edge_mode;
-  B.fuse_cons = (B.C > 0 && B.n_chunks > 0 && !getenv("SVS_BA_NO_FUSED_CONS")) ? 1 : 0;
+  B.fuse_cons = (B.C > 0 && B.n_chunks > 0 && !ba->opt.no_fused_cons) ? 1 : 0;
   return B;
 }
 
@@ -1790,6 +1801,16 @@ extern "C" int svs_ba_create(svs_ctx *ctx, svs_ba **out) {
   SVS_REQUIRE(ctx, ctx && out);
   svs_ba *ba = new svs_ba();
   ba->ctx = ctx;
+  SVS_DEVICE(ctx);
+  {
+    auto flag = [](const char *n) { return getenv(n) ? 1 : 0; };
+    auto num = [](const char *n, int lo, int hi, int dflt) { const char *e = getenv(n); if (!e) return dflt; const int v = atoi(e); return v < lo ? lo : (v > hi ? hi : v); };
+    BaOptions &o = ba->opt;
+    o.no_speculation = flag("SVS_BA_NO_SPECULATION"); o.one_front = flag("SVS_BA_ONE_FRONT"); o.no_fused_solve = flag("SVS_BA_NO_FUSED_SOLVE");
+    o.no_lds_solve = flag("SVS_BA_NO_LDS_SOLVE"); o.no_fused_cons = flag("SVS_BA_NO_FUSED_CONS"); o.nw4 = flag("SVS_BA_NW4");
+    o.debug = num("SVS_BA_DEBUG", 0, 2, 0); o.nw = num("SVS_BA_NW", 4, 8, 0); o.p1 = num("SVS_BA_P1", 0, SOLVE_MAX_P, -1);
+    o.group = num("SVS_BA_GROUP", 1, WIN, 0); o.host_threads = num("SVS_HOST_THREADS", 1, 64, 0);
+  }
   for (auto &e : ba->ev) SVS_HIP(ctx, hipEventCreate(&e));
   *out = ba;
   return SVS_OK;
@@ -1807,7 +1828,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
   ba->free_all();
-  delete ba->pool; ba->pool = nullptr;
+  ba->pool = nullptr;                   // shared, not owned
   for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
   delete ba;
   return SVS_OK;
@@ -1819,12 +1840,15 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && h_poses && (L == 0 || h_psi) && (E == 0 || h_edges) && (C == 0 || h_cons) && cam && prm);
   SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
+  SVS_DEVICE(ctx);
+  // a call that fails half-way must not leave new sizes next to old buffers behind: the handle is unusable until a call completes
+  ba->problem_valid = false;
   if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ba->h_stage_used = 0;
   { int rc = stage_reserve(ba, sizeof(double) * (12 * (size_t)P + 3 * (size_t)L) + sizeof(svs_ba_constraint) * (size_t)C + sizeof(int) * ((size_t)E / 8 + 6 * (size_t)P) + 8192);
     if (rc) return rc; }
-  const bool dbg_t = getenv("SVS_BA_DEBUG") != nullptr;
+  const bool dbg_t = ba->opt.debug != 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t_0 = now(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0, t_5 = t_0;
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = add_pose_terms; ba->cur = 0;
@@ -1842,11 +1866,19 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   int span = 1;
   // worker pool: one pass over the edge records is memory-bound on one core
   if (!ba->pool) {
-    int nt = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
-    if (const char *e = getenv("SVS_HOST_THREADS")) nt = std::max(1, atoi(e));
-    ba->pool = new HostPool(nt);
+    static std::mutex pool_mutex;
+    static HostPool *shared_pool = nullptr;
+    std::lock_guard<std::mutex> lk(pool_mutex);
+    if (!shared_pool) {
+      const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+      int nt = (int)std::min(8u, std::max(1u, hc / 2));
+      if (ba->opt.host_threads > 0) nt = std::min(ba->opt.host_threads, (int)hc);      // never more workers than cores
+      shared_pool = new HostPool(nt);                                                  // lives for the process
+    }
+    ba->pool = shared_pool;
   }
   HostPool &pool = *ba->pool;
+  std::lock_guard<std::mutex> pool_lock(pool.use_);
   const bool par = pool.size() > 1 && E >= 16384 && (size_t)L * pool.size() <= ((size_t)1 << 24);
   auto for_range = [&](int total, const std::function<void(int, int, int)> &body) {      // body(t, begin, end)
     if (!par) { body(0, 0, total); return; }
@@ -1905,7 +1937,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   }
   t_1 = now();
   int G = std::max(1, std::min(8, WIN - span));                          // anchors interleaved per group
-  if (const char *e = getenv("SVS_BA_GROUP")) G = std::max(1, atoi(e));     // experiments only
+  if (ba->opt.group > 0) G = ba->opt.group;                                 // experiments only (clamped to 1..WIN at svs_ba_create / set_option)
   // landmark order: per anchor the landmarks in index order; per group of G anchors deal them round-robin
   std::vector<int> &by_anchor_off = ba->w_aoff, &by_anchor = ba->w_alist, &lm_order = ba->w_order;
   by_anchor_off.assign(P + 1, 0);
@@ -2055,12 +2087,14 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     fprintf(stderr, "[svs_ba] set_problem: validate+count %.0f us, landmark order %.0f us, slots+sort+pattern %.0f us, gather+upload+chunks %.0f us, enqueue copies %.0f us, wait %.0f us\n",
             us(t_0, t_1), us(t_1, t_2), us(t_2, t_3), us(t_3, t_4), us(t_4, t_5), us(t_5, now()));
   }
+  ba->problem_valid = true;
   return SVS_OK;
 }
 
 extern "C" int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
-  SVS_REQUIRE(ctx, ba && h_poses && ba->d_poses[0]);
+  SVS_REQUIRE(ctx, ba && h_poses && ba->d_poses[0] && ba->problem_valid);
+  SVS_DEVICE(ctx);
   ba->cur = 0;
   for (int k = 0; k < 2; ++k) {
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[k], h_poses, sizeof(double) * 12 * (size_t)ba->P, hipMemcpyHostToDevice, ctx->stream));
@@ -2100,15 +2134,15 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
   const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 128 + (size_t)R * 6) +
                       sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
-  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD && !getenv("SVS_BA_NO_LDS_SOLVE");
+  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD && !ba->opt.no_lds_solve;
   ba->lds_solve_smem = need;
-  ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !getenv("SVS_BA_NO_FUSED_SOLVE");
+  ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !ba->opt.no_fused_solve;
   // two-front elimination (fused kernel only): front 1 takes the last P1 block rows in reversed order.  Balance: front 0
   // needs front 1's deltas when it reaches row P_top-(R-1), i.e. after P - P1 - (R-1) stages; front 1 needs P1 stages + the hand-over.
   ba->fuse_P1 = 0;
-  if (ba->use_fused_solve && !getenv("SVS_BA_ONE_FRONT")) {
+  if (ba->use_fused_solve && !ba->opt.one_front) {
     int P1 = (P - (R - 1) - 2) / 2;
-    if (const char *e = getenv("SVS_BA_P1")) P1 = atoi(e);               // experiments only
+    if (ba->opt.p1 >= 0) P1 = ba->opt.p1;                                // experiments only; goes through the same validity checks
     if (P1 >= 4 && P - P1 - (R - 1) >= 2) ba->fuse_P1 = P1;
   }
   std::vector<int> rm2(2 * (size_t)P, 0);
@@ -2171,14 +2205,13 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   SVS_HIP(ctx, hipMemsetAsync(ba->d_red, 0, sizeof(double) * ba->red_count, ctx->stream));
   if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
-  const char *dbg_env = getenv("SVS_BA_DEBUG");
-  const bool timeline = dbg_env && atoi(dbg_env) >= 2 && B.n_chunks > 0;
+  const bool timeline = ba->opt.debug >= 2 && B.n_chunks > 0;
   if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
   if (B.n_chunks > 0) {
     // waves per workgroup: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
     int nw = 4;
-    if (!getenv("SVS_BA_NW4")) for (int c = 5; c <= 8 && div_up(B.n_chunks, nw) > ctx->n_cu; ++c) if (div_up(B.n_chunks, c) <= ctx->n_cu) nw = c;
-    if (const char *e = getenv("SVS_BA_NW")) nw = atoi(e);
+    if (!ba->opt.nw4) for (int c = 5; c <= 8 && div_up(B.n_chunks, nw) > ctx->n_cu; ++c) if (div_up(B.n_chunks, c) <= ctx->n_cu) nw = c;
+    if (ba->opt.nw >= 4) nw = ba->opt.nw;      // 4..8 (clamped where it is set)
     const int xc = B.fuse_cons ? B.C : 0;      // pose-pose constraints in extra workgroups of the same launch
     switch (nw) {
       case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5>), dim3(div_up(B.n_chunks, 5) + xc), dim3(320), 0, ctx->stream, B); break;
@@ -2216,7 +2249,8 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
 
 extern "C" int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred, double *h_bred, double *h_chi2) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
-  SVS_REQUIRE(ctx, ba && ba->d_red);
+  SVS_REQUIRE(ctx, ba && ba->d_red && ba->problem_valid);
+  SVS_DEVICE(ctx);
   int rc = launch_reduce(ba, lambda);
   if (rc) return rc;
   BaDev B = make_dev(ba, lambda);
@@ -2284,7 +2318,9 @@ static int add_trial_times(svs_ba *ba, hipEvent_t *ev) {
 // from exactly that point.
 extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
-  SVS_REQUIRE(ctx, ba && ba->d_red);
+  SVS_REQUIRE(ctx, ba && ba->d_red && ba->problem_valid);
+  SVS_DEVICE(ctx);
+  if (!allreduce && ba->comm) { allreduce = svs_comm_allreduce_hook; user = ba->comm; }      // library-owned collective (svs_ba_set_comm)
   const svs_ba_params &prm = ba->prm;
   double lambda = prm.lambda_init, ni = 2;
   svs_ba_stats st{};
@@ -2296,7 +2332,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
   int it = 0;
   bool resume = false;                 // the first trial of iteration `it` was already run (and rejected) by the speculative phase
   double r_rho = 0, r_chi = 0;
-  const bool speculate = prm.num_iters >= 1 && prm.max_trials > 1 && !getenv("SVS_BA_DEBUG") && !getenv("SVS_BA_NO_SPECULATION");
+  const bool speculate = prm.num_iters >= 1 && prm.max_trials > 1 && !ba->opt.debug && !ba->opt.no_speculation;
   if (speculate) {
     const int n_it = prm.num_iters;
     const size_t n_ctl = 8 + 8 * (size_t)n_it;
@@ -2358,7 +2394,7 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       { int rc2 = add_trial_times(ba, ba->ev); if (rc2) return rc2; }
-      if (getenv("SVS_BA_DEBUG"))
+      if (ba->opt.debug)
         fprintf(stderr, "[svs_ba] solve phases: init %.1f us, forward %.1f us (pivot wave: load+row update %.1f, eliminate+emit %.1f, - %.1f, barrier wait %.1f), backward %.1f us\n",
                 h[5], h[6], h[8], h[9], h[10], h[11], h[7]);
       const bool fail = h[3] != 0.0;
@@ -2394,10 +2430,38 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
 
 extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
-  SVS_REQUIRE(ctx, ba && ba->d_poses[0]);
+  SVS_REQUIRE(ctx, ba && ba->d_poses[0] && ba->problem_valid);
   if (h_poses) SVS_HIP(ctx, hipMemcpyAsync(h_poses, ba->d_poses[ba->cur], sizeof(double) * 12 * (size_t)ba->P, hipMemcpyDeviceToHost, ctx->stream));
   if (h_psi && ba->L) SVS_HIP(ctx, hipMemcpyAsync(h_psi, ba->d_psi[ba->cur], sizeof(double) * 3 * (size_t)ba->L, hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_set_comm(svs_ba *ba, svs_comm *comm) {
+  if (!ba) return SVS_ERR_INVALID;
+  ba->comm = comm;
+  ba->profile_ready = false;            // the co-visibility pattern must be exchanged over the new communicator
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && name);
+  auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  BaOptions &o = ba->opt;
+  const std::string n(name);
+  if (n == "no_speculation") o.no_speculation = value != 0;
+  else if (n == "one_front") o.one_front = value != 0;
+  else if (n == "no_fused_solve") o.no_fused_solve = value != 0;
+  else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
+  else if (n == "no_fused_cons") o.no_fused_cons = value != 0;
+  else if (n == "debug") o.debug = clamp(value, 0, 2);
+  else if (n == "nw") o.nw = value == 0 ? 0 : clamp(value, 4, 8);
+  else if (n == "p1") o.p1 = value < 0 ? -1 : clamp(value, 0, SOLVE_MAX_P);
+  else if (n == "group") o.group = value == 0 ? 0 : clamp(value, 1, WIN);
+  else if (n == "host_threads") o.host_threads = clamp(value, 0, 64);
+  else SVS_REQUIRE(ctx, !"unknown option");
+  ba->profile_ready = false;            // solve-kernel choice depends on the switches
   return SVS_OK;
 }
 

@@ -344,7 +344,7 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 // every workgroup add the partials up in the same fixed order, and each then runs the identical LM bookkeeping redundantly,
 // so no pose has to be broadcast.  Partials are double-buffered by pass parity: a workgroup can only overwrite a buffer after
 // everyone has passed the barrier of the pass in between, i.e. after everyone has read it.
-struct TrackMulti { double *part; unsigned *bar; };      // [batch][2][nwg][32], [batch] (zeroed before the launch)
+struct TrackMulti { double *part; unsigned *bar; int fail_off; };      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
@@ -354,6 +354,8 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   __shared__ double s_out[NSUM + 1];
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
   __shared__ float s_iplut[256];
+  __shared__ bool s_failed;
+  if (threadIdx.x == 0) s_failed = false;
   const int slot = MULTI ? blockIdx.y : blockIdx.x, wg = MULTI ? blockIdx.x : 0, nwg = MULTI ? gridDim.x : 1;
   const int first = wg * TRK_THREADS + threadIdx.x;
   int sweep = 0;
@@ -367,7 +369,13 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     if (threadIdx.x == 0) {
       __hip_atomic_fetch_add(G.bar + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)sweep * (unsigned)nwg;
-      for (long spin = 0; spin < (1l << 26) && __hip_atomic_load(G.bar + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      long spin = 0;
+      for (; spin < (1l << 24) && __hip_atomic_load(G.bar + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      // a sibling workgroup never arrived (they are not all resident: the device is shared with other work).  Summing what is
+      // there would let the replicated LM bookkeeping diverge silently: raise the stream's failure flag instead -- every
+      // workgroup sees it at its next barrier at the latest, the pose is left as it came in and passes_out reports -1.
+      if (spin >= (1l << 24)) __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_failed = __hip_atomic_load(G.bar + G.fail_off + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   for (int i = threadIdx.x; i < 256; i += TRK_THREADS) s_iplut[i] = (float)((1. / 255.) * i);
   __syncthreads();
   int passes = 0, n_rec = 0;
+  bool failed = false;
   // One fused pass per LM iteration.  The reference runs, per iteration, an H,b pass at T and a
   // chi2 pass at T_new, and after an accepted step starts the next iteration with an H,b pass at
   // that same T_new.  Evaluating chi2 AND H,b together at T_new therefore serves both (identical
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
     track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     all_workgroups();
+    if (MULTI && s_failed) { failed = true; break; }
     ++passes;
     float chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
       track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);        // new_chi2 (:335-367) + H,b for the next iteration
       all_workgroups();
+      if (MULTI && s_failed) { failed = true; break; }
       ++passes;
       const float new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
@@ -440,9 +451,11 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
         stop = true;
       }
     }
+    if (failed) break;
   }
   __syncthreads();
   if (wg != 0) return;
+  if (failed) { if (threadIdx.x == 0 && passes_out) passes_out[slot] = -1; return; }      // pose left as it came in
   if (threadIdx.x < 12) T_io[(size_t)slot * 12 + threadIdx.x] = s_T[threadIdx.x];
   if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
   if (threadIdx.x == 0 && A.n_rec) A.n_rec[slot] = n_rec;
@@ -603,14 +616,15 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
   int nwg = batch <= 32 ? 4 : 1;      // measured (B = 1 / 8): 4 workgroups 0.26 ms / 19.4k fps, 8: 0.26 / 15.6k, 16: 0.28 / 10.4k, 1: 0.34 / 14.4k;
                                       // 2 per stream at 64 streams lose to one (barrier + redundant LM tails)
   if (ctx->trk_nwg) nwg = ctx->trk_nwg;
-  TrackMulti G{nullptr, nullptr};
+  TrackMulti G{nullptr, nullptr, 0};
   if (nwg >= 2) {
     double *scratch = nullptr;
     const size_t n_part = (size_t)batch * 2 * nwg * 32;
-    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch);          // + one counter word (8 bytes) per stream
+    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch);          // + one counter word and one failure flag (4 + 4 bytes) per stream
     if (rc) return rc;
     G.part = scratch;
     G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
+    G.fail_off = batch;
     SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (size_t)batch, ctx->stream));
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

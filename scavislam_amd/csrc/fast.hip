@@ -540,6 +540,7 @@ struct svs_fast {
   std::vector<int> t_lo_src;
   int *d_ovf = nullptr;       // [batch][ncell_total] cells the list compaction left to the sweep
   bool use_lists = false;
+  bool force_cmp16 = false;   // SVS_FAST_NO_LISTS / SVS_FAST_CMP16, read once at svs_fast_create (experiments only)
 };
 
 extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
@@ -599,7 +600,8 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
   SVS_HIP(ctx, hipMemcpyAsync(P.thr, thr0.data(), nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   f->n_tiles = (int)tiles.size();
   P.n_tiles = f->n_tiles;
-  f->use_lists = lists_ok;
+  f->use_lists = lists_ok && !getenv("SVS_FAST_NO_LISTS");
+  f->force_cmp16 = getenv("SVS_FAST_CMP16") != nullptr;
   SVS_HIP(ctx, hipMalloc(&P.cand, sizeof(uint32_t) * (size_t)batch * tiles.size() * CAND_CAP));
   SVS_HIP(ctx, hipMalloc(&P.cand_n, sizeof(int) * (size_t)batch * tiles.size()));
   SVS_HIP(ctx, hipMalloc(&P.cell_tile0, sizeof(int) * cell_tile0.size()));
@@ -644,7 +646,7 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
   // compaction from the score kernel's candidate lists; cells whose lists overflowed (and everything, if the lists are
   // switched off) go through the score-map sweep
   const int *ovf = nullptr;
-  if (f->use_lists && !getenv("SVS_FAST_NO_LISTS")) {
+  if (f->use_lists) {
     if ((long)f->P.ncell_total * n_batch <= 1024) hipLaunchKernelGGL(fast_compact_list_kernel<1024>, dim3(f->P.ncell_total, n_batch), dim3(1024), 0, ctx->stream, f->P, f->d_ovf);
     else hipLaunchKernelGGL(fast_compact_list_kernel<256>, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P, f->d_ovf);
     SVS_LAUNCH_CHECK(ctx);
@@ -652,7 +654,7 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
   }
   if (mask_bytes <= 56 * 1024)
   {
-    if ((long)f->P.ncell_total * n_batch <= 1024 || getenv("SVS_FAST_CMP16"))
+    if ((long)f->P.ncell_total * n_batch <= 1024 || f->force_cmp16)
       hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P, ovf);
     else
       hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P, ovf);

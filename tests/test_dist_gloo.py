@@ -67,3 +67,73 @@ def test_sharded_reduced_system_allreduce_gloo(world):
     [p.join(180) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) is True
+
+
+# ---- GPU box: two PROCESSES share the one GPU, each builds its landmark shard with the HIP kernels, the partial reduced systems
+# meet in a gloo all-reduce (RCCL needs one GPU per rank; the exchange semantics are the same: SUM of the packed system on every
+# rank) -- the N > 1 optimize path end to end with HIP-built shards.
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer, _as_tensor, shard_problem
+    from scavislam_amd.ctypes_types import BaParams, Cam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx, stream = capi.torch_context(0)
+    prob = synth.ba_window(12, 1500, seed=41)
+    c = prob["cam"]
+    cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
+    prm = BaParams.reference_defaults()
+    sh = shard_problem(prob, rank, world)
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], cam, prm, add_pose_terms=sh["add_pose_terms"])
+    n_calls = [0]
+
+    def allreduce(d_buf, count, _u):
+        try:
+            ctx.sync()
+            t = _as_tensor(d_buf, count, 0)
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            torch.cuda.synchronize()
+            n_calls[0] += 1
+            return 0
+        except Exception as e:
+            print("allreduce failed", repr(e))
+            return 1
+    st = opt.optimize(capi.ALLREDUCE_FN(allreduce))
+    poses, psi = opt.restoreDataFromG2o()
+    mine = np.where((sh["owner"] == rank)[:, None], psi, 0.0)
+    t = torch.as_tensor(mine)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        import oracle as O
+        poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        upd = np.abs(poses_ref - prob["poses"]).max()
+        err_p = np.abs(poses - poses_ref).max() / upd
+        err_l = np.abs(t.numpy() - psi_ref).max() / np.abs(psi_ref - prob["psi"]).max()
+        q.put((st.trials == st_ref.trials and st.accepted == st_ref.accepted, float(err_p), float(err_l), n_calls[0]))
+    opt.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_optimize_two_processes_hip_shards():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    same_traj, err_p, err_l, n_calls = q.get(timeout=5)
+    assert same_traj and err_p < 1e-6 and err_l < 1e-6, (same_traj, err_p, err_l)
+    assert n_calls == 1 + 2 * 2          # pattern once, then (system + scalars) per LM trial

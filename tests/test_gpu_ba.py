@@ -215,7 +215,7 @@ def test_sharded_optimize_single_process(gpu_ctx):
 
 def test_speculative_lm_equals_host_driven_lm(gpu_ctx, monkeypatch):
     """The device-side accept/reject path (all iterations enqueued at once, ba_lm_kernel decides) and the
-    host-driven loop (SVS_BA_NO_SPECULATION=1: one synchronisation per trial) are the same arithmetic in
+    host-driven loop (option no_speculation: one synchronisation per trial) are the same arithmetic in
     the same order up to the order of the f64 atomics (not reproducible run to run either): identical LM
     trajectory, states and statistics equal to ~1e-8, also when trials are rejected mid-way."""
     from scavislam_amd import synth
@@ -227,13 +227,10 @@ def test_speculative_lm_equals_host_driven_lm(gpu_ctx, monkeypatch):
     for lam0, iters in ((1e-9, 3), (1e-3, 6), (50.0, 4)):
         out = []
         for no_spec in (False, True):
-            if no_spec:
-                monkeypatch.setenv("SVS_BA_NO_SPECULATION", "1")
-            else:
-                monkeypatch.delenv("SVS_BA_NO_SPECULATION", raising=False)
             prm = BaParams.reference_defaults()
             prm.lambda_init, prm.num_iters = lam0, iters
             opt = SlamGraphOptimizer(ctx, stream)
+            opt.set_option("no_speculation", int(no_spec))
             opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
             st = opt.optimize()
             out.append((st, *opt.restoreDataFromG2o()))
@@ -277,16 +274,11 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     from scavislam_amd.ctypes_types import BaParams
     ctx, stream = gpu_ctx
     rng = np.random.default_rng(3)
-    for k in ("SVS_BA_ONE_FRONT", "SVS_BA_NO_FUSED_SOLVE", "SVS_BA_NO_LDS_SOLVE"):
-        monkeypatch.delenv(k, raising=False)
     P = 40
     prob = synth.ba_window(P, 4000, seed=11, n_outer=2)
-    if case == "fused_one_front":
-        monkeypatch.setenv("SVS_BA_ONE_FRONT", "1")
-    elif case == "lds_forced":
-        monkeypatch.setenv("SVS_BA_NO_FUSED_SOLVE", "1")
-    elif case == "global_forced":
-        monkeypatch.setenv("SVS_BA_NO_LDS_SOLVE", "1")
+    options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve"}
+    if case in options:
+        pass
     elif case == "lds_wide_envelope":
         prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows
     elif case == "global_wide_envelope":
@@ -294,6 +286,8 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     cam = _cam(prob["cam"])
     prm = BaParams.reference_defaults()
     opt = SlamGraphOptimizer(ctx, stream)
+    if case in options:
+        opt.set_option(options[case], 1)
     opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
     st = opt.optimize()
     poses, psi = opt.restoreDataFromG2o()
@@ -422,4 +416,68 @@ def test_kernel_timing_brackets_are_opt_in(gpu_ctx):
     p1, s1 = opt.restoreDataFromG2o()
     assert _rel_update_err(p1, p0, prob["poses"]) < 1e-9
     opt.set_timing(False)
+    opt.close()
+
+
+def test_library_communicator_world_1(gpu_ctx):
+    """The library-owned RCCL communicator (svs_comm_*, comm.hip): created from a unique id, attached with svs_ba_set_comm, used by
+    svs_ba_optimize for every exchange of the sharded path.  One rank = the collectives are identities, so the result must equal the
+    plain single-GPU optimize bit-close, and the communicator must have carried 1 pattern + 2 x (system + scalars) all-reduces."""
+    import torch
+    from scavislam_amd import synth
+    from scavislam_amd.backend import Communicator, SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prob = synth.ba_window(10, 800, seed=4)
+    cam = _cam(prob["cam"])
+    prm = BaParams.reference_defaults()
+    base = SlamGraphOptimizer(ctx, stream)
+    base.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    st0 = base.optimize()
+    poses0, psi0 = base.restoreDataFromG2o()
+    comm = Communicator(ctx, 0, 1)
+    # the collective itself: in place, on the ctx stream
+    with torch.cuda.stream(stream):
+        t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allreduce(t.data_ptr(), t.numel())
+    ctx.sync()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    n0 = comm.stats()["n_calls"]
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.set_comm(comm)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    s = comm.stats()
+    assert (s["rank"], s["world"]) == (0, 1)
+    assert s["n_calls"] - n0 == 1 + 2 * st.trials
+    assert (st.trials, st.accepted) == (st0.trials, st0.accepted)
+    assert _rel_update_err(poses, poses0, prob["poses"]) < 1e-7 and _rel_update_err(psi, psi0, prob["psi"]) < 1e-7
+    opt.close(); base.close(); comm.close()
+
+
+def test_failed_set_problem_invalidates_the_handle(gpu_ctx):
+    """A svs_ba_set_problem that fails half-way (here: an out-of-range edge index after a valid smaller window) must leave the handle
+    unusable -- optimize / get_state / reduced_system refuse -- until a later call completes; no stale sizes next to old buffers."""
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    small = synth.ba_window(8, 200, seed=3)
+    big = synth.ba_window(60, 900, seed=5)
+    cam = _cam(small["cam"])
+    prm = BaParams.reference_defaults()
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(small["poses"], small["psi"], small["edges"], small["cons"], cam, prm)
+    opt.optimize()
+    bad = big["edges"].copy()
+    bad["pose"][len(bad) // 2] = 60                    # out of range
+    with pytest.raises(capi.SvsError):
+        opt.copyDataToG2o(big["poses"], big["psi"], bad, big["cons"], cam, prm)
+    for call in (opt.optimize, opt.restoreDataFromG2o, lambda: opt.reduced_system(50.0)):
+        with pytest.raises(capi.SvsError):
+            call()
+    opt.copyDataToG2o(big["poses"], big["psi"], big["edges"], big["cons"], cam, prm)      # a completed call revives it
+    st = opt.optimize()
+    assert st.trials >= 1
     opt.close()
