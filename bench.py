@@ -29,6 +29,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; rank 0's stdout must carry exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,7 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
     from scavislam_amd import capi, synth
-    from scavislam_amd.backend import SlamGraphOptimizer, make_allreduce, shard_problem
+    from scavislam_amd.backend import Communicator, SlamGraphOptimizer, shard_problem
     from scavislam_amd.ctypes_types import BaParams, Cam
     from scavislam_amd.frontend import DenseTracker, FastGrid, FramePyramid, GuidedMatcher, StereoMatcher
 
@@ -59,7 +73,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()                                   # creates torch's communicator now (banner goes to stderr)
     ctx, stream = capi.torch_context(local_rank)
     dev = torch.device("cuda", local_rank)
     K, W, B = args.steps, args.warmup, args.batch
@@ -345,7 +361,13 @@ def main():
     sh = shard_problem(prob, rank, world) if world > 1 else dict(prob, add_pose_terms=True)
     opt = SlamGraphOptimizer(ctx, stream)
     opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], camc, prm, add_pose_terms=sh["add_pose_terms"])
-    allreduce = make_allreduce(stream, local_rank) if use_dist else None
+    # sharded runs: the library's own RCCL communicator (ncclAllReduce on the ctx stream inside svs_ba_optimize); torch.distributed
+    # only carries the 128-byte unique id to the other ranks.  Also exercised at one rank when launched through torch.distributed.run.
+    with _stdout_to_stderr():
+        comm = Communicator(ctx, rank, world, device=dev) if use_dist else None
+    if comm is not None:
+        opt.set_comm(comm)
+    allreduce = None
     E_total, E_local = len(prob["edges"]), len(sh["edges"])
     stats = None
     t_red = t_sol = t_bs = 0.0
@@ -496,7 +518,8 @@ def main():
                                    " grid-FAST, ZNSSD match, dense cloud; disparity given) and DWO inner-window "
                                    "Schur solve 50 KF / 20k landmarks",
                        "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": args.points,
-                       "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system"},
+                       "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system",
+                       "collective": (dict(comm.stats(), transport="RCCL ncclAllReduce(ncclDouble) issued by the library on its stream") if comm is not None else None)},
             "schur": {"ms_per_optimize": round(ms_opt, 4), "lm_trials_per_optimize": n_tr / K,
                       "ms_per_call_incl_host_marshalling_and_copies": round(e2e_ms, 4) if e2e_ms else None,
                       "ms_per_schur_step": round(ms_opt / max(n_tr / K, 1), 4), "scaling": "strong",
