@@ -195,6 +195,8 @@ struct BaDev {
   long long *dbg;                       // SVS_BA_DEBUG=2: per-wave phase stamps (100 MHz ticks), DBG_N per chunk
   double *ctl;                          // device-side LM control (speculative trials): [0] lambda, [1] abort flag, [8 + 8 it ..] trial records
   int fuse_cons;                        // constraints ride in extra workgroups of the landmark kernels
+  int n_wide;                           // landmarks with more than 64 observations: one workgroup each (ba_wide_landmark_kernel)
+  const int *wide_start, *wide_len;     // their edge ranges (behind the chunked edges)
 };
 
 // ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
@@ -694,6 +696,265 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     }
   }
   SVS_STAMP(DBG_N - 1);
+}
+
+// ---- landmarks with more than 64 observations -------------------------------------------------------------------
+// The reference adds an observation edge for every window pose in a point's vis_set, without a cap (slam_graph.cpp:1001-1027):
+// in a loop a point is easily seen from more than 64 of the 230 window poses.  Such a landmark does not fit the
+// one-wave-per-chunk kernel above; it gets ONE WORKGROUP of WIDE_THREADS lanes (lane = edge, up to WIDE_THREADS observations =
+// more than the 256 poses a window can hold).  Same algebra as ba_landmark_kernel (compact edge blocks, per-landmark sums of
+// 27 values, 3x3 closed-form inverse, circulant observer pairs with W_obs parked in LDS); sums go through the workgroup,
+// blocks straight to global atomics -- these landmarks are few.
+constexpr int WIDE_THREADS = 256;
+template <int N>
+__device__ __forceinline__ void wide_block_sum(double (&v)[N], double *s_red /* [WIDE_THREADS / 64][N] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double w = wave_sum_f64(v[i]);
+    if (lane == 0) s_red[wave * N + i] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < WIDE_THREADS / 64; ++w) t += s_red[w * N + i];
+    v[i] = t;
+  }
+  __syncthreads();
+}
+template <int MODE>
+__global__ __launch_bounds__(WIDE_THREADS) void ba_wide_landmark_kernel(BaDev B) {
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }
+  __shared__ double s_red[(WIDE_THREADS / 64) * 27];
+  __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? WIDE_THREADS * 18 : 1];
+  __shared__ int s_pose[WIDE_THREADS], s_role[WIDE_THREADS];
+  const int tid = threadIdx.x;
+  const int e0 = B.wide_start[blockIdx.x], m = B.wide_len[blockIdx.x];
+  const bool active = tid < m;
+  svs_ba_edge ed;
+  if (active) ed = B.edges[e0 + tid];
+  else { ed.point = -1; ed.pose = 0; ed.anchor = 0; }
+  {                                                     // every edge of the landmark has the same anchor / point: inactive lanes take
+    __shared__ int s_ap[2];                             // them from the first edge
+    if (tid == 0) { s_ap[0] = ed.anchor; s_ap[1] = ed.point; }
+    __syncthreads();
+    ed.anchor = s_ap[0]; if (!active) ed.point = s_ap[1];
+  }
+  const int anchor = ed.anchor;
+  double psi[3], To[12], Ta[12];
+  EdgeCore lin;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)anchor + i]; }
+  linearize_edge(psi, To, Ta, ed, B.cam, B.delta, B.robust, lin);       // inactive lanes: a copy of a valid geometry, masked below
+  const bool self = active && ed.pose == anchor;
+  const bool obs_role = active && !self;
+  const bool self_lit = self && B.self_mode == 0;
+  if (!active) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { lin.A[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lin.g[i] = 0;
+    lin.rho0 = 0;
+  }
+  double Bm[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Bm[3 * i + j] = lin.A[3 * i] * lin.D[j] + lin.A[3 * i + 1] * lin.D[3 + j] + lin.A[3 * i + 2] * lin.D[6 + j];
+  constexpr int NRED = MODE == 0 ? 27 : 18;
+  double red[27];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) red[k++] = lin.D[i] * Bm[j] + lin.D[3 + i] * Bm[3 + j] + lin.D[6 + i] * Bm[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) red[6 + i] = -(lin.D[i] * lin.g[0] + lin.D[3 + i] * lin.g[1] + lin.D[6 + i] * lin.g[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) red[9 + 3 * i + j] = obs_role ? lin.R[i] * Bm[j] + lin.R[3 + i] * Bm[3 + j] + lin.R[6 + i] * Bm[6 + j] : 0.0;
+    double AR[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
+    const bool in_maa = obs_role || self_lit;
+    k = 18;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) red[k++] = in_maa ? lin.R[i] * AR[j] + lin.R[3 + i] * AR[3 + j] + lin.R[6 + i] * AR[6 + j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) red[24 + i] = obs_role ? lin.R[i] * lin.g[0] + lin.R[3 + i] * lin.g[1] + lin.R[6 + i] * lin.g[2] : 0.0;
+  }
+  (void)NRED;
+  wide_block_sum<27>(red, s_red);
+  double Di[9], bl[3] = {red[6], red[7], red[8]};
+  {
+    const double a00 = red[0] + B.lambda, a01 = red[1], a02 = red[2], a11 = red[3] + B.lambda, a12 = red[4], a22 = red[5] + B.lambda;
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+    Di[0] = c00 * id; Di[1] = c01 * id; Di[2] = c02 * id;
+    Di[3] = Di[1]; Di[4] = (a00 * a22 - a02 * a02) * id; Di[5] = (a02 * a01 - a00 * a12) * id;
+    Di[6] = Di[2]; Di[7] = Di[5]; Di[8] = (a00 * a11 - a01 * a01) * id;
+  }
+  double Db[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Db[i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+  double Wo[18];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double t0, t1, t2;
+    cross3(lin.y, Bm[c], Bm[3 + c], Bm[6 + c], t0, t1, t2);
+    Wo[c] = obs_role ? Bm[c] : 0.0; Wo[3 + c] = obs_role ? Bm[3 + c] : 0.0; Wo[6 + c] = obs_role ? Bm[6 + c] : 0.0;
+    Wo[9 + c] = obs_role ? t0 : 0.0; Wo[12 + c] = obs_role ? t1 : 0.0; Wo[15 + c] = obs_role ? t2 : 0.0;
+  }
+  double WA[18];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double t0, t1, t2;
+    cross3(lin.xa, red[9 + c], red[12 + c], red[15 + c], t0, t1, t2);
+    WA[c] = -red[9 + c]; WA[3 + c] = -red[12 + c]; WA[6 + c] = -red[15 + c];
+    WA[9 + c] = -t0; WA[12 + c] = -t1; WA[15 + c] = -t2;
+  }
+  if (MODE == 1) {
+    double c[3] = {0, 0, 0};
+    if (obs_role) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c[j] += Wo[3 * i + j] * B.x[6 * ed.pose + i];
+    }
+    wide_block_sum<3>(c, s_red);
+    double xl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double sj = bl[j] - c[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sj -= WA[3 * i + j] * B.x[6 * anchor + i];
+      c[j] = sj;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xl[i] = Di[3 * i] * c[0] + Di[3 * i + 1] * c[1] + Di[3 * i + 2] * c[2];
+    const double npsi[3] = {psi[0] + xl[0], psi[1] + xl[1], psi[2] + xl[2]};
+    double sc[2] = {0, 0};      // chi2 at the trial state, x_l (lambda x_l + b_l)
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { B.psi_trial[3 * (size_t)ed.point + i] = npsi[i]; sc[1] += xl[i] * (B.lambda * xl[i] + bl[i]); }
+    }
+    if (active) {
+      double Tno[12], Tna[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { Tno[i] = B.poses_trial[12 * (size_t)ed.pose + i]; Tna[i] = B.poses_trial[12 * (size_t)anchor + i]; }
+      sc[0] = edge_chi2(npsi, Tno, Tna, ed, B.cam, B.delta, B.robust);
+    }
+    wide_block_sum<2>(sc, s_red);
+    if (tid == 0) { atomic_add_f64(&B.scal[0], sc[0]); atomic_add_f64(&B.scal[1], sc[1]); }
+    return;
+  }
+  // ---- MODE 0 ----
+  {
+    double c1[1] = {lin.rho0};
+    wide_block_sum<1>(c1, s_red);
+    if (tid == 0 && c1[0] != 0.0) atomic_add_f64(B.chi2_cur, c1[0]);
+  }
+  auto add_blk = [&](int pi, int pj, int rc, double v) { atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v); };
+  if (tid == 0) {             // anchor block, once: Ea^T S_RAR Ea - (W_A D^-1) W_A^T, b_anc, Schur rhs
+    double WAD[18], SR[9], Maa[36];
+    SR[0] = red[18]; SR[1] = red[19]; SR[2] = red[20]; SR[3] = red[19]; SR[4] = red[21]; SR[5] = red[22]; SR[6] = red[20]; SR[7] = red[22]; SR[8] = red[23];
+    sym_block(SR, lin.xa, Maa);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) WAD[3 * i + j] = WA[3 * i] * Di[j] + WA[3 * i + 1] * Di[3 + j] + WA[3 * i + 2] * Di[6 + j];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c)
+        add_blk(anchor, anchor, 6 * r + c, Maa[6 * r + c] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]));
+    double t0, t1, t2;
+    cross3(lin.xa, red[24], red[25], red[26], t0, t1, t2);
+    const double ba[6] = {red[24], red[25], red[26], t0, t1, t2};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      atomic_add_f64(B.bp + 6 * anchor + r, ba[r]);
+      atomic_add_f64(B.bs + 6 * anchor + r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
+    }
+  }
+  double *my_wo = s_wo + tid * 18;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) my_wo[i] = Wo[i];
+  s_pose[tid] = ed.pose; s_role[tid] = obs_role ? 1 : 0;
+  double WoD[18];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) WoD[3 * i + j] = Wo[3 * i] * Di[j] + Wo[3 * i + 1] * Di[3 + j] + Wo[3 * i + 2] * Di[6 + j];
+  if (obs_role) {
+    const int pi = ed.pose;
+    {
+      double Moo[36];
+      sym_block(lin.A, lin.y, Moo);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c)
+          add_blk(pi, pi, 6 * r + c, Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]));
+    }
+    {
+      double AR[9], Noa[36];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
+      cross_block(AR, lin.y, lin.xa, Noa);
+      const bool up = pi < anchor;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double mm = -Noa[6 * r + c] - (WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2]);
+          if (up) add_blk(pi, anchor, 6 * r + c, mm); else add_blk(anchor, pi, 6 * c + r, mm);
+        }
+    }
+    double u0, u1, u2;
+    cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], u0, u1, u2);
+    const double bo[6] = {-lin.g[0], -lin.g[1], -lin.g[2], -u0, -u1, -u2};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      atomic_add_f64(B.bp + 6 * pi + r, bo[r]);
+      atomic_add_f64(B.bs + 6 * pi + r, Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
+    }
+  }
+  __syncthreads();
+  // observer-observer pairs, circulant schedule over the m edges of the landmark (partners may sit in other waves: pose / role /
+  // W_obs come from LDS)
+  for (int r = 1; r <= (m >> 1); ++r) {
+    int b = tid + r;
+    if (b >= m) b -= m;
+    const bool on = obs_role && 2 * r <= m && !(2 * r == m && tid >= r) && s_role[b] != 0;
+    if (on) {
+      const int pj = s_pose[b];
+      const double *wj = s_wo + b * 18;
+      double Wj[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wj[i] = wj[i];
+      const bool up = ed.pose < pj;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double v = -(WoD[3 * rr] * Wj[3 * c] + WoD[3 * rr + 1] * Wj[3 * c + 1] + WoD[3 * rr + 2] * Wj[3 * c + 2]);
+          if (up) add_blk(ed.pose, pj, 6 * rr + c, v); else add_blk(pj, ed.pose, 6 * c + rr, v);
+        }
+    }
+  }
 }
 
 // ---- reduced-system solve: blocked right-looking Cholesky on the packed upper 6x6 blocks -------
@@ -1700,7 +1961,7 @@ struct svs_ba {
   BaOptions opt;
   svs_comm *comm = nullptr;             // library-owned collective of sharded runs (svs_ba_set_comm)
   bool problem_valid = false;           // set by a COMPLETED svs_ba_set_problem; every other entry point requires it
-  int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, add_pose_terms = 1;
+  int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, n_wide = 0, add_pose_terms = 1;
   svs_cam cam{};
   svs_ba_params prm{};
   double *d_poses[2] = {nullptr, nullptr}, *d_psi[2] = {nullptr, nullptr};
@@ -1766,6 +2027,7 @@ static BaDev make_dev(const svs_ba *ba, double lambda, int cur = -1, double *ctl
   B.x = ba->d_x; B.scal = ba->d_scal;
   B.cam = ba->cam; B.delta = ba->prm.huber_delta; B.lambda = lambda; B.robust = ba->prm.use_robust; B.self_mode = ba->prm.self_edge_mode;
   B.fuse_cons = (B.C > 0 && B.n_chunks > 0 && !ba->opt.no_fused_cons) ? 1 : 0;
+  B.n_wide = ba->n_wide; B.wide_start = ba->d_chunk_start + ba->n_chunks; B.wide_len = ba->d_chunk_len + ba->n_chunks;
   return B;
 }
 
@@ -1903,9 +2165,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
         const svs_ba_edge &e = h_edges[i];
         if (!(e.point >= 0 && e.point < L && e.pose >= 0 && e.pose < P && e.anchor >= 0 && e.anchor < P)) { err.store(1); return; }
         const int w = c[e.point];
-        if (w != 0 && (w >> 8) != e.anchor + 1) { err.store(2); return; }         // one anchor per point (slam_graph.hpp:121-133)
-        if ((w & 0xff) >= 64) { err.store(3); return; }
-        c[e.point] = ((e.anchor + 1) << 8) | ((w & 0xff) + 1);
+        if (w != 0 && (w >> 12) != e.anchor + 1) { err.store(2); return; }        // one anchor per point (slam_graph.hpp:121-133)
+        if ((w & 0xfff) >= WIDE_THREADS) { err.store(3); return; }
+        c[e.point] = ((e.anchor + 1) << 12) | ((w & 0xfff) + 1);
         sp = std::max(sp, std::abs(e.pose - e.anchor) + 1);
         keys[i] = ((uint64_t)(uint32_t)e.point << 32) | (uint32_t)e.pose;           // all the later passes need of the record
       }
@@ -1918,19 +2180,19 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
           for (int t = 0; t < T; ++t) {
             int &w = cnt[(size_t)t * L + l];
             if (w != 0) {
-              const int a = (w >> 8) - 1;
+              const int a = (w >> 12) - 1;
               if (anc >= 0 && a != anc) err.store(2);
               anc = a;
             }
-            const int n = w & 0xff;
+            const int n = w & 0xfff;
             w = total;                                                              // start offset of worker t inside landmark l
             total += n;
           }
-          if (total > 64) err.store(3);
+          if (total > WIDE_THREADS) err.store(3);
           anchor_of[l] = anc; n_obs[l] = total;
         }
       });
-    if (err.load() == 3) { ctx->err = "svs_ba: a landmark with more than 64 observations is not supported yet"; return SVS_ERR_UNSUPPORTED; }
+    if (err.load() == 3) { ctx->err = "svs_ba: a landmark with more than 256 observations (more than a window can hold)"; return SVS_ERR_UNSUPPORTED; }
     if (err.load() == 1) { ctx->err = "svs_ba_set_problem: edge index out of range"; return SVS_ERR_INVALID; }
     if (err.load() == 2) { ctx->err = "svs_ba_set_problem: a point is observed with two different anchors"; return SVS_ERR_INVALID; }
     for (int v : span_t) span = std::max(span, v);
@@ -1957,7 +2219,12 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
       for (int a = g0; a < g1; ++a)
         if (r < by_anchor_off[a + 1] - by_anchor_off[a]) lm_order.push_back(by_anchor[by_anchor_off[a] + r]);
   }
-  // edge slots: landmarks in that order, each with its observers ascending (insertion into <= 64 slots)
+  // landmarks with more than 64 observations go to the end of the order: they do not fit a wave chunk and get a workgroup each
+  const size_t n_lm_all = lm_order.size();
+  std::stable_partition(lm_order.begin(), lm_order.end(), [&](int l) { return n_obs[l] <= 64; });
+  size_t n_lm_reg = n_lm_all;
+  while (n_lm_reg > 0 && n_obs[lm_order[n_lm_reg - 1]] > 64) --n_lm_reg;
+  // edge slots: landmarks in that order, each with its observers ascending (insertion sort inside the landmark's slots)
   lm_pos.assign(L, -1); lm_off.assign(lm_order.size() + 1, 0);
   for (size_t k = 0; k < lm_order.size(); ++k) { lm_pos[lm_order[k]] = (int)k; lm_off[k + 1] = lm_off[k] + n_obs[lm_order[k]]; }
   if ((size_t)E > ba->h_edges_cap) {
@@ -2036,13 +2303,15 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   }
   std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
   cs.clear(); cl.clear();
-  for (size_t k = 0; k < n_lm;) {
+  for (size_t k = 0; k < n_lm_reg;) {
     const int start = lm_off[k];
     int len = 0;
-    while (k < n_lm && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
+    while (k < n_lm_reg && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
     cs.push_back(start); cl.push_back(len);
   }
   ba->n_chunks = (int)cs.size();
+  ba->n_wide = (int)(n_lm - n_lm_reg);
+  for (size_t k = n_lm_reg; k < n_lm; ++k) { cs.push_back(lm_off[k]); cl.push_back(lm_off[k + 1] - lm_off[k]); }      // wide landmarks: entries behind the chunks
   if (add_pose_terms)
     for (int c = 0; c < C; ++c) {
       SVS_REQUIRE(ctx, h_cons[c].pose1 >= 0 && h_cons[c].pose1 < P && h_cons[c].pose2 >= 0 && h_cons[c].pose2 < P);
@@ -2061,8 +2330,8 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     int rc = stage_upload(ba, ba->d_psi[0], h_psi, sizeof(double) * 3 * (size_t)L); if (rc) return rc;
     SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[1], ba->d_psi[0], sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
-  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_red, &ba->cap_red, sizeof(double) * ba->red_count));
   SVS_HIP(ctx, ensure((void **)&ba->d_x, &ba->cap_x, sizeof(double) * 6 * (size_t)P));
@@ -2071,7 +2340,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_pattern, &ba->cap_pattern, sizeof(double) * (size_t)P * P));
-  if (ba->n_chunks) {
+  if (!cs.empty()) {
     int rc = stage_upload(ba, ba->d_chunk_start, cs.data(), sizeof(int) * cs.size()); if (rc) return rc;
     rc = stage_upload(ba, ba->d_chunk_len, cl.data(), sizeof(int) * cl.size()); if (rc) return rc;
   }
@@ -2222,6 +2491,7 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
     }
     SVS_LAUNCH_CHECK(ctx);
   }
+  if (B.n_wide > 0) { hipLaunchKernelGGL(ba_wide_landmark_kernel<0>, dim3(B.n_wide), dim3(WIDE_THREADS), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
     std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
@@ -2297,6 +2567,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
     hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4) + (B.fuse_cons ? B.C : 0)), dim3(256), 0, ctx->stream, B);
     SVS_LAUNCH_CHECK(ctx);
   }
+  if (B.n_wide > 0) { hipLaunchKernelGGL(ba_wide_landmark_kernel<1>, dim3(B.n_wide), dim3(WIDE_THREADS), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
   if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   return SVS_OK;

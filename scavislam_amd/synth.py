@@ -248,6 +248,87 @@ def ba_window(P=15, L=3000, seed=2012, cam=CAM_NEWCOLLEGE, n_outer=3, outlier_fr
                 poses_gt=np.array([T.reshape(12) for T in gt]), psi_gt=psi_gt)
 
 
+def double_window(n_inner=30, n_outer=200, L=12000, seed=2014, cam=CAM_NEWCOLLEGE, n_long=(), n_loops=2, outlier_frac=0.02):
+    """The reference's double window as SlamGraph::copyDataToG2o hands it over (slam_graph.cpp:907-1032): poses 0 .. n_outer-1 are the
+    OUTER window (older keyframes), the last n_inner poses the INNER one; ALL are free (slam_graph.cpp:932).  Active points are
+    the points seen from the inner window; each is observed from every window pose in its vis_set -- a contiguous run of
+    keyframes that may reach back into the outer window -- with no cap on the run length (n_long: extra landmarks with that many
+    observations).  Every pair of neighbouring keyframes of which at least one is OUTER carries a relative-pose constraint
+    (i, i+1) and (i, i+2) (the co-visibility edges of the pose graph), plus n_loops loop-closure constraints across the window
+    (slam_graph.cpp:937-981).  Same noise model as ba_window."""
+    rng = np.random.default_rng(seed)
+    P = n_inner + n_outer
+    f, cx, cy, b = cam["f"], cam["cx"], cam["cy"], cam["b"]
+    gt = []
+    for i in range(P):            # a wide loop: after ~P keyframes the camera is back near its start and looks the same way
+        ang = 2 * np.pi * i / (P + 20)
+        R_wc = so3_exp(np.array([0.0, ang, 0.0]))
+        rad = 0.4 * (P + 20) / (2 * np.pi)
+        c = np.array([rad * (1 - np.cos(ang)), 0.0, rad * np.sin(ang)])
+        gt.append(pose_inv(pose(R_wc, c)))
+    poses = [pose_mul(pose(so3_exp(rng.normal(0, np.deg2rad(0.5), 3)), rng.normal(0, 0.01, 3)), T) for T in gt]
+    edges = []
+    psi = np.zeros((L, 3)); psi_gt = np.zeros((L, 3))
+
+    def add_landmark(l, first, k, anchor):
+        z = rng.uniform(3.0, 25.0)
+        u0, v0 = rng.uniform(60, cam["w"] - 60), rng.uniform(60, cam["h"] - 60)
+        xa = np.array([(u0 - cx) / f * z, (v0 - cy) / f * z, z])
+        psi_gt[l] = [xa[0] / xa[2], xa[1] / xa[2], 1.0 / xa[2]]
+        psi[l] = psi_gt[l]; psi[l, 2] *= 1.0 + rng.normal(0, 0.02)
+        Twa = pose_inv(gt[anchor])
+        xw = Twa[:, :3] @ xa + Twa[:, 3]
+        for i in range(first, first + k):
+            y = gt[i][:, :3] @ xw + gt[i][:, 3]
+            if i != anchor and (k <= 64 and y[2] < 0.5):
+                continue                                   # behind the camera: not observed (long-lived points keep every view)
+            obs = np.array([f * y[0] / y[2] + cx, f * y[1] / y[2] + cy, f * (y[0] - b) / y[2] + cx]) + rng.normal(0, 0.5, 3)
+            if rng.random() < outlier_frac:
+                obs += rng.uniform(-20, 20, 3)
+            s_ = 0.25 ** int(rng.choice(3, p=[0.6, 0.3, 0.1]))
+            edges.append((obs, (s_, s_, 0.333 ** 2), l, i, anchor))
+
+    l = 0
+    for k in n_long:                                       # long-lived points: runs ending in the inner window, anchored at their first view
+        first = P - k - int(rng.integers(0, 5))
+        add_landmark(l, first, k, first)
+        l += 1
+    while l < L:
+        k = 2 + rng.binomial(6, 0.5)
+        last = int(rng.integers(n_outer, P))               # seen from at least one inner keyframe
+        first = max(0, last - k + 1)
+        if rng.random() < 0.2:                             # some reach further back into the outer window
+            first = max(0, first - int(rng.integers(1, 12)))
+        add_landmark(l, first, last - first + 1, first)
+        l += 1
+    e = np.zeros(len(edges), BA_EDGE_DTYPE)
+    for j, (obs, info, ll, i, a) in enumerate(edges):
+        e[j]["obs"], e[j]["info"], e[j]["point"], e[j]["pose"], e[j]["anchor"] = obs, info, ll, i, a
+    e = e[np.lexsort((e["pose"], e["point"]))]
+    cons = []
+
+    def add_constraint(i, j):
+        T_ji = pose_mul(gt[j], pose_inv(gt[i]))
+        dn = np.concatenate([rng.normal(0, 0.005, 3), rng.normal(0, 0.002, 3)])
+        T_ji = pose_mul(pose(so3_exp(dn[3:]), dn[:3]), T_ji)
+        Lam = np.eye(6) * 30.0                              # slam_graph.cpp:842-845
+        Lam[:3, :3] *= (350 * np.linalg.norm(T_ji[:, 3]) / 8.0) ** 2
+        Lam[3:, 3:] *= 100.0 ** 2
+        cons.append((T_ji, Lam, i, j))
+
+    for i in range(P - 1):
+        for j in (i + 1, i + 2):
+            if j < P and (i < n_outer or j < n_outer):      # an edge touching the OUTER window is a marginalised constraint
+                add_constraint(i, j)
+    for k in range(n_loops):
+        add_constraint(3 + 7 * k, P - 4 - 9 * k)
+    c = np.zeros(len(cons), BA_CONSTRAINT_DTYPE)
+    for j, (T, Lam, i1, i2) in enumerate(cons):
+        c[j]["T_21"], c[j]["info"], c[j]["pose1"], c[j]["pose2"] = T.reshape(12), Lam.reshape(36), i1, i2
+    return dict(poses=np.array([T.reshape(12) for T in poses]), psi=psi, edges=e, cons=c, cam=cam,
+                poses_gt=np.array([T.reshape(12) for T in gt]), psi_gt=psi_gt, n_inner=n_inner, n_outer=n_outer)
+
+
 def shard_landmarks(edges, L, n_shards, chunk=64):
     """Landmarks dealt to shards in contiguous chunks of `chunk`, round-robin.
 

@@ -296,28 +296,30 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     assert st_ref.accepted >= 1
     np.testing.assert_allclose(st.chi2_final, st_ref.chi2_final, rtol=1e-8)      # wide envelopes: longer elimination chains
     assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6               # the parity bar (measured: 2e-9 .. 2e-8)
-    # landmarks: the same 1e-6 bar.  x_l = D^-1 (b_l - sum W_i^T x_i) multiplies whatever the pose update carries (1e-9 relative:
-    # f64 atomics order) by a_l = |D^-1| |W|; a landmark whose a_l is far above the window's typical value (weak parallax: tiny
-    # smallest eigenvalue of H_ll) cannot meet a bar relative to the LARGEST update of the window.  Those are excluded by a stated,
-    # state-derived bound, and the test asserts how few they are.
+    # landmarks: the same 1e-6 bar, plus what the back-substitution x_l = D^-1 (b_l - sum W_i^T x_i) makes of the pose update's own
+    # error: |dx_l| <= a_l |dx_p| with a_l = |D^-1| |W| (np_model.landmark_amplification; numeric Jacobians at the start state).  The
+    # pose update differs from the oracle's by ~1e-9 relative (order of the f64 atomics); a weak-parallax landmark (tiny smallest
+    # eigenvalue of H_ll) multiplies that by several hundred.  So every landmark must satisfy
+    #     |psi - psi_ref|_l <= 1e-6 max|update| + 10 a_l max|poses - poses_ref|
+    # and the test reports for how many the second term was needed at all.
     import np_model as M
     c = prob["cam"]
     amp = M.landmark_amplification(prob["poses"], prob["psi"], prob["edges"], (c["f"], c["cx"], c["cy"], c["b"]), st_ref.lambda_final)
-    seen = amp > 0
-    bound = 50.0 * np.median(amp[seen])
-    keep = seen & (amp <= bound)
-    n_excluded = int((seen & ~keep).sum())
-    assert n_excluded <= 4, f"{n_excluded} landmarks above 50x the median amplification"
     upd = np.abs(psi_ref - prob["psi"]).max()
-    assert np.abs(psi - psi_ref)[keep].max() / upd < 1e-6, f"excluded {n_excluded}"
-    assert np.abs(psi - psi_ref)[~keep & seen].max(initial=0.0) / upd < 1e-4     # and even those stay close
+    err_pose = np.abs(poses - poses_ref).max()
+    err_l = np.abs(psi - psi_ref).max(1)
+    assert (err_l <= 1e-6 * upd + 10.0 * amp * err_pose).all(), float((err_l - 10.0 * amp * err_pose).max() / upd)
+    n_over = int((err_l > 1e-6 * upd).sum())
+    print(f"{case}: {n_over} of {int((amp > 0).sum())} landmarks above the plain 1e-6 bar (all explained by pose error x amplification)")
+    assert n_over <= 8
     opt.close()
 
 
 def test_landmarks_with_64_observations(gpu_ctx):
-    """Landmarks seen by 64 keyframes (the supported maximum: one landmark fills a whole wave chunk, 32 circulant pair rounds)
-    next to ordinary ones; anchors in the middle of their runs as well as at the start.  The reduced system spans 64 block
-    rows, so this also runs the global-memory solve on a real (not forced) wide envelope.  65 observations are refused."""
+    """Landmarks seen by 64 keyframes (one landmark fills a whole wave chunk, 32 circulant pair rounds) next to ordinary ones;
+    anchors in the middle of their runs as well as at the start.  The reduced system spans 64 block rows, so this also runs
+    the global-memory solve on a real (not forced) wide envelope.  A 65th observation switches that landmark to the
+    one-workgroup-per-landmark kernel (ba_wide_landmark_kernel)."""
     import oracle as O
     from scavislam_amd import capi, synth
     from scavislam_amd.backend import SlamGraphOptimizer
@@ -359,10 +361,51 @@ def test_landmarks_with_64_observations(gpu_ctx):
     assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
     assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
     assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    # a 65th observation moves landmark 5 from the wave-chunk kernel to the wide-landmark kernel: still the oracle's result
     one_more = edges[edges["point"] == 5][:1].copy()
     one_more["pose"] = 64
-    with pytest.raises(capi.SvsError, match="status 5"):
-        opt.copyDataToG2o(prob["poses"], prob["psi"], np.concatenate([edges, one_more]), prob["cons"], cam, prm)
+    y = gt[64][:, :3] @ (synth.pose_inv(gt[int(one_more["anchor"][0])])[:, :3] @ np.array([prob["psi_gt"][5][0], prob["psi_gt"][5][1], 1.0]) / prob["psi_gt"][5][2]
+                          + synth.pose_inv(gt[int(one_more["anchor"][0])])[:, 3]) + gt[64][:, 3]
+    one_more["obs"] = [c["f"] * y[0] / y[2] + c["cx"], c["f"] * y[1] / y[2] + c["cy"], c["f"] * (y[0] - c["b"]) / y[2] + c["cx"]]
+    edges65 = np.concatenate([edges, one_more])
+    opt.copyDataToG2o(prob["poses"], prob["psi"], edges65, prob["cons"], cam, prm)
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], edges65, prob["cons"], cam, prm)
+    assert (st.trials, st.accepted) == (st_ref.trials, st_ref.accepted)
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6 and _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
+    opt.close()
+
+
+def test_double_window_230_poses_wide_landmarks(gpu_ctx):
+    """The reference's real window shape (data/newcollege.cfg:21-22, backend.cpp:141-144): 30 inner + 200 outer poses, all free
+    (slam_graph.cpp:932), ~400 pose-pose constraints incl. two loop closures (slam_graph.cpp:937-981), active points observed from
+    every window pose that sees them -- among them landmarks with 100 and 180 observations (no cap in slam_graph.cpp:1001-1027).
+    Reduced system <= 1e-10 and optimize <= 1e-6 vs the oracle; the wide envelope lands on the global-memory solve."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prob = synth.double_window(n_inner=30, n_outer=200, L=6000, seed=21, n_long=(100, 180, 70), n_loops=2)
+    assert len(prob["poses"]) == 230 and 350 <= len(prob["cons"]) <= 450
+    counts = np.bincount(prob["edges"]["point"], minlength=len(prob["psi"]))
+    assert counts.max() == 180 and (counts > 64).sum() == 3
+    cam = _cam(prob["cam"])
+    prm = BaParams.reference_defaults()
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    H, b, chi2 = opt.reduced_system(50.0)
+    H_ref, b_ref = O.ba_reduced_system(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm, 50.0)
+    np.testing.assert_allclose(H, H_ref, rtol=0, atol=1e-10 * np.abs(H_ref).max())
+    np.testing.assert_allclose(b, b_ref, rtol=0, atol=1e-10 * np.abs(b_ref).max())
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
+    assert st_ref.accepted >= 1
+    assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
+    assert _rel_update_err(psi, psi_ref, prob["psi"]) < 1e-6
     opt.close()
 
 
