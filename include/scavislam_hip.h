@@ -343,6 +343,48 @@ int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, in
 int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ_colmajor, const float *d_disp, int w, int h,
                         int stride_in, int stride_out, int factor, float *d_cloud4);
 
+/* ---- one call per frame: replaces the data-parallel part of StereoFrontend::processFrame(bool*) / processFirstFrame()
+   (stereo_frontend.h:88-95, stereo_frontend.cpp:110-131,183-306) for one camera stream, HOST buffers in and out.  The stages are
+   the entry points above, chained on the context's stream with no host round trip in between; keyframe switching / dropping and
+   list building stay with the caller (stereo_frontend.cpp:265-296). -----------------------------------------------------------*/
+typedef struct {
+  int32_t fast_trials;                 /* 6 (stereo_frontend.cpp:232); the first frame uses one less (:118) */
+  int32_t search_radius, thr_mean, thr_std;      /* 8, 22, 10 (:989-1004, CPU build) */
+  float max_reproj_error;              /* ui.max_reproj_error = 2 (:845-846) */
+  int32_t use_block_matching;          /* 0: a disparity image comes with every frame (have_disp_img); 1: calcDisparityCpu from the right image */
+  svs_pose_opt_params pose_opt;        /* PoseOptimizerParams(true, 2, 15) (:1061) */
+  svs_stereo_params stereo;            /* cv::StereoBM state (:620-653); used if use_block_matching */
+} svs_frontend_params;
+typedef struct {
+  double T_cur_from_actkey[12];        /* after dense tracking and calcFastMotionOnly */
+  int32_t dense_passes;                /* fused H,b / chi2 sweeps of the dense tracker (-1: its workgroups could not synchronise) */
+  int32_t n_points;                    /* candidate points matched against (= records in h_matches / h_gated) */
+  int32_t n_matched;                   /* SVS_MATCH_OK records = obs_list.size() */
+  int32_t tracking_ok;                 /* n_matched >= 20: what matchAndTrack returns (stereo_frontend.cpp:1053-1056) */
+  svs_pose_opt_stats pose_stats;
+  svs_point_stats point_stats;
+} svs_frame_result;
+typedef struct svs_frontend svs_frontend;
+/* cam = level-0 stereo camera (w, h multiples of 16).  max_points: capacity of the candidate list (ap_map); max_keyframes: keyframe slots */
+int svs_frontend_create(svs_ctx *ctx, const svs_cam *cam, const svs_frontend_params *prm, int max_points, int max_keyframes, svs_frontend **out);
+int svs_frontend_destroy(svs_frontend *fe);
+/* processFirstFrame: pyramid, disparity, FAST (fast_trials - 1), reference cloud at the identity.  h_right or h_disp per use_block_matching */
+int svs_frontend_first_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp, int dstride);
+/* Frame::clone of the frame processed last into keyframe slot `slot` with its pose (keyframe_map entry + vertex_map pose) */
+int svs_frontend_keep_keyframe(svs_frontend *fe, int slot, const double *T_kf_from_w);
+/* ap_map: h_pts[i].kf_index = keyframe slot of the anchor; records [0, n_new_records) are the "new feature" candidates (:989-1030) */
+int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate_point *h_pts, int n, int n_new_records);
+/* processFrame.  T_cur_from_actkey: the motion-model guess (in); T_actkey_from_w: pose of the active keyframe.  h_matches / h_gated:
+   n_points records each (may be NULL).  Blocking, like the reference call. */
+int svs_frontend_process_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp,
+                               int dstride, const double *T_cur_from_actkey, const double *T_actkey_from_w, svs_frame_result *out,
+                               svs_match_result *h_matches, svs_gated_point *h_gated);
+/* computeDensePointCloudCpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302) */
+int svs_frontend_recompute_cloud(svs_frontend *fe, const double *T_cur_from_actkey);
+/* device views (tests, chaining): level images of the frame processed last, strides, disparity, reference clouds, the FastGrid object */
+int svs_frontend_device_view(svs_frontend *fe, const uint8_t **d_pyr_last, int32_t *stride, const float **d_disp, const float **d_cloud,
+                             svs_fast **fast);
+
 /* ---- multi-GPU: the library-owned collective of the landmark-sharded back-end.  The reference has no
    distributed code; one process per GPU each creates a context and a communicator (RCCL, bound at run time) --------------*/
 typedef struct { char bytes[128]; } svs_unique_id;      /* = ncclUniqueId */

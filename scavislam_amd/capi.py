@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import weakref
 
-from .ctypes_types import BaParams, BaStats, Cam, FastGrid, PoseOptParams, StereoParams
+from .ctypes_types import BaParams, BaStats, Cam, FastGrid, PoseOptParams, PoseOptStats, StereoParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVS_LIB_PATH") or os.path.join(_HERE, "libscavislam_hip.so")   # override = kernel A/B experiments only
@@ -38,6 +38,26 @@ class DenseTrackFullArgs(C.Structure):
                 ("f", C.c_double * 3), ("cx", C.c_double * 3), ("cy", C.c_double * 3),
                 ("d_T_jac_out", C.c_void_p), ("d_record_out", C.c_void_p), ("record_cap", C.c_int32),
                 ("d_n_record_out", C.c_void_p)]
+
+
+class FrontendParams(C.Structure):
+    _fields_ = [("fast_trials", C.c_int32), ("search_radius", C.c_int32), ("thr_mean", C.c_int32), ("thr_std", C.c_int32),
+                ("max_reproj_error", C.c_float), ("use_block_matching", C.c_int32), ("pose_opt", PoseOptParams), ("stereo", StereoParams)]
+
+    @classmethod
+    def reference(cls, use_block_matching=False):
+        """the values StereoFrontend uses (stereo_frontend.cpp:232, :989-1004, :845-846, :1061, :620-653)"""
+        return cls(6, 8, 22, 10, 2.0, int(use_block_matching), PoseOptParams.reference(), StereoParams.reference())
+
+
+class PointStatsC(C.Structure):
+    _fields_ = [("num_points_grid2x2", C.c_int32 * 4), ("num_points_grid3x3", C.c_int32 * 9), ("num_matched_points", C.c_int32 * 3),
+                ("num_track_points", C.c_int32), ("num_obs", C.c_int32), ("pad_", C.c_int32 * 2), ("sum_track_length", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("T_cur_from_actkey", C.c_double * 12), ("dense_passes", C.c_int32), ("n_points", C.c_int32), ("n_matched", C.c_int32),
+                ("tracking_ok", C.c_int32), ("pose_stats", PoseOptStats), ("point_stats", PointStatsC)]
 
 
 class MatchArgs(C.Structure):
@@ -106,6 +126,15 @@ _SIGS = {
     "svs_stereo_destroy": [C.c_void_p],
     "svs_stereo_compute": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                            C.c_size_t, C.c_int],
+    "svs_frontend_create": [C.c_void_p, C.POINTER(Cam), C.POINTER(FrontendParams), C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "svs_frontend_destroy": [C.c_void_p],
+    "svs_frontend_first_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_frontend_keep_keyframe": [C.c_void_p, C.c_int, C.c_void_p],
+    "svs_frontend_set_candidates": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "svs_frontend_process_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
+    "svs_frontend_recompute_cloud": [C.c_void_p, C.c_void_p],
+    "svs_frontend_device_view": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_create": [C.c_void_p, C.POINTER(C.c_void_p)],
     "svs_ba_destroy": [C.c_void_p],
     "svs_ba_set_problem": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

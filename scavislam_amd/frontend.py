@@ -570,6 +570,73 @@ class DenseTrackerGpu:
         return [r.cpu().numpy() for r in self.dev_residual_img]
 
 
+class StereoFrontend:
+    """StereoFrontend::processFrame / processFirstFrame (stereo_frontend.h:88-95) for one camera stream, host arrays in and out:
+    one library call per frame (svs_frontend_*), no host round trip between the stages."""
+
+    def __init__(self, ctx, cam, max_points=4096, max_keyframes=8, params=None):
+        self.ctx, self.cam = ctx, cam
+        self.params = params or capi.FrontendParams.reference()
+        camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.svs_frontend_create(ctx.h, C.byref(camc), C.byref(self.params), max_points, max_keyframes, C.byref(self.h)))
+        ctx.children.add(self)
+        self.n_points = 0
+
+    @staticmethod
+    def _img(a, dtype):
+        return None if a is None else np.ascontiguousarray(a, dtype)
+
+    def processFirstFrame(self, left, right=None, disp=None):
+        left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
+        w = left.shape[1]
+        self.ctx.check(self.ctx.lib.svs_frontend_first_frame(self.h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w,
+                                                             disp.ctypes.data if disp is not None else None, w))
+
+    def keepKeyframe(self, slot, T_kf_from_w):
+        T = np.ascontiguousarray(T_kf_from_w, np.float64).reshape(12)
+        self.ctx.check(self.ctx.lib.svs_frontend_keep_keyframe(self.h, slot, T.ctypes.data))
+
+    def setCandidates(self, pts, n_new_records):
+        pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_set_candidates(self.h, pts.ctypes.data, len(pts), int(n_new_records)))
+        self.n_points = len(pts)
+
+    def processFrame(self, left, T_cur_from_actkey, T_actkey_from_w, right=None, disp=None):
+        """returns (FrameResult, MATCH_RESULT_DTYPE[n], GATED_POINT_DTYPE[n])"""
+        left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
+        w = left.shape[1]
+        Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+        Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(12)
+        res = capi.FrameResult()
+        m = np.zeros(self.n_points, MATCH_RESULT_DTYPE)
+        g = np.zeros(self.n_points, GATED_POINT_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_process_frame(self.h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w,
+                                                               disp.ctypes.data if disp is not None else None, w, Tc.ctypes.data, Ta.ctypes.data,
+                                                               C.byref(res), m.ctypes.data, g.ctypes.data))
+        return res, m, g
+
+    def cloud_host(self, level):
+        """reference cloud (quarter grid) the last frame left for the next one"""
+        clouds = (C.c_void_p * 3)()
+        self.ctx.check(self.ctx.lib.svs_frontend_device_view(self.h, None, None, None, clouds, None))
+        w, h = (self.cam["w"] >> level) // 4, (self.cam["h"] >> level) // 4
+        out = np.zeros((h, w, 4), np.float32)
+        self.ctx.call("svs_memcpy_d2h", out.ctypes.data, clouds[level], out.nbytes)
+        return out
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.svs_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class StereoMatcher:
     """StereoFrontend::calcDisparityCpu (stereo_frontend.cpp:620-653): cv::StereoBM on the level-0 left image
     and the right image, float disparity written into the frame's `disp` (-1 where filtered)."""
