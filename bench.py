@@ -271,6 +271,25 @@ def main():
         ctx.sync()
         lat_ms = (time.perf_counter() - t0) / 20 * 1e3
     del fe1
+    # the drop-in call: StereoFrontend::processFrame for one stream, HOST image + disparity in, HOST pose / match records / gate records /
+    # statistics out (svs_frontend_process_frame: pinned staging, one upload, the same kernels, one download) -- PCIe-inclusive latency
+    from scavislam_amd.frontend import StereoFrontend
+    sfe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=2)
+    sfe.processFirstFrame(rend_kf[0], disp=rend_kf[1])
+    sfe.keepKeyframe(0, T_kf)
+    sfe.setCandidates(pts, int(args.points * 0.5))
+    T_guess0 = synth.pose_mul(T_cur_list[0], synth.pose_inv(T_prev_list[0]))
+    host_ms = []
+    for it in range(14):
+        sfe.processFirstFrame(rend_prev[0][0], disp=rend_prev[0][1])          # untimed: makes frame "prev" the active keyframe again
+        t0 = time.perf_counter()
+        fres, fm, fg = sfe.processFrame(rend_cur[0][0], I34, T_prev_list[0], disp=rend_cur[0][1])
+        host_ms.append((time.perf_counter() - t0) * 1e3)
+    host_io_ms = float(np.median(host_ms[3:]))
+    host_io = {"ms_per_frame": round(host_io_ms, 4), "frames_per_s": round(1e3 / host_io_ms, 1), "matched": int(fres.n_matched),
+               "dense_passes": int(fres.dense_passes), "bytes_in": int(cam["w"] * cam["h"] * 5), "bytes_out": int(len(pts) * (64 + 40) + 600),
+               "pose_err": float(np.abs(np.array(fres.T_cur_from_actkey).reshape(3, 4) - T_guess0).max())}
+    sfe.close()
     # batched modes in between (B in {1, 8, 64}): same step, B independent streams per launch
     batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
     for Bs in (8, 64, 256):
@@ -536,6 +555,7 @@ def main():
                          "corners_per_frame": n_corners, "matches_per_frame": n_matched,
                          "dense_track_pose_err": track_err,
                          "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
+                         "latency_mode_B1_host_io": host_io,
                          "frames_per_s_per_gpu_by_batch": batch_sweep,
                          "stereo_bm": dict(stereo_info, ms_per_batch=round(stage_ms["stereo_bm"], 4),
                                            frames_per_s_if_block_matching_is_added_to_the_step=round(world * B / ((t_front / K) + stage_ms["stereo_bm"] * 1e-3), 1)),

@@ -416,6 +416,9 @@ int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const do
 /* optimizer.optimize(num_iters) (slam_graph.cpp:346) incl. LM control flow; allreduce may be
    NULL (single GPU) */
 int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats);
+/* throughput mode: n independent windows (each svs_ba created on its OWN context, i.e. its own stream), all enqueued before the
+   first wait so that their kernels overlap on the device; stats[n] optional.  Single-GPU (no collectives). */
+int svs_ba_optimize_batch(svs_ba *const *bas, int n, svs_ba_stats *stats);
 /* restoreDataFromG2o (slam_graph.cpp:1035-1058): poses [P][12], psi [L][3] */
 int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
 /* landmark-sharded operation over a library-owned communicator: svs_ba_optimize(ba, NULL, NULL, stats) then all-reduces the

@@ -173,6 +173,18 @@ class SlamGraphOptimizer:
             pass
 
 
+def optimize_batch(optimizers):
+    """svs_ba_optimize_batch: the windows of `optimizers` (each on its own context) optimised concurrently; returns their BaStats."""
+    n = len(optimizers)
+    hs = (C.c_void_p * n)(*[o.h for o in optimizers])
+    st = (BaStats * n)()
+    rc = optimizers[0].ctx.lib.svs_ba_optimize_batch(hs, n, st)
+    if rc:
+        for o in optimizers:
+            o.ctx.check(rc)
+    return list(st)
+
+
 def shard_problem(prob, rank, world, chunk=64):
     """Landmark shard of a BA window for `rank`: landmarks dealt in
     contiguous chunks of 64, round-robin; point ids stay global; constraints live on rank 0."""

@@ -2587,23 +2587,32 @@ static int add_trial_times(svs_ba *ba, hipEvent_t *ev) {
 // accept/reject decision and the lambda update on the device (ba_lm_kernel), one host synchronisation in total; the first
 // rejection (or terminate condition) turns the remaining enqueued kernels into no-ops and the host loop below resumes
 // from exactly that point.
-extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats) {
+// An optimize() in two halves, so that several windows can be in flight at once (svs_ba_optimize_batch): optimize_begin enqueues the
+// speculative trials of one window on ITS context's stream and returns without waiting; optimize_finish waits, replays the device's
+// decisions and runs the host-driven remainder (rejected trials) if there is one.
+struct OptRun {
+  svs_allreduce_fn allreduce = nullptr; void *user = nullptr;
+  double lambda = 0, ni = 2;
+  svs_ba_stats st{};
+  size_t smem = 0;
+  bool speculate = false;
+};
+static int optimize_begin(svs_ba *ba, svs_allreduce_fn allreduce, void *user, OptRun &R) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->d_red && ba->problem_valid);
   SVS_DEVICE(ctx);
   if (!allreduce && ba->comm) { allreduce = svs_comm_allreduce_hook; user = ba->comm; }      // library-owned collective (svs_ba_set_comm)
+  R.allreduce = allreduce; R.user = user;
   const svs_ba_params &prm = ba->prm;
-  double lambda = prm.lambda_init, ni = 2;
-  svs_ba_stats st{};
+  double lambda = prm.lambda_init;
+  R.lambda = lambda; R.ni = 2; R.st = svs_ba_stats{};
   ba->t_reduce = ba->t_solve = ba->t_backsub = 0; ba->n_reduce = 0;
-  bool ok = true;
   { int rc = ensure_profile(ba, allreduce, user); if (rc) return rc; }
   const size_t smem = sizeof(double) * ((size_t)6 * ba->P + (size_t)ba->P * 36 + 36);
+  R.smem = smem;
   if (smem > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  int it = 0;
-  bool resume = false;                 // the first trial of iteration `it` was already run (and rejected) by the speculative phase
-  double r_rho = 0, r_chi = 0;
   const bool speculate = prm.num_iters >= 1 && prm.max_trials > 1 && !ba->opt.debug && !ba->opt.no_speculation;
+  R.speculate = speculate;
   if (speculate) {
     const int n_it = prm.num_iters;
     const size_t n_ctl = 8 + 8 * (size_t)n_it;
@@ -2629,6 +2638,23 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
       cur = 1 - cur;                   // as if accepted
     }
     SVS_HIP(ctx, hipMemcpyAsync(ba->h_ctl, ba->d_ctl, sizeof(double) * n_ctl, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  return SVS_OK;
+}
+static int optimize_finish(svs_ba *ba, OptRun &R, svs_ba_stats *stats) {
+  svs_ctx *ctx = ba->ctx;
+  SVS_DEVICE(ctx);
+  const svs_ba_params &prm = ba->prm;
+  svs_allreduce_fn allreduce = R.allreduce; void *user = R.user;
+  double lambda = R.lambda, ni = R.ni;
+  svs_ba_stats st = R.st;
+  const size_t smem = R.smem;
+  bool ok = true;
+  int it = 0;
+  bool resume = false;                 // the first trial of iteration `it` was already run (and rejected) by the speculative phase
+  double r_rho = 0, r_chi = 0;
+  if (R.speculate) {
+    const int n_it = prm.num_iters;
     SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int j = 0; j < n_it; ++j) {
       const double *rec = ba->h_ctl + 8 + 8 * j;
@@ -2697,6 +2723,32 @@ extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *use
   st.lambda_final = lambda;
   if (stats) *stats = st;
   return SVS_OK;
+}
+
+extern "C" int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats) {
+  OptRun R;
+  int rc = optimize_begin(ba, allreduce, user, R);
+  if (rc) return rc;
+  return optimize_finish(ba, R, stats);
+}
+
+// Throughput mode: n independent windows, each on its own context (= its own stream), all enqueued before the first wait -- the
+// kernels of different windows overlap on the device (a 50-keyframe window keeps 2 of 256 CUs busy during its solve).
+extern "C" int svs_ba_optimize_batch(svs_ba *const *bas, int n, svs_ba_stats *stats) {
+  if (!bas || n < 1) return SVS_ERR_INVALID;
+  std::vector<OptRun> runs((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    if (!bas[i]) return SVS_ERR_INVALID;
+    for (int j = 0; j < i; ++j) if (bas[j]->ctx == bas[i]->ctx) { bas[i]->ctx->err = "svs_ba_optimize_batch: every window needs its own context (stream)"; return SVS_ERR_INVALID; }
+    const int rc = optimize_begin(bas[i], nullptr, nullptr, runs[i]);
+    if (rc) return rc;
+  }
+  int rc_all = SVS_OK;
+  for (int i = 0; i < n; ++i) {
+    const int rc = optimize_finish(bas[i], runs[i], stats ? stats + i : nullptr);
+    if (rc && !rc_all) rc_all = rc;
+  }
+  return rc_all;
 }
 
 extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {

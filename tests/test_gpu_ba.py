@@ -524,3 +524,46 @@ def test_failed_set_problem_invalidates_the_handle(gpu_ctx):
     st = opt.optimize()
     assert st.trials >= 1
     opt.close()
+
+
+def test_optimize_batch_of_windows(gpu_ctx):
+    """svs_ba_optimize_batch: six different windows (sizes 6..40 keyframes, one of them with rejected first trials), each on its own
+    context, enqueued together: every window ends exactly where its stand-alone optimize ends (same statistics, state to 1e-9)."""
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer, optimize_batch
+    from scavislam_amd.ctypes_types import BaParams
+    ctx0, stream0 = gpu_ctx
+    specs = [(6, 200, 1, {}), (15, 3000, 2, {}), (40, 4000, 3, {}), (8, 300, 77, dict(pose_sigma_t=0.4, pose_sigma_r_deg=8.0, outlier_frac=0.2)),
+             (25, 2500, 5, {}), (12, 900, 6, {})]
+    probs = [synth.ba_window(P, L, seed=sd, n_outer=2 if P > 8 else 0, **kw) for P, L, sd, kw in specs]
+    prms = []
+    for i in range(len(probs)):
+        prm = BaParams.reference_defaults()
+        if i == 3:
+            prm.lambda_init, prm.use_robust, prm.num_iters = 1e-9, 0, 3      # rejected trials: the host-driven remainder runs inside the batch
+        prms.append(prm)
+    ref = []
+    for prob, prm in zip(probs, prms):
+        o = SlamGraphOptimizer(ctx0, stream0)
+        o.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], _cam(prob["cam"]), prm)
+        st = o.optimize()
+        ref.append((st, *o.restoreDataFromG2o()))
+        o.close()
+    ctxs = [capi.torch_context(0) for _ in probs]
+    opts = []
+    for (c, s), prob, prm in zip(ctxs, probs, prms):
+        o = SlamGraphOptimizer(c, s)
+        o.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], _cam(prob["cam"]), prm)
+        opts.append(o)
+    sts = optimize_batch(opts)
+    saw_reject = False
+    for o, st, (st0, p0, s0), prob in zip(opts, sts, ref, probs):
+        assert (st.iterations, st.trials, st.accepted, st.terminated) == (st0.iterations, st0.trials, st0.accepted, st0.terminated)
+        saw_reject |= st.trials > st.accepted
+        poses, psi = o.restoreDataFromG2o()
+        if st0.accepted:
+            assert _rel_update_err(poses, p0, prob["poses"]) < 1e-7 and _rel_update_err(psi, s0, prob["psi"]) < 1e-7
+        o.close()
+    assert saw_reject
+    for c, _ in ctxs:
+        c.close()
