@@ -288,7 +288,7 @@ def main():
     host_io_ms = float(np.median(host_ms[3:]))
     host_io = {"ms_per_frame": round(host_io_ms, 4), "frames_per_s": round(1e3 / host_io_ms, 1), "matched": int(fres.n_matched),
                "dense_passes": int(fres.dense_passes), "bytes_in": int(cam["w"] * cam["h"] * 5), "bytes_out": int(len(pts) * (64 + 40) + 600),
-               "pose_err": float(np.abs(np.array(fres.T_cur_from_actkey).reshape(3, 4) - T_guess0).max())}
+               "pose_dev_from_true_motion": float(np.abs(np.array(fres.T_cur_from_actkey).reshape(3, 4) - T_guess0).max())}
     sfe.close()
     # batched modes in between (B in {1, 8, 64}): same step, B independent streams per launch
     batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
@@ -434,6 +434,63 @@ def main():
                 opt.optimize(None)
                 opt.restoreDataFromG2o()
             e2e_ms = (time.perf_counter() - t0) / min(K, 10) * 1e3
+    # other window shapes + throughput mode (rank 0 at N = 1 only; each is one optimize() of a resident window, state restored untimed)
+    schur_rows = None
+    if world == 1:
+        from scavislam_amd.backend import optimize_batch
+        schur_rows = {}
+
+        def time_window(name, pr, reps=10):
+            o = SlamGraphOptimizer(ctx, stream)
+            cm = Cam(*(pr["cam"][k] for k in ("f", "cx", "cy", "b", "w", "h")))
+            t_e2e = []
+            with torch.cuda.stream(stream):
+                for rep in range(reps + 2):
+                    t0 = time.perf_counter()
+                    o.copyDataToG2o(pr["poses"], pr["psi"], pr["edges"], pr["cons"], cm, prm)
+                    st_ = o.optimize()
+                    o.restoreDataFromG2o()
+                    t_e2e.append(time.perf_counter() - t0)
+                t_opt = []
+                for rep in range(reps):
+                    o.reset_state(pr["poses"], pr["psi"])
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    o.optimize()
+                    ctx.sync()
+                    t_opt.append(time.perf_counter() - t0)
+            row = dict(keyframes=len(pr["poses"]), landmarks=int(np.unique(pr["edges"]["point"]).size), edges=len(pr["edges"]), constraints=len(pr["cons"]),
+                       ms_per_optimize=round(float(np.median(t_opt)) * 1e3, 4),
+                       ms_per_call_incl_host_marshalling_and_copies=round(float(np.median(t_e2e[2:])) * 1e3, 4),
+                       lm_trials=int(st_.trials), **o.info())
+            o.close()
+            schur_rows[name] = row
+        time_window("15KF_3k (configs[2])", synth.ba_window(15, 3000, seed=2012))
+        time_window("double_window_30_inner_200_outer", synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(100, 180, 70), n_loops=2))
+        time_window("double_window_30_inner_200_outer_no_loop_closure", synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(), n_loops=0))
+        # throughput mode: W independent 50 KF / 20k windows in flight (svs_ba_optimize_batch, one context = one stream per window)
+        by_w = {"1": round(1e3 / ms_opt, 1)}
+        for Wn in (8, 32):
+            ctxs_w = [capi.torch_context(local_rank) for _ in range(Wn)]
+            opts_w = []
+            for cw, sw in ctxs_w:
+                ow = SlamGraphOptimizer(cw, sw)
+                ow.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
+                opts_w.append(ow)
+            tt = []
+            for rep in range(5):
+                for ow in opts_w:
+                    ow.reset_state(prob["poses"], prob["psi"])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                optimize_batch(opts_w)
+                tt.append(time.perf_counter() - t0)
+            by_w[str(Wn)] = round(Wn / float(np.median(tt[1:])), 1)
+            for ow in opts_w:
+                ow.close()
+            for cw, _ in ctxs_w:
+                cw.close()
+        schur_rows["windows_per_s_by_batch_50KF_20k"] = by_w
     # weak-scaling row: every rank optimises its own complete 50 KF / 20k window, no collective
     schur_weak = None
     if world > 1:
@@ -548,6 +605,9 @@ def main():
                                     "backsub_chi2": round(t_bs / max(n_tr, 1), 5)},
                       "chi2_init": stats.chi2_init, "chi2_final": stats.chi2_final,
                       "speedup_vs_cpu_port": round(cpu_schur_ms / ms_opt, 2) if cpu_schur_ms else None,
+                      "speedup_vs_cpu_port_drop_in_call": round(cpu_schur_ms / e2e_ms, 2) if (cpu_schur_ms and e2e_ms) else None,
+                      "solve_kernel": opt.info()["solve_kernel"],
+                      "other_windows": schur_rows,
                       "weak_scaling": schur_weak},
             "frontend": {"stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                          "dense_passes_per_frame": round(passes, 2),

@@ -435,6 +435,10 @@ int svs_ba_set_option(svs_ba *ba, const char *name, int value);
 int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
 int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,
                           double *h_bred /* 6P */, double *h_chi2);
+/* what the last svs_ba_set_problem led to: solve_kind 0 = global-memory blocked Cholesky, 1 = LDS-window pipeline, 2 = fused
+   register-resident elimination (one front), 3 = the same with two fronts; envelope_rows = widest filled block row of the reduced
+   system (+1); wave chunks of the Schur kernel; landmarks with more than 64 observations */
+int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide);
 /* profiling: bracket the Schur, solve and back-substitution kernels of every LM trial with hipEvents on the ctx stream.
    Off by default: each event record costs ~4 us of stream time (12 per optimize() = 15 % of it at 50 KF / 20k). */
 int svs_ba_set_timing(svs_ba *ba, int on);

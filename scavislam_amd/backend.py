@@ -152,6 +152,14 @@ class SlamGraphOptimizer:
         """attach a library-owned communicator: optimize() then all-reduces with ncclAllReduce on the ctx stream"""
         self.ctx.check(self.ctx.lib.svs_ba_set_comm(self.h, comm.h if comm is not None else None))
 
+    SOLVE_KINDS = ("global-memory blocked Cholesky", "LDS-window pipeline", "fused register-resident elimination, one front",
+                   "fused register-resident elimination, two fronts")
+
+    def info(self):
+        k, r, c, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.ctx.check(self.ctx.lib.svs_ba_info(self.h, C.byref(k), C.byref(r), C.byref(c), C.byref(w)))
+        return dict(solve_kernel=self.SOLVE_KINDS[k.value], envelope_rows=r.value, wave_chunks=c.value, wide_landmarks=w.value)
+
     def set_timing(self, on):
         """hipEvent brackets around the dominant kernels of every LM trial (profiling; ~4 us per event)."""
         self.ctx.check(self.ctx.lib.svs_ba_set_timing(self.h, int(bool(on))))

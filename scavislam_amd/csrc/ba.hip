@@ -2788,6 +2788,17 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   return SVS_OK;
 }
 
+extern "C" int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && ba->problem_valid);
+  if (!ba->profile_ready) { const int rc = ensure_profile(ba, ba->comm ? svs_comm_allreduce_hook : nullptr, ba->comm); if (rc) return rc; }
+  if (solve_kind) *solve_kind = ba->use_fused_solve ? (ba->fuse_P1 > 0 ? 3 : 2) : (ba->use_lds_solve ? 1 : 0);
+  if (envelope_rows) *envelope_rows = ba->env_R;
+  if (n_chunks) *n_chunks = ba->n_chunks;
+  if (n_wide) *n_wide = ba->n_wide;
+  return SVS_OK;
+}
+
 extern "C" int svs_ba_set_timing(svs_ba *ba, int on) {
   if (!ba) return SVS_ERR_INVALID;
   ba->timing = on != 0;
