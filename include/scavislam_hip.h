@@ -427,7 +427,7 @@ int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
    (test hook). */
 int svs_ba_set_comm(svs_ba *ba, svs_comm *comm);
 /* experiment / test switches of one optimizer (0 = default behaviour): "no_speculation", "one_front", "no_fused_solve",
-   "no_lds_solve", "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
+   "no_lds_solve", "no_grid_solve", "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
    "p1" (rows of the reversed front), "group" (anchors dealt round-robin), "host_threads".  The environment (SVS_BA_*,
    SVS_HOST_THREADS) only supplies the initial values, read once by svs_ba_create; values are clamped to their valid ranges. */
 int svs_ba_set_option(svs_ba *ba, const char *name, int value);
@@ -436,7 +436,7 @@ int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
 int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,
                           double *h_bred /* 6P */, double *h_chi2);
 /* what the last svs_ba_set_problem led to: solve_kind 0 = global-memory blocked Cholesky, 1 = LDS-window pipeline, 2 = fused
-   register-resident elimination (one front), 3 = the same with two fronts; envelope_rows = widest filled block row of the reduced
+   register-resident elimination (one front), 3 = the same with two fronts, 4 = multi-workgroup blocked Cholesky; envelope_rows = widest filled block row of the reduced
    system (+1); wave chunks of the Schur kernel; landmarks with more than 64 observations */
 int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide);
 /* profiling: bracket the Schur, solve and back-substitution kernels of every LM trial with hipEvents on the ctx stream.

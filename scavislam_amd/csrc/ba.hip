@@ -1148,6 +1148,208 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
   if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
 }
 
+// ---- multi-workgroup variant for wide envelopes -------------------------------------------------------------------------
+// The reference's real window is 30 inner + 200 outer poses (data/newcollege.cfg:21-22), and a loop closure or a landmark seen from
+// 180 keyframes couples poses far apart: the filled envelope then spans most of the 230 block rows and the one-workgroup kernel
+// above spends 0.26 ms per elimination step on its trailing update (60 ms per solve).  Here the trailing update of every step is
+// spread over G workgroups (one per CU):
+//   * every workgroup factorises the 6x6 pivot block and forms the WHOLE panel row U_k* = L_kk^-1 A_k* itself (<= 255 blocks,
+//     50 kFLOP: cheaper than handing it around), into LDS;
+//   * the trailing tiles A_ij -= U_ki^T U_kj of the step are dealt to all lanes of all workgroups (one lane per tile row);
+//   * ONE device-scope arrival counter per step (monotonic, relaxed polls) makes row k+1 final before anybody reads it.  All
+//     traffic on H goes through write-through stores / L1-bypassing loads (agent scope), so no cache has to be flushed or
+//     invalidated and workgroups on different XCDs see each other's tiles (MI355X_MICROARCH.md, inter-workgroup visibility);
+//   * workgroup 0 keeps the right-hand side (forward substitution rides along), stores U for the back substitution and finishes
+//     alone: row-oriented back substitution, trial poses, scale.
+// The G workgroups must be resident together (G <= #CUs, one 256-lane workgroup each); a bounded wait turns a missing sibling into
+// the solve's failure path (the LM trial is then rejected like a non-positive pivot).
+__device__ __forceinline__ void g_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double g_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws,
+                                                                      const int *__restrict__ rowmax, unsigned *__restrict__ bar, unsigned epoch0) {
+  extern __shared__ double smem[];
+  if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }
+  const int P = B.P, n = 6 * P, tid = threadIdx.x, wg = blockIdx.x, G = gridDim.x;
+  double *s_panel = smem;                          // [P*36] panel row U_kj, j > k
+  double *s_linv = s_panel + (size_t)P * 36;       // [36] (U_kk^T)^-1, lower
+  double *s_b = s_linv + 36;                       // [n] rhs -> y -> x (workgroup 0 only)
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  if (wg == 0) for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
+  __syncthreads();
+  for (int k = 0; k < P; ++k) {
+    const long kk = blk_index(k, k, P);
+    if (tid == 0) {
+      double A[36], U[36], Li[36];
+      const double *Akk = B.H + kk * 36;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) { double v = g_ld(Akk + 6 * r + c); if (r == c) v += B.lambda; A[6 * r + c] = v; }
+      int fail = 0;
+#pragma unroll
+      for (int i = 0; i < 36; ++i) { U[i] = 0; Li[i] = 0; }
+      double rd[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) d -= U[6 * q + j] * U[6 * q + j];
+        if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1; }
+        d = sqrt(d);
+        U[6 * j + j] = d;
+        rd[j] = 1.0 / d;
+#pragma unroll
+        for (int c = j + 1; c < 6; ++c) {
+          double sv = A[6 * j + c];
+#pragma unroll
+          for (int q = 0; q < j; ++q) sv -= U[6 * q + j] * U[6 * q + c];
+          U[6 * j + c] = sv * rd[j];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = c; r < 6; ++r) {
+          double sv = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+          for (int q = c; q < r; ++q) sv -= U[6 * q + r] * Li[6 * q + c];
+          Li[6 * r + c] = sv * rd[r];
+        }
+#pragma unroll
+      for (int i = 0; i < 36; ++i) s_linv[i] = Li[i];
+      if (wg == 0) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) linv_ws[(size_t)k * 36 + i] = Li[i];
+      }
+      if (fail) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) break;                             // every workgroup takes the same decision from the same pivot block
+    const int nj = rowmax[k] - k;
+    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {        // panel: U_kj = Li * A_kj, one thread per (block, column)
+      const int jj = e / 6, c = e - jj * 6;
+      const double *Akj = B.H + (kk + 1 + jj) * 36;
+      double a[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) a[q] = g_ld(Akj + 6 * q + c);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double sv = 0;
+#pragma unroll
+        for (int q = 0; q <= r; ++q) sv += s_linv[6 * r + q] * a[q];
+        s_panel[(size_t)jj * 36 + 6 * r + c] = sv;
+      }
+    }
+    __syncthreads();
+    if (wg == 0) {
+      double yk[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { double sv = 0; for (int q = 0; q <= r; ++q) sv += s_linv[6 * r + q] * s_b[6 * k + q]; yk[r] = sv; }
+      __syncthreads();
+      if (tid < 6) s_b[6 * k + tid] = yk[tid];
+      for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {
+        const int jj = e / 6, c = e - jj * 6;
+        double sv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sv += s_panel[(size_t)jj * 36 + 6 * q + c] * yk[q];
+        s_b[6 * (k + 1 + jj) + c] -= sv;
+      }
+    }
+    // trailing update inside the envelope, dealt to all lanes of all workgroups: one lane per (tile, row)
+    const long nblk = (long)nj * (nj + 1) / 2;
+    for (long e = (long)wg * SOLVE_THREADS + tid; e < nblk * 6; e += (long)G * SOLVE_THREADS) {
+      const long bidx = e / 6;
+      const int r = (int)(e - bidx * 6);
+      int ii = (int)((2.0 * nj + 1.0 - sqrt((2.0 * nj + 1.0) * (2.0 * nj + 1.0) - 8.0 * (double)bidx)) * 0.5);
+      while ((long)ii * nj - (long)ii * (ii - 1) / 2 > bidx) --ii;
+      while ((long)(ii + 1) * nj - (long)(ii + 1) * ii / 2 <= bidx) ++ii;
+      const int jj = ii + (int)(bidx - ((long)ii * nj - (long)ii * (ii - 1) / 2));
+      double xi[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) xi[q] = s_panel[(size_t)ii * 36 + 6 * q + r];
+      double *Aij = B.H + blk_index(k + 1 + ii, k + 1 + jj, P) * 36 + 6 * r;
+      double acc[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] = g_ld(Aij + c);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double sv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sv += xi[q] * s_panel[(size_t)jj * 36 + 6 * q + c];
+        g_st(Aij + c, acc[c] - sv);
+      }
+    }
+    // arrival: this workgroup's tiles of step k are on their way; wait until everybody's are
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && k + 1 < P) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = epoch0 + (unsigned)G * (unsigned)(k + 1);
+      long spin = 0;
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && ++spin < (1l << 22)) __builtin_amdgcn_s_sleep(1);
+      if (spin >= (1l << 22)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_fail = 2;
+    }
+    __syncthreads();
+    if (s_fail) break;
+    // U_k* for the back substitution replaces A_k* only now: before the arrival above a slower workgroup could still be reading A_k*
+    // for its own copy of the panel row
+    if (wg == 0) {
+      for (int e = tid; e < nj * 36; e += SOLVE_THREADS) g_st(B.H + (kk + 1) * 36 + e, s_panel[e]);
+      __syncthreads();                              // s_panel is overwritten by the next step's panel
+    }
+  }
+  if (wg != 0) return;
+  const int fail = s_fail;
+  __syncthreads();
+  if (!fail) {
+    // back substitution, row oriented: x_k = Li_k^T (y_k - sum_{j > k} U_kj x_j); the row of U is contiguous in the packed storage
+    __shared__ double s_acc[SOLVE_THREADS / 64][6];
+    for (int k = P - 1; k >= 0; --k) {
+      const int nj = rowmax[k] - k;
+      const double *Uk = B.H + (blk_index(k, k, P) + 1) * 36;
+      double part[6] = {0, 0, 0, 0, 0, 0};
+      for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {      // thread = (block jj, column c): contributes U_kj[r][c] x_j[c] to every row r
+        const int jj = e / 6, c = e - jj * 6;
+        const double xv = s_b[6 * (k + 1 + jj) + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) part[r] += g_ld(Uk + (size_t)jj * 36 + 6 * r + c) * xv;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) part[r] = wave_sum_f64(part[r]);
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_acc[tid >> 6][r] = part[r];
+      }
+      __syncthreads();
+      if (tid < 6) {
+        double yv[6];
+        for (int q = 0; q < 6; ++q) { double t = s_b[6 * k + q]; for (int w = 0; w < SOLVE_THREADS / 64; ++w) t -= s_acc[w][q]; yv[q] = t; }
+        double sv = 0;
+        for (int q = tid; q < 6; ++q) sv += linv_ws[(size_t)k * 36 + 6 * q + tid] * yv[q];
+        s_linv[tid] = sv;
+      }
+      __syncthreads();
+      if (tid < 6) s_b[6 * k + tid] = s_linv[tid];
+      __syncthreads();
+    }
+  } else {
+    for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = 0;
+    __syncthreads();
+  }
+  double sc = 0;
+  for (int i = tid; i < n; i += SOLVE_THREADS) { const double xv = s_b[i]; x_out[i] = xv; sc += xv * (B.lambda * xv + B.bp[i]); }
+  sc = wave_sum_f64(sc);
+  if ((tid & 63) == 0 && sc != 0.0) atomic_add_f64(&B.scal[2], sc);
+  for (int p = tid; p < P; p += SOLVE_THREADS) {
+    double Tn[12];
+    d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
+    for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
+  }
+  if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
+}
+
 // ---- LDS-window variant of the solve -------------------------------------------------------------
 // When the filled block envelope is narrow (R = max_k(rowmax[k]-k)+1 rows fit in LDS) the active
 // R x R block window of the elimination lives entirely in LDS as a ring of envelope rows, and the
@@ -1951,7 +2153,7 @@ class HostPool {
 };
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
-  int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, debug = 0;
+  int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0;
 };
 int svs_comm_allreduce_hook(void *d_buf, size_t count, void *user);      // comm.hip
@@ -1979,6 +2181,7 @@ struct svs_ba {
   bool timing = false;                         // hipEvent brackets around the three dominant kernels of every trial (svs_ba_set_timing / svs_ba_kernel_times)
   int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
+  unsigned *d_gridbar = nullptr; int grid_G = 0;      // multi-workgroup solve: arrival counter + failure flag, number of workgroups (0 = not used)
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
   int ctl_iters = 0;
   std::vector<hipEvent_t> spec_ev;      // 6 events per speculative trial
@@ -2087,6 +2290,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
   if (ba->d_xfer) (void)hipFree(ba->d_xfer);
   if (ba->d_flags) (void)hipFree(ba->d_flags);
+  if (ba->d_gridbar) (void)hipFree(ba->d_gridbar);
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
   ba->free_all();
@@ -2462,6 +2666,18 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
       SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
   }
+  // wide envelopes (neither LDS variant fits): the trailing updates are spread over several workgroups once they are worth it
+  ba->grid_G = 0;
+  // (measured at P = 230: one workgroup 0.98 ms at R = 19, 29.9 ms at R = 224; several 1.59 / 3.67 ms -- the per-step arrival wait costs ~6 us)
+  if (!ba->use_lds_solve && !ba->opt.no_grid_solve && R >= 40) {
+    const long tile_rows = (long)R * (R + 1) / 2 * 6;
+    ba->grid_G = (int)std::max(8l, std::min((long)ctx->n_cu, (tile_rows + 4 * SOLVE_THREADS - 1) / (4 * SOLVE_THREADS)));
+    if (!ba->d_gridbar) {
+      SVS_HIP(ctx, hipMalloc(&ba->d_gridbar, sizeof(unsigned) * 4));
+    }
+    const size_t smem_g = sizeof(double) * ((size_t)P * 36 + 36 + 6 * (size_t)P);
+    if (smem_g > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
+  }
   ba->profile_ready = true;
   return SVS_OK;
 }
@@ -2557,6 +2773,11 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   }
   else if (ba->use_lds_solve)
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+  else if (ba->grid_G > 0) {
+    const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
+    SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * 4, ctx->stream));      // arrival counter + failure flag of this launch (a speculative
+    hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
+  }
   else
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
   SVS_LAUNCH_CHECK(ctx);
@@ -2778,6 +2999,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "no_fused_solve") o.no_fused_solve = value != 0;
   else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
   else if (n == "no_fused_cons") o.no_fused_cons = value != 0;
+  else if (n == "no_grid_solve") o.no_grid_solve = value != 0;
   else if (n == "debug") o.debug = clamp(value, 0, 2);
   else if (n == "nw") o.nw = value == 0 ? 0 : clamp(value, 4, 8);
   else if (n == "p1") o.p1 = value < 0 ? -1 : clamp(value, 0, SOLVE_MAX_P);
@@ -2792,7 +3014,7 @@ extern "C" int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_ro
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->problem_valid);
   if (!ba->profile_ready) { const int rc = ensure_profile(ba, ba->comm ? svs_comm_allreduce_hook : nullptr, ba->comm); if (rc) return rc; }
-  if (solve_kind) *solve_kind = ba->use_fused_solve ? (ba->fuse_P1 > 0 ? 3 : 2) : (ba->use_lds_solve ? 1 : 0);
+  if (solve_kind) *solve_kind = ba->use_fused_solve ? (ba->fuse_P1 > 0 ? 3 : 2) : (ba->use_lds_solve ? 1 : (ba->grid_G > 0 ? 4 : 0));
   if (envelope_rows) *envelope_rows = ba->env_R;
   if (n_chunks) *n_chunks = ba->n_chunks;
   if (n_wide) *n_wide = ba->n_wide;

@@ -263,11 +263,12 @@ def _with_loop_closure(prob, i, j, rng):
 
 
 @pytest.mark.parametrize("case", ["fused_two_fronts", "fused_one_front", "lds_forced", "global_forced", "lds_wide_envelope",
-                                  "global_wide_envelope"])
+                                  "global_wide_envelope", "grid_wide_envelope"])
 def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
-    """The reduced camera system is solved by one of three kernels depending on the width of its block envelope: the fused
+    """The reduced camera system is solved by one of four kernels depending on the width of its block envelope: the fused
     register-resident elimination (<= 10 block rows; two fronts when the window is long enough), the LDS-window pipeline
-    (<= 28), the global-memory blocked Cholesky (anything).  Each must give the oracle's update to 1e-6."""
+    (<= 28 and it fits LDS), the multi-workgroup blocked Cholesky (wide envelopes), the one-workgroup global-memory blocked
+    Cholesky (narrow envelopes with the LDS variants switched off, or on request).  Each must give the oracle's update to 1e-6."""
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.backend import SlamGraphOptimizer
@@ -276,19 +277,20 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     rng = np.random.default_rng(3)
     P = 40
     prob = synth.ba_window(P, 4000, seed=11, n_outer=2)
-    options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve"}
-    if case in options:
-        pass
-    elif case == "lds_wide_envelope":
-        prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows
-    elif case == "global_wide_envelope":
-        prob = _with_loop_closure(prob, 0, P - 1, rng)       # full envelope: 40 block rows
+    options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve", "global_wide_envelope": "no_grid_solve"}
+    if case == "lds_wide_envelope":
+        prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows: too wide for the LDS window at P = 40 (194 KB), one workgroup
+    elif case in ("global_wide_envelope", "grid_wide_envelope"):
+        prob = _with_loop_closure(prob, 0, P - 1, rng)       # full envelope: 40 block rows (one workgroup / spread over several)
     cam = _cam(prob["cam"])
     prm = BaParams.reference_defaults()
     opt = SlamGraphOptimizer(ctx, stream)
     if case in options:
         opt.set_option(options[case], 1)
     opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    expect = {"fused_two_fronts": "two fronts", "fused_one_front": "one front", "lds_forced": "LDS-window", "global_forced": "global-memory",
+              "lds_wide_envelope": "global-memory", "global_wide_envelope": "global-memory", "grid_wide_envelope": "multi-workgroup"}[case]
+    assert expect in opt.info()["solve_kernel"], opt.info()
     st = opt.optimize()
     poses, psi = opt.restoreDataFromG2o()
     poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
