@@ -8,7 +8,10 @@
 //   FastGrid        <- scavislam/fast_grid.h:27-63
 //   GuidedMatcher   <- scavislam/matcher.hpp:62-186
 //   DenseTracker    <- scavislam/dense_tracking.h:53-97  (CPU-path semantics, the parity target)
+//   GpuTracker / DenseTrackerGpu <- gpu/dense_tracking.cuh:281-342, DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-215)
+//   StereoFrontend  <- StereoFrontend::processFrame / processFirstFrame, scavislam/stereo_frontend.h:88-95 (one call per frame)
 //   SlamGraphBA     <- SlamGraph::optimize, scavislam/slam_graph.hpp:457-462
+//   Communicator    <- (no reference counterpart) landmark-sharded optimize over RCCL, SURVEY.md 8e
 //
 // One svs_ctx per calling thread (front-end on main, re-registration matcher/FAST + optimize on
 // the backend thread, backend.cpp:452-469,738,763): no static scratch like matcher.cpp:36-38.
@@ -358,6 +361,148 @@ class DenseTracker {
   DeviceBuffer<int32_t> d_passes_;
 };
 
+
+// GpuTracker (gpu/dense_tracking.cuh:281-342): the CUDA build's per-pass call surface, same argument lists (device pointers into the
+// caller's images, strides in elements), blocking like the reference (each call ends with a device synchronisation there too).
+struct GpuIntrinsics { float focal_length, pp_x, pp_y; void set(double fl, double px, double py) { focal_length = (float)fl; pp_x = (float)px; pp_y = (float)py; } };
+struct GpuMatrix34 { float data_colmajor[12]; void set(const double *m_colmajor) { for (int i = 0; i < 12; ++i) data_colmajor[i] = (float)m_colmajor[i]; } };
+struct GpuMatrix4 { float data_colmajor[16]; void set(const double *m_colmajor) { for (int i = 0; i < 16; ++i) data_colmajor[i] = (float)m_colmajor[i]; } };
+struct GpuTrackingData { double hessian[21], jacobian_times_res[6]; };      // packed upper by column, as GpuSymMatrix6 (f64 sums here)
+inline bool computePointCloud(const Context &c, const GpuMatrix4 &TQ_actkey_from_cur, const float *d_disparities, int width, int height, int stride_in,
+                              int stride_out, int factor, float *d_point_cloud4) {
+  return c.check(svs_pointcloud_full(c.get(), TQ_actkey_from_cur.data_colmajor, d_disparities, width, height, stride_in, stride_out, factor, d_point_cloud4)) &&
+         svs_ctx_sync(c.get()) == SVS_OK;
+}
+class GpuTracker {
+ public:
+  GpuTracker(const Context &c, int /*width*/, int /*height*/) : ctx_(c), d_sums_(c, 1), cur_(nullptr), dx_(nullptr), dy_(nullptr) {}
+  void bindTexture(const float *d_img_cur, const float *d_dx_img_cur, const float *d_dy_img_cur, int, int, int) { cur_ = d_img_cur; dx_ = d_dx_img_cur; dy_ = d_dy_img_cur; }
+  bool jacobianReduction(const float *d_img_prev, const float *d_point_cloud_prev4, const GpuMatrix34 &T_cur_from_prev, const GpuIntrinsics &K, int width, int height,
+                         int stride_float_img, int stride_float4_img, GpuTrackingData *tracking_result) {
+    svs_dense_sums s;
+    if (!pass(d_img_prev, d_point_cloud_prev4, T_cur_from_prev, K, width, height, stride_float_img, stride_float4_img, 1, &s)) return false;
+    for (int i = 0; i < 21; ++i) tracking_result->hessian[i] = s.H[i];
+    for (int i = 0; i < 6; ++i) tracking_result->jacobian_times_res[i] = s.b[i];
+    return true;
+  }
+  float chi2(const float *d_img_prev, const float *d_point_cloud_prev4, const GpuMatrix34 &T_cur_from_prev, const GpuIntrinsics &K, int width, int height,
+             int stride_float_img, int stride_float4_img) {
+    svs_dense_sums s;
+    return pass(d_img_prev, d_point_cloud_prev4, T_cur_from_prev, K, width, height, stride_float_img, stride_float4_img, 0, &s) ? (float)s.chi2 : -1.f;
+  }
+  bool residualImage(const float *d_img_prev, const float *d_point_cloud_prev4, const GpuMatrix34 &T, const GpuIntrinsics &K, int width, int height,
+                     int stride_float_img, int stride_float4_img, float *d_res_img4) {
+    return ctx_.check(svs_dense_residual_image_full(ctx_.get(), d_point_cloud_prev4, width, height, stride_float4_img, d_img_prev, cur_, stride_float_img,
+                                                    K.focal_length, K.pp_x, K.pp_y, T.data_colmajor, d_res_img4)) && svs_ctx_sync(ctx_.get()) == SVS_OK;
+  }
+
+ private:
+  bool pass(const float *prev, const float *cloud4, const GpuMatrix34 &T, const GpuIntrinsics &K, int w, int h, int sf, int s4, int jac, svs_dense_sums *out) {
+    return ctx_.check(svs_dense_pass_full(ctx_.get(), cloud4, w, h, s4, prev, cur_, dx_, dy_, sf, K.focal_length, K.pp_x, K.pp_y, T.data_colmajor, jac, d_sums_.get())) &&
+           d_sums_.download(out, 1);
+  }
+  const Context &ctx_;
+  DeviceBuffer<svs_dense_sums> d_sums_;
+  const float *cur_, *dx_, *dy_;
+};
+
+// DenseTracker of the CUDA build: denseTrackingGpu(SE3*) as ONE launch (dense_tracking.cpp:60-193).  The caller hands over the device images of
+// FrameData (gpu_pyr_float32 / _dx / _dy of the current frame, gpu_pyr_float32 of the previous one) and dev_ref_dense_points_.
+class DenseTrackerGpu {
+ public:
+  explicit DenseTrackerGpu(const Context &c) : ctx_(c), d_T_(c, 12), d_passes_(c, 1) {}
+  struct Levels {                          // per pyramid level, device pointers; strides in elements (float / float4)
+    const float *cloud4[SVS_NUM_PYR_LEVELS], *prev[SVS_NUM_PYR_LEVELS], *cur[SVS_NUM_PYR_LEVELS], *dx[SVS_NUM_PYR_LEVELS], *dy[SVS_NUM_PYR_LEVELS];
+    int stride_f4[SVS_NUM_PYR_LEVELS], stride_f[SVS_NUM_PYR_LEVELS];
+    svs_cam cam_vec[SVS_NUM_PYR_LEVELS];
+  };
+  // void denseTrackingGpu(SE3 * T_cur_from_actkey): in/out pose.  passes (optional): fused sweeps executed
+  bool denseTrackingGpu(const Levels &L, double T_cur_from_actkey[12], int *passes = nullptr) {
+    svs_dense_track_full_args a;
+    std::memset(&a, 0, sizeof a);
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l) {
+      a.d_cloud4[l] = L.cloud4[l]; a.stride_f4[l] = L.stride_f4[l]; a.d_prev[l] = L.prev[l]; a.d_cur[l] = L.cur[l]; a.d_dx[l] = L.dx[l]; a.d_dy[l] = L.dy[l];
+      a.stride_f[l] = L.stride_f[l]; a.w[l] = L.cam_vec[l].w; a.h[l] = L.cam_vec[l].h; a.f[l] = L.cam_vec[l].f; a.cx[l] = L.cam_vec[l].cx; a.cy[l] = L.cam_vec[l].cy;
+    }
+    if (!d_T_.upload(T_cur_from_actkey, 12)) return false;
+    if (!ctx_.check(svs_dense_track_full(ctx_.get(), &a, d_T_.get(), d_passes_.get(), 1))) return false;
+    int32_t p = 0;
+    if (!d_passes_.download(&p, 1) || p < 0) return false;
+    if (passes) *passes = p;
+    return d_T_.download(T_cur_from_actkey, 12);
+  }
+
+ private:
+  const Context &ctx_;
+  DeviceBuffer<double> d_T_;
+  DeviceBuffer<int32_t> d_passes_;
+};
+
+// StereoFrontend::processFrame(bool*) / processFirstFrame() (stereo_frontend.h:88-95): the data-parallel part of a frame in ONE blocking call with
+// host buffers in and out; the caller keeps the reference's bookkeeping (keyframe switch / drop, list building) and uses the returned records.
+class StereoFrontend {
+ public:
+  StereoFrontend(const Context &c, const svs_cam &cam, const svs_frontend_params &prm, int max_points, int max_keyframes) : ctx_(c), fe_(nullptr) {
+    ok_ = c.check(svs_frontend_create(c.get(), &cam, &prm, max_points, max_keyframes, &fe_));
+  }
+  ~StereoFrontend() { if (fe_) svs_frontend_destroy(fe_); }
+  StereoFrontend(const StereoFrontend &) = delete;
+  StereoFrontend &operator=(const StereoFrontend &) = delete;
+  static svs_frontend_params referenceParams(bool block_matching) {
+    svs_frontend_params p;
+    std::memset(&p, 0, sizeof p);
+    p.fast_trials = 6; p.search_radius = 8; p.thr_mean = 22; p.thr_std = 10; p.max_reproj_error = 2.f; p.use_block_matching = block_matching ? 1 : 0;
+    p.pose_opt.robust_kernel = 1; p.pose_opt.num_iter = 15; p.pose_opt.kernel_param = 2.0; p.pose_opt.initial_mu = -1.0; p.pose_opt.tau = 1e-5;
+    const svs_stereo_params sp = {31, 7, 0, 32, 10, 15, 100, 32, 1};
+    p.stereo = sp;
+    return p;
+  }
+  bool ok() const { return ok_; }
+  bool processFirstFrame(Image8 left, const Image8 *right, const ImageF *disp) {
+    return ctx_.check(svs_frontend_first_frame(fe_, left.data, left.stride, right ? right->data : nullptr, right ? right->stride : 0, disp ? disp->data : nullptr,
+                                               disp ? disp->stride : 0));
+  }
+  bool keepKeyframe(int slot, const double T_kf_from_w[12]) { return ctx_.check(svs_frontend_keep_keyframe(fe_, slot, T_kf_from_w)); }
+  bool setCandidates(const std::vector<svs_candidate_point> &ap_map, int n_new_records) {
+    n_ = (int)ap_map.size();
+    return ctx_.check(svs_frontend_set_candidates(fe_, ap_map.data(), n_, n_new_records));
+  }
+  // returns what matchAndTrack returns (enough features matched); *T_cur_from_actkey is in/out like the reference's member
+  bool processFrame(Image8 left, const Image8 *right, const ImageF *disp, double T_cur_from_actkey[12], const double T_actkey_from_w[12], svs_frame_result *res,
+                    std::vector<svs_match_result> *matches, std::vector<svs_gated_point> *gated) {
+    matches->resize((size_t)n_); gated->resize((size_t)n_);
+    if (!ctx_.check(svs_frontend_process_frame(fe_, left.data, left.stride, right ? right->data : nullptr, right ? right->stride : 0, disp ? disp->data : nullptr,
+                                               disp ? disp->stride : 0, T_cur_from_actkey, T_actkey_from_w, res, matches->data(), gated->data())))
+      return false;
+    for (int i = 0; i < 12; ++i) T_cur_from_actkey[i] = res->T_cur_from_actkey[i];
+    return res->tracking_ok != 0;
+  }
+  bool recomputeDensePointCloud(const double T_cur_from_actkey[12]) { return ctx_.check(svs_frontend_recompute_cloud(fe_, T_cur_from_actkey)); }
+
+ private:
+  const Context &ctx_;
+  svs_frontend *fe_;
+  bool ok_;
+  int n_ = 0;
+};
+
+// One rank of a landmark-sharded back-end: rank 0 calls uniqueId() and distributes it (MPI_Bcast, a TCP store, a file); every rank then constructs
+// the communicator and attaches it to its SlamGraphBA with attach().  svs_ba_optimize all-reduces over RCCL on the context's stream.
+class Communicator {
+ public:
+  static bool uniqueId(const Context &c, svs_unique_id *id) { return c.check(svs_comm_get_unique_id(c.get(), id)); }
+  Communicator(const Context &c, const svs_unique_id &id, int rank, int world) : comm_(nullptr) { ok_ = c.check(svs_comm_create(c.get(), &id, rank, world, &comm_)); }
+  ~Communicator() { if (comm_) svs_comm_destroy(comm_); }
+  Communicator(const Communicator &) = delete;
+  Communicator &operator=(const Communicator &) = delete;
+  bool ok() const { return ok_; }
+  svs_comm *get() const { return comm_; }
+
+ private:
+  svs_comm *comm_;
+  bool ok_;
+};
+
 // SlamGraph::optimize(const OptParams&) (slam_graph.hpp:457-462): the caller marshals the double
 // window exactly as copyDataToG2o does (slam_graph.cpp:983-1032) into flat arrays.
 struct OptParams {                       // slam_graph.hpp:36-50
@@ -387,6 +532,9 @@ class SlamGraphBA {
     if (!ctx_.check(svs_ba_optimize(ba_, nullptr, nullptr, stats))) return false;
     return ctx_.check(svs_ba_get_state(ba_, poses->data(), psi->data()));
   }
+  // landmark-sharded operation: this rank passes only ITS landmarks' edges to optimize() (pose terms on exactly one rank: add_pose_terms)
+  bool attach(const Communicator *comm) { return ctx_.check(svs_ba_set_comm(ba_, comm ? comm->get() : nullptr)); }
+  svs_ba *get() const { return ba_; }
 
  private:
   const Context &ctx_;

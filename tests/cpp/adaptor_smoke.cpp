@@ -104,5 +104,32 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < gated.size(); ++i) { n_acc += gated[i].accepted; n_new += gated[i].is_new; }
     std::printf("GATE %d %d %d %d %.17g\n", pst.num_obs, pst.num_track_points, n_acc, n_new, pst.sum_track_length);
   }
+  // ---- StereoFrontend::processFirstFrame / processFrame (one call per frame) and DenseTrackerGpu::denseTrackingGpu: the image shifted by
+  //      two pixels plays the next frame, constant disparity 8 ---------------------------------------------------------------------------
+  {
+    std::vector<uint8_t> next(img.size());
+    for (int y = 0; y < wh[1]; ++y) for (int x = 0; x < wh[0]; ++x) next[(size_t)y * wh[0] + x] = img[(size_t)y * wh[0] + (x + 2 < wh[0] ? x + 2 : wh[0] - 1)];
+    std::vector<float> disp((size_t)wh[0] * wh[1], 8.f);
+    svs_frontend_params prm = StereoFrontend::referenceParams(false);
+    svs_cam fcam = cam;                 // the BA window's intrinsics with this image's size
+    fcam.w = wh[0]; fcam.h = wh[1];
+    StereoFrontend fe(ctx, fcam, prm, 64, 2);
+    if (!fe.ok()) return 12;
+    Image8 v0 = {img.data(), wh[0], wh[1], wh[0]}, v1 = {next.data(), wh[0], wh[1], wh[0]};
+    ImageF dv = {disp.data(), wh[0], wh[1], wh[0]};
+    const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if (!fe.processFirstFrame(v0, nullptr, &dv) || !fe.keepKeyframe(0, I)) return 12;
+    std::vector<svs_candidate_point> none;
+    if (!fe.setCandidates(none, 0)) return 12;
+    double T[12];
+    for (int i = 0; i < 12; ++i) T[i] = I[i];
+    svs_frame_result res;
+    std::vector<svs_match_result> matches;
+    std::vector<svs_gated_point> gated;
+    fe.processFrame(v1, nullptr, &dv, T, I, &res, &matches, &gated);        // no candidates: returns false (fewer than 20 matches), the pose is tracked
+    std::printf("FRAME %d %d", res.dense_passes, res.n_matched);
+    for (int i = 0; i < 12; ++i) std::printf(" %.17g", res.T_cur_from_actkey[i]);
+    std::printf("\n");
+  }
   return 0;
 }
