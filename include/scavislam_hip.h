@@ -413,6 +413,21 @@ int svs_ba_destroy(svs_ba *ba);
 int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const double *h_psi,
                        int E, const svs_ba_edge *h_edges, int C, const svs_ba_constraint *h_cons,
                        const svs_cam *cam, const svs_ba_params *prm, int add_pose_terms);
+/* Persistent window -- the alternative to svs_ba_set_problem for a caller whose window evolves by about one
+   keyframe per optimize(): the library keeps every observation it has been given on the device; a call brings the window's definition
+   by the graph's own ids (frame ids and point ids come from one counter in the reference, stereo_frontend.cpp:826-831), the current
+   values, the observations made SINCE THE LAST CALL and the window's pose-pose constraints.
+     h_pose_ids [P] / h_poses [P][12]      the double window in block-row order (copyPosesToG2o, slam_graph.cpp:924-935)
+     h_point_ids [L] / h_psi [L][3] / h_anchor_pose_ids [L]   the active points (addPointToG2o :907-922), anchor by frame id
+     h_new_obs [n_new]                     svs_ba_edge records whose .point / .pose hold IDS (.anchor ignored): addObsToG2o's arguments
+     h_cons [C]                            constraints whose .pose1 / .pose2 hold frame IDS (copyContraintsToG2o :937-981)
+   The window's edges = all stored observations whose point is active, whose keyframe is in the window and whose point's anchor is in
+   the window (exactly the filter of slam_graph.cpp:1001-1006).  State comes back through svs_ba_get_state in the order given here.
+   svs_ba_window_reset forgets the stored observations. */
+int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids, const double *h_poses, int L, const int32_t *h_point_ids,
+                         const double *h_psi, const int32_t *h_anchor_pose_ids, int n_new, const svs_ba_edge *h_new_obs, int C,
+                         const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm);
+int svs_ba_window_reset(svs_ba *ba);
 /* optimizer.optimize(num_iters) (slam_graph.cpp:346) incl. LM control flow; allreduce may be
    NULL (single GPU) */
 int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats);

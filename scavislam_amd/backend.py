@@ -119,6 +119,26 @@ class SlamGraphOptimizer:
             self.h, self.P, poses.ctypes.data, self.L, psi.ctypes.data, len(edges), edges.ctypes.data, len(cons),
             cons.ctypes.data, C.byref(camc), C.byref(self.prm), int(add_pose_terms)))
 
+    def windowUpdate(self, pose_ids, poses, point_ids, psi, anchor_pose_ids, new_obs, cons, cam, prm=None):
+        """svs_ba_window_update: the persistent-window form of copyDataToG2o -- ids define the window, only the observations made since
+        the last call are handed over (new_obs: BA_EDGE_DTYPE with ids in point / pose; cons: BA_CONSTRAINT_DTYPE with frame ids)."""
+        pose_ids = np.ascontiguousarray(pose_ids, np.int32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        point_ids = np.ascontiguousarray(point_ids, np.int32)
+        psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)
+        anchor_pose_ids = np.ascontiguousarray(anchor_pose_ids, np.int32)
+        new_obs = np.ascontiguousarray(new_obs, BA_EDGE_DTYPE)
+        cons = np.ascontiguousarray(cons if cons is not None else np.zeros(0, BA_CONSTRAINT_DTYPE), BA_CONSTRAINT_DTYPE)
+        self.P, self.L = len(poses), len(psi)
+        self.prm = prm or BaParams.reference_defaults()
+        camc = cam if isinstance(cam, Cam) else Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        self.ctx.check(self.ctx.lib.svs_ba_window_update(
+            self.h, self.P, pose_ids.ctypes.data, poses.ctypes.data, self.L, point_ids.ctypes.data, psi.ctypes.data, anchor_pose_ids.ctypes.data,
+            len(new_obs), new_obs.ctypes.data, len(cons), cons.ctypes.data, C.byref(camc), C.byref(self.prm)))
+
+    def windowReset(self):
+        self.ctx.check(self.ctx.lib.svs_ba_window_reset(self.h))
+
     def reset_state(self, poses, psi):
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
         psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)

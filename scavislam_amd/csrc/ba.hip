@@ -18,6 +18,7 @@
 //    36*P(P+1)/2 + 12P + 1 doubles) and two scalars per LM trial; the 6P x 6P Cholesky is
 //    replicated (deterministic, no broadcast).
 #include "common.h"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -2162,7 +2163,13 @@ struct svs_ba {
   svs_ctx *ctx = nullptr;
   BaOptions opt;
   svs_comm *comm = nullptr;             // library-owned collective of sharded runs (svs_ba_set_comm)
-  bool problem_valid = false;           // set by a COMPLETED svs_ba_set_problem; every other entry point requires it
+  bool problem_valid = false;           // set by a COMPLETED svs_ba_set_problem / svs_ba_window_update; every other entry point requires it
+  // ---- persistent window (svs_ba_window_*): every observation handed over since the last reset stays on the device ----
+  svs_ba_edge *w_store = nullptr; size_t w_n = 0, w_cap = 0;           // observation store, ids in .point / .pose, arrival order
+  int *w_pose_tab = nullptr, *w_point_tab = nullptr; size_t w_pose_tab_n = 0, w_point_tab_n = 0;      // id -> window index (-1: not in the window)
+  void *w_work = nullptr; size_t w_work_bytes = 0;                      // per-call work arrays (grow-only)
+  void *w_sort_tmp = nullptr; size_t w_sort_tmp_bytes = 0;
+  unsigned char *w_hback = nullptr; size_t w_hback_bytes = 0;           // pinned read-back (counters, landmark lengths, pattern)
   int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, n_wide = 0, add_pose_terms = 1;
   svs_cam cam{};
   svs_ba_params prm{};
@@ -2291,6 +2298,12 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->d_xfer) (void)hipFree(ba->d_xfer);
   if (ba->d_flags) (void)hipFree(ba->d_flags);
   if (ba->d_gridbar) (void)hipFree(ba->d_gridbar);
+  if (ba->w_store) (void)hipFree(ba->w_store);
+  if (ba->w_pose_tab) (void)hipFree(ba->w_pose_tab);
+  if (ba->w_point_tab) (void)hipFree(ba->w_point_tab);
+  if (ba->w_work) (void)hipFree(ba->w_work);
+  if (ba->w_sort_tmp) (void)hipFree(ba->w_sort_tmp);
+  if (ba->w_hback) (void)hipHostFree(ba->w_hback);
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
   ba->free_all();
@@ -2559,6 +2572,309 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     fprintf(stderr, "[svs_ba] set_problem: validate+count %.0f us, landmark order %.0f us, slots+sort+pattern %.0f us, gather+upload+chunks %.0f us, enqueue copies %.0f us, wait %.0f us\n",
             us(t_0, t_1), us(t_1, t_2), us(t_2, t_3), us(t_3, t_4), us(t_4, t_5), us(t_5, now()));
+  }
+  ba->problem_valid = true;
+  return SVS_OK;
+}
+
+// ---- persistent window ----------------------------------------------------------------------------
+// The reference rebuilds a whole optimizer from its graph for every optimize() (slam_graph.cpp:324, copyDataToG2o :983-1032), and
+// svs_ba_set_problem mirrors that: all edge records cross PCIe and are re-ordered on every call although the window changes by about
+// one keyframe.  Here the library KEEPS every observation it has been given (device-resident, 64 B each, ids of point and keyframe as
+// the reference's graph names them) and a call only brings what is new: the window's poses and point values (they are the caller's
+// state), the ids that define the window, the observations made since the last call, and the few hundred pose-pose constraints.
+// The edge list of the window is then assembled ON THE DEVICE:
+//   id -> window-index tables (direct addressed)  ->  filter the store (observation is in the window iff its point and its keyframe
+//   are)  ->  64-bit keys (wide | anchor | point | pose)  ->  radix sort (rocPRIM through hipCUB: a plain library sort)  ->  gather
+//   into slot order  ->  landmark segments (scan)  ->  co-visibility pattern;
+// one small read-back (landmark lengths + pattern) lets the host pack landmarks into wave chunks and build the block envelope exactly
+// as svs_ba_set_problem does.  Host work per call is O(points + new observations), PCIe traffic likewise.
+namespace {
+struct WinCounters { int n_edges, n_lm, dup, pad; };
+__global__ void win_scatter_kernel(const int *__restrict__ ids, int n, int *__restrict__ tab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tab[ids[i]] = i;
+}
+__global__ void win_anchor_kernel(const int *__restrict__ anchor_ids, int n, const int *__restrict__ pose_tab, int *__restrict__ anchor_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) anchor_idx[i] = pose_tab[anchor_ids[i]];
+}
+__global__ void win_filter_kernel(const svs_ba_edge *__restrict__ store, size_t n, const int *__restrict__ pose_tab, size_t pose_tab_n,
+                                  const int *__restrict__ point_tab, size_t point_tab_n, const int *__restrict__ anchor_idx,
+                                  svs_ba_edge *__restrict__ tmp, int *__restrict__ count, WinCounters *__restrict__ ctr) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  svs_ba_edge e = store[r];
+  if ((size_t)e.point >= point_tab_n || (size_t)e.pose >= pose_tab_n) return;
+  const int li = point_tab[e.point], pi = pose_tab[e.pose];
+  if (li < 0 || pi < 0) return;
+  const int ai = anchor_idx[li];
+  if (ai < 0) return;
+  e.point = li; e.pose = pi; e.anchor = ai;
+  const int slot = atomicAdd(&ctr->n_edges, 1);
+  tmp[slot] = e;
+  atomicAdd(&count[li], 1);
+}
+__global__ void win_keys_kernel(const svs_ba_edge *__restrict__ tmp, const WinCounters *__restrict__ ctr, const int *__restrict__ count,
+                                unsigned long long *__restrict__ keys, int *__restrict__ vals, int cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  if (i >= ctr->n_edges) { keys[i] = ~0ull; vals[i] = 0; return; }      // padding sorts to the end
+  const svs_ba_edge &e = tmp[i];
+  const unsigned long long wide = count[e.point] > 64 ? 1ull : 0ull;
+  keys[i] = (wide << 41) | ((unsigned long long)e.anchor << 32) | ((unsigned long long)e.point << 9) | (unsigned long long)e.pose;
+  vals[i] = i;
+}
+__global__ void win_gather_kernel(const svs_ba_edge *__restrict__ tmp, const int *__restrict__ order, const unsigned long long *__restrict__ keys,
+                                  WinCounters *__restrict__ ctr, svs_ba_edge *__restrict__ edges, int *__restrict__ head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ctr->n_edges) return;
+  edges[i] = tmp[order[i]];
+  const bool h = i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9);
+  head[i] = h ? 1 : 0;
+  if (i > 0 && keys[i] == keys[i - 1]) ctr->dup = 1;                    // two observations of one point in one keyframe
+}
+__global__ void win_segments_kernel(const int *__restrict__ head, const int *__restrict__ rank, WinCounters *__restrict__ ctr, int *__restrict__ lm_start) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = ctr->n_edges;
+  if (i >= n) return;
+  if (head[i]) lm_start[rank[i]] = i;
+  if (i == n - 1) { const int n_lm = rank[i] + head[i]; ctr->n_lm = n_lm; lm_start[n_lm] = n; }      // rank = heads BEFORE i
+}
+__global__ void win_pattern_kernel(const svs_ba_edge *__restrict__ edges, const int *__restrict__ lm_start, const WinCounters *__restrict__ ctr, int P,
+                                   unsigned char *__restrict__ pat, int *__restrict__ lm_len) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ctr->n_lm) return;
+  const int a = lm_start[k], b = lm_start[k + 1];
+  lm_len[k] = b - a;
+  const int anc = edges[a].anchor, p_first = edges[a].pose, p_last = edges[b - 1].pose;
+  const int lo = min(p_first, anc), hi = max(p_last, anc);
+  for (int e = a; e < b; ++e) { const int p = edges[e].pose; pat[(size_t)p * P + hi] = 1; pat[(size_t)lo * P + p] = 1; }
+  pat[(size_t)anc * P + hi] = 1; pat[(size_t)lo * P + hi] = 1; pat[(size_t)lo * P + anc] = 1;
+}
+}  // namespace
+
+extern "C" int svs_ba_window_reset(svs_ba *ba) {
+  if (!ba) return SVS_ERR_INVALID;
+  ba->w_n = 0;
+  ba->problem_valid = false;
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids, const double *h_poses, int L, const int32_t *h_point_ids,
+                                    const double *h_psi, const int32_t *h_anchor_pose_ids, int n_new, const svs_ba_edge *h_new_obs, int C,
+                                    const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && h_pose_ids && h_poses && (L == 0 || (h_point_ids && h_psi && h_anchor_pose_ids)) && (n_new == 0 || h_new_obs) && (C == 0 || h_cons) && cam && prm);
+  SVS_REQUIRE(ctx, P >= 1 && L >= 0 && n_new >= 0 && C >= 0);
+  SVS_REQUIRE(ctx, !ba->comm);                        // single-GPU path (a sharded window goes through svs_ba_set_problem)
+  SVS_DEVICE(ctx);
+  ba->problem_valid = false;
+  if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
+  auto t_0 = std::chrono::steady_clock::now();
+  // ---- host: ranges of the ids, constraints by index -------------------------------------------------------------------------
+  int max_pose_id = -1, max_point_id = -1;
+  for (int i = 0; i < P; ++i) { SVS_REQUIRE(ctx, h_pose_ids[i] >= 0); max_pose_id = std::max(max_pose_id, h_pose_ids[i]); }
+  for (int i = 0; i < L; ++i) { SVS_REQUIRE(ctx, h_point_ids[i] >= 0 && h_anchor_pose_ids[i] >= 0); max_point_id = std::max(max_point_id, h_point_ids[i]); max_pose_id = std::max(max_pose_id, h_anchor_pose_ids[i]); }
+  for (int i = 0; i < n_new; ++i) {
+    SVS_REQUIRE(ctx, h_new_obs[i].point >= 0 && h_new_obs[i].pose >= 0);
+    max_point_id = std::max(max_point_id, h_new_obs[i].point); max_pose_id = std::max(max_pose_id, h_new_obs[i].pose);
+  }
+  SVS_REQUIRE(ctx, L < (1 << 23));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ba->h_stage_used = 0;
+  { int rc = stage_reserve(ba, sizeof(double) * (12 * (size_t)P + 3 * (size_t)L) + sizeof(int) * (4 * (size_t)P + 2 * (size_t)L) + sizeof(svs_ba_constraint) * (size_t)C +
+                                  sizeof(svs_ba_edge) * (size_t)n_new + sizeof(int) * (((size_t)ba->w_n + n_new) / 8 + 8 * (size_t)P) + 16384);
+    if (rc) return rc; }
+  auto grow = [&](void **ptr, size_t *cap, size_t bytes, bool keep, size_t keep_bytes) -> int {
+    if (bytes <= *cap && *ptr) return SVS_OK;
+    void *np = nullptr;
+    const size_t want = bytes + bytes / 2 + 4096;
+    SVS_HIP(ctx, hipMalloc(&np, want));
+    if (keep && *ptr && keep_bytes) SVS_HIP(ctx, hipMemcpy(np, *ptr, keep_bytes, hipMemcpyDeviceToDevice));
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = np; *cap = want;
+    return SVS_OK;
+  };
+  // ---- the store: append the new observations --------------------------------------------------------------------------------
+  {
+    size_t cap_b = ba->w_cap * sizeof(svs_ba_edge);
+    int rc = grow((void **)&ba->w_store, &cap_b, (ba->w_n + (size_t)n_new) * sizeof(svs_ba_edge), true, ba->w_n * sizeof(svs_ba_edge));
+    if (rc) return rc;
+    ba->w_cap = cap_b / sizeof(svs_ba_edge);
+    if (n_new) { rc = stage_upload(ba, ba->w_store + ba->w_n, h_new_obs, sizeof(svs_ba_edge) * (size_t)n_new); if (rc) return rc; }
+    ba->w_n += (size_t)n_new;
+  }
+  const size_t N = ba->w_n;
+  // ---- id tables ---------------------------------------------------------------------------------------------------------------
+  {
+    size_t cb = ba->w_pose_tab_n * sizeof(int);
+    int rc = grow((void **)&ba->w_pose_tab, &cb, ((size_t)max_pose_id + 1) * sizeof(int), false, 0); if (rc) return rc;
+    ba->w_pose_tab_n = cb / sizeof(int);
+    cb = ba->w_point_tab_n * sizeof(int);
+    rc = grow((void **)&ba->w_point_tab, &cb, ((size_t)max_point_id + 2) * sizeof(int), false, 0); if (rc) return rc;
+    ba->w_point_tab_n = cb / sizeof(int);
+  }
+  // ---- work arrays (one allocation): ids | anchor_idx | count | tmp edges | keys x2 | vals x2 | head | rank | lm_start | lm_len | pattern | counters
+  const size_t capE = N + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_pids = take(sizeof(int) * P), o_lids = take(sizeof(int) * (size_t)std::max(L, 1)), o_aids = take(sizeof(int) * (size_t)std::max(L, 1)),
+               o_aidx = take(sizeof(int) * (size_t)std::max(L, 1)), o_count = take(sizeof(int) * (size_t)std::max(L, 1)), o_tmp = take(sizeof(svs_ba_edge) * capE),
+               o_k0 = take(8 * capE), o_k1 = take(8 * capE), o_v0 = take(4 * capE), o_v1 = take(4 * capE), o_head = take(4 * capE), o_rank = take(4 * capE),
+               o_lms = take(4 * ((size_t)L + 2)), o_lml = take(4 * ((size_t)L + 2)), o_pat = take((size_t)P * P), o_ctr = take(sizeof(WinCounters));
+  { int rc = grow(&ba->w_work, &ba->w_work_bytes, off, false, 0); if (rc) return rc; }
+  char *W = static_cast<char *>(ba->w_work);
+  int *d_pids = (int *)(W + o_pids), *d_lids = (int *)(W + o_lids), *d_aids = (int *)(W + o_aids), *d_aidx = (int *)(W + o_aidx), *d_count = (int *)(W + o_count);
+  svs_ba_edge *d_tmp = (svs_ba_edge *)(W + o_tmp);
+  unsigned long long *d_k0 = (unsigned long long *)(W + o_k0), *d_k1 = (unsigned long long *)(W + o_k1);
+  int *d_v0 = (int *)(W + o_v0), *d_v1 = (int *)(W + o_v1), *d_head = (int *)(W + o_head), *d_rank = (int *)(W + o_rank), *d_lms = (int *)(W + o_lms),
+      *d_lml = (int *)(W + o_lml);
+  unsigned char *d_pat = (unsigned char *)(W + o_pat);
+  WinCounters *d_ctr = (WinCounters *)(W + o_ctr);
+  // device buffers of the optimizer proper (grow-only, as in svs_ba_set_problem)
+  auto ensure = [&](void **ptr, size_t *cap, size_t bytes) -> hipError_t {
+    if (bytes <= *cap && *ptr) return hipSuccess;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(ptr, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+  };
+  SVS_HIP(ctx, ensure((void **)&ba->d_edges, &ba->cap_edges, sizeof(svs_ba_edge) * capE));
+  for (int k = 0; k < 2; ++k) {
+    SVS_HIP(ctx, ensure((void **)&ba->d_poses[k], &ba->cap_poses[k], sizeof(double) * 12 * (size_t)P));
+    SVS_HIP(ctx, ensure((void **)&ba->d_psi[k], &ba->cap_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
+  }
+  // ---- enqueue ---------------------------------------------------------------------------------------------------------------
+  const int TB = 256;
+  int rc = stage_upload(ba, d_pids, h_pose_ids, sizeof(int) * (size_t)P); if (rc) return rc;
+  if (L) {
+    if ((rc = stage_upload(ba, d_lids, h_point_ids, sizeof(int) * (size_t)L))) return rc;
+    if ((rc = stage_upload(ba, d_aids, h_anchor_pose_ids, sizeof(int) * (size_t)L))) return rc;
+  }
+  if ((rc = stage_upload(ba, ba->d_poses[0], h_poses, sizeof(double) * 12 * (size_t)P))) return rc;
+  SVS_HIP(ctx, hipMemcpyAsync(ba->d_poses[1], ba->d_poses[0], sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToDevice, ctx->stream));
+  if (L) {
+    if ((rc = stage_upload(ba, ba->d_psi[0], h_psi, sizeof(double) * 3 * (size_t)L))) return rc;
+    SVS_HIP(ctx, hipMemcpyAsync(ba->d_psi[1], ba->d_psi[0], sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  SVS_HIP(ctx, hipMemsetAsync(ba->w_pose_tab, 0xff, ba->w_pose_tab_n * sizeof(int), ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(ba->w_point_tab, 0xff, ba->w_point_tab_n * sizeof(int), ctx->stream));
+  SVS_HIP(ctx, hipMemsetAsync(W + o_count, 0, (o_tmp - o_count), ctx->stream));                     // count
+  SVS_HIP(ctx, hipMemsetAsync(W + o_pat, 0, (o_ctr - o_pat) + sizeof(WinCounters), ctx->stream));   // pattern + counters
+  hipLaunchKernelGGL(win_scatter_kernel, dim3(div_up(P, TB)), dim3(TB), 0, ctx->stream, d_pids, P, ba->w_pose_tab);
+  if (L) {
+    hipLaunchKernelGGL(win_scatter_kernel, dim3(div_up(L, TB)), dim3(TB), 0, ctx->stream, d_lids, L, ba->w_point_tab);
+    hipLaunchKernelGGL(win_anchor_kernel, dim3(div_up(L, TB)), dim3(TB), 0, ctx->stream, d_aids, L, ba->w_pose_tab, d_aidx);
+  }
+  SVS_LAUNCH_CHECK(ctx);
+  auto stage = [&](const char *what) { if (ba->opt.debug >= 2) { const hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[svs_ba] window stage %s: %s\n", what, hipGetErrorString(e)); } };
+  stage("tables");
+  if (N && L) {
+    hipLaunchKernelGGL(win_filter_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, ba->w_store, N, ba->w_pose_tab, ba->w_pose_tab_n,
+                       ba->w_point_tab, ba->w_point_tab_n, d_aidx, d_tmp, d_count, d_ctr);
+    stage("filter");
+    hipLaunchKernelGGL(win_keys_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_ctr, d_count, d_k0, d_v0, (int)N);
+    SVS_LAUNCH_CHECK(ctx);
+    stage("keys");
+    size_t tmp_bytes = 0;
+    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, 42, ctx->stream));
+    size_t scan_bytes = 0;
+    SVS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_head, d_rank, (int)N, ctx->stream));
+    { int rc2 = grow(&ba->w_sort_tmp, &ba->w_sort_tmp_bytes, std::max(tmp_bytes, scan_bytes), false, 0); if (rc2) return rc2; }
+    tmp_bytes = ba->w_sort_tmp_bytes;
+    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ba->w_sort_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, 42, ctx->stream));
+    stage("sort");
+    SVS_HIP(ctx, hipMemsetAsync(d_head, 0, 4 * capE, ctx->stream));
+    hipLaunchKernelGGL(win_gather_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_v1, d_k1, d_ctr, ba->d_edges, d_head);
+    SVS_LAUNCH_CHECK(ctx);
+    stage("gather");
+    scan_bytes = ba->w_sort_tmp_bytes;
+    SVS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ba->w_sort_tmp, scan_bytes, d_head, d_rank, (int)N, ctx->stream));
+    stage("scan");
+    hipLaunchKernelGGL(win_segments_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_head, d_rank, d_ctr, d_lms);
+    stage("segments");
+    if (ba->opt.debug >= 2) { WinCounters hc; (void)hipMemcpy(&hc, d_ctr, sizeof hc, hipMemcpyDeviceToHost); fprintf(stderr, "[svs_ba] window counters: n_edges %d n_lm %d dup %d (N %zu L %d P %d)\n", hc.n_edges, hc.n_lm, hc.dup, N, L, P); }
+    hipLaunchKernelGGL(win_pattern_kernel, dim3(div_up(std::max(L, 1), TB)), dim3(TB), 0, ctx->stream, ba->d_edges, d_lms, d_ctr, P, d_pat, d_lml);
+    SVS_LAUNCH_CHECK(ctx);
+  }
+  // ---- one read-back: counters, landmark lengths, pattern ----------------------------------------------------------------------------
+  const size_t back_bytes = sizeof(WinCounters) + 4 * ((size_t)L + 2) + (size_t)P * P + 64;
+  if (back_bytes > ba->w_hback_bytes) {
+    if (ba->w_hback) (void)hipHostFree(ba->w_hback);
+    ba->w_hback = nullptr; ba->w_hback_bytes = 0;
+    SVS_HIP(ctx, hipHostMalloc((void **)&ba->w_hback, back_bytes + back_bytes / 2, hipHostMallocDefault));
+    ba->w_hback_bytes = back_bytes + back_bytes / 2;
+  }
+  WinCounters *h_ctr = reinterpret_cast<WinCounters *>(ba->w_hback);
+  int *h_lml = reinterpret_cast<int *>(ba->w_hback + sizeof(WinCounters));
+  unsigned char *h_pat = ba->w_hback + sizeof(WinCounters) + 4 * ((size_t)L + 2);
+  SVS_HIP(ctx, hipMemcpyAsync(h_ctr, d_ctr, sizeof(WinCounters), hipMemcpyDeviceToHost, ctx->stream));
+  if (L) SVS_HIP(ctx, hipMemcpyAsync(h_lml, d_lml, 4 * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(h_pat, d_pat, (size_t)P * P, hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ba->h_stage_used = 0;                                 // everything staged so far has been consumed
+  auto t_1 = std::chrono::steady_clock::now();
+  if (h_ctr->dup) { ctx->err = "svs_ba_window_update: two observations of one point in one keyframe"; return SVS_ERR_INVALID; }
+  const int E = (N && L) ? h_ctr->n_edges : 0, n_lm = (N && L) ? h_ctr->n_lm : 0;
+  // ---- host: wave chunks, wide landmarks, constraints by index, pattern -> envelope -------------------------------------------------
+  std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
+  cs.clear(); cl.clear();
+  int n_reg = n_lm;
+  while (n_reg > 0 && h_lml[n_reg - 1] > 64) --n_reg;               // wide landmarks sort to the end (key bit 41)
+  {
+    int start = 0;
+    for (int k = 0; k < n_reg;) {
+      const int s0 = start;
+      int len = 0;
+      while (k < n_reg && len + h_lml[k] <= 64) { len += h_lml[k]; ++k; }
+      cs.push_back(s0); cl.push_back(len);
+      start += len;
+    }
+    ba->n_chunks = (int)cs.size();
+    ba->n_wide = n_lm - n_reg;
+    for (int k = n_reg; k < n_lm; ++k) {
+      if (h_lml[k] > WIDE_THREADS) { ctx->err = "svs_ba: a landmark with more than 256 observations"; return SVS_ERR_UNSUPPORTED; }
+      cs.push_back(start); cl.push_back(h_lml[k]); start += h_lml[k];
+    }
+  }
+  ba->h_pattern.assign((size_t)P * P, 0.0);
+  for (size_t i = 0; i < (size_t)P * P; ++i) if (h_pat[i]) ba->h_pattern[i] = 1.0;
+  std::vector<svs_ba_constraint> cons_idx((size_t)C);
+  for (int c = 0; c < C; ++c) {
+    cons_idx[c] = h_cons[c];
+    int i1 = -1, i2 = -1;
+    for (int i = 0; i < P; ++i) { if (h_pose_ids[i] == h_cons[c].pose1) i1 = i; if (h_pose_ids[i] == h_cons[c].pose2) i2 = i; }
+    SVS_REQUIRE(ctx, i1 >= 0 && i2 >= 0);                   // a constraint of this window names two window poses
+    cons_idx[c].pose1 = i1; cons_idx[c].pose2 = i2;
+    ba->h_pattern[(size_t)std::min(i1, i2) * P + std::max(i1, i2)] = 1.0;
+  }
+  ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = 1; ba->cur = 0;
+  ba->profile_ready = false; ba->env_R = 0; ba->use_lds_solve = ba->use_fused_solve = false;
+  const size_t nblk = (size_t)P * (P + 1) / 2;
+  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
+  SVS_HIP(ctx, ensure((void **)&ba->d_red, &ba->cap_red, sizeof(double) * ba->red_count));
+  SVS_HIP(ctx, ensure((void **)&ba->d_x, &ba->cap_x, sizeof(double) * 6 * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * 16));
+  SVS_HIP(ctx, ensure((void **)&ba->d_linv, &ba->cap_linv, sizeof(double) * 36 * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
+  SVS_HIP(ctx, ensure((void **)&ba->d_pattern, &ba->cap_pattern, sizeof(double) * (size_t)P * P));
+  if (!cs.empty()) {
+    if ((rc = stage_upload(ba, ba->d_chunk_start, cs.data(), sizeof(int) * cs.size()))) return rc;
+    if ((rc = stage_upload(ba, ba->d_chunk_len, cl.data(), sizeof(int) * cl.size()))) return rc;
+  }
+  if (C) { if ((rc = stage_upload(ba, ba->d_cons, cons_idx.data(), sizeof(svs_ba_constraint) * (size_t)C))) return rc; }
+  SVS_HIP(ctx, hipMemsetAsync(ba->d_x, 0, sizeof(double) * 6 * (size_t)P, ctx->stream));
+  if (ba->opt.debug) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[svs_ba] window_update: store %zu obs (+%d), window %d edges / %d landmarks / %d chunks / %d wide; enqueue + device pipeline + read-back %.0f us, host tail %.0f us\n",
+            N, n_new, E, n_lm, ba->n_chunks, ba->n_wide, us(t_0, t_1), us(t_1, std::chrono::steady_clock::now()));
   }
   ba->problem_valid = true;
   return SVS_OK;

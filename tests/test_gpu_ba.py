@@ -569,3 +569,71 @@ def test_optimize_batch_of_windows(gpu_ctx):
     assert saw_reject
     for c, _ in ctxs:
         c.close()
+
+
+def test_persistent_window_equals_rebuilt_window(gpu_ctx):
+    """svs_ba_window_update: a window of 30 keyframes slides over a 48-keyframe sequence, one keyframe per step.
+    Every step hands over ONLY the newest keyframe's observations (+ ids, current values, constraints); the edge list is assembled on
+    the device from the stored observations.  Each step's optimize must equal -- statistics exactly, state to 1e-9 of the update --
+    the optimize of the same window handed over completely through svs_ba_set_problem (copyDataToG2o's form)."""
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BA_CONSTRAINT_DTYPE, BaParams
+    ctx, stream = gpu_ctx
+    Pall, W = 48, 30
+    uni = synth.ba_window(Pall, 4000, seed=91, n_outer=0)
+    cam = _cam(uni["cam"])
+    prm = BaParams.reference_defaults()
+    pose_id = 1000 + 3 * np.arange(Pall)                          # the graph's own ids: sparse, not window indices
+    point_id = 5 + 7 * np.arange(len(uni["psi"]))
+    edges = uni["edges"]
+    anchor_of = np.full(len(uni["psi"]), -1)
+    anchor_of[edges["point"]] = edges["anchor"]
+    poses = uni["poses"].copy()
+    psi = uni["psi"].copy()
+    inc = SlamGraphOptimizer(ctx, stream)
+    full = SlamGraphOptimizer(ctx, stream)
+    gt = uni["poses_gt"].reshape(-1, 3, 4)
+    given = np.zeros(len(edges), bool)
+    for step, last in enumerate(range(W - 1, Pall)):
+        win = np.arange(last - W + 1, last + 1)                   # keyframes of the window, oldest first
+        in_win = np.zeros(Pall, bool); in_win[win] = True
+        e_ok = in_win[edges["pose"]] & in_win[edges["anchor"]]
+        active = np.unique(edges["point"][e_ok])                  # points seen from the window whose anchor is in it
+        new = e_ok & ~given if step else e_ok.copy()
+        if step == 0:                                             # hand over a few observations that are NOT (yet) in the window, too
+            new |= (edges["pose"] == last + 1)
+        else:
+            new = (edges["pose"] == last + 1) & ~given if last + 1 < Pall else np.zeros(len(edges), bool)
+            new |= e_ok & ~given
+        given |= new
+        new_obs = edges[new].copy()
+        new_obs["point"] = point_id[edges["point"][new]]
+        new_obs["pose"] = pose_id[edges["pose"][new]]
+        new_obs["anchor"] = -123                                   # ignored
+        # two relative-pose constraints between window poses (by frame id)
+        cons = np.zeros(2, BA_CONSTRAINT_DTYPE)
+        for k, (i, j) in enumerate(((win[0], win[1]), (win[2], win[4]))):
+            cons[k]["T_21"] = synth.pose_mul(gt[j], synth.pose_inv(gt[i])).reshape(12)
+            cons[k]["info"] = (np.eye(6) * 200.0).reshape(36)
+            cons[k]["pose1"], cons[k]["pose2"] = pose_id[i], pose_id[j]
+        inc.windowUpdate(pose_id[win], poses[win], point_id[active], psi[active], pose_id[anchor_of[active]], new_obs, cons, cam, prm)
+        st = inc.optimize()
+        p_inc, s_inc = inc.restoreDataFromG2o()
+        # the same window, complete, by index
+        remap_pose = np.full(Pall, -1); remap_pose[win] = np.arange(W)
+        remap_point = np.full(len(uni["psi"]), -1); remap_point[active] = np.arange(len(active))
+        ef = edges[e_ok].copy()
+        ef["point"], ef["pose"], ef["anchor"] = remap_point[edges["point"][e_ok]], remap_pose[edges["pose"][e_ok]], remap_pose[edges["anchor"][e_ok]]
+        cf = cons.copy()
+        cf["pose1"], cf["pose2"] = [remap_pose[(c["pose1"] - 1000) // 3] for c in cons], [remap_pose[(c["pose2"] - 1000) // 3] for c in cons]
+        full.copyDataToG2o(poses[win], psi[active], ef, cf, cam, prm)
+        st_f = full.optimize()
+        p_f, s_f = full.restoreDataFromG2o()
+        assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_f.iterations, st_f.trials, st_f.accepted, st_f.terminated), step
+        np.testing.assert_allclose(st.chi2_final, st_f.chi2_final, rtol=1e-9, err_msg=f"step {step}")
+        assert _rel_update_err(p_inc, p_f, poses[win]) < 1e-8 and _rel_update_err(s_inc, s_f, psi[active]) < 1e-8, step
+        assert inc.info()["wave_chunks"] >= 1
+        poses[win] = p_inc                                         # the graph takes the result (restoreDataFromG2o) and moves on
+        psi[active] = s_inc
+    inc.close(); full.close()
