@@ -558,16 +558,41 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
   }
 
   // ---- MODE 0: reduced camera system -------------------------------------------------------
-  // add v to element rc of upper block (pi <= pj) of the reduced system
-  auto add_blk = [&](int pi, int pj, int rc, double v) {
+  // A block (pi <= pj) of the reduced system lives either in the workgroup's LDS window or (out of window) in global memory.  The
+  // test is made ONCE per block and the six values of a block row are added under one branch: the per-element form of this
+  // (a divergent `if` around every one of the ~270 adds of a lane) cost as many scalar instructions as the kernel has vector ones
+  // (PMC: 2440 SALU vs 2490 VALU per wave, profiles/r2_notes.md).
+  // (destinations are kept as INDICES into s_win / B.H, not as pointers: a pointer that may point to either would be a flat pointer and
+  //  every add a flat atomic)
+  struct Dst { bool in_lds; int lds; long glb; };
+  auto blk_dst = [&](int pi, int pj) __attribute__((always_inline)) {
     const int wi = pi - pmin, wj = pj - pmin;
-    if (wj < WIN) lds_add_f64(&s_win[win_blk(wi, wj) * WBLK + rc], v);
-    else atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v);
+    Dst d;
+    d.in_lds = wj < WIN;
+    d.lds = d.in_lds ? win_blk(wi, wj) * WBLK : 0;
+    d.glb = d.in_lds ? 0 : blk_index(pi, pj, B.P) * 36;
+    return d;
   };
-  auto add_vec = [&](int which, int p, int r, double v) {     // which: 0 = b_p, 1 = b_s
+  // v[c] -> element (r, c) of the block (stride 1), or -- transposed store -- element (c, r) (stride 6)
+  auto add_row6 = [&](const Dst &d, int first, int stride, const double (&v)[6], int c0) __attribute__((always_inline)) {
+    if (d.in_lds) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) if (c >= c0) lds_add_f64(&s_win[d.lds + first + stride * c], v[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) if (c >= c0) atomic_add_f64(&B.H[d.glb + first + stride * c], v[c]);
+    }
+  };
+  auto add_vec6 = [&](int which, int p, const double (&v)[6]) __attribute__((always_inline)) {      // which: 0 = b_p, 1 = b_s
     const int wp = p - pmin;
-    if (wp < WIN) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + r], v);
-    else atomic_add_f64((which ? B.bs : B.bp) + 6 * p + r, v);
+    if (wp < WIN) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + c], v[c]);
+    } else {
+      double *g = (which ? B.bs : B.bp) + 6 * p;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) atomic_add_f64(g + c, v[c]);
+    }
   };
   // (1) anchor block, once per landmark: Ea^T S_RAR Ea - (W_A D^-1) W_A^T,  b_anc = Ea^T S_Rg,  Schur rhs W_A D^-1 b_l
   if (active && head) {
@@ -579,19 +604,22 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) WAD[3 * i + j] = WA[3 * i] * Di[j] + WA[3 * i + 1] * Di[3 + j] + WA[3 * i + 2] * Di[6 + j];
+    const Dst dst = blk_dst(anchor, anchor);
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r) {
+      double v[6];
 #pragma unroll
-      for (int c = r; c < 6; ++c)
-        add_blk(anchor, anchor, 6 * r + c, Maa[6 * r + c] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]));
+      for (int c = 0; c < 6; ++c) v[c] = c >= r ? Maa[6 * r + c] - (WAD[3 * r] * WA[3 * c] + WAD[3 * r + 1] * WA[3 * c + 1] + WAD[3 * r + 2] * WA[3 * c + 2]) : 0.0;
+      add_row6(dst, 6 * r, 1, v, r);
+    }
     double t0, t1, t2;
     cross3(lin.xa, red[24], red[25], red[26], t0, t1, t2);
     const double ba[6] = {red[24], red[25], red[26], t0, t1, t2};
+    double bsv[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      add_vec(0, anchor, r, ba[r]);
-      add_vec(1, anchor, r, WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2]);
-    }
+    for (int r = 0; r < 6; ++r) bsv[r] = WA[3 * r] * Db[0] + WA[3 * r + 1] * Db[1] + WA[3 * r + 2] * Db[2];
+    add_vec6(0, anchor, ba);
+    add_vec6(1, anchor, bsv);
   }
   SVS_STAMP(7);
   // (2) observer part: blocks (i,i), (i,A), b_i;  W_obs is parked in LDS for the pair phase
@@ -608,11 +636,14 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     {
       double Moo[36];
       sym_block(lin.A, lin.y, Moo);                           // M_oo = Eo^T A Eo
+      const Dst dst = blk_dst(pi, pi);
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+      for (int r = 0; r < 6; ++r) {
+        double v[6];
 #pragma unroll
-        for (int c = r; c < 6; ++c)
-          add_blk(pi, pi, 6 * r + c, Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]));
+        for (int c = 0; c < 6; ++c) v[c] = c >= r ? Moo[6 * r + c] - (WoD[3 * r] * Wo[3 * c] + WoD[3 * r + 1] * Wo[3 * c + 1] + WoD[3 * r + 2] * Wo[3 * c + 2]) : 0.0;
+        add_row6(dst, 6 * r, 1, v, r);
+      }
     }
     {
       double AR[9], Noa[36], WA[18];
@@ -623,22 +654,24 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
         for (int j = 0; j < 3; ++j) AR[3 * i + j] = lin.A[3 * i] * lin.R[j] + lin.A[3 * i + 1] * lin.R[3 + j] + lin.A[3 * i + 2] * lin.R[6 + j];
       cross_block(AR, lin.y, lin.xa, Noa);                    // M_oa = -Eo^T (A R) Ea
       const bool up = pi < anchor;
+      const Dst dst = blk_dst(up ? pi : anchor, up ? anchor : pi);
+      const int rs = up ? 6 : 1, cstr = up ? 1 : 6;           // element (r, c) of M goes to (r, c) of block (pi, anchor) or to (c, r) of block (anchor, pi)
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+      for (int r = 0; r < 6; ++r) {
+        double v[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double m = -Noa[6 * r + c] - (WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2]);
-          if (up) add_blk(pi, anchor, 6 * r + c, m); else add_blk(anchor, pi, 6 * c + r, m);
-        }
+        for (int c = 0; c < 6; ++c) v[c] = -Noa[6 * r + c] - (WoD[3 * r] * WA[3 * c] + WoD[3 * r + 1] * WA[3 * c + 1] + WoD[3 * r + 2] * WA[3 * c + 2]);
+        add_row6(dst, rs * r, cstr, v, 0);
+      }
     }
     double u0, u1, u2;
     cross3(lin.y, lin.g[0], lin.g[1], lin.g[2], u0, u1, u2);
     const double bo[6] = {-lin.g[0], -lin.g[1], -lin.g[2], -u0, -u1, -u2};    // b_obs = -Eo^T g
+    double bsv[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      add_vec(0, pi, r, bo[r]);
-      add_vec(1, pi, r, Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2]);
-    }
+    for (int r = 0; r < 6; ++r) bsv[r] = Wo[3 * r] * Db[0] + Wo[3 * r + 1] * Db[1] + Wo[3 * r + 2] * Db[2];
+    add_vec6(0, pi, bo);
+    add_vec6(1, pi, bsv);
   }
   SVS_STAMP(8);
   // (3) observer-observer pairs of a landmark, circulant schedule: in round r the edge with local index a
@@ -649,26 +682,40 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
   {
     const int m = seg_end - seg_begin + 1, a_loc = lane - seg_begin;
     const double *wave_wo = s_wo + (threadIdx.x >> 6) * 64 * 18;
-    for (int r = 1; r <= (maxlen >> 1); ++r) {
+    // LDS operations of a wave complete in order: a partner fetch issued right behind the 36 adds of the previous round would wait for
+    // all of them.  So the partner of round r+1 (its pose, role and W_obs) is fetched BEFORE the adds of round r are issued, and the
+    // products of round r are formed while that fetch (and the adds of round r-1 in front of it) drain.
+    const int rounds = maxlen >> 1;
+    auto partner = [&](int r, int &pj, bool &on, double (&Wj)[18]) __attribute__((always_inline)) {
       int b_loc = a_loc + r;
       if (b_loc >= m) b_loc -= m;
       const int lane_b = seg_begin + b_loc;
-      const int pj = __shfl(ed.pose, lane_b, 64);
+      pj = __shfl(ed.pose, lane_b, 64);
       const int rolej = __shfl((int)obs_role, lane_b, 64);
-      const bool on = obs_role && rolej && 2 * r <= m && !(2 * r == m && a_loc >= r);
+      on = obs_role && rolej && 2 * r <= m && !(2 * r == m && a_loc >= r);
+      const double *wj = wave_wo + lane_b * 18;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wj[i] = wj[i];
+    };
+    int pj_n = 0; bool on_n = false; double W_n[18];
+    if (rounds >= 1) partner(1, pj_n, on_n, W_n);
+    for (int r = 1; r <= rounds; ++r) {
+      const int pj = pj_n; const bool on = on_n;
+      double Wj[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wj[i] = W_n[i];
+      if (r < rounds) partner(r + 1, pj_n, on_n, W_n);
       if (on) {
-        const double *wj = wave_wo + lane_b * 18;
-        double Wj[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) Wj[i] = wj[i];
         const bool up = ed.pose < pj;
+        const Dst dst = blk_dst(up ? ed.pose : pj, up ? pj : ed.pose);
+        const int rs = up ? 6 : 1, cstr = up ? 1 : 6;
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr)
+        for (int rr = 0; rr < 6; ++rr) {
+          double v[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const double v = -(WoD[3 * rr] * Wj[3 * c] + WoD[3 * rr + 1] * Wj[3 * c + 1] + WoD[3 * rr + 2] * Wj[3 * c + 2]);
-            if (up) add_blk(ed.pose, pj, 6 * rr + c, v); else add_blk(pj, ed.pose, 6 * c + rr, v);
-          }
+          for (int c = 0; c < 6; ++c) v[c] = -(WoD[3 * rr] * Wj[3 * c] + WoD[3 * rr + 1] * Wj[3 * c + 1] + WoD[3 * rr + 2] * Wj[3 * c + 2]);
+          add_row6(dst, rs * rr, cstr, v, 0);
+        }
       }
     }
   }

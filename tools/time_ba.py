@@ -8,7 +8,8 @@ from scavislam_amd.backend import SlamGraphOptimizer
 from scavislam_amd.ctypes_types import BaParams, Cam
 
 ctx, stream = capi.torch_context(0)
-for P, L in ((15, 3000), (50, 20000), (100, 40000)):
+sizes = ((int(sys.argv[1]), int(sys.argv[2])),) if len(sys.argv) > 2 else ((15, 3000), (50, 20000), (100, 40000))
+for P, L in sizes:
     prob = synth.ba_window(P, L, seed=2012)
     c = prob["cam"]
     cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
