@@ -548,11 +548,26 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 5),
                 "alg_bytes_per_launch": int(alg_schur), "avg_launch_ms": round(red_ms, 5),
-                # HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the
-                # gfx950 note in MI355X_MICROARCH.md), measured on this kernel at this size in profiles/r1_summary.md;
-                # it cannot be collected inside this process, so it is only reported for the profiled configuration
-                "traffic": 14113400 if (world == 1 and E_local == 99587) else None,
-                "traffic_source": "profiles/r1_summary.md section 3 (2*FETCH_SIZE + WRITE_SIZE)"}
+                "traffic": None, "traffic_source": None}
+    # HBM bytes per launch come from rocprofv3 PMC passes (they cannot be collected inside this process): profiles/pmc_latest.json holds
+    # them per kernel together with the hash of the kernel's source at profiling time -- reported only while that source is unchanged
+    # and the workload is the profiled one.
+    def pmc_traffic(key, workload_ok):
+        import hashlib
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"][key]
+            cur = hashlib.sha256(open(os.path.join(ROOT, pj["source"]), "rb").read()).hexdigest()[:16]
+            if cur == pj["source_sha16"] and workload_ok(pj["workload"]):
+                return pj["traffic"], f"profiles/pmc_latest.json ({pj['correction']})"
+        except Exception:
+            pass
+        return None, "profiles/pmc_latest.json is missing, or the kernel source / workload changed since it was taken"
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic("ba_landmark_kernel<0>", lambda wl: world == 1 and wl.get("edges") == E_local)
+    df_traffic, df_src = pmc_traffic("dense_track_full_kernel", lambda wl: wl.get("streams_per_launch") == FB)
+    if df_traffic is not None:      # measured on the same kernel at the same batch but other frames: carried over as the ratio to algorithmic bytes
+        ratio = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["dense_track_full_kernel"]["traffic_over_algorithmic"]
+        df_traffic = int(ratio * dense_full["roofline"]["alg_bytes_per_launch"])
+    dense_full["roofline"]["traffic"], dense_full["roofline"]["traffic_source"] = df_traffic, df_src
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
     cpu = None

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""profiles/pmc_latest.json: HBM bytes per launch of the roofline kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+runs, as MI355X_MICROARCH.md prescribes), keyed by kernel, with the hash of the kernel's source file at profiling time: bench.py reports
+`roofline.traffic` from here and prints null when the source has changed since.
+usage: make_pmc_latest.py <pmc_FETCH_SIZE.txt> <pmc_WRITE_SIZE.txt> <bench.log>   (the .txt files are tools/pmc_any.py outputs)"""
+import hashlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
+        if m:
+            out[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)) * 1024.0)      # the counters are in KB
+    return out
+
+
+def sha(rel):
+    return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+
+
+def main(fetch_txt, write_txt, bench_log, df_fetch_txt=None, df_write_txt=None, df_log=None):
+    F, W = parse(fetch_txt), parse(write_txt)
+    bench = json.loads([l for l in open(bench_log).read().splitlines() if l.startswith("{")][-1])
+    res = {"note": "bytes per launch; FETCH_SIZE counts a 16-byte-per-lane streaming read at half its size on gfx950 (MI355X_MICROARCH.md, HBM section): "
+                   "`traffic` applies that correction to the part of the fetch that is such a stream, `fetch_raw` / `write_raw` are the counters as read",
+           "kernels": {}}
+
+    def pick(sub):
+        ks = [k for k in F if sub in k]
+        return max(ks, key=lambda k: F[k][1]) if ks else None
+    k = pick("ba_landmark_kernel<0")
+    if k:
+        f, w = F[k][1], W.get(k, (0, 0.0))[1]
+        res["kernels"]["ba_landmark_kernel<0>"] = {
+            "kernel": k, "launches": F[k][0], "fetch_raw": round(f), "write_raw": round(w), "traffic": round(2 * f + w),
+            "correction": "edge records, poses and psi arrive as 16 B/lane loads: 2 x FETCH_SIZE + WRITE_SIZE",
+            "workload": {"keyframes": bench["schur"]["keyframes"], "landmarks": bench["schur"]["landmarks"], "edges": bench["schur"]["edges"]},
+            "source": "scavislam_amd/csrc/ba.hip", "source_sha16": sha("scavislam_amd/csrc/ba.hip")}
+    if df_fetch_txt and "dense_full" in bench:
+        Fd, Wd = parse(df_fetch_txt), parse(df_write_txt)
+        ks = [k for k in Fd if "<false" in k]
+        line = [l for l in open(df_log).read().splitlines() if l.startswith("B=") and "fuse=0" in l]
+        if ks and line:
+            k = ks[0]
+            alg = float(re.search(r"alg\s+([0-9.]+) MB", line[-1]).group(1)) * 1e6
+            f, w = Fd[k][1], Wd.get(k, (0, 0.0))[1]
+            traffic = f + alg / 4 + w
+            res["kernels"]["dense_track_full_kernel"] = {
+                "kernel": k, "launches": Fd[k][0], "fetch_raw": round(f), "write_raw": round(w), "alg_bytes_of_the_profiled_launch": round(alg),
+                "traffic": round(traffic), "traffic_over_algorithmic": round(traffic / alg, 4),
+                "correction": "only the float4 cloud stream (16 of the 32 algorithmic B/px) is a 16 B/lane load: FETCH_SIZE + (algorithmic bytes / 2) / 2 + WRITE_SIZE",
+                "workload": {"streams_per_launch": 64, "command": "tools/time_dense_full.py 64 (the batched launches only)"},
+                "source": "scavislam_amd/csrc/dense_full.hip", "source_sha16": sha("scavislam_amd/csrc/dense_full.hip")}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:7])
