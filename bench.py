@@ -565,8 +565,8 @@ def main():
     roofline["traffic"], roofline["traffic_source"] = pmc_traffic("ba_landmark_kernel<0>", lambda wl: world == 1 and wl.get("edges") == E_local)
     df_traffic, df_src = pmc_traffic("dense_track_full_kernel", lambda wl: wl.get("streams_per_launch") == FB)
     if df_traffic is not None:      # measured on the same kernel at the same batch but other frames: carried over as the ratio to algorithmic bytes
-        ratio = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["dense_track_full_kernel"]["traffic_over_algorithmic"]
-        df_traffic = int(ratio * dense_full["roofline"]["alg_bytes_per_launch"])
+        ratio = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["dense_track_full_kernel"].get("traffic_over_algorithmic")
+        df_traffic = int(ratio * dense_full["roofline"]["alg_bytes_per_launch"]) if ratio else None
     dense_full["roofline"]["traffic"], dense_full["roofline"]["traffic_source"] = df_traffic, df_src
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)

@@ -161,6 +161,13 @@ class FastGrid {
     ctx_.check(svs_fast_download(f_, 0, level, nullptr, 0, nullptr, nullptr, nullptr, thr.data()));
     return thr;
   }
+  // corners kept per cell by the last detection, cells row-major: the reference's quadtree content is the corner's index
+  // INSIDE its cell (fast_grid.cpp:143-149), so the host walks corners[l] with these counts
+  std::vector<int32_t> cell_counts(int level) {
+    std::vector<int32_t> cnt((size_t)grids_[level].gx * grids_[level].gy);
+    ctx_.check(svs_fast_download(f_, 0, level, nullptr, 0, nullptr, cnt.data(), nullptr, nullptr));
+    return cnt;
+  }
   bool set_cell_grid2d(int level, const std::vector<int32_t> &thr) { return ctx_.check(svs_fast_set_thresholds(f_, 0, level, thr.data())); }
   svs_fast *handle() const { return f_; }
 
