@@ -43,23 +43,65 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 // of the WIN x WIN pose window (plus b_p / b_s rows) lives in LDS; contributions whose poses fall
 // outside the window go straight to global atomics.  Landmarks are processed sorted by anchor,
 // so a workgroup's landmarks touch a narrow band of poses and nearly everything lands in LDS.
-constexpr int DBG_N = 12;   // phase stamps per wave of the Schur kernel timeline (SVS_BA_DEBUG=2)
+constexpr int DBG_N = 10;   // phase stamps per wave of the Schur kernel timeline (SVS_BA_DEBUG=2)
 constexpr int WIN = 16;
 constexpr int WIN_BLOCKS = WIN * (WIN + 1) / 2;
 // LDS stride of one 6x6 window block in doubles: 37 (not 36) spreads the same element of different
 // blocks over all banks -- measured 11 vs 32 cycles per ds_add_f64 wave instruction (tools/ubench.hip)
 constexpr int WBLK = 37;
+// Copies of the window: a lane adds into copy (lane % WCOPIES).  The cost of a ds_add_f64 wave instruction is set by the number of lanes
+// that hit the SAME address (~3.6 cycles each: 13 lanes 47 cycles, 4 lanes 11, tools/ubench.hip) -- lanes of different landmarks seen
+// from the same keyframe -- and two copies halve that multiplicity.  The flush adds the copies.
+constexpr int WCOPIES_MAX = 2;      // (template parameter WC of the kernel: 2 where one workgroup per CU is resident anyway, 1 where two must fit)
+constexpr int SEG_DPP_MAX = 12;      // longest landmark of a wave for which the segmented sums use DPP shifts (seg_allreduce)
 __device__ __forceinline__ int win_blk(int wi, int wj) { return wi * WIN - wi * (wi - 1) / 2 + (wj - wi); }
 
-template <int N>
-__device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int seg_begin, int seg_end, int maxlen) {
-  for (int o = 1; o < maxlen; o <<= 1) {
-    const bool take = (lane - o) >= seg_begin;
+// value of the lane below (wave_shr:1 reaches across the 16-lane DPP rows on gfx9), 0 in lane 0 and wherever `keep` is 0: one
+// v_and_b32_dpp per word, no LDS-pipeline slot (a __shfl is two ds_bpermute_b32 that queue behind the kernel's LDS atomics)
+__device__ __forceinline__ double shr1_keep(double x, unsigned keep) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true) & keep;
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true) & keep;
+  return __hiloint2double(hi, lo);
+}
+// Sum of v over the lanes of each segment (= landmark).  The total is formed in the segment's LAST lane; its first NB values are
+// handed to every lane of the segment, the remaining N - NB stay valid in the last lane only (the per-landmark anchor terms, which
+// one lane consumes).  Short segments (the common case: a landmark has 3..9 observations) run a sliding sum with DPP shifts: after
+// step k a lane holds v[lane] + ... + v[lane - k], cut at its segment head -- maxlen - 1 steps of 3 VALU instructions per value and
+// no LDS-pipeline slot.  The recursive-doubling form (long segments) needs fewer steps, but each is two bpermutes per value on the
+// LDS pipeline, which the Schur kernel's atomics already saturate (27 values x 4 x 2 = 216 per wave were 5 us of its 40,
+// SVS_BA_DEBUG=2 timeline).  The hand-over goes through `slot` (SEG_SLOT doubles of LDS per lane, 16-byte aligned): 9 wide
+// writes by the tail lanes + 9 wide reads instead of 54 bpermutes.
+constexpr int SEG_SLOT = 18;
+template <int N, int NB>
+__device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int seg_begin, int seg_end, int maxlen, double *wave_slots) {
+  static_assert(NB <= SEG_SLOT && NB <= N, "");
+  if (maxlen <= SEG_DPP_MAX) {
+    const unsigned keep = lane == seg_begin ? 0u : 0xffffffffu;      // a head lane takes nothing from below
+    double s[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { double up = __shfl_up(v[i], o, 64); if (take) v[i] += up; }
+    for (int i = 0; i < N; ++i) s[i] = v[i];
+    for (int k = 1; k < maxlen; ++k) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) { s[i] = shr1_keep(s[i], keep); v[i] += s[i]; }
+    }
+  } else {
+    for (int o = 1; o < maxlen; o <<= 1) {
+      const bool take = (lane - o) >= seg_begin;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { double up = __shfl_up(v[i], o, 64); if (take) v[i] += up; }
+    }
   }
+  double *slot = wave_slots + seg_end * SEG_SLOT;
+  if (lane == seg_end) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = __shfl(v[i], seg_end, 64);
+    for (int i = 0; i < NB; ++i) slot[i] = v[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int i = 0; i < NB; ++i) v[i] = slot[i];
 }
 
 __device__ __forceinline__ long blk_index(int i, int j, int P) {   // i <= j, packed upper block row-major
@@ -355,8 +397,9 @@ __device__ __forceinline__ void ba_lm_decide(const BaDev &B, int it) {
 // MODE 1: back-substitute landmarks (psi_trial = psi + x_l), scale_l, chi2 at the trial state.
 // NW waves (chunks) per workgroup: 4 by default; the host picks more when that brings the number of workgroups down to
 // one per CU (at 50 KF / 20k: 1 612 chunks -> 231 workgroups of 7 waves instead of 403 of 4 that load the CUs unevenly).
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(BaDev B) {
+template <int MODE, int NW, int WC = 1>
+__global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_landmark_kernel(BaDev B) {
+  constexpr int WCOPIES = WC;
   constexpr int NT = NW * 64;
   if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int lane = threadIdx.x & 63;
@@ -375,18 +418,24 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
   svs_ba_edge ed;
   if (active) ed = B.edges[e0 + lane];
   else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
-  __shared__ double s_win[MODE == 0 ? WIN_BLOCKS * WBLK : 1];
-  __shared__ double s_vec[MODE == 0 ? 2 * WIN * 6 : 1];
-  __shared__ __attribute__((aligned(16))) double s_wo[MODE == 0 ? NW * 64 * 18 : 1];   // W_obs of every edge lane
+  __shared__ double s_win[MODE == 0 ? WCOPIES * WIN_BLOCKS * WBLK : 1];
+  __shared__ double s_vec[MODE == 0 ? WCOPIES * 2 * WIN * 6 : 1];
+  __shared__ __attribute__((aligned(16))) double s_wo[NW * 64 * 18];   // W_obs of every edge lane (MODE 0); before that, hand-over slots of the segmented sums
   __shared__ int s_pmin;
+  __shared__ unsigned char s_wrow[MODE == 0 ? WIN_BLOCKS : 1];
   int pmin = 0;
   __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
   if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
   if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 16) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < WIN_BLOCKS * WBLK; i += NT) s_win[i] = 0.0;
-    for (int i = threadIdx.x; i < 2 * WIN * 6; i += NT) s_vec[i] = 0.0;
+    for (int i = threadIdx.x; i < WCOPIES * WIN_BLOCKS * WBLK; i += NT) s_win[i] = 0.0;
+    for (int i = threadIdx.x; i < WCOPIES * 2 * WIN * 6; i += NT) s_vec[i] = 0.0;
     if (threadIdx.x == 0) s_pmin = 0x7fffffff;
+    if (threadIdx.x < WIN_BLOCKS) {                       // block row of every packed window block (for the flush)
+      int wi = 0, rem = threadIdx.x;
+      while (rem >= WIN - wi) { rem -= WIN - wi; ++wi; }
+      s_wrow[threadIdx.x] = (unsigned char)wi;
+    }
     __syncthreads();
     int mn = active ? min(ed.pose, ed.anchor) : 0x7fffffff;
 #pragma unroll
@@ -416,7 +465,6 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)ed.anchor + i]; }
-    SVS_STAMP(1);
     linearize_edge(psi, To, Ta, ed, B.cam, B.delta, B.robust, lin);
   } else {
 #pragma unroll
@@ -425,6 +473,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     for (int i = 0; i < 3; ++i) { lin.xa[i] = 0; lin.y[i] = 0; lin.g[i] = 0; }
     lin.rho0 = 0;
   }
+  SVS_STAMP(1);
   // one global atomic per WORKGROUP for the scalar sums: same-address f64 atomics serialise in L2 (~20 ns each), and one
   // per wave cost more than the rest of the back-substitution kernel
   if (MODE == 0) {
@@ -476,7 +525,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     }
   }
   SVS_STAMP(2);
-  seg_allreduce<NRED>(red, lane, seg_begin, seg_end, maxlen);
+  seg_allreduce<NRED, 18>(red, lane, seg_begin, seg_end, maxlen, s_wo + (threadIdx.x >> 6) * 64 * 18);
   SVS_STAMP(3);
   double Di[9], bl[3] = {red[6], red[7], red[8]};
   {
@@ -509,7 +558,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
       WA[9 + c] = -t0; WA[12 + c] = -t1; WA[15 + c] = -t2;
     }
   };
-  SVS_STAMP(5);
+  SVS_STAMP(4);
   const int anchor = ed.anchor;
 
   if (MODE == 1) {
@@ -521,7 +570,8 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
 #pragma unroll
         for (int i = 0; i < 6; ++i) c[j] += Wo[3 * i + j] * B.x[6 * ed.pose + i];
     }
-    seg_allreduce<3>(c, lane, seg_begin, seg_end, maxlen);
+    __builtin_amdgcn_wave_barrier();      // every lane has read its slot of the first hand-over
+    seg_allreduce<3, 3>(c, lane, seg_begin, seg_end, maxlen, s_wo + (threadIdx.x >> 6) * 64 * 18);
     double xl[3] = {0, 0, 0};
     if (active) {
       double WA[18];
@@ -564,12 +614,13 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
   // (PMC: 2440 SALU vs 2490 VALU per wave, profiles/r2_notes.md).
   // (destinations are kept as INDICES into s_win / B.H, not as pointers: a pointer that may point to either would be a flat pointer and
   //  every add a flat atomic)
+  const int my_copy = lane % WCOPIES;
   struct Dst { bool in_lds; int lds; long glb; };
   auto blk_dst = [&](int pi, int pj) __attribute__((always_inline)) {
     const int wi = pi - pmin, wj = pj - pmin;
     Dst d;
     d.in_lds = wj < WIN;
-    d.lds = d.in_lds ? win_blk(wi, wj) * WBLK : 0;
+    d.lds = d.in_lds ? my_copy * (WIN_BLOCKS * WBLK) + win_blk(wi, wj) * WBLK : 0;
     d.glb = d.in_lds ? 0 : blk_index(pi, pj, B.P) * 36;
     return d;
   };
@@ -587,7 +638,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     const int wp = p - pmin;
     if (wp < WIN) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lds_add_f64(&s_vec[(which * WIN + wp) * 6 + c], v[c]);
+      for (int c = 0; c < 6; ++c) lds_add_f64(&s_vec[my_copy * (2 * WIN * 6) + (which * WIN + wp) * 6 + c], v[c]);
     } else {
       double *g = (which ? B.bs : B.bp) + 6 * p;
 #pragma unroll
@@ -595,7 +646,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     }
   };
   // (1) anchor block, once per landmark: Ea^T S_RAR Ea - (W_A D^-1) W_A^T,  b_anc = Ea^T S_Rg,  Schur rhs W_A D^-1 b_l
-  if (active && head) {
+  if (active && lane == seg_end) {      // the lane that holds the landmark's complete sums
     double WA[18], WAD[18], SR[9], Maa[36];
     make_WA(WA);
     SR[0] = red[18]; SR[1] = red[19]; SR[2] = red[20]; SR[3] = red[19]; SR[4] = red[21]; SR[5] = red[22]; SR[6] = red[20]; SR[7] = red[22]; SR[8] = red[23];
@@ -621,7 +672,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     add_vec6(0, anchor, ba);
     add_vec6(1, anchor, bsv);
   }
-  SVS_STAMP(7);
+  SVS_STAMP(5);
   // (2) observer part: blocks (i,i), (i,A), b_i;  W_obs is parked in LDS for the pair phase
   double *my_wo = s_wo + ((threadIdx.x >> 6) * 64 + lane) * 18;
 #pragma unroll
@@ -673,26 +724,34 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
     add_vec6(0, pi, bo);
     add_vec6(1, pi, bsv);
   }
-  SVS_STAMP(8);
+  SVS_STAMP(6);
   // (3) observer-observer pairs of a landmark, circulant schedule: in round r the edge with local index a
   //     pairs with (a + r) mod m, so all m lanes of a landmark work for floor(m/2) rounds (instead of one
   //     lane-partner distance per round over m-1 rounds).  -(W_a D^-1) W_b^T goes to block (min, max).
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   {
-    const int m = seg_end - seg_begin + 1, a_loc = lane - seg_begin;
+    // The circulant runs over the landmark's OBSERVERS only: its self edge (observer == anchor, at most one per landmark: one edge
+    // per (point, keyframe)) has no W_obs and would only lengthen the schedule -- a landmark seen from its anchor and four more
+    // keyframes takes 2 rounds instead of 2.5 -> 3, and the wave runs as many rounds as its largest landmark needs.
+    const unsigned long long seg_mask = (seg_end == 63 ? ~0ull : ((1ull << (seg_end + 1)) - 1ull)) & ~((1ull << seg_begin) - 1ull);
+    const unsigned long long self_in_seg = __ballot(active && !obs_role) & seg_mask;      // (a non-literal self edge included: it pairs with nobody)
+    const int self_pos = self_in_seg ? (__ffsll((long long)self_in_seg) - 1) - seg_begin : 64;
+    const int m = (seg_end - seg_begin + 1) - (self_in_seg ? 1 : 0);
+    const int a_loc = (lane - seg_begin) - ((lane - seg_begin) > self_pos ? 1 : 0);
+    int rounds = active ? (m >> 1) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
     const double *wave_wo = s_wo + (threadIdx.x >> 6) * 64 * 18;
     // LDS operations of a wave complete in order: a partner fetch issued right behind the 36 adds of the previous round would wait for
     // all of them.  So the partner of round r+1 (its pose, role and W_obs) is fetched BEFORE the adds of round r are issued, and the
     // products of round r are formed while that fetch (and the adds of round r-1 in front of it) drain.
-    const int rounds = maxlen >> 1;
     auto partner = [&](int r, int &pj, bool &on, double (&Wj)[18]) __attribute__((always_inline)) {
       int b_loc = a_loc + r;
       if (b_loc >= m) b_loc -= m;
-      const int lane_b = seg_begin + b_loc;
+      const int lane_b = min(seg_begin + b_loc + (b_loc >= self_pos ? 1 : 0), 63);
       pj = __shfl(ed.pose, lane_b, 64);
-      const int rolej = __shfl((int)obs_role, lane_b, 64);
-      on = obs_role && rolej && 2 * r <= m && !(2 * r == m && a_loc >= r);
+      on = obs_role && 2 * r <= m && !(2 * r == m && a_loc >= r);
       const double *wj = wave_wo + lane_b * 18;
 #pragma unroll
       for (int i = 0; i < 18; ++i) Wj[i] = wj[i];
@@ -719,24 +778,26 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void ba_landmark_kernel(B
       }
     }
   }
-  SVS_STAMP(9);
+  SVS_STAMP(7);
   // flush the LDS window: one global atomic per touched element per workgroup
   __syncthreads();
-  SVS_STAMP(10);
+  SVS_STAMP(8);
   if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur, s_scal[0]);
   if (pmin != 0x7fffffff) {
     for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += NT) {
       const int wb = i / 36, rc = i - wb * 36;
-      const double v = s_win[wb * WBLK + rc];
+      double v = s_win[wb * WBLK + rc];
+#pragma unroll
+      for (int k = 1; k < WCOPIES; ++k) v += s_win[k * (WIN_BLOCKS * WBLK) + wb * WBLK + rc];
       if (v != 0.0) {
-        int wi = 0, rem = wb;
-        while (rem >= WIN - wi) { rem -= WIN - wi; ++wi; }
-        const int pi = pmin + wi, pj = pmin + wi + rem;
+        const int wi = s_wrow[wb], pi = pmin + wi, pj = pmin + wi + (wb - win_blk(wi, wi));
         if (pj < P) atomic_add_f64(&B.H[blk_index(pi, pj, P) * 36 + rc], v);
       }
     }
     for (int i = threadIdx.x; i < 2 * WIN * 6; i += NT) {
-      const double v = s_vec[i];
+      double v = s_vec[i];
+#pragma unroll
+      for (int k = 1; k < WCOPIES; ++k) v += s_vec[k * (2 * WIN * 6) + i];
       if (v != 0.0) {
         const int which = i / (WIN * 6), rest = i - which * WIN * 6, wp = rest / 6, r = rest - wp * 6;
         if (pmin + wp < P) atomic_add_f64((which ? B.bs : B.bp) + 6 * (pmin + wp) + r, v);
@@ -2205,6 +2266,13 @@ struct BaOptions {                      // experiment / test switches, latched a
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0;
 };
 int svs_comm_allreduce_hook(void *d_buf, size_t count, void *user);      // comm.hip
+// waves per workgroup of the Schur kernel: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
+static inline int pick_nw(int n_chunks, int n_cu, const BaOptions &opt) {
+  int nw = 4;
+  if (!opt.nw4) for (int c = 5; c <= 8 && (n_chunks + nw - 1) / nw > n_cu; ++c) if ((n_chunks + c - 1) / c <= n_cu) nw = c;
+  if (opt.nw >= 4) nw = opt.nw;      // 4..8 (clamped where it is set)
+  return nw;
+}
 
 struct svs_ba {
   svs_ctx *ctx = nullptr;
@@ -2218,6 +2286,8 @@ struct svs_ba {
   void *w_sort_tmp = nullptr; size_t w_sort_tmp_bytes = 0;
   unsigned char *w_hback = nullptr; size_t w_hback_bytes = 0;           // pinned read-back (counters, landmark lengths, pattern)
   int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, n_wide = 0, add_pose_terms = 1;
+  std::vector<int> w_chunk_nlm;                       // landmarks per wave chunk (set_problem work vector)
+  int nw_sched = 0;                                   // waves per Schur workgroup the chunk list was laid out for (0: chosen at launch)
   svs_cam cam{};
   svs_ba_params prm{};
   double *d_poses[2] = {nullptr, nullptr}, *d_psi[2] = {nullptr, nullptr};
@@ -2488,6 +2558,47 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   std::stable_partition(lm_order.begin(), lm_order.end(), [&](int l) { return n_obs[l] <= 64; });
   size_t n_lm_reg = n_lm_all;
   while (n_lm_reg > 0 && n_obs[lm_order[n_lm_reg - 1]] > 64) --n_lm_reg;
+  // Workgroup composition.  A workgroup of the Schur kernel = nw consecutive wave chunks (whole landmarks, <= 64 edges each).
+  //  * The pair phase of a wave runs as many rounds as its LARGEST landmark needs, and the waves of a workgroup share one LDS
+  //    pipeline: inside each workgroup's batch the landmarks are sorted by observation count, so most waves hold landmarks of
+  //    one size (1..2 rounds) and only the wave(s) with the large ones run 3 (every wave ran 3..4 before: max of a random mix).
+  //    Every workgroup keeps the same mix, so the CUs stay evenly loaded.
+  //  * A workgroup accumulates into an LDS window of WIN poses from the smallest pose it touches; one that held landmarks of TWO
+  //    anchor groups would reach past it (2G + span - 1 poses) and send those blocks to global atomics -- 6 such workgroups of 231
+  //    set the kernel's span at 50 KF (39 vs 32 us).  So a group of anchors starts a new workgroup (empty chunks pad the last one).
+  std::vector<int> &chunk_nlm = ba->w_chunk_nlm;
+  chunk_nlm.clear();
+  {
+    long e_reg = 0;
+    for (size_t k = 0; k < n_lm_reg; ++k) e_reg += n_obs[lm_order[k]];
+    const int nw = pick_nw((int)((e_reg + 59) / 60), ctx->n_cu, ba->opt);
+    ba->nw_sched = nw;
+    const bool align_groups = 2 * G + span - 1 > WIN;
+    std::vector<int> out, cand, carry;
+    out.reserve(n_lm_reg);
+    size_t k = 0;
+    while (k < n_lm_reg || !carry.empty()) {
+      const int grp = !carry.empty() ? anchor_of[carry[0]] / G : anchor_of[lm_order[k]] / G;
+      cand.clear();
+      int sum = 0;
+      for (int l : carry) { cand.push_back(l); sum += n_obs[l]; }
+      carry.clear();
+      while (k < n_lm_reg && sum + n_obs[lm_order[k]] <= nw * 64 && (!align_groups || anchor_of[lm_order[k]] / G == grp)) { sum += n_obs[lm_order[k]]; cand.push_back(lm_order[k]); ++k; }
+      std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return n_obs[a] > n_obs[b]; });
+      int n_ch = 0, len = 0, cnt = 0;
+      size_t i = 0;
+      for (; i < cand.size(); ++i) {
+        const int n = n_obs[cand[i]];
+        if (cnt > 0 && len + n > 64) { chunk_nlm.push_back(cnt); ++n_ch; len = 0; cnt = 0; if (n_ch == nw) break; }
+        len += n; ++cnt; out.push_back(cand[i]);
+      }
+      if (cnt > 0) { chunk_nlm.push_back(cnt); ++n_ch; }
+      for (; i < cand.size(); ++i) carry.push_back(cand[i]);          // did not fit the nw chunks after sorting: first in line for the next workgroup
+      const bool group_ends = carry.empty() && (k >= n_lm_reg || anchor_of[lm_order[k]] / G != grp);
+      if (align_groups && group_ends && k < n_lm_reg) while (n_ch < nw) { chunk_nlm.push_back(0); ++n_ch; }
+    }
+    std::copy(out.begin(), out.end(), lm_order.begin());
+  }
   // edge slots: landmarks in that order, each with its observers ascending (insertion sort inside the landmark's slots)
   lm_pos.assign(L, -1); lm_off.assign(lm_order.size() + 1, 0);
   for (size_t k = 0; k < lm_order.size(); ++k) { lm_pos[lm_order[k]] = (int)k; lm_off[k + 1] = lm_off[k] + n_obs[lm_order[k]]; }
@@ -2567,11 +2678,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   }
   std::vector<int> &cs = ba->w_cs, &cl = ba->w_cl;
   cs.clear(); cl.clear();
-  for (size_t k = 0; k < n_lm_reg;) {
-    const int start = lm_off[k];
-    int len = 0;
-    while (k < n_lm_reg && len + (lm_off[k + 1] - lm_off[k]) <= 64) { len += lm_off[k + 1] - lm_off[k]; ++k; }
-    cs.push_back(start); cl.push_back(len);
+  {
+    size_t k = 0;
+    for (int cnt : chunk_nlm) { cs.push_back(lm_off[k]); cl.push_back(lm_off[k + cnt] - lm_off[k]); k += cnt; }
   }
   ba->n_chunks = (int)cs.size();
   ba->n_wide = (int)(n_lm - n_lm_reg);
@@ -2881,6 +2990,7 @@ extern "C" int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids
       start += len;
     }
     ba->n_chunks = (int)cs.size();
+    ba->nw_sched = 0;
     ba->n_wide = n_lm - n_reg;
     for (int k = n_reg; k < n_lm; ++k) {
       if (h_lml[k] > WIDE_THREADS) { ctx->err = "svs_ba: a landmark with more than 256 observations"; return SVS_ERR_UNSUPPORTED; }
@@ -3056,17 +3166,18 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   const bool timeline = ba->opt.debug >= 2 && B.n_chunks > 0;
   if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
   if (B.n_chunks > 0) {
-    // waves per workgroup: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
-    int nw = 4;
-    if (!ba->opt.nw4) for (int c = 5; c <= 8 && div_up(B.n_chunks, nw) > ctx->n_cu; ++c) if (div_up(B.n_chunks, c) <= ctx->n_cu) nw = c;
-    if (ba->opt.nw >= 4) nw = ba->opt.nw;      // 4..8 (clamped where it is set)
+    const int nw = (ba->nw_sched > 0 && ba->opt.nw < 4 && !ba->opt.nw4) ? ba->nw_sched : pick_nw(B.n_chunks, ctx->n_cu, ba->opt);
     const int xc = B.fuse_cons ? B.C : 0;      // pose-pose constraints in extra workgroups of the same launch
+    const int n_wg = div_up(B.n_chunks, nw);
     switch (nw) {
-      case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5>), dim3(div_up(B.n_chunks, 5) + xc), dim3(320), 0, ctx->stream, B); break;
-      case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6>), dim3(div_up(B.n_chunks, 6) + xc), dim3(384), 0, ctx->stream, B); break;
-      case 7: hipLaunchKernelGGL((ba_landmark_kernel<0, 7>), dim3(div_up(B.n_chunks, 7) + xc), dim3(448), 0, ctx->stream, B); break;
-      case 8: hipLaunchKernelGGL((ba_landmark_kernel<0, 8>), dim3(div_up(B.n_chunks, 8) + xc), dim3(512), 0, ctx->stream, B); break;
-      default: hipLaunchKernelGGL((ba_landmark_kernel<0, 4>), dim3(div_up(B.n_chunks, 4) + xc), dim3(256), 0, ctx->stream, B); break;
+      case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5, 2>), dim3(n_wg + xc), dim3(320), 0, ctx->stream, B); break;
+      case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6, 2>), dim3(n_wg + xc), dim3(384), 0, ctx->stream, B); break;
+      case 7: hipLaunchKernelGGL((ba_landmark_kernel<0, 7, 2>), dim3(n_wg + xc), dim3(448), 0, ctx->stream, B); break;
+      case 8: hipLaunchKernelGGL((ba_landmark_kernel<0, 8, 2>), dim3(n_wg + xc), dim3(512), 0, ctx->stream, B); break;
+      default:
+        if (n_wg <= ctx->n_cu) hipLaunchKernelGGL((ba_landmark_kernel<0, 4, 2>), dim3(n_wg + xc), dim3(256), 0, ctx->stream, B);      // one workgroup per CU: LDS to spare
+        else hipLaunchKernelGGL((ba_landmark_kernel<0, 4, 1>), dim3(n_wg + xc), dim3(256), 0, ctx->stream, B);                         // two per CU must fit
+        break;
     }
     SVS_LAUNCH_CHECK(ctx);
   }
@@ -3079,18 +3190,20 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
     (void)hipFree(B.dbg);
     long long t0 = h[0], t1 = h[DBG_N - 1];
     for (int c = 0; c < B.n_chunks; ++c) { t0 = std::min(t0, h[(size_t)DBG_N * c]); t1 = std::max(t1, h[(size_t)DBG_N * c + DBG_N - 1]); }
-    double ph[DBG_N] = {}, s_start = 0, mx_start = 0, mx_dur = 0;
+    double ph[DBG_N] = {}, phmax[DBG_N] = {}, s_start = 0, mx_start = 0, mx_dur = 0;
+    int slow = 0;
     for (int c = 0; c < B.n_chunks; ++c) {
       const long long *d = &h[(size_t)DBG_N * c];
       const double st = (d[0] - t0) * 0.01, dur = (d[DBG_N - 1] - d[0]) * 0.01;
-      s_start += st; mx_start = std::max(mx_start, st); mx_dur = std::max(mx_dur, dur);
-      for (int k = 1; k < DBG_N; ++k) ph[k] += (d[k] - d[k - 1]) * 0.01;
+      s_start += st; mx_start = std::max(mx_start, st);
+      if (dur > mx_dur) { mx_dur = dur; slow = c; }
+      for (int k = 1; k < DBG_N; ++k) { ph[k] += (d[k] - d[k - 1]) * 0.01; phmax[k] = std::max(phmax[k], (d[k] - d[k - 1]) * 0.01); }
     }
     const double n = B.n_chunks;
-    static const char *names[DBG_N] = {"", "load", "linearize + landmark sums", "segment reduce", "-", "D^-1, W", "-", "anchor block", "observer blocks", "pairs", "barrier", "flush"};
-    fprintf(stderr, "[svs_ba] schur kernel timeline: span %.1f us, %d waves, start avg %.1f max %.1f us, wave duration max %.1f us; phases (us avg):",
+    static const char *names[DBG_N] = {"", "load", "linearize + landmark sums", "segment reduce", "D^-1, W", "anchor block", "observer blocks", "pairs", "barrier", "flush"};
+    fprintf(stderr, "[svs_ba] schur kernel timeline: span %.1f us, %d waves, start avg %.1f max %.1f us, wave duration max %.1f us; phases (us avg / max / slowest wave):",
             (t1 - t0) * 0.01, B.n_chunks, s_start / n, mx_start, mx_dur);
-    for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f |", names[k], ph[k] / n);
+    for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f / %.2f / %.2f |", names[k], ph[k] / n, phmax[k], (h[(size_t)DBG_N * slow + k] - h[(size_t)DBG_N * slow + k - 1]) * 0.01);
     fprintf(stderr, "\n");
   }
   return SVS_OK;
