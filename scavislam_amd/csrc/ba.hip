@@ -44,17 +44,24 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 // outside the window go straight to global atomics.  Landmarks are processed sorted by anchor,
 // so a workgroup's landmarks touch a narrow band of poses and nearly everything lands in LDS.
 constexpr int DBG_N = 10;   // phase stamps per wave of the Schur kernel timeline (SVS_BA_DEBUG=2)
-constexpr int WIN = 16;
-constexpr int WIN_BLOCKS = WIN * (WIN + 1) / 2;
+constexpr int DBG_X = 8;    // + per-wave structure words: landmarks, same-address multiplicity of the observer / anchor adds, pair rounds
+constexpr int DBG_W = DBG_N + DBG_X;
+constexpr int WIN = 16;               // widest window of the small pool (two workgroups per CU); the host lays out anchor groups against it
+constexpr int WIN_BIG = 22;           // widest window of the big pool (one workgroup per CU)
+constexpr int WIN_BLOCKS_MAX = WIN_BIG * (WIN_BIG + 1) / 2;
 // LDS stride of one 6x6 window block in doubles: 37 (not 36) spreads the same element of different
 // blocks over all banks -- measured 11 vs 32 cycles per ds_add_f64 wave instruction (tools/ubench.hip)
 constexpr int WBLK = 37;
-// Copies of the window: a lane adds into copy (lane % WCOPIES).  The cost of a ds_add_f64 wave instruction is set by the number of lanes
-// that hit the SAME address (~3.6 cycles each: 13 lanes 47 cycles, 4 lanes 11, tools/ubench.hip) -- lanes of different landmarks seen
-// from the same keyframe -- and two copies halve that multiplicity.  The flush adds the copies.
-constexpr int WCOPIES_MAX = 2;      // (template parameter WC of the kernel: 2 where one workgroup per CU is resident anyway, 1 where two must fit)
+// The window is sized PER WORKGROUP: win = the pose span its edges actually touch (pmin .. pmax, at most WIN / WIN_BIG), and the pool
+// holds as many COPIES of that window as fit (at most WCOPIES_MAX).  The cost of a ds_add_f64 wave instruction is set by the number of
+// lanes that hit the SAME address (~3.6 cycles each: 13 lanes 47 cycles, <= 3 lanes 11 = the floor, tools/ubench.hip) -- lanes of
+// different landmarks seen from the same keyframe.  A lane adds into copy (ordinal of its landmark in the wave) % copies, so with c
+// copies at most ceil(landmarks per wave / c) lanes collide; a one-anchor workgroup spans ~9 poses = 45 blocks = 6 copies.  The
+// flush adds the copies.
+constexpr int WCOPIES_MAX = 8;
 constexpr int SEG_DPP_MAX = 12;      // longest landmark of a wave for which the segmented sums use DPP shifts (seg_allreduce)
-__device__ __forceinline__ int win_blk(int wi, int wj) { return wi * WIN - wi * (wi - 1) / 2 + (wj - wi); }
+__device__ __host__ constexpr int win_pool_doubles(int nw, int wc) { return wc == 2 ? (163840 - nw * 64 * 18 * 8 - 4096) / 8 : 5224; }
+__device__ __forceinline__ int win_blk(int wi, int wj, int win) { return wi * win - wi * (wi - 1) / 2 + (wj - wi); }
 
 // value of the lane below (wave_shr:1 reaches across the 16-lane DPP rows on gfx9), 0 in lane 0 and wherever `keep` is 0: one
 // v_and_b32_dpp per word, no LDS-pipeline slot (a __shfl is two ds_bpermute_b32 that queue behind the kernel's LDS atomics)
@@ -399,8 +406,8 @@ __device__ __forceinline__ void ba_lm_decide(const BaDev &B, int it) {
 // one per CU (at 50 KF / 20k: 1 612 chunks -> 231 workgroups of 7 waves instead of 403 of 4 that load the CUs unevenly).
 template <int MODE, int NW, int WC = 1>
 __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_landmark_kernel(BaDev B) {
-  constexpr int WCOPIES = WC;
   constexpr int NT = NW * 64;
+  constexpr int POOL = win_pool_doubles(NW, WC), WMAX = WC == 2 ? WIN_BIG : WIN;
   if (B.ctl) { if (B.ctl[1] != 0.0) return; B.lambda = B.ctl[0]; }      // speculative trial: lambda decided on the device, skipped after a rejection
   const int lane = threadIdx.x & 63;
   __shared__ double s_cons[8][36];
@@ -413,37 +420,59 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   const bool wave_valid = chunk < B.n_chunks;                        // wave-uniform
   const int e0 = wave_valid ? B.chunk_start[chunk] : 0, len = wave_valid ? B.chunk_len[chunk] : 0;
   const bool active = lane < len;
-#define SVS_STAMP(k) do { if (B.dbg && lane == 0 && wave_valid) B.dbg[DBG_N * (size_t)chunk + (k)] = (long long)wall_clock64(); } while (0)
+#define SVS_STAMP(k) do { if (B.dbg && lane == 0 && wave_valid) B.dbg[DBG_W * (size_t)chunk + (k)] = (long long)wall_clock64(); } while (0)
   SVS_STAMP(0);
   svs_ba_edge ed;
   if (active) ed = B.edges[e0 + lane];
   else { ed.point = -1 - lane; ed.pose = 0; ed.anchor = 0; }
-  __shared__ double s_win[MODE == 0 ? WCOPIES * WIN_BLOCKS * WBLK : 1];
-  __shared__ double s_vec[MODE == 0 ? WCOPIES * 2 * WIN * 6 : 1];
+  __shared__ __attribute__((aligned(16))) double s_win[MODE == 0 ? POOL : 1];      // `copies` x [window blocks (stride WBLK) | b_p rows | b_s rows]
   __shared__ __attribute__((aligned(16))) double s_wo[NW * 64 * 18];   // W_obs of every edge lane (MODE 0); before that, hand-over slots of the segmented sums
-  __shared__ int s_pmin;
-  __shared__ unsigned char s_wrow[MODE == 0 ? WIN_BLOCKS : 1];
-  int pmin = 0;
+  __shared__ int s_wmin[NW], s_wmax[NW];
+  __shared__ unsigned char s_wrow[MODE == 0 ? WIN_BLOCKS_MAX : 1];
   __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
   if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
   if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 16) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
+  if (MODE == 0) {      // the whole pool is zeroed while the edge records are on their way (how much of it the window uses is known after them)
+    double2 *w2 = reinterpret_cast<double2 *>(s_win);
+    const double2 z2 = {0.0, 0.0};
+    for (int i = threadIdx.x; i < POOL / 2; i += NT) w2[i] = z2;
+  }
+#define SVS_SUBSTAMP(k) do { if (B.dbg) { __builtin_amdgcn_s_waitcnt(0x0F70); if (lane == 0 && wave_valid) B.dbg[DBG_W * (size_t)chunk + DBG_N + (k)] = (long long)wall_clock64(); } } while (0)
+  SVS_SUBSTAMP(4);
+  // the state gathers depend on the record alone: in flight while the window is set up (three barriers further down)
+  double psi[3] = {1, 1, 1}, To[12], Ta[12];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)ed.anchor + i]; }
+  }
+  SVS_SUBSTAMP(5);
+  int pmin = 0, win = 1, nblk = 1, cstride = 1, copies = 1;
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < WCOPIES * WIN_BLOCKS * WBLK; i += NT) s_win[i] = 0.0;
-    for (int i = threadIdx.x; i < WCOPIES * 2 * WIN * 6; i += NT) s_vec[i] = 0.0;
-    if (threadIdx.x == 0) s_pmin = 0x7fffffff;
-    if (threadIdx.x < WIN_BLOCKS) {                       // block row of every packed window block (for the flush)
+    int mn = active ? min(ed.pose, ed.anchor) : 0x7fffffff, mx = active ? max(ed.pose, ed.anchor) : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+    if (lane == 0) { s_wmin[threadIdx.x >> 6] = mn; s_wmax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    SVS_SUBSTAMP(6);
+    pmin = s_wmin[0];
+    int pmax = s_wmax[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) { pmin = min(pmin, s_wmin[k]); pmax = max(pmax, s_wmax[k]); }
+    if (pmin != 0x7fffffff) {
+      win = min(pmax - pmin + 1, WMAX);
+      nblk = win * (win + 1) / 2;
+      cstride = (nblk * WBLK + 12 * win) | 1;               // odd: the copies start in different banks
+      copies = min(WCOPIES_MAX, POOL / cstride);          // >= 1: WMAX fits the pool once
+    }
+    if (threadIdx.x < nblk) {                               // block row of every packed window block (for the flush, behind the next barrier)
       int wi = 0, rem = threadIdx.x;
-      while (rem >= WIN - wi) { rem -= WIN - wi; ++wi; }
+      while (rem >= win - wi) { rem -= win - wi; ++wi; }
       s_wrow[threadIdx.x] = (unsigned char)wi;
     }
-    __syncthreads();
-    int mn = active ? min(ed.pose, ed.anchor) : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
-    if (lane == 0 && mn != 0x7fffffff) atomicMin(&s_pmin, mn);
-    __syncthreads();
-    pmin = s_pmin;
   }
+  SVS_SUBSTAMP(7);
   // segment (= landmark) bounds inside the wave
   const int prev_point = __shfl_up(ed.point, 1, 64);
   const bool head = lane == 0 || prev_point != ed.point;
@@ -455,16 +484,19 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   int maxlen = seg_end - seg_begin + 1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+  // The waves of a workgroup share the CU's LDS pipeline and meet at the flush barrier: the ones holding the largest landmarks (most
+  // pair rounds) are the critical path, so they get the higher issue priority
+  if (MODE == 0) {
+    const int ml = __builtin_amdgcn_readfirstlane(maxlen);
+    if (ml >= 7) __builtin_amdgcn_s_setprio(3);
+    else if (ml >= 5) __builtin_amdgcn_s_setprio(2);
+    else if (ml >= 4) __builtin_amdgcn_s_setprio(1);
+  }
 
   const int P = B.P;
-  double psi[3] = {1, 1, 1}, To[12], Ta[12];
   EdgeCore lin;
   const bool self = active && ed.pose == ed.anchor;
   if (active) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) psi[i] = B.psi[3 * (size_t)ed.point + i];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { To[i] = B.poses[12 * (size_t)ed.pose + i]; Ta[i] = B.poses[12 * (size_t)ed.anchor + i]; }
     linearize_edge(psi, To, Ta, ed, B.cam, B.delta, B.robust, lin);
   } else {
 #pragma unroll
@@ -614,13 +646,14 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   // (PMC: 2440 SALU vs 2490 VALU per wave, profiles/r2_notes.md).
   // (destinations are kept as INDICES into s_win / B.H, not as pointers: a pointer that may point to either would be a flat pointer and
   //  every add a flat atomic)
-  const int my_copy = lane % WCOPIES;
+  const int lm_ord = __popcll(heads & le_mask) - 1;                            // ordinal of this lane's landmark in the wave
+  const int my_copy = lm_ord % copies, my_base = my_copy * cstride, vec_base = my_base + nblk * WBLK;
   struct Dst { bool in_lds; int lds; long glb; };
   auto blk_dst = [&](int pi, int pj) __attribute__((always_inline)) {
     const int wi = pi - pmin, wj = pj - pmin;
     Dst d;
-    d.in_lds = wj < WIN;
-    d.lds = d.in_lds ? my_copy * (WIN_BLOCKS * WBLK) + win_blk(wi, wj) * WBLK : 0;
+    d.in_lds = wj < win;
+    d.lds = d.in_lds ? my_base + win_blk(wi, wj, win) * WBLK : 0;
     d.glb = d.in_lds ? 0 : blk_index(pi, pj, B.P) * 36;
     return d;
   };
@@ -636,9 +669,9 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   };
   auto add_vec6 = [&](int which, int p, const double (&v)[6]) __attribute__((always_inline)) {      // which: 0 = b_p, 1 = b_s
     const int wp = p - pmin;
-    if (wp < WIN) {
+    if (wp < win) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lds_add_f64(&s_vec[my_copy * (2 * WIN * 6) + (which * WIN + wp) * 6 + c], v[c]);
+      for (int c = 0; c < 6; ++c) lds_add_f64(&s_win[vec_base + (which * win + wp) * 6 + c], v[c]);
     } else {
       double *g = (which ? B.bs : B.bp) + 6 * p;
 #pragma unroll
@@ -743,6 +776,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
     const double *wave_wo = s_wo + (threadIdx.x >> 6) * 64 * 18;
+    if (B.dbg && wave_valid && lane == 0) B.dbg[DBG_W * (size_t)chunk + DBG_N + 3] = rounds;
     // LDS operations of a wave complete in order: a partner fetch issued right behind the 36 adds of the previous round would wait for
     // all of them.  So the partner of round r+1 (its pose, role and W_obs) is fetched BEFORE the adds of round r are issued, and the
     // products of round r are formed while that fetch (and the adds of round r-1 in front of it) drain.
@@ -784,27 +818,43 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   SVS_STAMP(8);
   if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur, s_scal[0]);
   if (pmin != 0x7fffffff) {
-    for (int i = threadIdx.x; i < WIN_BLOCKS * 36; i += NT) {
+    for (int i = threadIdx.x; i < nblk * 36; i += NT) {
       const int wb = i / 36, rc = i - wb * 36;
       double v = s_win[wb * WBLK + rc];
-#pragma unroll
-      for (int k = 1; k < WCOPIES; ++k) v += s_win[k * (WIN_BLOCKS * WBLK) + wb * WBLK + rc];
+      for (int k = 1; k < copies; ++k) v += s_win[k * cstride + wb * WBLK + rc];
       if (v != 0.0) {
-        const int wi = s_wrow[wb], pi = pmin + wi, pj = pmin + wi + (wb - win_blk(wi, wi));
+        const int wi = s_wrow[wb], pi = pmin + wi, pj = pmin + wi + (wb - win_blk(wi, wi, win));
         if (pj < P) atomic_add_f64(&B.H[blk_index(pi, pj, P) * 36 + rc], v);
       }
     }
-    for (int i = threadIdx.x; i < 2 * WIN * 6; i += NT) {
-      double v = s_vec[i];
-#pragma unroll
-      for (int k = 1; k < WCOPIES; ++k) v += s_vec[k * (2 * WIN * 6) + i];
+    for (int i = threadIdx.x; i < 2 * win * 6; i += NT) {
+      double v = s_win[nblk * WBLK + i];
+      for (int k = 1; k < copies; ++k) v += s_win[k * cstride + nblk * WBLK + i];
       if (v != 0.0) {
-        const int which = i / (WIN * 6), rest = i - which * WIN * 6, wp = rest / 6, r = rest - wp * 6;
+        const int which = i / (win * 6), rest = i - which * win * 6, wp = rest / 6, r = rest - wp * 6;
         if (pmin + wp < P) atomic_add_f64((which ? B.bs : B.bp) + 6 * (pmin + wp) + r, v);
       }
     }
   }
   SVS_STAMP(DBG_N - 1);
+  if (B.dbg && wave_valid) {      // structure words of the timeline (debug only)
+    const bool tail = active && lane == seg_end;
+    int m_obs = 0, m_anc = 0;
+    for (int j = 0; j < 64; ++j) {
+      const int pj = __shfl(ed.pose, j, 64), aj = __shfl(ed.anchor, j, 64), cj = __shfl(my_copy, j, 64);
+      const int oj = __shfl((int)obs_role, j, 64), tj = __shfl((int)tail, j, 64);
+      if (obs_role && oj && pj == ed.pose && cj == my_copy) ++m_obs;
+      if (tail && tj && aj == ed.anchor && cj == my_copy) ++m_anc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m_obs = max(m_obs, __shfl_xor(m_obs, o, 64)); m_anc = max(m_anc, __shfl_xor(m_anc, o, 64)); }
+    const unsigned long long act_mask = __ballot(active);
+    if (lane == 0) {
+      B.dbg[DBG_W * (size_t)chunk + DBG_N + 0] = __popcll(heads & act_mask) * 100 + copies;      // landmarks * 100 + window copies
+      B.dbg[DBG_W * (size_t)chunk + DBG_N + 1] = m_obs;
+      B.dbg[DBG_W * (size_t)chunk + DBG_N + 2] = m_anc;
+    }
+  }
 }
 
 // ---- landmarks with more than 64 observations -------------------------------------------------------------------
@@ -2532,7 +2582,11 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     for (int v : span_t) span = std::max(span, v);
   }
   t_1 = now();
-  int G = std::max(1, std::min(8, WIN - span));                          // anchors interleaved per group
+  // anchors interleaved per group.  One: a workgroup's landmarks then share their anchor (or two neighbouring ones where a batch crosses
+  // the group boundary), its window is as narrow as the data allows (span .. span + 1 poses) and holds the most copies; the lanes that
+  // collide on one address -- the landmarks of a wave seen from the same keyframe -- are dealt to different copies by landmark ordinal.
+  // (Round 1 interleaved up to 8 anchors to spread those lanes over blocks instead: that needs a 2 x wider window = a quarter of the copies.)
+  int G = 1;
   if (ba->opt.group > 0) G = ba->opt.group;                                 // experiments only (clamped to 1..WIN at svs_ba_create / set_option)
   // landmark order: per anchor the landmarks in index order; per group of G anchors deal them round-robin
   std::vector<int> &by_anchor_off = ba->w_aoff, &by_anchor = ba->w_alist, &lm_order = ba->w_order;
@@ -3164,11 +3218,13 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<0>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));     // brackets the landmark (Schur) kernel alone
   const bool timeline = ba->opt.debug >= 2 && B.n_chunks > 0;
-  if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_N * (size_t)B.n_chunks));
+  if (timeline) SVS_HIP(ctx, hipMalloc(&B.dbg, sizeof(long long) * DBG_W * (size_t)B.n_chunks));
+  int dbg_nw = 1;
   if (B.n_chunks > 0) {
     const int nw = (ba->nw_sched > 0 && ba->opt.nw < 4 && !ba->opt.nw4) ? ba->nw_sched : pick_nw(B.n_chunks, ctx->n_cu, ba->opt);
     const int xc = B.fuse_cons ? B.C : 0;      // pose-pose constraints in extra workgroups of the same launch
     const int n_wg = div_up(B.n_chunks, nw);
+    dbg_nw = nw;
     switch (nw) {
       case 5: hipLaunchKernelGGL((ba_landmark_kernel<0, 5, 2>), dim3(n_wg + xc), dim3(320), 0, ctx->stream, B); break;
       case 6: hipLaunchKernelGGL((ba_landmark_kernel<0, 6, 2>), dim3(n_wg + xc), dim3(384), 0, ctx->stream, B); break;
@@ -3184,16 +3240,16 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
   if (B.n_wide > 0) { hipLaunchKernelGGL(ba_wide_landmark_kernel<0>, dim3(B.n_wide), dim3(WIDE_THREADS), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
   if (timeline) {   // per-wave timeline of the Schur kernel (debug only; synchronises)
-    std::vector<long long> h(DBG_N * (size_t)B.n_chunks);
+    std::vector<long long> h(DBG_W * (size_t)B.n_chunks);
     SVS_HIP(ctx, hipMemcpyAsync(h.data(), B.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(B.dbg);
     long long t0 = h[0], t1 = h[DBG_N - 1];
-    for (int c = 0; c < B.n_chunks; ++c) { t0 = std::min(t0, h[(size_t)DBG_N * c]); t1 = std::max(t1, h[(size_t)DBG_N * c + DBG_N - 1]); }
+    for (int c = 0; c < B.n_chunks; ++c) { t0 = std::min(t0, h[(size_t)DBG_W * c]); t1 = std::max(t1, h[(size_t)DBG_W * c + DBG_N - 1]); }
     double ph[DBG_N] = {}, phmax[DBG_N] = {}, s_start = 0, mx_start = 0, mx_dur = 0;
     int slow = 0;
     for (int c = 0; c < B.n_chunks; ++c) {
-      const long long *d = &h[(size_t)DBG_N * c];
+      const long long *d = &h[(size_t)DBG_W * c];
       const double st = (d[0] - t0) * 0.01, dur = (d[DBG_N - 1] - d[0]) * 0.01;
       s_start += st; mx_start = std::max(mx_start, st);
       if (dur > mx_dur) { mx_dur = dur; slow = c; }
@@ -3203,7 +3259,28 @@ static int launch_reduce(svs_ba *ba, double lambda, int cur = -1, double *ctl = 
     static const char *names[DBG_N] = {"", "load", "linearize + landmark sums", "segment reduce", "D^-1, W", "anchor block", "observer blocks", "pairs", "barrier", "flush"};
     fprintf(stderr, "[svs_ba] schur kernel timeline: span %.1f us, %d waves, start avg %.1f max %.1f us, wave duration max %.1f us; phases (us avg / max / slowest wave):",
             (t1 - t0) * 0.01, B.n_chunks, s_start / n, mx_start, mx_dur);
-    for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f / %.2f / %.2f |", names[k], ph[k] / n, phmax[k], (h[(size_t)DBG_N * slow + k] - h[(size_t)DBG_N * slow + k - 1]) * 0.01);
+    for (int k = 1; k < DBG_N; ++k) fprintf(stderr, " %s %.2f / %.2f / %.2f |", names[k], ph[k] / n, phmax[k], (h[(size_t)DBG_W * slow + k] - h[(size_t)DBG_W * slow + k - 1]) * 0.01);
+    {   // structure of the waves: landmarks per wave, largest same-address multiplicity of one observer-block add / anchor-block add, pair rounds
+      static const char *xn[DBG_X] = {"landmarks", "observer multiplicity", "anchor multiplicity", "pair rounds", "", "", "", ""};
+      {
+        double a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+        for (int c = 0; c < B.n_chunks; ++c) { const long long *d = &h[(size_t)DBG_W * c]; a1 += (d[DBG_N + 4] - d[0]) * 0.01; a2 += (d[DBG_N + 5] - d[DBG_N + 4]) * 0.01; a3 += (d[DBG_N + 6] - d[DBG_N + 5]) * 0.01; a4 += (d[DBG_N + 7] - d[DBG_N + 6]) * 0.01; a5 += (d[1] - d[DBG_N + 7]) * 0.01; }
+        fprintf(stderr, "\n[svs_ba]   load phase (avg us, debug waits serialise it): edge record %.2f, state gathers %.2f, window extent + barrier %.2f, zeroing + barrier %.2f, linearize %.2f", a1 / n, a2 / n, a3 / n, a4 / n, a5 / n);
+      }
+      fprintf(stderr, "\n[svs_ba]   wave structure (avg / max / slowest wave):");
+      for (int k = 0; k < 4; ++k) {
+        double sum = 0; long long mx = 0;
+        for (int c = 0; c < B.n_chunks; ++c) { const long long v = h[(size_t)DBG_W * c + DBG_N + k]; sum += (double)v; mx = std::max(mx, v); }
+        fprintf(stderr, " %s %.1f / %lld / %lld |", xn[k], sum / n, mx, h[(size_t)DBG_W * slow + DBG_N + k]);
+      }
+      // workgroup view: duration of the slowest wave of each workgroup
+      const int nwg = (B.n_chunks + dbg_nw - 1) / dbg_nw;
+      std::vector<double> wg((size_t)nwg, 0.0);
+      for (int c = 0; c < B.n_chunks; ++c) wg[c / dbg_nw] = std::max(wg[c / dbg_nw], (h[(size_t)DBG_W * c + DBG_N - 2] - h[(size_t)DBG_W * c]) * 0.01);
+      std::vector<double> srt(wg); std::sort(srt.begin(), srt.end());
+      fprintf(stderr, "\n[svs_ba]   workgroups (%d of %d waves): time to the barrier of the slowest wave: min %.1f median %.1f p90 %.1f max %.1f us", nwg, dbg_nw,
+              srt.front(), srt[srt.size() / 2], srt[srt.size() * 9 / 10], srt.back());
+    }
     fprintf(stderr, "\n");
   }
   return SVS_OK;
