@@ -1882,11 +1882,17 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     lut[2 * t] = (unsigned char)(t - jj * (jj - 1) / 2 + 1);
     lut[2 * t + 1] = (unsigned char)jj;
   }
-  for (int r = 0; r < R && r < P; ++r) {
-    for (int e = tid; e < R * 36; e += FUSE_THREADS) {
-      const int c = e / 36;
-      s_win[((size_t)(r % R) * R) * 36 + e] = (r + c < P) ? hval(r, c, e - c * 36) : 0.0;
+  {   // the first R envelope rows: all loads of a lane in flight together (one global round trip, not one per row)
+    constexpr int NI = (FUSE_SLOTS * FUSE_SLOTS * 36 + FUSE_THREADS - 1) / FUSE_THREADS;
+    const int rows0 = min(R, P), total = rows0 * R * 36;
+    double v[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int e = tid + u * FUSE_THREADS, r = e / (R * 36), rem = e - r * R * 36, c = rem / 36;
+      v[u] = (e < total && r + c < P) ? hval(r, c, rem - c * 36) : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) { const int e = tid + u * FUSE_THREADS; if (e < total) s_win[e] = v[u]; }      // row r of the ring = slot r % R = r
   }
   constexpr int LDN = (FUSE_SLOTS * 36 + 63) / 64;     // loader registers per lane and buffer
   double ra[LDN], rb_[LDN];
@@ -2002,6 +2008,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
     wave_lds_fence();
   };
   auto env_len = [&](int k) { return k < P ? rowmax[k] - k : 0; };
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);      // the pivot wave is the critical path of every stage
   if (wave == 0) pivot_stage(0, 0, env_len(0), 0, 0);
   lds_barrier();
   const long long t_loop = wall_clock64();
