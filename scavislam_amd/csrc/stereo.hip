@@ -15,6 +15,10 @@
 //   stereo_ccl_*             speckle filter = connected components (horizontal runs, then union-find with atomicMin
 //                            across rows) + saturating size count; the size test is fused with the 1/16 float conversion
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace {
 
@@ -31,6 +35,13 @@ struct StereoDev {
   int16_t *disp16;       // [batch][h][w]
   uint16_t *cost;        // [batch][h][w]
   int32_t *label, *count;// [batch][h*w]
+  // strip speckle filter: components still undecided at strip boundaries
+  int strip_rows, n_strips;
+  int32_t *brow;         // [batch][2 * n_strips][w]: component id of the first / last row of every strip (-1 filtered, -2 big, else node)
+  int2 *pend;            // [batch][h*w]: (pixel, node) of the pixels of undecided components, a list per strip (at the strip's first pixel)
+  int32_t *npend;        // [batch][n_strips]
+  int timing;            // SVS_STEREO_DEBUG: phase stamps of one workgroup behind the error word
+  int *err;              // [1] set when a bounded walk of the strip path gave up (never expected)
 };
 
 __device__ __forceinline__ int xsobel_tab(int v, int cap) { return v < -cap ? 0 : v > cap ? 2 * cap : v + cap; }
@@ -293,6 +304,24 @@ __device__ __forceinline__ void ccl_union(int32_t *label, int a, int b) {      /
     a = old;                                            // a was no longer a root: continue from its new parent
   }
 }
+// bounded variants for the strip path (nodes of undecided components only)
+__device__ __forceinline__ int ccl_find_b(const int32_t *label, int x, int *err) {
+  int p = label[x], steps = 0;
+  while (p != x && p >= 0) { x = p; p = label[x]; if (++steps > (1 << 16)) { atomicOr(err, 8); return CCL_BIG; } }
+  return p < 0 ? CCL_BIG : x;
+}
+__device__ __forceinline__ void ccl_union_b(int32_t *label, int a, int b, int *err) {
+  for (int tries = 0; tries < (1 << 16); ++tries) {
+    if (a >= 0) a = ccl_find_b(label, a, err);
+    if (b >= 0) b = ccl_find_b(label, b, err);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&label[a], b);
+    if (old == a) return;
+    a = old;
+  }
+  atomicOr(err, 16);
+}
 __device__ __forceinline__ bool ccl_linked(int a, int b, int range) { return a != FILTERED16 && b != FILTERED16 && abs(a - b) <= range; }
 
 // Horizontal runs: label = index of the first pixel of the maximal run of horizontally linked pixels, so the union-find
@@ -459,6 +488,366 @@ __global__ __launch_bounds__(256) void stereo_finish4_kernel(StereoDev S, int us
   for (int k = 0; k < 4; ++k) o[k] = (float)d[k] * (1.f / (1 << DISP_SHIFT));
 }
 
+
+// ---- speckle filter by strips ------------------------------------------------------------------------------------------
+// filterSpeckles needs the SIZE of every 4-connected component, but only up to speckle_window (100 pixels in the reference's
+// configuration): nearly every component is either far larger or a speck of a few pixels, and both kinds are decided inside a strip
+// of rows held in LDS.  One workgroup per (strip, frame):
+//   runs      one wave per row: a pixel's label is the strip index of the first pixel of its horizontal run (two ballots per 64-pixel
+//             segment, the last run start carried across segments in an SGPR); the run's last pixel knows its length -- runs longer
+//             than the window make their start a member of BIG at once;
+//   stitch    vertically linked pixels unite their runs (lock-free union-find on LDS words: a root holds ~(pixels | touch << 24), i.e.
+//             a negative word, every other node the index of its parent; the larger root index is hung under the smaller with a CAS);
+//   count     the last pixel of every run adds its length to the root (saturating: the test is size <= window) and marks the root if
+//             the run lies on a row that has a neighbour strip;
+//   decide    more than window pixels, or BIG: kept.  Small and not touching a neighbour strip: filtered.  Small and touching: UNDECIDED
+//             -- the pixels are kept for now and listed (pixel, node) with node = the frame index of the root pixel; the first / last
+//             row of the strip leaves its node ids in `brow`.  The float conversion of the stage is fused in here.
+// Three small kernels finish the undecided ones: unite nodes across strip boundaries (global union-find, the same routines as the
+// whole-frame path below), count the listed pixels per united root, filter the pixels of the roots that stay <= window.
+// HBM traffic of the whole filter: disparity read once (2 B/px), float written once (4 B/px); the whole-frame path moved 46 B/px.
+constexpr int SPK_THREADS = 1024;
+constexpr int SPK_NS = 10;                         // segments of a row handled in registers at once
+constexpr int SPK_MAX_SEG = 40;                   // 64-pixel segments per row: w <= 2560
+constexpr int SPK_BIG = (int)0x80000000;           // root value of the BIG set; no real root value is that negative
+constexpr int SPK_TOUCH = 1 << 24;
+// (every loop of the union-find routines is bounded: a parent index is smaller than its child, so a walk takes fewer steps than the strip
+//  has pixels; past that something is broken and the walk gives up -- the library never hangs the GPU -- leaving a mark in *err)
+constexpr int SPK_MAX_STEPS = 1 << 16;
+__device__ __forceinline__ int spk_find(const int *lab, int x, int *err) {      // -> root index, or -1 for BIG
+  int v = lab[x], steps = 0;
+  while (v >= 0) { x = v; v = lab[x]; if (++steps > SPK_MAX_STEPS) { atomicOr(err, 1); return -1; } }
+  return v == SPK_BIG ? -1 : x;
+}
+// same, halving the path on the way (a parent word is only ever replaced by an ancestor: safe next to concurrent unions and finds)
+__device__ __forceinline__ int spk_find_halve(int *lab, int x, int *err) {
+  int v = lab[x], steps = 0;
+  while (v >= 0) {
+    const int vv = lab[v];
+    if (vv >= 0) lab[x] = vv;
+    x = v; v = vv;
+    if (++steps > SPK_MAX_STEPS) { atomicOr(err, 2); return -1; }
+  }
+  return v == SPK_BIG ? -1 : x;
+}
+__device__ __forceinline__ void spk_union(int *lab, int a, int b, int *err) {   // a, b: nodes of the strip
+  for (int tries = 0;; ++tries) {
+    if (tries > SPK_MAX_STEPS) { atomicOr(err, 4); return; }
+    if (a >= 0) a = spk_find_halve(lab, a, err);              // (-1 = BIG stays BIG: it is not an index)
+    if (b >= 0) b = spk_find_halve(lab, b, err);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }                     // a > b >= -1: hang root a under b (b == -1: a joins BIG)
+    if (atomicCAS(&lab[a], ~0, b < 0 ? SPK_BIG : b) == ~0) return;    // (a root before the counting pass is ~0: zero pixels, no mark)
+    // a stopped being a root in the meantime: look again from the top
+  }
+}
+// grid: (n_strips, batch), block SPK_THREADS, dynamic LDS = strip_rows * round_up(w, 4) * 6 bytes (labels: int, disparities: int16).
+// Four horizontally adjacent pixels per lane and step (one 8-byte disparity read, one 16-byte label read); a pixel of a run longer than
+// the window carries SPK_BIG itself, so the common cases -- filtered, or big above big -- leave after those two reads.
+__device__ __forceinline__ void spk_unpack4(uint2 v, int (&d)[4]) {
+  d[0] = (int16_t)(v.x & 0xffff); d[1] = (int16_t)(v.x >> 16); d[2] = (int16_t)(v.y & 0xffff); d[3] = (int16_t)(v.y >> 16);
+}
+__global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(StereoDev S, float *__restrict__ out, int dstride, size_t d_bstride) {
+  extern __shared__ int s_mem[];
+  __shared__ unsigned long long s_bb[SPK_THREADS / 64][SPK_MAX_SEG];
+  __shared__ int s_npend;
+  if (threadIdx.x == 0) s_npend = 0;
+  const int w = S.w, h = S.h, wp = (w + 3) & ~3, gpr = wp >> 2;
+  const int b = blockIdx.y, strip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int y0 = strip * S.strip_rows, y1 = min(h, y0 + S.strip_rows), nr = y1 - y0, ng = nr * gpr;
+#define SPK_STAMP(k) do { if (S.timing && tid == 0 && strip == S.n_strips / 2 && b == 0) reinterpret_cast<long long *>(S.err + 8)[k] = (long long)wall_clock64(); } while (0)
+  SPK_STAMP(0);
+  int *lab = s_mem;
+  int16_t *dsp = reinterpret_cast<int16_t *>(s_mem + S.strip_rows * wp);
+  const size_t fbase = (size_t)b * w * h, sbase = fbase + (size_t)y0 * w;
+  const int range = S.speckle_range, window = S.speckle_window;
+  const bool vec = (w & 3) == 0;                               // then every row of the frame starts 8-byte aligned
+  const uint32_t f2 = (uint32_t)(uint16_t)FILTERED16 * 0x00010001u;
+  for (int g = tid; g < ng; g += SPK_THREADS) {
+    const int row = g / gpr, x0 = (g - row * gpr) * 4;
+    const int16_t *src = S.disp16 + sbase + (size_t)row * w + x0;
+    uint2 v;
+    if (vec) v = *reinterpret_cast<const uint2 *>(src);
+    else {
+      uint32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = x0 + k < w ? (uint32_t)(uint16_t)src[k] : (uint32_t)(uint16_t)FILTERED16;
+      v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16);
+    }
+    *reinterpret_cast<uint2 *>(dsp + row * wp + x0) = v;
+  }
+  __syncthreads();
+  SPK_STAMP(1);
+  // ---- runs: one wave per row.  Left to right: the start of every pixel's run; right to left: its end, hence its length.
+  //      Rows of up to SPK_NS segments (640 pixels) are handled in registers: all the row's loads in flight at once, the ballots of its
+  //      segments in scalar registers, one label store per pixel -- the stepwise form below paid three LDS round trips per segment.
+  const int nseg = (w + 63) >> 6;
+  if (nseg <= SPK_NS) {
+    for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+      const int16_t *d = dsp + row * wp;
+      int *l = lab + row * wp;
+      int dv[SPK_NS], dl[SPK_NS];
+#pragma unroll
+      for (int sg = 0; sg < SPK_NS; ++sg) {
+        const int x = sg * 64 + lane;
+        dv[sg] = x < w ? d[x] : FILTERED16;
+        dl[sg] = (x < w && x > 0) ? d[x - 1] : FILTERED16;
+      }
+      unsigned long long sb[SPK_NS], bb[SPK_NS];
+#pragma unroll
+      for (int sg = 0; sg < SPK_NS; ++sg) {
+        const bool filt = dv[sg] == FILTERED16, start = !filt && !ccl_linked(dv[sg], dl[sg], range);
+        sb[sg] = __ballot(start); bb[sg] = __ballot(start || filt);
+      }
+      int carry[SPK_NS], nbc[SPK_NS];                         // last run start left of segment sg / first boundary right of it
+      { int c = 0; 
+#pragma unroll
+        for (int sg = 0; sg < SPK_NS; ++sg) { carry[sg] = c; if (sb[sg]) c = sg * 64 + 63 - __clzll((long long)sb[sg]); } }
+      { int c = w;
+#pragma unroll
+        for (int sg = SPK_NS - 1; sg >= 0; --sg) { nbc[sg] = c; if (bb[sg]) c = sg * 64 + __ffsll((long long)bb[sg]) - 1; } }
+#pragma unroll
+      for (int sg = 0; sg < SPK_NS; ++sg) {
+        const int x = sg * 64 + lane;
+        const unsigned long long lower = sb[sg] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const unsigned long long above = lane == 63 ? 0ull : (bb[sg] >> (lane + 1));
+        const int st = lower ? sg * 64 + 63 - __clzll((long long)lower) : carry[sg];
+        const int nbx = above ? x + __ffsll((long long)above) : nbc[sg];
+        if (x < w) l[x] = dv[sg] == FILTERED16 ? SPK_BIG + 1 : (nbx - st > window) ? SPK_BIG : st == x ? ~0 : row * wp + st;
+      }
+      for (int x = w + lane; x < wp; x += 64) l[x] = SPK_BIG + 1;
+    }
+  } else {
+    for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+      const int16_t *d = dsp + row * wp;
+      int *l = lab + row * wp;
+      int carry = 0;                                            // last run start of the earlier segments
+      for (int seg = 0; seg < nseg; ++seg) {
+        const int x = seg * 64 + lane;
+        const bool in = x < w;
+        const int dv = in ? d[x] : FILTERED16, dl = (in && x > 0) ? d[x - 1] : FILTERED16;
+        const bool filt = dv == FILTERED16, start = !filt && !ccl_linked(dv, dl, range);
+        const unsigned long long sb = __ballot(start), bb = __ballot(start || filt);
+        const unsigned long long lower = sb & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        if (in) l[x] = filt ? -1 : lower ? seg * 64 + 63 - __clzll((long long)lower) : carry;
+        if (lane == 0) s_bb[wave][seg] = bb;
+        if (sb) carry = seg * 64 + 63 - __clzll((long long)sb);
+      }
+      int nb_carry = w;                                         // first boundary (run start, filtered pixel, row end) of the later segments
+      for (int seg = nseg - 1; seg >= 0; --seg) {
+        const int x = seg * 64 + lane;
+        const unsigned long long bb = s_bb[wave][seg];
+        const unsigned long long above = lane == 63 ? 0ull : (bb >> (lane + 1));
+        const int nbx = above ? x + __ffsll((long long)above) : nb_carry;
+        if (x < w) {
+          const int st = l[x];
+          l[x] = st < 0 ? SPK_BIG + 1 : (nbx - st > window) ? SPK_BIG : st == x ? ~0 : row * wp + st;
+        }
+        if (bb) nb_carry = seg * 64 + __ffsll((long long)bb) - 1;
+      }
+      for (int x = w + lane; x < wp; x += 64) l[x] = SPK_BIG + 1;
+    }
+  }
+  __syncthreads();
+  SPK_STAMP(2);
+  // ---- stitch / count / classify share one shape: a wave takes a row, lane = column, all the row's operands in flight at once; the few
+  //      lanes with real work (a union, a run to count, a pixel of a small component) do not do it in place -- every such block would
+  //      cost the whole wave three dependent LDS round trips per segment -- but append their column to a queue, and the queue is worked
+  //      off with one entry per lane.
+  int *const q = reinterpret_cast<int *>(s_bb[wave]);        // 64 entries (the ballots of the stepwise runs pass are done with)
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // ---- stitch rows.  A pixel unites its run with the one below where it is the LEFTMOST linked column of the two runs' overlap:
+  //      vertically linked, and not (left neighbours vertically linked + both horizontal links)
+  for (int row = wave; row < nr - 1; row += SPK_THREADS / 64) {
+    const int16_t *da = dsp + row * wp, *db = da + wp;
+    const int *la = lab + row * wp, *lb = la + wp;
+    auto flush = [&](int qn) {
+      if (lane < qn) {
+        const int x = q[lane];
+        const int a = la[x], c = lb[x];
+        // node of a pixel = its run start (the pixel itself where it starts a run or carries SPK_BIG: its word is a root / parent word then)
+        if (!(a == SPK_BIG && c == SPK_BIG)) spk_union(lab, a >= 0 ? a : row * wp + x, c >= 0 ? c : (row + 1) * wp + x, S.err);
+      }
+    };
+    int qn = 0;
+    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
+      int va[SPK_NS], vb[SPK_NS], pa[SPK_NS], pb[SPK_NS];
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const int x = (s0 + k) * 64 + lane;
+        const bool in = x < w;
+        va[k] = in ? da[x] : FILTERED16; vb[k] = in ? db[x] : FILTERED16;
+        pa[k] = (in && x > 0) ? da[x - 1] : FILTERED16; pb[k] = (in && x > 0) ? db[x - 1] : FILTERED16;
+      }
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const bool lk = ccl_linked(va[k], vb[k], range);
+        const bool covered = ccl_linked(pa[k], pb[k], range) && ccl_linked(pa[k], va[k], range) && ccl_linked(pb[k], vb[k], range);
+        const bool on = lk && !covered;
+        const unsigned long long m = __ballot(on);
+        if (m == 0) continue;
+        const int c = __popcll(m);
+        if (qn + c > 64) { flush(qn); qn = 0; }
+        if (on) q[qn + __popcll(m & lt_mask)] = (s0 + k) * 64 + lane;
+        qn += c;
+      }
+    }
+    flush(qn);
+  }
+  __syncthreads();
+  SPK_STAMP(3);
+  // ---- count: the last pixel of a run adds the run to its root
+  const bool nb_top = y0 > 0, nb_bot = y1 < h;
+  for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+    const int16_t *d = dsp + row * wp;
+    const int *l = lab + row * wp;
+    const bool edge_row = (row == 0 && nb_top) || (row == nr - 1 && nb_bot);
+    auto flush = [&](int qn) {
+      if (lane < qn) {
+        const int e = q[lane], x = e & 0xffff;
+        const int st = (e >> 16) ? row * wp + x : l[x];      // (the word of a start pixel is a root / parent word, not a start index)
+        const int root = spk_find(lab, st, S.err);
+        if (root >= 0) {
+          if ((~lab[root] & (SPK_TOUCH - 1)) <= window) atomicSub(&lab[root], row * wp + x - st + 1);      // ~(V + len) = ~V - len
+          if (edge_row) atomicAnd(&lab[root], ~SPK_TOUCH);                                                    // sets the mark in V
+        }
+      }
+    };
+    int qn = 0;
+    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
+      int dv[SPK_NS], dl[SPK_NS], dr[SPK_NS], lv[SPK_NS];
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const int x = (s0 + k) * 64 + lane;
+        const bool in = x < w;
+        dv[k] = in ? d[x] : FILTERED16; lv[k] = in ? l[x] : SPK_BIG + 1;
+        dl[k] = (in && x > 0) ? d[x - 1] : FILTERED16; dr[k] = (in && x + 1 < w) ? d[x + 1] : FILTERED16;
+      }
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const bool on = dv[k] != FILTERED16 && lv[k] != SPK_BIG && !ccl_linked(dv[k], dr[k], range);      // last pixel of a run that is not big
+        const unsigned long long m = __ballot(on);
+        if (m == 0) continue;
+        const int c = __popcll(m);
+        if (qn + c > 64) { flush(qn); qn = 0; }
+        if (on) q[qn + __popcll(m & lt_mask)] = ((s0 + k) * 64 + lane) | ((ccl_linked(dv[k], dl[k], range) ? 0 : 1) << 16);
+        qn += c;
+      }
+    }
+    flush(qn);
+  }
+  __syncthreads();
+  SPK_STAMP(4);
+  // ---- classify the pixels of the components that are not big: filtered (their disparity in LDS becomes FILTERED), kept, or undecided
+  //      (kept for now and listed; on the strip's first / last row they publish their node)
+  __shared__ unsigned s_pmask[2][SPK_MAX_SEG * 2];            // undecided pixels of the first / last row
+  for (int i = tid; i < 2 * SPK_MAX_SEG * 2; i += SPK_THREADS) (&s_pmask[0][0])[i] = 0u;
+  __syncthreads();
+  for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+    int16_t *d = dsp + row * wp;
+    const int *l = lab + row * wp;
+    auto flush = [&](int qn) {
+      if (lane < qn) {
+        const int e = q[lane], x = e & 0xffff, idx = row * wp + x;
+        const int root = spk_find(lab, (e >> 16) ? idx : l[x], S.err);
+        if (root >= 0) {                                      // else: joined BIG
+          const int V = ~lab[root];
+          if ((V & (SPK_TOUCH - 1)) <= window) {
+            if (!(V & SPK_TOUCH)) d[x] = (int16_t)FILTERED16;
+            else {                                            // undecided: decided after the strips have been united
+              const int rrow = root / wp, node = (y0 + rrow) * w + (root - rrow * wp);      // frame index of the root pixel
+              if (root == idx) { S.label[fbase + node] = node; S.count[fbase + node] = 0; }
+              const int slot = atomicAdd(&s_npend, 1);        // (a per-frame counter in global memory cost more than the rest of the kernel)
+              S.pend[sbase + slot] = make_int2((y0 + row) * w + x, node);
+              for (int side = 0; side < 2; ++side)
+                if (side == 0 ? (row == 0 && nb_top) : (row == nr - 1 && nb_bot)) {
+                  S.brow[((size_t)b * 2 * S.n_strips + 2 * strip + side) * w + x] = node;
+                  atomicOr(&s_pmask[side][x >> 5], 1u << (x & 31));
+                }
+            }
+          }
+        }
+      }
+    };
+    int qn = 0;
+    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
+      int dv[SPK_NS], dl[SPK_NS], lv[SPK_NS];
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const int x = (s0 + k) * 64 + lane;
+        const bool in = x < w;
+        dv[k] = in ? d[x] : FILTERED16; lv[k] = in ? l[x] : SPK_BIG + 1;
+        dl[k] = (in && x > 0) ? d[x - 1] : FILTERED16;
+      }
+#pragma unroll
+      for (int k = 0; k < SPK_NS; ++k) {
+        const bool on = dv[k] != FILTERED16 && lv[k] != SPK_BIG;
+        const unsigned long long m = __ballot(on);
+        if (m == 0) continue;
+        const int c = __popcll(m);
+        if (qn + c > 64) { flush(qn); qn = 0; }
+        if (on) q[qn + __popcll(m & lt_mask)] = ((s0 + k) * 64 + lane) | ((ccl_linked(dv[k], dl[k], range) ? 0 : 1) << 16);
+        qn += c;
+      }
+    }
+    flush(qn);
+  }
+  __syncthreads();
+  SPK_STAMP(5);
+  // ---- convert: the float disparity of the stage (four pixels per lane); the strip's first / last row publish -1 (filtered) / -2 (kept)
+  //      where no undecided node stands
+  const float sc = 1.f / (1 << DISP_SHIFT);
+  for (int g = tid; g < ng; g += SPK_THREADS) {
+    const int i0 = g * 4, row = g / gpr, x0 = (g - row * gpr) * 4;
+    int dq[4];
+    spk_unpack4(*reinterpret_cast<const uint2 *>(dsp + i0), dq);
+    float *o = out + (size_t)b * d_bstride + (size_t)(y0 + row) * dstride + x0;
+    if (vec && (dstride & 3) == 0 && (d_bstride & 3) == 0) *reinterpret_cast<float4 *>(o) = make_float4((float)dq[0] * sc, (float)dq[1] * sc, (float)dq[2] * sc, (float)dq[3] * sc);
+    else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (x0 + k < w) o[k] = (float)dq[k] * sc;
+    }
+#pragma unroll
+    for (int side = 0; side < 2; ++side)
+      if (side == 0 ? (row == 0 && nb_top) : (row == nr - 1 && nb_bot)) {
+        int32_t *br = S.brow + ((size_t)b * 2 * S.n_strips + 2 * strip + side) * w + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (x0 + k < w && !((s_pmask[side][(x0 + k) >> 5] >> ((x0 + k) & 31)) & 1u)) br[k] = dq[k] == FILTERED16 ? -1 : -2;
+      }
+  }
+  __syncthreads();
+  SPK_STAMP(6);
+  if (tid == 0) S.npend[b * S.n_strips + strip] = s_npend;
+}
+// unite the undecided components across strip boundaries.  grid: (n_strips - 1, batch), block 256
+__global__ __launch_bounds__(256) void stereo_speckle_merge_kernel(StereoDev S) {
+  const int w = S.w, b = blockIdx.y, k = blockIdx.x;            // boundary between strip k and k + 1
+  const int yb = (k + 1) * S.strip_rows - 1;                    // last row of strip k
+  const size_t fbase = (size_t)b * w * S.h;
+  const int32_t *na = S.brow + ((size_t)b * 2 * S.n_strips + 2 * k + 1) * w, *nb = S.brow + ((size_t)b * 2 * S.n_strips + 2 * k + 2) * w;
+  const int16_t *da = S.disp16 + fbase + (size_t)yb * w, *db = da + w;
+  int32_t *label = S.label + fbase;
+  for (int x = threadIdx.x; x < w; x += 256) {
+    const int a = na[x], c = nb[x];
+    if (a == -1 || c == -1 || (a == -2 && c == -2)) continue;
+    if (!ccl_linked(da[x], db[x], S.speckle_range)) continue;
+    ccl_union_b(label, a == -2 ? CCL_BIG : a, c == -2 ? CCL_BIG : c, S.err);
+  }
+}
+// pass 0: pixels per united root (saturating); pass 1: filter the pixels of the roots that stay small.  grid: (n_strips, batch), block 256
+__global__ __launch_bounds__(256) void stereo_speckle_resolve_kernel(StereoDev S, int pass, float *__restrict__ out, int dstride, size_t d_bstride) {
+  const int b = blockIdx.y, np = S.npend[b * S.n_strips + blockIdx.x], w = S.w;
+  const size_t fbase = (size_t)b * w * S.h, sbase = fbase + (size_t)blockIdx.x * S.strip_rows * w;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    const int2 e = S.pend[sbase + i];
+    const int root = ccl_find_b(S.label + fbase, e.y, S.err);
+    if (root < 0) continue;
+    if (pass == 0) { if (S.count[fbase + root] <= S.speckle_window) atomicAdd(&S.count[fbase + root], 1); }
+    else if (S.count[fbase + root] <= S.speckle_window) out[(size_t)b * d_bstride + (size_t)(e.x / w) * dstride + (e.x % w)] = (float)FILTERED16 * (1.f / (1 << DISP_SHIFT));
+  }
+}
+
 }  // namespace
 
 struct svs_stereo {
@@ -469,6 +858,11 @@ struct svs_stereo {
   int16_t *d_disp16 = nullptr;
   uint16_t *d_cost = nullptr;
   int32_t *d_label = nullptr, *d_count = nullptr;
+  int strip_rows = 0, n_strips = 0;                     // strip speckle filter (0: whole-frame path)
+  int32_t *d_brow = nullptr, *d_npend = nullptr;
+  int2 *d_pend = nullptr;
+  int debug = 0;                                      // SVS_STEREO_DEBUG=1 at create
+  int force_frame_ccl = 0;                            // SVS_STEREO_FRAME_CCL=1 at create: the whole-frame union-find path (tests compare the two)
 };
 
 extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out) {
@@ -480,6 +874,8 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
   }
   svs_stereo *s = new svs_stereo();
   s->ctx = ctx; s->w = w; s->h = h; s->max_batch = max_batch; s->pitch = (w + PADL + PADR + 3) & ~3; s->prm = *prm;
+  { const char *e = getenv("SVS_STEREO_FRAME_CCL"); s->force_frame_ccl = e && atoi(e) != 0; }
+  { const char *e = getenv("SVS_STEREO_DEBUG"); s->debug = e && atoi(e) != 0; }
   const size_t n = (size_t)w * h * max_batch, np = (size_t)s->pitch * h * max_batch + 64;
   SVS_HIP(ctx, hipMalloc(&s->d_lp, np));
   SVS_HIP(ctx, hipMalloc(&s->d_rp, np));
@@ -487,6 +883,20 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
   SVS_HIP(ctx, hipMalloc(&s->d_cost, n * sizeof(uint16_t)));
   SVS_HIP(ctx, hipMalloc(&s->d_label, n * sizeof(int32_t)));
   SVS_HIP(ctx, hipMalloc(&s->d_count, n * sizeof(int32_t)));
+  // strip speckle filter where a strip of >= 16 rows (labels 4 B + disparities 2 B per pixel) fits LDS, and the saturating run counts of
+  // SPK_THREADS concurrent adds stay below the mark bit
+  {
+    const int wp = (w + 3) & ~3;
+    const int rows = std::min(h, (150 * 1024) / (6 * wp));
+    if (rows >= 16 && w <= 64 * SPK_MAX_SEG && (size_t)rows * w < (1u << 24) && (long long)(SPK_THREADS + 1) * std::max(prm->speckle_window, w) < SPK_TOUCH) {
+      s->strip_rows = rows; s->n_strips = div_up(h, rows);
+      SVS_HIP(ctx, hipMalloc(&s->d_brow, sizeof(int32_t) * 2 * (size_t)s->n_strips * w * max_batch));
+      SVS_HIP(ctx, hipMalloc(&s->d_pend, sizeof(int2) * n));
+      SVS_HIP(ctx, hipMalloc(&s->d_npend, sizeof(int32_t) * ((size_t)max_batch * s->n_strips + 32)));
+      SVS_HIP(ctx, hipMemset(s->d_npend, 0, sizeof(int32_t) * ((size_t)max_batch * s->n_strips + 32)));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)stereo_speckle_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rows * wp * 6));
+    }
+  }
   *out = s;
   return SVS_OK;
 }
@@ -497,6 +907,7 @@ extern "C" int svs_stereo_destroy(svs_stereo *s) {
   if (s->d_lp) (void)hipFree(s->d_lp); if (s->d_rp) (void)hipFree(s->d_rp);
   if (s->d_disp16) (void)hipFree(s->d_disp16); if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_label) (void)hipFree(s->d_label); if (s->d_count) (void)hipFree(s->d_count);
+  if (s->d_brow) (void)hipFree(s->d_brow); if (s->d_pend) (void)hipFree(s->d_pend); if (s->d_npend) (void)hipFree(s->d_npend);
   delete s;
   return SVS_OK;
 }
@@ -526,6 +937,32 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   }
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
   const dim3 gp(div_up(n, 256), n_batch);
+  if (ccl && s->strip_rows > 0 && !s->force_frame_ccl) {
+    S.strip_rows = s->strip_rows; S.n_strips = s->n_strips; S.brow = s->d_brow; S.pend = s->d_pend; S.npend = s->d_npend; S.err = s->d_npend + (((size_t)s->max_batch * s->n_strips + 1) & ~(size_t)1); S.timing = s->debug;
+    hipLaunchKernelGGL(stereo_speckle_strip_kernel, dim3(s->n_strips, n_batch), dim3(SPK_THREADS), (size_t)s->strip_rows * ((w + 3) & ~3) * 6, ctx->stream, S, d_disp, dstride, d_bstride);
+    SVS_LAUNCH_CHECK(ctx);
+    if (s->n_strips > 1) {
+      hipLaunchKernelGGL(stereo_speckle_merge_kernel, dim3(s->n_strips - 1, n_batch), dim3(256), 0, ctx->stream, S);
+      for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(stereo_speckle_resolve_kernel, dim3(s->n_strips, n_batch), dim3(256), 0, ctx->stream, S, pass, d_disp, dstride, d_bstride);
+      SVS_LAUNCH_CHECK(ctx);
+    }
+    if (s->debug) {
+      int ev[24] = {};
+      SVS_HIP(ctx, hipMemcpyAsync(ev, S.err, sizeof(ev), hipMemcpyDeviceToHost, ctx->stream));
+      SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const int e = ev[0];
+      std::vector<int> np((size_t)n_batch * s->n_strips);
+      SVS_HIP(ctx, hipMemcpy(np.data(), s->d_npend, sizeof(int) * np.size(), hipMemcpyDeviceToHost));
+      long tot = 0; int mx = 0;
+      for (int v : np) { tot += v; mx = std::max(mx, v); }
+      { const long long *t = reinterpret_cast<const long long *>(ev + 8);
+        fprintf(stderr, "[svs_stereo] strip kernel phases of one workgroup (us): load %.1f runs %.1f stitch %.1f count %.1f classify %.1f convert %.1f\n", (t[1] - t[0]) * 0.01,
+                (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01); }
+      fprintf(stderr, "[svs_stereo] strip speckle filter: error mask %d, undecided pixels %ld in %d frames (max %d per strip)\n", e, tot, n_batch, mx);
+    }
+    return SVS_OK;
+  }
   if (ccl) {
     hipLaunchKernelGGL(stereo_ccl_runs_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * (2 * (size_t)w + 2 * (size_t)((w + 63) / 64)), ctx->stream, S);
     SVS_LAUNCH_CHECK(ctx);

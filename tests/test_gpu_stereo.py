@@ -96,3 +96,38 @@ def test_stereo_unsupported_parameters(gpu_ctx):
     h = C.c_void_p()
     rc = ctx.lib.svs_stereo_create(ctx.h, 640, 480, 1, C.byref(p), C.byref(h))
     assert rc == 5 and not h.value      # SVS_ERR_UNSUPPORTED, nothing allocated
+
+
+def test_speckle_filter_strips_many_frames_and_widths(gpu_ctx):
+    """The speckle filter works on strips of rows held in LDS and finishes the components that cross strip boundaries in three small
+    kernels: four 640x480 pairs in one batch (several calls: the first version re-walked from the BIG sentinel after a lost CAS and only
+    one of these pairs hit it), a width that is not a multiple of 4 with several strips, and images made of specks (noise pairs: nearly every
+    component is small, many straddle a boundary)."""
+    import oracle as O
+    from scavislam_amd import synth
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(5)
+    pairs = [synth.render_stereo(sc, synth.CAM_DEFAULT, traj[i], seed=10 + i) for i in range(4)]
+    for _ in range(2):
+        got = _run(gpu_ctx, synth.CAM_DEFAULT, [p[0] for p in pairs], [p[1] for p in pairs], _prm())
+        for (l, r, _t), g in zip(pairs, got):
+            assert np.array_equal(g, O.stereo_bm(l, r))
+    cam = dict(synth.CAM_DEFAULT)
+    cam.update(w=322, h=250, cx=161.0, cy=125.0, f=250.0, b=0.3)
+    l, r, _ = synth.render_stereo(sc, cam, traj[2], seed=5)
+    rng = np.random.default_rng(11)
+    nl = np.clip(l.astype(np.int32) + rng.integers(-40, 41, l.shape), 0, 255).astype(np.uint8)      # heavy noise: specks everywhere
+    nr_ = np.clip(r.astype(np.int32) + rng.integers(-40, 41, r.shape), 0, 255).astype(np.uint8)
+    got = _run(gpu_ctx, cam, [l, nl], [r, nr_], _prm())
+    for (a, b_), g in zip([(l, r), (nl, nr_)], got):
+        ref = O.stereo_bm(a, b_)
+        assert np.array_equal(g, ref), f"{(g != ref).sum()} px differ"
+    cam2 = dict(synth.CAM_DEFAULT)
+    rng = np.random.default_rng(12)
+    l2, r2, _ = pairs[1]
+    nl2 = np.clip(l2.astype(np.int32) + rng.integers(-30, 31, l2.shape), 0, 255).astype(np.uint8)
+    nr2 = np.clip(r2.astype(np.int32) + rng.integers(-30, 31, r2.shape), 0, 255).astype(np.uint8)
+    got = _run(gpu_ctx, cam2, [nl2], [nr2], _prm())[0]
+    ref = O.stereo_bm(nl2, nr2)
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} px differ"
+    assert 0.02 < (ref >= 0).mean() < 0.98
