@@ -204,18 +204,20 @@ __global__ __launch_bounds__(64) void stereo_bm_kernel(StereoDev S) {
 
 // columns X < 31 (never searched) and x in [0,3), whose right-image window clamps at column 0 BEFORE the disparity
 // shift (so it is not a contiguous byte window).  Half a wave per pixel: lane = disparity index d.
-// grid: (ceil(3*h/2), batch), block 64
-__global__ __launch_bounds__(64) void stereo_bm_edge_kernel(StereoDev S) {
-  const int b = blockIdx.y, w = S.w, h = S.h, lane = threadIdx.x, d = lane & 31;
+// grid: (ceil(3*h/8), batch), block 256 (eight pixels per workgroup: 92 000 two-pixel workgroups per 128 frames cost more in dispatch
+// than in arithmetic)
+constexpr int EDGE_THREADS = 256;
+__global__ __launch_bounds__(EDGE_THREADS) void stereo_bm_edge_kernel(StereoDev S) {
+  const int b = blockIdx.y, w = S.w, h = S.h, tid = threadIdx.x, lane = tid & 63, d = lane & 31;
   const int width1 = w - NDISP + 1, ncol = min(3, width1);
   {   // the never-searched left border, FILTERED
     const int n = (NDISP - 1) * h;
-    for (int i = blockIdx.x * 64 + lane; i < n; i += gridDim.x * 64) {
+    for (int i = blockIdx.x * EDGE_THREADS + tid; i < n; i += gridDim.x * EDGE_THREADS) {
       const size_t o = ((size_t)b * h + i / (NDISP - 1)) * w + i % (NDISP - 1);
       S.disp16[o] = (int16_t)FILTERED16; S.cost[o] = 0;
     }
   }
-  const int pix = blockIdx.x * 2 + (lane >> 5);
+  const int pix = blockIdx.x * (EDGE_THREADS / 32) + (tid >> 5);
   const bool act = pix < ncol * h;
   const int y = act ? pix / ncol : 0, x = act ? pix % ncol : 0;
   const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL, *rp = S.rp + (size_t)b * h * S.pitch + PADL;
@@ -925,7 +927,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 4), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
                      l_bstride, d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, 2), n_batch), dim3(64), 0, ctx->stream, S);
+  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, EDGE_THREADS / 32), n_batch), dim3(EDGE_THREADS), 0, ctx->stream, S);
   SVS_LAUNCH_CHECK(ctx);
   if (width1 > 3) {
     hipLaunchKernelGGL(stereo_bm_kernel, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
