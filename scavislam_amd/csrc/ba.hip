@@ -3535,6 +3535,7 @@ extern "C" int svs_ba_optimize_batch(svs_ba *const *bas, int n, svs_ba_stats *st
 extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->d_poses[0] && ba->problem_valid);
+  SVS_DEVICE(ctx);
   if (h_poses) SVS_HIP(ctx, hipMemcpyAsync(h_poses, ba->d_poses[ba->cur], sizeof(double) * 12 * (size_t)ba->P, hipMemcpyDeviceToHost, ctx->stream));
   if (h_psi && ba->L) SVS_HIP(ctx, hipMemcpyAsync(h_psi, ba->d_psi[ba->cur], sizeof(double) * 3 * (size_t)ba->L, hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));

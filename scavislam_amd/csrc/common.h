@@ -18,6 +18,10 @@ struct svs_ctx {
   // device scratch owned by the context (block partials, cross-workgroup hand-off words): grown on demand, freed with the ctx
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // the matcher's per-call tables (relative poses per (stream, keyframe), predictions per point): its own buffer, because the trackers'
+  // scratch above carries hand-off words across the launches of one call chain
+  void *match_scratch = nullptr;
+  size_t match_scratch_bytes = 0;
   // switches read ONCE at svs_ctx_create (debug / experiment only; never per call)
   int trk_nwg = 0;            // SVS_TRK_NWG: workgroups per stream of the latency-mode quarter-grid tracker (0 = automatic)
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
@@ -25,6 +29,7 @@ struct svs_ctx {
 };
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
+int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
 // every entry point that allocates or launches runs on the context's device, whatever the calling thread's current device is
 #define SVS_DEVICE(ctx) SVS_HIP(ctx, hipSetDevice((ctx)->device))
 

@@ -565,6 +565,7 @@ extern "C" int svs_pointcloud_cpu_sem(svs_ctx *ctx, const float *d_disp, int dis
                                       const svs_cam *cam, int level, const double *d_T, float *d_cloud,
                                       size_t cloud_bstride, int batch) {
   SVS_REQUIRE(ctx, ctx && d_disp && cam && d_T && d_cloud && level >= 0 && level < 3 && batch >= 1);
+  SVS_DEVICE(ctx);
   SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);            // dense_tracking.cpp:45-46 asserts
   int n = (cam->w / 4) * (cam->h / 4);
   hipLaunchKernelGGL(pointcloud_cpu_sem_kernel, dim3(div_up(n, 256), batch), dim3(256), 0, ctx->stream, d_disp, disp_stride,
@@ -578,6 +579,7 @@ extern "C" int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t
                                       const float *d_dy, int fstride, size_t f_bstride, const svs_cam *cam,
                                       const double *d_T, int do_jac, svs_dense_sums *d_out, int batch) {
   SVS_REQUIRE(ctx, ctx && d_cloud && d_prev_u8 && d_cur && cam && d_T && d_out && batch >= 1);
+  SVS_DEVICE(ctx);
   SVS_REQUIRE(ctx, !do_jac || (d_dx && d_dy));
   SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);
   LevelArgs L{d_cloud, d_prev_u8, d_cur, d_dx, d_dy, pstride, fstride, *cam, nullptr, 0};
@@ -599,6 +601,7 @@ extern "C" int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t
 extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out,
                                        int batch) {
   SVS_REQUIRE(ctx, ctx && a && d_T_io && batch >= 1);
+  SVS_DEVICE(ctx);
   TrackArgs A;
   const bool u8src = a->d_cur_u8[0] != nullptr;
   for (int l = 0; l < 3; ++l) {
@@ -644,6 +647,7 @@ extern "C" int svs_dense_residual_image_cpu_sem(svs_ctx *ctx, const float *d_clo
                                                 const uint8_t *d_cur_u8, int c8stride, size_t c8_bstride, const svs_cam *cam,
                                                 const double *d_T, size_t T_bstride, float *d_res_img4, size_t res_bstride, int batch) {
   SVS_REQUIRE(ctx, ctx && d_cloud && d_prev_u8 && (d_cur || d_cur_u8) && cam && d_T && d_res_img4 && batch >= 1);
+  SVS_DEVICE(ctx);
   SVS_REQUIRE(ctx, cam->w % 4 == 0 && cam->h % 4 == 0);
   LevelArgs L{d_cloud, d_prev_u8, d_cur, nullptr, nullptr, pstride, fstride, *cam, d_cur_u8, c8stride};
   const int n = (cam->w / 4) * (cam->h / 4);
@@ -890,6 +894,7 @@ extern "C" int svs_process_matched_points(svs_ctx *ctx, const svs_match_result *
                                           float max_reproj_error, svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats,
                                           int batch) {
   SVS_REQUIRE(ctx, ctx && cam && d_T && d_stats && batch >= 1 && n >= 0 && (n == 0 || (d_results && d_pts && d_gated)));
+  SVS_DEVICE(ctx);
   hipLaunchKernelGGL(gate_matched_kernel, dim3(batch), dim3(256), 0, ctx->stream, d_results, d_pts, n, res_bstride, pts_bstride, n_new_records,
                      *cam, d_T, max_reproj_error, d_gated, gated_bstride, d_stats);
   SVS_LAUNCH_CHECK(ctx);
@@ -899,6 +904,7 @@ extern "C" int svs_process_matched_points(svs_ctx *ctx, const svs_match_result *
 extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
                                const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch) {
   SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && batch >= 1 && n >= 0 && (n == 0 || d_results));
+  SVS_DEVICE(ctx);
   hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;

@@ -546,6 +546,7 @@ struct svs_fast {
 extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
                                const svs_fastgrid *grids, int batch, int cap, svs_fast **out) {
   SVS_REQUIRE(ctx, ctx && out && w && h && grids && n_levels >= 1 && n_levels <= SVS_NUM_PYR_LEVELS && batch >= 1 && cap >= 1);
+  SVS_DEVICE(ctx);
   svs_fast *f = new svs_fast();
   f->ctx = ctx; f->batch = batch;
   FastParams &P = f->P;
@@ -630,6 +631,7 @@ extern "C" int svs_fast_destroy(svs_fast *f) {
 extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const int32_t *stride, const size_t *bstride,
                                int n_batch, int trials) {
   SVS_REQUIRE(f ? f->ctx : nullptr, f && d_img && stride && bstride && n_batch >= 1 && n_batch <= f->batch && trials >= 0);
+  SVS_DEVICE(f->ctx);
   svs_ctx *ctx = f->ctx;
   ImgPtrs I{};
   for (int l = 0; l < f->P.n_levels; ++l) { I.img[l] = d_img[l]; I.stride[l] = stride[l]; I.bstride[l] = bstride[l]; }
@@ -668,6 +670,7 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
 extern "C" int svs_fast_download(svs_fast *f, int slot, int level, int16_t *h_xy, int cap, int32_t *h_n,
                                  int32_t *h_cell_count, int32_t *h_emit_thr, int32_t *h_thr_state) {
   SVS_REQUIRE(f ? f->ctx : nullptr, f && slot >= 0 && slot < f->batch && level >= 0 && level < f->P.n_levels);
+  SVS_DEVICE(f->ctx);
   svs_ctx *ctx = f->ctx;
   const FastParams &P = f->P;
   const LevelDev &L = P.lv[level];
@@ -690,6 +693,7 @@ extern "C" int svs_fast_download(svs_fast *f, int slot, int level, int16_t *h_xy
 
 extern "C" int svs_fast_set_thresholds(svs_fast *f, int slot, int level, const int32_t *h_thr) {
   SVS_REQUIRE(f ? f->ctx : nullptr, f && h_thr && slot >= 0 && slot < f->batch && level >= 0 && level < f->P.n_levels);
+  SVS_DEVICE(f->ctx);
   svs_ctx *ctx = f->ctx;
   const LevelDev &L = f->P.lv[level];
   int nc = L.gx * L.gy;

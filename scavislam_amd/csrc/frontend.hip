@@ -147,6 +147,7 @@ extern "C" int svs_frontend_create(svs_ctx *ctx, const svs_cam *cam, const svs_f
 extern "C" int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate_point *h_pts, int n, int n_new_records) {
   svs_ctx *ctx = fe ? fe->ctx : nullptr;
   SVS_REQUIRE(ctx, fe && n >= 0 && n <= fe->max_points && (n == 0 || h_pts) && n_new_records >= 0 && n_new_records <= n);
+  SVS_DEVICE(ctx);
   for (int i = 0; i < n; ++i) SVS_REQUIRE(ctx, h_pts[i].kf_index >= 0 && h_pts[i].kf_index < fe->max_keyframes);
   if (n) SVS_HIP(ctx, hipMemcpyAsync(fe->d_pts, h_pts, sizeof(svs_candidate_point) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));      // h_pts may be pageable and reused by the caller
@@ -157,6 +158,7 @@ extern "C" int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate
 extern "C" int svs_frontend_keep_keyframe(svs_frontend *fe, int slot, const double *T_kf_from_w) {
   svs_ctx *ctx = fe ? fe->ctx : nullptr;
   SVS_REQUIRE(ctx, fe && T_kf_from_w && slot >= 0 && slot < fe->max_keyframes && fe->have_prev);
+  SVS_DEVICE(ctx);
   // Frame::clone of the frame processed last (it sits in the "previous" slot after the swap at the end of process_frame)
   const int src = 1 - fe->cur;
   uint8_t *base = fe->d_kf_pyr + fe->kf_bytes * (size_t)slot;

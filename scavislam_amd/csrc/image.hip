@@ -33,6 +33,7 @@ extern "C" int svs_ctx_destroy(svs_ctx *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->match_scratch) (void)hipFree(c->match_scratch);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SVS_OK;
@@ -47,6 +48,18 @@ int svs_ctx_scratch(svs_ctx *c, size_t bytes, void **out) {
     c->scratch_bytes = want;
   }
   *out = c->scratch;
+  return SVS_OK;
+}
+int svs_ctx_match_scratch(svs_ctx *c, size_t bytes, void **out) {
+  SVS_REQUIRE(c, c && out);
+  if (c->match_scratch_bytes < bytes) {
+    SVS_DEVICE(c);
+    if (c->match_scratch) { SVS_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->match_scratch); c->match_scratch = nullptr; c->match_scratch_bytes = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    SVS_HIP(c, hipMalloc(&c->match_scratch, want));
+    c->match_scratch_bytes = want;
+  }
+  *out = c->match_scratch;
   return SVS_OK;
 }
 extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
@@ -70,19 +83,23 @@ extern "C" int svs_malloc(svs_ctx *c, size_t bytes, void **p) {
 extern "C" int svs_free(svs_ctx *c, void *p) { SVS_REQUIRE(c, c); if (p) SVS_HIP(c, hipFree(p)); return SVS_OK; }
 extern "C" int svs_memcpy_h2d(svs_ctx *c, void *d, const void *h, size_t n) {
   SVS_REQUIRE(c, c);
+  SVS_DEVICE(c);
   SVS_HIP(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
   SVS_HIP(c, hipStreamSynchronize(c->stream));  // h may be pageable and reused by the caller
   return SVS_OK;
 }
 extern "C" int svs_memcpy_d2h(svs_ctx *c, void *h, const void *d, size_t n) {
   SVS_REQUIRE(c, c);
+  SVS_DEVICE(c);
   SVS_HIP(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
   SVS_HIP(c, hipStreamSynchronize(c->stream));
   return SVS_OK;
 }
-extern "C" int svs_timer_start(svs_ctx *c) { SVS_REQUIRE(c, c); SVS_HIP(c, hipEventRecord(c->ev0, c->stream)); return SVS_OK; }
+extern "C" int svs_timer_start(svs_ctx *c) { SVS_REQUIRE(c, c);
+  SVS_DEVICE(c); SVS_HIP(c, hipEventRecord(c->ev0, c->stream)); return SVS_OK; }
 extern "C" int svs_timer_stop_ms(svs_ctx *c, float *ms) {
   SVS_REQUIRE(c, c && ms);
+  SVS_DEVICE(c);
   SVS_HIP(c, hipEventRecord(c->ev1, c->stream));
   SVS_HIP(c, hipEventSynchronize(c->ev1));
   SVS_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -186,6 +203,7 @@ __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restr
 extern "C" int svs_pyr_down_u8(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride,
                                uint8_t *d_dst, int dstride, size_t d_bstride, int batch) {
   SVS_REQUIRE(ctx, ctx && d_src && d_dst && w >= 3 && h >= 3 && batch >= 1);
+  SVS_DEVICE(ctx);
   int dw = (w + 1) / 2, dh = (h + 1) / 2;
   dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
   hipLaunchKernelGGL(pyr_down_u8_kernel, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw,
@@ -241,6 +259,7 @@ extern "C" int svs_convert_sobel_f32(svs_ctx *ctx, const uint8_t *d_src, int w, 
                                      float *d_img, float *d_dx, float *d_dy, int fstride, size_t f_bstride,
                                      int batch) {
   SVS_REQUIRE(ctx, ctx && d_src && d_img && d_dx && d_dy && w >= 2 && h >= 2 && batch >= 1);
+  SVS_DEVICE(ctx);
   dim3 block(64), grid(div_up(div_up(w, 4), 64), h, batch);
   hipLaunchKernelGGL(convert_sobel_kernel, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_img,
                      d_dx, d_dy, fstride, f_bstride);

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
 
 extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out) {
   SVS_REQUIRE(ctx, ctx && a && f);
+  SVS_DEVICE(ctx);
   SVS_REQUIRE(ctx, a->n_pts >= 0 && a->n_batch >= 1 && a->search_radius >= 0 && a->search_radius <= 31);
   if (a->n_pts == 0) return SVS_OK;                 // empty ap_map: nothing to append (matcher.cpp:332)
   SVS_REQUIRE(ctx, d_out && a->d_pts && a->d_kfs);
@@ -369,27 +370,14 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   M.a = *a;
   M.fv = svs_fast_view_internal(f);
   SVS_REQUIRE(ctx, M.fv.n_levels >= 1 && a->n_kf >= 1);
-  // per-ctx scratch for the (stream, keyframe) relative poses (one ctx per calling thread)
-  static thread_local svs_ctx *owner = nullptr;
-  static thread_local double *kf_T = nullptr;
-  static thread_local size_t kf_T_n = 0;
-  const size_t need = (size_t)a->n_batch * a->n_kf * 24;
-  if (owner != ctx || kf_T_n < need) {
-    if (kf_T) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(kf_T); kf_T = nullptr; kf_T_n = 0; }
-    SVS_HIP(ctx, hipMalloc(&kf_T, need * sizeof(double)));
-    kf_T_n = need; owner = ctx;
-  }
+  // the per-call tables live in the context (one buffer: relative poses per (stream, keyframe), then the predictions per point)
+  const size_t kf_bytes = (((size_t)a->n_batch * a->n_kf * 24 * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t pred_bytes = (size_t)a->n_batch * a->n_pts * sizeof(PointPred);
+  void *buf = nullptr;
+  { const int rc = svs_ctx_match_scratch(ctx, kf_bytes + pred_bytes, &buf); if (rc) return rc; }
+  double *kf_T = static_cast<double *>(buf);
   M.kf_T = kf_T;
-  static thread_local svs_ctx *owner_p = nullptr;
-  static thread_local PointPred *pred = nullptr;
-  static thread_local size_t pred_n = 0;
-  const size_t need_p = (size_t)a->n_batch * a->n_pts;
-  if (owner_p != ctx || pred_n < need_p) {
-    if (pred) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(pred); pred = nullptr; pred_n = 0; }
-    SVS_HIP(ctx, hipMalloc(&pred, need_p * sizeof(PointPred)));
-    pred_n = need_p; owner_p = ctx;
-  }
-  M.pred = pred;
+  M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + kf_bytes);
   hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, *a, kf_T);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);

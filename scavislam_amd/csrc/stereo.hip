@@ -869,6 +869,7 @@ struct svs_stereo {
 
 extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out) {
   SVS_REQUIRE(ctx, ctx && prm && out && w > 0 && h > 0 && max_batch > 0);
+  SVS_DEVICE(ctx);
   if (prm->sad_window != 7 || prm->min_disparity != 0 || prm->num_disparities != NDISP || prm->prefilter_cap < 1 || prm->prefilter_cap > 63 ||
       w < NDISP + 2 * WSZ2 || w > 65535 || h < 2 || prm->speckle_window > 65535) {
     ctx->err = "svs_stereo: only SADWindowSize 7, minDisparity 0, numberOfDisparities 32, preFilterCap 1..63, w >= 38 are supported";
@@ -918,6 +919,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
                                   size_t r_bstride, float *d_disp, int dstride, size_t d_bstride, int n_batch) {
   svs_ctx *ctx = s ? s->ctx : nullptr;
   SVS_REQUIRE(ctx, s && d_left && d_right && d_disp && n_batch >= 1 && n_batch <= s->max_batch && lstride >= s->w && rstride >= s->w && dstride >= s->w);
+  SVS_DEVICE(ctx);
   StereoDev S{};
   S.w = s->w; S.h = s->h; S.pitch = s->pitch;
   S.cap = s->prm.prefilter_cap; S.texthr = s->prm.texture_threshold; S.uniq = s->prm.uniqueness_ratio;
