@@ -79,6 +79,9 @@ __device__ __forceinline__ double shr1_keep(double x, unsigned keep) {
 // LDS pipeline, which the Schur kernel's atomics already saturate (27 values x 4 x 2 = 216 per wave were 5 us of its 40,
 // SVS_BA_DEBUG=2 timeline).  The hand-over goes through `slot` (SEG_SLOT doubles of LDS per lane, 16-byte aligned): 9 wide
 // writes by the tail lanes + 9 wide reads instead of 54 bpermutes.
+// (Measured alternatives at 50 KF / 20k, against 2.7 us per wave for this form: a column sum through LDS -- every lane parks its values,
+// one lane per column walks the segment's rows -- 4.3 us, ~40 dependent read groups per lane; ds_add_f64 of the 27 values into the
+// segment's first slot -- 4.1 us, the seven waves of a workgroup queue on the LDS pipeline.)
 constexpr int SEG_SLOT = 18;
 template <int N, int NB>
 __device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int seg_begin, int seg_end, int maxlen, double *wave_slots) {
