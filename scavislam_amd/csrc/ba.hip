@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void ba_wide_landmark_kernel(BaDev B)
 // panel row and the rhs live in LDS.  A = U^T U, U upper.  Fused forward substitution; column
 // oriented back substitution.  Then T_trial = exp(x_p) T, scale_p, bookkeeping scalars.
 constexpr int SOLVE_THREADS = 256;
+constexpr int GRID_NBAR = 16;        // arrival counters of the multi-workgroup solve (bar[32 i], failure flag at bar[32 GRID_NBAR])
 constexpr int SOLVE_MAX_P = 256;
 
 __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   // exp(x) * T  (G2oVertexSE3::oplusImpl)
@@ -1332,6 +1333,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
 // the solve's failure path (the LM trial is then rejected like a non-positive pivot).
 __device__ __forceinline__ void g_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double g_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double bcast_f64(double v, int l) {      // value of lane l (wave-uniform l)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, double *__restrict__ x_out, double *__restrict__ linv_ws,
                                                                       const int *__restrict__ rowmax, unsigned *__restrict__ bar, unsigned epoch0) {
   extern __shared__ double smem[];
@@ -1344,68 +1348,109 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
   if (tid == 0) s_fail = 0;
   if (wg == 0) for (int i = tid; i < n; i += SOLVE_THREADS) s_b[i] = B.bp[i] - B.bs[i];
   __syncthreads();
+  // Everything a step reads from H -- the pivot block, the panel row, this lane's trailing tiles -- was completed by the previous step's
+  // arrival, and every such load bypasses the caches (other workgroups wrote the data) at the price of a memory round trip of ~2 us.
+  // So a step issues ALL of its loads first and works from registers: one round trip per step instead of three dependent ones
+  // (pivot block -> panel row -> trailing tiles; 13.5 -> 9 us per block row at 224 block columns).
+  constexpr int NIT = (SOLVE_MAX_P * 6 + SOLVE_THREADS - 1) / SOLVE_THREADS;       // panel columns per lane
+  long long acc_t[6] = {0, 0, 0, 0, 0, 0};      // workgroup 0, lane 0: where the time of a step goes (SVS_BA_DEBUG=1)
   for (int k = 0; k < P; ++k) {
+    long long ts = wall_clock64();
+#define GRID_LAP(i) do { const long long tn = wall_clock64(); acc_t[i] += tn - ts; ts = tn; } while (0)
     const long kk = blk_index(k, k, P);
-    if (tid == 0) {
-      double A[36], U[36], Li[36];
+    const int nj = rowmax[k] - k;
+    const long nblk = (long)nj * (nj + 1) / 2, stride = (long)G * SOLVE_THREADS;
+    // ---- loads: pivot block (lane 0), panel columns, the first three trailing tile rows of this lane
+    double Acol[6] = {0, 0, 0, 0, 0, 0};         // lane c < 6: column c of the pivot block's upper triangle
+    if (tid < 6) {
       const double *Akk = B.H + kk * 36;
 #pragma unroll
       for (int r = 0; r < 6; ++r)
+        if (r <= tid) { double v = g_ld(Akk + 6 * r + tid); if (r == tid) v += B.lambda; Acol[r] = v; }
+    }
+    double a[NIT][6];
 #pragma unroll
-        for (int c = r; c < 6; ++c) { double v = g_ld(Akk + 6 * r + c); if (r == c) v += B.lambda; A[6 * r + c] = v; }
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * SOLVE_THREADS;
+      if (e < nj * 6) {
+        const int jj = e / 6, c = e - jj * 6;
+        const double *Akj = B.H + (kk + 1 + jj) * 36;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[it][q] = g_ld(Akj + 6 * q + c);
+      }
+    }
+    double *Aij[3];
+    int ti[3], tj[3], tr[3];
+    double acc[3][6];
+    auto tile_of = [&](long e, int u) {      // tile row e = (block (ii, jj) of the trailing triangle, row r): index + loads
+      Aij[u] = nullptr;
+      if (e < nblk * 6) {
+        const long bidx = e / 6;
+        tr[u] = (int)(e - bidx * 6);
+        int i_ = (int)((2.0 * nj + 1.0 - sqrt((2.0 * nj + 1.0) * (2.0 * nj + 1.0) - 8.0 * (double)bidx)) * 0.5);
+        while ((long)i_ * nj - (long)i_ * (i_ - 1) / 2 > bidx) --i_;
+        while ((long)(i_ + 1) * nj - (long)(i_ + 1) * i_ / 2 <= bidx) ++i_;
+        ti[u] = i_;
+        tj[u] = i_ + (int)(bidx - ((long)i_ * nj - (long)i_ * (i_ - 1) / 2));
+        Aij[u] = B.H + blk_index(k + 1 + ti[u], k + 1 + tj[u], P) * 36 + 6 * tr[u];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[u][c] = g_ld(Aij[u] + c);
+      }
+    };
+    const long e_first = (long)wg * SOLVE_THREADS + tid;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) tile_of(e_first + u * stride, u);
+    // ---- pivot block: U_kk and (U_kk^T)^-1 in every workgroup (cheaper than handing them around), lane c of wave 0 = column c,
+    //      the elements of other columns by readlane: six short steps instead of ~600 dependent instructions on one lane
+    if (tid < 64) {
+      const int c = tid;
+      double Ucol[6] = {0, 0, 0, 0, 0, 0}, rdv[6];      // U[q][c], q <= c
       int fail = 0;
 #pragma unroll
-      for (int i = 0; i < 36; ++i) { U[i] = 0; Li[i] = 0; }
-      double rd[6];
-#pragma unroll
       for (int j = 0; j < 6; ++j) {
-        double d = A[6 * j + j];
+        double sv = Acol[j];                              // A[j][c], meaningful for c >= j
 #pragma unroll
-        for (int q = 0; q < j; ++q) d -= U[6 * q + j] * U[6 * q + j];
+        for (int q = 0; q < j; ++q) sv -= bcast_f64(Ucol[q], j) * Ucol[q];      // U[q][j] U[q][c]
+        double d = bcast_f64(sv, j);
         if (!(d > 0) || !isfinite(d)) { fail = 1; d = 1; }
         d = sqrt(d);
-        U[6 * j + j] = d;
-        rd[j] = 1.0 / d;
-#pragma unroll
-        for (int c = j + 1; c < 6; ++c) {
-          double sv = A[6 * j + c];
-#pragma unroll
-          for (int q = 0; q < j; ++q) sv -= U[6 * q + j] * U[6 * q + c];
-          U[6 * j + c] = sv * rd[j];
-        }
+        rdv[j] = 1.0 / d;
+        Ucol[j] = c == j ? d : (c > j ? sv * rdv[j] : 0.0);
       }
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int r = c; r < 6; ++r) {
-          double sv = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-          for (int q = c; q < r; ++q) sv -= U[6 * q + r] * Li[6 * q + c];
-          Li[6 * r + c] = sv * rd[r];
-        }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) s_linv[i] = Li[i];
-      if (wg == 0) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) linv_ws[(size_t)k * 36 + i] = Li[i];
-      }
-      if (fail) s_fail = 1;
-    }
-    __syncthreads();
-    if (s_fail) break;                             // every workgroup takes the same decision from the same pivot block
-    const int nj = rowmax[k] - k;
-    for (int e = tid; e < nj * 6; e += SOLVE_THREADS) {        // panel: U_kj = Li * A_kj, one thread per (block, column)
-      const int jj = e / 6, c = e - jj * 6;
-      const double *Akj = B.H + (kk + 1 + jj) * 36;
-      double a[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) a[q] = g_ld(Akj + 6 * q + c);
+      double Lic[6];                                      // (U^T)^-1 [r][c], r >= c
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        double sv = 0;
+        double sv = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q <= r; ++q) sv += s_linv[6 * r + q] * a[q];
-        s_panel[(size_t)jj * 36 + 6 * r + c] = sv;
+        for (int q = 0; q < r; ++q) sv -= bcast_f64(Ucol[q], r) * Lic[q];      // U[q][r] Li[q][c] (Li[q][c] = 0 for q < c)
+        Lic[r] = r >= c ? sv * rdv[r] : 0.0;
+      }
+      if (c < 6) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_linv[6 * r + c] = Lic[r];
+        if (wg == 0) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) linv_ws[(size_t)k * 36 + 6 * r + c] = Lic[r];
+        }
+      }
+      if (fail && c == 0) s_fail = 1;
+    }
+    __syncthreads();
+    GRID_LAP(0);
+    if (s_fail) break;                             // every workgroup takes the same decision from the same pivot block
+    // ---- panel: U_kj = Li * A_kj, one lane per (block, column)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * SOLVE_THREADS;
+      if (e < nj * 6) {
+        const int jj = e / 6, c = e - jj * 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double sv = 0;
+#pragma unroll
+          for (int q = 0; q <= r; ++q) sv += s_linv[6 * r + q] * a[it][q];
+          s_panel[(size_t)jj * 36 + 6 * r + c] = sv;
+        }
       }
     }
     __syncthreads();
@@ -1423,42 +1468,55 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
         s_b[6 * (k + 1 + jj) + c] -= sv;
       }
     }
-    // trailing update inside the envelope, dealt to all lanes of all workgroups: one lane per (tile, row)
-    const long nblk = (long)nj * (nj + 1) / 2;
-    for (long e = (long)wg * SOLVE_THREADS + tid; e < nblk * 6; e += (long)G * SOLVE_THREADS) {
-      const long bidx = e / 6;
-      const int r = (int)(e - bidx * 6);
-      int ii = (int)((2.0 * nj + 1.0 - sqrt((2.0 * nj + 1.0) * (2.0 * nj + 1.0) - 8.0 * (double)bidx)) * 0.5);
-      while ((long)ii * nj - (long)ii * (ii - 1) / 2 > bidx) --ii;
-      while ((long)(ii + 1) * nj - (long)(ii + 1) * ii / 2 <= bidx) ++ii;
-      const int jj = ii + (int)(bidx - ((long)ii * nj - (long)ii * (ii - 1) / 2));
-      double xi[6];
+    GRID_LAP(1);
+    // ---- trailing update inside the envelope, dealt to all lanes of all workgroups: one lane per (tile, row), three per trip
+    for (long e0 = e_first;; e0 += 3 * stride) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) xi[q] = s_panel[(size_t)ii * 36 + 6 * q + r];
-      double *Aij = B.H + blk_index(k + 1 + ii, k + 1 + jj, P) * 36 + 6 * r;
-      double acc[6];
+      for (int u = 0; u < 3; ++u) {
+        if (Aij[u]) {
+          double xi[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[c] = g_ld(Aij + c);
+          for (int q = 0; q < 6; ++q) xi[q] = s_panel[(size_t)ti[u] * 36 + 6 * q + tr[u]];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double sv = 0;
+          for (int c = 0; c < 6; ++c) {
+            double sv = 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) sv += xi[q] * s_panel[(size_t)jj * 36 + 6 * q + c];
-        g_st(Aij + c, acc[c] - sv);
+            for (int q = 0; q < 6; ++q) sv += xi[q] * s_panel[(size_t)tj[u] * 36 + 6 * q + c];
+            g_st(Aij[u] + c, acc[u][c] - sv);
+          }
+        }
       }
+      if (e0 + 3 * stride >= nblk * 6) break;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) tile_of(e0 + (3 + u) * stride, u);      // (only windows with few workgroups get here)
     }
     // arrival: this workgroup's tiles of step k are on their way; wait until everybody's are
+    GRID_LAP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && k + 1 < P) {
-      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned want = epoch0 + (unsigned)G * (unsigned)(k + 1);
+    GRID_LAP(3);
+    // GRID_NBAR counters, 128 bytes apart, workgroup w arrives on counter w % GRID_NBAR: 256 same-address device-scope atomics per step
+    // serialise at the memory side (3 of the 16 us a step took); 16 per counter do not.  Wave 0 polls, one counter per lane.
+    if (tid < 64 && k + 1 < P) {
+      if (tid == 0) __hip_atomic_fetch_add(bar + 32 * (wg % GRID_NBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool mine = tid < GRID_NBAR && tid < G;
+      const unsigned n_here = mine ? (unsigned)((G - tid + GRID_NBAR - 1) / GRID_NBAR) : 0u;      // workgroups that arrive on this lane's counter
+      const unsigned want = epoch0 + n_here * (unsigned)(k + 1);
       long spin = 0;
-      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && ++spin < (1l << 22)) __builtin_amdgcn_s_sleep(1);
-      if (spin >= (1l << 22)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_fail = 2;
+      bool late = false;
+      for (;;) {
+        const unsigned v = mine ? __hip_atomic_load(bar + 32 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+        if (__all((int)(v - want) >= 0)) break;
+        if (++spin >= (1l << 22)) { late = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (tid == 0) {
+        if (late) __hip_atomic_store(bar + 32 * GRID_NBAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(bar + 32 * GRID_NBAR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_fail = 2;
+      }
     }
     __syncthreads();
+    GRID_LAP(4);
     if (s_fail) break;
     // U_k* for the back substitution replaces A_k* only now: before the arrival above a slower workgroup could still be reading A_k*
     // for its own copy of the panel row
@@ -1466,6 +1524,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
       for (int e = tid; e < nj * 36; e += SOLVE_THREADS) g_st(B.H + (kk + 1) * 36 + e, s_panel[e]);
       __syncthreads();                              // s_panel is overwritten by the next step's panel
     }
+    GRID_LAP(5);
   }
   if (wg != 0) return;
   const int fail = s_fail;
@@ -1481,7 +1540,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
         const int jj = e / 6, c = e - jj * 6;
         const double xv = s_b[6 * (k + 1 + jj) + c];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) part[r] += g_ld(Uk + (size_t)jj * 36 + 6 * r + c) * xv;
+        for (int r = 0; r < 6; ++r) part[r] += Uk[(size_t)jj * 36 + 6 * r + c] * xv;      // plain loads: every U row was written by THIS workgroup (write-through), nothing of it sits in this CU's L1
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) part[r] = wave_sum_f64(part[r]);
@@ -1514,7 +1573,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
     d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
     for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
   }
-  if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
+  if (tid == 0) {
+    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+    // loads + pivot | panel + rhs | trailing issue | store drain | arrival | write-back  (read as: init, forward, load+row update, eliminate, -, barrier wait)
+    B.scal[5] = acc_t[0] * 0.01; B.scal[6] = acc_t[1] * 0.01; B.scal[8] = acc_t[2] * 0.01; B.scal[9] = acc_t[3] * 0.01; B.scal[10] = acc_t[5] * 0.01; B.scal[11] = acc_t[4] * 0.01; B.scal[7] = 0;
+  }
 }
 
 // ---- LDS-window variant of the solve -------------------------------------------------------------
@@ -2328,7 +2391,7 @@ class HostPool {
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
   int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, debug = 0;
-  int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0;
+  int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
 };
 int svs_comm_allreduce_hook(void *d_buf, size_t count, void *user);      // comm.hip
 // waves per workgroup of the Schur kernel: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
@@ -3215,8 +3278,9 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   if (!ba->use_lds_solve && !ba->opt.no_grid_solve && R >= 40) {
     const long tile_rows = (long)R * (R + 1) / 2 * 6;
     ba->grid_G = (int)std::max(8l, std::min((long)ctx->n_cu, (tile_rows + 4 * SOLVE_THREADS - 1) / (4 * SOLVE_THREADS)));
+    if (ba->opt.grid_g > 0) ba->grid_G = std::min(ba->opt.grid_g, ctx->n_cu);      // experiments only
     if (!ba->d_gridbar) {
-      SVS_HIP(ctx, hipMalloc(&ba->d_gridbar, sizeof(unsigned) * 4));
+      SVS_HIP(ctx, hipMalloc(&ba->d_gridbar, sizeof(unsigned) * (32 * GRID_NBAR + 4)));
     }
     const size_t smem_g = sizeof(double) * ((size_t)P * 36 + 36 + 6 * (size_t)P);
     if (smem_g > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
@@ -3344,7 +3408,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
   else if (ba->grid_G > 0) {
     const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
-    SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * 4, ctx->stream));      // arrival counter + failure flag of this launch (a speculative
+    SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
     hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
   }
   else
@@ -3574,6 +3638,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "nw") o.nw = value == 0 ? 0 : clamp(value, 4, 8);
   else if (n == "p1") o.p1 = value < 0 ? -1 : clamp(value, 0, SOLVE_MAX_P);
   else if (n == "group") o.group = value == 0 ? 0 : clamp(value, 1, WIN);
+  else if (n == "grid_g") o.grid_g = clamp(value, 0, 1024);
   else if (n == "host_threads") o.host_threads = clamp(value, 0, 64);
   else SVS_REQUIRE(ctx, !"unknown option");
   ba->profile_ready = false;            // solve-kernel choice depends on the switches
