@@ -437,7 +437,7 @@ int svs_ba_optimize_batch(svs_ba *const *bas, int n, svs_ba_stats *stats);
 /* restoreDataFromG2o (slam_graph.cpp:1035-1058): poses [P][12], psi [L][3] */
 int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
 /* landmark-sharded operation over a library-owned communicator: svs_ba_optimize(ba, NULL, NULL, stats) then all-reduces the
-   packed reduced system and the two trial scalars of every LM trial (and, once per problem, the co-visibility pattern) with
+   packed reduced system and the two trial sums of every LM trial (32 doubles: each sum is kept in 16 partial slots) (and, once per problem, the co-visibility pattern) with
    ncclAllReduce on the ctx stream.  comm == NULL detaches.  A non-NULL `allreduce` argument of svs_ba_optimize takes precedence
    (test hook). */
 int svs_ba_set_comm(svs_ba *ba, svs_comm *comm);

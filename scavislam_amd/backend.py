@@ -11,7 +11,7 @@ edges, pose-pose constraints.
 Multi-GPU: landmarks shard across ranks, each rank reduces its own landmarks into a
 partial reduced camera system, ONE all-reduce (RCCL through torch.distributed; "nccl" backend on
 ROCm) sums the packed system, every rank runs the identical 6Px6P Cholesky, back-substitutes its
-own landmarks; two scalars per LM trial are all-reduced for the accept/reject decision.
+own landmarks; two sums per LM trial (32 doubles: 16 partial slots each) are all-reduced for the accept/reject decision.
 """
 import ctypes as C
 

@@ -43,6 +43,10 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v) {
 // of the WIN x WIN pose window (plus b_p / b_s rows) lives in LDS; contributions whose poses fall
 // outside the window go straight to global atomics.  Landmarks are processed sorted by anchor,
 // so a workgroup's landmarks touch a narrow band of poses and nearly everything lands in LDS.
+// Trial scalars (d_scal): [2] scale_p [3] fail [4] chi2_cur copy [5..11] solve phase times; the sums every workgroup contributes to --
+// chi2 at the trial state and x_l (lambda x_l + b_l) -- are spread over SC_SLOTS words each (a workgroup adds to slot blockIdx % 16:
+// hundreds of same-address f64 atomics serialise at the memory side) and folded by their readers
+constexpr int SC_SLOTS = 16, SC_CHI = 16, SC_SCL = 32, SC_N = 48;
 constexpr int DBG_N = 10;   // phase stamps per wave of the Schur kernel timeline (SVS_BA_DEBUG=2)
 constexpr int DBG_X = 8;    // + per-wave structure words: landmarks, same-address multiplicity of the observer / anchor adds, pair rounds
 constexpr int DBG_W = DBG_N + DBG_X;
@@ -239,7 +243,7 @@ struct BaDev {
   const svs_ba_constraint *cons;
   double *H;                            // packed upper blocks [nblk][36]
   double *bp, *bs;                      // [6P] pure b, Schur correction
-  double *chi2_cur;                     // [1]
+  double *chi2_cur;                     // [SC_SLOTS] partial sums of chi2 at the current state (a workgroup adds to slot blockIdx % SC_SLOTS)
   const double *x;                      // [6P] pose solution
   double *scal;                         // [0]=chi2_trial [1]=scale_l [2]=scale_p [3]=fail [4]=chi2_cur copy
   svs_cam cam;
@@ -252,6 +256,7 @@ struct BaDev {
   const int *wide_start, *wide_len;     // their edge ranges (behind the chunked edges)
   int wide_split;                       // workgroups per wide landmark in the Schur pass (they share its pair rounds)
 };
+__device__ __forceinline__ double chi2_cur_sum(const BaDev &B) { double t = 0; for (int i = 0; i < SC_SLOTS; ++i) t += B.chi2_cur[i]; return t; }
 
 // ---- pose-pose constraints: G2oEdgeSE3 (anchored_points.cpp:207-235) -------------------------
 __device__ void d_so3_log(const double *R, double *w, double &theta) {
@@ -314,8 +319,8 @@ __device__ __forceinline__ void ba_constraint_body(const BaDev &B, int c, double
   double oe[6], e2 = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) { oe[i] = 0; for (int j = 0; j < 6; ++j) oe[i] += cc.info[6 * i + j] * err[j]; e2 += err[i] * oe[i]; }
-  if (MODE == 1) { if (lane == 0) atomic_add_f64(&B.scal[0], e2); return; }
-  if (lane == 0) atomic_add_f64(B.chi2_cur, e2);
+  if (MODE == 1) { if (lane == 0) atomic_add_f64(&B.scal[SC_CHI + (c & (SC_SLOTS - 1))], e2); return; }
+  if (lane == 0) atomic_add_f64(B.chi2_cur + (c & (SC_SLOTS - 1)), e2);
   const int i = lane / 6, j = lane - 6 * i;             // lanes 0..35 own element (i,j)
   const bool on = lane < 36;
   // Adj(T21) = [[R, t^R],[0, R]];  d_lieBracketab_by_d_a(d) = -ad_d   
@@ -387,8 +392,10 @@ __global__ __launch_bounds__(64) void ba_constraint_kernel(BaDev B) {
 __device__ __forceinline__ void ba_lm_decide(const BaDev &B, int it) {
   double *rec = B.ctl + 8 + 8 * it;
   const double chi_cur = B.scal[4], fail = B.scal[3];
-  const double tempChi = fail != 0.0 ? 1.7976931348623157e308 : B.scal[0];
-  const double scale = B.scal[1] + B.scal[2] + 1e-3;
+  double chi_t = 0, scale_l = 0;
+  for (int i = 0; i < SC_SLOTS; ++i) { chi_t += B.scal[SC_CHI + i]; scale_l += B.scal[SC_SCL + i]; }
+  const double tempChi = fail != 0.0 ? 1.7976931348623157e308 : chi_t;
+  const double scale = scale_l + B.scal[2] + 1e-3;
   const double rho = (chi_cur - tempChi) / scale;
   double lambda = B.ctl[0];
   const bool accept = rho > 0 && isfinite(tempChi);
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   __shared__ unsigned char s_wrow[MODE == 0 ? WIN_BLOCKS_MAX : 1];
   __shared__ double s_scal[2];      // per-workgroup chi2 (MODE 0) / trial chi2 and scale (MODE 1)
   if (threadIdx.x < 2) s_scal[threadIdx.x] = 0.0;
-  if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 16) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
+  if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < SC_N) B.scal[threadIdx.x] = 0.0;      // trial scalars: zeroed here instead of by a memset launch
   if (MODE == 0) {      // the whole pool is zeroed while the edge records are on their way (how much of it the window uses is known after them)
     double2 *w2 = reinterpret_cast<double2 *>(s_win);
     const double2 z2 = {0.0, 0.0};
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
     __syncthreads();                                   // s_scal zeroed
     if (lane == 0) { lds_add_f64(&s_scal[0], chi); lds_add_f64(&s_scal[1], sc); }
     __syncthreads();
-    if (threadIdx.x == 0) { atomic_add_f64(&B.scal[0], s_scal[0]); atomic_add_f64(&B.scal[1], s_scal[1]); }
+    if (threadIdx.x == 0) { atomic_add_f64(&B.scal[SC_CHI + (blockIdx.x & (SC_SLOTS - 1))], s_scal[0]); atomic_add_f64(&B.scal[SC_SCL + (blockIdx.x & (SC_SLOTS - 1))], s_scal[1]); }
     return;
   }
 
@@ -820,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
   // flush the LDS window: one global atomic per touched element per workgroup
   __syncthreads();
   SVS_STAMP(8);
-  if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur, s_scal[0]);
+  if (threadIdx.x == 0 && s_scal[0] != 0.0) atomic_add_f64(B.chi2_cur + (blockIdx.x & (SC_SLOTS - 1)), s_scal[0]);
   if (pmin != 0x7fffffff) {
     for (int i = threadIdx.x; i < nblk * 36; i += NT) {
       const int wb = i / 36, rc = i - wb * 36;
@@ -1022,14 +1029,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void ba_wide_landmark_kernel(BaDev B)
       sc[0] = edge_chi2(npsi, Tno, Tna, ed, B.cam, B.delta, B.robust);
     }
     wide_block_sum<2>(sc, s_red);
-    if (tid == 0) { atomic_add_f64(&B.scal[0], sc[0]); atomic_add_f64(&B.scal[1], sc[1]); }
+    if (tid == 0) { atomic_add_f64(&B.scal[SC_CHI + (blockIdx.x & (SC_SLOTS - 1))], sc[0]); atomic_add_f64(&B.scal[SC_SCL + (blockIdx.x & (SC_SLOTS - 1))], sc[1]); }
     return;
   }
   // ---- MODE 0 ----
   if (part == 0) {            // (workgroup-uniform)
     double c1[1] = {lin.rho0};
     wide_block_sum<1>(c1, s_red);
-    if (tid == 0 && c1[0] != 0.0) atomic_add_f64(B.chi2_cur, c1[0]);
+    if (tid == 0 && c1[0] != 0.0) atomic_add_f64(B.chi2_cur + (blockIdx.x & (SC_SLOTS - 1)), c1[0]);
   }
   auto add_blk = [&](int pi, int pj, int rc, double v) { atomic_add_f64(&B.H[blk_index(pi, pj, B.P) * 36 + rc], v); };
   if (tid == 0 && part == 0) {             // anchor block, once: Ea^T S_RAR Ea - (W_A D^-1) W_A^T, b_anc, Schur rhs
@@ -1313,7 +1320,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(BaDev B, double
     d_se3_exp_mul(s_b + 6 * p, B.poses + 12 * (size_t)p, Tn);
     for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
   }
-  if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur; }
+  if (tid == 0) { B.scal[3] = (double)fail; B.scal[4] = chi2_cur_sum(B); }
 }
 
 // ---- multi-workgroup variant for wide envelopes -------------------------------------------------------------------------
@@ -1574,7 +1581,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_grid_kernel(BaDev B, d
     for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
   }
   if (tid == 0) {
-    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+    B.scal[3] = (double)fail; B.scal[4] = chi2_cur_sum(B);
     // loads + pivot | panel + rhs | trailing issue | store drain | arrival | write-back  (read as: init, forward, load+row update, eliminate, -, barrier wait)
     B.scal[5] = acc_t[0] * 0.01; B.scal[6] = acc_t[1] * 0.01; B.scal[8] = acc_t[2] * 0.01; B.scal[9] = acc_t[3] * 0.01; B.scal[10] = acc_t[5] * 0.01; B.scal[11] = acc_t[4] * 0.01; B.scal[7] = 0;
   }
@@ -1865,7 +1872,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void ba_solve_lds_kernel(BaDev B, dou
     for (int i = 0; i < 12; ++i) B.poses_trial[12 * (size_t)p + i] = Tn[i];
   }
   if (tid == 0) {
-    B.scal[3] = (double)fail; B.scal[4] = *B.chi2_cur;
+    B.scal[3] = (double)fail; B.scal[4] = chi2_cur_sum(B);
     // phase timing (100 MHz wall clock ticks -> us), read by SVS_BA_DEBUG=1
     B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
     B.scal[8] = acc_upd * 0.01; B.scal[9] = acc_piv * 0.01; B.scal[10] = acc_pan * 0.01; B.scal[11] = acc_bar * 0.01;
@@ -2301,7 +2308,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void ba_solve_fused_kernel(BaDev B, d
   }
   if (tid == 0 && fail) B.scal[3] = 1.0;                               // zeroed before every trial by the Schur kernel / the host memset
   if (tid == 0 && !front) {
-    B.scal[4] = *B.chi2_cur;
+    B.scal[4] = chi2_cur_sum(B);
     B.scal[5] = (double)(t_loop - t_begin) * 0.01; B.scal[6] = (double)(t_fwd - t_loop) * 0.01; B.scal[7] = (double)(t_back - t_fwd) * 0.01;
     B.scal[8] = acc_ld * 0.01; B.scal[9] = (acc_piv - acc_ld) * 0.01; B.scal[10] = 0; B.scal[11] = acc_bar * 0.01;
   }
@@ -2825,7 +2832,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
     }
   t_4 = now();
   const size_t nblk = (size_t)P * (P + 1) / 2;
-  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
+  ba->red_count = nblk * 36 + 12 * (size_t)P + SC_SLOTS;
   for (int k = 0; k < 2; ++k) {
     SVS_HIP(ctx, ensure((void **)&ba->d_poses[k], &ba->cap_poses[k], sizeof(double) * 12 * (size_t)P));
     SVS_HIP(ctx, ensure((void **)&ba->d_psi[k], &ba->cap_psi[k], sizeof(double) * 3 * (size_t)std::max(L, 1)));
@@ -2841,7 +2848,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_red, &ba->cap_red, sizeof(double) * ba->red_count));
   SVS_HIP(ctx, ensure((void **)&ba->d_x, &ba->cap_x, sizeof(double) * 6 * (size_t)P));
-  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * 16));
+  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * SC_N));
   SVS_HIP(ctx, ensure((void **)&ba->d_linv, &ba->cap_linv, sizeof(double) * 36 * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
@@ -3148,13 +3155,13 @@ extern "C" int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids
   ba->P = P; ba->L = L; ba->E = E; ba->C = C; ba->cam = *cam; ba->prm = *prm; ba->add_pose_terms = 1; ba->cur = 0;
   ba->profile_ready = false; ba->env_R = 0; ba->use_lds_solve = ba->use_fused_solve = false;
   const size_t nblk = (size_t)P * (P + 1) / 2;
-  ba->red_count = nblk * 36 + 12 * (size_t)P + 1;
+  ba->red_count = nblk * 36 + 12 * (size_t)P + SC_SLOTS;
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_start, &ba->cap_cs, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_chunk_len, &ba->cap_cl, sizeof(int) * (size_t)std::max(ba->n_chunks + ba->n_wide, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_cons, &ba->cap_cons, sizeof(svs_ba_constraint) * (size_t)std::max(C, 1)));
   SVS_HIP(ctx, ensure((void **)&ba->d_red, &ba->cap_red, sizeof(double) * ba->red_count));
   SVS_HIP(ctx, ensure((void **)&ba->d_x, &ba->cap_x, sizeof(double) * 6 * (size_t)P));
-  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * 16));
+  SVS_HIP(ctx, ensure((void **)&ba->d_scal, &ba->cap_scal, sizeof(double) * SC_N));
   SVS_HIP(ctx, ensure((void **)&ba->d_linv, &ba->cap_linv, sizeof(double) * 36 * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_rowmax, &ba->cap_rowmax, sizeof(int) * (size_t)P));
   SVS_HIP(ctx, ensure((void **)&ba->d_colmin, &ba->cap_colmin, sizeof(int) * (size_t)P));
@@ -3385,8 +3392,10 @@ extern "C" int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred, 
   SVS_LAUNCH_CHECK(ctx);
   if (h_Hred) SVS_HIP(ctx, hipMemcpyAsync(h_Hred, d_full, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
   if (h_bred) SVS_HIP(ctx, hipMemcpyAsync(h_bred, d_b, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-  if (h_chi2) SVS_HIP(ctx, hipMemcpyAsync(h_chi2, B.chi2_cur, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  double chi_slots[SC_SLOTS] = {};
+  if (h_chi2) SVS_HIP(ctx, hipMemcpyAsync(chi_slots, B.chi2_cur, sizeof(chi_slots), hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_chi2) { double t = 0; for (int i = 0; i < SC_SLOTS; ++i) t += chi_slots[i]; *h_chi2 = t; }
   (void)hipFree(d_full); (void)hipFree(d_b);
   return SVS_OK;
 }
@@ -3400,7 +3409,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   if (rc) return rc;
   if (allreduce) { rc = allreduce(ba->d_red, ba->red_count, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   BaDev B = make_dev(ba, lambda, cur, ctl);
-  if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * 16, ctx->stream));      // else zeroed by the Schur kernel
+  if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * SC_N, ctx->stream));      // else zeroed by the Schur kernel
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   if (ba->use_fused_solve)
   {
@@ -3422,12 +3431,22 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
   if (B.n_chunks > 0) {
-    hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4) + (B.fuse_cons ? B.C : 0)), dim3(256), 0, ctx->stream, B);
+    // the same waves per workgroup as the Schur pass: one workgroup per CU where that is possible (403 four-wave workgroups left some CUs
+    // with two and others with one: 19.6 us; 231 seven-wave ones: 17.0 us at 50 KF / 20k)
+    const int nw = (ba->nw_sched > 0 && ba->opt.nw < 4 && !ba->opt.nw4) ? ba->nw_sched : pick_nw(B.n_chunks, ctx->n_cu, ba->opt);
+    const int xc = B.fuse_cons ? B.C : 0;
+    switch (nw) {
+      case 5: hipLaunchKernelGGL((ba_landmark_kernel<1, 5>), dim3(div_up(B.n_chunks, 5) + xc), dim3(320), 0, ctx->stream, B); break;
+      case 6: hipLaunchKernelGGL((ba_landmark_kernel<1, 6>), dim3(div_up(B.n_chunks, 6) + xc), dim3(384), 0, ctx->stream, B); break;
+      case 7: hipLaunchKernelGGL((ba_landmark_kernel<1, 7>), dim3(div_up(B.n_chunks, 7) + xc), dim3(448), 0, ctx->stream, B); break;
+      case 8: hipLaunchKernelGGL((ba_landmark_kernel<1, 8>), dim3(div_up(B.n_chunks, 8) + xc), dim3(512), 0, ctx->stream, B); break;
+      default: hipLaunchKernelGGL((ba_landmark_kernel<1, 4>), dim3(div_up(B.n_chunks, 4) + xc), dim3(256), 0, ctx->stream, B); break;
+    }
     SVS_LAUNCH_CHECK(ctx);
   }
   if (B.n_wide > 0) { hipLaunchKernelGGL(ba_wide_landmark_kernel<1>, dim3(B.n_wide), dim3(WIDE_THREADS), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
-  if (allreduce) { rc = allreduce(ba->d_scal, 2, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
+  if (allreduce) { rc = allreduce(ba->d_scal + SC_CHI, 2 * SC_SLOTS, user); if (rc) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; } }
   return SVS_OK;
 }
 static int add_trial_times(svs_ba *ba, hipEvent_t *ev) {
@@ -3544,9 +3563,9 @@ static int optimize_finish(svs_ba *ba, OptRun &R, svs_ba_stats *stats) {
       if (skip) { skip = false; continue; }      // `continue` in a do-while jumps to the condition: the speculative phase ran this trial
       int rc = enqueue_trial(ba, lambda, -1, nullptr, ba->ev, smem, allreduce, user);
       if (rc) return rc;
-      if (!ba->h_scal) SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_scal, sizeof(double) * 16, hipHostMallocDefault));
+      if (!ba->h_scal) SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_scal, sizeof(double) * SC_N, hipHostMallocDefault));
       double *h = ba->h_scal;
-      SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+      SVS_HIP(ctx, hipMemcpyAsync(h, ba->d_scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, ctx->stream));
       SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       { int rc2 = add_trial_times(ba, ba->ev); if (rc2) return rc2; }
       if (ba->opt.debug)
@@ -3554,9 +3573,11 @@ static int optimize_finish(svs_ba *ba, OptRun &R, svs_ba_stats *stats) {
                 h[5], h[6], h[8], h[9], h[10], h[11], h[7]);
       const bool fail = h[3] != 0.0;
       if (qmax == 0) { currentChi = h[4]; if (it == 0) st.chi2_init = currentChi; }
-      double tempChi = fail ? 1.7976931348623157e308 : h[0];
+      double chi_t = 0, scale_l = 0;
+      for (int i = 0; i < SC_SLOTS; ++i) { chi_t += h[SC_CHI + i]; scale_l += h[SC_SCL + i]; }
+      double tempChi = fail ? 1.7976931348623157e308 : chi_t;
       rho = currentChi - tempChi;
-      double scale = h[1] + h[2] + 1e-3;
+      double scale = scale_l + h[2] + 1e-3;
       rho /= scale;
       ++st.trials;
       if (rho > 0 && std::isfinite(tempChi)) {
