@@ -64,7 +64,7 @@ constexpr int WBLK = 37;
 // flush adds the copies.
 constexpr int WCOPIES_MAX = 8;
 constexpr int SEG_DPP_MAX = 12;      // longest landmark of a wave for which the segmented sums use DPP shifts (seg_allreduce)
-__device__ __host__ constexpr int win_pool_doubles(int nw, int wc) { return wc == 2 ? (163840 - nw * 64 * 18 * 8 - 4096) / 8 : 5224; }
+__device__ __host__ constexpr int win_pool_doubles(int nw, int wc) { return wc == 2 ? (163840 - nw * 64 * 18 * 8 - 4096) / 8 : 5226; }      // small pool: one 16-pose window (136 * 37 + 192 doubles, odd stride)
 __device__ __forceinline__ int win_blk(int wi, int wj, int win) { return wi * win - wi * (wi - 1) / 2 + (wj - wi); }
 
 // value of the lane below (wave_shr:1 reaches across the 16-lane DPP rows on gfx9), 0 in lane 0 and wherever `keep` is 0: one
@@ -472,10 +472,13 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 && WC == 1) ? 2 : 1) void ba_land
 #pragma unroll
     for (int k = 1; k < NW; ++k) { pmin = min(pmin, s_wmin[k]); pmax = max(pmax, s_wmax[k]); }
     if (pmin != 0x7fffffff) {
-      win = min(pmax - pmin + 1, WMAX);
-      nblk = win * (win + 1) / 2;
-      cstride = (nblk * WBLK + 12 * win) | 1;               // odd: the copies start in different banks
-      copies = min(WCOPIES_MAX, POOL / cstride);          // >= 1: WMAX fits the pool once
+      win = min(pmax - pmin + 1, WMAX) + 1;
+      do {                                                  // (WMAX fits the pool once; the loop is the guarantee, not the rule)
+        --win;
+        nblk = win * (win + 1) / 2;
+        cstride = (nblk * WBLK + 12 * win) | 1;             // odd: the copies start in different banks
+      } while (cstride > POOL && win > 1);
+      copies = max(1, min(WCOPIES_MAX, POOL / cstride));
     }
     if (threadIdx.x < nblk) {                               // block row of every packed window block (for the flush, behind the next barrier)
       int wi = 0, rem = threadIdx.x;

@@ -411,6 +411,35 @@ def test_double_window_230_poses_wide_landmarks(gpu_ctx):
     opt.close()
 
 
+def test_many_chunks_two_workgroups_per_cu(gpu_ctx):
+    """More wave chunks than 8 x the CUs: the Schur pass runs four waves per workgroup, two workgroups per CU, with the SMALL LDS pool
+    (one window of at most 16 poses).  (a) a plain 100-keyframe / 40 000-landmark inner window; (b) the 230-pose double window with
+    30 000 landmarks, whose long tracks and loop closures span more poses than the window holds (clamped window, the rest by global
+    atomics) and whose 100- and 180-observation landmarks take the wide-landmark kernel."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prm = BaParams.reference_defaults()
+    cases = [synth.ba_window(100, 40000, seed=31), synth.double_window(n_inner=30, n_outer=200, L=30000, seed=5, n_long=(100, 180), n_loops=2)]
+    for prob in cases:
+        cam = _cam(prob["cam"])
+        opt = SlamGraphOptimizer(ctx, stream)
+        opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        assert opt.info()["wave_chunks"] > 8 * 256
+        H, b, chi2 = opt.reduced_system(50.0)
+        H_ref, b_ref = O.ba_reduced_system(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm, 50.0)
+        np.testing.assert_allclose(H, H_ref, rtol=0, atol=1e-10 * np.abs(H_ref).max())
+        np.testing.assert_allclose(b, b_ref, rtol=0, atol=1e-10 * np.abs(b_ref).max())
+        st = opt.optimize()
+        poses, psi = opt.restoreDataFromG2o()
+        poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        assert (st.iterations, st.trials, st.accepted, st.terminated) == (st_ref.iterations, st_ref.trials, st_ref.accepted, st_ref.terminated)
+        assert _rel_update_err(poses, poses_ref, prob["poses"]) < 1e-6
+        opt.close()
+
+
 def test_largest_supported_window_256_poses(gpu_ctx):
     """P = 256 keyframes (the documented maximum of the single-workgroup solves): long two-front elimination
     (front 1 takes ~120 block rows), everything else as usual; 257 poses are refused with SVS_ERR_UNSUPPORTED."""
