@@ -61,36 +61,48 @@ __device__ __forceinline__ uint32_t load_u32_clamped(const uint8_t *row, int q, 
   const uint32_t raw = load_u32_unaligned(row + qs);
   return d == 0 ? raw : (d >= 4 || d <= -4) ? 0u : d > 0 ? raw >> (8 * d) : raw << (-8 * d);
 }
-// 4 padded columns per thread, 4 rows per workgroup.  grid: (ceil(pitch/256), ceil(h/4), 2*batch), block (64, 4);
-// z = 2*b + (0 left | 1 right)
+// 4 padded columns x 4 rows per thread (the six input rows of a 4-row group are read once: 12 dword loads per 16 pixels instead of 24; the
+// horizontal differences of an input row serve three output rows), 16 rows per workgroup.
+// grid: (ceil(pitch/256), ceil(h/16), 2*batch), block (64, 4); z = 2*b + (0 left | 1 right)
 __global__ __launch_bounds__(256) void stereo_prefilter_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
                                                                const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
-  const int pc0 = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int pc0 = 4 * (blockIdx.x * 64 + threadIdx.x), y0 = (blockIdx.y * 4 + threadIdx.y) * 4, b = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int w = S.w, h = S.h, cap = S.cap;
-  if (pc0 >= S.pitch || y >= h) return;      // pitch is a multiple of 4
+  if (pc0 >= S.pitch || y0 >= h) return;      // pitch is a multiple of 4
   const uint8_t *src = side ? right + (size_t)b * r_bstride : left + (size_t)b * l_bstride;
   const int stride = side ? rstride : lstride;
   const int x0 = pc0 - PADL;
   const uint32_t fill = 0x01010101u * (uint32_t)(cap + 1);      // pads, border columns, odd last row
-  uint32_t out = fill;
-  if (!((h & 1) && y == h - 1)) {
-    const int yp = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yn = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-    const uint8_t *r0 = src + (size_t)yp * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yn * stride;
-    // bytes x0-1 .. x0+4 of the three rows (w >= 38, checked at create)
-    const uint32_t a0 = load_u32_clamped(r0, x0 - 1, w), a1 = load_u32_clamped(r0, x0 + 3, w);
-    const uint32_t b0 = load_u32_clamped(r1, x0 - 1, w), b1 = load_u32_clamped(r1, x0 + 3, w);
-    const uint32_t c0 = load_u32_clamped(r2, x0 - 1, w), c1 = load_u32_clamped(r2, x0 + 3, w);
-    out = 0;
+  // horizontal differences byte(j + 2) - byte(j), j = 0..3, of the six input rows y0-1 .. y0+4 (rows outside the image: the row the
+  // original's yp / yn pick, i.e. 1 above the top and h-2 below the bottom)
+  int d[6][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int x = x0 + j;
-      const int v = (byte_of(a0, a1, j + 2) - byte_of(a0, a1, j)) + 2 * (byte_of(b0, b1, j + 2) - byte_of(b0, b1, j)) +
-                    (byte_of(c0, c1, j + 2) - byte_of(c0, c1, j));
-      const uint32_t o = (x >= 1 && x <= w - 2) ? (uint32_t)(xsobel_tab(v, cap) + 1) : (uint32_t)(cap + 1);
-      out |= o << (8 * j);
-    }
+  for (int i = 0; i < 6; ++i) {
+    int r = y0 - 1 + i;
+    r = r < 0 ? (h > 1 ? 1 : 0) : (r > h - 1 ? (h > 1 ? h - 2 : 0) : r);
+    r = min(max(r, 0), h - 1);                                  // (rows far below the image only feed rows that are not written)
+    const uint8_t *row = src + (size_t)r * stride;
+    const uint32_t a0 = load_u32_clamped(row, x0 - 1, w), a1 = load_u32_clamped(row, x0 + 3, w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[i][j] = byte_of(a0, a1, j + 2) - byte_of(a0, a1, j);
   }
-  *reinterpret_cast<uint32_t *>((side ? S.rp : S.lp) + ((size_t)b * h + y) * S.pitch + pc0) = out;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = y0 + k;
+    if (y >= h) break;
+    uint32_t out = fill;
+    if (!((h & 1) && y == h - 1)) {
+      out = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 + j;
+        const int v = d[k][j] + 2 * d[k + 1][j] + d[k + 2][j];
+        const uint32_t o = (x >= 1 && x <= w - 2) ? (uint32_t)(xsobel_tab(v, cap) + 1) : (uint32_t)(cap + 1);
+        out |= o << (8 * j);
+      }
+    }
+    *reinterpret_cast<uint32_t *>((side ? S.rp : S.lp) + ((size_t)b * h + y) * S.pitch + pc0) = out;
+  }
 }
 
 
@@ -221,16 +233,23 @@ __global__ __launch_bounds__(EDGE_THREADS) void stereo_bm_edge_kernel(StereoDev 
   const bool act = pix < ncol * h;
   const int y = act ? pix / ncol : 0, x = act ? pix % ncol : 0;
   const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL, *rp = S.rp + (size_t)b * h * S.pitch + PADL;
-  int sad = 0, tsum = 0;
+  // A window row: left bytes x+28 .. x+34 (two dwords, 8th byte masked); right bytes max(x + dx, 0) + d for dx = -3..3 -- the clamp repeats
+  // column d, so the seven taps are a byte shuffle (V_PERM) of the two dwords at d .. d+7 (x <= 2, d <= 31: index <= 36 < w, no upper clamp).
+  // 28 dword loads + 14 shuffles + 28 V_SAD_U8 per lane instead of 98 byte loads.
+  const uint32_t selA = x == 0 ? 0x00000000u : x == 1 ? 0x01000000u : 0x02010000u;      // taps dx = -3..0
+  const uint32_t selB = x == 0 ? 0x0c030201u : x == 1 ? 0x0c040302u : 0x0c050403u;      // taps dx = 1..3, then a zero byte
+  const uint32_t ft4 = 0x01010101u * (uint32_t)(S.cap + 1);
+  uint32_t sad_u = 0, tsum_u = 0;
   for (int dy = -WSZ2; dy <= WSZ2; ++dy) {
     const int yy = min(max(y + dy, 0), h - 1);
-#pragma unroll
-    for (int dx = -WSZ2; dx <= WSZ2; ++dx) {
-      const int lval = lp[(size_t)yy * S.pitch + x + dx + NDISP - 1];      // x + dx + 31 >= 28: no clamp on the left image here
-      sad += abs(lval - (int)rp[(size_t)yy * S.pitch + min(max(x + dx, 0) + d, w - 1)]);
-      tsum += abs(lval - (S.cap + 1));
-    }
+    const uint8_t *lrow = lp + (size_t)yy * S.pitch + x + NDISP - 1 - WSZ2, *rrow = rp + (size_t)yy * S.pitch + d;
+    const uint32_t l0 = load_u32_unaligned(lrow), l1 = load_u32_unaligned(lrow + 4) & 0x00ffffffu;
+    const uint32_t r0 = load_u32_unaligned(rrow), r1 = load_u32_unaligned(rrow + 4);
+    const uint32_t ra = __builtin_amdgcn_perm(r1, r0, selA), rb = __builtin_amdgcn_perm(r1, r0, selB);
+    sad_u = __builtin_amdgcn_sad_u8(l1, rb, __builtin_amdgcn_sad_u8(l0, ra, sad_u));
+    tsum_u = __builtin_amdgcn_sad_u8(l1 | (ft4 & 0xff000000u), ft4, __builtin_amdgcn_sad_u8(l0, ft4, tsum_u));
   }
+  const int sad = (int)sad_u, tsum = (int)tsum_u;
   // selection across the 32 lanes of the pixel (same rules as bm_select)
   uint32_t key = ((uint32_t)sad << 5) | (uint32_t)d;
 #pragma unroll
@@ -926,7 +945,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   S.speckle_window = s->prm.speckle_window; S.speckle_range = s->prm.speckle_range; S.disp12 = s->prm.disp12_max_diff;
   S.lp = s->d_lp; S.rp = s->d_rp; S.disp16 = s->d_disp16; S.cost = s->d_cost; S.label = s->d_label; S.count = s->d_count;
   const int w = s->w, h = s->h, width1 = w - NDISP + 1, n = w * h;
-  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 4), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
+  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 16), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
                      l_bstride, d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, EDGE_THREADS / 32), n_batch), dim3(EDGE_THREADS), 0, ctx->stream, S);
