@@ -44,6 +44,7 @@ struct StereoDev {
   int *err;              // [1] set when a bounded walk of the strip path gave up (never expected)
 };
 
+__device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ int xsobel_tab(int v, int cap) { return v < -cap ? 0 : v > cap ? 2 * cap : v + cap; }
 
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
@@ -271,28 +272,31 @@ __global__ __launch_bounds__(EDGE_THREADS) void stereo_bm_edge_kernel(StereoDev 
   S.disp16[o] = d16; S.cost[o] = c16;
 }
 
-// validateDisparity (with D2): one workgroup per image row.  The reference's sequential first pass ("a strictly smaller
-// cost wins", ascending x => first x on ties) is a minimum over (cost, x): every valid source pixel does one LDS atomicMin
-// of the packed key (cost << 16 | x) on its target column.  grid: (h, batch), block 256, dynamic LDS = 2 * w ints
+// validateDisparity (with D2): one WAVE per image row, four rows per workgroup (a row is 640 pixels: a 256-lane workgroup per row spent
+// its time in dispatch and two workgroup barriers; a wave orders its own LDS traffic without them).  The reference's sequential first
+// pass ("a strictly smaller cost wins", ascending x => first x on ties) is a minimum over (cost, x): every valid source pixel does one
+// LDS atomicMin of the packed key (cost << 16 | x) on its target column.  grid: (ceil(h/R), batch), block 64 R, dynamic LDS = R * 2 * w ints
+// (R = 4 rows per workgroup; 1 for rows wider than 2048 pixels)
 __global__ __launch_bounds__(256) void stereo_validate_kernel(StereoDev S) {
   extern __shared__ int s_mem[];
-  const int w = S.w, y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  int *s_d = s_mem;
-  unsigned *s_key = reinterpret_cast<unsigned *>(s_mem + w);
+  const int w = S.w, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, y = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
+  if (y >= S.h) return;                                     // wave-uniform; no workgroup barrier below
+  int *s_d = s_mem + wave * 2 * w;
+  unsigned *s_key = reinterpret_cast<unsigned *>(s_d + w);
   const int SCALE = 1 << DISP_SHIFT, INVALID = -SCALE, maxdiff = S.disp12 * SCALE;
   int16_t *dp = S.disp16 + ((size_t)b * S.h + y) * w;
   const uint16_t *cp = S.cost + ((size_t)b * S.h + y) * w;
-  for (int x = tid; x < w; x += 256) { s_d[x] = dp[x]; s_key[x] = 0xffffffffu; }
-  __syncthreads();
+  for (int x = lane; x < w; x += 64) { s_d[x] = dp[x]; s_key[x] = 0xffffffffu; }
+  wave_sync_lds();
   const int minX1 = NDISP;
-  for (int x = minX1 + tid; x < w; x += 256) {
+  for (int x = minX1 + lane; x < w; x += 64) {
     const int d = s_d[x];
     if (d == INVALID) continue;
     const int x2 = x - ((d + SCALE / 2) >> DISP_SHIFT);
     if (x2 >= 0 && x2 < w) atomicMin(&s_key[x2], ((unsigned)cp[x] << 16) | (unsigned)x);
   }
-  __syncthreads();
-  for (int x = minX1 + tid; x < w; x += 256) {
+  wave_sync_lds();
+  for (int x = minX1 + lane; x < w; x += 64) {
     const int d = s_d[x];
     if (d == INVALID) continue;
     const int x0 = x - (d >> DISP_SHIFT), x1 = x - ((d + SCALE - 1) >> DISP_SHIFT);
@@ -955,7 +959,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
     SVS_LAUNCH_CHECK(ctx);
   }
   if (s->prm.disp12_max_diff >= 0) {
-    hipLaunchKernelGGL(stereo_validate_kernel, dim3(h, n_batch), dim3(256), sizeof(int) * 2 * (size_t)w, ctx->stream, S);
+    { const int R = w <= 2048 ? 4 : 1; hipLaunchKernelGGL(stereo_validate_kernel, dim3(div_up(h, R), n_batch), dim3(64 * R), sizeof(int) * 2 * R * (size_t)w, ctx->stream, S); }
     SVS_LAUNCH_CHECK(ctx);
   }
   const bool ccl = s->prm.speckle_range >= 0 && s->prm.speckle_window > 0;
