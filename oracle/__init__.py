@@ -661,6 +661,116 @@ class RefGpu:
             return out
 
 
+class RefQuadTree:
+    """oracle/_ref/libsvs_ref_qt.so: the reference's own QuadTree<int> (scavislam/quadtree.h) compiled on the host against stand-in headers
+    (oracle/Makefile, ref_shim/fake, ref_shim/refqt_wrap.cc).  Test infrastructure; built only where /root/reference exists."""
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            so = os.path.join(_HERE, "_ref", "libsvs_ref_qt.so")
+            if os.path.isdir("/root/reference/scavislam"):
+                subprocess.check_call(["make", "-C", _HERE, "-s"])
+            if not os.path.exists(so):
+                raise FileNotFoundError(so)
+            L = C.CDLL(so)
+            L.svs_refqt_create.restype = C.c_void_p
+            L.svs_refqt_create.argtypes = [C.c_double] * 5
+            L.svs_refqt_destroy.argtypes = [C.c_void_p]
+            L.svs_refqt_insert.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+            L.svs_refqt_query.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_int]
+            L.svs_refqt_is_window_empty.argtypes = [C.c_void_p] + [C.c_double] * 4
+            cls._L = L
+        return cls._L
+
+    def __init__(self, w, h, delta=1.0, x=0.0, y=0.0):
+        self.h = C.c_void_p(self.lib().svs_refqt_create(float(x), float(y), float(w), float(h), float(delta)))
+
+    def insert(self, x, y, content):
+        return self.lib().svs_refqt_insert(self.h, float(x), float(y), int(content))
+
+    def query(self, x, y, w, h, cap=8192):
+        out = np.zeros((cap, 3), np.int32)
+        n = self.lib().svs_refqt_query(self.h, float(x), float(y), float(w), float(h), _p(out), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+    def is_window_empty(self, x, y, w, h):
+        return bool(self.lib().svs_refqt_is_window_empty(self.h, float(x), float(y), float(w), float(h)))
+
+    def __del__(self):
+        try:
+            self.lib().svs_refqt_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _ref_lib(name):
+    so = os.path.join(_HERE, "_ref", name)
+    if os.path.isdir("/root/reference/scavislam"):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if not os.path.exists(so):
+        raise FileNotFoundError(so)
+    return C.CDLL(so)
+
+
+class RefFastGrid:
+    """oracle/_ref/libsvs_ref_fastgrid.so: the reference's own FastGrid (fast_grid.{h,cpp}) compiled on the host; its corner detector is bound
+    to the oracle's FAST-9/16 restatement (svs_ref_fast9_16).  Test infrastructure."""
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            L = _ref_lib("libsvs_ref_fastgrid.so")
+            L.svs_reffg_create.restype = C.c_void_p
+            L.svs_reffg_create.argtypes = [C.c_int] * 9
+            L.svs_reffg_destroy.argtypes = [C.c_void_p]
+            L.svs_reffg_set_fast.argtypes = [C.c_void_p]
+            L.svs_reffg_detect_adaptively.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int]
+            L.svs_reffg_detect.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int]
+            L.svs_reffg_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            L.svs_reffg_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
+            cls._L = L
+        return cls._L
+
+    def __init__(self, w, h, n_per_cell, boundary, fast_thr, gx, gy, fast_min=10, fast_max=40):
+        self.w, self.h = int(w), int(h)
+        self.g = C.c_void_p(self.lib().svs_reffg_create(self.w, self.h, int(n_per_cell), int(boundary), int(fast_thr), int(gx), int(gy), int(fast_min), int(fast_max)))
+
+    def _dump(self, fn, img, *extra):
+        img = np.ascontiguousarray(img)
+        assert img.shape == (self.h, self.w) and img.dtype == np.uint8
+        out = np.zeros((self.w * self.h, 3), np.int32)
+        n = fn(self.g, _p(img), img.strides[0], self.w, self.h, *extra, _p(out), len(out))
+        return out[:n].copy()
+
+    def detect_adaptively(self, img, trials):
+        return self._dump(self.lib().svs_reffg_detect_adaptively, img, int(trials))
+
+    def detect(self, img):
+        return self._dump(self.lib().svs_reffg_detect, img)
+
+    def cells(self):
+        out = np.zeros((256, 5), np.int32)
+        n = self.lib().svs_reffg_cells(self.g, _p(out), 256)
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            self.lib().svs_reffg_destroy(self.g)
+        except Exception:
+            pass
+
+
+def ref_znssd_lib():
+    L = _ref_lib("libsvs_ref_znssd.so")
+    L.svs_refznssd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.svs_refznssd_patch_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
 _REF = None
 
 

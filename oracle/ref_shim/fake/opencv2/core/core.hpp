@@ -1,0 +1,88 @@
+// TEST INFRASTRUCTURE -- not part of the product.
+// The OpenCV 2.4 names the reference's quadtree.h / global.h / maths_utils.h / keyframes.h / fast_grid.{h,cpp} use, written from the public
+// OpenCV 2.4 interface so that those reference files compile on the host from where they lie (oracle/Makefile):
+//   Point_<T>, Rect_<T> (half-open contains(): x <= pt.x < x + width, y <= pt.y < y + height), Range, Size, KeyPoint;
+//   Mat: a 2-D 8-bit view (data, step, rows, cols) with the ROI operator (rowRange, colRange), clone() and copyTo();
+//   FastFeatureDetector(threshold, nonmaxSuppression).detect(image, keypoints): forwards to a hook.  The pin binds the hook to the
+//   oracle's restatement of OpenCV's FAST-9/16 (svs_ref_fast9_16): what is compiled from the reference and checked is everything AROUND
+//   the detector -- cell layout, the adaptive threshold state machine, corner offsets and the quadtree insertion (fast_grid.cpp:23-152).
+#pragma once
+#include <cstring>
+#include <memory>
+#include <stdint.h>
+#include <vector>
+namespace cv {
+template <typename T> struct Point_ {
+  T x, y;
+  Point_() : x(0), y(0) {}
+  Point_(T x_, T y_) : x(x_), y(y_) {}
+};
+typedef Point_<double> Point2d;
+typedef Point_<float> Point2f;
+template <typename T> struct Rect_ {
+  T x, y, width, height;
+  Rect_() : x(0), y(0), width(0), height(0) {}
+  Rect_(T x_, T y_, T w_, T h_) : x(x_), y(y_), width(w_), height(h_) {}
+  bool contains(const Point_<T> &pt) const { return x <= pt.x && pt.x < x + width && y <= pt.y && pt.y < y + height; }
+};
+struct Range {
+  int start, end;
+  Range() : start(0), end(0) {}
+  Range(int s, int e) : start(s), end(e) {}
+};
+struct Size {
+  int width, height;
+  Size() : width(0), height(0) {}
+  Size(int w, int h) : width(w), height(h) {}
+};
+struct KeyPoint {
+  Point2f pt;
+  KeyPoint() {}
+  KeyPoint(float x, float y) : pt(x, y) {}
+};
+enum { CV_8U = 0 };
+class Mat {
+ public:
+  int rows, cols;
+  size_t step;
+  uint8_t *data;
+  std::shared_ptr<std::vector<uint8_t> > own;      // storage of clones / allocations (views leave it empty or share it)
+  Mat() : rows(0), cols(0), step(0), data(0) {}
+  Mat(int r, int c, int /*type*/, void *d, size_t s = 0) : rows(r), cols(c), step(s ? s : (size_t)c), data(static_cast<uint8_t *>(d)) {}
+  Mat operator()(const Range &rr, const Range &cr) const {
+    Mat m(*this);
+    m.rows = rr.end - rr.start; m.cols = cr.end - cr.start;
+    m.data = data + (size_t)rr.start * step + cr.start;
+    return m;
+  }
+  Mat clone() const {
+    Mat m;
+    m.rows = rows; m.cols = cols; m.step = (size_t)cols;
+    m.own.reset(new std::vector<uint8_t>((size_t)rows * cols));
+    m.data = m.own->data();
+    for (int r = 0; r < rows; ++r) std::memcpy(m.data + (size_t)r * m.step, data + (size_t)r * step, (size_t)cols);
+    return m;
+  }
+  void copyTo(Mat &dst) const {
+    if (dst.rows != rows || dst.cols != cols || !dst.data) dst = clone();
+    else for (int r = 0; r < rows; ++r) std::memcpy(dst.data + (size_t)r * dst.step, data + (size_t)r * step, (size_t)cols);
+  }
+};
+// hook: n = fn(image, w, h, stride, threshold, xy (x, y pairs, detection order), cap)
+typedef int (*svs_shim_fast_fn)(const uint8_t *, int, int, int, int, int16_t *, int);
+extern svs_shim_fast_fn svs_shim_fast_hook;
+class FastFeatureDetector {
+ public:
+  FastFeatureDetector(int threshold = 10, bool nonmax = true) : thr_(threshold), nonmax_(nonmax) {}
+  void detect(const Mat &img, std::vector<KeyPoint> &kp) const {
+    kp.clear();
+    if (nonmax_ || !svs_shim_fast_hook || img.rows <= 0 || img.cols <= 0) return;      // the reference only ever asks for (thr, false)
+    std::vector<int16_t> xy((size_t)2 * img.rows * img.cols + 2);
+    const int n = svs_shim_fast_hook(img.data, img.cols, img.rows, (int)img.step, thr_, xy.data(), img.rows * img.cols);
+    for (int i = 0; i < n; ++i) kp.push_back(KeyPoint((float)xy[2 * i], (float)xy[2 * i + 1]));
+  }
+ private:
+  int thr_;
+  bool nonmax_;
+};
+}  // namespace cv
