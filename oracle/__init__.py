@@ -764,6 +764,52 @@ class RefFastGrid:
             pass
 
 
+def _cam6(cams):
+    return np.ascontiguousarray([[c.f, c.cx, c.cy, c.b, c.w, c.h] for c in cams], np.float64)
+
+
+def ref_dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T):
+    """the reference's own DenseTracker::denseTrackingCpu (oracle/_ref/libsvs_ref_dense.so) -> (T, residual images)"""
+    L = _ref_lib("libsvs_ref_dense.so")
+    clouds = [np.ascontiguousarray(a, np.float32).copy() for a in clouds]
+    prev = [np.ascontiguousarray(a) for a in prev_pyr]
+    cur = [np.ascontiguousarray(a, np.float32) for a in cur_f]
+    dx = [np.ascontiguousarray(a, np.float32) for a in dx_f]
+    dy = [np.ascontiguousarray(a, np.float32) for a in dy_f]
+    rimg = [np.tile(np.array([0, 0, 0, 1], np.float32), (*c.shape[:2], 1)) for c in clouds]      # the constructor's fill (dense_tracking.cpp:54)
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    T = np.array(T, np.float64).reshape(12).copy()
+    cam6 = _cam6(cams)
+    L.svs_refdense_track.argtypes = [C.c_void_p] * 10
+    L.svs_refdense_track(P3(*[a.ctypes.data for a in clouds]), P3(*[a.ctypes.data for a in prev]), I3(*[a.strides[0] for a in prev]),
+                         P3(*[a.ctypes.data for a in cur]), P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]),
+                         I3(*[a.strides[0] for a in cur]), _p(cam6), _p(T), P3(*[a.ctypes.data for a in rimg]))
+    return T.reshape(3, 4), rimg
+
+
+def ref_pointcloud_cpu(disp, cams, T_cur_from_actkey):
+    """the reference's own DenseTracker::computeDensePointCloudCpu -> the three quarter-grid clouds"""
+    L = _ref_lib("libsvs_ref_dense.so")
+    disp = np.ascontiguousarray(disp, np.float32)
+    cam6 = _cam6(cams)
+    clouds = [np.zeros((c.h // 4, c.w // 4, 4), np.float32) for c in cams]
+    T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+    L.svs_refdense_cloud.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svs_refdense_cloud(_p(disp), disp.strides[0], disp.shape[1], disp.shape[0], _p(cam6), _p(T), (C.c_void_p * 3)(*[a.ctypes.data for a in clouds]))
+    return clouds
+
+
+def ref_edges_lib():
+    """oracle/_ref/libsvs_ref_edges.so: the reference's own BA edge / vertex code (anchored_points.{h,cpp} slices + transformations.h:62-95)"""
+    L = _ref_lib("libsvs_ref_edges.so")
+    L.svs_refedge_psi2uvu.argtypes = [C.c_void_p] * 9
+    L.svs_refedge_se3.argtypes = [C.c_void_p] * 6
+    L.svs_refvertex_oplus_se3.argtypes = [C.c_void_p] * 3
+    L.svs_refvertex_oplus_xyz.argtypes = [C.c_void_p] * 3
+    L.svs_refcam_uvu.argtypes = [C.c_void_p] * 3
+    return L
+
+
 def ref_znssd_lib():
     L = _ref_lib("libsvs_ref_znssd.so")
     L.svs_refznssd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]

@@ -40,32 +40,48 @@ struct KeyPoint {
   KeyPoint() {}
   KeyPoint(float x, float y) : pt(x, y) {}
 };
-enum { CV_8U = 0 };
+}  // namespace cv
+#define CV_8U 0
+#define CV_32F 5
+#define CV_32FC4 29
+namespace cv {
+struct Vec4f {
+  float v[4];
+  Vec4f() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+  template <typename A, typename B, typename C, typename D> Vec4f(A a, B b, C c, D d) { v[0] = (float)a; v[1] = (float)b; v[2] = (float)c; v[3] = (float)d; }
+  float &operator[](int i) { return v[i]; }
+  const float &operator[](int i) const { return v[i]; }
+};
 class Mat {
  public:
-  int rows, cols;
-  size_t step;
+  int rows, cols, type_;
+  size_t step;      // bytes
   uint8_t *data;
   std::shared_ptr<std::vector<uint8_t> > own;      // storage of clones / allocations (views leave it empty or share it)
-  Mat() : rows(0), cols(0), step(0), data(0) {}
-  Mat(int r, int c, int /*type*/, void *d, size_t s = 0) : rows(r), cols(c), step(s ? s : (size_t)c), data(static_cast<uint8_t *>(d)) {}
+  Mat() : rows(0), cols(0), type_(CV_8U), step(0), data(0) {}
+  static size_t elem(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : 16; }
+  Mat(int r, int c, int type, void *d, size_t s = 0) : rows(r), cols(c), type_(type), step(s ? s : (size_t)c * elem(type)), data(static_cast<uint8_t *>(d)) {}
+  int type() const { return type_; }
+  Size size() const { return Size(cols, rows); }
+  template <typename T> T &at(int y, int x) { return *reinterpret_cast<T *>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+  template <typename T> const T &at(int y, int x) const { return *reinterpret_cast<const T *>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
   Mat operator()(const Range &rr, const Range &cr) const {
     Mat m(*this);
     m.rows = rr.end - rr.start; m.cols = cr.end - cr.start;
-    m.data = data + (size_t)rr.start * step + cr.start;
+    m.data = data + (size_t)rr.start * step + (size_t)cr.start * elem(type_);
     return m;
   }
   Mat clone() const {
     Mat m;
-    m.rows = rows; m.cols = cols; m.step = (size_t)cols;
-    m.own.reset(new std::vector<uint8_t>((size_t)rows * cols));
+    m.rows = rows; m.cols = cols; m.type_ = type_; m.step = (size_t)cols * elem(type_);
+    m.own.reset(new std::vector<uint8_t>((size_t)rows * m.step));
     m.data = m.own->data();
-    for (int r = 0; r < rows; ++r) std::memcpy(m.data + (size_t)r * m.step, data + (size_t)r * step, (size_t)cols);
+    for (int r = 0; r < rows; ++r) std::memcpy(m.data + (size_t)r * m.step, data + (size_t)r * step, m.step);
     return m;
   }
   void copyTo(Mat &dst) const {
     if (dst.rows != rows || dst.cols != cols || !dst.data) dst = clone();
-    else for (int r = 0; r < rows; ++r) std::memcpy(dst.data + (size_t)r * dst.step, data + (size_t)r * step, (size_t)cols);
+    else for (int r = 0; r < rows; ++r) std::memcpy(dst.data + (size_t)r * dst.step, data + (size_t)r * step, (size_t)cols * elem(type_));
   }
 };
 // hook: n = fn(image, w, h, stride, threshold, xy (x, y pairs, detection order), cap)

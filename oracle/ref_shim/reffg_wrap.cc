@@ -29,13 +29,13 @@ void svs_reffg_destroy(void *g) { delete static_cast<FastGrid *>(g); }
 // the tree's query order over the whole image
 int svs_reffg_detect_adaptively(void *g, const uint8_t *img, int stride, int w, int h, int trials, int *out_xyc, int cap) {
   QuadTree<int> qt(ScaViSLAM::Rectangle(0, 0, w, h), 1);
-  cv::Mat m(h, w, cv::CV_8U, const_cast<uint8_t *>(img), (size_t)stride);
+  cv::Mat m(h, w, CV_8U, const_cast<uint8_t *>(img), (size_t)stride);
   static_cast<FastGrid *>(g)->detectAdaptively(m, trials, &qt);
   return dump_tree(qt, w, h, out_xyc, cap);
 }
 int svs_reffg_detect(void *g, const uint8_t *img, int stride, int w, int h, int *out_xyc, int cap) {
   QuadTree<int> qt(ScaViSLAM::Rectangle(0, 0, w, h), 1);
-  cv::Mat m(h, w, cv::CV_8U, const_cast<uint8_t *>(img), (size_t)stride);
+  cv::Mat m(h, w, CV_8U, const_cast<uint8_t *>(img), (size_t)stride);
   FastGrid::detect(m, static_cast<FastGrid *>(g)->cell_grid2d(), &qt);
   return dump_tree(qt, w, h, out_xyc, cap);
 }

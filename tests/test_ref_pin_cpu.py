@@ -433,3 +433,105 @@ def test_znssd_equals_reference_compiled_znssd():
         for dA, dAA in ((5, -11), (-300, 4000)):                # foreign sums
             assert L.svs_refznssd(key.ctypes.data, cur.ctypes.data, sA.value + dA, sAA.value + dAA) == \
                 O.lib().svs_ref_znssd(C.c_void_p(key.ctypes.data), C.c_void_p(cur.ctypes.data), sA.value + dA, sAA.value + dAA)
+
+
+# ---- the reference's own quarter-grid dense tracker (rows a11 / a12) ---------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dense_cpu_cases():
+    from scavislam_amd.ctypes_types import level_cams
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(6)
+    cam = synth.CAM_DEFAULT
+    cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+    out = []
+    for a, b_, holes in [(2, 3, False), (0, 2, True), (3, 5, True)]:
+        img_p, disp_p = sc.render(cam, traj[a], seed=20 + a)
+        img_c, _ = sc.render(cam, traj[b_], seed=20 + b_)
+        if holes:
+            disp_p = disp_p.copy(); disp_p[90:200, 150:400] = 0; disp_p[::7, ::5] = -1.0      # no-depth regions and specks
+        out.append((img_p, disp_p, img_c))
+    return cams, out
+
+
+def test_dense_tracker_equals_reference_compiled_loop(dense_cpu_cases):
+    """oracle/_ref/libsvs_ref_dense.so is dense_tracking.cpp:222-423 compiled from where it lies (SE3 / ldlt / camera handed to the oracle's
+    helpers, see oracle/Makefile).  computeDensePointCloudCpu: the three clouds bit-equal, incl. no-depth pixels.  denseTrackingCpu from the
+    identity and from a perturbed start: the final pose and the three residual images (they record the LAST H,b pass of every level, i.e.
+    the whole accept / reject trajectory) bit-equal to the oracle's restated loop."""
+    cams, cases = dense_cpu_cases
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    T_off = synth.pose(synth.so3_exp(np.array([0.004, -0.006, 0.003])), np.array([0.03, -0.01, 0.05]))
+    n_moved = 0
+    for img_p, disp_p, img_c in cases:
+        for T_cloud in (I, T_off):
+            ref_clouds = O.ref_pointcloud_cpu(disp_p, cams, T_cloud)
+            for l in range(3):
+                assert np.array_equal(ref_clouds[l], O.pointcloud_cpu(disp_p, cams[l], l, T_cloud)), f"cloud level {l}"
+        clouds = [O.pointcloud_cpu(disp_p, cams[l], l, I) for l in range(3)]
+        pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
+        fl = [O.convert_sobel(p) for p in pyr_c]
+        for T0 in (I, T_off):
+            T_ref, rimg_ref = O.ref_dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cams, T0)
+            T, passes, rimg = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cams, T0, want_rimg=True)
+            assert np.array_equal(T, T_ref), f"pose differs by {np.abs(T - T_ref).max()}"
+            for l in range(3):
+                assert np.array_equal(rimg[l], rimg_ref[l]), f"residual image level {l}"
+            n_moved += int(np.abs(T - np.asarray(T0).reshape(3, 4)).max() > 1e-4)
+    assert n_moved >= 4
+
+
+# ---- the reference's own BA edges and vertices (rows a17 - a19) ---------------------------------------------------------------------
+def test_ba_edges_equal_reference_compiled_edges():
+    """oracle/_ref/libsvs_ref_edges.so: G2oEdgeProjectPSI2UVU::computeError / linearizeOplus, G2oEdgeSE3::computeError / linearizeOplus with
+    third(), the two oplusImpl and stereocam_uvu_map, compiled from the reference (anchored_points.h as it is, the function bodies and the
+    Jacobian helpers of transformations.h:62-95 piped from where they lie; SE3 algebra handed to the oracle's).  Random anchored points seen
+    from random keyframes, incl. self edges (observer = anchor), points close to the camera and far away: the oracle's error and its three
+    Jacobian blocks are BIT-EQUAL to the reference's; the pose-pose edge agrees to 1e-14 (its (1/12) dl dl Adj term associates differently)."""
+    import ctypes as C
+    L = O.ref_edges_lib()
+    rng = np.random.default_rng(17)
+    from scavislam_amd.ctypes_types import Cam
+    def ptr(a):
+        return C.c_void_p(a.ctypes.data)
+    n_self = 0
+    for k in range(600):
+        f, cx, cy, b = 300 + 500 * rng.random(), 320 + 20 * rng.normal(), 240 + 20 * rng.normal(), 0.05 + 0.3 * rng.random()
+        cam = Cam(f, cx, cy, b, 640, 480)
+        cam4 = np.array([f, cx, cy, b])
+        T_anc = synth.pose(synth.so3_exp(rng.normal(0, 0.3, 3)), rng.normal(0, 2.0, 3)).reshape(12)
+        self_edge = k % 7 == 0
+        T_obs = T_anc.copy() if self_edge else synth.pose_mul(synth.pose(synth.so3_exp(rng.normal(0, 0.05, 3)), rng.normal(0, 0.4, 3)), T_anc.reshape(3, 4)).reshape(12)
+        n_self += self_edge
+        z = np.exp(rng.uniform(np.log(0.3), np.log(80.0)))
+        psi = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.4, 0.4), 1.0 / z])
+        obs = np.array([rng.uniform(0, 640), rng.uniform(0, 480), rng.uniform(0, 640)])
+        err, Jp, Jo, Ja = np.zeros(3), np.zeros(9), np.zeros(18), np.zeros(18)
+        L.svs_refedge_psi2uvu(ptr(psi), ptr(T_obs), ptr(T_anc), ptr(obs), ptr(cam4), ptr(err), ptr(Jp), ptr(Jo), ptr(Ja))
+        e2, Jp2, Jo2, Ja2 = O.edge_psi2uvu(psi, T_obs, T_anc, obs, cam)
+        assert np.array_equal(err, e2), f"error {err} vs {e2}"
+        assert np.array_equal(Jp, Jp2.ravel()) and np.array_equal(Jo, Jo2.ravel()) and np.array_equal(Ja, Ja2.ravel()), k
+        # camera map on its own
+        xyz = np.array([rng.normal(), rng.normal(), z]); uvu = np.zeros(3)
+        L.svs_refcam_uvu(ptr(cam4), ptr(xyz), ptr(uvu))
+        assert np.array_equal(uvu, [xyz[0] / xyz[2] * f + cx, xyz[1] / xyz[2] * f + cy, (xyz[0] - b) / xyz[2] * f + cx])
+    assert n_self > 50
+    for k in range(300):
+        T1 = synth.pose(synth.so3_exp(rng.normal(0, 0.4, 3)), rng.normal(0, 2.0, 3)).reshape(12)
+        T2 = synth.pose(synth.so3_exp(rng.normal(0, 0.4, 3)), rng.normal(0, 2.0, 3)).reshape(12)
+        T21 = synth.pose_mul(synth.pose(synth.so3_exp(rng.normal(0, 0.02, 3)), rng.normal(0, 0.05, 3)),
+                             synth.pose_mul(T2.reshape(3, 4), synth.pose_inv(T1.reshape(3, 4)))).reshape(12)
+        err, J1, J2 = np.zeros(6), np.zeros(36), np.zeros(36)
+        L.svs_refedge_se3(ptr(T21), ptr(T1), ptr(T2), ptr(err), ptr(J1), ptr(J2))
+        e2, J1o, J2o = O.edge_se3(T21, T1, T2)
+        assert np.array_equal(err, e2)
+        np.testing.assert_allclose(J1, J1o.ravel(), rtol=0, atol=1e-14 * np.abs(J1).max())
+        np.testing.assert_allclose(J2, J2o.ravel(), rtol=0, atol=1e-14 * np.abs(J2).max())
+    # vertex updates: exp(update) * T from the left; psi += update
+    for k in range(100):
+        T = synth.pose(synth.so3_exp(rng.normal(0, 0.4, 3)), rng.normal(0, 2.0, 3)).reshape(12)
+        upd = rng.normal(0, 0.05, 6); out = np.zeros(12)
+        L.svs_refvertex_oplus_se3(ptr(T), ptr(upd), ptr(out))
+        np.testing.assert_allclose(out.reshape(3, 4), synth.pose_mul(np.asarray(O.se3_exp(upd)).reshape(3, 4), T.reshape(3, 4)), rtol=0, atol=1e-15 * 10)
+        p = rng.normal(0, 1, 3); u3 = rng.normal(0, 0.1, 3); o3 = np.zeros(3)
+        L.svs_refvertex_oplus_xyz(ptr(p), ptr(u3), ptr(o3))
+        assert np.array_equal(o3, p + u3)
