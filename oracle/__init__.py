@@ -810,11 +810,77 @@ def ref_edges_lib():
     return L
 
 
-def ref_znssd_lib():
-    L = _ref_lib("libsvs_ref_znssd.so")
+def ref_matcher_lib():
+    """oracle/_ref/libsvs_ref_matcher.so: the reference's own GuidedMatcher<StereoCamera> (matcher.cpp:31-459 + matcher-impl.cpp:30-51)."""
+    L = _ref_lib("libsvs_ref_matcher.so")
     L.svs_refznssd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.svs_refznssd_patch_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svs_refmatch_warp_affine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.svs_refmatch_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]
+    L.svs_refmatch_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
     return L
+
+
+def ref_warp_affine(frame, T, depth, key_uv, cam, halfpatch=5):
+    """The reference's own GuidedMatcher::warpAffinve (matcher.cpp:403-458); same arguments as warp_affine()."""
+    frame = np.ascontiguousarray(frame)
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    kuv = np.ascontiguousarray(key_uv, np.float64)
+    out = np.zeros((2 * halfpatch, 2 * halfpatch), np.uint8)
+    ref_matcher_lib().svs_refmatch_warp_affine(_p(frame), frame.strides[0], _p(T), float(depth), _p(kuv), C.byref(cam), halfpatch, _p(out))
+    return out
+
+
+def match_candidates(cur_img, cam, cand_xyc, key, sumA, sumAA, init_dist, ref=False, level=0):
+    """matchCandidates (matcher.cpp:144-181) over (x, y, content) triples in list order -> (min_dist, index, u, v); ref=True: the
+    reference's own function."""
+    cur = np.ascontiguousarray(cur_img)
+    cand = np.ascontiguousarray(cand_xyc, np.int32).reshape(-1, 3)
+    key = np.ascontiguousarray(key, np.uint8).reshape(64)
+    out = np.zeros(4, np.int32)
+    if ref:
+        ref_matcher_lib().svs_refmatch_candidates(_p(cur), cur.strides[0], C.byref(cam), level, _p(cand), len(cand), _p(key), int(sumA), int(sumAA),
+                                                  int(init_dist), _p(out))
+    else:
+        L = lib()
+        L.svs_ref_match_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svs_ref_match_candidates(_p(cur), cur.strides[0], C.byref(cam), _p(cand), len(cand), _p(key), int(sumA), int(sumAA), int(init_dist), _p(out))
+    return tuple(int(v) for v in out)
+
+
+def ref_match(kf_pyrs, kf_poses, T_cur_from_actkey, actkey_index, cur_pyr, disp, corners, cams, pts, radius=8, thr_mean=22, thr_std=10):
+    """The reference's own GuidedMatcher<StereoCamera>::match.  corners: per level an [n, 2] array, inserted into that level's QuadTree in
+    this order; the active keyframe is kf_poses[actkey_index].  Returns (point index, obs uvu, xyz_actkey) per appended observation, in
+    TrackData order."""
+    n_kf = len(kf_pyrs)
+    kfs = np.zeros(n_kf, KEYFRAME_DTYPE)
+    keep = []
+    for i, pyr in enumerate(kf_pyrs):
+        kfs[i]["T_anchor_from_w"] = np.asarray(kf_poses[i], np.float64).reshape(12)
+        for l in range(3):
+            a = np.ascontiguousarray(pyr[l])
+            keep.append(a)
+            kfs[i]["pyr"][l] = a.ctypes.data
+            kfs[i]["stride"][l] = a.strides[0]
+    kf_ids = np.arange(100, 100 + 7 * n_kf, 7, dtype=np.int32)      # arbitrary keyframe ids: the reference looks them up in hash maps
+    cur = [np.ascontiguousarray(a) for a in cur_pyr]
+    cur_ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in cur])
+    cur_strides = (C.c_int * 3)(*[a.strides[0] for a in cur])
+    disp = np.ascontiguousarray(disp, np.float32)
+    cor = [np.ascontiguousarray(c, np.float64).reshape(-1, 2) for c in corners]
+    cor_ptrs = (C.c_void_p * 3)(*[c.ctypes.data for c in cor])
+    cor_n = (C.c_int * 3)(*[len(c) for c in cor])
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+    n = len(pts)
+    obs_point = np.zeros(n, np.int32); obs = np.zeros((n, 3)); xyz = np.zeros((n, 3))
+    k = ref_matcher_lib().svs_refmatch_match(_p(kfs), n_kf, _p(kf_ids), int(kf_ids[actkey_index]), _p(Tc), cur_ptrs, cur_strides, _p(disp),
+                                             disp.strides[0] // 4, disp.shape[1], disp.shape[0], cor_ptrs, cor_n, cams, _p(pts), n, radius,
+                                             thr_mean, thr_std, _p(obs_point), _p(obs), _p(xyz))
+    return obs_point[:k].copy(), obs[:k].copy(), xyz[:k].copy()
 
 
 _REF = None

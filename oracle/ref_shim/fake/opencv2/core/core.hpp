@@ -19,12 +19,14 @@ template <typename T> struct Point_ {
 };
 typedef Point_<double> Point2d;
 typedef Point_<float> Point2f;
+typedef Point_<int> Point;
 template <typename T> struct Rect_ {
   T x, y, width, height;
   Rect_() : x(0), y(0), width(0), height(0) {}
   Rect_(T x_, T y_, T w_, T h_) : x(x_), y(y_), width(w_), height(h_) {}
   bool contains(const Point_<T> &pt) const { return x <= pt.x && pt.x < x + width && y <= pt.y && pt.y < y + height; }
 };
+struct Size;
 struct Range {
   int start, end;
   Range() : start(0), end(0) {}
@@ -35,6 +37,11 @@ struct Size {
   Size() : width(0), height(0) {}
   Size(int w, int h) : width(w), height(h) {}
 };
+struct Rect : public Rect_<int> {
+  Rect() {}
+  Rect(int x_, int y_, int w_, int h_) : Rect_<int>(x_, y_, w_, h_) {}
+  Rect(const Point &p, const Size &s) : Rect_<int>(p.x, p.y, s.width, s.height) {}
+};
 struct KeyPoint {
   Point2f pt;
   KeyPoint() {}
@@ -42,6 +49,7 @@ struct KeyPoint {
 };
 }  // namespace cv
 #define CV_8U 0
+#define CV_8UC1 0
 #define CV_32F 5
 #define CV_32FC4 29
 namespace cv {
@@ -61,6 +69,11 @@ class Mat {
   Mat() : rows(0), cols(0), type_(CV_8U), step(0), data(0) {}
   static size_t elem(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : 16; }
   Mat(int r, int c, int type, void *d, size_t s = 0) : rows(r), cols(c), type_(type), step(s ? s : (size_t)c * elem(type)), data(static_cast<uint8_t *>(d)) {}
+  Mat(int r, int c, int type) : rows(r), cols(c), type_(type), step((size_t)c * elem(type)), data(0) { own.reset(new std::vector<uint8_t>((size_t)r * step)); data = own->data(); }
+  Mat(Size sz, int type) : rows(sz.height), cols(sz.width), type_(type), step((size_t)sz.width * elem(type)), data(0) { own.reset(new std::vector<uint8_t>((size_t)rows * step)); data = own->data(); }
+  template <typename T> T *ptr(int y, int x) { return &at<T>(y, x); }
+  template <typename T> const T *ptr(int y, int x) const { return &at<T>(y, x); }
+  Mat operator()(const Rect &r) const { return (*this)(Range(r.y, r.y + r.height), Range(r.x, r.x + r.width)); }
   int type() const { return type_; }
   Size size() const { return Size(cols, rows); }
   template <typename T> T &at(int y, int x) { return *reinterpret_cast<T *>(data + (size_t)y * step + (size_t)x * sizeof(T)); }

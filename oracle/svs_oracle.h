@@ -171,6 +171,9 @@ void svs_ref_warp_affine(const uint8_t *frame, int stride, const double T_c2_fro
                          int halfpatch, uint8_t *patch /* (2*halfpatch)^2 */);
 /* matcher.cpp:42-74 */
 int svs_ref_znssd(const uint8_t key[64], const uint8_t cur[64], int sumA, int sumAA);
+/* matcher.cpp:144-181 matchCandidates over (x, y, content) triples in query order; out = {min_dist, index, u, v} */
+void svs_ref_match_candidates(const uint8_t *cur_img, int cur_stride, const svs_cam *cam, const int32_t *cand_xyc, int nc,
+                              const uint8_t *key, int sumA, int sumAA, int init_dist, int *out);
 /* GuidedMatcher<StereoCamera>::match for n points; corners per level given as quadtrees */
 void svs_ref_match(const svs_keyframe *kfs, int n_kf,
                    const double T_cur_from_actkey[12], const double T_actkey_from_w[12],

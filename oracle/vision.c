@@ -333,6 +333,23 @@ int svs_ref_znssd(const uint8_t *key, const uint8_t *cur, int sumA, int sumAA) {
   return sumAA - 2 * sumAB - sumBB - (sumA * sumA - 2 * sumA * sumB - sumB * sumB) / 64;
 }
 
+/* matcher.cpp:144-181 matchCandidates: the candidates in the order the quadtree query returned them, strict '<' (the first of equal
+   scores wins); out = {min_dist, index (content of the winner, -1: none), u, v} */
+void svs_ref_match_candidates(const uint8_t *cur_img, int cur_stride, const svs_cam *cam, const int32_t *cand_xyc, int nc,
+                              const uint8_t *key, int sumA, int sumAA, int init_dist, int *out) {
+  int min_dist = init_dist, index = -1, bu = 0, bv = 0;
+  for (int k = 0; k < nc; ++k) {
+    int cu = cand_xyc[3 * k], cv = cand_xyc[3 * k + 1];
+    if (!in_frame(cam, cu, cv, 6)) continue;
+    uint8_t cur[64];
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c)
+      cur[r * 8 + c] = cur_img[(size_t)(cv - 4 + r) * cur_stride + (cu - 4 + c)];
+    int z = svs_ref_znssd(key, cur, sumA, sumAA);
+    if (z < min_dist) { min_dist = z; index = cand_xyc[3 * k + 2]; bu = cu; bv = cv; }
+  }
+  out[0] = min_dist; out[1] = index; out[2] = bu; out[3] = bv;
+}
+
 /* matcher.cpp:312-398 for each point (+ computePrediction :98-142, matchCandidates :144-181,
  * returnBestMatch :183-214, createObervation matcher-impl.cpp:33-51). */
 void svs_ref_match(const svs_keyframe *kfs, int n_kf, const double *T_cur_from_actkey,
@@ -375,16 +392,9 @@ void svs_ref_match(const svs_keyframe *kfs, int n_kf, const double *T_cur_from_a
     for (int r = 0; r < 64; ++r) { sA += key[r]; sAA += key[r] * key[r]; }
     int sumA = (int)sA, sumAA = (int)sAA;
     if (sumA * sumA - sumAA < (int)(thr_std * thr_std * 64)) { o->status = SVS_MATCH_TEXTURE; continue; }
-    int min_dist = thr_mean * thr_mean * 64, index = -1, bu = 0, bv = 0;
-    for (int k = 0; k < nc; ++k) {
-      int cu = cand[3 * k], cv = cand[3 * k + 1];
-      if (!in_frame(cam, cu, cv, 6)) continue;
-      uint8_t cur[64];
-      for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c)
-        cur[r * 8 + c] = cur_pyr[lvl][(size_t)(cv - 4 + r) * cur_stride[lvl] + (cu - 4 + c)];
-      int z = svs_ref_znssd(key, cur, sumA, sumAA);
-      if (z < min_dist) { min_dist = z; index = cand[3 * k + 2]; bu = cu; bv = cv; }
-    }
+    int best[4];
+    svs_ref_match_candidates(cur_pyr[lvl], cur_stride[lvl], cam, cand, nc, key, sumA, sumAA, thr_mean * thr_mean * 64, best);
+    int min_dist = best[0], index = best[1], bu = best[2], bv = best[3];
     double T_anchor_from_actkey[12], T_actkey_from_anchor[12];
     pose_mul(kf->T_anchor_from_w, T_w_from_actkey, T_anchor_from_actkey);
     pose_inv(T_anchor_from_actkey, T_actkey_from_anchor);

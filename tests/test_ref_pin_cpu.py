@@ -414,10 +414,10 @@ def test_fastgrid_reference_state_machine_edge_cases():
 
 # ---- the reference's own ZNSSD (row a8) ---------------------------------------------------------------------------------------------
 def test_znssd_equals_reference_compiled_znssd():
-    """matcher.cpp:35-97 compiled from where it lies: computePatchScores and matchPatchZeroMeanSSD on random, flat, saturated and
+    """matcher.cpp:35-97 (part of the matcher library) compiled from where it lies: computePatchScores and matchPatchZeroMeanSSD on random, flat, saturated and
     anti-correlated 8x8 patches -- the oracle's integer formula (incl. the truncating division and the sign pattern of the reference) is
     bit-equal, also when the caller's sums are not the patch's own (the function takes them as arguments)."""
-    L = O.ref_znssd_lib()
+    L = O.ref_matcher_lib()
     rng = np.random.default_rng(8)
     import ctypes as C
     cases = [(rng.integers(0, 256, 64), rng.integers(0, 256, 64)) for _ in range(2000)]
@@ -433,6 +433,135 @@ def test_znssd_equals_reference_compiled_znssd():
         for dA, dAA in ((5, -11), (-300, 4000)):                # foreign sums
             assert L.svs_refznssd(key.ctypes.data, cur.ctypes.data, sA.value + dA, sAA.value + dAA) == \
                 O.lib().svs_ref_znssd(C.c_void_p(key.ctypes.data), C.c_void_p(cur.ctypes.data), sA.value + dA, sAA.value + dAA)
+
+
+# ---- the reference's own GuidedMatcher (rows a8 - a10) --------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def matcher_cpu_case():
+    from scavislam_amd.ctypes_types import level_cams
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8)
+    cam = synth.CAM_DEFAULT
+    cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+    k0, k1, c = 0, 2, 5
+    img_k0, disp_k0 = sc.render(cam, traj[k0], seed=k0)
+    img_k1, disp_k1 = sc.render(cam, traj[k1], seed=k1)
+    img_c, disp_c = sc.render(cam, traj[c], seed=c)
+    img_k0 = img_k0.copy(); img_k0[100:180, 200:330] = 0      # black key patches: the (sum^2 - sum of squares) gate of match()
+    disp_c = disp_c.copy(); disp_c[::9, ::4] = 0.0; disp_c[200:260, 100:300] = -1.0        # matches without a disparity
+    pyr_c = O.build_pyramid(img_c)
+    corners = []
+    for l in range(3):
+        g = O.fastgrid_for_level(pyr_c[l].shape[1], pyr_c[l].shape[0], l)
+        for _ in range(3):
+            xy, cc, et = O.fastgrid_detect_adaptively(g, pyr_c[l], 6)
+        corners.append(xy.astype(np.int32))
+    rng = np.random.default_rng(31)
+    pts = np.concatenate([synth.candidate_points(rng, cam, disp_k0, traj[k0], (500, 250, 90), kf_index=0),
+                          synth.candidate_points(rng, cam, disp_k1, traj[k1], (500, 250, 90), kf_index=1)])
+    rng.shuffle(pts)
+    pts["point_id"] = np.arange(len(pts))
+    pts[0]["kf_index"] = -1                                   # anchor keyframe not in the vertex map
+    pts[1]["anchor_obs_pyr"][:2] = (2.0, 2.0)                 # anchor observation at the border
+    pts[2]["xyz_anchor"] *= 0.05                              # inverse depth ratio > 3
+    pts[3]["xyz_anchor"] *= 9.0
+    T_act = traj[k1]
+    T_guess = synth.pose_mul(traj[c], synth.pose_inv(T_act))
+    T_guess[:, 3] += np.array([0.003, -0.002, 0.004])
+    return dict(cams=cams, kf_pyrs=[O.build_pyramid(img_k0), O.build_pyramid(img_k1)], kf_poses=[traj[k0].reshape(12), traj[k1].reshape(12)],
+                T_guess=T_guess, T_act=T_act, pyr_c=pyr_c, disp_c=disp_c, corners=corners, pts=pts)
+
+
+def _oracle_trees(case):
+    trees = []
+    for l in range(3):
+        t = O.QuadTree(case["pyr_c"][l].shape[1], case["pyr_c"][l].shape[0], 1.0)
+        for i, (x, y) in enumerate(case["corners"][l]):
+            assert t.insert(x, y, i)
+        trees.append(t)
+    return trees
+
+
+def test_warp_affine_equals_reference_compiled_warp(matcher_cpu_case):
+    """matcher.cpp:403-458 compiled from where it lies (Eigen's 2x2 inverse = adjugate / determinant, SE3 action = the oracle's): the 10x10
+    key patches of 400 candidate points incl. ones whose warp leaves the image (zeros) are byte-equal with the restatement, also for a
+    rotated / scaled relative pose and for a non-square half size."""
+    case = matcher_cpu_case
+    rng = np.random.default_rng(5)
+    T_cw = synth.pose_mul(case["T_guess"], case["T_act"])
+    n_zero = 0
+    for p in case["pts"][4:404]:
+        l = int(p["anchor_level"]); k = int(p["kf_index"])
+        T = synth.pose_mul(T_cw, synth.pose_inv(case["kf_poses"][k].reshape(3, 4)))
+        if rng.random() < 0.3:                                 # strong in-plane rotation + approach
+            T = synth.pose_mul(np.hstack([synth.so3_exp(rng.normal(0, 0.3, 3)), rng.normal(0, 0.3, (3, 1))]), T)
+        key_uv = p["anchor_obs_pyr"][:2] + (rng.random(2) if rng.random() < 0.5 else 0.0)
+        if rng.random() < 0.1:
+            key_uv = np.array([rng.uniform(-3, 6), rng.uniform(-3, 6)])      # patch partly outside the keyframe
+        for hp in (5, 3):
+            a = O.ref_warp_affine(case["kf_pyrs"][k][l], T, p["xyz_anchor"][2], key_uv, case["cams"][l], hp)
+            b = O.warp_affine(case["kf_pyrs"][k][l], T, p["xyz_anchor"][2], key_uv, case["cams"][l], hp)
+            assert np.array_equal(a, b)
+            n_zero += int((a == 0).sum() > 10)
+    assert n_zero > 5
+
+
+def test_match_candidates_equals_reference_compiled_loop(matcher_cpu_case):
+    """matcher.cpp:144-181 compiled from where it lies, fed with the candidate lists of the reference's own QuadTree query: winner, score and
+    position equal the restatement's -- incl. lists with corners inside the 6-pixel frame margin, ties (first wins) and no winner."""
+    case = matcher_cpu_case
+    rng = np.random.default_rng(6)
+    n_hit = n_none = 0
+    for l in range(3):
+        img = case["pyr_c"][l]
+        h, w = img.shape
+        cam = case["cams"][l]
+        rt = O.RefQuadTree(w, h, 1.0)
+        for i, (x, y) in enumerate(case["corners"][l]):
+            rt.insert(x, y, i)
+        margin = np.array([[3, 40, 9001], [w - 4, 50, 9002], [60, 5, 9003], [70, h - 6, 9004]], np.int32)      # rejected by isInFrame(.., 6)
+        for _ in range(150):
+            cx, cy = int(rng.integers(10, w - 10)), int(rng.integers(10, h - 10))
+            cand = rt.query(cx - 8, cy - 8, 17, 17)
+            cand = np.concatenate([margin[:2], cand, margin[2:]]).astype(np.int32)
+            if len(cand) > 6 and rng.random() < 0.3:
+                cand = np.concatenate([cand, cand[4:6]])       # the same corner twice: equal score, the first stays
+            x0, y0 = (cand[len(cand) // 2][:2] if rng.random() < 0.7 else (cx, cy))
+            x0 = int(np.clip(x0, 4, w - 5)); y0 = int(np.clip(y0, 4, h - 5))
+            key = img[y0 - 4:y0 + 4, x0 - 4:x0 + 4].astype(np.int32) + rng.integers(-6, 7, (8, 8))
+            key = np.clip(key, 0, 255).astype(np.uint8)
+            sA = int(key.astype(np.int64).sum()); sAA = int((key.astype(np.int64) ** 2).sum())
+            for init in (22 * 22 * 64, 300):
+                a = O.match_candidates(img, cam, cand, key, sA, sAA, init, ref=True, level=l)
+                b = O.match_candidates(img, cam, cand, key, sA, sAA, init)
+                if a[1] < 0:
+                    assert b[1] < 0 and a[0] == b[0] == init
+                    n_none += 1
+                else:
+                    assert a == b and a[1] < 9000
+                    n_hit += 1
+    assert n_hit > 300 and n_none > 30
+
+
+def test_match_equals_reference_compiled_match(matcher_cpu_case):
+    """The reference's whole GuidedMatcher<StereoCamera>::match (computePrediction, quadtree query, warpAffinve, texture gate, matchCandidates,
+    returnBestMatch / createObervation / interpolateDisparity) compiled from where it lies, with its own containers (hash maps of keyframes
+    and vertices, list of shared CandidatePoints, vector of QuadTrees): the observations it appends are exactly the points the restatement
+    reports with status OK, in the same order, with bit-equal observations (u, v, u - d at level 0) and points in the active keyframe."""
+    case = matcher_cpu_case
+    trees = _oracle_trees(case)
+    for thr_mean, thr_std, radius in ((22, 10, 8), (12, 0, 5)):
+        ref_idx, ref_obs, ref_xyz = O.ref_match(case["kf_pyrs"], case["kf_poses"], case["T_guess"], 1, case["pyr_c"], case["disp_c"], case["corners"],
+                                                case["cams"], case["pts"], radius, thr_mean, thr_std)
+        res = O.match(case["kf_pyrs"], case["kf_poses"], case["T_guess"], case["T_act"], case["pyr_c"], case["disp_c"], trees, case["cams"], case["pts"],
+                      radius, thr_mean, thr_std)
+        ok = np.nonzero(res["status"] == 0)[0]
+        assert np.array_equal(ok, ref_idx), (len(ok), len(ref_idx))
+        assert np.array_equal(res["obs"][ok], ref_obs)
+        assert np.array_equal(res["xyz_actkey"][ok], ref_xyz)
+        counts = np.bincount(res["status"], minlength=7)
+        assert counts[0] > 300 and counts[6] > 10 and counts[1] == 1 and counts[2] >= 1 and counts[3] >= 1 and counts[5] > 10, counts
+        assert (counts[4] > 3) == (thr_std > 0), counts
 
 
 # ---- the reference's own quarter-grid dense tracker (rows a11 / a12) ---------------------------------------------------------------
