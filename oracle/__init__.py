@@ -452,6 +452,18 @@ def motion_only(results, cam, T, prm=None):
     return Tio.reshape(3, 4), st
 
 
+def ref_motion_only(results, cam, T, prm=None):
+    """The reference's own PoseOptimizer::calcFastMotionOnly (oracle/_ref/libsvs_ref_pose.so); same arguments as motion_only()."""
+    prm = prm or PoseOptParams.reference()
+    res = np.ascontiguousarray(results, MATCH_RESULT_DTYPE)
+    Tio = np.array(T, np.float64).reshape(12).copy()
+    st = PoseOptStats()
+    L = _ref_lib("libsvs_ref_pose.so")
+    L.svs_refpose_motion_only.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svs_refpose_motion_only(_p(res), len(res), C.byref(cam), C.byref(prm), _p(Tio), C.byref(st))
+    return Tio.reshape(3, 4), st
+
+
 def process_matched_points(results, pts, n_new_records, cam, T, max_reproj_error=2.0):
     """StereoFrontend::processMatchedPoints over a MATCH_RESULT_DTYPE array and its CANDIDATE_DTYPE points;
     returns (GATED_POINT_DTYPE[n], POINT_STATS_DTYPE scalar)."""

@@ -10,3 +10,5 @@ template <class K, class M> const typename M::mapped_type &svs_get_map_elem(cons
 }
 }
 #define GET_MAP_ELEM(key, map) VisionTools::svs_get_map_elem(key, map)
+// GET_VEC_VAL_REF(index, pointer to vector) = reference to the element that must exist (pose_optimizer.h:159)
+#define GET_VEC_VAL_REF(idx, vec) ((vec)->at(idx))

@@ -564,6 +564,52 @@ def test_match_equals_reference_compiled_match(matcher_cpu_case):
         assert (counts[4] > 3) == (thr_std > 0), counts
 
 
+# ---- the reference's own motion-only pose refinement (after the matcher, stereo_frontend.cpp:1058-1063) ------------------------------
+def _motion_results(rng, cam, T_true, n, outliers=0.1, n_fail=30, noise=0.4):
+    from scavislam_amd.ctypes_types import MATCH_RESULT_DTYPE
+    res = np.zeros(n, MATCH_RESULT_DTYPE)
+    xyz = np.stack([rng.uniform(-3, 3, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2.5, 15, n)], 1)
+    p = xyz @ T_true[:, :3].T + T_true[:, 3]
+    obs = np.stack([p[:, 0] / p[:, 2] * cam["f"] + cam["cx"], p[:, 1] / p[:, 2] * cam["f"] + cam["cy"],
+                    (p[:, 0] - cam["b"]) / p[:, 2] * cam["f"] + cam["cx"]], 1) + rng.normal(0, noise, (n, 3))
+    bad = rng.random(n) < outliers
+    obs[bad] += rng.uniform(-25, 25, (int(bad.sum()), 3))
+    res["obs"], res["xyz_actkey"] = obs, xyz
+    if n_fail:
+        res["status"][rng.choice(n, n_fail, replace=False)] = rng.integers(1, 7, n_fail)
+    return res
+
+
+def test_motion_only_equals_reference_compiled_pose_optimizer():
+    """pose_optimizer.h compiled as it is (calcFastMotionOnly, the pseudo-Huber kernel, mulW / sqrW) with AbstractPrediction / SE3XYZ_STEREO /
+    IdObs from transformations.h and the reference's StereoCamera::map_uvu: refined pose, initial / final chi2, max error and observation
+    count are bit-equal with the restatement -- robust and plain, automatic and given mu, with outliers, from a far start (rejected steps)
+    and at the optimum (stop by five rejections); the empty list is refused by both."""
+    from scavislam_amd.ctypes_types import Cam, PoseOptParams
+    rng = np.random.default_rng(17)
+    n_cases = 0
+    for cam in (synth.CAM_DEFAULT, synth.CAM_NEWCOLLEGE):
+        camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        T_true = synth.pose(synth.so3_exp(np.array([0.01, -0.02, 0.005])), np.array([0.03, -0.01, 0.08]))
+        far = synth.pose(synth.so3_exp(np.array([0.1, 0.05, -0.08])), np.array([0.4, -0.3, 0.5]))
+        for n, outl, noise in ((400, 0.1, 0.4), (60, 0.0, 0.0), (25, 0.3, 1.0)):
+            res = _motion_results(rng, cam, T_true, n, outl, n_fail=n // 10, noise=noise)
+            for T0 in (np.eye(3, 4), T_true, far):
+                for prm in (None, PoseOptParams(0, 15, 2.0, -1.0, 1e-5), PoseOptParams(1, 3, 1.0, 1e-3, 1e-5), PoseOptParams(1, 50, 0.5, -1.0, 1e-3)):
+                    Ta, sa = O.ref_motion_only(res, camc, T0, prm)
+                    Tb, sb = O.motion_only(res, camc, T0, prm)
+                    assert sa.status == sb.status == 0
+                    assert np.array_equal(Ta, Tb), np.abs(Ta - Tb).max()
+                    assert (sa.initial_chi2, sa.chi2, sa.max_err, sa.num_obs) == (sb.initial_chi2, sb.chi2, sb.max_err, sb.num_obs)
+                    assert sa.num_obs == int((res["status"] == 0).sum()) and sa.chi2 <= sa.initial_chi2
+                    n_cases += 1
+            if noise == 0.4:
+                assert np.abs(O.motion_only(res, camc, np.eye(3, 4))[0] - T_true).max() < 5e-3
+        empty = res.copy(); empty["status"] = 5
+        assert O.ref_motion_only(empty, camc, T_true)[1].status == 1 and O.motion_only(empty, camc, T_true)[1].status == 1
+    assert n_cases == 72
+
+
 # ---- the reference's own quarter-grid dense tracker (rows a11 / a12) ---------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dense_cpu_cases():
