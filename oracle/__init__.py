@@ -482,6 +482,27 @@ def process_matched_points(results, pts, n_new_records, cam, T, max_reproj_error
     return gated, stats[0]
 
 
+def ref_process_matched_points(results, pts, n_new_records, cam, T, max_reproj_error=2.0):
+    """The reference's own StereoFrontend::processMatchedPoints (oracle/_ref/libsvs_ref_gate.so); arguments as process_matched_points().
+    Returns (gated, stats, tree) -- stats["sum_track_length"] holds the reference's AVERAGE track length (its member av_track_length_),
+    tree = [m, 4] (level, x, y, point_id) content of the point trees it filled, in query order."""
+    res = np.ascontiguousarray(results, MATCH_RESULT_DTYPE)
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    assert len(res) == len(pts)
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    gated = np.zeros(len(res), GATED_POINT_DTYPE)
+    stats = np.zeros(1, POINT_STATS_DTYPE)
+    tree = np.zeros((len(res) + 1, 4), np.float64)
+    tn = C.c_int(0)
+    L = _ref_lib("libsvs_ref_gate.so")
+    L.svs_refgate_process_matched_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.svs_refgate_process_matched_points.restype = None
+    L.svs_refgate_process_matched_points(_p(res), _p(pts), len(res), int(n_new_records), C.byref(cam), _p(T), C.c_float(max_reproj_error),
+                                         _p(gated), _p(stats), _p(tree), len(tree), C.byref(tn))
+    return gated, stats[0], tree[:tn.value].copy()
+
+
 # ---- full-resolution (CUDA-build) dense tracker: restatement + the reference-compiled pin -----------------
 SUM_F64, SUM_F32_TREE = 0, 1
 

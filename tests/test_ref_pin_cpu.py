@@ -610,6 +610,59 @@ def test_motion_only_equals_reference_compiled_pose_optimizer():
     assert n_cases == 72
 
 
+# ---- the reference's own processMatchedPoints (row f3: the reprojection gate behind the motion-only refinement) ----------------------
+def test_gate_equals_reference_compiled_process_matched_points():
+    """stereo_frontend.cpp:832-974 compiled from where it lies against the reference's own stereo_frontend.h / draw_items.h / matcher.hpp /
+    data_structures.h, driven with its own containers (TrackData lists, shared CandidatePoints, point QuadTrees, hash set of new features):
+    which records pass the gate and which of them are new features, the 2x2 / 3x3 / per-level counters, the pyramid-level positions of both
+    line ends, the average track length and the points inserted into the per-level trees all equal the restatement bit for bit -- residuals
+    straddling the three thresholds (2 * 2^level px in u, v; 6 px in u_right), three slider positions, two cameras."""
+    from scavislam_amd.ctypes_types import CANDIDATE_DTYPE, Cam
+    rng = np.random.default_rng(5)
+    for cam in (synth.CAM_DEFAULT, synth.CAM_NEWCOLLEGE):
+        camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        T = synth.pose(synth.so3_exp(np.array([0.01, -0.02, 0.005])), np.array([0.03, -0.01, 0.08]))
+        n, n_new = 700, 260
+        res = _motion_results(rng, cam, T, n, outliers=0.25)
+        res["obs"] += rng.choice([0.0, 1.9, 2.1, 3.9, 4.1, 5.9, 6.1, 7.9, 8.1], size=res["obs"].shape) * rng.choice([-1, 1], size=res["obs"].shape)
+        inside = (res["obs"][:, 0] >= 1) & (res["obs"][:, 0] < cam["w"] - 1) & (res["obs"][:, 1] >= 1) & (res["obs"][:, 1] < cam["h"] - 1)
+        res["status"][~inside] = 5                              # the reference asserts that an accepted observation lies inside its level image
+        pts = np.zeros(n, CANDIDATE_DTYPE)
+        pts["anchor_level"] = rng.integers(0, 3, n)
+        pts["point_id"] = rng.permutation(n) + 1000
+        pts["kf_index"] = rng.integers(0, 4, n)
+        for mre in (2.0, 0.75, 5.0):
+            ga, sa, tree = O.ref_process_matched_points(res, pts, n_new, camc, T, mre)
+            gb, sb = O.process_matched_points(res, pts, n_new, camc, T, mre)
+            for k in ("accepted", "is_new", "uv_pyr", "curkey_uv_pyr"):
+                assert np.array_equal(ga[k], gb[k]), (k, mre)
+            for k in ("num_points_grid2x2", "num_points_grid3x3", "num_matched_points", "num_track_points", "num_obs"):
+                assert np.array_equal(sa[k], sb[k]), (k, sa[k], sb[k])
+            assert sa["sum_track_length"] == sb["sum_track_length"] / sb["num_track_points"]
+            acc = np.nonzero(gb["accepted"])[0]
+            assert 0 < len(acc) < sb["num_obs"] and gb["is_new"].sum() == gb["accepted"][:n_new].sum() > 0
+            # the point trees: the accepted observations inserted in list order at uv_pyr (fractional) with content = point id; a point closer
+            # than delta = 1 to the leaf it lands in is refused (quadtree.h:632) -- same content and query order as the restated tree
+            k_tree = 0
+            for l in range(3):
+                qt = O.QuadTree(cam["w"] >> l, cam["h"] >> l, 1.0)
+                for k in acc:
+                    if pts["anchor_level"][k] == l:
+                        qt.insert(gb["uv_pyr"][k][0], gb["uv_pyr"][k][1], int(pts["point_id"][k]))
+                mine = qt.query(0, 0, cam["w"] >> l, cam["h"] >> l, cap=4096)
+                theirs = tree[tree[:, 0] == l]
+                assert len(mine) == len(theirs)
+                assert np.array_equal(mine[:, 2], theirs[:, 3].astype(np.int64))
+                assert np.array_equal(mine[:, :2], theirs[:, 1:3].astype(np.int64))      # the restated query returns integer positions
+                k_tree += len(mine)
+            assert k_tree == len(tree) <= len(acc) and (mre < 2.0 or k_tree > 60)
+    # nothing matched: no division by zero surprises in the restatement's sum
+    res["status"] = 5
+    ga, sa, tree = O.ref_process_matched_points(res, pts, n_new, camc, T, 2.0)
+    gb, sb = O.process_matched_points(res, pts, n_new, camc, T, 2.0)
+    assert ga["accepted"].sum() == gb["accepted"].sum() == 0 and sa["num_obs"] == sb["num_obs"] == 0 and len(tree) == 0
+
+
 # ---- the reference's own quarter-grid dense tracker (rows a11 / a12) ---------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dense_cpu_cases():
