@@ -820,6 +820,41 @@ def ref_dense_tracking_cpu(clouds, prev_pyr, cur_f, dx_f, dy_f, cams, T):
     return T.reshape(3, 4), rimg
 
 
+def _cam6d(cams):
+    return np.ascontiguousarray([[c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"]] for c in cams], np.float64)
+
+
+def ref_dense_tracking_gpu(cloud, prev, cur, dx, dy, cams, T):
+    """The reference's own DenseTracker::denseTrackingGpu host loop (dense_tracking.cpp:60-193) around its own emulated kernels
+    (oracle/_ref/libsvs_ref_densegpu.so).  cams: list of 3 dicts (f, cx, cy, b, w, h).  Returns (T 3x4, residual images [h][w][4])."""
+    L = _ref_lib("libsvs_ref_densegpu.so")
+    cloud = [np.ascontiguousarray(a, np.float32) for a in cloud]
+    prev, cur, dx, dy = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (prev, cur, dx, dy)]
+    for l, c in enumerate(cams):
+        assert cloud[l].shape == (c["h"], c["w"], 4) and prev[l].shape == cur[l].shape == dx[l].shape == dy[l].shape == (c["h"], c["w"])
+    rimg = [np.zeros((c["h"], c["w"], 4), np.float32) for c in cams]
+    P3 = C.c_void_p * 3
+    T = np.array(T, np.float64).reshape(12).copy()
+    cam6 = _cam6d(cams)
+    L.svs_refdg_dense_tracking_gpu.argtypes = [C.c_void_p] * 8
+    L.svs_refdg_dense_tracking_gpu(_p(cam6), P3(*[a.ctypes.data for a in cloud]), P3(*[a.ctypes.data for a in prev]), P3(*[a.ctypes.data for a in cur]),
+                                   P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]), _p(T), P3(*[a.ctypes.data for a in rimg]))
+    return T.reshape(3, 4), rimg
+
+
+def ref_pointcloud_gpu(disp, cams, T_cur_from_actkey):
+    """The reference's own DenseTracker::computeDensePointCloudGpu (dense_tracking.cpp:195-216) -> the three level clouds"""
+    L = _ref_lib("libsvs_ref_densegpu.so")
+    disp = np.ascontiguousarray(disp, np.float32)
+    assert disp.shape == (cams[0]["h"], cams[0]["w"])
+    out = [np.zeros((c["h"], c["w"], 4), np.float32) for c in cams]
+    T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+    cam6 = _cam6d(cams)
+    L.svs_refdg_pointcloud_gpu.argtypes = [C.c_void_p] * 4
+    L.svs_refdg_pointcloud_gpu(_p(cam6), _p(disp), _p(T), (C.c_void_p * 3)(*[a.ctypes.data for a in out]))
+    return out
+
+
 def ref_pointcloud_cpu(disp, cams, T_cur_from_actkey):
     """the reference's own DenseTracker::computeDensePointCloudCpu -> the three quarter-grid clouds"""
     L = _ref_lib("libsvs_ref_dense.so")

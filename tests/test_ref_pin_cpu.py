@@ -258,6 +258,53 @@ def test_lm_loop_matches_reference_driven_loop(ref, case):
         np.testing.assert_allclose(T64, T_o, rtol=0, atol=1e-5)
 
 
+def test_lm_loop_equals_reference_compiled_host_loop(case):
+    """DenseTracker::denseTrackingGpu ITSELF (dense_tracking.cpp:60-193, compiled from where it lies with SCAVISLAM_CUDA_SUPPORT against the
+    reference's own dense_tracking.h / gpu/dense_tracking.cuh, Eigen / Sophus stood in by the oracle's helpers) around the reference's own
+    emulated kernels: the restated loop in the reference's arithmetic (f32 block-tree sums) ends at the bit-equal pose from three starts,
+    and the residual images the reference leaves on every level are the restated residual image at the pose of the level's last
+    jacobianReduction (the reference renders with gpuT_cur_from_prev, :177-186)."""
+    cams = case["cams"]
+    K = ([c["f"] for c in cams], [c["cx"] for c in cams], [c["cy"] for c in cams])
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    starts = [I, case["T_true"], synth.pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])), np.array([-0.01, 0.005, -0.02]))]
+    n_acc = 0
+    for T0 in starts:
+        T_ref, rimg_ref = O.ref_dense_tracking_gpu(case["cloud"], case["fp"], case["fc"], case["dx"], case["dy"], cams, T0)
+        T_o, passes, rec, Tj = O.dense_tracking_gpu(case["cloud"], case["fp"], case["fc"], case["dx"], case["dy"], *K, T0, O.SUM_F32_TREE)
+        assert np.array_equal(T_ref, T_o), np.abs(T_ref - T_o).max()
+        for l in range(3):
+            mine = O.residual_image_full(case["cloud"][l], case["fp"][l], case["fc"][l], np.float32(K[0][l]), np.float32(K[1][l]), np.float32(K[2][l]),
+                                         colmajor34(Tj[l]).astype(np.float32))
+            assert np.array_equal(rimg_ref[l], mine), l
+        n_acc += int((rec[:, 1] == 1).sum())
+    assert n_acc >= 5
+    assert np.abs(O.ref_dense_tracking_gpu(case["cloud"], case["fp"], case["fc"], case["dx"], case["dy"], cams, I)[0] - case["T_true"]).max() < \
+        0.5 * np.abs(I - case["T_true"]).max()
+
+
+def test_point_cloud_host_side_equals_reference_compiled(case):
+    """DenseTracker::computeDensePointCloudGpu (dense_tracking.cpp:195-216) compiled from where it lies: TQ = T^-1 Q in f64 (the reference's own
+    StereoCamera::Q), narrowed to f32 by GpuMatrix4::set, kernel launched per level with factor 2^level -- equal to the restated kernel fed
+    with the same matrix."""
+    cams = case["cams"]
+    T = case["T_true"]
+    got = O.ref_pointcloud_gpu(case["disp_prev"], cams, T)
+    Ti = O.se3_inv(T)
+    for l, c in enumerate(cams):
+        Q = np.array([[1, 0, 0, -c["cx"]], [0, 1, 0, -c["cy"]], [0, 0, 0, c["f"]], [0, 0, 1.0 / c["b"], 0]])
+        T4 = np.vstack([np.asarray(Ti).reshape(3, 4), [0, 0, 0, 1]])
+        TQ = np.zeros((4, 4))
+        for i in range(4):
+            for j in range(4):
+                t = T4[i, 0] * Q[0, j]
+                for k in range(1, 4):
+                    t += T4[i, k] * Q[k, j]
+                TQ[i, j] = t
+        mine = O.pointcloud_full(TQ.T.reshape(16).astype(np.float32), case["disp_prev"], c["w"], c["h"], 1 << l)
+        assert np.array_equal(got[l], mine), l
+
+
 def test_texture_unit_quantisation_is_small(ref, case):
     """NVIDIA's texture unit keeps the bilinear weights in 1.8 fixed point; the emulator can switch that on.  It is device
     behaviour, not reference arithmetic, and is NOT reproduced by oracle or product: this test only bounds what it would do."""
