@@ -1,7 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/libsvs_oracle.so).
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg, never by scavislam_amd/.  Parity unpinned (see svs_oracle.h header).
+cpu_baseline leg, never by scavislam_amd/.  The reference's own code is pinned by the libraries under oracle/_ref (ref_* functions below),
+third-party arithmetic is unpinned (see svs_oracle.h header).
 """
 import ctypes as C
 import os

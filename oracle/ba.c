@@ -1,4 +1,4 @@
-/* ba.c -- oracle (TEST INFRASTRUCTURE ONLY; parity unpinned, see svs_oracle.h) for the
+/* ba.c -- oracle (TEST INFRASTRUCTURE ONLY; edge types pinned by oracle/_ref/libsvs_ref_edges.so, the g2o solver unpinned, see svs_oracle.h) for the
  * double-window bundle adjustment SlamGraph::optimize (slam_graph.cpp:312-355).
  *
  * The reference's own code on this path is only the g2o vertex/edge types

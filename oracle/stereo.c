@@ -1,6 +1,6 @@
 /*
  * stereo.c -- CPU restatement of the reference's block-matching disparity stage.
- * TEST INFRASTRUCTURE ONLY (see svs_oracle.h).  PARITY UNPINNED.
+ * TEST INFRASTRUCTURE ONLY (see svs_oracle.h).  PARITY UNPINNED (cv::StereoBM is OpenCV 2.4.2, not under /root/reference).
  *
  * Reference call site: StereoFrontend::calcDisparityCpu, stereo_frontend.cpp:620-653:
  *   cv::StereoBM (default-constructed = BASIC preset: preFilterType XSOBEL, preFilterSize 9)

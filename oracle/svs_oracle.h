@@ -5,15 +5,28 @@
  * this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only
  * as the checker / the timed CPU baseline, never as the product path.
  *
- * PARITY UNPINNED: the reference (strasdat/ScaViSLAM) ships no tests, golden vectors or
- * fixtures, cannot be built here (needs OpenCV 2.4.2, g2o, Sophus a621ff, VisionTools,
- * Pangolin, Eigen, SuiteSparse, Boost -- none on disk), and the arithmetic of FAST / pyrDown /
- * Sobel (OpenCV 2.4.2) and of the LM/Schur solve (g2o, unpinned fork) lives in third-party
- * code that is not under /root/reference.  This file restates
+ * PARITY: PINNED against the reference's OWN code wherever that code can be compiled, UNPINNED for the
+ * third-party arithmetic.  The reference (strasdat/ScaViSLAM) ships no tests, golden vectors or fixtures and
+ * cannot be built as a whole (OpenCV 2.4.2, g2o, Sophus a621ff, VisionTools, Pangolin, Eigen, SuiteSparse,
+ * Boost are not on disk).  oracle/Makefile therefore compiles the reference files / functions of the hot
+ * path one by one, FROM WHERE THEY LIE under /root/reference, against stand-in headers for the type names of
+ * the absent libraries (oracle/ref_shim/fake; their algebra is handed to this oracle's own helpers) and, for
+ * the CUDA files, through a host emulation of the CUDA execution model.  The libraries under oracle/_ref:
+ *   libsvs_ref_gpu.so       gpu/dense_tracking.{cuh,cu}: per-pixel helpers, the three kernels, GpuTracker
+ *   libsvs_ref_densegpu.so  dense_tracking.cpp CUDA branch: denseTrackingGpu (LM loop), computeDensePointCloudGpu
+ *   libsvs_ref_dense.so     dense_tracking.cpp CPU branch: denseTrackingCpu, computeDensePointCloudCpu, maths_utils.cpp
+ *   libsvs_ref_qt.so        quadtree.h;   libsvs_ref_fastgrid.so  fast_grid.cpp (FAST-9/16 itself hooked to this oracle)
+ *   libsvs_ref_matcher.so   matcher.cpp / matcher-impl.cpp: ZNSSD, warpAffinve, matchCandidates, match()
+ *   libsvs_ref_pose.so      pose_optimizer.h: calcFastMotionOnly;   libsvs_ref_gate.so  processMatchedPoints
+ *   libsvs_ref_edges.so     g2o_types/anchored_points.{h,cpp}: edge errors, Jacobians, oplus
+ * tests/test_ref_pin_cpu.py holds this restatement BIT-EQUAL to every one of them.  What stays UNPINNED is
+ * what is not under /root/reference: the arithmetic of FAST / pyrDown / Sobel / convertTo / StereoBM
+ * (OpenCV 2.4.2), of the LM / Schur / Huber solve (g2o, unpinned fork), Sophus' SE3 exp, Eigen's ldlt and
+ * VisionTools' pinhole maps.  This file restates
  *   - the reference's own code, citing file:line of /root/reference/scavislam/..., and
  *   - the published algorithm of the third-party calls at the reference's call sites
- *     (SURVEY.md Appendix A), marked "[3rd-party: ...]".
- * It is cross-checked by an independent NumPy/SciPy float64 model (tests/np_model.py) and by
+ *     (SURVEY.md Appendix A), marked "[3rd-party: ...]";
+ * the latter is cross-checked by an independent NumPy/SciPy float64 model (tests/np_model.py) and by
  * analytic properties (numeric-vs-analytic Jacobians, FAST monotonicity, Schur solution
  * satisfies the full normal equations).
  *

@@ -1,4 +1,4 @@
-/* vision.c -- oracle (TEST INFRASTRUCTURE ONLY; parity unpinned, see svs_oracle.h) for the
+/* vision.c -- oracle (TEST INFRASTRUCTURE ONLY; the reference's own code pinned by oracle/_ref, third-party arithmetic unpinned, see svs_oracle.h) for the
  * per-frame front-end: pyramid, f32+Sobel, FAST-9/16, FastGrid, QuadTree, GuidedMatcher,
  * DenseTracker.  Each function cites the /root/reference/scavislam file:line it follows. */
 #include "svs_oracle.h"
