@@ -798,6 +798,55 @@ class RefFastGrid:
             pass
 
 
+class RefFrontendGrids:
+    """oracle/_ref/libsvs_ref_gate.so: the reference's own StereoFrontend::initialize / ::computeFastCorners / ::recomputeFastCorners (per-level
+    FAST grids of the front end) around its own FastGrid; FAST-9/16 itself is bound to the oracle's restatement.  cams: 3 dicts (f, cx, cy, b, w, h)."""
+
+    def __init__(self, cams, use_n_levels=-1):
+        L = _ref_lib("libsvs_ref_gate.so")
+        L.svs_reffe_create.restype = C.c_void_p
+        L.svs_reffe_create.argtypes = [C.c_void_p, C.c_int]
+        L.svs_reffe_destroy.argtypes = [C.c_void_p]
+        L.svs_reffe_num_levels.argtypes = [C.c_void_p]
+        L.svs_reffe_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.svs_reffe_compute_fast_corners.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.svs_reffe_recompute_fast_corners.argtypes = [C.c_void_p]
+        L.svs_reffe_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.svs_reffe_set_fast.argtypes = [C.c_void_p]
+        L.svs_reffe_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
+        self.L, self.cams = L, cams
+        self.h = C.c_void_p(L.svs_reffe_create(_p(_cam6d(cams)), int(use_n_levels)))
+        self.num_levels = L.svs_reffe_num_levels(self.h)
+
+    def grid(self, level):
+        """-> (dict of the FastGrid's members, cells [n, 5] = u0, u1, v0, v1, threshold)"""
+        out = np.zeros(10, np.int32)
+        cells = np.zeros((256, 5), np.int32)
+        n = self.L.svs_reffe_grid(self.h, level, _p(out), _p(cells), 256)
+        keys = ("num_features_per_cell", "boundary_per_cell", "min_inner", "min_outer", "max_inner", "max_outer", "fast_min", "fast_max", "gy", "gx")
+        return dict(zip(keys, (int(v) for v in out))), cells[:n].copy()
+
+    def compute_fast_corners(self, pyr, trials):
+        self._pyr = [np.ascontiguousarray(a) for a in pyr]
+        self.L.svs_reffe_compute_fast_corners(self.h, (C.c_void_p * 3)(*[a.ctypes.data for a in self._pyr]), (C.c_int * 3)(*[a.strides[0] for a in self._pyr]),
+                                              int(trials))
+
+    def recompute_fast_corners(self):
+        self.L.svs_reffe_recompute_fast_corners(self.h)
+
+    def tree(self, level):
+        c = self.cams[level]
+        out = np.zeros((c["w"] * c["h"], 3), np.int32)
+        n = self.L.svs_reffe_tree(self.h, level, _p(out), len(out))
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            self.L.svs_reffe_destroy(self.h)
+        except Exception:
+            pass
+
+
 def _cam6(cams):
     return np.ascontiguousarray([[c.f, c.cx, c.cy, c.b, c.w, c.h] for c in cams], np.float64)
 

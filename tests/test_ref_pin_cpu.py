@@ -435,6 +435,50 @@ def test_fastgrid_equals_reference_compiled_fastgrid():
         assert np.array_equal(got, O.quadtree_from_corners(xy, cc, w, h).query(0, 0, w, h, cap=1 << 16))
 
 
+@pytest.mark.parametrize("cam,use_n_levels", [(synth.CAM_DEFAULT, -1), (synth.CAM_DEFAULT, 3), (synth.CAM_NEWCOLLEGE, 3)])
+def test_frontend_level_grids_equal_reference_compiled_initialize(cam, use_n_levels):
+    """StereoFrontend::initialize, ::computeFastCorners and ::recomputeFastCorners (stereo_frontend.cpp:52-108,656-679) compiled from where
+    they lie around the reference's own FastGrid: the per-level grid parameters (cells per side, features per cell, boundary, the inner / outer
+    ranges derived from them, thresholds) equal the restated svs_ref_fastgrid_init_level on every level the front end uses -- the reference's
+    default is TWO levels ("use_n_levels_in_frontent") --, and over a frame sequence the per-level trees it keeps for the matcher and the trees
+    of the keyframe re-detection equal the restatement's."""
+    cams = synth.level_cams(cam)
+    fe = O.RefFrontendGrids(cams, use_n_levels)
+    assert fe.num_levels == (2 if use_n_levels < 0 else use_n_levels)
+    grids = []
+    for l in range(fe.num_levels):
+        w, h = cams[l]["w"], cams[l]["h"]
+        g = O.fastgrid_for_level(w, h, l)
+        m, cells = fe.grid(l)
+        per_cell, bound, dim = _level_grid_params(l)
+        assert (m["gx"], m["gy"]) == (dim, dim) == (g.gx, g.gy)      # (the reference never sets the two members num_features_per_cell_ /
+        # boundary_per_cell_, fast_grid.cpp:24-38: the four ranges below are all that is left of those arguments)
+        assert (m["min_inner"], m["min_outer"]) == (int(per_cell - bound * 0.33), per_cell - bound)
+        assert (m["min_inner"], m["min_outer"], m["max_inner"], m["max_outer"], m["fast_min"], m["fast_max"]) == \
+            (g.min_inner, g.min_outer, g.max_inner, g.max_outer, g.fast_min, g.fast_max)
+        for c, (u0, u1, v0, v1, thr) in enumerate(cells):
+            i, j = c % dim, c // dim
+            assert (u0, u1, v0, v1, thr) == (i * g.cell_w, (i + 1) * g.cell_w, j * g.cell_h, (j + 1) * g.cell_h, 25)
+        grids.append(g)
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(5)
+    for k in range(4):
+        img = synth.render_stereo(sc, cam, traj[k], seed=70 + k)[0]
+        pyr = O.build_pyramid(img)
+        trials = 6 if k else 5                                   # processFirstFrame: 5, processFrame: 6 (stereo_frontend.cpp:155,232)
+        fe.compute_fast_corners(pyr, trials)
+        for l in range(fe.num_levels):
+            w, h = cams[l]["w"], cams[l]["h"]
+            xy, cc, et = O.fastgrid_detect_adaptively(grids[l], pyr[l], trials)
+            assert np.array_equal(fe.tree(l), O.quadtree_from_corners(xy, cc, w, h).query(0, 0, w, h, cap=1 << 16)) and len(xy) > 30
+            assert np.array_equal(fe.grid(l)[1][:, 4], np.array(grids[l].thr[:grids[l].gx * grids[l].gy]))
+    fe.recompute_fast_corners()                                  # FastGrid::detect with the thresholds the frame kept
+    for l in range(fe.num_levels):
+        w, h = cams[l]["w"], cams[l]["h"]
+        xy, cc = O.fastgrid_detect(grids[l], pyr[l])
+        assert np.array_equal(fe.tree(l), O.quadtree_from_corners(xy, cc, w, h).query(0, 0, w, h, cap=1 << 16))
+
+
 def test_fastgrid_reference_state_machine_edge_cases():
     """Flat image (no corners: thresholds walk down to fast_min and stay), noise image (too many: they walk up to fast_max), a grid whose
     cell size does not divide the image, and many frames of the same image (the oscillation guard): thresholds and trees equal."""
