@@ -169,49 +169,59 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
 }
 
 // grid: (ceil((width1-3)/64), ceil(h/BM_STRIP), batch), block 64.  Output columns x in [3, width1), X = x + 31.
-// The vertical 7-row sum slides down the strip: the entering row's SADs are added, the leaving row's are recomputed and
-// subtracted (cheaper than keeping a ring of 7 rows x 32 SADs: no LDS traffic, and occupancy is not LDS-bound); the
-// next step's two row windows are loaded before the current step's arithmetic.
-__global__ __launch_bounds__(64) void stereo_bm_kernel(StereoDev S) {
+// The vertical 7-row sum slides down the strip: the entering row's 32 SADs are added, the leaving row's are subtracted.  The six rows
+// of the window live in a register ring (7 slots x 16 VGPRs, slot = row mod 7: the entering row y+3 is computed straight into the slot
+// the row that left one step earlier freed; the loop is unrolled by seven so that the slots are static) -- one V_QSAD / V_MQSAD pass and one row window load per output row
+// instead of two (round 2 recomputed the leaving row); the next step's row window is loaded before the current step's arithmetic.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void stereo_bm_kernel(StereoDev S) {
   __shared__ SelScr s_scr[64];
   const int lane = threadIdx.x, b = blockIdx.z;
   const int w = S.w, h = S.h, width1 = w - NDISP + 1;
   const int x = min(3 + blockIdx.x * 64 + lane, width1 - 1);      // lanes past the end redo the last column (no store)
   const bool store = 3 + blockIdx.x * 64 + lane < width1;
   const int y0 = blockIdx.y * BM_STRIP, y1 = min(y0 + BM_STRIP, h);
-  const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL + x + (NDISP - 1) - WSZ2;
-  const uint8_t *rp = S.rp + (size_t)b * h * S.pitch + PADL + x - WSZ2;
+  const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL + (NDISP - 1) - WSZ2;      // uniform bases + one 32-bit lane offset for both images
+  const uint8_t *rp = S.rp + (size_t)b * h * S.pitch + PADL - WSZ2;
   const uint32_t ft4 = 0x01010101u * (uint32_t)(S.cap + 1);
-  auto win = [&](int r) { const size_t o = (size_t)min(max(r, 0), h - 1) * S.pitch; return load_rowwin(lp + o, rp + o); };
-  Pk sad[8], hh[8];
+  auto win = [&](int r) { const uint32_t o = (uint32_t)min(max(r, 0), h - 1) * (uint32_t)S.pitch + (uint32_t)x; return load_rowwin(lp + o, rp + o); };
+  constexpr int NR = 2 * WSZ2 + 1;      // ring slots = window rows
+  Pk sad[8], ring[NR][8];
+  int tring[NR];
 #pragma unroll
   for (int g = 0; g < 8; ++g) sad[g].q = 0;
-  int tsum = 0, t;
-  for (int r = y0 - WSZ2; r < y0 + WSZ2; ++r) {      // rows y0-3 .. y0+2 of the first window
-    const RowWin wv = win(r);
-    row_sads(wv, ft4, hh, t);
+  int tsum = 0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { sad[g].h[0] += hh[g].h[0]; sad[g].h[1] += hh[g].h[1]; }
-    tsum += t;
+  for (int j = 0; j < NR - 1; ++j) {      // rows y0-3 .. y0+2 of the first window
+    const RowWin wv = win(y0 - WSZ2 + j);
+    row_sads(wv, ft4, ring[j], tring[j]);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[j][g].h[0]; sad[g].h[1] += ring[j][g].h[1]; }
+    tsum += tring[j];
   }
-  RowWin wa = win(y0 + WSZ2), ws = win(y0 - WSZ2);
-  for (int y = y0; y < y1; ++y) {
-    const RowWin na = win(y + WSZ2 + 1), ns = win(y - WSZ2 + 1);      // next step's rows, in flight during this step
-    row_sads(wa, ft4, hh, t);
+  RowWin wa = win(y0 + WSZ2);
+  for (int yb = y0; yb < y1; yb += NR) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { sad[g].h[0] += hh[g].h[0]; sad[g].h[1] += hh[g].h[1]; }
-    tsum += t;
-    int16_t d16; uint16_t c16;
-    bm_select(sad, tsum, S, s_scr[lane], d16, c16);
-    if (store) {
-      const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
-      S.disp16[o] = d16; S.cost[o] = c16;
+    for (int k = 0; k < NR; ++k) {      // step k: row y+3 enters into the free slot (k + 6) % 7, row y-3 leaves from slot k, which is free then
+      const int y = yb + k;
+      if (y < y1) {      // (uniform)
+        const int in = (k + NR - 1) % NR;
+        const RowWin na = win(y + WSZ2 + 1);      // next step's row, in flight during this step
+        row_sads(wa, ft4, ring[in], tring[in]);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[in][g].h[0]; sad[g].h[1] += ring[in][g].h[1]; }
+        tsum += tring[in];
+        int16_t d16; uint16_t c16;
+        bm_select(sad, tsum, S, s_scr[lane], d16, c16);
+        if (store) {
+          const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
+          S.disp16[o] = d16; S.cost[o] = c16;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { sad[g].h[0] -= ring[k][g].h[0]; sad[g].h[1] -= ring[k][g].h[1]; }
+        tsum -= tring[k];
+        wa = na;
+      }
     }
-    row_sads(ws, ft4, hh, t);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) { sad[g].h[0] -= hh[g].h[0]; sad[g].h[1] -= hh[g].h[1]; }
-    tsum -= t;
-    wa = na; ws = ns;
   }
 }
 
