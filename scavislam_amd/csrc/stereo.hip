@@ -24,7 +24,7 @@ namespace {
 
 constexpr int PADL = 16, PADR = 48;         // prefiltered rows are padded: pitch = w + PADL + PADR
 constexpr int NDISP = 32, WSZ2 = 3;
-constexpr int BM_STRIP = 40;                // output rows per wave
+constexpr int BM_STRIP = 96;                // output rows per wave (the six rows above a strip are summed without producing output)
 constexpr int DISP_SHIFT = 4;
 constexpr int FILTERED16 = -(1 << DISP_SHIFT);      // (minDisparity - 1) << 4 with minDisparity 0
 
@@ -135,17 +135,33 @@ __device__ __forceinline__ void row_sads(const RowWin &wv, uint32_t ft4, Pk (&hh
 union SelScr { uint32_t u[17]; unsigned short s[34]; };
 // winner selection of one pixel from its 32 window SADs (findStereoCorrespondenceBM inner loop).  Dynamic indexing
 // (sad[mind +- 1], masking the winner's neighbourhood) goes through the per-lane LDS scratch.
+template <bool SMALL>      // SMALL: every SAD < 4096 (prefilter cap <= 41)
 __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const StereoDev &S, SelScr &scr, int16_t &disp, uint16_t &cost) {
   disp = (int16_t)FILTERED16; cost = 0;
-  uint32_t best = 0xffffffffu;
+  int minsad, mind;
+  if (SMALL) {      // 49 taps x |difference| <= 2 cap: every SAD < 4096, so a 16-bit key holds sad << 4 | dword index and both
+    us2 m = {0xffff, 0xffff};      // halves of the 16 dwords are searched at once; first minimum wins within a half, d = 2 * index + half
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {      // first minimum wins: key = sad * 32 + d
-    best = min(best, ((sad[g].u[0] & 0xffffu) << 5) | (uint32_t)(4 * g));
-    best = min(best, ((sad[g].u[0] >> 16) << 5) | (uint32_t)(4 * g + 1));
-    best = min(best, ((sad[g].u[1] & 0xffffu) << 5) | (uint32_t)(4 * g + 2));
-    best = min(best, ((sad[g].u[1] >> 16) << 5) | (uint32_t)(4 * g + 3));
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const us2 idx = {(unsigned short)(2 * g + j), (unsigned short)(2 * g + j)};
+        m = __builtin_elementwise_min(m, (us2)((sad[g].h[j] << 4) | idx));
+      }
+    const int s0 = m.x >> 4, d0 = 2 * (m.x & 15), s1 = m.y >> 4, d1 = 2 * (m.y & 15) + 1;
+    const bool first = s0 < s1 || (s0 == s1 && d0 < d1);
+    minsad = first ? s0 : s1; mind = first ? d0 : d1;
+  } else {
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {      // first minimum wins: key = sad * 32 + d
+      best = min(best, ((sad[g].u[0] & 0xffffu) << 5) | (uint32_t)(4 * g));
+      best = min(best, ((sad[g].u[0] >> 16) << 5) | (uint32_t)(4 * g + 1));
+      best = min(best, ((sad[g].u[1] & 0xffffu) << 5) | (uint32_t)(4 * g + 2));
+      best = min(best, ((sad[g].u[1] >> 16) << 5) | (uint32_t)(4 * g + 3));
+    }
+    minsad = (int)(best >> 5); mind = (int)(best & 31);
   }
-  const int minsad = (int)(best >> 5), mind = (int)(best & 31);
   if (tsum < S.texthr) return;
 #pragma unroll
   for (int g = 0; g < 8; ++g) { scr.u[2 * g] = sad[g].u[0]; scr.u[2 * g + 1] = sad[g].u[1]; }
@@ -173,6 +189,7 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
 // of the window live in a register ring (7 slots x 16 VGPRs, slot = row mod 7: the entering row y+3 is computed straight into the slot
 // the row that left one step earlier freed; the loop is unrolled by seven so that the slots are static) -- one V_QSAD / V_MQSAD pass and one row window load per output row
 // instead of two (round 2 recomputed the leaving row); the next step's row window is loaded before the current step's arithmetic.
+template <bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void stereo_bm_kernel(StereoDev S) {
   __shared__ SelScr s_scr[64];
   const int lane = threadIdx.x, b = blockIdx.z;
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
         for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[in][g].h[0]; sad[g].h[1] += ring[in][g].h[1]; }
         tsum += tring[in];
         int16_t d16; uint16_t c16;
-        bm_select(sad, tsum, S, s_scr[lane], d16, c16);
+        bm_select<SMALL>(sad, tsum, S, s_scr[lane], d16, c16);
         if (store) {
           const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
           S.disp16[o] = d16; S.cost[o] = c16;
@@ -965,7 +982,8 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, EDGE_THREADS / 32), n_batch), dim3(EDGE_THREADS), 0, ctx->stream, S);
   SVS_LAUNCH_CHECK(ctx);
   if (width1 > 3) {
-    hipLaunchKernelGGL(stereo_bm_kernel, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
+    if (S.cap <= 41) hipLaunchKernelGGL(stereo_bm_kernel<true>, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
+    else hipLaunchKernelGGL(stereo_bm_kernel<false>, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
     SVS_LAUNCH_CHECK(ctx);
   }
   if (s->prm.disp12_max_diff >= 0) {
