@@ -188,7 +188,7 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
 // The vertical 7-row sum slides down the strip: the entering row's 32 SADs are added, the leaving row's are subtracted.  The six rows
 // of the window live in a register ring (7 slots x 16 VGPRs, slot = row mod 7: the entering row y+3 is computed straight into the slot
 // the row that left one step earlier freed; the loop is unrolled by seven so that the slots are static) -- one V_QSAD / V_MQSAD pass and one row window load per output row
-// instead of two (round 2 recomputed the leaving row); the next step's row window is loaded before the current step's arithmetic.
+// instead of two (round 2 recomputed the leaving row); the next step's row window is loaded as soon as the current one is consumed.
 template <bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void stereo_bm_kernel(StereoDev S) {
   __shared__ SelScr s_scr[64];
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
       const int y = yb + k;
       if (y < y1) {      // (uniform)
         const int in = (k + NR - 1) % NR;
-        const RowWin na = win(y + WSZ2 + 1);      // next step's row, in flight during this step
         row_sads(wa, ft4, ring[in], tring[in]);
+        wa = win(y + WSZ2 + 1);      // next step's row: issued as soon as this step's is consumed, in flight during the selection
 #pragma unroll
         for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[in][g].h[0]; sad[g].h[1] += ring[in][g].h[1]; }
         tsum += tring[in];
@@ -236,7 +236,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
 #pragma unroll
         for (int g = 0; g < 8; ++g) { sad[g].h[0] -= ring[k][g].h[0]; sad[g].h[1] -= ring[k][g].h[1]; }
         tsum -= tring[k];
-        wa = na;
       }
     }
   }

@@ -87,6 +87,35 @@ def test_stereo_bm_degenerate_images(gpu_ctx):
     assert keep.any() and (got[2][keep] == 0).mean() > 0.9      # ties inside flat blobs go to the larger disparity
 
 
+@pytest.mark.parametrize("cap", [5, 41, 42, 63])
+def test_stereo_bm_prefilter_caps(gpu_ctx, cap):
+    """preFilterCap decides which winner search runs: cap <= 41 bounds every SAD below 4096 (packed 16-bit keys), above it the 32-bit keys.
+    A textured pair, a noise pair and a two-pixel stripe pattern against its one-pixel shift (every tap saturates: SADs of 49 * 2 cap =
+    6174 at cap 63 on one disparity parity, 0 on the other -- long runs of equal minima, first one wins): bit-exact for all caps."""
+    import oracle as O
+    from scavislam_amd import synth
+    cam = dict(synth.CAM_DEFAULT, w=320, h=240, cx=160.0, cy=120.0)
+    sc = synth.Scene(7)
+    l, r, _ = synth.render_stereo(sc, cam, synth.trajectory(2)[1], seed=3)
+    rng = np.random.default_rng(cap)
+    nl = rng.integers(0, 256, (240, 320)).astype(np.uint8)
+    nr_ = np.roll(nl, -5, axis=1)
+    stripes = np.tile(np.repeat(np.array([0, 255], np.uint8), 2), (240, 80))
+    sl, sr = stripes, np.roll(stripes, -1, axis=1)
+    prm = _prm()
+    prm.prefilter_cap = cap
+    got = _run(gpu_ctx, cam, [l, nl, sl], [r, nr_, sr], prm)
+    for g, (a, b) in zip(got, [(l, r), (nl, nr_), (sl, sr)]):
+        assert np.array_equal(g, O.stereo_bm(a, b, prm))
+    prm2 = _prm(validate=False, speckle=False)      # the raw search output of the stripe pair
+    prm2.prefilter_cap = cap
+    prm2.uniqueness_ratio = 0
+    prm2.texture_threshold = 0
+    g = _run(gpu_ctx, cam, [sl], [sr], prm2)[0]
+    ref = O.stereo_bm(sl, sr, prm2)
+    assert np.array_equal(g, ref) and (ref >= 0).mean() > 0.5
+
+
 def test_stereo_unsupported_parameters(gpu_ctx):
     import ctypes as C
     from scavislam_amd.ctypes_types import StereoParams
