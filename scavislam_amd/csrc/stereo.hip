@@ -312,23 +312,36 @@ __global__ __launch_bounds__(256) void stereo_validate_kernel(StereoDev S) {
   const int SCALE = 1 << DISP_SHIFT, INVALID = -SCALE, maxdiff = S.disp12 * SCALE;
   int16_t *dp = S.disp16 + ((size_t)b * S.h + y) * w;
   const uint16_t *cp = S.cost + ((size_t)b * S.h + y) * w;
-  for (int x = lane; x < w; x += 64) { s_d[x] = dp[x]; s_key[x] = 0xffffffffu; }
+  // the row into LDS, one word per pixel: cost << 16 | disparity (16 bits each).  Rows of 4 n pixels: four pixels per lane and load (8 bytes of
+  // each array; 2-byte loads made the wave wait on twenty narrow loads per row)
+  if ((w & 3) == 0) {
+    for (int x = 4 * lane; x < w; x += 256) {
+      const uint2 dv = *reinterpret_cast<const uint2 *>(dp + x), cv = *reinterpret_cast<const uint2 *>(cp + x);
+      int4 e;
+      e.x = (int)((dv.x & 0xffffu) | (cv.x << 16)); e.y = (int)((dv.x >> 16) | (cv.x & 0xffff0000u));
+      e.z = (int)((dv.y & 0xffffu) | (cv.y << 16)); e.w = (int)((dv.y >> 16) | (cv.y & 0xffff0000u));
+      *reinterpret_cast<int4 *>(s_d + x) = e;
+      *reinterpret_cast<uint4 *>(s_key + x) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    }
+  } else {
+    for (int x = lane; x < w; x += 64) { s_d[x] = (int)(((unsigned)(uint16_t)dp[x]) | ((unsigned)cp[x] << 16)); s_key[x] = 0xffffffffu; }
+  }
   wave_sync_lds();
   const int minX1 = NDISP;
   for (int x = minX1 + lane; x < w; x += 64) {
-    const int d = s_d[x];
+    const int e = s_d[x], d = (int16_t)(e & 0xffff);
     if (d == INVALID) continue;
     const int x2 = x - ((d + SCALE / 2) >> DISP_SHIFT);
-    if (x2 >= 0 && x2 < w) atomicMin(&s_key[x2], ((unsigned)cp[x] << 16) | (unsigned)x);
+    if (x2 >= 0 && x2 < w) atomicMin(&s_key[x2], ((unsigned)e & 0xffff0000u) | (unsigned)x);
   }
   wave_sync_lds();
   for (int x = minX1 + lane; x < w; x += 64) {
-    const int d = s_d[x];
+    const int d = (int16_t)(s_d[x] & 0xffff);
     if (d == INVALID) continue;
     const int x0 = x - (d >> DISP_SHIFT), x1 = x - ((d + SCALE - 1) >> DISP_SHIFT);
     bool bad0 = false, bad1 = false;
-    if (x0 >= 0 && x0 < w) { const unsigned k = s_key[x0]; bad0 = k != 0xffffffffu && abs(s_d[k & 0xffffu] - d) > maxdiff; }
-    if (x1 >= 0 && x1 < w) { const unsigned k = s_key[x1]; bad1 = k != 0xffffffffu && abs(s_d[k & 0xffffu] - d) > maxdiff; }
+    if (x0 >= 0 && x0 < w) { const unsigned k = s_key[x0]; bad0 = k != 0xffffffffu && abs((int16_t)(s_d[k & 0xffffu] & 0xffff) - d) > maxdiff; }
+    if (x1 >= 0 && x1 < w) { const unsigned k = s_key[x1]; bad1 = k != 0xffffffffu && abs((int16_t)(s_d[k & 0xffffu] & 0xffff) - d) > maxdiff; }
     if (bad0 && bad1) dp[x] = (int16_t)INVALID;
   }
 }
