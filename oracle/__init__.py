@@ -847,6 +847,37 @@ class RefFrontendGrids:
             pass
 
 
+def ref_slamgraph_optimize(pose_ids, window_types, poses, point_ids, anchor_ids, xyz_anchor, obs_point, obs_pose, obs_level, obs_center,
+                           pe_ids, pe_marginalized, pe_T12, pe_L12, pe_L21, cam, num_iters=2, use_robust_kernel=True, huber_kernel_width=1.0,
+                           move=0.0):
+    """The reference's own SlamGraph<SE3, StereoCamera, SE3XYZ_STEREO, 3>::optimize (oracle/_ref/libsvs_ref_slamgraph.so) on tables filled from the
+    arguments, with a RECORDING g2o behind it.  Returns dict(vertices (kind, id, fixed, marginalized), estimates [n, 12], edges (kind, v0, v1, v2,
+    robust, parameter id), edge_data [n, 49] (measurement 12, information 36, kernel delta), settings [10], poses_out, points_out)."""
+    L = _ref_lib("libsvs_ref_slamgraph.so")
+    pose_int = np.ascontiguousarray(np.stack([pose_ids, window_types], 1), np.int32)
+    pose_T = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+    point_int = np.ascontiguousarray(np.stack([point_ids, anchor_ids], 1), np.int32)
+    point_xyz = np.ascontiguousarray(xyz_anchor, np.float64).reshape(-1, 3)
+    obs_int = np.ascontiguousarray(np.stack([obs_point, obs_pose, obs_level], 1), np.int32)
+    obs_c = np.ascontiguousarray(obs_center, np.float64).reshape(-1, 3)
+    n_pe = len(pe_ids)
+    pe_int = np.ascontiguousarray(np.concatenate([np.asarray(pe_ids, np.int32).reshape(-1, 2), np.asarray(pe_marginalized, np.int32).reshape(-1, 1)], 1), np.int32)
+    pe_dbl = np.ascontiguousarray(np.concatenate([np.asarray(pe_T12, np.float64).reshape(n_pe, 12), np.asarray(pe_L12, np.float64).reshape(n_pe, 36),
+                                                  np.asarray(pe_L21, np.float64).reshape(n_pe, 36)], 1))
+    cam6 = np.array([cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"]], np.float64)
+    poses_out = np.zeros_like(pose_T); points_out = np.zeros_like(point_xyz)
+    L.svs_refsg_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.svs_refsg_optimize(_p(pose_int), _p(pose_T), len(pose_int), _p(point_int), _p(point_xyz), len(point_int), _p(obs_int), _p(obs_c), len(obs_int),
+                         _p(pe_int), _p(pe_dbl), n_pe, _p(cam6), int(num_iters), int(bool(use_robust_kernel)), float(huber_kernel_width), float(move),
+                         _p(poses_out), _p(points_out))
+    nv, ne = L.svs_refsg_num_vertices(), L.svs_refsg_num_edges()
+    v_int = np.zeros((nv, 4), np.int32); v_est = np.zeros((nv, 12)); e_int = np.zeros((ne, 6), np.int32); e_dbl = np.zeros((ne, 49)); st = np.zeros(10)
+    L.svs_refsg_get.argtypes = [C.c_void_p] * 5
+    L.svs_refsg_get(_p(v_int), _p(v_est), _p(e_int), _p(e_dbl), _p(st))
+    return dict(vertices=v_int, estimates=v_est, edges=e_int, edge_data=e_dbl, settings=st, poses_out=poses_out, points_out=points_out)
+
+
 def _cam6(cams):
     return np.ascontiguousarray([[c.f, c.cx, c.cy, c.b, c.w, c.h] for c in cams], np.float64)
 

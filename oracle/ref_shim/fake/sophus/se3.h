@@ -8,6 +8,7 @@
 namespace Sophus {
 class SE3 {
  public:
+  static const int DoF = 6;
   double T[12];      // 3x4 row-major
   SE3() { for (int i = 0; i < 12; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0; }
   explicit SE3(const double *t) { for (int i = 0; i < 12; ++i) T[i] = t[i]; }

@@ -1,14 +1,27 @@
-// TEST INFRASTRUCTURE: VisionTools' checked map access GET_MAP_ELEM(key, map) = the element that must exist (maths_utils.cpp includes the
-// header and uses nothing of it; matcher.cpp looks keyframes and vertices up with it)
+// TEST INFRASTRUCTURE: VisionTools' checked container access as the reference uses it (maths_utils.cpp includes the header and uses nothing of it;
+// matcher.cpp, pose_optimizer.h and slam_graph.cpp look elements up with it).  GET_MAP_ELEM(key, map) = the element that must exist: a value
+// by reference, a raw pointer as it is, the POINTEE of a shared pointer (slam_graph.cpp binds `const Vertex &` to an element of a table of
+// VertexPtr); GET_MAP_ELEM_REF(key, pointer to map) = the same, writable; GET_VEC_VAL_REF(index, pointer to vector).
 #pragma once
 #include <cassert>
+#include <tr1/memory>
 namespace VisionTools {
-template <class K, class M> const typename M::mapped_type &svs_get_map_elem(const K &k, const M &m) {
+template <class T> const T &svs_elem(const T &v) { return v; }
+template <class T> T *svs_elem(T *const &p) { return p; }
+template <class T> const T &svs_elem(const std::tr1::shared_ptr<T> &p) { return *p; }
+template <class T> T &svs_elem_ref(T &v) { return v; }
+template <class T> T &svs_elem_ref(std::tr1::shared_ptr<T> &p) { return *p; }
+template <class K, class M> decltype(auto) svs_get_map_elem(const K &k, const M &m) {
   typename M::const_iterator it = m.find(k);
   assert(it != m.end());
-  return it->second;
+  return svs_elem(it->second);
+}
+template <class K, class M> decltype(auto) svs_get_map_elem_ref(const K &k, M *m) {
+  typename M::iterator it = m->find(k);
+  assert(it != m->end());
+  return svs_elem_ref(it->second);
 }
 }
 #define GET_MAP_ELEM(key, map) VisionTools::svs_get_map_elem(key, map)
-// GET_VEC_VAL_REF(index, pointer to vector) = reference to the element that must exist (pose_optimizer.h:159)
+#define GET_MAP_ELEM_REF(key, map) VisionTools::svs_get_map_elem_ref(key, map)
 #define GET_VEC_VAL_REF(idx, vec) ((vec)->at(idx))

@@ -19,6 +19,7 @@
  *   libsvs_ref_matcher.so   matcher.cpp / matcher-impl.cpp: ZNSSD, warpAffinve, matchCandidates, match()
  *   libsvs_ref_pose.so      pose_optimizer.h: calcFastMotionOnly;   libsvs_ref_gate.so  processMatchedPoints
  *   libsvs_ref_edges.so     g2o_types/anchored_points.{h,cpp}: edge errors, Jacobians, oplus
+ *   libsvs_ref_slamgraph.so slam_graph.cpp / -impl.cpp: optimize, copyDataToG2o and friends, into a recording g2o stand-in
  * tests/test_ref_pin_cpu.py holds this restatement BIT-EQUAL to every one of them.  What stays UNPINNED is
  * what is not under /root/reference: the arithmetic of FAST / pyrDown / Sobel / convertTo / StereoBM
  * (OpenCV 2.4.2), of the LM / Schur / Huber solve (g2o, unpinned fork), Sophus' SE3 exp, Eigen's ldlt and

@@ -179,6 +179,7 @@ def ba_window(P=15, L=3000, seed=2012, cam=CAM_NEWCOLLEGE, n_outer=3, outlier_fr
 
     Returns dict(poses [P,12] (perturbed T_me_from_world), psi [L,3] (perturbed inverse-depth in
     the anchor frame), edges (sorted by landmark, then pose), cons, cam dict, poses_gt, psi_gt).
+    (Each relative-pose constraint is listed once; the reference's copyContraintsToG2o inserts it in both directions.)
     """
     rng = np.random.default_rng(seed)
     f, cx, cy, b = cam["f"], cam["cx"], cam["cy"], cam["b"]

@@ -854,3 +854,84 @@ def test_ba_edges_equal_reference_compiled_edges():
         p = rng.normal(0, 1, 3); u3 = rng.normal(0, 0.1, 3); o3 = np.zeros(3)
         L.svs_refvertex_oplus_xyz(ptr(p), ptr(u3), ptr(o3))
         assert np.array_equal(o3, p + u3)
+
+
+# ---- the reference's own marshalling of the back end (row a16: what SlamGraph::optimize hands to g2o) ------------------------------
+def test_ba_marshalling_equals_reference_compiled_copy_data_to_g2o():
+    """SlamGraph::optimize / setupG2o / copyDataToG2o / copyPosesToG2o / copyContraintsToG2o / add{Pose,Point,Obs,Constraint}ToG2o /
+    restoreDataFromG2o (slam_graph.cpp:312-355,907-1082, slam_graph-impl.cpp:25-126) compiled from where they lie against the reference's own
+    slam_graph.hpp and g2o types, with a g2o stand-in that records what it is given.  A double window (9 inner + 3 outer keyframes) is put into
+    the reference's tables from the same flat arrays the HIP back end takes (synth.ba_window), and the recorded graph must BE those arrays:
+    every pose a free SE3 vertex, every active point a marginalised vertex holding the inverse-depth parameters, one G2oEdgeProjectPSI2UVU per
+    (point, window pose of its vis_set) with vertices (point, pose, anchor), our obs / info fields bit for bit (information = diag(4^-level,
+    4^-level, 0.333^2)), Huber kernels with g2o's default width (OptParams::huber_kernel_width is never passed on), camera parameter 0,
+    lambda 50, five trials after failure, verbose; observations from frames outside the window are skipped; and each marginalised pose-pose
+    edge with an OUTER end arrives TWICE, once per direction, with that direction's information matrix.  restoreDataFromG2o writes the
+    solver's poses back and inverts the point parametrisation."""
+    prob = synth.ba_window(P=12, L=300, seed=5, n_outer=3)
+    P, Lm = len(prob["poses"]), len(prob["psi"])
+    inner = P - 3
+    pose_ids = 100 + 3 * np.arange(P)
+    point_ids = 5000 + 7 * np.arange(Lm)
+    wtype = (np.arange(P) >= inner).astype(np.int32)
+    e = prob["edges"]
+    psi = prob["psi"]
+    xyz = np.stack([psi[:, 0] / psi[:, 2], psi[:, 1] / psi[:, 2], 1.0 / psi[:, 2]], 1)
+    anchor_of = np.zeros(Lm, np.int64)
+    anchor_of[e["point"]] = e["anchor"]
+    level = np.round(np.log(1.0 / e["info"][:, 0]) / np.log(4.0)).astype(np.int32)
+    # + observations of some points from two frames that are not in the window
+    rng = np.random.default_rng(1)
+    extra_pt = rng.choice(Lm, 40, replace=False)
+    obs_point = np.concatenate([point_ids[e["point"]], point_ids[extra_pt]])
+    obs_pose = np.concatenate([pose_ids[e["pose"]], np.where(np.arange(40) % 2 == 0, 7, 9001)])
+    obs_level = np.concatenate([level, np.zeros(40, np.int32)])
+    obs_center = np.concatenate([e["obs"], rng.uniform(0, 400, (40, 3))])
+    cons = prob["cons"]
+    assert len(cons) == 3
+    pe_ids, pe_marg, pe_T12, pe_L12, pe_L21 = [], [], [], [], []
+    for c in cons:                                            # marginalised edges (i, j): T_j_from_i with its information, another one for the way back
+        pe_ids.append((pose_ids[c["pose1"]], pose_ids[c["pose2"]])); pe_marg.append(1)
+        pe_T12.append(O.se3_inv(c["T_21"]).reshape(12)); pe_L21.append(c["info"]); pe_L12.append(0.5 * c["info"] + np.eye(6).reshape(36))
+    for i in (0, 3):                                          # co-visibility edges inside the inner window: points are used, no constraint
+        pe_ids.append((pose_ids[i + 1], pose_ids[i])); pe_marg.append(0)
+        pe_T12.append(np.eye(3, 4).reshape(12)); pe_L12.append(np.zeros(36)); pe_L21.append(np.zeros(36))
+    move = 1e-3
+    for robust, width, iters in ((True, 1.0, 2), (False, 3.0, 5), (True, 0.25, 1)):
+        r = O.ref_slamgraph_optimize(pose_ids, wtype, prob["poses"], point_ids, pose_ids[anchor_of], xyz, obs_point, obs_pose, obs_level, obs_center,
+                                     pe_ids, pe_marg, pe_T12, pe_L12, pe_L21, prob["cam"], iters, robust, width, move)
+        cam = prob["cam"]
+        assert list(r["settings"]) == [1.0, 50.0, 5.0, float(iters), 1.0, cam["f"], cam["cx"], cam["cy"], cam["b"], 0.0]
+        v, est = r["vertices"], r["estimates"]
+        assert len(v) == P + Lm and (v[:P, 0] == 0).all() and (v[P:, 0] == 1).all()        # poses first, then the points
+        assert (v[:, 2] == 0).all()                                                         # nothing is fixed (slam_graph.cpp:932)
+        assert (v[:P, 3] == 0).all() and (v[P:, 3] == 1).all()                              # points are marginalised (Schur)
+        po = np.argsort(v[:P, 1]); assert np.array_equal(v[:P, 1][po], pose_ids) and np.array_equal(est[:P][po], prob["poses"])
+        lo = np.argsort(v[P:, 1]); assert np.array_equal(v[P:, 1][lo], point_ids)
+        inv = np.stack([xyz[:, 0] / xyz[:, 2], xyz[:, 1] / xyz[:, 2], 1.0 / xyz[:, 2]], 1)  # invert_depth (maths_utils.h:66-69)
+        assert np.array_equal(est[P:][lo][:, :3], inv)
+        np.testing.assert_allclose(inv, psi, rtol=1e-15)                                    # = the psi array of the HIP back end
+        ed, dd = r["edges"], r["edge_data"]
+        proj = ed[:, 0] == 0
+        assert proj.sum() == len(e) and (ed[~proj, 0] == 1).all() and not proj[np.argmax(~proj):].any()      # constraints come last
+        got = sorted(zip(ed[proj, 1], ed[proj, 2], ed[proj, 3], map(tuple, dd[proj][:, :3]), map(tuple, dd[proj][:, 12:21])))
+        want = sorted(zip(point_ids[e["point"]], pose_ids[e["pose"]], pose_ids[e["anchor"]], map(tuple, e["obs"]),
+                          [(a, 0, 0, 0, b, 0, 0, 0, c) for a, b, c in e["info"]]))
+        assert got == want                                   # ids, measurement and information: bit for bit our edge records
+        assert (ed[proj, 4] == int(robust)).all() and (ed[proj, 5] == 0).all()
+        assert (dd[proj][:, 48] == (1.0 if robust else 0.0)).all()                          # g2o's default delta, whatever huber_kernel_width says
+        assert (~proj).sum() == 2 * len(cons)
+        recs = {(a, b): (tuple(m), tuple(i)) for a, b, m, i in zip(ed[~proj, 1], ed[~proj, 2], dd[~proj][:, :12], dd[~proj][:, 12:48])}
+        for c, L12 in zip(cons, pe_L12):
+            a, b = pose_ids[c["pose1"]], pose_ids[c["pose2"]]
+            # direction pose1 -> pose2: our constraint record (pose1, pose2, T_21, info); the table keeps T_1_from_2, the way there is its inverse
+            assert recs[(a, b)][1] == tuple(c["info"])
+            np.testing.assert_allclose(np.array(recs[(a, b)][0]), c["T_21"], rtol=0, atol=1e-15)
+            # and the way back: the stored transformation with the other information matrix
+            assert recs[(b, a)] == (tuple(O.se3_inv(c["T_21"]).reshape(12)), tuple(L12))
+        assert (ed[~proj, 3] == -1).all() and (ed[~proj, 4] == 0).all()                      # binary edges, no kernel
+        # restoreDataFromG2o
+        exp_T = prob["poses"].copy(); exp_T[:, 3] += move * (1 + pose_ids)
+        assert np.array_equal(r["poses_out"], exp_T)
+        e2 = inv.copy(); e2[:, 2] += move
+        assert np.array_equal(r["points_out"], np.stack([e2[:, 0] / e2[:, 2], e2[:, 1] / e2[:, 2], 1.0 / e2[:, 2]], 1))
