@@ -382,11 +382,25 @@ def main():
     opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], camc, prm, add_pose_terms=sh["add_pose_terms"])
     # sharded runs: the library's own RCCL communicator (ncclAllReduce on the ctx stream inside svs_ba_optimize); torch.distributed
     # only carries the 128-byte unique id to the other ranks.  Also exercised at one rank when launched through torch.distributed.run.
-    with _stdout_to_stderr():
-        comm = Communicator(ctx, rank, world, device=dev) if use_dist else None
-    if comm is not None:
-        opt.set_comm(comm)
-    allreduce = None
+    comm, allreduce, comm_error = None, None, None
+    if use_dist:
+        try:
+            with _stdout_to_stderr():
+                comm = Communicator(ctx, rank, world, device=dev)
+        except Exception as e:                                # e.g. librccl cannot be bound in this environment
+            comm_error = repr(e)
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank takes the same path
+        if int(ok.item()) == 1:
+            opt.set_comm(comm)
+        else:                                                 # safety net: the collective through torch.distributed (also RCCL), as a callback
+            if comm is not None:
+                comm.close()
+                comm = None
+            from scavislam_amd.backend import make_allreduce
+            allreduce = make_allreduce(stream, local_rank)
+            print("bench: library communicator unavailable (%s); all-reduce through torch.distributed" % comm_error, file=sys.stderr)
     E_total, E_local = len(prob["edges"]), len(sh["edges"])
     stats = None
     t_red = t_sol = t_bs = 0.0
@@ -640,7 +654,8 @@ def main():
                                    "Schur solve 50 KF / 20k landmarks",
                        "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": args.points,
                        "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system",
-                       "collective": (dict(comm.stats(), transport="RCCL ncclAllReduce(ncclDouble) issued by the library on its stream") if comm is not None else None)},
+                       "collective": (dict(comm.stats(), transport="RCCL ncclAllReduce(ncclDouble) issued by the library on its stream") if comm is not None
+                                      else ({"transport": "torch.distributed all_reduce callback (library communicator unavailable)"} if allreduce is not None else None))},
             "schur": {"ms_per_optimize": round(ms_opt, 4), "lm_trials_per_optimize": n_tr / K,
                       "ms_per_call_incl_host_marshalling_and_copies": round(e2e_ms, 4) if e2e_ms else None,
                       "ms_per_schur_step": round(ms_opt / max(n_tr / K, 1), 4), "scaling": "strong",
