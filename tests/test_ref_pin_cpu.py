@@ -527,12 +527,12 @@ def test_znssd_equals_reference_compiled_znssd():
 
 
 # ---- the reference's own GuidedMatcher (rows a8 - a10) --------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def matcher_cpu_case():
+@pytest.fixture(scope="module", params=["default_640x480", "newcollege_512x384"])
+def matcher_cpu_case(request):
     from scavislam_amd.ctypes_types import level_cams
     sc = synth.Scene(2011)
     traj = synth.trajectory(8)
-    cam = synth.CAM_DEFAULT
+    cam = synth.CAM_DEFAULT if request.param.startswith("default") else synth.CAM_NEWCOLLEGE
     cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
     k0, k1, c = 0, 2, 5
     img_k0, disp_k0 = sc.render(cam, traj[k0], seed=k0)
@@ -641,7 +641,7 @@ def test_match_equals_reference_compiled_match(matcher_cpu_case):
     reports with status OK, in the same order, with bit-equal observations (u, v, u - d at level 0) and points in the active keyframe."""
     case = matcher_cpu_case
     trees = _oracle_trees(case)
-    for thr_mean, thr_std, radius in ((22, 10, 8), (12, 0, 5)):
+    for thr_mean, thr_std, radius in ((22, 10, 8), (12, 0, 5), (22, 10, 4)):      # radius 8: the CPU build, 4: the CUDA build (stereo_frontend.cpp:1043-1047)
         ref_idx, ref_obs, ref_xyz = O.ref_match(case["kf_pyrs"], case["kf_poses"], case["T_guess"], 1, case["pyr_c"], case["disp_c"], case["corners"],
                                                 case["cams"], case["pts"], radius, thr_mean, thr_std)
         res = O.match(case["kf_pyrs"], case["kf_poses"], case["T_guess"], case["T_act"], case["pyr_c"], case["disp_c"], trees, case["cams"], case["pts"],
