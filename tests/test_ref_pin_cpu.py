@@ -8,12 +8,24 @@ GpuSymMatrix6::addOuter / copyTo, GpuVector6::scaledAdd (.cuh:40-217), pointclou
 jacobianReduction_kernel / chi2_kernel with their f32 reduction trees and host sums (.cu:172-493) and
 residualImage_kernel (.cu:495-569).  The restatement's SVS_SUM_F32_TREE mode must equal it BIT FOR BIT; the f64 mode (what the
 HIP path is compared with) shares the per-pixel code and differs only in the accumulator.
+
+Round 2, later: the same for the reference's HOST code on the hot paths, compiled function by function from where it lies against
+stand-in headers for the type names of the absent third-party libraries (oracle/ref_shim/fake; DESIGN.md section 4 has the table):
+QuadTree, FastGrid and the front end's per-level grids, the whole GuidedMatcher, calcFastMotionOnly, processMatchedPoints, both
+DenseTracker branches incl. the denseTrackingGpu LM loop, the g2o edge types and the back end's marshalling into g2o.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle as O
 from scavislam_amd import synth
+
+# the libraries are built here from /root/reference (oracle/Makefile) and travel prebuilt (git-ignored) to boxes without it
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/scavislam") and
+                                not os.path.exists(os.path.join(os.path.dirname(O.__file__), "_ref", "libsvs_ref_slamgraph.so")),
+                                reason="neither /root/reference nor prebuilt oracle/_ref libraries are present")
 
 CAM_SMALL = dict(f=591.524 / 2, cx=159.5, cy=119.5, b=0.07468, w=320, h=240)
 
