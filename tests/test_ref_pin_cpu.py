@@ -909,7 +909,7 @@ def test_ba_marshalling_equals_reference_compiled_copy_data_to_g2o():
         pe_ids.append((pose_ids[i + 1], pose_ids[i])); pe_marg.append(0)
         pe_T12.append(np.eye(3, 4).reshape(12)); pe_L12.append(np.zeros(36)); pe_L21.append(np.zeros(36))
     move = 1e-3
-    for robust, width, iters in ((True, 1.0, 2), (False, 3.0, 5), (True, 0.25, 1)):
+    for robust, width, iters in ((True, 3.0, 2), (False, 3.0, 5), (True, 0.25, 1)):      # the first: Backend's own call, OptParams(2, true, 3) (backend.cpp:187)
         r = O.ref_slamgraph_optimize(pose_ids, wtype, prob["poses"], point_ids, pose_ids[anchor_of], xyz, obs_point, obs_pose, obs_level, obs_center,
                                      pe_ids, pe_marg, pe_T12, pe_L12, pe_L21, prob["cam"], iters, robust, width, move)
         cam = prob["cam"]
