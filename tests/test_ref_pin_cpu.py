@@ -914,6 +914,10 @@ def test_ba_marshalling_equals_reference_compiled_copy_data_to_g2o():
                                      pe_ids, pe_marg, pe_T12, pe_L12, pe_L21, prob["cam"], iters, robust, width, move)
         cam = prob["cam"]
         assert list(r["settings"]) == [1.0, 50.0, 5.0, float(iters), 1.0, cam["f"], cam["cx"], cam["cy"], cam["b"], 0.0]
+        if (robust, width, iters) == (True, 3.0, 2):         # = the defaults the HIP back end is configured with
+            from scavislam_amd.ctypes_types import BaParams
+            d = BaParams.reference_defaults()
+            assert (d.num_iters, d.use_robust, d.huber_delta, d.lambda_init, d.max_trials) == (2, 1, 1.0, 50.0, 5)
         v, est = r["vertices"], r["estimates"]
         assert len(v) == P + Lm and (v[:P, 0] == 0).all() and (v[P:, 0] == 1).all()        # poses first, then the points
         assert (v[:, 2] == 0).all()                                                         # nothing is fixed (slam_graph.cpp:932)
