@@ -878,6 +878,43 @@ def ref_slamgraph_optimize(pose_ids, window_types, poses, point_ids, anchor_ids,
     return dict(vertices=v_int, estimates=v_est, edges=e_int, edge_data=e_dbl, settings=st, poses_out=poses_out, points_out=points_out)
 
 
+def ref_match_and_track(kf_pyrs, kf_poses, actkey_index, neighbours, T_cur_from_actkey, cur_pyr, disp, corners, cams, pts, list_of, num_max_points=0):
+    """The reference's own StereoFrontend::matchAndTrack (oracle/_ref/libsvs_ref_track.so).  neighbours: [(keyframe index, strength)] of the active
+    keyframe; list_of[i]: -1 = neighbourhood point list, k = new-point list of keyframe k.  Returns (ok, T 3x4, num_new_feat_matched, point index /
+    obs / xyz_actkey of TrackData)."""
+    n_kf = len(kf_pyrs)
+    kfs = np.zeros(n_kf, KEYFRAME_DTYPE)
+    keep = []
+    for i, pyr in enumerate(kf_pyrs):
+        kfs[i]["T_anchor_from_w"] = np.asarray(kf_poses[i], np.float64).reshape(12)
+        for l in range(3):
+            a = np.ascontiguousarray(pyr[l])
+            keep.append(a)
+            kfs[i]["pyr"][l] = a.ctypes.data
+            kfs[i]["stride"][l] = a.strides[0]
+    kf_ids = np.arange(100, 100 + 7 * n_kf, 7, dtype=np.int32)
+    nb = np.ascontiguousarray(np.asarray(neighbours, np.int32).reshape(-1, 2))
+    cur = [np.ascontiguousarray(a) for a in cur_pyr]
+    disp = np.ascontiguousarray(disp, np.float32)
+    cor = [np.ascontiguousarray(c, np.float64).reshape(-1, 2) for c in corners]
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    lo = np.ascontiguousarray(list_of, np.int32)
+    T = np.array(T_cur_from_actkey, np.float64).reshape(12).copy()
+    n = len(pts)
+    obs_point = np.zeros(n, np.int32); obs = np.zeros((n, 3)); xyz = np.zeros((n, 3))
+    num_new, n_obs = C.c_int(0), C.c_int(0)
+    L = _ref_lib("libsvs_ref_track.so")
+    L.svs_reftrack_match_and_track.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+    ok = L.svs_reftrack_match_and_track(_p(kfs), n_kf, _p(kf_ids), int(actkey_index), _p(nb), len(nb), _p(T), (C.c_void_p * 3)(*[a.ctypes.data for a in cur]),
+                                        (C.c_int * 3)(*[a.strides[0] for a in cur]), _p(disp), disp.strides[0] // 4, (C.c_void_p * 3)(*[c.ctypes.data for c in cor]),
+                                        (C.c_int * 3)(*[len(c) for c in cor]), cams, _p(pts), _p(lo), n, int(num_max_points), C.byref(num_new), C.byref(n_obs),
+                                        _p(obs_point), _p(obs), _p(xyz))
+    k = n_obs.value
+    return bool(ok), T.reshape(3, 4), num_new.value, obs_point[:k].copy(), obs[:k].copy(), xyz[:k].copy()
+
+
 def _cam6(cams):
     return np.ascontiguousarray([[c.f, c.cx, c.cy, c.b, c.w, c.h] for c in cams], np.float64)
 

@@ -17,7 +17,8 @@
  *   libsvs_ref_dense.so     dense_tracking.cpp CPU branch: denseTrackingCpu, computeDensePointCloudCpu, maths_utils.cpp
  *   libsvs_ref_qt.so        quadtree.h;   libsvs_ref_fastgrid.so  fast_grid.cpp (FAST-9/16 itself hooked to this oracle)
  *   libsvs_ref_matcher.so   matcher.cpp / matcher-impl.cpp: ZNSSD, warpAffinve, matchCandidates, match()
- *   libsvs_ref_pose.so      pose_optimizer.h: calcFastMotionOnly;   libsvs_ref_gate.so  processMatchedPoints
+ *   libsvs_ref_pose.so      pose_optimizer.h: calcFastMotionOnly;   libsvs_ref_gate.so  processMatchedPoints, initialize, computeFastCorners
+ *   libsvs_ref_track.so     stereo_frontend.cpp matchAndTrack = matcher + pose optimiser chained as the front end chains them
  *   libsvs_ref_edges.so     g2o_types/anchored_points.{h,cpp}: edge errors, Jacobians, oplus
  *   libsvs_ref_slamgraph.so slam_graph.cpp / -impl.cpp: optimize, copyDataToG2o and friends, into a recording g2o stand-in
  * tests/test_ref_pin_cpu.py holds this restatement BIT-EQUAL to every one of them.  What stays UNPINNED is

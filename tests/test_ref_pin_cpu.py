@@ -667,6 +667,65 @@ def test_match_equals_reference_compiled_match(matcher_cpu_case):
         assert (counts[4] > 3) == (thr_std > 0), counts
 
 
+def test_match_and_track_equals_reference_compiled_chain(matcher_cpu_case):
+    """StereoFrontend::matchAndTrack (stereo_frontend.cpp:976-1065) compiled from where it lies in ONE translation unit with the reference's matcher and
+    pose_optimizer.h: match on the active keyframe's new points, on its neighbours' new points while 2 * observations < ui.num_max_points, on the
+    neighbourhood's points (search radius 8, thresholds 22 / 10), then calcFastMotionOnly(PoseOptimizerParams(true, 2, 15)) -- against the restated
+    stages chained the same way (what svs_frontend_process_frame does on the device): same observation list, same count of new-feature
+    observations, bit-equal refined pose; the neighbour cut and the fewer-than-20-observations exit included."""
+    from scavislam_amd.ctypes_types import PoseOptParams
+    case = matcher_cpu_case
+    trees = _oracle_trees(case)
+    pts = case["pts"]
+    n = len(pts)
+    rng = np.random.default_rng(3)
+    # lists: new points of the active keyframe (index 1), new points of keyframe 0 (a neighbour), the neighbourhood's points
+    list_of = np.where(rng.random(n) < 0.25, 1, np.where(rng.random(n) < 0.2, 0, -1)).astype(np.int32)
+    list_of[pts["kf_index"] < 0] = -1
+    neighbours = [(0, 37)]
+    cam0 = case["cams"][0]
+
+    def chain(num_max_points, keep=None):
+        sel = np.arange(n) if keep is None else keep
+        order, n_obs, num_new = [], 0, 0
+        groups = [sel[list_of[sel] == 1]]
+        results = {}
+        for gi, idx in enumerate([sel[list_of[sel] == 1], sel[list_of[sel] == 0], sel[list_of[sel] == -1]]):
+            if gi == 1 and not 2 * n_obs < num_max_points:
+                continue                                     # the neighbour's list is skipped
+            r = O.match(case["kf_pyrs"], case["kf_poses"], case["T_guess"], case["T_act"], case["pyr_c"], case["disp_c"], trees, case["cams"], pts[idx], 8, 22, 10)
+            order.append(idx); results[gi] = r
+            n_obs += int((r["status"] == 0).sum())
+            if gi <= 1:
+                num_new = n_obs
+        idx_all = np.concatenate(order)
+        res_all = np.concatenate([results[g] for g in sorted(results)])
+        okm = res_all["status"] == 0
+        if okm.sum() < 20:
+            return False, np.asarray(case["T_guess"]).reshape(3, 4), num_new, idx_all[okm], res_all
+        T, st = O.motion_only(res_all, cam0, case["T_guess"], PoseOptParams.reference())
+        return True, T, num_new, idx_all[okm], res_all
+
+    n_cut = 0
+    for nmp in (0, 2000):
+        ok, T, num_new, obs_idx, obs, xyz = O.ref_match_and_track(case["kf_pyrs"], case["kf_poses"], 1, neighbours, case["T_guess"], case["pyr_c"], case["disp_c"],
+                                                               case["corners"], case["cams"], pts, list_of, nmp)
+        ok2, T2, num_new2, idx2, res_all = chain(300 if nmp == 0 else nmp)
+        assert ok and ok2 and num_new == num_new2 > 20
+        assert np.array_equal(obs_idx, idx2) and len(obs_idx) > 200
+        okm = res_all["status"] == 0
+        assert np.array_equal(obs, res_all["obs"][okm]) and np.array_equal(xyz, res_all["xyz_actkey"][okm])
+        assert np.array_equal(T, T2) and np.abs(T - np.asarray(case["T_guess"]).reshape(3, 4)).max() > 1e-5
+        n_cut += int(not np.isin(np.nonzero(list_of == 0)[0], obs_idx).any())
+    assert n_cut == 1                                         # at the default of 300 the neighbour's new points are not matched any more, at 2000 they are
+    # fewer than 20 observations: false, pose untouched
+    few = np.nonzero(list_of == -1)[0][:25]
+    lo2 = np.full(n, -1, np.int32)
+    ok, T, num_new, obs_idx, obs, xyz = O.ref_match_and_track(case["kf_pyrs"], case["kf_poses"], 1, [], case["T_guess"], case["pyr_c"], case["disp_c"], case["corners"],
+                                                           case["cams"], pts[few], lo2[:len(few)], 0)
+    assert not ok and len(obs_idx) < 20 and num_new == 0 and np.array_equal(T, np.asarray(case["T_guess"]).reshape(3, 4))
+
+
 # ---- the reference's own motion-only pose refinement (after the matcher, stereo_frontend.cpp:1058-1063) ------------------------------
 def _motion_results(rng, cam, T_true, n, outliers=0.1, n_fail=30, noise=0.4):
     from scavislam_amd.ctypes_types import MATCH_RESULT_DTYPE
