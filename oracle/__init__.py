@@ -915,6 +915,50 @@ def ref_match_and_track(kf_pyrs, kf_poses, actkey_index, neighbours, T_cur_from_
     return bool(ok), T.reshape(3, 4), num_new.value, obs_point[:k].copy(), obs[:k].copy(), xyz[:k].copy()
 
 
+def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, list_of, T_cur_from_actkey, clouds, prev_pyr, cur_pyr, cur_f32, cur_dx, cur_dy, disp):
+    """The reference's own StereoFrontend::processFrame (oracle/_ref/libsvs_ref_frame.so: dense tracking, grid FAST with 6 trials on fresh grids, matchAndTrack,
+    processMatchedPoints, dense cloud; the keyframe decisions answer "no").  Returns dict(ok, T, clouds, rimg, lines [per level: rows (is_new, uv_pyr 2,
+    curkey_uv_pyr 2)], av_track_length, is_frame_dropped)."""
+    L = _ref_lib("libsvs_ref_frame.so")
+    L.svs_refframe_set_fast.argtypes = [C.c_void_p]
+    L.svs_refframe_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
+    n_kf = len(kf_pyrs)
+    kfs = np.zeros(n_kf, KEYFRAME_DTYPE)
+    keep = []
+    for i, pyr in enumerate(kf_pyrs):
+        kfs[i]["T_anchor_from_w"] = np.asarray(kf_poses[i], np.float64).reshape(12)
+        for l in range(3):
+            a = np.ascontiguousarray(pyr[l])
+            keep.append(a)
+            kfs[i]["pyr"][l] = a.ctypes.data
+            kfs[i]["stride"][l] = a.strides[0]
+    kf_ids = np.arange(100, 100 + 7 * n_kf, 7, dtype=np.int32)
+    nb = np.ascontiguousarray(np.asarray(neighbours, np.int32).reshape(-1, 2))
+    pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
+    lo = np.ascontiguousarray(list_of, np.int32)
+    T = np.array(T_cur_from_actkey, np.float64).reshape(12).copy()
+    clouds = [np.ascontiguousarray(c, np.float32).copy() for c in clouds]
+    prev = [np.ascontiguousarray(a, np.uint8) for a in prev_pyr]
+    cur = [np.ascontiguousarray(a, np.uint8) for a in cur_pyr]
+    f32, dx, dy = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (cur_f32, cur_dx, cur_dy)]
+    disp = np.ascontiguousarray(disp, np.float32)
+    rimg = [np.zeros_like(c) for c in clouds]
+    cap = len(pts) + 1
+    lines = np.zeros((cap, 5)); n_lines = (C.c_int * 3)()
+    av = C.c_double(0); dropped = C.c_int(0)
+    P3 = C.c_void_p * 3
+    L.svs_refframe_process_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + \
+        [C.c_void_p] * 8 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    ok = L.svs_refframe_process_frame(_p(kfs), n_kf, _p(kf_ids), int(actkey_index), _p(nb), len(nb), cams, _p(pts), _p(lo), len(pts), _p(T),
+                                      P3(*[a.ctypes.data for a in clouds]), P3(*[a.ctypes.data for a in prev]), P3(*[a.ctypes.data for a in cur]),
+                                      P3(*[a.ctypes.data for a in f32]), P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]), _p(disp),
+                                      P3(*[a.ctypes.data for a in rimg]), _p(lines), cap, n_lines, C.byref(av), C.byref(dropped))
+    out_lines, k = [], 0
+    for l in range(3):
+        out_lines.append(lines[k:k + n_lines[l]].copy()); k += n_lines[l]
+    return dict(ok=bool(ok), T=T.reshape(3, 4), clouds=clouds, rimg=rimg, lines=out_lines, av_track_length=av.value, is_frame_dropped=bool(dropped.value))
+
+
 def _cam6(cams):
     return np.ascontiguousarray([[c.f, c.cx, c.cy, c.b, c.w, c.h] for c in cams], np.float64)
 

@@ -50,9 +50,15 @@ struct KeyPoint {
 }  // namespace cv
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_HSV2BGR 54
 #define CV_32F 5
 #define CV_32FC4 29
 namespace cv {
+struct Scalar {
+  double val[4];
+  Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+};
 struct Vec4f {
   float v[4];
   Vec4f() { v[0] = v[1] = v[2] = v[3] = 0.f; }
@@ -67,10 +73,18 @@ class Mat {
   uint8_t *data;
   std::shared_ptr<std::vector<uint8_t> > own;      // storage of clones / allocations (views leave it empty or share it)
   Mat() : rows(0), cols(0), type_(CV_8U), step(0), data(0) {}
-  static size_t elem(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : 16; }
+  static size_t elem(int type) { return type == CV_8U ? 1 : type == CV_8UC3 ? 3 : type == CV_32F ? 4 : 16; }
   Mat(int r, int c, int type, void *d, size_t s = 0) : rows(r), cols(c), type_(type), step(s ? s : (size_t)c * elem(type)), data(static_cast<uint8_t *>(d)) {}
   Mat(int r, int c, int type) : rows(r), cols(c), type_(type), step((size_t)c * elem(type)), data(0) { own.reset(new std::vector<uint8_t>((size_t)r * step)); data = own->data(); }
   Mat(Size sz, int type) : rows(sz.height), cols(sz.width), type_(type), step((size_t)sz.width * elem(type)), data(0) { own.reset(new std::vector<uint8_t>((size_t)rows * step)); data = own->data(); }
+  Mat(Size sz, int type, int) : rows(sz.height), cols(sz.width), type_(type), step((size_t)sz.width * elem(type)), data(0) { own.reset(new std::vector<uint8_t>((size_t)rows * step)); data = own->data(); }      // (fill value: display images only)
+  void create(int r, int c, int type) { rows = r; cols = c; type_ = type; step = (size_t)c * elem(type); own.reset(new std::vector<uint8_t>((size_t)r * step)); data = own->data(); }
+  void create(Size sz, int type) { create(sz.height, sz.width, type); }
+  void setTo(const Scalar &s) {      // float images (1 or 4 channels)
+    const int ch = (int)(elem(type_) / 4);
+    for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) for (int k = 0; k < ch; ++k) reinterpret_cast<float *>(data + (size_t)r * step)[c * ch + k] = (float)s.val[k];
+  }
+  void convertTo(Mat &, int, double = 1, double = 0) const {}      // (only the colour-coded disparity DISPLAY image of processFrame goes through it)
   template <typename T> T *ptr(int y, int x) { return &at<T>(y, x); }
   template <typename T> const T *ptr(int y, int x) const { return &at<T>(y, x); }
   Mat operator()(const Rect &r) const { return (*this)(Range(r.y, r.y + r.height), Range(r.x, r.x + r.width)); }
@@ -97,6 +111,8 @@ class Mat {
     else for (int r = 0; r < rows; ++r) std::memcpy(dst.data + (size_t)r * dst.step, data + (size_t)r * step, (size_t)cols * elem(type_));
   }
 };
+inline void merge(const std::vector<Mat> &, Mat &) {}      // display only
+inline void cvtColor(const Mat &, Mat &, int) {}            // display only
 // hook: n = fn(image, w, h, stride, threshold, xy (x, y pairs, detection order), cap)
 typedef int (*svs_shim_fast_fn)(const uint8_t *, int, int, int, int, int16_t *, int);
 extern svs_shim_fast_fn svs_shim_fast_hook;

@@ -3,10 +3,6 @@
 #pragma once
 #include <opencv2/core/core.hpp>
 namespace cv {
-struct Scalar {
-  double val[4];
-  Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
-};
 namespace gpu {
 class GpuMat {
  public:

@@ -1,3 +1,3 @@
-// TEST INFRASTRUCTURE: empty stand-in (StereoFrontend keeps a pointer to one)
+// TEST INFRASTRUCTURE: stand-in for VisionTools::PerformanceMonitor (StereoFrontend brackets its stages with start / stop)
 #pragma once
-namespace VisionTools { class PerformanceMonitor {}; }
+namespace VisionTools { class PerformanceMonitor { public: void start(const char *) {} void stop(const char *) {} }; }

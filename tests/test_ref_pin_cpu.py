@@ -726,6 +726,76 @@ def test_match_and_track_equals_reference_compiled_chain(matcher_cpu_case):
     assert not ok and len(obs_idx) < 20 and num_new == 0 and np.array_equal(T, np.asarray(case["T_guess"]).reshape(3, 4))
 
 
+def test_process_frame_equals_reference_compiled_process_frame(matcher_cpu_case):
+    """The WHOLE per-frame path: StereoFrontend::processFrame (stereo_frontend.cpp:183-306) compiled from where it lies with everything it calls
+    (DenseTracker's CPU branch, computeFastCorners on the front end's own grids, matchAndTrack with the reference's matcher and pose optimiser,
+    processMatchedPoints, computeDensePointCloudCpu) in one translation unit -- against the restated stages chained in that order, each stage
+    consuming what the one before produced (the surface svs_frontend_process_frame replaces): bit-equal tracked pose, residual images, refined
+    pose, accepted points with their level positions, average track length and the new dense clouds."""
+    from scavislam_amd.ctypes_types import PoseOptParams
+    case = matcher_cpu_case
+    cams = case["cams"]
+    cam = dict(f=cams[0].f, cx=cams[0].cx, cy=cams[0].cy, b=cams[0].b, w=cams[0].w, h=cams[0].h)
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8)
+    img_prev, disp_prev = sc.render(cam, traj[4], seed=4)
+    pyr_prev = O.build_pyramid(img_prev)
+    T_prev_from_act = synth.pose_mul(traj[4], synth.pose_inv(case["T_act"]))
+    clouds = [O.pointcloud_cpu(disp_prev, cams[l], l, T_prev_from_act) for l in range(3)]
+    fl = [O.convert_sobel(p) for p in case["pyr_c"]]
+    f32, dx, dy = [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl]
+    pts = case["pts"]
+    n = len(pts)
+    rng = np.random.default_rng(3)
+    list_of = np.where(rng.random(n) < 0.12, 1, np.where(rng.random(n) < 0.1, 0, -1)).astype(np.int32)
+    list_of[pts["kf_index"] < 0] = -1
+    r = O.ref_process_frame(case["kf_pyrs"], case["kf_poses"], 1, [(0, 37)], cams, pts, list_of, T_prev_from_act, clouds, pyr_prev, case["pyr_c"], f32, dx, dy,
+                            case["disp_c"])
+    assert r["ok"] and not r["is_frame_dropped"]
+    # 1. dense tracking from the previous pose
+    T1, passes, rimg = O.dense_tracking_cpu(clouds, pyr_prev, f32, dx, dy, cams, T_prev_from_act, want_rimg=True)
+    for l in range(3):
+        assert np.array_equal(r["rimg"][l], rimg[l]), l
+    assert np.abs(T1 - T_prev_from_act).max() > 1e-4
+    # 2. corners: the front end's grids, fresh, six trials
+    trees = []
+    for l in range(3):
+        h, w = case["pyr_c"][l].shape
+        xy, cc, et = O.fastgrid_detect_adaptively(O.fastgrid_for_level(w, h, l), case["pyr_c"][l], 6)
+        trees.append(O.quadtree_from_corners(xy, cc, w, h))
+    # 3. the matcher chain at the tracked pose, then the motion-only refinement
+    order, results, n_obs, n_new_records = [], [], 0, 0
+    for gi, idx in enumerate([np.nonzero(list_of == 1)[0], np.nonzero(list_of == 0)[0], np.nonzero(list_of == -1)[0]]):
+        if gi == 1 and not 2 * n_obs < 300:
+            continue
+        res = O.match(case["kf_pyrs"], case["kf_poses"], T1, case["T_act"], case["pyr_c"], case["disp_c"], trees, cams, pts[idx], 8, 22, 10)
+        order.append(idx); results.append(res)
+        n_obs += int((res["status"] == 0).sum())
+        if gi <= 1:
+            n_new_records += len(idx)
+    idx_all, res_all = np.concatenate(order), np.concatenate(results)
+    assert (res_all["status"] == 0).sum() > 100
+    T2, st = O.motion_only(res_all, cams[0], T1, PoseOptParams.reference())
+    assert np.array_equal(r["T"], T2), np.abs(r["T"] - T2).max()
+    # 4. the gate at the refined pose: the draw lines are the accepted points, new features first, in list order per level
+    gated, stats = O.process_matched_points(res_all, pts[idx_all], n_new_records, cams[0], T2, 2.0)
+    n_lines = 0
+    for l in range(3):
+        lvl = pts[idx_all]["anchor_level"] == l
+        exp = []
+        for kind in (1, 0):
+            m = (gated["accepted"] == 1) & (gated["is_new"] == kind) & lvl
+            exp.append(np.concatenate([np.full((int(m.sum()), 1), float(kind)), gated["uv_pyr"][m], gated["curkey_uv_pyr"][m]], 1))
+        exp = np.concatenate(exp)
+        assert np.array_equal(r["lines"][l], exp), l
+        n_lines += len(exp)
+    assert n_lines == stats["num_track_points"] > 50 and (gated["is_new"] == 1).sum() > 5
+    assert r["av_track_length"] == stats["sum_track_length"] / stats["num_track_points"]
+    # 5. the dense clouds of this frame at the refined pose
+    for l in range(3):
+        assert np.array_equal(r["clouds"][l], O.pointcloud_cpu(case["disp_c"], cams[l], l, T2)), l
+
+
 # ---- the reference's own motion-only pose refinement (after the matcher, stereo_frontend.cpp:1058-1063) ------------------------------
 def _motion_results(rng, cam, T_true, n, outliers=0.1, n_fail=30, noise=0.4):
     from scavislam_amd.ctypes_types import MATCH_RESULT_DTYPE
