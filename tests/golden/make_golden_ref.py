@@ -64,6 +64,27 @@ for l in range(3):
     out[f"corners_l{l}"] = corners[l]
 np.savez_compressed(os.path.join(HERE, "ref_matcher.npz"), **out)
 
+# ---- the whole StereoFrontend::processFrame on the same scene (inputs shared with ref_matcher.npz; + the previous frame) -----------------------
+img_prev, disp_prev = sc.render(cam, traj[3], seed=4)
+pyr_prev = O.build_pyramid(img_prev)
+T_prev_from_act = synth.pose_mul(traj[3], synth.pose_inv(T_act))
+clouds_prev = [O.pointcloud_cpu(disp_prev, cams[l], l, T_prev_from_act) for l in range(3)]
+flc = [O.convert_sobel(p) for p in pyr_c]
+rngf = np.random.default_rng(3)
+list_of = np.where(rngf.random(len(pts)) < 0.12, 1, np.where(rngf.random(len(pts)) < 0.1, 0, -1)).astype(np.int32)
+list_of[pts["kf_index"] < 0] = -1
+fr = O.ref_process_frame(pyr_k, kf_poses, 1, [(0, 37)], cams, pts, list_of, T_prev_from_act, clouds_prev, pyr_prev, pyr_c, [f[0] for f in flc], [f[1] for f in flc],
+                         [f[2] for f in flc], disp_c)
+assert fr["ok"] and sum(len(x) for x in fr["lines"]) > 50
+out = dict(T0=T_prev_from_act, list_of=list_of, T=fr["T"], av_track_length=np.array([fr["av_track_length"]]))
+for l in range(3):
+    out[f"prev_l{l}"] = pyr_prev[l]
+    out[f"cloud_prev_l{l}"] = clouds_prev[l]
+    out[f"rimg_l{l}"] = fr["rimg"][l]
+    out[f"lines_l{l}"] = fr["lines"][l]
+    out[f"cloud_l{l}"] = fr["clouds"][l]
+np.savez_compressed(os.path.join(HERE, "ref_frame.npz"), **out)
+
 # ---- calcFastMotionOnly and processMatchedPoints on the matcher's own output ---------------------------------------------------------
 camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
 res = np.zeros(len(pts), MATCH_RESULT_DTYPE)
