@@ -915,11 +915,13 @@ def ref_match_and_track(kf_pyrs, kf_poses, actkey_index, neighbours, T_cur_from_
     return bool(ok), T.reshape(3, 4), num_new.value, obs_point[:k].copy(), obs[:k].copy(), xyz[:k].copy()
 
 
-def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, list_of, T_cur_from_actkey, clouds, prev_pyr, cur_pyr, cur_f32, cur_dx, cur_dy, disp):
+def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, list_of, T_cur_from_actkey, clouds, prev_pyr, cur_pyr, cur_f32, cur_dx, cur_dy, disp,
+                      cuda_build=False):
     """The reference's own StereoFrontend::processFrame (oracle/_ref/libsvs_ref_frame.so: dense tracking, grid FAST with 6 trials on fresh grids, matchAndTrack,
     processMatchedPoints, dense cloud; the keyframe decisions answer "no").  Returns dict(ok, T, clouds, rimg, lines [per level: rows (is_new, uv_pyr 2,
-    curkey_uv_pyr 2)], av_track_length, is_frame_dropped)."""
-    L = _ref_lib("libsvs_ref_frame.so")
+    curkey_uv_pyr 2)], av_track_length, is_frame_dropped).  cuda_build: the reference's CUDA build of the path (libsvs_ref_frame_cuda.so: denseTrackingGpu on
+    the emulated kernels, matcher radius 4) -- then clouds are full-resolution [h][w][4] and prev_pyr is the previous frame's F32 pyramid."""
+    L = _ref_lib("libsvs_ref_frame_cuda.so" if cuda_build else "libsvs_ref_frame.so")
     L.svs_refframe_set_fast.argtypes = [C.c_void_p]
     L.svs_refframe_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
     n_kf = len(kf_pyrs)
@@ -938,7 +940,7 @@ def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, li
     lo = np.ascontiguousarray(list_of, np.int32)
     T = np.array(T_cur_from_actkey, np.float64).reshape(12).copy()
     clouds = [np.ascontiguousarray(c, np.float32).copy() for c in clouds]
-    prev = [np.ascontiguousarray(a, np.uint8) for a in prev_pyr]
+    prev = [np.ascontiguousarray(a, np.float32 if cuda_build else np.uint8) for a in prev_pyr]
     cur = [np.ascontiguousarray(a, np.uint8) for a in cur_pyr]
     f32, dx, dy = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (cur_f32, cur_dx, cur_dy)]
     disp = np.ascontiguousarray(disp, np.float32)

@@ -20,6 +20,10 @@ class GpuMat {
     const int ch = (int)(Mat::elem(type_) / 4);
     for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) for (int k = 0; k < ch; ++k) reinterpret_cast<float *>(data + (size_t)r * step)[c * ch + k] = (float)s.val[k];
   }
+  void upload(const Mat &m) {      // host -> "device": a deep copy with a tight pitch
+    create(Size(m.cols, m.rows), m.type());
+    for (int r = 0; r < rows; ++r) std::memcpy(data + (size_t)r * step, m.data + (size_t)r * m.step, step);
+  }
   Size size() const { return Size(cols, rows); }
   size_t step1() const { return step / (type_ == CV_8U ? 1 : 4); }      // step in units of one channel's element
 };

@@ -20,6 +20,7 @@
  *   libsvs_ref_pose.so      pose_optimizer.h: calcFastMotionOnly;   libsvs_ref_gate.so  processMatchedPoints, initialize, computeFastCorners
  *   libsvs_ref_track.so     stereo_frontend.cpp matchAndTrack = matcher + pose optimiser chained as the front end chains them
  *   libsvs_ref_frame.so     stereo_frontend.cpp processFrame with everything it calls on the hot path, one translation unit
+ *   libsvs_ref_frame_cuda.so  the same with SCAVISLAM_CUDA_SUPPORT: the reference's CUDA build of the per-frame path
  *   libsvs_ref_edges.so     g2o_types/anchored_points.{h,cpp}: edge errors, Jacobians, oplus
  *   libsvs_ref_slamgraph.so slam_graph.cpp / -impl.cpp: optimize, copyDataToG2o and friends, into a recording g2o stand-in
  * tests/test_ref_pin_cpu.py holds this restatement BIT-EQUAL to every one of them.  What stays UNPINNED is

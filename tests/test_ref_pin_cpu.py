@@ -796,6 +796,70 @@ def test_process_frame_equals_reference_compiled_process_frame(matcher_cpu_case)
         assert np.array_equal(r["clouds"][l], O.pointcloud_cpu(case["disp_c"], cams[l], l, T2)), l
 
 
+def test_process_frame_cuda_build_equals_reference_compiled_process_frame(case):
+    """The same for the reference's CUDA build of the path (SCAVISLAM_CUDA_SUPPORT: denseTrackingGpu -- the damped full-resolution LM on the reference's own
+    emulated kernels --, matcher search radius 4, computeDensePointCloudGpu): one 320 x 240 frame through processFrame against the restated stages in the
+    reference's f32 block-tree arithmetic, chained: bit-equal residual images, refined pose, accepted points and full-resolution clouds."""
+    from scavislam_amd.ctypes_types import PoseOptParams, level_cams
+    cams_d = case["cams"]
+    camd = case["cam"]
+    cams = level_cams(camd["f"], camd["cx"], camd["cy"], camd["b"], camd["w"], camd["h"])
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    # the previous frame is the active keyframe (world = its frame); the current frame's disparity from the scene
+    sc = synth.Scene(2013)
+    traj = synth.trajectory(5, step=0.02, yaw_deg=0.2)
+    img_c, disp_c = sc.render(camd, traj[4], seed=2014)
+    assert np.array_equal(img_c, case["img_cur"])
+    pyr_k, pyr_c = O.build_pyramid(case["img_prev"]), O.build_pyramid(case["img_cur"])
+    rng = np.random.default_rng(9)
+    pts = synth.candidate_points(rng, camd, np.maximum(case["disp_prev"], 0), I, (260, 120, 40))
+    rng.shuffle(pts)
+    pts["point_id"] = np.arange(len(pts))
+    list_of = np.where(rng.random(len(pts)) < 0.2, 0, -1).astype(np.int32)
+    r = O.ref_process_frame([pyr_k], [I.reshape(12)], 0, [], cams, pts, list_of, I, case["cloud"], case["fp"], pyr_c, case["fc"], case["dx"], case["dy"], disp_c,
+                            cuda_build=True)
+    assert r["ok"]
+    K = ([c["f"] for c in cams_d], [c["cx"] for c in cams_d], [c["cy"] for c in cams_d])
+    T1, passes, rec, Tj = O.dense_tracking_gpu(case["cloud"], case["fp"], case["fc"], case["dx"], case["dy"], *K, I, O.SUM_F32_TREE)
+    for l in range(3):
+        assert np.array_equal(r["rimg"][l], O.residual_image_full(case["cloud"][l], case["fp"][l], case["fc"][l], np.float32(K[0][l]), np.float32(K[1][l]),
+                                                                  np.float32(K[2][l]), colmajor34(Tj[l]).astype(np.float32))), l
+    trees = []
+    for l in range(3):
+        h, w = pyr_c[l].shape
+        xy, cc, et = O.fastgrid_detect_adaptively(O.fastgrid_for_level(w, h, l), pyr_c[l], 6)
+        trees.append(O.quadtree_from_corners(xy, cc, w, h))
+    order, results = [], []
+    for idx in (np.nonzero(list_of == 0)[0], np.nonzero(list_of == -1)[0]):
+        order.append(idx)
+        results.append(O.match([pyr_k], [I.reshape(12)], T1, I, pyr_c, disp_c, trees, cams, pts[idx], 4, 22, 10))      # radius 4 (stereo_frontend.cpp:1044)
+    idx_all, res_all = np.concatenate(order), np.concatenate(results)
+    assert (res_all["status"] == 0).sum() > 60
+    T2, st = O.motion_only(res_all, cams[0], T1, PoseOptParams.reference())
+    assert np.array_equal(r["T"], T2), np.abs(r["T"] - T2).max()
+    gated, stats = O.process_matched_points(res_all, pts[idx_all], int((list_of == 0).sum()), cams[0], T2, 2.0)
+    for l in range(3):
+        lvl = pts[idx_all]["anchor_level"] == l
+        exp = []
+        for kind in (1, 0):
+            m = (gated["accepted"] == 1) & (gated["is_new"] == kind) & lvl
+            exp.append(np.concatenate([np.full((int(m.sum()), 1), float(kind)), gated["uv_pyr"][m], gated["curkey_uv_pyr"][m]], 1))
+        assert np.array_equal(r["lines"][l], np.concatenate(exp)), l
+    assert stats["num_track_points"] > 30
+    Ti = O.se3_inv(T2)
+    for l, c in enumerate(cams_d):                              # computeDensePointCloudGpu: T^-1 Q in f64, products summed in ascending k
+        Q = np.array([[1, 0, 0, -c["cx"]], [0, 1, 0, -c["cy"]], [0, 0, 0, c["f"]], [0, 0, 1.0 / c["b"], 0]])
+        T4 = np.vstack([np.asarray(Ti).reshape(3, 4), [0, 0, 0, 1]])
+        TQ = np.zeros((4, 4))
+        for i in range(4):
+            for j in range(4):
+                t = T4[i, 0] * Q[0, j]
+                for k in range(1, 4):
+                    t += T4[i, k] * Q[k, j]
+                TQ[i, j] = t
+        assert np.array_equal(r["clouds"][l], O.pointcloud_full(TQ.T.reshape(16).astype(np.float32), disp_c, c["w"], c["h"], 1 << l)), l
+
+
 # ---- the reference's own motion-only pose refinement (after the matcher, stereo_frontend.cpp:1058-1063) ------------------------------
 def _motion_results(rng, cam, T_true, n, outliers=0.1, n_fail=30, noise=0.4):
     from scavislam_amd.ctypes_types import MATCH_RESULT_DTYPE
