@@ -64,7 +64,8 @@ typedef struct {                       /* keyframe_map entry + vertex_map pose *
 } svs_keyframe;
 
 enum { SVS_MATCH_OK = 0, SVS_MATCH_NO_ANCHOR, SVS_MATCH_BORDER, SVS_MATCH_DEPTH,
-       SVS_MATCH_TEXTURE, SVS_MATCH_NONE, SVS_MATCH_NO_DISP };
+       SVS_MATCH_TEXTURE, SVS_MATCH_NONE, SVS_MATCH_NO_DISP,
+       SVS_MATCH_SKIPPED /* svs_frontend_*: a neighbour's new-point list behind matchAndTrack's cut (stereo_frontend.cpp:1000-1003) */ };
 
 typedef struct {
   int32_t status, u, v, znssd;
@@ -191,6 +192,9 @@ typedef struct {
   svs_cam cam_vec[3];
   int32_t search_radius, thr_mean, thr_std;        /* 8, 22, 10 at stereo_frontend.cpp:989-1004 */
   int32_t n_batch;
+  /* element distances between the tables of consecutive slots; 0 = the default: one keyframe table shared by all slots,
+     point and result arrays packed [n_batch][n_pts] */
+  size_t kf_bstride, pts_bstride, out_bstride;
 } svs_match_args;
 /* corners come from `f` (the feature_tree argument of the reference): candidate set and
    tie-break order are those of QuadTree::query. d_out: [n_batch][n_pts] */
@@ -204,11 +208,15 @@ typedef struct {
   double kernel_param;
   double initial_mu;       /* -1 => tau * max diag(J^T J) (pose_optimizer.h:187-190) */
   double tau;              /* 1e-5 */
+  int32_t min_obs;         /* matchAndTrack returns before calcFastMotionOnly with fewer than 20 observations (stereo_frontend.cpp:1053-1056):
+                              with fewer than min_obs the pose is left untouched and status = 3; 0 = no minimum */
+  int32_t pad_;
 } svs_pose_opt_params;
 typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
   double initial_chi2, chi2, max_err;
   int32_t num_obs;
-  int32_t status;          /* 0 ok; 1 empty observation list (the reference asserts); 2 residual became NaN (the reference throws) */
+  int32_t status;          /* 0 ok; 1 empty observation list (the reference asserts); 2 residual became NaN (the reference throws);
+                              3 fewer than min_obs observations: nothing done */
 } svs_pose_opt_stats;
 /* obs_list / point_list = the SVS_MATCH_OK entries of d_results[b][0..n) in order (several svs_match outputs may be
    concatenated, as matchAndTrack appends into one TrackData); d_T_io[b][12] = T_cur_from_actkey in/out */
@@ -342,6 +350,11 @@ int svs_dense_residual_image_full(svs_ctx *ctx, const float *d_cloud4, int w, in
 /* computePointCloud (gpu/dense_tracking.cu:82-148) */
 int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ_colmajor, const float *d_disp, int w, int h,
                         int stride_in, int stride_out, int factor, float *d_cloud4);
+/* one level of DenseTracker::computeDensePointCloudGpu (dense_tracking.cpp:195-215) for `batch` streams with the poses on the DEVICE:
+   TQ = T_cur_from_actkey^-1 * cam.Q() in double (products summed in ascending k), narrowed to float, then computePointCloud.
+   d_T [batch][12]; cam = cam_vec[level]; factor = 2^level; strides in elements (float / float4), batch strides likewise */
+int svs_pointcloud_full_pose(svs_ctx *ctx, const double *d_T, const svs_cam *cam, const float *d_disp, int disp_stride, size_t disp_bstride,
+                             int w, int h, int stride_out, size_t cloud_bstride, int factor, float *d_cloud4, int batch);
 
 /* ---- one call per frame: replaces the data-parallel part of StereoFrontend::processFrame(bool*) / processFirstFrame()
    (stereo_frontend.h:88-95, stereo_frontend.cpp:110-131,183-306) for one camera stream, HOST buffers in and out.  The stages are
@@ -354,6 +367,13 @@ typedef struct {
   int32_t use_block_matching;          /* 0: a disparity image comes with every frame (have_disp_img); 1: calcDisparityCpu from the right image */
   svs_pose_opt_params pose_opt;        /* PoseOptimizerParams(true, 2, 15) (:1061) */
   svs_stereo_params stereo;            /* cv::StereoBM state (:620-653); used if use_block_matching */
+  int32_t n_levels;                    /* use_n_levels_in_frontent (:68): pyramid levels FAST and the matcher run on; the code default is 2, the shipped
+                                          configurations set 3.  0 = 3 */
+  int32_t num_max_points;              /* ui.num_max_points (:1000): neighbours' new-point lists are matched while 2 * observations < this.  0 = 300 */
+  int32_t min_matches;                 /* matchAndTrack fails below this many observations (:1053).  0 = 20 */
+  int32_t cuda_build;                  /* 0: the reference's CPU build (quarter-grid denseTrackingCpu, computeDensePointCloudCpu; search_radius 8);
+                                          1: its SCAVISLAM_CUDA_SUPPORT build (full-resolution denseTrackingGpu on f32 pyramids, computeDensePointCloudGpu;
+                                          the caller passes search_radius 4, :1043-1047) */
 } svs_frontend_params;
 typedef struct {
   double T_cur_from_actkey[12];        /* after dense tracking and calcFastMotionOnly */
@@ -367,22 +387,60 @@ typedef struct {
 typedef struct svs_frontend svs_frontend;
 /* cam = level-0 stereo camera (w, h multiples of 16).  max_points: capacity of the candidate list (ap_map); max_keyframes: keyframe slots */
 int svs_frontend_create(svs_ctx *ctx, const svs_cam *cam, const svs_frontend_params *prm, int max_points, int max_keyframes, svs_frontend **out);
+/* the same for n_streams independent camera streams (one front end each: own previous frame, keyframes, candidate points, FAST thresholds) whose
+   stages run as ONE launch per stage.  Stream 0 is the one the host-buffer entry points (first_frame / process_frame / ...) talk to; they need n_streams == 1 */
+int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const svs_frontend_params *prm, int max_points, int max_keyframes, int n_streams,
+                              svs_frontend **out);
 int svs_frontend_destroy(svs_frontend *fe);
 /* processFirstFrame: pyramid, disparity, FAST (fast_trials - 1), reference cloud at the identity.  h_right or h_disp per use_block_matching */
 int svs_frontend_first_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp, int dstride);
 /* Frame::clone of the frame processed last into keyframe slot `slot` with its pose (keyframe_map entry + vertex_map pose) */
 int svs_frontend_keep_keyframe(svs_frontend *fe, int slot, const double *T_kf_from_w);
-/* ap_map: h_pts[i].kf_index = keyframe slot of the anchor; records [0, n_new_records) are the "new feature" candidates (:989-1030) */
+int svs_frontend_keep_keyframe_of(svs_frontend *fe, int stream, int slot, const double *T_kf_from_w);
+/* ap_map: h_pts[i].kf_index = keyframe slot of the anchor (a slot svs_frontend_keep_keyframe has filled; < 0 = anchor frame not in keyframe_map,
+   matcher.cpp:336-339); records [0, n_new_records) are the "new feature" candidates (:989-1030) */
 int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate_point *h_pts, int n, int n_new_records);
+/* the candidate lists of matchAndTrack (stereo_frontend.cpp:976-1050) in the order it walks them, for one stream: group 0 = newpoint_map[actkey_id],
+   groups 1 .. n_groups-2 = newpoint_map[neighbour] in the order of active_vertex.strength_to_neighbors, group n_groups-1 = neighborhood_->point_list.
+   h_group_end[g] = one past the last record of group g (n_groups >= 2, <= 64; h_group_end[n_groups-1] == n).  The neighbour lists behind the cut
+   "2 * obs_list.size() < ui.num_max_points" come back with status SVS_MATCH_SKIPPED and take no part in the refinement or the gate. */
+int svs_frontend_set_candidates_grouped(svs_frontend *fe, int stream, const svs_candidate_point *h_pts, int n, const int32_t *h_group_end, int n_groups);
 /* processFrame.  T_cur_from_actkey: the motion-model guess (in); T_actkey_from_w: pose of the active keyframe.  h_matches / h_gated:
    n_points records each (may be NULL).  Blocking, like the reference call. */
 int svs_frontend_process_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp,
                                int dstride, const double *T_cur_from_actkey, const double *T_actkey_from_w, svs_frame_result *out,
                                svs_match_result *h_matches, svs_gated_point *h_gated);
-/* computeDensePointCloudCpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302) */
+/* processFrame in two halves (stream 0, n_streams == 1): submit stages the images, enqueues upload + all stages + the download and returns; wait blocks
+   and hands the results out (h_matches / h_gated only if asked for at submit).  In between the caller is free -- e.g. to prefetch the next frame. */
+int svs_frontend_submit_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp, int dstride,
+                              const double *T_cur_from_actkey, const double *T_actkey_from_w, int want_matches, int want_gated);
+int svs_frontend_wait_frame(svs_frontend *fe, svs_frame_result *out, svs_match_result *h_matches, svs_gated_point *h_gated);
+/* upload the NEXT frame on a copy stream while the frame submitted last is being processed -- the reference's FrameData double buffer
+   (frame_grabber.hpp:93-155: the grabber thread fills the next frame while the front end works on the current one).  The following
+   first_frame / submit_frame / process_frame must pass NULL images. */
+int svs_frontend_prefetch_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp, int dstride);
+/* ---- all streams at once, frames in DEVICE memory (camera DMA target, decoder output, another kernel's result) ---- */
+typedef struct {                       /* images of all streams: stream b at + b * bstride (elements); unused members NULL */
+  const uint8_t *d_left; int32_t lstride; size_t l_bstride;
+  const uint8_t *d_right; int32_t rstride; size_t r_bstride;   /* use_block_matching */
+  const float *d_disp; int32_t dstride; size_t d_bstride;      /* otherwise; read in place during the call, not copied */
+} svs_frames_dev;
+/* where the NEXT frames may be written in place (then pass in == NULL below): level-0 image, right image (NULL without block matching), disparity.
+   Valid until the next first_frames / process_frames call, which moves on to other buffers */
+int svs_frontend_input_view(svs_frontend *fe, uint8_t **d_left, int32_t *lstride, size_t *l_bstride, uint8_t **d_right, int32_t *rstride, size_t *r_bstride,
+                            float **d_disp, int32_t *dstride, size_t *d_bstride);
+/* processFirstFrame for every stream (blocking) */
+int svs_frontend_first_frames(svs_frontend *fe, const svs_frames_dev *in);
+/* processFrame for every stream: poses [n_streams][12] from the host; ASYNCHRONOUS on the context's stream, results stay on the device */
+int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_dev *in, const double *h_T_cur_from_actkey, const double *h_T_actkey_from_w);
+/* blocking downloads after svs_frontend_process_frames: everything of one stream; refined poses [n_streams][12] + tracking flags of all (NULL = not wanted) */
+int svs_frontend_results(svs_frontend *fe, int stream, svs_frame_result *out, svs_match_result *h_matches, svs_gated_point *h_gated);
+int svs_frontend_poses(svs_frontend *fe, double *h_T_cur_from_actkey, int32_t *h_tracking_ok);
+/* computeDensePointCloudCpu / Gpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302); n_streams == 1 */
 int svs_frontend_recompute_cloud(svs_frontend *fe, const double *T_cur_from_actkey);
-/* device views (tests, chaining): level images of the frame processed last, strides, disparity, reference clouds, the FastGrid object */
-int svs_frontend_device_view(svs_frontend *fe, const uint8_t **d_pyr_last, int32_t *stride, const float **d_disp, const float **d_cloud,
+/* device views of one stream (tests, chaining): level images of the frame processed last, strides, its disparity (the caller's buffer if it passed
+   one), reference clouds (quarter grid, or full resolution in the CUDA build), the FastGrid object (shared by all streams: slot = stream) */
+int svs_frontend_device_view(svs_frontend *fe, int stream, const uint8_t **d_pyr_last, int32_t *stride, const float **d_disp, const float **d_cloud,
                              svs_fast **fast);
 
 /* ---- multi-GPU: the library-owned collective of the landmark-sharded back-end.  The reference has no

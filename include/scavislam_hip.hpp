@@ -254,6 +254,7 @@ class BA_SE3_XYZ_STEREO {
     DeviceBuffer<svs_pose_opt_stats> d_st(ctx_, 1);
     if ((track.size() && !d_res.upload(track.data(), track.size())) || !d_T.upload(T_cur_from_actkey, 12)) return false;
     svs_pose_opt_params p;
+    std::memset(&p, 0, sizeof p);
     p.robust_kernel = ba_params.robust_kernel; p.num_iter = ba_params.num_iter; p.kernel_param = ba_params.kernel_param;
     p.initial_mu = ba_params.initial_mu; p.tau = ba_params.tau;
     if (!ctx_.check(svs_motion_only(ctx_.get(), d_res.get(), (int)track.size(), track.size(), &cam, &p, d_T.get(), d_st.get(), 1))) return false;
@@ -455,10 +456,13 @@ class StereoFrontend {
   ~StereoFrontend() { if (fe_) svs_frontend_destroy(fe_); }
   StereoFrontend(const StereoFrontend &) = delete;
   StereoFrontend &operator=(const StereoFrontend &) = delete;
-  static svs_frontend_params referenceParams(bool block_matching) {
+  // cuda_build: the reference compiled with SCAVISLAM_CUDA_SUPPORT (full-resolution denseTrackingGpu, matcher search radius 4, stereo_frontend.cpp:1043-1047);
+  // n_levels: use_n_levels_in_frontent (stereo_frontend.cpp:68; the code default is 2, the shipped configurations set 3)
+  static svs_frontend_params referenceParams(bool block_matching, bool cuda_build = false, int n_levels = 3) {
     svs_frontend_params p;
     std::memset(&p, 0, sizeof p);
-    p.fast_trials = 6; p.search_radius = 8; p.thr_mean = 22; p.thr_std = 10; p.max_reproj_error = 2.f; p.use_block_matching = block_matching ? 1 : 0;
+    p.fast_trials = 6; p.search_radius = cuda_build ? 4 : 8; p.thr_mean = 22; p.thr_std = 10; p.max_reproj_error = 2.f; p.use_block_matching = block_matching ? 1 : 0;
+    p.n_levels = n_levels; p.num_max_points = 300; p.min_matches = 20; p.cuda_build = cuda_build ? 1 : 0;
     p.pose_opt.robust_kernel = 1; p.pose_opt.num_iter = 15; p.pose_opt.kernel_param = 2.0; p.pose_opt.initial_mu = -1.0; p.pose_opt.tau = 1e-5;
     const svs_stereo_params sp = {31, 7, 0, 32, 10, 15, 100, 32, 1};
     p.stereo = sp;
@@ -473,6 +477,25 @@ class StereoFrontend {
   bool setCandidates(const std::vector<svs_candidate_point> &ap_map, int n_new_records) {
     n_ = (int)ap_map.size();
     return ctx_.check(svs_frontend_set_candidates(fe_, ap_map.data(), n_, n_new_records));
+  }
+  // matchAndTrack's lists in the order it walks them (stereo_frontend.cpp:976-1050): group_end[0] = end of newpoint_map[actkey_id], one end per neighbour in
+  // strength_to_neighbors order, the last = ap_map.size() = end of neighborhood_->point_list
+  bool setCandidateLists(const std::vector<svs_candidate_point> &ap_map, const std::vector<int32_t> &group_end) {
+    n_ = (int)ap_map.size();
+    return ctx_.check(svs_frontend_set_candidates_grouped(fe_, 0, ap_map.data(), n_, group_end.data(), (int)group_end.size()));
+  }
+  // the grabber side of frame_grabber.hpp:93-155: hand the NEXT frame over while the current one is processed; processFrame / processFirstFrame then get no image
+  bool prefetchFrame(Image8 left, const Image8 *right, const ImageF *disp) {
+    return ctx_.check(svs_frontend_prefetch_frame(fe_, left.data, left.stride, right ? right->data : nullptr, right ? right->stride : 0, disp ? disp->data : nullptr,
+                                                  disp ? disp->stride : 0));
+  }
+  bool processPrefetchedFrame(double T_cur_from_actkey[12], const double T_actkey_from_w[12], svs_frame_result *res, std::vector<svs_match_result> *matches,
+                              std::vector<svs_gated_point> *gated) {
+    matches->resize((size_t)n_); gated->resize((size_t)n_);
+    if (!ctx_.check(svs_frontend_process_frame(fe_, nullptr, 0, nullptr, 0, nullptr, 0, T_cur_from_actkey, T_actkey_from_w, res, matches->data(), gated->data())))
+      return false;
+    for (int i = 0; i < 12; ++i) T_cur_from_actkey[i] = res->T_cur_from_actkey[i];
+    return res->tracking_ok != 0;
   }
   // returns what matchAndTrack returns (enough features matched); *T_cur_from_actkey is in/out like the reference's member
   bool processFrame(Image8 left, const Image8 *right, const ImageF *disp, double T_cur_from_actkey[12], const double T_actkey_from_w[12], svs_frame_result *res,

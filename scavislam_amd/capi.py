@@ -42,12 +42,24 @@ class DenseTrackFullArgs(C.Structure):
 
 class FrontendParams(C.Structure):
     _fields_ = [("fast_trials", C.c_int32), ("search_radius", C.c_int32), ("thr_mean", C.c_int32), ("thr_std", C.c_int32),
-                ("max_reproj_error", C.c_float), ("use_block_matching", C.c_int32), ("pose_opt", PoseOptParams), ("stereo", StereoParams)]
+                ("max_reproj_error", C.c_float), ("use_block_matching", C.c_int32), ("pose_opt", PoseOptParams), ("stereo", StereoParams),
+                ("n_levels", C.c_int32), ("num_max_points", C.c_int32), ("min_matches", C.c_int32), ("cuda_build", C.c_int32)]
 
     @classmethod
-    def reference(cls, use_block_matching=False):
-        """the values StereoFrontend uses (stereo_frontend.cpp:232, :989-1004, :845-846, :1061, :620-653)"""
-        return cls(6, 8, 22, 10, 2.0, int(use_block_matching), PoseOptParams.reference(), StereoParams.reference())
+    def reference(cls, use_block_matching=False, cuda_build=False, n_levels=3, search_radius=None, thr_mean=22, thr_std=10, num_max_points=300):
+        """the values StereoFrontend uses (stereo_frontend.cpp:232, :989-1004, :845-846, :1061, :620-653); cuda_build = its SCAVISLAM_CUDA_SUPPORT
+        build (full-resolution tracker, matcher search radius 4, :1043-1047).  n_levels: use_n_levels_in_frontent (code default 2, shipped cfgs 3)"""
+        if search_radius is None:
+            search_radius = 4 if cuda_build else 8
+        return cls(6, search_radius, thr_mean, thr_std, 2.0, int(use_block_matching), PoseOptParams.reference(), StereoParams.reference(),
+                   n_levels, num_max_points, 20, int(cuda_build))
+
+
+class FramesDev(C.Structure):
+    """svs_frames_dev: images of all streams in device memory"""
+    _fields_ = [("d_left", C.c_void_p), ("lstride", C.c_int32), ("l_bstride", C.c_size_t),
+                ("d_right", C.c_void_p), ("rstride", C.c_int32), ("r_bstride", C.c_size_t),
+                ("d_disp", C.c_void_p), ("dstride", C.c_int32), ("d_bstride", C.c_size_t)]
 
 
 class PointStatsC(C.Structure):
@@ -68,7 +80,8 @@ class MatchArgs(C.Structure):
                 ("d_disp", C.c_void_p), ("disp_stride", C.c_int32), ("disp_bstride", C.c_size_t),
                 ("cam_vec", Cam * 3),
                 ("search_radius", C.c_int32), ("thr_mean", C.c_int32), ("thr_std", C.c_int32),
-                ("n_batch", C.c_int32)]
+                ("n_batch", C.c_int32),
+                ("kf_bstride", C.c_size_t), ("pts_bstride", C.c_size_t), ("out_bstride", C.c_size_t)]
 
 
 _SIGS = {
@@ -127,6 +140,20 @@ _SIGS = {
     "svs_stereo_compute": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                            C.c_size_t, C.c_int],
     "svs_frontend_create": [C.c_void_p, C.POINTER(Cam), C.POINTER(FrontendParams), C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "svs_frontend_create_batch": [C.c_void_p, C.POINTER(Cam), C.POINTER(FrontendParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "svs_frontend_keep_keyframe_of": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "svs_frontend_set_candidates_grouped": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_frontend_submit_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "svs_frontend_wait_frame": [C.c_void_p, C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
+    "svs_frontend_prefetch_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_frontend_input_view": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)],
+    "svs_frontend_first_frames": [C.c_void_p, C.POINTER(FramesDev)],
+    "svs_frontend_process_frames": [C.c_void_p, C.POINTER(FramesDev), C.c_void_p, C.c_void_p],
+    "svs_frontend_results": [C.c_void_p, C.c_int, C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
+    "svs_frontend_poses": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_pointcloud_full_pose": [C.c_void_p, C.c_void_p, C.POINTER(Cam), C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                 C.c_void_p, C.c_int],
     "svs_frontend_destroy": [C.c_void_p],
     "svs_frontend_first_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "svs_frontend_keep_keyframe": [C.c_void_p, C.c_int, C.c_void_p],
@@ -134,7 +161,7 @@ _SIGS = {
     "svs_frontend_process_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
     "svs_frontend_recompute_cloud": [C.c_void_p, C.c_void_p],
-    "svs_frontend_device_view": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_frontend_device_view": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_create": [C.c_void_p, C.POINTER(C.c_void_p)],
     "svs_ba_destroy": [C.c_void_p],
     "svs_ba_set_problem": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -26,6 +26,7 @@ struct svs_ctx {
   int trk_nwg = 0;            // SVS_TRK_NWG: workgroups per stream of the latency-mode quarter-grid tracker (0 = automatic)
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
+  int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
@@ -57,6 +58,11 @@ int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
   } while (0)
 
 #define SVS_LAUNCH_CHECK(ctx) SVS_HIP(ctx, hipGetLastError())
+
+// internal (not exported through the header): svs_process_matched_points with the record count of the new-feature lists per stream, on the device
+int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n, size_t res_bstride,
+                                   size_t pts_bstride, const int32_t *d_n_new_records, const svs_cam *cam, const double *d_T, float max_reproj_error,
+                                   svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats, int batch);
 
 __host__ __device__ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 

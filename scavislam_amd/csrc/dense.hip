@@ -753,8 +753,8 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
     mu = prm.initial_mu == -1 ? prm.tau * v[3] : prm.initial_mu;
   }
   const double initial_chi2 = chi2;
-  int status = num_obs == 0 ? 1 : 0, trial = 0;
-  bool stop = num_obs == 0;
+  int status = num_obs == 0 ? 1 : (num_obs < prm.min_obs ? 3 : 0), trial = 0;
+  bool stop = status != 0;
   for (int ig = 0; ig < prm.num_iter && !stop; ++ig) {
     double rho = 0;
     do {
@@ -823,19 +823,240 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
   }
 }
 
-}  // namespace
 
+
+// ---- the same loop, restructured for latency (round 3) ---------------------------------------------------------------------------
+// The kernel above walks the matcher's record array (status test + 64-byte record from global memory per observation) twice per LM
+// trial and solves on one lane: 202 us for ~850 observations at B = 1.  Here:
+//  * the status-OK records are compacted ONCE (order-preserving: ballots + a wave prefix) into an index list in LDS, and every thread keeps
+//    up to MO2_RC observations in registers for the whole loop (observations beyond MO2_RC * MO2_THREADS are re-read through the list);
+//  * ONE sweep per LM trial: chi2 / max error at the trial pose and the normal equations at the same pose share their residuals, so the
+//    reference's "new chi2" pass and the next iteration's J^T J pass are one (a rejected trial keeps the stored system and only re-damps);
+//  * 28 sums per wave by recursive halving (32 exchanges instead of 168 butterflies), two block barriers per trial;
+//  * the 6x6 solve runs on seven lanes of wave 0 (lane = column of [A + mu I | B], Gauss-Jordan with readlane broadcasts; the matrix is
+//    symmetric positive definite, so no pivoting is needed where the reference's ldlt() pivots), exp(delta) * T on the same wave.
+// Same LM schedule and stopping rules as pose_optimizer.h:134-298; sums in a different order and one reciprocal instead of five divisions
+// per residual => the pose agrees with the oracle to ~1e-12 (test bar 1e-9).
+constexpr int MO2_THREADS = 256, MO2_RC = 4, MO2_WAVES = MO2_THREADS / 64;
+struct MoObs { double o[3], q[3]; };
+
+__device__ __forceinline__ void mo2_terms(const double *T, const MoObs &ob, const svs_cam &cam, int robust, double kb, double (&x)[32], double &max_err,
+                                          double *max_diag) {
+  const double *q = ob.q;
+  const double X = T[0] * q[0] + T[1] * q[1] + T[2] * q[2] + T[3];
+  const double Y = T[4] * q[0] + T[5] * q[1] + T[6] * q[2] + T[7];
+  const double Z = T[8] * q[0] + T[9] * q[1] + T[10] * q[2] + T[11];
+  const double fl = cam.f, iz = 1.0 / Z, fiz = fl * iz;
+  double f[3] = {ob.o[0] - (X * fiz + cam.cx), ob.o[1] - (Y * fiz + cam.cy), ob.o[2] - ((X - cam.b) * fiz + cam.cx)};
+  const double A = -fiz, C = fiz * X * iz, D = fiz * Y * iz, E = fiz * (X - cam.b) * iz;
+  double J[18];
+  J[0] = A; J[1] = 0; J[2] = C; J[3] = Y * C; J[4] = Z * A - X * C; J[5] = -Y * A;
+  J[6] = 0; J[7] = A; J[8] = D; J[9] = -Z * A + Y * D; J[10] = -X * D; J[11] = X * A;
+  J[12] = A; J[13] = 0; J[14] = E; J[15] = Y * E; J[16] = Z * A - X * E; J[17] = -Y * A;
+  if (max_diag) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) *max_diag = fmax(*max_diag, fabs(J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c]));
+  }
+  x[27] += mo_weighted_sq(f, robust, kb);
+  max_err = fmax(max_err, fmax(fabs(f[0]), fmax(fabs(f[1]), fabs(f[2]))));
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = r; c < 6; ++c) { x[k] += J[r] * J[c] + J[6 + r] * J[6 + c] + J[12 + r] * J[12 + c]; ++k; }
+    x[21 + r] += J[r] * f[0] + J[6 + r] * f[1] + J[12 + r] * f[2];
+  }
+}
+// value id held by lane `lane` (< 32) after the recursive halving of mo2_wave_reduce
+__device__ __forceinline__ int mo2_id(int lane) { return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4); }
+__device__ __forceinline__ double mo2_wave_reduce(double (&x)[32]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const int half = 16 >> step, bit = 1 << step;
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double send = up ? x[k] : x[k + half];
+      const double keep = up ? x[k + half] : x[k];
+      x[k] = keep + __shfl_xor(send, bit, 64);
+    }
+  }
+  return x[0] + __shfl_xor(x[0], 32, 64);
+}
+__device__ __forceinline__ double mo2_bcast(double v, int src_lane) {      // src_lane is a compile-time constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
+                                                                        svs_pose_opt_params prm, double *__restrict__ T_io,
+                                                                        svs_pose_opt_stats *__restrict__ stats) {
+  extern __shared__ int s_idx[];                   // [n]: indices of the status-OK records, in list order
+  __shared__ double s_part[MO2_WAVES][32];         // per wave: 28 sums (21 of J^T J, 6 of J^T w f, chi2), max error, max diag
+  __shared__ double s_T[12], s_Tn[12];
+  __shared__ int s_wcnt[MO2_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
+  res += (size_t)slot * res_bstride;
+  if (tid < 12) s_T[tid] = T_io[12 * slot + tid];
+  // ---- compaction of obs_list / point_list (the OK records, in order)
+  int n_ok = 0;
+  for (int base = 0; base < n; base += MO2_THREADS) {
+    const int i = base + tid;
+    const bool ok = i < n && res[i].status == 0;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_ok, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MO2_WAVES; ++w) { const int c = s_wcnt[w]; off += w < wave ? c : 0; tot += c; }
+    if (ok) s_idx[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    n_ok += tot;
+    __syncthreads();
+  }
+  MoObs ob[MO2_RC];
+#pragma unroll
+  for (int k = 0; k < MO2_RC; ++k) {
+    const int j = tid + k * MO2_THREADS;
+    if (j < n_ok) {
+      const svs_match_result &r = res[s_idx[j]];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ob[k].o[c] = r.obs[c]; ob[k].q[c] = r.xyz_actkey[c]; }
+    }
+  }
+  // one sweep at pose T: sums -> s_part
+  auto sweep = [&](const double *Tp, bool first) {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = Tp[i];
+    double x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = 0.0;
+    double me = 0.0, md = 0.0;
+#pragma unroll
+    for (int k = 0; k < MO2_RC; ++k)
+      if (tid + k * MO2_THREADS < n_ok) mo2_terms(T, ob[k], cam, prm.robust_kernel, prm.kernel_param, x, me, first ? &md : nullptr);
+    for (int j = tid + MO2_RC * MO2_THREADS; j < n_ok; j += MO2_THREADS) {
+      const svs_match_result &r = res[s_idx[j]];
+      MoObs t;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { t.o[c] = r.obs[c]; t.q[c] = r.xyz_actkey[c]; }
+      mo2_terms(T, t, cam, prm.robust_kernel, prm.kernel_param, x, me, first ? &md : nullptr);
+    }
+    const double v = mo2_wave_reduce(x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { me = fmax(me, __shfl_xor(me, o, 64)); if (first) md = fmax(md, __shfl_xor(md, o, 64)); }
+    const int id = mo2_id(lane);
+    if (lane < 32 && id < 28) s_part[wave][id] = v;
+    if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
+  };
+  auto total = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s += s_part[w][id]; return s; };
+  auto total_max = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s = fmax(s, s_part[w][id]); return s; };
+  __syncthreads();
+  sweep(s_T, true);
+  __syncthreads();
+  const int num_obs = n_ok;
+  double chi2 = total(27), max_err = total_max(28), mu = prm.initial_mu == -1 ? prm.tau * total_max(29) : prm.initial_mu, nu = 2;
+  const double initial_chi2 = chi2;
+  int status = num_obs == 0 ? 1 : (num_obs < prm.min_obs ? 3 : 0), trial = 0;
+  bool stop = status != 0;
+  // wave 0, lane c < 6: column c of the stored J^T J; lane 6: -J^T w f
+  double col[6] = {0, 0, 0, 0, 0, 0};
+  auto load_system = [&]() {
+    if (wave == 0 && lane < 7) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int a = r < lane ? r : lane, b = r < lane ? lane : r;      // upper-triangular index of (r, lane)
+        col[r] = lane < 6 ? total(a * (13 - a) / 2 + (b - a)) : -total(21 + r);
+      }
+    }
+  };
+  load_system();
+  for (int ig = 0; ig < prm.num_iter && !stop; ++ig) {
+    double rho = 0;
+    do {
+      __syncthreads();                               // everybody has read the sums of the last sweep
+      double bmax = 0;
+      if (wave == 0) {
+        // (A + mu I) delta = B on lanes 0..6: Gauss-Jordan, multipliers broadcast from the pivot column's lane
+        double a[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[r] = col[r] + (r == lane ? mu : 0.0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bmax = fmax(bmax, fabs(mo2_bcast(col[r], 6)));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const double ip = 1.0 / mo2_bcast(a[k], k);
+          const double ak = a[k] * ip;               // row k of this lane's column, scaled
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            if (r == k) continue;
+            const double m = mo2_bcast(a[r], k);     // element (r, k) of the pivot column
+            a[r] -= m * ak;
+          }
+          a[k] = ak;
+        }
+        double delta[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) delta[r] = mo2_bcast(a[r], 6);
+        double Tc[12], Tn[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tc[i] = s_T[i];
+        d_se3_exp_mul(delta, Tc, Tn);                // prediction.add: exp(delta) * T (every lane of the wave, same values)
+        if (lane < 12) {
+          double v = Tn[0];
+#pragma unroll
+          for (int i = 1; i < 12; ++i) v = lane == i ? Tn[i] : v;
+          s_Tn[lane] = v;
+        }
+      }
+      __syncthreads();
+      sweep(s_Tn, false);
+      __syncthreads();
+      const double new_chi2 = total(27), new_max = total_max(28);
+      if (isnan(new_chi2)) { status = 2; stop = true; break; }      // the reference throws here
+      rho = chi2 - new_chi2;
+      if (rho > 0) {
+        if (tid < 12) s_T[tid] = s_Tn[tid];
+        chi2 = new_chi2; max_err = new_max;
+        bmax = __shfl(bmax, 0, 64);
+        // |B|_inf of the step just taken: wave 0 has it; the other waves learn the decision through LDS
+        if (tid == 0) s_wcnt[0] = bmax <= 1e-10 ? 1 : 0;
+        load_system();
+        const double q = 2 * rho - 1, sc = 1 - q * q * q;
+        mu *= fmax(1. / 3., sc);
+        nu = 2.; trial = 0;
+        __syncthreads();
+        stop = s_wcnt[0] != 0;
+      } else {
+        mu *= nu; nu *= 2.; ++trial;
+        if (trial == 5) stop = true;
+      }
+    } while (!(rho > 0 || stop));
+  }
+  __syncthreads();
+  if (tid < 12) T_io[12 * slot + tid] = s_T[tid];
+  if (tid == 0) {
+    svs_pose_opt_stats st;
+    st.initial_chi2 = initial_chi2; st.chi2 = chi2; st.max_err = max_err; st.num_obs = num_obs; st.status = status;
+    stats[slot] = st;
+  }
+}
+
+}  // namespace
 // ---- StereoFrontend::processMatchedPoints (stereo_frontend.cpp:834-974), data-parallel part ---------------------------
 // One workgroup per stream sweeps the matcher records: reprojection gate at the refined pose, the 2x2 / 3x3 / per-level
 // counters (LDS atomics), the pyramid-level positions the host needs for point_tree and the draw lists, and the
 // track-length sum.  The host-side remainder (building new_point_list / track_point_list) walks the flags.
 namespace {
 __global__ __launch_bounds__(256) void gate_matched_kernel(const svs_match_result *__restrict__ res, const svs_candidate_point *__restrict__ pts, int n,
-                                                           size_t res_b, size_t pts_b, int n_new, svs_cam cam, const double *__restrict__ Tarr,
-                                                           float mre, svs_gated_point *__restrict__ out, size_t out_b, svs_point_stats *__restrict__ stats) {
+                                                           size_t res_b, size_t pts_b, int n_new, const int32_t *__restrict__ n_new_arr, svs_cam cam,
+                                                           const double *__restrict__ Tarr, float mre, svs_gated_point *__restrict__ out, size_t out_b,
+                                                           svs_point_stats *__restrict__ stats) {
   __shared__ int s_cnt[18];          // 4 + 9 + 3 + num_track + num_obs
   __shared__ double s_sum[4];
   const int tid = threadIdx.x, slot = blockIdx.x;
+  if (n_new_arr) n_new = n_new_arr[slot];
   res += slot * res_b; pts += slot * pts_b; out += slot * out_b;
   if (tid < 18) s_cnt[tid] = 0;
   __syncthreads();
@@ -896,7 +1117,18 @@ extern "C" int svs_process_matched_points(svs_ctx *ctx, const svs_match_result *
   SVS_REQUIRE(ctx, ctx && cam && d_T && d_stats && batch >= 1 && n >= 0 && (n == 0 || (d_results && d_pts && d_gated)));
   SVS_DEVICE(ctx);
   hipLaunchKernelGGL(gate_matched_kernel, dim3(batch), dim3(256), 0, ctx->stream, d_results, d_pts, n, res_bstride, pts_bstride, n_new_records,
-                     *cam, d_T, max_reproj_error, d_gated, gated_bstride, d_stats);
+                     (const int32_t *)nullptr, *cam, d_T, max_reproj_error, d_gated, gated_bstride, d_stats);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+// the same with one record count of the new-feature lists PER STREAM, on the device (frontend.hip: streams carry different candidate lists)
+int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n, size_t res_bstride,
+                                   size_t pts_bstride, const int32_t *d_n_new_records, const svs_cam *cam, const double *d_T, float max_reproj_error,
+                                   svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats, int batch) {
+  SVS_REQUIRE(ctx, ctx && cam && d_T && d_stats && d_n_new_records && batch >= 1 && n >= 0 && (n == 0 || (d_results && d_pts && d_gated)));
+  SVS_DEVICE(ctx);
+  hipLaunchKernelGGL(gate_matched_kernel, dim3(batch), dim3(256), 0, ctx->stream, d_results, d_pts, n, res_bstride, pts_bstride, 0, d_n_new_records, *cam, d_T,
+                     max_reproj_error, d_gated, gated_bstride, d_stats);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
@@ -905,7 +1137,12 @@ extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, 
                                const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch) {
   SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && batch >= 1 && n >= 0 && (n == 0 || d_results));
   SVS_DEVICE(ctx);
-  hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
+  // the record-walking kernel stays for candidate lists whose index list does not fit LDS, and as the A/B partner ("mo_legacy")
+  if ((size_t)n * sizeof(int) <= 48 * 1024 && !ctx->mo_legacy)
+    hipLaunchKernelGGL(motion_only_fused_kernel, dim3(batch), dim3(MO2_THREADS), (size_t)std::max(n, 1) * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam,
+                       *prm, d_T_io, d_stats);
+  else
+    hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -607,6 +607,47 @@ __global__ __launch_bounds__(256) void pointcloud_full_kernel(M44 TQ, const floa
   reinterpret_cast<float4 *>(cloud)[(size_t)v * so + u] = o;
 }
 
+// computeDensePointCloudGpu with the pose on the device: TQ = [T^-1; 0 0 0 1] * Q in double, every product sum in ascending k (what
+// Eigen's 4x4 product does and the oracle pins), narrowed to float (GpuMatrix4::set), then the kernel above per stream
+__global__ __launch_bounds__(256) void pointcloud_full_pose_kernel(const double *__restrict__ Tarr, svs_cam cam, const float *__restrict__ disp, int w, int h, int si,
+                                                                   size_t disp_b, int so, size_t cloud_b, int factor, float *__restrict__ cloud) {
+  const int slot = blockIdx.z;
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= w || v >= h) return;
+  double T[12], Ti[16];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * 12 + k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) Ti[4 * r + 3] = -(Ti[4 * r] * T[3] + Ti[4 * r + 1] * T[7] + Ti[4 * r + 2] * T[11]);
+  Ti[12] = 0; Ti[13] = 0; Ti[14] = 0; Ti[15] = 1;
+  const double Q[16] = {1, 0, 0, -cam.cx, 0, 1, 0, -cam.cy, 0, 0, 0, cam.f, 0, 0, 1.0 / cam.b, 0};      // stereo_camera.cpp:24-34
+  float TQ[16];                                                                                          // column-major, like GpuMatrix4
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double s = Ti[4 * r] * Q[c];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) s += Ti[4 * r + k] * Q[4 * k + c];
+      TQ[4 * c + r] = (float)s;
+    }
+  const float d = disp[slot * disp_b + (size_t)v * si + u * factor] * factor;     // row not scaled: .cu:97-98 quirk kept
+  float4 o;
+  if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
+  else {
+    const float q[4] = {(float)u, (float)v, d, 1.f};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = q[0] * TQ[i] + q[1] * TQ[4 + i] + q[2] * TQ[8 + i] + q[3] * TQ[12 + i];
+    o = make_float4(r[0] / r[3], r[1] / r[3], r[2] / r[3], 1.f);
+  }
+  reinterpret_cast<float4 *>(cloud)[slot * cloud_b + (size_t)v * so + u] = o;
+}
+
 // ---- CUDA-build preprocessing (frame_grabber.cpp:291-313): f32 level 0, f32 pyrDown, REPLICATE derivatives ---------
 __global__ __launch_bounds__(256) void convert_f32_kernel(const uint8_t *__restrict__ src, int w, int h, int ss, size_t s_b,
                                                           float *__restrict__ dst, int ds, size_t d_b) {
@@ -745,6 +786,16 @@ extern "C" int svs_pointcloud_full(svs_ctx *ctx, const float *h_TQ, const float 
   for (int i = 0; i < 16; ++i) TQ.m[i] = h_TQ[i];
   hipLaunchKernelGGL(pointcloud_full_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, ctx->stream, TQ, d_disp, w, h,
                      stride_in, stride_out, factor, d_cloud4);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+extern "C" int svs_pointcloud_full_pose(svs_ctx *ctx, const double *d_T, const svs_cam *cam, const float *d_disp, int disp_stride, size_t disp_bstride, int w, int h,
+                                        int stride_out, size_t cloud_bstride, int factor, float *d_cloud4, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_T && cam && d_disp && d_cloud4 && w > 0 && h > 0 && factor >= 1 && batch >= 1 && stride_out >= w);
+  SVS_DEVICE(ctx);
+  hipLaunchKernelGGL(pointcloud_full_pose_kernel, dim3(div_up(w, 64), div_up(h, 4), batch), dim3(256), 0, ctx->stream, d_T, *cam, d_disp, w, h, disp_stride,
+                     disp_bstride, stride_out, cloud_bstride, factor, d_cloud4);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -105,7 +105,7 @@ __global__ void match_pose_kernel(svs_match_args A, double *__restrict__ out) {
   const int kf = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
   if (kf >= A.n_kf) return;
   double kfT[12], Tcw[12], Twk[12], t0[12], t1[12];
-  for (int i = 0; i < 12; ++i) { kfT[i] = A.d_kfs[kf].T_anchor_from_w[i]; Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
+  for (int i = 0; i < 12; ++i) { kfT[i] = A.d_kfs[(size_t)slot * A.kf_bstride + kf].T_anchor_from_w[i]; Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
   d_pose_inv(kfT, t0);
   d_pose_mul(Tcw, t0, t1);
   double *o = out + ((size_t)slot * A.n_kf + kf) * 24;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   const svs_match_args &A = M.a;
   const int ip = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   if (ip >= A.n_pts) return;
-  const svs_candidate_point ap = A.d_pts[(size_t)slot * A.n_pts + ip];
+  const svs_candidate_point ap = A.d_pts[(size_t)slot * A.pts_bstride + ip];
   PointPred pr;
   pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0;
   pr.inv[0] = pr.inv[1] = pr.inv[2] = pr.inv[3] = 0; pr.key_uv[0] = ap.anchor_obs_pyr[0]; pr.key_uv[1] = ap.anchor_obs_pyr[1];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
   const int slot = blockIdx.y;
   if (ip >= A.n_pts) return;                       // wave-uniform
   const PointPred pp = M.pred[(size_t)slot * A.n_pts + __builtin_amdgcn_readfirstlane(ip)];      // wave-uniform record
-  svs_match_result *o = &out[(size_t)slot * A.n_pts + ip];
+  svs_match_result *o = &out[(size_t)slot * A.out_bstride + ip];
   const int R = A.search_radius;
   const int init_dist = A.thr_mean * A.thr_mean * 64;
   int status = pp.status;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
       // are read with scalar loads
       const int kfi = __builtin_amdgcn_readfirstlane(pp.kfi);
       const int lvl = __builtin_amdgcn_readfirstlane(pp.lvl);
-      const svs_keyframe *kfp = A.d_kfs + kfi;
+      const svs_keyframe *kfp = A.d_kfs + (size_t)slot * A.kf_bstride + kfi;
       const svs_cam cam = A.cam_vec[lvl];
       const int ui = pp.ui, vi = pp.vi;
       // ---- warpAffinve: 10x10 patch, lanes take pixels lane and lane+64 -------------------
@@ -368,6 +368,9 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   SVS_REQUIRE(ctx, d_out && a->d_pts && a->d_kfs);
   MatchParams M;
   M.a = *a;
+  if (!M.a.pts_bstride) M.a.pts_bstride = (size_t)a->n_pts;
+  if (!M.a.out_bstride) M.a.out_bstride = (size_t)a->n_pts;
+  SVS_REQUIRE(ctx, M.a.pts_bstride >= (size_t)a->n_pts && M.a.out_bstride >= (size_t)a->n_pts);
   M.fv = svs_fast_view_internal(f);
   SVS_REQUIRE(ctx, M.fv.n_levels >= 1 && a->n_kf >= 1);
   // the per-call tables live in the context (one buffer: relative poses per (stream, keyframe), then the predictions per point)
@@ -378,7 +381,7 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   double *kf_T = static_cast<double *>(buf);
   M.kf_T = kf_T;
   M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + kf_bytes);
-  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, *a, kf_T);
+  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M.a, kf_T);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
   SVS_LAUNCH_CHECK(ctx);

@@ -75,7 +75,7 @@ class BaStats(C.Structure):
                 ("lambda_final", C.c_double)]
 
 
-MATCH_OK, MATCH_NO_ANCHOR, MATCH_BORDER, MATCH_DEPTH, MATCH_TEXTURE, MATCH_NONE, MATCH_NO_DISP = range(7)
+MATCH_OK, MATCH_NO_ANCHOR, MATCH_BORDER, MATCH_DEPTH, MATCH_TEXTURE, MATCH_NONE, MATCH_NO_DISP, MATCH_SKIPPED = range(8)
 
 
 def level_cams(f, cx, cy, b, w, h, levels=3):
@@ -101,7 +101,7 @@ class StereoParams(C.Structure):
 class PoseOptParams(C.Structure):
     """svs_pose_opt_params: PoseOptimizerParams (pose_optimizer.h:36-58)."""
     _fields_ = [("robust_kernel", C.c_int32), ("num_iter", C.c_int32), ("kernel_param", C.c_double),
-                ("initial_mu", C.c_double), ("tau", C.c_double)]
+                ("initial_mu", C.c_double), ("tau", C.c_double), ("min_obs", C.c_int32), ("pad_", C.c_int32)]
 
     @classmethod
     def reference(cls):

@@ -571,59 +571,153 @@ class DenseTrackerGpu:
 
 
 class StereoFrontend:
-    """StereoFrontend::processFrame / processFirstFrame (stereo_frontend.h:88-95) for one camera stream, host arrays in and out:
-    one library call per frame (svs_frontend_*), no host round trip between the stages."""
+    """StereoFrontend::processFrame / processFirstFrame (stereo_frontend.h:88-95): one library call per frame (svs_frontend_*), no host round
+    trip between the stages.  n_streams == 1: host arrays in and out, the way stereo_slam calls it.  n_streams > 1: that many independent front
+    ends whose stages run as one launch each, frames in device memory (torch tensors), results fetched per stream."""
 
-    def __init__(self, ctx, cam, max_points=4096, max_keyframes=8, params=None):
-        self.ctx, self.cam = ctx, cam
+    def __init__(self, ctx, cam, max_points=4096, max_keyframes=8, params=None, n_streams=1):
+        self.ctx, self.cam, self.n_streams = ctx, cam, n_streams
         self.params = params or capi.FrontendParams.reference()
         camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
         self.h = C.c_void_p()
-        ctx.check(ctx.lib.svs_frontend_create(ctx.h, C.byref(camc), C.byref(self.params), max_points, max_keyframes, C.byref(self.h)))
+        ctx.check(ctx.lib.svs_frontend_create_batch(ctx.h, C.byref(camc), C.byref(self.params), max_points, max_keyframes, n_streams, C.byref(self.h)))
         ctx.children.add(self)
-        self.n_points = 0
+        self.n_points = [0] * n_streams
 
     @staticmethod
     def _img(a, dtype):
         return None if a is None else np.ascontiguousarray(a, dtype)
 
-    def processFirstFrame(self, left, right=None, disp=None):
+    @staticmethod
+    def _ptr(a):
+        return a.ctypes.data if a is not None else None
+
+    def processFirstFrame(self, left=None, right=None, disp=None):
         left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
-        w = left.shape[1]
-        self.ctx.check(self.ctx.lib.svs_frontend_first_frame(self.h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w,
-                                                             disp.ctypes.data if disp is not None else None, w))
+        w = self.cam["w"]
+        self.ctx.check(self.ctx.lib.svs_frontend_first_frame(self.h, self._ptr(left), w, self._ptr(right), w, self._ptr(disp), w))
 
-    def keepKeyframe(self, slot, T_kf_from_w):
+    def keepKeyframe(self, slot, T_kf_from_w, stream=0):
         T = np.ascontiguousarray(T_kf_from_w, np.float64).reshape(12)
-        self.ctx.check(self.ctx.lib.svs_frontend_keep_keyframe(self.h, slot, T.ctypes.data))
+        self.ctx.check(self.ctx.lib.svs_frontend_keep_keyframe_of(self.h, stream, slot, T.ctypes.data))
 
-    def setCandidates(self, pts, n_new_records):
+    def setCandidates(self, pts, n_new_records, stream=0):
+        self.setCandidateLists(pts, [int(n_new_records), len(pts)], stream)
+
+    def setCandidateLists(self, pts, group_end, stream=0):
+        """matchAndTrack's lists in the order it walks them: group_end[0] = end of newpoint_map[actkey], then one end per neighbour (strength order),
+        last = len(pts) = end of the neighbourhood's point_list"""
         pts = np.ascontiguousarray(pts, CANDIDATE_DTYPE)
-        self.ctx.check(self.ctx.lib.svs_frontend_set_candidates(self.h, pts.ctypes.data, len(pts), int(n_new_records)))
-        self.n_points = len(pts)
+        ge = np.ascontiguousarray(group_end, np.int32)
+        self.ctx.check(self.ctx.lib.svs_frontend_set_candidates_grouped(self.h, stream, pts.ctypes.data, len(pts), ge.ctypes.data, len(ge)))
+        self.n_points[stream] = len(pts)
+
+    def prefetchFrame(self, left, right=None, disp=None):
+        left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
+        w = self.cam["w"]
+        self._keep = (left, right, disp)
+        self.ctx.check(self.ctx.lib.svs_frontend_prefetch_frame(self.h, self._ptr(left), w, self._ptr(right), w, self._ptr(disp), w))
+
+    def submitFrame(self, left, T_cur_from_actkey, T_actkey_from_w, right=None, disp=None):
+        left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
+        w = self.cam["w"]
+        Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+        Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(12)
+        self.ctx.check(self.ctx.lib.svs_frontend_submit_frame(self.h, self._ptr(left), w, self._ptr(right), w, self._ptr(disp), w, Tc.ctypes.data, Ta.ctypes.data, 1, 1))
+
+    def waitFrame(self):
+        res = capi.FrameResult()
+        m = np.zeros(self.n_points[0], MATCH_RESULT_DTYPE)
+        g = np.zeros(self.n_points[0], GATED_POINT_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_wait_frame(self.h, C.byref(res), m.ctypes.data, g.ctypes.data))
+        return res, m, g
 
     def processFrame(self, left, T_cur_from_actkey, T_actkey_from_w, right=None, disp=None):
-        """returns (FrameResult, MATCH_RESULT_DTYPE[n], GATED_POINT_DTYPE[n])"""
+        """returns (FrameResult, MATCH_RESULT_DTYPE[n], GATED_POINT_DTYPE[n]); left=None: the frame was prefetched"""
         left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
-        w = left.shape[1]
+        w = self.cam["w"]
         Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
         Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(12)
         res = capi.FrameResult()
-        m = np.zeros(self.n_points, MATCH_RESULT_DTYPE)
-        g = np.zeros(self.n_points, GATED_POINT_DTYPE)
-        self.ctx.check(self.ctx.lib.svs_frontend_process_frame(self.h, left.ctypes.data, w, right.ctypes.data if right is not None else None, w,
-                                                               disp.ctypes.data if disp is not None else None, w, Tc.ctypes.data, Ta.ctypes.data,
+        m = np.zeros(self.n_points[0], MATCH_RESULT_DTYPE)
+        g = np.zeros(self.n_points[0], GATED_POINT_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_process_frame(self.h, self._ptr(left), w, self._ptr(right), w, self._ptr(disp), w, Tc.ctypes.data, Ta.ctypes.data,
                                                                C.byref(res), m.ctypes.data, g.ctypes.data))
         return res, m, g
 
-    def cloud_host(self, level):
-        """reference cloud (quarter grid) the last frame left for the next one"""
+    # ---- all streams, frames in device memory
+    def _frames(self, left, right, disp):
+        """torch tensors [n_streams][h][stride] (u8, u8, f32) -> svs_frames_dev (None = written in place through inputView)"""
+        if left is None:
+            return None
+        fr = capi.FramesDev()
+        fr.d_left, fr.lstride, fr.l_bstride = left.data_ptr(), left.stride(1), left.stride(0)
+        if right is not None:
+            fr.d_right, fr.rstride, fr.r_bstride = right.data_ptr(), right.stride(1), right.stride(0)
+        if disp is not None:
+            fr.d_disp, fr.dstride, fr.d_bstride = disp.data_ptr(), disp.stride(1), disp.stride(0)
+        return fr
+
+    def inputView(self):
+        """(left, right, disp): device pointer, row stride, stream stride of the buffers the next frames may be written into"""
+        p = [C.c_void_p() for _ in range(3)]
+        st = [C.c_int32() for _ in range(3)]
+        bs = [C.c_size_t() for _ in range(3)]
+        self.ctx.check(self.ctx.lib.svs_frontend_input_view(self.h, C.byref(p[0]), C.byref(st[0]), C.byref(bs[0]), C.byref(p[1]), C.byref(st[1]), C.byref(bs[1]),
+                                                            C.byref(p[2]), C.byref(st[2]), C.byref(bs[2])))
+        return [(p[i].value, st[i].value, bs[i].value) for i in range(3)]
+
+    def processFirstFrames(self, left=None, right=None, disp=None):
+        fr = self._frames(left, right, disp)
+        self.ctx.check(self.ctx.lib.svs_frontend_first_frames(self.h, C.byref(fr) if fr is not None else None))
+
+    def processFrames(self, T_cur_from_actkey, T_actkey_from_w, left=None, right=None, disp=None):
+        """asynchronous; poses [n_streams][12]"""
+        fr = self._frames(left, right, disp)
+        Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(self.n_streams, 12)
+        Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(self.n_streams, 12)
+        self.ctx.check(self.ctx.lib.svs_frontend_process_frames(self.h, C.byref(fr) if fr is not None else None, Tc.ctypes.data, Ta.ctypes.data))
+
+    def results(self, stream=0):
+        res = capi.FrameResult()
+        m = np.zeros(self.n_points[stream], MATCH_RESULT_DTYPE)
+        g = np.zeros(self.n_points[stream], GATED_POINT_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_results(self.h, stream, C.byref(res), m.ctypes.data, g.ctypes.data))
+        return res, m, g
+
+    def poses(self):
+        T = np.zeros((self.n_streams, 12))
+        ok = np.zeros(self.n_streams, np.int32)
+        self.ctx.check(self.ctx.lib.svs_frontend_poses(self.h, T.ctypes.data, ok.ctypes.data))
+        return T.reshape(-1, 3, 4), ok
+
+    def recomputeCloud(self, T_cur_from_actkey):
+        T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+        self.ctx.check(self.ctx.lib.svs_frontend_recompute_cloud(self.h, T.ctypes.data))
+
+    def cloud_host(self, level, stream=0):
+        """reference cloud (quarter grid; full resolution in the CUDA build) the last frame left for the next one"""
         clouds = (C.c_void_p * 3)()
-        self.ctx.check(self.ctx.lib.svs_frontend_device_view(self.h, None, None, None, clouds, None))
-        w, h = (self.cam["w"] >> level) // 4, (self.cam["h"] >> level) // 4
+        self.ctx.check(self.ctx.lib.svs_frontend_device_view(self.h, stream, None, None, None, clouds, None))
+        q = 1 if self.params.cuda_build else 4
+        w, h = (self.cam["w"] >> level) // q, (self.cam["h"] >> level) // q
         out = np.zeros((h, w, 4), np.float32)
         self.ctx.call("svs_memcpy_d2h", out.ctypes.data, clouds[level], out.nbytes)
         return out
+
+    def fast_handle(self):
+        f = C.c_void_p()
+        self.ctx.check(self.ctx.lib.svs_frontend_device_view(self.h, 0, None, None, None, None, C.byref(f)))
+        return f
+
+    def corners(self, stream=0, level=0, cap=8192):
+        """corner list of the last frame (quadtree insertion order), per-cell counts, emit thresholds, persistent thresholds"""
+        f = self.fast_handle()
+        xy = np.zeros((cap, 2), np.int16)
+        n = C.c_int32()
+        cc, et, ts = np.zeros(64, np.int32), np.zeros(64, np.int32), np.zeros(64, np.int32)
+        self.ctx.check(self.ctx.lib.svs_fast_download(f, stream, level, xy.ctypes.data, cap, C.byref(n), cc.ctypes.data, et.ctypes.data, ts.ctypes.data))
+        return xy[:n.value].copy(), cc, et, ts
 
     def close(self):
         if self.h and self.ctx.h:

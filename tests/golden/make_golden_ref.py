@@ -85,6 +85,32 @@ for l in range(3):
     out[f"cloud_l{l}"] = fr["clouds"][l]
 np.savez_compressed(os.path.join(HERE, "ref_frame.npz"), **out)
 
+# ---- the reference's CUDA build of processFrame (denseTrackingGpu on the emulated kernels, matcher radius 4, computeDensePointCloudGpu) on a 320 x 240 frame:
+# inputs come from the seeded renderer (tests/test_gpu_ref_frame.py::_cuda_case builds the same case), only the reference's outputs are stored
+cam_small = dict(f=591.524 / 2, cx=159.5, cy=119.5, b=0.07468, w=320, h=240)
+cc = synth.dense_full_case(cam=cam_small, seed=2013, step=0.02, yaw_deg=0.2)
+camsc = level_cams(cam_small["f"], cam_small["cx"], cam_small["cy"], cam_small["b"], cam_small["w"], cam_small["h"])
+scc = synth.Scene(2013)
+trajc = synth.trajectory(5, step=0.02, yaw_deg=0.2)
+img_cc, disp_cc = scc.render(cc["cam"], trajc[4], seed=2014)
+assert np.array_equal(img_cc, cc["img_cur"])
+rngc = np.random.default_rng(9)
+ptsc = synth.candidate_points(rngc, cc["cam"], np.maximum(cc["disp_prev"], 0), I34, (260, 120, 40))
+rngc.shuffle(ptsc)
+ptsc["point_id"] = np.arange(len(ptsc))
+list_ofc = np.where(rngc.random(len(ptsc)) < 0.2, 0, -1).astype(np.int32)
+fpc, _, _ = O.preprocess_gpu_sem(cc["img_prev"])
+fcc, dxc, dyc = O.preprocess_gpu_sem(cc["img_cur"])
+cloud_prevc = O.ref_pointcloud_gpu(cc["disp_prev"], synth.level_cams(cc["cam"]), I34)
+frc = O.ref_process_frame([O.build_pyramid(cc["img_prev"])], [I34.reshape(12)], 0, [], camsc, ptsc, list_ofc, I34, cloud_prevc, fpc, O.build_pyramid(cc["img_cur"]), fcc, dxc, dyc,
+                          disp_cc, cuda_build=True)
+assert frc["ok"] and sum(len(x) for x in frc["lines"]) > 40
+out = dict(list_of=list_ofc, img_cur_checksum=np.array([int(cc["img_cur"].astype(np.int64).sum())]), T=frc["T"], av_track_length=np.array([frc["av_track_length"]]))
+for l in range(3):
+    out[f"lines_l{l}"] = frc["lines"][l]
+    out[f"cloud_l{l}"] = frc["clouds"][l][::4] if l == 0 else frc["clouds"][l]
+np.savez_compressed(os.path.join(HERE, "ref_frame_cuda.npz"), **out)
+
 # ---- calcFastMotionOnly and processMatchedPoints on the matcher's own output ---------------------------------------------------------
 camc = Cam(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
 res = np.zeros(len(pts), MATCH_RESULT_DTYPE)

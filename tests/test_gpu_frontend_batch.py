@@ -1,0 +1,240 @@
+"""The batched / asynchronous forms of the one-call front end (svs_frontend_create_batch, *_frames, submit / wait / prefetch) and its configuration
+switches (use_n_levels_in_frontent = 2, fewer than 20 matches, unkept keyframe slots).  The reference point is the blocking one-stream call
+svs_frontend_process_frame, which tests/test_gpu_ref_frame.py holds against the reference's own processFrame: every other way of driving the same
+kernels must return the same bits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+I34 = np.hstack([np.eye(3), np.zeros((3, 1))])
+
+
+def _streams(n, block_matching=False):
+    """n camera streams with their own scene position, keyframe, previous and current frame, candidate list and motion guess"""
+    from scavislam_amd import synth
+    cam = synth.CAM_NEWCOLLEGE
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8 + n)
+    out = []
+    for b in range(n):
+        kf_i, prev_i, cur_i = b, b + 3, b + 4
+        fr = {name: synth.render_stereo(sc, cam, traj[i], seed=10 * b + s) for name, i, s in (("kf", kf_i, 1), ("prev", prev_i, 2), ("cur", cur_i, 3))}
+        rng = np.random.default_rng(7 + b)
+        pts = synth.candidate_points(rng, cam, np.maximum(fr["kf"][2], 0), traj[kf_i], (400 - 60 * b, 200, 60 + 10 * b))
+        T_guess = synth.pose_mul(synth.pose(synth.so3_exp(np.array([0.001, -0.002, 0.0005]) * (b + 1)), np.array([0.004, 0.0, -0.004])),
+                                 synth.pose_mul(traj[cur_i], synth.pose_inv(traj[prev_i])))
+        out.append(dict(fr=fr, pts=pts, n_new=150 + 20 * b, T_guess=T_guess, T_kf=traj[kf_i], T_act=traj[prev_i]))
+    return cam, out
+
+
+def _single(ctx, cam, s, params, prefetch=False, split=False):
+    from scavislam_amd.frontend import StereoFrontend
+    bm = bool(params.use_block_matching)
+    kw = (lambda n: dict(right=s["fr"][n][1])) if bm else (lambda n: dict(disp=s["fr"][n][2]))
+    fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=params)
+    fe.processFirstFrame(s["fr"]["kf"][0], **kw("kf"))
+    fe.keepKeyframe(0, s["T_kf"])
+    if prefetch:
+        fe.prefetchFrame(s["fr"]["prev"][0], **kw("prev"))
+        fe.processFirstFrame()
+    else:
+        fe.processFirstFrame(s["fr"]["prev"][0], **kw("prev"))
+    fe.setCandidates(s["pts"], s["n_new"])
+    if prefetch:
+        fe.prefetchFrame(s["fr"]["cur"][0], **kw("cur"))
+        out, m, g = fe.processFrame(None, s["T_guess"], s["T_act"])
+    elif split:
+        fe.submitFrame(s["fr"]["cur"][0], s["T_guess"], s["T_act"], **kw("cur"))
+        out, m, g = fe.waitFrame()
+    else:
+        out, m, g = fe.processFrame(s["fr"]["cur"][0], s["T_guess"], s["T_act"], **kw("cur"))
+    clouds = [fe.cloud_host(l) for l in range(3)]
+    corners = [fe.corners(0, l)[0] for l in range(params.n_levels)]
+    fe.close()
+    return out, m, g, clouds, corners
+
+
+def _same(a, b, what):
+    oa, ma, ga, ca, ka = a
+    ob, mb, gb, cb, kb = b
+    assert np.array_equal(np.array(oa.T_cur_from_actkey), np.array(ob.T_cur_from_actkey)), what
+    assert oa.dense_passes == ob.dense_passes and oa.n_matched == ob.n_matched and oa.tracking_ok == ob.tracking_ok, what
+    assert ma.tobytes() == mb.tobytes() and ga.tobytes() == gb.tobytes(), what
+    assert bytes(oa.point_stats) == bytes(ob.point_stats) and bytes(oa.pose_stats) == bytes(ob.pose_stats), what
+    for l in range(3):
+        assert np.array_equal(ca[l], cb[l]), (what, l)
+    for x, y in zip(ka, kb):
+        assert np.array_equal(x, y), what
+
+
+@pytest.mark.parametrize("block_matching", [False, True])
+def test_batch_of_streams_equals_one_stream_calls(gpu_ctx, block_matching):
+    """three streams with different frames, keyframes, candidate lists (different lengths) and poses through svs_frontend_process_frames (frames in
+    device memory, one launch per stage) == each stream through its own blocking one-stream call"""
+    import torch
+    from scavislam_amd import capi
+    from scavislam_amd.frontend import StereoFrontend
+    ctx, stream = gpu_ctx
+    cam, S = _streams(3, block_matching)
+    prm = capi.FrontendParams.reference(use_block_matching=block_matching)
+    singles = [_single(ctx, cam, s, prm) for s in S]
+    B, h, w = len(S), cam["h"], cam["w"]
+    fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=prm, n_streams=B)
+    dev = torch.device("cuda", 0)
+
+    def frames(name):
+        with torch.cuda.stream(stream):
+            left = torch.as_tensor(np.stack([s["fr"][name][0] for s in S])).to(dev)
+            right = torch.as_tensor(np.stack([s["fr"][name][1] for s in S])).to(dev) if block_matching else None
+            disp = None if block_matching else torch.as_tensor(np.stack([s["fr"][name][2] for s in S]).astype(np.float32)).to(dev)
+        stream.synchronize()
+        return dict(left=left, right=right, disp=disp)
+
+    fe.processFirstFrames(**frames("kf"))
+    for b, s in enumerate(S):
+        fe.keepKeyframe(0, s["T_kf"], stream=b)
+    fe.processFirstFrames(**frames("prev"))
+    for b, s in enumerate(S):
+        fe.setCandidates(s["pts"], s["n_new"], stream=b)
+    cur = frames("cur")
+    fe.processFrames(np.stack([s["T_guess"].reshape(12) for s in S]), np.stack([s["T_act"].reshape(12) for s in S]), **cur)
+    T_all, ok_all = fe.poses()
+    for b in range(B):
+        out, m, g = fe.results(b)
+        clouds = [fe.cloud_host(l, stream=b) for l in range(3)]
+        corners = [fe.corners(b, l)[0] for l in range(3)]
+        _same((out, m, g, clouds, corners), singles[b], f"stream {b}")
+        assert np.array_equal(T_all[b].reshape(12), np.array(out.T_cur_from_actkey)) and ok_all[b] == 1
+        assert out.n_points == len(S[b]["pts"]) and out.n_matched > 100
+    # in place: the next frames written straight into the front end's own buffers (no copy kernel), same result as passing pointers
+    fe2 = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=prm, n_streams=B)
+
+    def put(name):
+        (pl, sl, bl), (pr, sr, br), (pd, sd, bd) = fe2.inputView()
+        for b, s in enumerate(S):
+            L, R, D = s["fr"][name]
+            Lp = np.zeros((h, sl), np.uint8); Lp[:, :w] = L
+            ctx.call("svs_memcpy_h2d", pl + b * bl, Lp.ctypes.data, Lp.nbytes)
+            if block_matching:
+                Rp = np.zeros((h, sr), np.uint8); Rp[:, :w] = R
+                ctx.call("svs_memcpy_h2d", pr + b * br, Rp.ctypes.data, Rp.nbytes)
+            else:
+                Dp = np.zeros((h, sd), np.float32); Dp[:, :w] = D
+                ctx.call("svs_memcpy_h2d", pd + 4 * b * bd, Dp.ctypes.data, Dp.nbytes)
+        ctx.sync()
+
+    put("kf"); fe2.processFirstFrames()
+    for b, s in enumerate(S):
+        fe2.keepKeyframe(0, s["T_kf"], stream=b)
+    put("prev"); fe2.processFirstFrames()
+    for b, s in enumerate(S):
+        fe2.setCandidates(s["pts"], s["n_new"], stream=b)
+    put("cur")
+    fe2.processFrames(np.stack([s["T_guess"].reshape(12) for s in S]), np.stack([s["T_act"].reshape(12) for s in S]))
+    for b in range(B):
+        out, m, g = fe2.results(b)
+        _same((out, m, g, [fe2.cloud_host(l, stream=b) for l in range(3)], [fe2.corners(b, l)[0] for l in range(3)]), singles[b], f"in place, stream {b}")
+    fe.close(); fe2.close()
+
+
+def test_prefetch_and_split_call_equal_blocking_call(gpu_ctx):
+    """svs_frontend_prefetch_frame (upload on the copy stream) + process_frame(NULL), and submit_frame / wait_frame, return what the blocking call returns;
+    a three-frame sequence with the next frame prefetched while the current one is in flight keeps doing so."""
+    from scavislam_amd import capi, synth
+    from scavislam_amd.frontend import StereoFrontend
+    ctx, stream = gpu_ctx
+    cam, S = _streams(1)
+    prm = capi.FrontendParams.reference()
+    ref = _single(ctx, cam, S[0], prm)
+    _same(_single(ctx, cam, S[0], prm, prefetch=True), ref, "prefetched")
+    _same(_single(ctx, cam, S[0], prm, split=True), ref, "submit / wait")
+    # sequence: frame k+1 is prefetched between submit(k) and wait(k)
+    sc = synth.Scene(2011)
+    traj = synth.trajectory(8)
+    frames = [sc.render(cam, traj[i], seed=i) for i in range(5)]
+    rng = np.random.default_rng(3)
+    pts = synth.candidate_points(rng, cam, np.maximum(frames[0][1], 0), traj[0], (300, 150, 50))
+    results = {}
+    for mode in ("blocking", "overlapped"):
+        fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=2, params=prm)
+        fe.processFirstFrame(frames[0][0], disp=frames[0][1])
+        fe.keepKeyframe(0, traj[0])
+        fe.setCandidates(pts, 100)
+        T, seq = I34.copy(), []
+        if mode == "overlapped":
+            fe.prefetchFrame(frames[1][0], disp=frames[1][1])
+        for k in range(1, 5):
+            if mode == "blocking":
+                out, m, g = fe.processFrame(frames[k][0], T, traj[0], disp=frames[k][1])
+            else:
+                fe.submitFrame(None, T, traj[0])
+                if k + 1 < 5:
+                    fe.prefetchFrame(frames[k + 1][0], disp=frames[k + 1][1])
+                out, m, g = fe.waitFrame()
+            T = np.array(out.T_cur_from_actkey).reshape(3, 4)
+            seq.append((T.copy(), m.tobytes(), out.dense_passes))
+        results[mode] = seq
+        fe.close()
+    for a, b in zip(results["blocking"], results["overlapped"]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+    assert np.abs(results["blocking"][-1][0] - I34).max() > 1e-3
+
+
+def test_two_front_end_levels(gpu_ctx):
+    """use_n_levels_in_frontent = 2 (the reference's code default, stereo_frontend.cpp:68): FAST and the matcher run on levels 0 and 1 only.  Corner
+    lists of those levels equal the oracle's; candidates of levels 0 / 1 get the results of the three-level run (levels are independent), a level-2
+    candidate (the reference never creates one then) comes back unmatched."""
+    import oracle as O
+    from scavislam_amd import capi
+    ctx, stream = gpu_ctx
+    cam, S = _streams(1)
+    s = S[0]
+    three = _single(ctx, cam, s, capi.FrontendParams.reference(n_levels=3))
+    two = _single(ctx, cam, s, capi.FrontendParams.reference(n_levels=2))
+    lv = s["pts"]["anchor_level"]
+    m3, m2 = three[1], two[1]
+    assert m2[lv < 2].tobytes() == m3[lv < 2].tobytes() and (lv == 2).sum() > 10
+    assert (m2["status"][lv == 2] != 0).all()
+    pyr = O.build_pyramid(s["fr"]["cur"][0])
+    grids = [O.fastgrid_for_level(pyr[l].shape[1], pyr[l].shape[0], l) for l in range(2)]
+    for name in ("kf", "prev"):                                  # the front end's FastGrid saw two first frames (5 trials) before this one
+        p = O.build_pyramid(s["fr"][name][0])
+        for l in range(2):
+            O.fastgrid_detect_adaptively(grids[l], p[l], 5)
+    for l in range(2):
+        xy, cc, et = O.fastgrid_detect_adaptively(grids[l], pyr[l], 6)
+        assert np.array_equal(two[4][l], xy), l
+        assert np.array_equal(three[4][l], xy), l
+    assert two[0].n_matched < three[0].n_matched and two[0].tracking_ok == 1
+
+
+def test_too_few_matches_and_unkept_keyframes(gpu_ctx):
+    """matchAndTrack returns false below 20 observations, before calcFastMotionOnly (stereo_frontend.cpp:1053-1056): tracking_ok = 0 and the pose is the
+    dense tracker's.  A candidate naming a keyframe slot that was never kept is refused (it would send the matcher after a null pyramid)."""
+    from scavislam_amd import capi
+    from scavislam_amd.frontend import StereoFrontend
+    ctx, stream = gpu_ctx
+    cam, S = _streams(1)
+    s = S[0]
+    full = _single(ctx, cam, s, capi.FrontendParams.reference())
+    k = int(np.searchsorted(np.cumsum(full[1]["status"] == 0), 12)) + 1     # the first records holding 12 matches (a record's result does not depend on the others)
+    few = dict(s, pts=s["pts"][:k], n_new=min(10, k))
+    out, m, g, clouds, corners = _single(ctx, cam, few, capi.FrontendParams.reference())
+    n_ok = int((m["status"] == 0).sum())
+    assert 0 < n_ok < 20 and out.tracking_ok == 0 and out.n_matched == n_ok and out.pose_stats.status == 3
+    # the pose is what the dense tracker left: same tracker input as the full run, whose refined pose differs from it
+    out0, m0, g0, _, _ = _single(ctx, cam, dict(s, pts=s["pts"][:0], n_new=0), capi.FrontendParams.reference())
+    assert np.array_equal(np.array(out.T_cur_from_actkey), np.array(out0.T_cur_from_actkey))
+    assert not np.array_equal(np.array(out.T_cur_from_actkey), np.array(full[0].T_cur_from_actkey))
+    assert out0.n_points == 0 and out0.tracking_ok == 0
+    fe = StereoFrontend(ctx, cam, max_points=64, max_keyframes=3)
+    fe.processFirstFrame(s["fr"]["kf"][0], disp=s["fr"]["kf"][2])
+    fe.keepKeyframe(0, s["T_kf"])
+    bad = s["pts"][:8].copy()
+    bad["kf_index"][3] = 2                                        # slot 2 exists but holds nothing
+    with pytest.raises(capi.SvsError):
+        fe.setCandidates(bad, 4)
+    bad["kf_index"][3] = -1                                       # "anchor frame not in keyframe_map" is a legal candidate (matcher.cpp:336-339)
+    fe.setCandidates(bad, 4)
+    fe.close()
