@@ -110,202 +110,237 @@ def main():
         T_rel_p = synth.pose(R_rel, np.array([mrng.normal(0, 0.003), mrng.normal(0, 0.002), -step]))     # camera moves forward: points come closer
         T_prev_list.append(T_p)
         T_cur_list.append(synth.pose_mul(T_rel_p, T_p))
-    rend_kf = scene.render(cam, traj[kf_id], seed=kf_id)
     rend_prev = [scene.render(cam, T_prev_list[p], seed=100 + p) for p in range(NPAIR)]
     rend_cur = [scene.render(cam, T_cur_list[p], seed=200 + p) for p in range(NPAIR)]
     T_right = synth.pose(np.eye(3), np.array([-cam["b"], 0.0, 0.0]))      # right camera of the stereo rig (for the block matcher)
     NRIGHT = min(NPAIR, 4)
     rend_right = [scene.render(cam, synth.pose_mul(T_right, T_cur_list[p]), seed=1000 + p)[0] for p in range(NRIGHT)]
+    rend_right_prev = [scene.render(cam, synth.pose_mul(T_right, T_prev_list[p]), seed=1100 + p)[0] for p in range(NRIGHT)]
     I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
-    def build_frontend(B):
-        prev_imgs = np.stack([rend_prev[b % NPAIR][0] for b in range(B)])
-        prev_disp = np.stack([rend_prev[b % NPAIR][1] for b in range(B)])
-        cur_imgs = np.stack([rend_cur[b % NPAIR][0] for b in range(B)])
-        cur_disp = np.stack([rend_cur[b % NPAIR][1] for b in range(B)])
+    T_AB = [synth.pose_mul(T_cur_list[p], synth.pose_inv(T_prev_list[p])) for p in range(NPAIR)]      # T_B_from_A: the motion between a stream's two frames
+    n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
+    pts_of_pair = {}
 
-        prev = FramePyramid(ctx, stream, cam, batch=B)
-        cur = FramePyramid(ctx, stream, cam, batch=B)
-        kf = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
-        prev.upload(prev_imgs, prev_disp)
-        cur.upload(cur_imgs, cur_disp)
-        kf.upload(rend_kf[0][None], rend_kf[1][None])
-        prev.preprocessing()
-        kf.preprocessing()
-        fast = FastGrid(ctx, cur)
-        dtrack = DenseTracker(ctx, cur)
-        dprev = DenseTracker(ctx, prev)
-        dprev.computeDensePointCloudCpu(I34)          # reference cloud of the previous frame
-        track_args = dtrack.track_args(prev.pyr, from_u8=True)    # fused: f32 image + Sobel taps formed from the u8 pyramid
+    def candidates_from_corners(p, corners):
+        """candidate points of a stream = FAST corners of its active keyframe with their stereo depth (what addNewPoints seeds from the keyframe's
+        feature_tree, stereo_frontend.cpp:680-830): up to n_per_level per level, the rest of the quota from level 0 (2000 points)"""
+        from scavislam_amd.ctypes_types import CANDIDATE_DTYPE
+        rng = np.random.default_rng(2011 + p)
+        disp = rend_prev[p][1]
+        per_level = []
         for l in range(3):
-            track_args.d_cloud[l] = dprev.ref_dense_points[l].data_ptr()
-        rng = np.random.default_rng(2011)
-        n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
-        pts = synth.candidate_points(rng, cam, rend_kf[1], traj[kf_id], n_per_level)
-        T_kf = traj[kf_id]
-        Tc = np.stack([synth.pose_mul(T_cur_list[b % NPAIR], synth.pose_inv(T_kf)).reshape(12) for b in range(B)])
-        matcher = GuidedMatcher(ctx, cur, fast)
-        margs = matcher.prepare([(kf.pyr, 0, T_kf.reshape(12))], Tc, T_kf.reshape(12), pts)
-        T_rel = np.stack([synth.pose_mul(T_cur_list[b % NPAIR], synth.pose_inv(T_prev_list[b % NPAIR])).reshape(12) for b in range(B)])
+            xy = corners[l].astype(np.int64)
+            u0, v0 = xy[:, 0] << l, xy[:, 1] << l
+            d = disp[v0, u0]
+            keep = np.nonzero(d > 0.5)[0]
+            per_level.append((l, xy[keep], d[keep].astype(np.float64), rng.permutation(len(keep))))
+        take = [min(n_per_level[l], len(per_level[l][3])) for l in range(3)]
+        take[0] = min(len(per_level[0][3]), take[0] + (args.points - sum(take)))
+        rows = []
+        for (l, xy, d, perm), n in zip(per_level, take):
+            sel = perm[:n]
+            s_ = float(1 << l)
+            u0, v0 = xy[sel, 0] * s_, xy[sel, 1] * s_
+            z = cam["f"] * cam["b"] / d[sel]
+            r = np.zeros(n, CANDIDATE_DTYPE)
+            r["xyz_anchor"] = np.stack([(u0 - cam["cx"]) / cam["f"] * z, (v0 - cam["cy"]) / cam["f"] * z, z], 1)
+            r["anchor_obs_pyr"] = np.stack([u0 / s_, v0 / s_, (u0 - d[sel]) / s_], 1)
+            r["anchor_level"] = l
+            rows.append(r)
+        pts = np.concatenate(rows)
+        pts = pts[rng.permutation(len(pts))]                    # new-feature list and neighbourhood list both hold all levels
+        pts["kf_index"] = 0
+        pts["point_id"] = np.arange(len(pts))
+        return pts
+
+    from scavislam_amd.frontend import StereoFrontend
+
+    class OneCall:
+        """B camera streams through the one-call front end (svs_frontend_process_frames): every stream owns two resident frames A, B of a
+        ping-pong sequence A B A B ... (A = its active keyframe, world = A's pose), the frames stay in HBM (svs_frames_dev pointers), a step =
+        StereoFrontend::processFrame for all B streams: copy-in + pyramid, dense tracking, [block matching], grid FAST (6 trials), guided matching of
+        `points` candidates (half of them "new features"), calcFastMotionOnly, processMatchedPoints' gate, dense cloud.  Guess = the pose of the
+        frame before (one inter-frame motion to recover each step, in alternating directions)."""
+
+        def __init__(self, B, block_matching=False, cuda_build=False):
+            self.B, self.bm = B, block_matching
+            prm = capi.FrontendParams.reference(use_block_matching=block_matching, cuda_build=cuda_build)
+            self.fe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=1, params=prm, n_streams=B)
+            pair = [b % NPAIR for b in range(B)]
+            if block_matching:      # only NRIGHT pairs have a rendered right image
+                pair = [p % NRIGHT for p in pair]
+            self.pair = pair
+            with torch.cuda.stream(stream):
+                self.left = [torch.as_tensor(np.stack([(rend_prev if k == 0 else rend_cur)[p][0] for p in pair])).to(dev) for k in range(2)]
+                if block_matching:
+                    self.right = [torch.as_tensor(np.stack([(rend_right_prev if k == 0 else rend_right)[p] for p in pair])).to(dev) for k in range(2)]
+                    self.disp = [None, None]
+                else:
+                    self.right = [None, None]
+                    self.disp = [torch.as_tensor(np.stack([(rend_prev if k == 0 else rend_cur)[p][1] for p in pair]).astype(np.float32)).to(dev) for k in range(2)]
+            stream.synchronize()
+            self.T_act = np.stack([T_prev_list[p].reshape(12) for p in pair])
+            self.T_pose = [np.tile(I34, (B, 1)), np.stack([T_AB[p].reshape(12) for p in pair])]      # true pose of frame A / B relative to the active keyframe
+            self.fe.processFirstFrames(left=self.left[0], right=self.right[0], disp=self.disp[0])     # frame A: the active keyframe, cloud at the identity
+            for b in range(B):
+                self.fe.keepKeyframe(0, T_prev_list[pair[b]], stream=b)
+                if pair[b] not in pts_of_pair:                  # the keyframe's own FAST corners (this front end's, first frame: 5 trials)
+                    pts_of_pair[pair[b]] = candidates_from_corners(pair[b], [self.fe.corners(b, l)[0] for l in range(3)])
+                pp = pts_of_pair[pair[b]]
+                self.fe.setCandidates(pp, len(pp) // 2, stream=b)
+            self.k = 0
+
+        def step(self):
+            self.k += 1
+            f = self.k & 1                                        # 1: frame B (guess: A's pose), 0: frame A (guess: B's pose)
+            self.fe.processFrames(self.T_pose[1 - f], self.T_act, left=self.left[f], right=self.right[f], disp=self.disp[f])
+
+        def close(self):
+            self.fe.close()
+
+    def timed_steps(oc, warm, steps):
         with torch.cuda.stream(stream):
-            d_T0 = torch.as_tensor(np.tile(I34, (B, 1))).to(dev)
+            for _ in range(warm):
+                oc.step()
+            barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                oc.step()
+            barrier_sync()
+            return time.perf_counter() - t0
 
-        def frontend_step():
-            cur.preprocessing(with_float=False)                        # "preprocess" (f32/Sobel fused into the tracker)
-            dtrack.d_T.copy_(d_T0)
-            dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)   # "dense tracking"
-            fast.detectAdaptively(trials=6)                            # "fast"
-            matcher.launch(margs)                                      # "match"
-            dtrack.computeDensePointCloudCpu_dev()                     # "dense point cloud"
-
-        # computeDensePointCloudCpu with the tracked pose already on the device (no host round trip)
-        def _pc_dev():
-            import ctypes as C
-            for l in range(3):
-                cb = (cur.h[l] // 4) * (cur.w[l] // 4) * 4
-                ctx.call("svs_pointcloud_cpu_sem", cur.disp.data_ptr(), cur.stride[0], cur.bstride(0), C.byref(cur.cams[l]), l,
-                         dtrack.d_T.data_ptr(), dtrack.ref_dense_points[l].data_ptr(), cb, B)
-        dtrack.computeDensePointCloudCpu_dev = _pc_dev
-
-
-        return dict(step=frontend_step, cur=cur, prev=prev, kf=kf, fast=fast, dtrack=dtrack, dprev=dprev, matcher=matcher, margs=margs,
-                    track_args=track_args, d_T0=d_T0, pc_dev=_pc_dev, pts=pts, Tc=Tc, T_rel=T_rel, T_kf=T_kf)
-
-    fe = build_frontend(B)
-    frontend_step, cur, prev, fast, dtrack, matcher, margs = fe["step"], fe["cur"], fe["prev"], fe["fast"], fe["dtrack"], fe["matcher"], fe["margs"]
-    track_args, d_T0, _pc_dev, pts, Tc, T_rel, T_kf = fe["track_args"], fe["d_T0"], fe["pc_dev"], fe["pts"], fe["Tc"], fe["T_rel"], fe["T_kf"]
-    with torch.cuda.stream(stream):
-        for _ in range(W):
-            frontend_step()
-        barrier_sync()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            frontend_step()
-        barrier_sync()
-        t_front = time.perf_counter() - t0
-    t_front = max_over_ranks(t_front)
+    oc = OneCall(B)
+    t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
     fps = world * B * K / t_front
-    T_tracked = dtrack.d_T.cpu().numpy().reshape(B, 3, 4)
-    mres = matcher.download()
-    n_matched = int((mres["status"] == 0).sum(axis=1).mean())
-    track_err = float(max(np.abs(T_tracked[b] - T_rel[b].reshape(3, 4)).max() for b in range(min(B, NPAIR))))
-
-    # per-stage / per-kernel timing with HIP events on the ctx stream (not part of the timed steps)
-    stage_ms = {}
-
-    def time_stage(name, fn, reps=10):
-        with torch.cuda.stream(stream):
-            fn()
-            ctx.sync()
-            ctx.timer_start()
-            for _ in range(reps):
-                fn()
-            stage_ms[name] = ctx.timer_stop_ms() / reps
-
-    def _pyr_only():
-        for l in (1, 2):
-            ctx.call("svs_pyr_down_u8", cur.pyr[l - 1].data_ptr(), cur.w[l - 1], cur.h[l - 1], cur.stride[l - 1],
-                     cur.bstride(l - 1), cur.pyr[l].data_ptr(), cur.stride[l], cur.bstride(l), B)
-
-    def _sobel_only():
-        for l in range(3):
-            ctx.call("svs_convert_sobel_f32", cur.pyr[l].data_ptr(), cur.w[l], cur.h[l], cur.stride[l], cur.bstride(l),
-                     cur.f32[l].data_ptr(), cur.dx[l].data_ptr(), cur.dy[l].data_ptr(), cur.stride[l], cur.bstride(l), B)
-
-    def _track_only():
-        dtrack.d_T.copy_(d_T0)
-        dtrack.denseTrackingCpu(prev.pyr, None, args=track_args, download=False)
-
-    time_stage("pyramid", _pyr_only)
-    time_stage("convert_sobel", _sobel_only)
-    time_stage("dense_tracking", _track_only)
-    time_stage("fast", lambda: fast.detectAdaptively(trials=6))
-    time_stage("match", lambda: matcher.launch(margs))
-    time_stage("pointcloud", _pc_dev)
-    # "stereo" stage of processFrame (calcDisparityCpu = cv::StereoBM): SURVEY 8f rank 1.  Timed on its own; the
-    # headline step uses the have_disp_img path (disparity given), as BASELINE's configs do.
-    stereo = StereoMatcher(ctx, cur)
-    stereo.upload_right(np.stack([rend_right[(b % NPAIR) % NRIGHT] for b in range(B)]))
-    if NPAIR > NRIGHT:      # only the first NRIGHT pairs have a rendered right image: give every stream a matching left image for this stage
-        with torch.cuda.stream(stream):
-            left_keep = cur.pyr[0].clone()
-            cur.pyr[0][:, :, :cur.w[0]] = torch.as_tensor(np.stack([rend_cur[(b % NPAIR) % NRIGHT][0] for b in range(B)])).to(dev)
-    disp_given = cur.disp.clone()
-    time_stage("stereo_bm", stereo.calcDisparityCpu, reps=5)
+    # what the last step left: poses, matches, dense sweeps (checked against the true motion: the bench is not timing a diverged tracker)
+    T_all, ok_all = oc.fe.poses()
+    f_last = oc.k & 1
+    track_err = float(max(np.abs(T_all[b] - oc.T_pose[f_last][b].reshape(3, 4)).max() for b in range(min(B, NPAIR))))
+    res0 = [oc.fe.results(b)[0] for b in range(min(B, NPAIR))]
+    n_matched = int(np.mean([r.n_matched for r in res0]))
+    n_points = int(np.mean([r.n_points for r in res0]))
+    n_accepted = int(np.mean([r.point_stats.num_track_points for r in res0]))
+    passes_all = np.array([r.dense_passes for r in res0])
+    passes = float(passes_all.mean())
+    n_corners = int(np.mean([sum(len(oc.fe.corners(b, l)[0]) for l in range(3)) for b in range(min(B, 4))]))
+    tracking_ok_frac = float(ok_all.mean())
+    # per-stage times: the same K steps again with event brackets between the stages inside the library (9 events per step)
+    oc.fe.setTiming(True)
+    stage_acc = {}
     with torch.cuda.stream(stream):
-        d_bm = cur.disp[0, :, :cur.w[0]].cpu().numpy()
-        d_gt = disp_given[0, :, :cur.w[0]].cpu().numpy()
-        cur.disp.copy_(disp_given)
-        if NPAIR > NRIGHT:
-            cur.pyr[0].copy_(left_keep)
+        for _ in range(K + (K & 1)):
+            oc.step()
+            for k_, v_ in oc.fe.stageTimes().items():
+                stage_acc.setdefault(k_, []).append(v_)
+    oc.fe.setTiming(False)
+    stage_ms = {k_: float(np.mean(v_)) for k_, v_ in stage_acc.items()}
+    # dense-tracker bytes from the per-level record of the LM loop (sweeps per level, per stream), SURVEY 8d: 33 B per quarter-grid sample and sweep
+    lvl_px = [(cam["w"] >> l) * (cam["h"] >> l) for l in range(3)]
+    sweeps_lvl = np.zeros(3)
+    for b in range(min(B, NPAIR)):
+        rec = oc.fe.denseRecords(b)
+        for l in range(3):
+            sweeps_lvl[l] += int((rec["level"] == l).sum())
+    sweeps_lvl /= min(B, NPAIR)
+    px = sum(lvl_px)
+    alg = {
+        "preprocess": 2 * lvl_px[0] + lvl_px[0] + lvl_px[1] + lvl_px[1] + lvl_px[2],      # copy-in (r + w) + two pyrDown steps (r + w)
+        "dense_tracking": int(sum(sweeps_lvl[l] * (lvl_px[l] // 16) * (16 + 1 + 16) for l in range(3))),   # cloud float4 + prev u8 + 4x4 u8 taps per sample and sweep
+        "fast": px + 4 * n_corners + 22 * 4,
+        "match": n_points * (60 + 121 + 20) + n_points * 10 * 64,
+        "pose_refinement": 64 * n_matched,                      # the matched records, read once (they stay in registers for all LM trials)
+        "process_points": n_points * (64 + 64 + 40),
+        "pointcloud": (px // 16) * 20,
+    }
+    oc.close()
+    # the stereo-input path (New College: no disparity image, calcDisparityCpu = cv::StereoBM inside the step)
+    ocs = OneCall(B, block_matching=True)
+    t_stereo = max_over_ranks(timed_steps(ocs, 2, max(4, K // 2 * 2)))
+    fps_stereo = world * B * max(4, K // 2 * 2) / t_stereo
+    ocs.fe.setTiming(True)
+    st_acc = {}
+    with torch.cuda.stream(stream):
+        for _ in range(4):
+            ocs.step()
+            for k_, v_ in ocs.fe.stageTimes().items():
+                st_acc.setdefault(k_, []).append(v_)
+    stage_ms_stereo = {k_: float(np.mean(v_)) for k_, v_ in st_acc.items()}
+    ocs.close()
+    alg["stereo"] = lvl_px[0] * (2 + 4)                          # left + right u8 in, f32 disparity out
+    stage_ms_roof = dict(stage_ms, stereo=stage_ms_stereo["stereo"])
+    roofline_frontend = {k: {"ms": round(stage_ms_roof[k], 4), "alg_bytes_per_frame": int(alg[k]),
+                             "achieved_GBs": round(alg[k] * B / (stage_ms_roof[k] * 1e-3) / 1e9, 2),
+                             "frac": round(alg[k] * B / (stage_ms_roof[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in alg}
+    # block matcher quality on one pair (its disparity against the renderer's), through the staged API
+    cur = FramePyramid(ctx, stream, cam, batch=1, with_float=False)
+    cur.upload(rend_cur[0][0][None])
+    stereo = StereoMatcher(ctx, cur)
+    stereo.upload_right(rend_right[0][None])
+    stereo.calcDisparityCpu()
+    d_bm = stereo.disparity_host(0)
+    d_gt = rend_cur[0][1]
     bm_valid = d_bm >= 0
     stereo_info = {"valid_fraction": round(float(bm_valid.mean()), 4),
                    "median_abs_err_px_vs_true_disparity": round(float(np.median(np.abs(d_bm - d_gt)[bm_valid])), 4)}
     stereo.close()
-    px = sum(cur.w[l] * cur.h[l] for l in range(3))
-    n_corners = sum(len(fast.corners(0, l)[0]) for l in range(3))
-    passes_all = dtrack.d_passes.cpu().numpy()
-    passes = float(passes_all.mean())
-    # algorithmic bytes per frame, SURVEY.md 8d table
-    alg = {
-        "pyramid": cur.w[0] * cur.h[0] + cur.w[1] * cur.h[1] + cur.w[2] * cur.h[2],
-        "convert_sobel": px * 13,      # stand-alone kernel, timed for reference; NOT part of the fused step
-        "fast": px + 4 * n_corners + 22 * 4,
-        "match": args.points * (60 + 121 + 20) + args.points * 10 * 64,
-        "dense_tracking": int(passes * (px // 16) * (16 + 1 + 16) / 3),     # cloud float4 + prev u8 + 4x4 u8 taps; passes spread over 3 levels
-        "pointcloud": (px // 16) * 20,
-        "stereo_bm": cur.w[0] * cur.h[0] * (2 + 4),     # left + right u8 in, f32 disparity out
-    }
-    roofline_frontend = {k: {"ms": round(stage_ms[k], 4), "alg_bytes_per_frame": int(alg[k]),
-                             "achieved_GBs": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 2),
-                             "frac": round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} for k in stage_ms}
 
-    # latency mode: one camera stream per launch (the drop-in B = 1 call pattern), same stages
-    fe1 = build_frontend(1)
+    # latency mode: one camera stream per call, frames resident (same one-call path, B = 1)
+    oc1 = OneCall(1)
+    lat_ms = timed_steps(oc1, 4, 20) / 20 * 1e3
+    oc1.fe.setTiming(True)
     with torch.cuda.stream(stream):
-        for _ in range(3):
-            fe1["step"]()
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            fe1["step"]()
-        ctx.sync()
-        lat_ms = (time.perf_counter() - t0) / 20 * 1e3
-    del fe1
+        oc1.step(); oc1.step()
+        lat_stages = {k_: round(v_, 4) for k_, v_ in oc1.fe.stageTimes().items()}
+    oc1.close()
     # the drop-in call: StereoFrontend::processFrame for one stream, HOST image + disparity in, HOST pose / match records / gate records /
     # statistics out (svs_frontend_process_frame: pinned staging, one upload, the same kernels, one download) -- PCIe-inclusive latency
-    from scavislam_amd.frontend import StereoFrontend
-    sfe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=2)
-    sfe.processFirstFrame(rend_kf[0], disp=rend_kf[1])
+    T_kf = T_prev_list[0]
+    pts = pts_of_pair[0]
+    sfe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=1)
+    sfe.processFirstFrame(rend_prev[0][0], disp=rend_prev[0][1])
     sfe.keepKeyframe(0, T_kf)
-    sfe.setCandidates(pts, int(args.points * 0.5))
-    T_guess0 = synth.pose_mul(T_cur_list[0], synth.pose_inv(T_prev_list[0]))
+    sfe.setCandidates(pts, len(pts) // 2)
+    seq = [(rend_cur[0], I34, T_AB[0]), (rend_prev[0], T_AB[0].reshape(12), np.hstack([np.eye(3), np.zeros((3, 1))]))]      # B, A, B, A ...: (frame, guess, true pose)
     host_ms = []
-    for it in range(14):
-        sfe.processFirstFrame(rend_prev[0][0], disp=rend_prev[0][1])          # untimed: makes frame "prev" the active keyframe again
+    for it in range(16):
+        (img_, disp_), guess_, true_ = seq[it & 1]
         t0 = time.perf_counter()
-        fres, fm, fg = sfe.processFrame(rend_cur[0][0], I34, T_prev_list[0], disp=rend_cur[0][1])
+        fres, fm, fg = sfe.processFrame(img_, guess_, T_kf, disp=disp_)
         host_ms.append((time.perf_counter() - t0) * 1e3)
-    host_io_ms = float(np.median(host_ms[3:]))
-    host_io = {"ms_per_frame": round(host_io_ms, 4), "frames_per_s": round(1e3 / host_io_ms, 1), "matched": int(fres.n_matched),
+    host_io_ms = float(np.median(host_ms[4:]))
+    host_dev = float(np.abs(np.array(fres.T_cur_from_actkey).reshape(3, 4) - np.asarray(true_).reshape(3, 4)).max())
+    # the same with the next frame's upload overlapped (svs_frontend_prefetch_frame between submit and wait): the reference's FrameData double buffer
+    ov_ms = []
+    sfe.prefetchFrame(seq[0][0][0], disp=seq[0][0][1])
+    for it in range(16):
+        (img_, disp_), guess_, true_ = seq[it & 1]
+        nxt = seq[(it + 1) & 1][0]
+        t0 = time.perf_counter()
+        sfe.submitFrame(None, guess_, T_kf)
+        sfe.prefetchFrame(nxt[0], disp=nxt[1])
+        fres2, _, _ = sfe.waitFrame()
+        ov_ms.append((time.perf_counter() - t0) * 1e3)
+    sfe.processFrame(None, seq[0][1], T_kf)      # consume the last prefetch
+    host_ov_ms = float(np.median(ov_ms[4:]))
+    host_io = {"ms_per_frame": round(host_io_ms, 4), "frames_per_s": round(1e3 / host_io_ms, 1),
+               "ms_per_frame_next_upload_overlapped": round(host_ov_ms, 4), "matched": int(fres.n_matched),
                "dense_passes": int(fres.dense_passes), "bytes_in": int(cam["w"] * cam["h"] * 5), "bytes_out": int(len(pts) * (64 + 40) + 600),
-               "pose_dev_from_true_motion": float(np.abs(np.array(fres.T_cur_from_actkey).reshape(3, 4) - T_guess0).max())}
+               "pose_dev_from_true_motion": host_dev}
     sfe.close()
-    # batched modes in between (B in {1, 8, 64}): same step, B independent streams per launch
+    # batched modes in between (SURVEY 8d: B in {1, 8, 64}): same step, B independent streams per call
     batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
     for Bs in (8, 64, 256):
         if Bs >= B:
             continue
-        fes = build_frontend(Bs)
-        with torch.cuda.stream(stream):
-            for _ in range(3):
-                fes["step"]()
-            ctx.sync()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                fes["step"]()
-            ctx.sync()
-            batch_sweep[str(Bs)] = round(Bs * 10 / (time.perf_counter() - t0), 1)
-        del fes
+        ocb = OneCall(Bs)
+        batch_sweep[str(Bs)] = round(Bs * 10 / timed_steps(ocb, 2, 10), 1)
+        ocb.close()
+    # the reference's CUDA build of the same path (full-resolution tracker, matcher radius 4) through the same call
+    FBc = min(B, 64)
+    occ = OneCall(FBc, cuda_build=True)
+    t_cuda = timed_steps(occ, 2, 6)
+    cuda_path = {"streams_per_call": FBc, "ms_per_step": round(t_cuda / 6 * 1e3, 4), "frames_per_s": round(FBc * 6 / t_cuda, 1)}
+    occ.close()
 
     # ------------------------------------------------------------------ BASELINE config 5: RGB-D full-resolution dense tracking
     # DenseTracker::denseTrackingGpu (dense_tracking.cpp:60-193) for FB independent 640x480 RGB-D streams per launch: CUDA-branch
@@ -479,9 +514,11 @@ def main():
                        lm_trials=int(st_.trials), **o.info())
             o.close()
             schur_rows[name] = row
-        time_window("15KF_3k (configs[2])", synth.ba_window(15, 3000, seed=2012))
-        time_window("double_window_30_inner_200_outer", synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(100, 180, 70), n_loops=2))
-        time_window("double_window_30_inner_200_outer_no_loop_closure", synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(), n_loops=0))
+        other_probs = {"15KF_3k (configs[2])": synth.ba_window(15, 3000, seed=2012),
+                       "double_window_30_inner_200_outer": synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(100, 180, 70), n_loops=2),
+                       "double_window_30_inner_200_outer_no_loop_closure": synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(), n_loops=0)}
+        for name_, pr_ in other_probs.items():
+            time_window(name_, pr_)
         # throughput mode: W independent 50 KF / 20k windows in flight (svs_ba_optimize_batch, one context = one stream per window)
         by_w = {"1": round(1e3 / ms_opt, 1)}
         for Wn in (8, 32):
@@ -591,27 +628,35 @@ def main():
     cpu_schur_ms = None
     if rank == 0 and world == 1 and not args.no_cpu:      # the contract: rank 0 at N=1 only
         import oracle as O
-        grids = [O.fastgrid_for_level(cur.w[l], cur.h[l], l) for l in range(3)]
-        # state the reference also carries over from the previous frame (not timed)
+        from scavislam_amd.ctypes_types import PoseOptParams, level_cams as level_cams_c
+        cams_c = level_cams_c(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
+        lw, lh = [cam["w"] >> l for l in range(3)], [cam["h"] >> l for l in range(3)]
+        grids = [O.fastgrid_for_level(lw[l], lh[l], l) for l in range(3)]
+        # state the reference also carries over from the previous frame (not timed): the active keyframe = frame A, its pyramid and cloud
         pyr_p_cache = {p: O.build_pyramid(rend_prev[p][0]) for p in range(NPAIR)}
-        clouds_cache = {p: [O.pointcloud_cpu(rend_prev[p][1], cur.cams[l], l, I34.reshape(3, 4)) for l in range(3)]
+        clouds_cache = {p: [O.pointcloud_cpu(rend_prev[p][1], cams_c[l], l, I34.reshape(3, 4)) for l in range(3)]
                         for p in range(NPAIR)}
-        kf_pyr = O.build_pyramid(rend_kf[0])
         t0 = time.perf_counter()
         nfr = 0
         while nfr < 3 or (time.perf_counter() - t0 < 8.0 and nfr < 200):      # BASELINE configs[0]: 200 frames
             p = nfr % NPAIR
             img_c, disp_c = rend_cur[p]
+            T_kfp = T_prev_list[p]
             pyr_c = O.build_pyramid(img_c)                                      # "preprocess"
             fl = [O.convert_sobel(x) for x in pyr_c]
             Tt, _ = O.dense_tracking_cpu(clouds_cache[p], pyr_p_cache[p], [f[0] for f in fl], [f[1] for f in fl],
-                                         [f[2] for f in fl], cur.cams, I34.reshape(3, 4))   # "dense tracking"
+                                         [f[2] for f in fl], cams_c, I34.reshape(3, 4))     # "dense tracking"
             trees = []
             for l in range(3):                                                  # "fast"
                 xy, cc, et = O.fastgrid_detect_adaptively(grids[l], pyr_c[l], 6)
-                trees.append(O.quadtree_from_corners(xy, cc, cur.w[l], cur.h[l]))
-            O.match([kf_pyr], [T_kf.reshape(12)], Tc[p].reshape(3, 4), T_kf, pyr_c, disp_c, trees, cur.cams, pts)   # "match"
-            [O.pointcloud_cpu(disp_c, cur.cams[l], l, Tt) for l in range(3)]    # "dense point cloud"
+                trees.append(O.quadtree_from_corners(xy, cc, lw[l], lh[l]))
+            mres_c = O.match([pyr_p_cache[p]], [T_kfp.reshape(12)], Tt, T_kfp, pyr_c, disp_c, trees, cams_c, pts_of_pair[p])   # "match"
+            if (mres_c["status"] == 0).sum() >= 20:
+                Tm, _ = O.motion_only(mres_c, cams_c[0], Tt, PoseOptParams.reference())                                        # calcFastMotionOnly
+                O.process_matched_points(mres_c, pts_of_pair[p], len(pts_of_pair[p]) // 2, cams_c[0], Tm, 2.0)                            # "process points"
+            else:
+                Tm = Tt
+            [O.pointcloud_cpu(disp_c, cams_c[l], l, Tm) for l in range(3)]      # "dense point cloud"
             nfr += 1
         t_cpu = time.perf_counter() - t0
         cpu_fps = nfr / t_cpu
@@ -621,6 +666,18 @@ def main():
             O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
             nba += 1
         cpu_schur_ms = (time.perf_counter() - t0) / nba * 1e3
+        # the other window shapes of the Schur table: every BA row gets its CPU time (bounded: >= 2 calls, <= 3 s each)
+        for name_, pr_ in (other_probs.items() if schur_rows is not None else ()):
+            cm_ = Cam(*(pr_["cam"][k] for k in ("f", "cx", "cy", "b", "w", "h")))
+            t0 = time.perf_counter()
+            nb_ = 0
+            while nb_ < 2 or (time.perf_counter() - t0 < 3.0 and nb_ < 30):
+                O.ba_optimize(pr_["poses"], pr_["psi"], pr_["edges"], pr_["cons"], cm_, prm)
+                nb_ += 1
+            ms_ = (time.perf_counter() - t0) / nb_ * 1e3
+            schur_rows[name_]["cpu_port_ms_per_optimize"] = round(ms_, 2)
+            schur_rows[name_]["speedup_vs_cpu_port"] = round(ms_ / schur_rows[name_]["ms_per_optimize"], 1)
+            schur_rows[name_]["speedup_vs_cpu_port_drop_in_call"] = round(ms_ / schur_rows[name_]["ms_per_call_incl_host_marshalling_and_copies"], 1)
         # context: one build + Schur accumulation of the same window from 1 and from 8 host threads
         acc_ms = {}
         for nthr in (1, 8):
@@ -636,7 +693,7 @@ def main():
             nst += 1
         cpu_stereo_ms = (time.perf_counter() - t0) / nst * 1e3
         cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{nfr} frames 640x480 through the CPU oracle (same stages, same inputs)"
+               "sample": f"{nfr} frames 640x480 through the CPU oracle (the same eight stages minus block matching, same inputs, disparity given)"
                          f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
                "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1),
                "stereo_bm_note": "naive scalar restatement of cv::StereoBM, NOT OpenCV's SIMD implementation (30-50x faster): no speed-up claim for this stage",
@@ -649,10 +706,15 @@ def main():
             "ms_per_step": round(t_front / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (FAST, ZNSSD), f32+f64 (dense tracking), f64 (Schur)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]+[3]: per-frame front-end on 640x480 stereo frames (pyramid, dense tracking with fused f32+Sobel, "
-                                   " grid-FAST, ZNSSD match, dense cloud; disparity given) and DWO inner-window "
-                                   "Schur solve 50 KF / 20k landmarks",
-                       "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": args.points,
+            "value_stereo_input": round(fps_stereo, 2),
+            "config": {"workload": "configs[1]+[3]: StereoFrontend::processFrame as ONE library call for a batch of camera streams on 640x480 stereo frames "
+                                   "resident in HBM -- all eight stages: preprocess (copy-in + pyramid), dense tracking (fused f32 + Sobel taps), stereo "
+                                   "(disparity given for `value`; cv::StereoBM block matching inside the step for `value_stereo_input`), grid FAST, guided "
+                                   "ZNSSD match, pose refinement (calcFastMotionOnly), process points (reprojection gate), dense point cloud -- and DWO "
+                                   "inner-window Schur solve 50 KF / 20k landmarks",
+                       "api": "svs_frontend_process_frames (frames by device pointer, poses from the host, results stay on the device)",
+                       "stages": list(stage_ms.keys()),
+                       "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": n_points,
                        "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system",
                        "collective": (dict(comm.stats(), transport="RCCL ncclAllReduce(ncclDouble) issued by the library on its stream") if comm is not None
                                       else ({"transport": "torch.distributed all_reduce callback (library communicator unavailable)"} if allreduce is not None else None))},
@@ -673,15 +735,20 @@ def main():
                       "other_windows": schur_rows,
                       "weak_scaling": schur_weak},
             "frontend": {"stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+                         "stage_ms_sum": round(sum(stage_ms.values()), 4),
+                         "stage_ms_note": "measured inside the library with 9 events per step in a second pass over the same steps; ms_per_step is measured without them",
                          "dense_passes_per_frame": round(passes, 2),
+                         "dense_sweeps_per_level": [round(float(x), 2) for x in sweeps_lvl],
                          "dense_passes_per_frame_spread": {"min": int(passes_all.min()), "max": int(passes_all.max()), "distinct_frame_pairs": NPAIR},
-                         "corners_per_frame": n_corners, "matches_per_frame": n_matched,
-                         "dense_track_pose_err": track_err,
-                         "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1)},
+                         "corners_per_frame": n_corners, "matches_per_frame": n_matched, "accepted_points_per_frame": n_accepted,
+                         "tracking_ok_fraction": tracking_ok_frac,
+                         "refined_pose_err_vs_true_motion": track_err,
+                         "latency_mode_B1": {"ms_per_frame": round(lat_ms, 4), "frames_per_s": round(1e3 / lat_ms, 1), "stage_ms": lat_stages},
                          "latency_mode_B1_host_io": host_io,
                          "frames_per_s_per_gpu_by_batch": batch_sweep,
-                         "stereo_bm": dict(stereo_info, ms_per_batch=round(stage_ms["stereo_bm"], 4),
-                                           frames_per_s_if_block_matching_is_added_to_the_step=round(world * B / ((t_front / K) + stage_ms["stereo_bm"] * 1e-3), 1)),
+                         "stereo_input_path": dict(stereo_info, ms_per_step=round(t_stereo / max(4, K // 2 * 2) * 1e3, 4), frames_per_s=round(fps_stereo, 1),
+                                                   stage_ms_per_batch={k: round(v, 4) for k, v in stage_ms_stereo.items()}),
+                         "cuda_build_path": cuda_path,
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
             "dense_full": dense_full,
             "roofline": roofline,

@@ -436,6 +436,16 @@ int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_dev *in, cons
 /* blocking downloads after svs_frontend_process_frames: everything of one stream; refined poses [n_streams][12] + tracking flags of all (NULL = not wanted) */
 int svs_frontend_results(svs_frontend *fe, int stream, svs_frame_result *out, svs_match_result *h_matches, svs_gated_point *h_gated);
 int svs_frontend_poses(svs_frontend *fe, double *h_T_cur_from_actkey, int32_t *h_tracking_ok);
+/* profiling: hipEvents between the stages of the following process_frame(s) / submit_frame calls (off by default: an event costs ~4 us of stream time).
+   svs_frontend_stage_times (blocking): ms[SVS_FRONTEND_STAGES] of the last such call, in the order of the reference's per_mon_ stages
+   (stereo_frontend.cpp:190-302): preprocess (upload or copy + pyramid), dense tracking, stereo, fast, match, pose refinement (calcFastMotionOnly),
+   process points, dense point cloud */
+#define SVS_FRONTEND_STAGES 8
+int svs_frontend_set_timing(svs_frontend *fe, int on);
+int svs_frontend_stage_times(svs_frontend *fe, float *ms);
+/* blocking: the accept / reject record of the dense tracker's LM loop of one stream in the last call (one entry per chi2 evaluation: level, accepted,
+   chi2 before / after); *n = records produced, of which the first min(*n, cap, 64) are stored */
+int svs_frontend_dense_records(svs_frontend *fe, int stream, svs_dense_lm_record *h_rec, int cap, int32_t *n);
 /* computeDensePointCloudCpu / Gpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302); n_streams == 1 */
 int svs_frontend_recompute_cloud(svs_frontend *fe, const double *T_cur_from_actkey);
 /* device views of one stream (tests, chaining): level images of the frame processed last, strides, its disparity (the caller's buffer if it passed

@@ -20,7 +20,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "scavislam_hip.h"
@@ -339,6 +341,9 @@ class DenseTracker {
       if (!ctx_.check(svs_pointcloud_cpu_sem(ctx_.get(), fr.disp(), fr.stride(0), 0, &cam_[l], l, d_T_.get(), cloud_[l].get(), 0, 1))) return false;
     return svs_ctx_sync(ctx_.get()) == SVS_OK;
   }
+  // ref_dense_points_[level] given by the host (state restored from a saved session; tests): float4 per quarter-grid sample, row-major
+  bool setDensePointCloud(int level, const float *h_cloud4) { return cloud_[level].upload(h_cloud4, cloud_[level].size()); }
+  bool getDensePointCloud(int level, float *h_cloud4) const { return cloud_[level].download(h_cloud4, cloud_[level].size()); }
   // void denseTrackingCpu(SE3* T_cur_from_actkey): in/out pose, whole LM loop in one device launch
   bool denseTrackingCpu(const FrameDev &prev, const FrameDev &cur, double T_cur_from_actkey[12]) {
     svs_dense_track_args a;
@@ -550,23 +555,119 @@ class SlamGraphBA {
   bool optimize(const OptParams &opt, const svs_cam &cam, std::vector<double> *poses, std::vector<double> *psi,
                 const std::vector<svs_ba_edge> &obs_edges, const std::vector<svs_ba_constraint> &constraints,
                 svs_ba_stats *stats = nullptr, bool exact_self_edges = false) {
-    svs_ba_params prm;
-    prm.num_iters = opt.num_iters; prm.use_robust = opt.use_robust_kernel ? 1 : 0;
-    prm.huber_delta = 1.0;               // huber_kernel_width is dead in the reference (slam_graph-impl.cpp:86-90)
-    prm.lambda_init = 50.0;              // slam_graph.cpp:338
-    prm.max_trials = 5;                  // slam_graph.cpp:1073
-    prm.self_edge_mode = exact_self_edges ? 1 : 0;
+    svs_ba_params prm = params(opt, exact_self_edges);
     const int P = (int)(poses->size() / 12), L = (int)(psi->size() / 3);
     if (!ctx_.check(svs_ba_set_problem(ba_, P, poses->data(), L, psi->data(), (int)obs_edges.size(), obs_edges.data(),
                                        (int)constraints.size(), constraints.data(), &cam, &prm, 1))) return false;
     if (!ctx_.check(svs_ba_optimize(ba_, nullptr, nullptr, stats))) return false;
     return ctx_.check(svs_ba_get_state(ba_, poses->data(), psi->data()));
   }
+  // ---- the marshalling of SlamGraph::copyDataToG2o / restoreDataFromG2o (slam_graph.cpp:983-1058) from records that keep the GRAPH'S OWN IDS ----
+  // One record per addObsToG2o call (slam_graph-impl.cpp:44-97): the ImageFeature of vertex `pose_id`'s feature_table for point `point_id`
+  struct ObsById { int point_id, pose_id, level; double center[3]; };
+  // One record per addConstraintToG2o call (slam_graph-impl.cpp:99-126).  copyContraintsToG2o (slam_graph.cpp:937-981) walks ORDERED pairs of the double
+  // window, so a marginalised edge with an OUTER end is handed over twice: (1, 2, T_2_from_1, Lambda_2_from_1) and (2, 1, T_1_from_2, Lambda_1_from_2) --
+  // the caller passes both, as the reference does
+  struct ConstraintById { int pose_id_1, pose_id_2; double T_2_from_1[12], Lambda_2_from_1[36]; };
+  // pose_ids / poses [P][12]: the double window in the order of copyPosesToG2o; point_ids / anchor_ids / xyz_anchor [L][3]: the active points (Point::xyz_anchor,
+  // Point::anchorframe_id) -- converted to the inverse-depth parameters the solver works on (invert_depth, slam_graph.cpp:916) and back (:1054);
+  // observations from frames outside the window are skipped like slam_graph.cpp:1001-1006 does; information = diag(4^-level, 4^-level, 0.333^2) (:1010-1015).
+  // poses and xyz_anchor are updated in place.  false: an anchor frame outside the window (the reference asserts), or a library error
+  bool optimizeWindow(const OptParams &opt, const svs_cam &cam, const std::vector<int> &pose_ids, std::vector<double> *poses, const std::vector<int> &point_ids,
+                      const std::vector<int> &anchor_ids, std::vector<double> *xyz_anchor, const std::vector<ObsById> &obs,
+                      const std::vector<ConstraintById> &constraints, svs_ba_stats *stats = nullptr) {
+    const size_t P = pose_ids.size(), L = point_ids.size();
+    if (poses->size() != 12 * P || xyz_anchor->size() != 3 * L || anchor_ids.size() != L) return false;
+    std::vector<std::pair<int, int> > pmap(P), lmap(L);                      // (id, index), sorted: the hash maps of the reference flattened
+    for (size_t i = 0; i < P; ++i) pmap[i] = std::make_pair(pose_ids[i], (int)i);
+    for (size_t i = 0; i < L; ++i) lmap[i] = std::make_pair(point_ids[i], (int)i);
+    std::sort(pmap.begin(), pmap.end()); std::sort(lmap.begin(), lmap.end());
+    std::vector<double> psi(3 * L);
+    std::vector<int> anchor_idx(L);
+    for (size_t i = 0; i < L; ++i) {
+      const double *x = &(*xyz_anchor)[3 * i];
+      psi[3 * i] = x[0] / x[2]; psi[3 * i + 1] = x[1] / x[2]; psi[3 * i + 2] = 1. / x[2];      // invert_depth (maths_utils.h:66-69)
+      if ((anchor_idx[i] = find(pmap, anchor_ids[i])) < 0) return false;
+    }
+    std::vector<svs_ba_edge> edges;
+    edges.reserve(obs.size());
+    for (size_t k = 0; k < obs.size(); ++k) {
+      const int pt = find(lmap, obs[k].point_id), po = find(pmap, obs[k].pose_id);
+      if (pt < 0 || po < 0) continue;                                         // point not active / frame not in the double window
+      svs_ba_edge e;
+      std::memset(&e, 0, sizeof e);
+      const double f = 1. / (double)(1 << obs[k].level);                     // pyrFromZero_d(1., level)
+      for (int c = 0; c < 3; ++c) e.obs[c] = obs[k].center[c];
+      e.info[0] = e.info[1] = f * f; e.info[2] = 0.333 * 0.333;               // Po2(...) (slam_graph.cpp:1010-1015)
+      e.point = pt; e.pose = po; e.anchor = anchor_idx[pt];
+      edges.push_back(e);
+    }
+    std::vector<svs_ba_constraint> cons(constraints.size());
+    for (size_t k = 0; k < constraints.size(); ++k) {
+      std::memcpy(cons[k].T_21, constraints[k].T_2_from_1, sizeof cons[k].T_21);
+      std::memcpy(cons[k].info, constraints[k].Lambda_2_from_1, sizeof cons[k].info);
+      cons[k].pose1 = find(pmap, constraints[k].pose_id_1); cons[k].pose2 = find(pmap, constraints[k].pose_id_2);
+      if (cons[k].pose1 < 0 || cons[k].pose2 < 0) return false;
+    }
+    if (!optimize(opt, cam, poses, &psi, edges, cons, stats)) return false;
+    for (size_t i = 0; i < L; ++i) {                                          // invert_depth again (slam_graph.cpp:1054)
+      double *x = &(*xyz_anchor)[3 * i];
+      const double *s = &psi[3 * i];
+      x[0] = s[0] / s[2]; x[1] = s[1] / s[2]; x[2] = 1. / s[2];
+    }
+    return true;
+  }
+  // The same call for a window that slides: the library keeps the observations it has been given (svs_ba_window_update), a call brings the window by ids,
+  // the current values and the observations made SINCE THE LAST CALL.  new_obs: ObsById records; everything else as optimizeWindow
+  bool optimizeSlidingWindow(const OptParams &opt, const svs_cam &cam, const std::vector<int> &pose_ids, std::vector<double> *poses,
+                             const std::vector<int> &point_ids, const std::vector<int> &anchor_ids, std::vector<double> *xyz_anchor,
+                             const std::vector<ObsById> &new_obs, const std::vector<ConstraintById> &constraints, svs_ba_stats *stats = nullptr) {
+    const size_t P = pose_ids.size(), L = point_ids.size();
+    if (poses->size() != 12 * P || xyz_anchor->size() != 3 * L || anchor_ids.size() != L) return false;
+    std::vector<double> psi(3 * L);
+    for (size_t i = 0; i < L; ++i) { const double *x = &(*xyz_anchor)[3 * i]; psi[3 * i] = x[0] / x[2]; psi[3 * i + 1] = x[1] / x[2]; psi[3 * i + 2] = 1. / x[2]; }
+    std::vector<svs_ba_edge> eo(new_obs.size());
+    for (size_t k = 0; k < new_obs.size(); ++k) {
+      std::memset(&eo[k], 0, sizeof eo[k]);
+      const double f = 1. / (double)(1 << new_obs[k].level);
+      for (int c = 0; c < 3; ++c) eo[k].obs[c] = new_obs[k].center[c];
+      eo[k].info[0] = eo[k].info[1] = f * f; eo[k].info[2] = 0.333 * 0.333;
+      eo[k].point = new_obs[k].point_id; eo[k].pose = new_obs[k].pose_id;     // ids: the library resolves them against the window
+    }
+    std::vector<svs_ba_constraint> cons(constraints.size());
+    for (size_t k = 0; k < constraints.size(); ++k) {
+      std::memcpy(cons[k].T_21, constraints[k].T_2_from_1, sizeof cons[k].T_21);
+      std::memcpy(cons[k].info, constraints[k].Lambda_2_from_1, sizeof cons[k].info);
+      cons[k].pose1 = constraints[k].pose_id_1; cons[k].pose2 = constraints[k].pose_id_2;
+    }
+    svs_ba_params prm = params(opt, false);
+    if (!ctx_.check(svs_ba_window_update(ba_, (int)P, pose_ids.data(), poses->data(), (int)L, point_ids.data(), psi.data(), anchor_ids.data(), (int)eo.size(),
+                                         eo.data(), (int)cons.size(), cons.data(), &cam, &prm)))
+      return false;
+    if (!ctx_.check(svs_ba_optimize(ba_, nullptr, nullptr, stats))) return false;
+    if (!ctx_.check(svs_ba_get_state(ba_, poses->data(), psi.data()))) return false;
+    for (size_t i = 0; i < L; ++i) { double *x = &(*xyz_anchor)[3 * i]; const double *s = &psi[3 * i]; x[0] = s[0] / s[2]; x[1] = s[1] / s[2]; x[2] = 1. / s[2]; }
+    return true;
+  }
+  bool windowReset() { return ctx_.check(svs_ba_window_reset(ba_)); }
   // landmark-sharded operation: this rank passes only ITS landmarks' edges to optimize() (pose terms on exactly one rank: add_pose_terms)
   bool attach(const Communicator *comm) { return ctx_.check(svs_ba_set_comm(ba_, comm ? comm->get() : nullptr)); }
   svs_ba *get() const { return ba_; }
 
  private:
+  static svs_ba_params params(const OptParams &opt, bool exact_self_edges) {
+    svs_ba_params prm;
+    prm.num_iters = opt.num_iters; prm.use_robust = opt.use_robust_kernel ? 1 : 0;
+    prm.huber_delta = 1.0;               // huber_kernel_width is dead in the reference (slam_graph-impl.cpp:86-90)
+    prm.lambda_init = 50.0;              // slam_graph.cpp:338
+    prm.max_trials = 5;                  // slam_graph.cpp:1073
+    prm.self_edge_mode = exact_self_edges ? 1 : 0;
+    return prm;
+  }
+  static int find(const std::vector<std::pair<int, int> > &m, int id) {
+    std::vector<std::pair<int, int> >::const_iterator it = std::lower_bound(m.begin(), m.end(), std::make_pair(id, -1));
+    return it != m.end() && it->first == id ? it->second : -1;
+  }
   const Context &ctx_;
   svs_ba *ba_;
 };

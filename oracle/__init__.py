@@ -849,11 +849,16 @@ class RefFrontendGrids:
 
 def ref_slamgraph_optimize(pose_ids, window_types, poses, point_ids, anchor_ids, xyz_anchor, obs_point, obs_pose, obs_level, obs_center,
                            pe_ids, pe_marginalized, pe_T12, pe_L12, pe_L21, cam, num_iters=2, use_robust_kernel=True, huber_kernel_width=1.0,
-                           move=0.0):
+                           move=0.0, hip_branch=False):
     """The reference's own SlamGraph<SE3, StereoCamera, SE3XYZ_STEREO, 3>::optimize (oracle/_ref/libsvs_ref_slamgraph.so) on tables filled from the
     arguments, with a RECORDING g2o behind it.  Returns dict(vertices (kind, id, fixed, marginalized), estimates [n, 12], edges (kind, v0, v1, v2,
     robust, parameter id), edge_data [n, 49] (measurement 12, information 36, kernel delta), settings [10], poses_out, points_out)."""
-    L = _ref_lib("libsvs_ref_slamgraph.so")
+    if hip_branch:
+        # SlamGraph::optimize compiled with the SCAVISLAM_HIP_SUPPORT branch in place (oracle/Makefile: libsvs_hipbranch_slamgraph.so): no g2o graph is built, the
+        # tables go to scavislam_amd/libscavislam_hip.so (the GPU) and come back; returns dict(poses_out, points_out, stats)
+        from scavislam_amd import capi
+        capi.load()
+    L = _ref_lib("libsvs_hipbranch_slamgraph.so" if hip_branch else "libsvs_ref_slamgraph.so")
     pose_int = np.ascontiguousarray(np.stack([pose_ids, window_types], 1), np.int32)
     pose_T = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
     point_int = np.ascontiguousarray(np.stack([point_ids, anchor_ids], 1), np.int32)
@@ -871,6 +876,12 @@ def ref_slamgraph_optimize(pose_ids, window_types, poses, point_ids, anchor_ids,
     L.svs_refsg_optimize(_p(pose_int), _p(pose_T), len(pose_int), _p(point_int), _p(point_xyz), len(point_int), _p(obs_int), _p(obs_c), len(obs_int),
                          _p(pe_int), _p(pe_dbl), n_pe, _p(cam6), int(num_iters), int(bool(use_robust_kernel)), float(huber_kernel_width), float(move),
                          _p(poses_out), _p(points_out))
+    if hip_branch:
+        i4, d3 = np.zeros(4, np.int32), np.zeros(3)
+        L.svs_refsg_hip_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.svs_refsg_hip_stats(_p(i4), _p(d3))
+        return dict(poses_out=poses_out, points_out=points_out,
+                    stats=dict(iterations=int(i4[0]), trials=int(i4[1]), accepted=int(i4[2]), terminated=int(i4[3]), chi2_init=d3[0], chi2_final=d3[1], lambda_final=d3[2]))
     nv, ne = L.svs_refsg_num_vertices(), L.svs_refsg_num_edges()
     v_int = np.zeros((nv, 4), np.int32); v_est = np.zeros((nv, 12)); e_int = np.zeros((ne, 6), np.int32); e_dbl = np.zeros((ne, 49)); st = np.zeros(10)
     L.svs_refsg_get.argtypes = [C.c_void_p] * 5
@@ -916,12 +927,17 @@ def ref_match_and_track(kf_pyrs, kf_poses, actkey_index, neighbours, T_cur_from_
 
 
 def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, list_of, T_cur_from_actkey, clouds, prev_pyr, cur_pyr, cur_f32, cur_dx, cur_dy, disp,
-                      cuda_build=False):
+                      cuda_build=False, hip_branch=False):
     """The reference's own StereoFrontend::processFrame (oracle/_ref/libsvs_ref_frame.so: dense tracking, grid FAST with 6 trials on fresh grids, matchAndTrack,
     processMatchedPoints, dense cloud; the keyframe decisions answer "no").  Returns dict(ok, T, clouds, rimg, lines [per level: rows (is_new, uv_pyr 2,
     curkey_uv_pyr 2)], av_track_length, is_frame_dropped).  cuda_build: the reference's CUDA build of the path (libsvs_ref_frame_cuda.so: denseTrackingGpu on
     the emulated kernels, matcher radius 4) -- then clouds are full-resolution [h][w][4] and prev_pyr is the previous frame's F32 pyramid."""
-    L = _ref_lib("libsvs_ref_frame_cuda.so" if cuda_build else "libsvs_ref_frame.so")
+    if hip_branch:
+        # the reference's processFrame compiled with the SCAVISLAM_HIP_SUPPORT branch in place (oracle/Makefile: libsvs_hipbranch_frame.so): its arithmetic runs
+        # in scavislam_amd/libscavislam_hip.so on the GPU -- load that library first (through torch's HIP runtime), the branch library binds to it
+        from scavislam_amd import capi
+        capi.load()
+    L = _ref_lib("libsvs_hipbranch_frame.so" if hip_branch else ("libsvs_ref_frame_cuda.so" if cuda_build else "libsvs_ref_frame.so"))
     L.svs_refframe_set_fast.argtypes = [C.c_void_p]
     L.svs_refframe_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
     n_kf = len(kf_pyrs)

@@ -152,6 +152,9 @@ _SIGS = {
     "svs_frontend_process_frames": [C.c_void_p, C.POINTER(FramesDev), C.c_void_p, C.c_void_p],
     "svs_frontend_results": [C.c_void_p, C.c_int, C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
     "svs_frontend_poses": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "svs_frontend_set_timing": [C.c_void_p, C.c_int],
+    "svs_frontend_stage_times": [C.c_void_p, C.c_void_p],
+    "svs_frontend_dense_records": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)],
     "svs_pointcloud_full_pose": [C.c_void_p, C.c_void_p, C.POINTER(Cam), C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                  C.c_void_p, C.c_int],
     "svs_frontend_destroy": [C.c_void_p],

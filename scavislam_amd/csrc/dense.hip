@@ -837,10 +837,10 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
 //    symmetric positive definite, so no pivoting is needed where the reference's ldlt() pivots), exp(delta) * T on the same wave.
 // Same LM schedule and stopping rules as pose_optimizer.h:134-298; sums in a different order and one reciprocal instead of five divisions
 // per residual => the pose agrees with the oracle to ~1e-12 (test bar 1e-9).
-constexpr int MO2_THREADS = 256, MO2_RC = 4, MO2_WAVES = MO2_THREADS / 64;
+constexpr int MO2_THREADS = 512, MO2_RC = 2, MO2_WAVES = MO2_THREADS / 64;
 struct MoObs { double o[3], q[3]; };
 
-__device__ __forceinline__ void mo2_terms(const double *T, const MoObs &ob, const svs_cam &cam, int robust, double kb, double (&x)[32], double &max_err,
+__device__ __forceinline__ void mo2_terms(const double (&T)[12], const MoObs &ob, const svs_cam &cam, int robust, double kb, double (&x)[32], double &max_err,
                                           double *max_diag) {
   const double *q = ob.q;
   const double X = T[0] * q[0] + T[1] * q[1] + T[2] * q[2] + T[3];
@@ -889,29 +889,77 @@ __device__ __forceinline__ double mo2_bcast(double v, int src_lane) {      // sr
   return __hiloint2double(hi, lo);
 }
 
+// exp(x) * T with everything in registers (d_se3_exp_mul above is an out-of-line call on arrays in scratch memory: fine once per pass of a long
+// sweep, not on the critical chain of a 3 us trial)
+__device__ __forceinline__ void mo2_exp_mul(const double (&x)[6], const double (&T)[12], double (&Tn)[12]) {
+  const double w0 = x[3], w1 = x[4], w2 = x[5];
+  const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
+  // a = sin(th) / th, b = c = (1 - cos th) / th^2, d = (th - sin th) / th^3.  An LM step rotates by far less than half a radian: there the three
+  // are even power series in th^2 (9 terms: remainder < 1e-22), no square root, no division, no libm call on the chain of the trial
+  double a, b, c, d;
+  if (th2 < 0.25) {
+    const double f[20] = {1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600,
+                          1.0 / 6227020800., 1.0 / 87178291200., 1.0 / 1307674368000., 1.0 / 20922789888000., 1.0 / 355687428096000., 1.0 / 6402373705728000.,
+                          1.0 / 121645100408832000., 1.0 / 2432902008176640000.};      // 1 / (k + 1)!
+    a = f[18]; b = f[19]; d = f[19] / 21.0;
+#pragma unroll
+    for (int k = 8; k >= 0; --k) { a = f[2 * k] - th2 * a; b = f[2 * k + 1] - th2 * b; d = f[2 * k + 2] - th2 * d; }
+    c = b;
+  } else {
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const double ith2 = 1.0 / th2;
+    a = sn / th; b = (1.0 - cs) * ith2; c = b; d = (th - sn) * ith2 / th;
+  }
+  // W = hat(w), W2 = W * W
+  const double W[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+  double W2[9], R[9], V[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { R[i] = a * W[i] + b * W2[i]; V[i] = c * W[i] + d * W2[i]; }
+  R[0] += 1; R[4] += 1; R[8] += 1;
+  V[0] += 1; V[4] += 1; V[8] += 1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double t = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+    Tn[4 * i + 3] += t;
+  }
+}
+
 __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
                                                                         svs_pose_opt_params prm, double *__restrict__ T_io,
                                                                         svs_pose_opt_stats *__restrict__ stats) {
   extern __shared__ int s_idx[];                   // [n]: indices of the status-OK records, in list order
   __shared__ double s_part[MO2_WAVES][32];         // per wave: 28 sums (21 of J^T J, 6 of J^T w f, chi2), max error, max diag
-  __shared__ double s_T[12], s_Tn[12];
-  __shared__ int s_wcnt[MO2_WAVES];
+  __shared__ double s_Tn[12];
+  __shared__ int s_wcnt[8][MO2_WAVES];
+  __shared__ int s_conv;                           // |B|_inf <= 1e-10 at the pose the pending step was taken from
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
   res += (size_t)slot * res_bstride;
-  if (tid < 12) s_T[tid] = T_io[12 * slot + tid];
-  // ---- compaction of obs_list / point_list (the OK records, in order)
+  // ---- compaction of obs_list / point_list (the OK records, in order).  Eight chunks per round: their status words are requested together
+  // (one memory round trip instead of eight), one barrier per round
   int n_ok = 0;
-  for (int base = 0; base < n; base += MO2_THREADS) {
-    const int i = base + tid;
-    const bool ok = i < n && res[i].status == 0;
-    const unsigned long long m = __ballot(ok);
-    if (lane == 0) s_wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = n_ok, tot = 0;
+  for (int base = 0; base < n; base += 8 * MO2_THREADS) {
+    int st[8];
 #pragma unroll
-    for (int w = 0; w < MO2_WAVES; ++w) { const int c = s_wcnt[w]; off += w < wave ? c : 0; tot += c; }
-    if (ok) s_idx[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
-    n_ok += tot;
+    for (int c = 0; c < 8; ++c) { const int i = base + c * MO2_THREADS + tid; st[c] = i < n ? res[i].status : 1; }
+    unsigned long long m[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { m[c] = __ballot(st[c] == 0); if (lane == 0) s_wcnt[c][wave] = __popcll(m[c]); }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int off = n_ok, tot = 0;
+#pragma unroll
+      for (int w = 0; w < MO2_WAVES; ++w) { const int k = s_wcnt[c][w]; off += w < wave ? k : 0; tot += k; }
+      if (st[c] == 0) s_idx[off + __popcll(m[c] & ((1ull << lane) - 1ull))] = base + c * MO2_THREADS + tid;
+      n_ok += tot;
+    }
     __syncthreads();
   }
   MoObs ob[MO2_RC];
@@ -925,10 +973,7 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
     }
   }
   // one sweep at pose T: sums -> s_part
-  auto sweep = [&](const double *Tp, bool first) {
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = Tp[i];
+  auto sweep = [&](const double (&T)[12], bool first) {
     double x[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) x[i] = 0.0;
@@ -952,9 +997,11 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
   };
   auto total = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s += s_part[w][id]; return s; };
   auto total_max = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s = fmax(s, s_part[w][id]); return s; };
-  __syncthreads();
-  sweep(s_T, true);
-  __syncthreads();
+  double Tc[12], Tn[12];                           // accepted pose / trial pose, replicated in every thread
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Tc[i] = T_io[12 * slot + i];
+  sweep(Tc, true);
+  __syncthreads();                                 // (A) sums of the sweep are in s_part
   const int num_obs = n_ok;
   double chi2 = total(27), max_err = total_max(28), mu = prm.initial_mu == -1 ? prm.tau * total_max(29) : prm.initial_mu, nu = 2;
   const double initial_chi2 = chi2;
@@ -972,14 +1019,13 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
     }
   };
   load_system();
+  // Two barriers per LM trial: (B) the trial pose is in s_Tn and every wave has read the sums of the sweep before; (A) the new sums are in s_part.
   for (int ig = 0; ig < prm.num_iter && !stop; ++ig) {
     double rho = 0;
     do {
-      __syncthreads();                               // everybody has read the sums of the last sweep
-      double bmax = 0;
       if (wave == 0) {
-        // (A + mu I) delta = B on lanes 0..6: Gauss-Jordan, multipliers broadcast from the pivot column's lane
-        double a[6];
+        // (A + mu I) delta = B on lanes 0..6: Gauss-Jordan, multipliers broadcast from the pivot column's lane (SPD: no pivoting needed)
+        double a[6], bmax = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) a[r] = col[r] + (r == lane ? mu : 0.0);
 #pragma unroll
@@ -999,43 +1045,46 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
         double delta[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) delta[r] = mo2_bcast(a[r], 6);
-        double Tc[12], Tn[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Tc[i] = s_T[i];
-        d_se3_exp_mul(delta, Tc, Tn);                // prediction.add: exp(delta) * T (every lane of the wave, same values)
+        double Tx[12];
+        mo2_exp_mul(delta, Tc, Tx);                  // prediction.add: exp(delta) * T (every lane of the wave, same values)
         if (lane < 12) {
-          double v = Tn[0];
+          double v = Tx[0];
 #pragma unroll
-          for (int i = 1; i < 12; ++i) v = lane == i ? Tn[i] : v;
+          for (int i = 1; i < 12; ++i) v = lane == i ? Tx[i] : v;
           s_Tn[lane] = v;
         }
+        if (lane == 0) s_conv = bmax <= 1e-10 ? 1 : 0;
       }
-      __syncthreads();
-      sweep(s_Tn, false);
-      __syncthreads();
+      __syncthreads();                               // (B)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Tn[i] = s_Tn[i];
+      const int conv = s_conv;
+      sweep(Tn, false);
+      __syncthreads();                               // (A)
       const double new_chi2 = total(27), new_max = total_max(28);
       if (isnan(new_chi2)) { status = 2; stop = true; break; }      // the reference throws here
       rho = chi2 - new_chi2;
       if (rho > 0) {
-        if (tid < 12) s_T[tid] = s_Tn[tid];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tc[i] = Tn[i];
         chi2 = new_chi2; max_err = new_max;
-        bmax = __shfl(bmax, 0, 64);
-        // |B|_inf of the step just taken: wave 0 has it; the other waves learn the decision through LDS
-        if (tid == 0) s_wcnt[0] = bmax <= 1e-10 ? 1 : 0;
         load_system();
+        stop = conv != 0;                            // |B|_inf <= 1e-10 at the pose the accepted step started from
         const double q = 2 * rho - 1, sc = 1 - q * q * q;
         mu *= fmax(1. / 3., sc);
         nu = 2.; trial = 0;
-        __syncthreads();
-        stop = s_wcnt[0] != 0;
       } else {
         mu *= nu; nu *= 2.; ++trial;
         if (trial == 5) stop = true;
       }
     } while (!(rho > 0 || stop));
   }
-  __syncthreads();
-  if (tid < 12) T_io[12 * slot + tid] = s_T[tid];
+  if (tid < 12) {
+    double v = Tc[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) v = tid == i ? Tc[i] : v;
+    T_io[12 * slot + tid] = v;
+  }
   if (tid == 0) {
     svs_pose_opt_stats st;
     st.initial_chi2 = initial_chi2; st.chi2 = chi2; st.max_err = max_err; st.num_obs = num_obs; st.status = status;

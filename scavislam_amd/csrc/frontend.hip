@@ -139,7 +139,13 @@ struct svs_frontend {
   hipEvent_t ev_upload[2] = {}, ev_done[2] = {};
   bool prefetched = false, submitted = false, want_matches = false, want_gated = false;
   int n_submitted = 0;
+  // accept / reject record of the dense tracker's LM loop, per stream (svs_frontend_dense_records)
+  svs_dense_lm_record *d_rec = nullptr; int32_t *d_nrec = nullptr;
+  // optional stage timing (svs_frontend_set_timing): events between the stages of the last call
+  bool timing = false;
+  hipEvent_t ev_stage[SVS_FRONTEND_STAGES + 1] = {};
 };
+constexpr int REC_CAP = 64;
 
 static void fastgrid_for_level(int w, int h, int level, svs_fastgrid *g) {      // stereo_frontend.cpp:73-88 + fast_grid.cpp:23-58
   const int dim = std::max(3 - (int)(level * 0.5), 1);
@@ -171,6 +177,9 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
     if (fe->ev_done[k]) (void)hipEventDestroy(fe->ev_done[k]);
   }
   if (fe->h_out) (void)hipHostFree(fe->h_out);
+  if (fe->d_rec) (void)hipFree(fe->d_rec);
+  if (fe->d_nrec) (void)hipFree(fe->d_nrec);
+  for (hipEvent_t e : fe->ev_stage) if (e) (void)hipEventDestroy(e);
   if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
   delete fe;
   return SVS_OK;
@@ -250,6 +259,9 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
   }
   if (hipHostMalloc((void **)&fe->h_out, fe->h_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(SVS_ERR_HIP);
   if (hipStreamCreateWithFlags(&fe->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(SVS_ERR_HIP);
+  if (hipMalloc(&fe->d_rec, sizeof(svs_dense_lm_record) * REC_CAP * B) != hipSuccess || hipMalloc(&fe->d_nrec, sizeof(int32_t) * B) != hipSuccess ||
+      hipMemsetAsync(fe->d_nrec, 0, sizeof(int32_t) * B, ctx->stream) != hipSuccess)
+    return fail(SVS_ERR_HIP);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SVS_ERR_HIP);
   *out = fe;
   return SVS_OK;
@@ -371,6 +383,7 @@ int frontend_take_device_frames(svs_frontend *fe, const svs_frames_dev *in) {
 
 struct DispView { const float *p; int stride; size_t bstride; };
 // everything behind the arrival of the images: pyramid, (tracking), stereo, FAST, (match, motion-only, gate), cloud.  first: processFirstFrame
+#define STAGE_MARK(k) do { if (fe->timing) SVS_HIP(ctx, hipEventRecord(fe->ev_stage[k], ctx->stream)); } while (0)
 int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
   svs_ctx *ctx = fe->ctx;
   const int B = fe->B, cur = fe->i_cur, prev = fe->i_prev, n = fe->n_launch;
@@ -386,6 +399,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
       return rc;
   }
   double *d_T = fe->d_small, *d_Ta = fe->d_small + 12 * (size_t)B, *d_Tcw = fe->d_small + 24 * (size_t)B, *d_Twa = fe->d_small + 36 * (size_t)B;
+  STAGE_MARK(1);
   if (!first) {                                                                               // "dense tracking"
     if (fe->prm.cuda_build) {
       svs_dense_track_full_args ta{};
@@ -395,6 +409,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
         ta.stride_f[l] = fe->stride[l]; ta.f_bstride[l] = fe->lvl_elems[l]; ta.w[l] = fe->w[l]; ta.h[l] = fe->h[l];
         ta.f[l] = fe->cams[l].f; ta.cx[l] = fe->cams[l].cx; ta.cy[l] = fe->cams[l].cy;
       }
+      ta.d_record_out = fe->d_rec; ta.record_cap = REC_CAP; ta.d_n_record_out = fe->d_nrec;
       if ((rc = svs_dense_track_full(ctx, &ta, d_T, fe->d_passes, B))) return rc;
     } else {
       svs_dense_track_args ta{};
@@ -403,18 +418,22 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
         ta.d_prev_u8[l] = fe->d_pyr[prev][l]; ta.pstride[l] = fe->stride[l]; ta.p_bstride[l] = fe->lvl_elems[l];
         ta.d_cur_u8[l] = fe->d_pyr[cur][l]; ta.c8stride[l] = fe->stride[l]; ta.c8_bstride[l] = fe->lvl_elems[l]; ta.cam_vec[l] = fe->cams[l];
       }
+      ta.d_record_out = fe->d_rec; ta.record_cap = REC_CAP; ta.d_n_record_out = fe->d_nrec;
       if ((rc = svs_dense_track_cpu_sem(ctx, &ta, d_T, fe->d_passes, B))) return rc;
     }
   }
+  STAGE_MARK(2);
   if (fe->prm.use_block_matching) {                                                           // "stereo"
     if ((rc = svs_stereo_compute(fe->stereo, fe->d_pyr[cur][0], fe->stride[0], fe->lvl_elems[0], fe->d_right[fe->i_cur], fe->stride[0], fe->lvl_elems[0], fe->d_disp[cur],
                                  fe->stride[0], fe->lvl_elems[0], B)))
       return rc;
     dv = DispView{fe->d_disp[cur], fe->stride[0], fe->lvl_elems[0]};
   }
+  STAGE_MARK(3);
   const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
   const int trials = first ? (fe->prm.fast_trials > 1 ? fe->prm.fast_trials - 1 : 5) : fe->prm.fast_trials;      // stereo_frontend.cpp:118 / :232
   if ((rc = svs_fast_detect(fe->fast, imgs, fe->stride, fe->lvl_elems, B, trials))) return rc; // "fast"
+  STAGE_MARK(4);
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"
       hipLaunchKernelGGL(frontend_pose_kernel, dim3(B), dim3(64), 0, ctx->stream, (const double *)d_T, (const double *)d_Ta, d_Tcw, d_Twa);
@@ -432,16 +451,20 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
                            (const int32_t *)fe->d_n_groups, fe->prm.num_max_points);
         SVS_LAUNCH_CHECK(ctx);
       }
+      STAGE_MARK(5);
       svs_pose_opt_params po = fe->prm.pose_opt;
       po.min_obs = fe->prm.min_matches;
       if ((rc = svs_motion_only(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, B))) return rc;
+      STAGE_MARK(6);
       if ((rc = svs_process_matched_points_dev(ctx, fe->d_res, fe->d_pts, n, (size_t)fe->max_points, (size_t)fe->max_points, fe->d_n_new, &fe->cams[0], d_T,
                                                fe->prm.max_reproj_error, fe->d_gated, (size_t)fe->max_points, fe->d_ptstats, B)))
         return rc;
     } else {
       SVS_HIP(ctx, hipMemsetAsync(fe->d_pstats, 0, (sizeof(svs_pose_opt_stats) + sizeof(svs_point_stats)) * (size_t)B, ctx->stream));
+      STAGE_MARK(5); STAGE_MARK(6);
     }
-  }
+  } else { STAGE_MARK(5); STAGE_MARK(6); }
+  STAGE_MARK(7);
   for (int l = 0; l < 3; ++l) {                                                               // "dense point cloud" (reference for the next frame)
     if (fe->prm.cuda_build)
       rc = svs_pointcloud_full_pose(ctx, d_T, &fe->cams[l], dv.p, dv.stride, dv.bstride, fe->w[l], fe->h[l], fe->w[l], fe->cloud_elems[l] / 4, 1 << l, fe->d_cloud[l], B);
@@ -449,6 +472,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
       rc = svs_pointcloud_cpu_sem(ctx, dv.p, dv.stride, dv.bstride, &fe->cams[l], l, d_T, fe->d_cloud[l], fe->cloud_elems[l], B);
     if (rc) return rc;
   }
+  STAGE_MARK(8);
   fe->last_disp = dv.p; fe->last_dstride = dv.stride; fe->last_dbstride = dv.bstride;
   return SVS_OK;
 }
@@ -553,6 +577,7 @@ extern "C" int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_de
   SVS_REQUIRE(ctx, fe && h_T_cur_from_actkey && h_T_actkey_from_w && fe->have_prev && !fe->submitted && !fe->prefetched);
   SVS_DEVICE(ctx);
   int rc;
+  if (fe->timing) SVS_HIP(ctx, hipEventRecord(fe->ev_stage[0], ctx->stream));
   if (in && (rc = frontend_take_device_frames(fe, in))) return rc;
   const int stage = fe->i_stage;
   if ((rc = stage_acquire(fe, stage))) return rc;
@@ -623,6 +648,7 @@ extern "C" int svs_frontend_submit_frame(svs_frontend *fe, const uint8_t *h_left
   SVS_REQUIRE(ctx, fe && fe->B == 1 && T_cur_from_actkey && T_actkey_from_w && fe->have_prev && !fe->submitted);
   SVS_DEVICE(ctx);
   int stage, rc;
+  if (fe->timing) SVS_HIP(ctx, hipEventRecord(fe->ev_stage[0], ctx->stream));
   if ((rc = frontend_begin(fe, h_left, lstride, h_right, rstride, h_disp, dstride, &stage))) return rc;
   double *in_T = stage_poses(fe, stage);
   for (int i = 0; i < 12; ++i) { in_T[i] = T_cur_from_actkey[i]; in_T[12 + i] = T_actkey_from_w[i]; }
@@ -698,5 +724,38 @@ extern "C" int svs_frontend_device_view(svs_frontend *fe, int stream, const uint
   }
   if (d_disp) *d_disp = fe->last_disp ? fe->last_disp + fe->last_dbstride * stream : nullptr;
   if (fast) *fast = fe->fast;
+  return SVS_OK;
+}
+
+/* profiling: hipEvents between the stages of the next svs_frontend_process_frame(s) / submit_frame call (off by default: ~4 us of stream time each) */
+extern "C" int svs_frontend_set_timing(svs_frontend *fe, int on) {
+  svs_ctx *ctx = fe ? fe->ctx : nullptr;
+  SVS_REQUIRE(ctx, fe);
+  SVS_DEVICE(ctx);
+  if (on && !fe->ev_stage[0])
+    for (hipEvent_t &e : fe->ev_stage) SVS_HIP(ctx, hipEventCreate(&e));
+  fe->timing = on != 0;
+  return SVS_OK;
+}
+/* blocking: ms[SVS_FRONTEND_STAGES] of the last timed call, in the order of the reference's per_mon_ stages: preprocess (upload / copy + pyramid),
+   dense tracking, stereo, fast, match, pose refinement (calcFastMotionOnly), process points, dense point cloud */
+extern "C" int svs_frontend_stage_times(svs_frontend *fe, float *ms) {
+  svs_ctx *ctx = fe ? fe->ctx : nullptr;
+  SVS_REQUIRE(ctx, fe && ms && fe->timing && fe->ev_stage[0]);
+  SVS_DEVICE(ctx);
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < SVS_FRONTEND_STAGES; ++k) SVS_HIP(ctx, hipEventElapsedTime(&ms[k], fe->ev_stage[k], fe->ev_stage[k + 1]));
+  return SVS_OK;
+}
+/* blocking: the accept / reject record of the dense tracker's LM loop of one stream in the last call (level, accepted, chi2 before / after per chi2
+   evaluation); *n = records produced (only the first min(*n, cap, 64) are stored) */
+extern "C" int svs_frontend_dense_records(svs_frontend *fe, int stream, svs_dense_lm_record *h_rec, int cap, int32_t *n) {
+  svs_ctx *ctx = fe ? fe->ctx : nullptr;
+  SVS_REQUIRE(ctx, fe && stream >= 0 && stream < fe->B && n && cap >= 0 && (cap == 0 || h_rec));
+  SVS_DEVICE(ctx);
+  SVS_HIP(ctx, hipMemcpyAsync(n, fe->d_nrec + stream, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int k = std::min(std::min((int)*n, cap), REC_CAP);
+  if (k > 0) SVS_HIP(ctx, hipMemcpy(h_rec, fe->d_rec + (size_t)stream * REC_CAP, sizeof(svs_dense_lm_record) * (size_t)k, hipMemcpyDeviceToHost));
   return SVS_OK;
 }

@@ -691,6 +691,23 @@ class StereoFrontend:
         self.ctx.check(self.ctx.lib.svs_frontend_poses(self.h, T.ctypes.data, ok.ctypes.data))
         return T.reshape(-1, 3, 4), ok
 
+    STAGES = ("preprocess", "dense_tracking", "stereo", "fast", "match", "pose_refinement", "process_points", "pointcloud")
+
+    def setTiming(self, on):
+        self.ctx.check(self.ctx.lib.svs_frontend_set_timing(self.h, int(on)))
+
+    def stageTimes(self):
+        """ms per stage of the last timed call (the reference's per_mon_ stages, stereo_frontend.cpp:190-302)"""
+        ms = np.zeros(len(self.STAGES), np.float32)
+        self.ctx.check(self.ctx.lib.svs_frontend_stage_times(self.h, ms.ctypes.data))
+        return dict(zip(self.STAGES, [float(v) for v in ms]))
+
+    def denseRecords(self, stream=0):
+        rec = np.zeros(64, DENSE_LM_RECORD_DTYPE)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.svs_frontend_dense_records(self.h, stream, rec.ctypes.data, 64, C.byref(n)))
+        return rec[:min(n.value, 64)].copy()
+
     def recomputeCloud(self, T_cur_from_actkey):
         T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
         self.ctx.check(self.ctx.lib.svs_frontend_recompute_cloud(self.h, T.ctypes.data))
