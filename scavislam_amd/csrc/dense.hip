@@ -837,35 +837,57 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
 //    symmetric positive definite, so no pivoting is needed where the reference's ldlt() pivots), exp(delta) * T on the same wave.
 // Same LM schedule and stopping rules as pose_optimizer.h:134-298; sums in a different order and one reciprocal instead of five divisions
 // per residual => the pose agrees with the oracle to ~1e-12 (test bar 1e-9).
-constexpr int MO2_THREADS = 512, MO2_RC = 2, MO2_WAVES = MO2_THREADS / 64;
+constexpr int MO2_THREADS = 512, MO2_RC = 4, MO2_WAVES = MO2_THREADS / 64;
 struct MoObs { double o[3], q[3]; };
 
+template <bool FIRST>
 __device__ __forceinline__ void mo2_terms(const double (&T)[12], const MoObs &ob, const svs_cam &cam, int robust, double kb, double (&x)[32], double &max_err,
-                                          double *max_diag) {
+                                          double &max_diag) {
   const double *q = ob.q;
   const double X = T[0] * q[0] + T[1] * q[1] + T[2] * q[2] + T[3];
   const double Y = T[4] * q[0] + T[5] * q[1] + T[6] * q[2] + T[7];
   const double Z = T[8] * q[0] + T[9] * q[1] + T[10] * q[2] + T[11];
-  const double fl = cam.f, iz = 1.0 / Z, fiz = fl * iz;
-  double f[3] = {ob.o[0] - (X * fiz + cam.cx), ob.o[1] - (Y * fiz + cam.cy), ob.o[2] - ((X - cam.b) * fiz + cam.cx)};
-  const double A = -fiz, C = fiz * X * iz, D = fiz * Y * iz, E = fiz * (X - cam.b) * iz;
-  double J[18];
-  J[0] = A; J[1] = 0; J[2] = C; J[3] = Y * C; J[4] = Z * A - X * C; J[5] = -Y * A;
-  J[6] = 0; J[7] = A; J[8] = D; J[9] = -Z * A + Y * D; J[10] = -X * D; J[11] = X * A;
-  J[12] = A; J[13] = 0; J[14] = E; J[15] = Y * E; J[16] = Z * A - X * E; J[17] = -Y * A;
-  if (max_diag) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) *max_diag = fmax(*max_diag, fabs(J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c]));
+  const double fl = cam.f, iz = 1.0 / Z, fiz = fl * iz, Xb = X - cam.b;
+  double f0 = ob.o[0] - (X * fiz + cam.cx), f1 = ob.o[1] - (Y * fiz + cam.cy), f2 = ob.o[2] - (Xb * fiz + cam.cx);
+  // frameJac (transformations.h:424-447): rows (A 0 C yC zA-xC -yA), (0 A D -zA+yD -xD xA), (A 0 E yE zA-xE -yA) with A = -f/z, C = f x/z^2, ...
+  const double A = -fiz, C = fiz * X * iz, D = fiz * Y * iz, E = fiz * Xb * iz;
+  const double a3 = Y * C, a4 = Z * A - X * C, a5 = -Y * A;      // row 0, columns 3..5
+  const double b3 = Y * D - Z * A, b4 = -X * D, b5 = X * A;      // row 1
+  const double c3 = Y * E, c4 = Z * A - X * E;                   // row 2 (column 5 = a5)
+  if (FIRST) {
+    const double AA = A * A;
+    double m = fmax(AA + AA, AA);
+    m = fmax(m, C * C + D * D + E * E);
+    m = fmax(m, a3 * a3 + b3 * b3 + c3 * c3);
+    m = fmax(m, a4 * a4 + b4 * b4 + c4 * c4);
+    m = fmax(m, a5 * a5 + b5 * b5 + a5 * a5);
+    max_diag = fmax(max_diag, m);
   }
-  x[27] += mo_weighted_sq(f, robust, kb);
-  max_err = fmax(max_err, fmax(fabs(f[0]), fmax(fabs(f[1]), fabs(f[2]))));
-  int k = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-#pragma unroll
-    for (int c = r; c < 6; ++c) { x[k] += J[r] * J[c] + J[6 + r] * J[6 + c] + J[12 + r] * J[12 + c]; ++k; }
-    x[21 + r] += J[r] * f[0] + J[6 + r] * f[1] + J[12 + r] * f[2];
+  // pseudo-Huber weight (pose_optimizer.h:169-175,426-435): f *= sqrt(k(|f|)) / |f|, chi2 += |w f|^2 = k(|f|)
+  const double ss = f0 * f0 + f1 * f1 + f2 * f2;
+  double chi = ss;
+  if (robust) {
+    const double nrm = fmax(1e-10, sqrt(ss));
+    if (nrm >= kb) {                                             // outliers only: inside the kernel width the weight is sqrt(n^2) / n = 1
+      const double k = 2 * kb * nrm - kb * kb, w = sqrt(k) / nrm;
+      f0 *= w; f1 *= w; f2 *= w;
+      chi = f0 * f0 + f1 * f1 + f2 * f2;
+    }
   }
+  x[27] += chi;
+  max_err = fmax(max_err, fmax(fabs(f0), fmax(fabs(f1), fabs(f2))));
+  // J^T J, upper triangle row-major (21) -- the structural zeros of frameJac are not multiplied out -- and J^T (w f) (6)
+  x[0] += A * A + A * A;          x[1] += 0.0;                     x[2] += A * C + A * E;
+  x[3] += A * a3 + A * c3;        x[4] += A * a4 + A * c4;         x[5] += A * a5 + A * a5;
+  x[6] += A * A;                  x[7] += A * D;                   x[8] += A * b3;
+  x[9] += A * b4;                 x[10] += A * b5;
+  x[11] += C * C + D * D + E * E; x[12] += C * a3 + D * b3 + E * c3; x[13] += C * a4 + D * b4 + E * c4;
+  x[14] += C * a5 + D * b5 + E * a5;
+  x[15] += a3 * a3 + b3 * b3 + c3 * c3; x[16] += a3 * a4 + b3 * b4 + c3 * c4; x[17] += a3 * a5 + b3 * b5 + c3 * a5;
+  x[18] += a4 * a4 + b4 * b4 + c4 * c4; x[19] += a4 * a5 + b4 * b5 + c4 * a5;
+  x[20] += a5 * a5 + b5 * b5 + a5 * a5;
+  x[21] += A * f0 + A * f2;       x[22] += A * f1;                 x[23] += C * f0 + D * f1 + E * f2;
+  x[24] += a3 * f0 + b3 * f1 + c3 * f2; x[25] += a4 * f0 + b4 * f1 + c4 * f2; x[26] += a5 * f0 + b5 * f1 + a5 * f2;
 }
 // value id held by lane `lane` (< 32) after the recursive halving of mo2_wave_reduce
 __device__ __forceinline__ int mo2_id(int lane) { return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4); }
@@ -877,8 +899,12 @@ __device__ __forceinline__ double mo2_wave_reduce(double (&x)[32]) {
     const bool up = (lane & bit) != 0;
 #pragma unroll
     for (int k = 0; k < half; ++k) {
-      const double send = up ? x[k] : x[k + half];
-      const double keep = up ? x[k + half] : x[k];
+      // the two candidates are pinned as VALUES: left alone, the optimiser turns "select of two array elements" into one load at a selected address
+      // before the loops are unrolled -- and the accumulator array then lives (and is stored after every observation) in scratch memory
+      double lo = x[k], hi = x[k + half];
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const double send = up ? lo : hi;
+      const double keep = up ? hi : lo;
       x[k] = keep + __shfl_xor(send, bit, 64);
     }
   }
@@ -887,6 +913,33 @@ __device__ __forceinline__ double mo2_wave_reduce(double (&x)[32]) {
 __device__ __forceinline__ double mo2_bcast(double v, int src_lane) {      // src_lane is a compile-time constant after unrolling
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
+}
+
+// one sweep over the observations at pose T: per-wave sums -> s_part[wave]
+template <bool FIRST>
+__device__ __forceinline__ void mo2_sweep(const double (&T)[12], const MoObs (&ob)[MO2_RC], int n_ok, const int *s_idx, const svs_match_result *__restrict__ res,
+                                          const svs_cam &cam, int robust, double kb, double (*s_part)[32]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double x[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x[i] = 0.0;
+  double me = 0.0, md = 0.0;
+#pragma unroll
+  for (int k = 0; k < MO2_RC; ++k)
+    if (tid + k * MO2_THREADS < n_ok) mo2_terms<FIRST>(T, ob[k], cam, robust, kb, x, me, md);
+  for (int j = tid + MO2_RC * MO2_THREADS; j < n_ok; j += MO2_THREADS) {
+    const svs_match_result &r = res[s_idx[j]];
+    MoObs t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.o[c] = r.obs[c]; t.q[c] = r.xyz_actkey[c]; }
+    mo2_terms<FIRST>(T, t, cam, robust, kb, x, me, md);
+  }
+  const double v = mo2_wave_reduce(x);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { me = fmax(me, __shfl_xor(me, o, 64)); if (FIRST) md = fmax(md, __shfl_xor(md, o, 64)); }
+  const int id = mo2_id(lane);
+  if (lane < 32 && id < 28) s_part[wave][id] = v;
+  if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
 }
 
 // exp(x) * T with everything in registers (d_se3_exp_mul above is an out-of-line call on arrays in scratch memory: fine once per pass of a long
@@ -898,12 +951,16 @@ __device__ __forceinline__ void mo2_exp_mul(const double (&x)[6], const double (
   // are even power series in th^2 (9 terms: remainder < 1e-22), no square root, no division, no libm call on the chain of the trial
   double a, b, c, d;
   if (th2 < 0.25) {
-    const double f[20] = {1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600,
-                          1.0 / 6227020800., 1.0 / 87178291200., 1.0 / 1307674368000., 1.0 / 20922789888000., 1.0 / 355687428096000., 1.0 / 6402373705728000.,
-                          1.0 / 121645100408832000., 1.0 / 2432902008176640000.};      // 1 / (k + 1)!
-    a = f[18]; b = f[19]; d = f[19] / 21.0;
-#pragma unroll
-    for (int k = 8; k >= 0; --k) { a = f[2 * k] - th2 * a; b = f[2 * k + 1] - th2 * b; d = f[2 * k + 2] - th2 * d; }
+    // Horner in th^2 with the coefficients 1 / (k + 1)! written out (a table would live in scratch memory)
+#define SVS_IF(k) (1.0 / k)
+    const double t = th2;
+    a = 1.0 - t * (SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
+        t * (SVS_IF(355687428096000.) - t * SVS_IF(121645100408832000.)))))))));
+    b = SVS_IF(2.) - t * (SVS_IF(24.) - t * (SVS_IF(720.) - t * (SVS_IF(40320.) - t * (SVS_IF(3628800.) - t * (SVS_IF(479001600.) - t * (SVS_IF(87178291200.) -
+        t * (SVS_IF(20922789888000.) - t * (SVS_IF(6402373705728000.) - t * SVS_IF(2432902008176640000.)))))))));
+    d = SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
+        t * (SVS_IF(355687428096000.) - t * (SVS_IF(121645100408832000.) - t * SVS_IF(51090942171709440000.)))))))));
+#undef SVS_IF
     c = b;
   } else {
     double sn, cs;
@@ -936,7 +993,7 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
                                                                         svs_pose_opt_stats *__restrict__ stats) {
   extern __shared__ int s_idx[];                   // [n]: indices of the status-OK records, in list order
   __shared__ double s_part[MO2_WAVES][32];         // per wave: 28 sums (21 of J^T J, 6 of J^T w f, chi2), max error, max diag
-  __shared__ double s_Tn[12];
+  __shared__ double s_Tn[12], s_Tc[12];        // trial pose / accepted pose (the latter is wave 0's)
   __shared__ int s_wcnt[8][MO2_WAVES];
   __shared__ int s_conv;                           // |B|_inf <= 1e-10 at the pose the pending step was taken from
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
@@ -972,35 +1029,20 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
       for (int c = 0; c < 3; ++c) { ob[k].o[c] = r.obs[c]; ob[k].q[c] = r.xyz_actkey[c]; }
     }
   }
-  // one sweep at pose T: sums -> s_part
-  auto sweep = [&](const double (&T)[12], bool first) {
-    double x[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = 0.0;
-    double me = 0.0, md = 0.0;
-#pragma unroll
-    for (int k = 0; k < MO2_RC; ++k)
-      if (tid + k * MO2_THREADS < n_ok) mo2_terms(T, ob[k], cam, prm.robust_kernel, prm.kernel_param, x, me, first ? &md : nullptr);
-    for (int j = tid + MO2_RC * MO2_THREADS; j < n_ok; j += MO2_THREADS) {
-      const svs_match_result &r = res[s_idx[j]];
-      MoObs t;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { t.o[c] = r.obs[c]; t.q[c] = r.xyz_actkey[c]; }
-      mo2_terms(T, t, cam, prm.robust_kernel, prm.kernel_param, x, me, first ? &md : nullptr);
-    }
-    const double v = mo2_wave_reduce(x);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { me = fmax(me, __shfl_xor(me, o, 64)); if (first) md = fmax(md, __shfl_xor(md, o, 64)); }
-    const int id = mo2_id(lane);
-    if (lane < 32 && id < 28) s_part[wave][id] = v;
-    if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
-  };
   auto total = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s += s_part[w][id]; return s; };
   auto total_max = [&](int id) { double s = s_part[0][id]; for (int w = 1; w < MO2_WAVES; ++w) s = fmax(s, s_part[w][id]); return s; };
-  double Tc[12], Tn[12];                           // accepted pose / trial pose, replicated in every thread
+  // the pose of a sweep is wave-uniform: read once, moved to scalar registers (24 SGPRs instead of 24 VGPRs per lane)
+  auto uniform_pose = [&](const double *p, double (&T)[12]) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) Tc[i] = T_io[12 * slot + i];
-  sweep(Tc, true);
+    for (int i = 0; i < 12; ++i) {
+      const double v = p[i];
+      T[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+  };
+  double Tn[12];
+  uniform_pose(T_io + 12 * slot, Tn);
+  if (tid < 12) s_Tc[tid] = T_io[12 * slot + tid];
+  mo2_sweep<true>(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
   __syncthreads();                                 // (A) sums of the sweep are in s_part
   const int num_obs = n_ok;
   double chi2 = total(27), max_err = total_max(28), mu = prm.initial_mu == -1 ? prm.tau * total_max(29) : prm.initial_mu, nu = 2;
@@ -1045,7 +1087,9 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
         double delta[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) delta[r] = mo2_bcast(a[r], 6);
-        double Tx[12];
+        double Tc[12], Tx[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tc[i] = s_Tc[i];
         mo2_exp_mul(delta, Tc, Tx);                  // prediction.add: exp(delta) * T (every lane of the wave, same values)
         if (lane < 12) {
           double v = Tx[0];
@@ -1056,17 +1100,15 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
         if (lane == 0) s_conv = bmax <= 1e-10 ? 1 : 0;
       }
       __syncthreads();                               // (B)
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Tn[i] = s_Tn[i];
+      uniform_pose(s_Tn, Tn);
       const int conv = s_conv;
-      sweep(Tn, false);
+      mo2_sweep<false>(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
       __syncthreads();                               // (A)
       const double new_chi2 = total(27), new_max = total_max(28);
       if (isnan(new_chi2)) { status = 2; stop = true; break; }      // the reference throws here
       rho = chi2 - new_chi2;
       if (rho > 0) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Tc[i] = Tn[i];
+        if (tid < 12) s_Tc[tid] = s_Tn[tid];         // wave 0 only: it is the one that reads s_Tc (next solve) and rewrites s_Tn (after it)
         chi2 = new_chi2; max_err = new_max;
         load_system();
         stop = conv != 0;                            // |B|_inf <= 1e-10 at the pose the accepted step started from
@@ -1079,12 +1121,7 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
       }
     } while (!(rho > 0 || stop));
   }
-  if (tid < 12) {
-    double v = Tc[0];
-#pragma unroll
-    for (int i = 1; i < 12; ++i) v = tid == i ? Tc[i] : v;
-    T_io[12 * slot + tid] = v;
-  }
+  if (tid < 12) T_io[12 * slot + tid] = s_Tc[tid];
   if (tid == 0) {
     svs_pose_opt_stats st;
     st.initial_chi2 = initial_chi2; st.chi2 = chi2; st.max_err = max_err; st.num_obs = num_obs; st.status = status;
