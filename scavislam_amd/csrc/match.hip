@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include "fast_view.h"
+#include <algorithm>
 
 namespace {
 
@@ -89,6 +90,11 @@ struct PointPred {
   double inv[4];          // inverse of the local affine A (matcher.cpp:415-426)
   double key_uv[2];       // anchor_obs_pyr
   double xyz_actkey[3];
+  // for match_kernel2: the keyframe's level image (saves the dependent read of the keyframe record) and the search window's cell geometry --
+  // the one column / row boundary it may cross and the four emit thresholds (+1) of the cells it touches
+  const uint8_t *kimg;
+  int32_t kstride, xb, yb;
+  uint8_t t00m1, t01m1, t10m1, t11m1;      // thresholds - 1 (1..256 does not fit a byte)
 };
 struct MatchParams {
   svs_match_args a;
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0;
   pr.inv[0] = pr.inv[1] = pr.inv[2] = pr.inv[3] = 0; pr.key_uv[0] = ap.anchor_obs_pyr[0]; pr.key_uv[1] = ap.anchor_obs_pyr[1];
   pr.xyz_actkey[0] = pr.xyz_actkey[1] = pr.xyz_actkey[2] = 0;
+  pr.kimg = nullptr; pr.kstride = 0; pr.xb = pr.yb = 0x7fffffff; pr.t00m1 = pr.t01m1 = pr.t10m1 = pr.t11m1 = 255;
   if (ap.kf_index < 0 || ap.kf_index >= A.n_kf) pr.status = SVS_MATCH_NO_ANCHOR;
   else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) pr.status = SVS_MATCH_NONE;  // no feature_tree for that level
   if (pr.status == SVS_MATCH_OK) {
@@ -155,6 +162,19 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) T_actkey_from_anchor[i] = kfT[12 + i];
       d_pose_act(T_actkey_from_anchor, ap.xyz_anchor, pr.xyz_actkey);
+      const int lvl = ap.anchor_level, R = A.search_radius;
+      const svs_keyframe &kf = A.d_kfs[(size_t)slot * A.kf_bstride + ap.kf_index];
+      pr.kimg = kf.pyr[lvl]; pr.kstride = kf.stride[lvl];
+      const int *emit = M.fv.emit + (size_t)slot * M.fv.ncell_total + M.fv.cell_base[lvl];
+      const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
+      const int x0 = pr.ui - R, y0 = pr.vi - R;
+      int cxa = 0, cya = 0;
+      for (int q = 1; q < gx; ++q) cxa += max(x0, 0) >= q * cw;
+      for (int q = 1; q < gy; ++q) cya += max(y0, 0) >= q * chh;
+      pr.xb = cxa + 1 < gx ? (cxa + 1) * cw : 0x7fffffff; pr.yb = cya + 1 < gy ? (cya + 1) * chh : 0x7fffffff;
+      const int cxb = min(cxa + 1, gx - 1), cyb = min(cya + 1, gy - 1);
+      pr.t00m1 = (uint8_t)min(max(emit[cya * gx + cxa], 0), 255); pr.t01m1 = (uint8_t)min(max(emit[cya * gx + cxb], 0), 255);
+      pr.t10m1 = (uint8_t)min(max(emit[cyb * gx + cxa], 0), 255); pr.t11m1 = (uint8_t)min(max(emit[cyb * gx + cxb], 0), 255);
     }
   }
   M.pred[(size_t)slot * A.n_pts + ip] = pr;
@@ -358,6 +378,194 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
   }
 }
 
+
+// ---- round 3: the same matcher with a leaner window scan ---------------------------------------------------------------------------
+// match_kernel above spends ~45 % of its instructions in the scan of the (2R+1)^2 window: two trips of 64 tasks at four positions each, four
+// ballots per trip, per-lane cell look-ups with loops over the grid and vector loads of the emit thresholds.  Here the window's cell geometry is
+// resolved ONCE per point on the scalar unit -- a window is narrower than a cell, so it meets at most one vertical and one horizontal cell
+// boundary: four thresholds in scalar registers --, a lane tests EIGHT adjacent positions of a row from one 8-byte read (17 x 3 tasks = one trip
+// at R = 8), and the sparse hits (~10 of 289) go to the per-wave list through an LDS counter (their order is irrelevant: the winner is the
+// lexicographic minimum of (ZNSSD, quadrant key)).  Everything else -- warp, texture gate, scoring, tie-break, observation -- is the code above.
+constexpr int CAND_CAP2 = 64 * 8;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_kernel2(MatchParams M, svs_match_result *__restrict__ out) {
+  __shared__ int s_cand[WAVES_PER_BLOCK][CAND_CAP2];
+  __shared__ int s_ncand[WAVES_PER_BLOCK];
+  const svs_match_args &A = M.a;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ip = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const int slot = blockIdx.y;
+  if (ip >= A.n_pts) return;                       // wave-uniform
+  const PointPred pp = M.pred[(size_t)slot * A.n_pts + __builtin_amdgcn_readfirstlane(ip)];      // wave-uniform record
+  svs_match_result *o = &out[(size_t)slot * A.out_bstride + ip];
+  const int R = A.search_radius;
+  const int init_dist = A.thr_mean * A.thr_mean * 64;
+  int status = pp.status;
+  double xyz_actkey[3] = {0, 0, 0}, obs[3] = {0, 0, 0};
+  int best = init_dist, bu = 0, bv = 0;
+  if (status == SVS_MATCH_OK) {
+    const int lvl = __builtin_amdgcn_readfirstlane(pp.lvl);
+    const svs_cam cam = A.cam_vec[lvl];
+    const int ui = __builtin_amdgcn_readfirstlane(pp.ui), vi = __builtin_amdgcn_readfirstlane(pp.vi);
+    // ---- the first (at R <= 10: the only) trip of the window scan is requested NOW: its addresses depend on the prediction alone, so the score-map
+    // read travels together with the keyframe pixels of the warp below instead of behind the texture gate
+    const uint8_t *score = M.fv.score[lvl] + (size_t)slot * M.fv.score_bstride[lvl];
+    const int sstride = M.fv.score_stride[lvl];
+    const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
+    const int side = 2 * R + 1, x0 = ui - R, y0 = vi - R;
+    const int xlo = 6, xhi = min(gx * cw, cam.w - 6), ylo = 6, yhi = min(gy * chh, cam.h - 6);      // isInFrame(uv, 6) and inside the cell grid
+    const int nseg = (side + 7) >> 3, ntask = side * nseg;
+    const float inv_nseg = 1.0f / (float)nseg;
+    auto read8 = [&](int task, int &cy, int &cx0, int &g8, bool &row_ok, uint32_t &lo, uint32_t &hi) {
+      const int wy = (int)(((float)task + 0.5f) * inv_nseg);      // exact for task < 2^12
+      g8 = 8 * (task - wy * nseg);
+      cy = y0 + wy; cx0 = x0 + g8;
+      row_ok = task < ntask && cy >= ylo && cy < yhi;
+      lo = 0; hi = 0;
+      if (row_ok) {
+        const uint8_t *srow = score + (size_t)cy * sstride;
+        if (cx0 >= 0 && cx0 + 7 < cam.w) { __builtin_memcpy(&lo, srow + cx0, 4); __builtin_memcpy(&hi, srow + cx0 + 4, 4); }
+        else {
+          for (int k = 0; k < 8; ++k) {
+            const int cx = cx0 + k;
+            const uint32_t b = cx >= 0 && cx < cam.w ? (uint32_t)srow[cx] : 0u;
+            if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
+          }
+        }
+      }
+    };
+    int cy_f, cx0_f, g8_f; bool row_ok_f; uint32_t lo_f, hi_f;
+    read8(lane, cy_f, cx0_f, g8_f, row_ok_f, lo_f, hi_f);
+    // ---- warpAffinve: lane = pixel of the centre 8x8 of the 10x10 patch (as in match_kernel)
+    const double i00 = pp.inv[0], i01 = pp.inv[1], i10 = pp.inv[2], i11 = pp.inv[3];
+    const double key_u = pp.key_uv[0], key_v = pp.key_uv[1];
+    const uint8_t *kimg = pp.kimg;
+    const int kstride = pp.kstride;
+    int keyv;
+    {
+      const int iy = (lane >> 3) + 1, ix = (lane & 7) + 1;
+      const double dx = ix - 5, dy = iy - 5;
+      const double r0 = (i00 * dx + i01 * dy) + key_u;
+      const double r1 = (i10 * dx + i11 * dy) + key_v;
+      const double x = floor(r0), y = floor(r1);
+      uint8_t val;
+      if (!(x >= 0) || !(y >= 0) || x + 1 >= cam.w || y + 1 >= cam.h) val = 0;
+      else {
+        const double sx = r0 - x, sy = r1 - y;
+        const double wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+        const int xi = (int)x, yi = (int)y;
+        const double v00 = kimg[(size_t)yi * kstride + xi], v01 = kimg[(size_t)(yi + 1) * kstride + xi];
+        const double v10 = kimg[(size_t)yi * kstride + xi + 1], v11 = kimg[(size_t)(yi + 1) * kstride + xi + 1];
+        const double s = (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
+        val = (uint8_t)(s < 255. ? s : 255.);
+      }
+      keyv = val;
+    }
+    const int sumA = wave_sum_i32(keyv), sumAA = wave_sum_i32(keyv * keyv);
+    if (sumA * sumA - sumAA < A.thr_std * A.thr_std * 64) status = SVS_MATCH_TEXTURE;
+    else {
+      const uint8_t *cimg = A.d_cur_pyr[lvl] + (size_t)slot * A.cur_bstride[lvl];
+      const int cstride = A.cur_stride[lvl];
+      const uint32_t kd = (uint32_t)keyv | ((uint32_t)__shfl_down(keyv, 1, 64) << 8) | ((uint32_t)__shfl_down(keyv, 2, 64) << 16) |
+                          ((uint32_t)__shfl_down(keyv, 3, 64) << 24);
+      uint32_t key4[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) key4[i] = (uint32_t)__builtin_amdgcn_readlane((int)kd, 4 * i);
+      // the window's cell geometry comes with the prediction (match_predict_kernel): one boundary per axis, four thresholds
+      const int xb = pp.xb, yb = pp.yb;
+      const int t00 = pp.t00m1 + 1, t01 = pp.t01m1 + 1, t10 = pp.t10m1 + 1, t11 = pp.t11m1 + 1;
+      int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-lane running best
+      unsigned gkey = 0xffffffffu;
+      for (int p0 = 0; p0 < ntask; p0 += 64) {
+        if (lane == 0) s_ncand[wave] = 0;
+        int cy = cy_f, cx0 = cx0_f, g8 = g8_f; bool row_ok = row_ok_f; uint32_t lo = lo_f, hi = hi_f;
+        if (p0) read8(p0 + lane, cy, cx0, g8, row_ok, lo, hi);
+        const int tA = cy >= yb ? t10 : t00, tB = cy >= yb ? t11 : t01;
+        unsigned hits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cx = cx0 + k, sc = (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xffu);
+          const bool h = g8 + k < side && cx >= xlo && cx < xhi && sc >= (cx >= xb ? tB : tA);
+          hits |= (unsigned)h << k;
+        }
+        hits = row_ok ? hits : 0u;
+        __builtin_amdgcn_wave_barrier();
+        while (hits) {                                 // sparse: ~10 hits per window
+          const int k = __ffs((int)hits) - 1;
+          hits &= hits - 1;
+          const int pos = atomicAdd(&s_ncand[wave], 1);
+          s_cand[wave][pos] = (cy << 16) | (cx0 + k);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const int ncand = s_ncand[wave];
+        for (int base = 0; base < ncand; base += 64) {
+          if (base + lane < ncand) {
+            const int packed = s_cand[wave][base + lane];
+            const int hx = packed & 0xffff, hy = packed >> 16;
+            const uint8_t *p = cimg + (size_t)(hy - 4) * cstride + (hx - 4);
+            uint32_t sB = 0, sBB = 0, sAB = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              uint32_t v0, v1;
+              __builtin_memcpy(&v0, p + (size_t)r * cstride, 4);
+              __builtin_memcpy(&v1, p + (size_t)r * cstride + 4, 4);
+              sB = __builtin_amdgcn_sad_u8(v0, 0u, sB); sB = __builtin_amdgcn_sad_u8(v1, 0u, sB);
+              sBB = __builtin_amdgcn_udot4(v0, v0, sBB, false); sBB = __builtin_amdgcn_udot4(v1, v1, sBB, false);
+              sAB = __builtin_amdgcn_udot4(v0, key4[2 * r], sAB, false); sAB = __builtin_amdgcn_udot4(v1, key4[2 * r + 1], sAB, false);
+            }
+            const int iB = (int)sB;
+            const int z = sumAA - 2 * (int)sAB - (int)sBB - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
+            // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, key); z must also beat thr_mean.
+            if (z < init_dist) {
+              if (z < gbest) { gbest = z; gx_ = hx; gy_ = hy; }
+              else if (z == gbest && quad_key(hx, hy, cam.w, cam.h) < quad_key(gx_, gy_, cam.w, cam.h)) { gx_ = hx; gy_ = hy; }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      int zmin = gbest;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) zmin = min(zmin, __shfl_xor(zmin, o2, 64));
+      if (zmin != 0x7fffffff) {
+        unsigned long long tie = __ballot(gbest == zmin);
+        if (__popcll(tie) > 1) {
+          unsigned k = gbest == zmin ? quad_key(gx_, gy_, cam.w, cam.h) : 0xffffffffu;
+          unsigned kmin = k;
+#pragma unroll
+          for (int o2 = 1; o2 < 64; o2 <<= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o2, 64));
+          tie = __ballot(gbest == zmin && k == kmin);
+        }
+        const int win = __ffsll((long long)tie) - 1;
+        gbest = zmin;
+        gx_ = __builtin_amdgcn_readlane(gx_, win);
+        gy_ = __builtin_amdgcn_readlane(gy_, win);
+        gkey = 0;
+      }
+      xyz_actkey[0] = pp.xyz_actkey[0]; xyz_actkey[1] = pp.xyz_actkey[1]; xyz_actkey[2] = pp.xyz_actkey[2];
+      if (gkey == 0xffffffffu) { status = SVS_MATCH_NONE; best = init_dist; }
+      else {
+        best = gbest; bu = gx_; bv = gy_;
+        const double inv_factor = 1.0 / (double)(1 << lvl);
+        const float *disp = A.d_disp + (size_t)slot * A.disp_bstride;
+        const double d = disp[(size_t)(bv << lvl) * A.disp_stride + (bu << lvl)] * inv_factor;
+        if (d > 0) {
+          const double sc = (double)(1 << lvl);
+          const float fu_ = (float)bu, fv_ = (float)bv;
+          obs[0] = fu_ * sc; obs[1] = fv_ * sc; obs[2] = (fu_ - d) * sc;
+        } else status = SVS_MATCH_NO_DISP;
+      }
+    }
+  }
+  if (lane == 0) {
+    svs_match_result r;
+    r.status = status; r.u = bu; r.v = bv; r.znssd = best;
+    r.obs[0] = obs[0]; r.obs[1] = obs[1]; r.obs[2] = obs[2];
+    r.xyz_actkey[0] = xyz_actkey[0]; r.xyz_actkey[1] = xyz_actkey[1]; r.xyz_actkey[2] = xyz_actkey[2];
+    *o = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out) {
@@ -386,7 +594,11 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
   SVS_LAUNCH_CHECK(ctx);
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
-  hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
+  // the lean scan resolves a window's cells once per point: it needs windows narrower than a cell (always so for the reference's grids and radii)
+  bool lean = !ctx->match_legacy;
+  for (int l = 0; l < M.fv.n_levels; ++l) lean = lean && 2 * a->search_radius + 1 <= std::min(M.fv.cell_w[l], M.fv.cell_h[l]);
+  if (lean) hipLaunchKernelGGL(match_kernel2, grid, block, 0, ctx->stream, M, d_out);
+  else hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
