@@ -286,6 +286,78 @@ __device__ void d_se3_exp_mul(const double *x, const double *T, double *Tn) {   
   }
 }
 
+__device__ __forceinline__ double mo2_bcast(double v, int src_lane) {      // src_lane is a compile-time constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// A x = b for a symmetric positive definite 6x6 system on seven lanes of a wave: lane c < 6 holds column c of A in col[0..6), lane 6 holds b.
+// Gauss-Jordan, the multipliers of a step broadcast from the pivot column's lane; no pivoting (the reference's ldlt() pivots, which an SPD matrix
+// does not need).  Every lane returns x in x[0..6).
+__device__ __forceinline__ void wave_solve6(const double (&col)[6], double (&x)[6]) {
+  double a[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) a[r] = col[r];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double ip = 1.0 / mo2_bcast(a[k], k);
+    const double ak = a[k] * ip;               // row k of this lane's column, scaled
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r == k) continue;
+      const double m = mo2_bcast(a[r], k);     // element (r, k) of the pivot column
+      a[r] -= m * ak;
+    }
+    a[k] = ak;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) x[r] = mo2_bcast(a[r], 6);
+}
+// exp(x) * T with everything in registers (d_se3_exp_mul above is an out-of-line call on arrays in scratch memory)
+__device__ __forceinline__ void mo2_exp_mul(const double (&x)[6], const double (&T)[12], double (&Tn)[12]) {
+  const double w0 = x[3], w1 = x[4], w2 = x[5];
+  const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
+  // a = sin(th) / th, b = c = (1 - cos th) / th^2, d = (th - sin th) / th^3.  An LM step rotates by far less than half a radian: there the three
+  // are even power series in th^2 (9 terms: remainder < 1e-22), no square root, no division, no libm call on the chain of the trial
+  double a, b, c, d;
+  if (th2 < 0.25) {
+    // Horner in th^2 with the coefficients 1 / (k + 1)! written out (a table would live in scratch memory)
+#define SVS_IF(k) (1.0 / k)
+    const double t = th2;
+    a = 1.0 - t * (SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
+        t * (SVS_IF(355687428096000.) - t * SVS_IF(121645100408832000.)))))))));
+    b = SVS_IF(2.) - t * (SVS_IF(24.) - t * (SVS_IF(720.) - t * (SVS_IF(40320.) - t * (SVS_IF(3628800.) - t * (SVS_IF(479001600.) - t * (SVS_IF(87178291200.) -
+        t * (SVS_IF(20922789888000.) - t * (SVS_IF(6402373705728000.) - t * SVS_IF(2432902008176640000.)))))))));
+    d = SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
+        t * (SVS_IF(355687428096000.) - t * (SVS_IF(121645100408832000.) - t * SVS_IF(51090942171709440000.)))))))));
+#undef SVS_IF
+    c = b;
+  } else {
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const double ith2 = 1.0 / th2;
+    a = sn / th; b = (1.0 - cs) * ith2; c = b; d = (th - sn) * ith2 / th;
+  }
+  // W = hat(w), W2 = W * W
+  const double W[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+  double W2[9], R[9], V[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { R[i] = a * W[i] + b * W2[i]; V[i] = c * W[i] + d * W2[i]; }
+  R[0] += 1; R[4] += 1; R[8] += 1;
+  V[0] += 1; V[4] += 1; V[8] += 1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double t = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+    Tn[4 * i + 3] += t;
+  }
+}
+
+
 struct TrackArgs {
   LevelArgs lv[3];
   size_t cloud_b[3], prev_b[3], f_b[3], c8_b[3];
@@ -361,16 +433,17 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   int sweep = 0;
   auto all_workgroups = [&]() {      // s_out[0..NSUM] <- sum over the workgroups of this stream
     if (!MULTI) return;
+    // write-through 8-byte words + one arrival counter (relaxed, agent scope): no fence that would write an XCD's whole L2 back
     double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * nwg * 32;
-    if (threadIdx.x <= NSUM) buf[wg * 32 + threadIdx.x] = s_out[threadIdx.x];
-    __threadfence();
+    if (threadIdx.x <= NSUM) __hip_atomic_store(buf + wg * 32 + threadIdx.x, s_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ++sweep;
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(G.bar + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(G.bar + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)sweep * (unsigned)nwg;
       long spin = 0;
-      for (; spin < (1l << 24) && __hip_atomic_load(G.bar + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      for (; spin < (1l << 24) && __hip_atomic_load(G.bar + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
       // a sibling workgroup never arrived (they are not all resident: the device is shared with other work).  Summing what is
       // there would let the replicated LM bookkeeping diverge silently: raise the stream's failure flag instead -- every
       // workgroup sees it at its next barrier at the latest, the pose is left as it came in and passes_out reports -1.
@@ -378,10 +451,9 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       s_failed = __hip_atomic_load(G.bar + G.fail_off + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (threadIdx.x <= NSUM) {
       double acc = 0;
-      for (int w = 0; w < nwg; ++w) acc += buf[w * 32 + threadIdx.x];
+      for (int w = 0; w < nwg; ++w) acc += __hip_atomic_load(buf + w * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_out[threadIdx.x] = acc;
     }
     __syncthreads();
@@ -417,16 +489,30 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     bool stop = false;
     for (int it = 0; it < 15 && !stop; ++it) {
       if (threadIdx.x >= 64 && threadIdx.x < 76) s_Tj[level][threadIdx.x - 64] = s_T[threadIdx.x - 64];   // the reference's H,b pass of this iteration ran at s_T
-      if (threadIdx.x == 0) {
-        double H[36], nb[6], x[6];
-        int k = 0;
-        for (int c = 0; c < 6; ++c) for (int r = 0; r <= c; ++r) { H[6 * r + c] = s_H[k]; H[6 * c + r] = s_H[k]; ++k; }
-        for (int q = 0; q < 6; ++q) nb[q] = -s_H[21 + q];
-        d_solve6(H, nb, x);                         // H.ldlt().solve(-Jres): undamped (dense_tracking.cpp:332)
-        double Tn[12];
-        d_se3_exp_mul(x, s_T, Tn);
-        for (int i = 0; i < 12; ++i) s_Tn[i] = Tn[i];
-        for (int i = 0; i < 6; ++i) s_x[i] = x[i];
+      if (threadIdx.x < 64) {                        // H.ldlt().solve(-Jres): undamped (dense_tracking.cpp:332) -- on seven lanes of wave 0
+        const int lane = threadIdx.x;
+        double col[6], x[6], Tc[12], Tn[12];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int lo = r < lane ? r : lane, hi = r < lane ? lane : r;      // packed upper by column: (lo, hi) at hi (hi + 1) / 2 + lo
+          col[r] = lane < 6 ? s_H[hi * (hi + 1) / 2 + lo] : (lane == 6 ? -s_H[21 + r] : (r == 0 ? 1.0 : 0.0));
+        }
+        wave_solve6(col, x);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tc[i] = s_T[i];
+        mo2_exp_mul(x, Tc, Tn);
+        if (lane < 12) {
+          double v = Tn[0];
+#pragma unroll
+          for (int i = 1; i < 12; ++i) v = lane == i ? Tn[i] : v;
+          s_Tn[lane] = v;
+        }
+        if (lane < 6) {
+          double v = x[0];
+#pragma unroll
+          for (int i = 1; i < 6; ++i) v = lane == i ? x[i] : v;
+          s_x[lane] = v;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -910,10 +996,6 @@ __device__ __forceinline__ double mo2_wave_reduce(double (&x)[32]) {
   }
   return x[0] + __shfl_xor(x[0], 32, 64);
 }
-__device__ __forceinline__ double mo2_bcast(double v, int src_lane) {      // src_lane is a compile-time constant after unrolling
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
 
 // one sweep over the observations at pose T: per-wave sums -> s_part[wave]
 template <bool FIRST>
@@ -940,52 +1022,6 @@ __device__ __forceinline__ void mo2_sweep(const double (&T)[12], const MoObs (&o
   const int id = mo2_id(lane);
   if (lane < 32 && id < 28) s_part[wave][id] = v;
   if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
-}
-
-// exp(x) * T with everything in registers (d_se3_exp_mul above is an out-of-line call on arrays in scratch memory: fine once per pass of a long
-// sweep, not on the critical chain of a 3 us trial)
-__device__ __forceinline__ void mo2_exp_mul(const double (&x)[6], const double (&T)[12], double (&Tn)[12]) {
-  const double w0 = x[3], w1 = x[4], w2 = x[5];
-  const double th2 = w0 * w0 + w1 * w1 + w2 * w2, th = sqrt(th2);
-  // a = sin(th) / th, b = c = (1 - cos th) / th^2, d = (th - sin th) / th^3.  An LM step rotates by far less than half a radian: there the three
-  // are even power series in th^2 (9 terms: remainder < 1e-22), no square root, no division, no libm call on the chain of the trial
-  double a, b, c, d;
-  if (th2 < 0.25) {
-    // Horner in th^2 with the coefficients 1 / (k + 1)! written out (a table would live in scratch memory)
-#define SVS_IF(k) (1.0 / k)
-    const double t = th2;
-    a = 1.0 - t * (SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
-        t * (SVS_IF(355687428096000.) - t * SVS_IF(121645100408832000.)))))))));
-    b = SVS_IF(2.) - t * (SVS_IF(24.) - t * (SVS_IF(720.) - t * (SVS_IF(40320.) - t * (SVS_IF(3628800.) - t * (SVS_IF(479001600.) - t * (SVS_IF(87178291200.) -
-        t * (SVS_IF(20922789888000.) - t * (SVS_IF(6402373705728000.) - t * SVS_IF(2432902008176640000.)))))))));
-    d = SVS_IF(6.) - t * (SVS_IF(120.) - t * (SVS_IF(5040.) - t * (SVS_IF(362880.) - t * (SVS_IF(39916800.) - t * (SVS_IF(6227020800.) - t * (SVS_IF(1307674368000.) -
-        t * (SVS_IF(355687428096000.) - t * (SVS_IF(121645100408832000.) - t * SVS_IF(51090942171709440000.)))))))));
-#undef SVS_IF
-    c = b;
-  } else {
-    double sn, cs;
-    sincos(th, &sn, &cs);
-    const double ith2 = 1.0 / th2;
-    a = sn / th; b = (1.0 - cs) * ith2; c = b; d = (th - sn) * ith2 / th;
-  }
-  // W = hat(w), W2 = W * W
-  const double W[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
-  double W2[9], R[9], V[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { R[i] = a * W[i] + b * W2[i]; V[i] = c * W[i] + d * W2[i]; }
-  R[0] += 1; R[4] += 1; R[8] += 1;
-  V[0] += 1; V[4] += 1; V[8] += 1;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double t = V[3 * i] * x[0] + V[3 * i + 1] * x[1] + V[3 * i + 2] * x[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Tn[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
-    Tn[4 * i + 3] += t;
-  }
 }
 
 __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
@@ -1066,27 +1102,13 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
     double rho = 0;
     do {
       if (wave == 0) {
-        // (A + mu I) delta = B on lanes 0..6: Gauss-Jordan, multipliers broadcast from the pivot column's lane (SPD: no pivoting needed)
-        double a[6], bmax = 0;
+        // (A + mu I) delta = B on lanes 0..6 (wave_solve6)
+        double a[6], bmax = 0, delta[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) a[r] = col[r] + (r == lane ? mu : 0.0);
 #pragma unroll
         for (int r = 0; r < 6; ++r) bmax = fmax(bmax, fabs(mo2_bcast(col[r], 6)));
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const double ip = 1.0 / mo2_bcast(a[k], k);
-          const double ak = a[k] * ip;               // row k of this lane's column, scaled
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            if (r == k) continue;
-            const double m = mo2_bcast(a[r], k);     // element (r, k) of the pivot column
-            a[r] -= m * ak;
-          }
-          a[k] = ak;
-        }
-        double delta[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) delta[r] = mo2_bcast(a[r], 6);
+        wave_solve6(a, delta);
         double Tc[12], Tx[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) Tc[i] = s_Tc[i];
