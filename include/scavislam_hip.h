@@ -419,6 +419,10 @@ int svs_frontend_wait_frame(svs_frontend *fe, svs_frame_result *out, svs_match_r
    (frame_grabber.hpp:93-155: the grabber thread fills the next frame while the front end works on the current one).  The following
    first_frame / submit_frame / process_frame must pass NULL images. */
 int svs_frontend_prefetch_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp, int dstride);
+/* the pinned host buffers the NEXT frame is staged in (w x h each, contiguous; right image or disparity per use_block_matching): a frame grabber that writes
+   its images straight into them and passes these pointers (stride = w) to the next first_frame / submit_frame / process_frame / prefetch_frame call saves the
+   host-side copy (1.5 MB per 640 x 480 frame).  The pointers change with every such call (two staging sets) */
+int svs_frontend_staging_view(svs_frontend *fe, uint8_t **h_left, uint8_t **h_right, float **h_disp);
 /* ---- all streams at once, frames in DEVICE memory (camera DMA target, decoder output, another kernel's result) ---- */
 typedef struct {                       /* images of all streams: stream b at + b * bstride (elements); unused members NULL */
   const uint8_t *d_left; int32_t lstride; size_t l_bstride;

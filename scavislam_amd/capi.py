@@ -146,6 +146,7 @@ _SIGS = {
     "svs_frontend_submit_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "svs_frontend_wait_frame": [C.c_void_p, C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
     "svs_frontend_prefetch_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_frontend_staging_view": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
     "svs_frontend_input_view": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)],
     "svs_frontend_first_frames": [C.c_void_p, C.POINTER(FramesDev)],

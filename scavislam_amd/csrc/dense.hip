@@ -416,7 +416,7 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 // every workgroup add the partials up in the same fixed order, and each then runs the identical LM bookkeeping redundantly,
 // so no pose has to be broadcast.  Partials are double-buffered by pass parity: a workgroup can only overwrite a buffer after
 // everyone has passed the barrier of the pass in between, i.e. after everyone has read it.
-struct TrackMulti { double *part; unsigned *bar; int fail_off; };      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
+struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast; };      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
@@ -470,6 +470,23 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   // undamped solve at the unchanged T (mu is never applied, dense_tracking.cpp:332), reject again and
   // stop (trial == 2, :379-384): that is "stop on the first rejection" here.
   for (int level = 2; level >= 0; --level) {
+    // MULTI: the coarsest level (1/16 of the samples: less than one per lane and workgroup) is run by workgroup 0 ALONE -- a sweep of it is
+    // shorter than the cross-workgroup exchange that sharing it would cost -- and the others pick the pose up when it is done
+    const bool solo = MULTI && level == 2;
+    if (solo && wg != 0) {
+      if (threadIdx.x == 0) {
+        long spin = 0;
+        for (; spin < (1l << 24) && __hip_atomic_load(reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++spin)
+          __builtin_amdgcn_s_sleep(2);
+        if (spin >= (1l << 24)) s_failed = true;
+      }
+      __syncthreads();
+      if (s_failed) { failed = true; break; }
+      if (threadIdx.x < 12) s_T[threadIdx.x] = __hip_atomic_load(G.bcast + (size_t)slot * 16 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      continue;
+    }
+    const int lfirst = solo ? (int)threadIdx.x : first, lnwg = solo ? 1 : nwg;
     LevelArgs L = A.lv[level];
     L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
     if (U8SRC) L.cur8 += slot * A.c8_b[level];
@@ -477,8 +494,8 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);          // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
-    all_workgroups();
+    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, lfirst, lnwg);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    if (!solo) all_workgroups();
     if (MULTI && s_failed) { failed = true; break; }
     ++passes;
     float chi2 = (float)s_out[27];
@@ -517,8 +534,8 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, first, nwg);        // new_chi2 (:335-367) + H,b for the next iteration
-      all_workgroups();
+      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, lfirst, lnwg);      // new_chi2 (:335-367) + H,b for the next iteration
+      if (!solo) all_workgroups();
       if (MULTI && s_failed) { failed = true; break; }
       ++passes;
       const float new_chi2 = (float)s_out[27];
@@ -538,6 +555,13 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       }
     }
     if (failed) break;
+    if (solo) {                                      // workgroup 0 hands the pose of the coarsest level to its siblings
+      __syncthreads();
+      if (threadIdx.x < 12) __hip_atomic_store(G.bcast + (size_t)slot * 16 + threadIdx.x, s_T[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 12), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if (wg != 0) return;
@@ -702,19 +726,21 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
   A.rec = a->d_record_out; A.rec_cap = a->d_record_out ? a->record_cap : 0; A.n_rec = a->d_n_record_out;
   SVS_REQUIRE(ctx, !a->d_record_out || a->record_cap > 0);
   // latency mode: with few streams, NW workgroups share each stream's sweeps (they must all be resident: NW * batch <= 128 CUs)
-  int nwg = batch <= 32 ? 4 : 1;      // measured (B = 1 / 8): 4 workgroups 0.26 ms / 19.4k fps, 8: 0.26 / 15.6k, 16: 0.28 / 10.4k, 1: 0.34 / 14.4k;
-                                      // 2 per stream at 64 streams lose to one (barrier + redundant LM tails)
+  // workgroups per stream in latency mode.  Round 3 (exchange without a device-wide fence, coarsest level on one workgroup), B = 1:
+  // 2 -> 0.211, 4 -> 0.165, 8 -> 0.160, 16 -> 0.184 ms per frame; round 2 (fence per sweep): 4 -> 0.26, 8 -> 0.26, 16 -> 0.28, 1 -> 0.34 ms
+  int nwg = batch <= 16 ? 8 : (batch <= 32 ? 4 : 1);
   if (ctx->trk_nwg) nwg = ctx->trk_nwg;
-  TrackMulti G{nullptr, nullptr, 0};
+  TrackMulti G{nullptr, nullptr, 0, nullptr};
   if (nwg >= 2) {
     double *scratch = nullptr;
     const size_t n_part = (size_t)batch * 2 * nwg * 32;
-    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch);          // + one counter word and one failure flag (4 + 4 bytes) per stream
+    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch + (size_t)batch * 16);      // + one counter word and one failure flag (4 + 4 bytes) per stream + the hand-over words
     if (rc) return rc;
     G.part = scratch;
     G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
     G.fail_off = batch;
-    SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (size_t)batch, ctx->stream));
+    G.bcast = scratch + n_part + (size_t)batch;
+    SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * ((size_t)batch + (size_t)batch * 16), ctx->stream));
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create

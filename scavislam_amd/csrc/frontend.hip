@@ -339,6 +339,19 @@ extern "C" int svs_frontend_input_view(svs_frontend *fe, uint8_t **d_left, int32
   return SVS_OK;
 }
 
+/* the pinned host buffers the NEXT frame of stream 0 is staged in (w x h, contiguous): a frame grabber that writes its images straight into them
+   (and then passes these pointers with stride = w) saves the host-side copy of 1.5 MB per 640 x 480 frame.  Valid until the next first_frame /
+   submit_frame / process_frame / prefetch_frame call, which moves on to the other staging set. */
+extern "C" int svs_frontend_staging_view(svs_frontend *fe, uint8_t **h_left, uint8_t **h_right, float **h_disp) {
+  if (!fe) return SVS_ERR_INVALID;
+  const size_t px = (size_t)fe->w[0] * fe->h[0];
+  uint8_t *base = fe->h_in[fe->i_stage];
+  if (h_left) *h_left = base;
+  if (h_right) *h_right = base + px;
+  if (h_disp) *h_disp = reinterpret_cast<float *>(base + 2 * px);
+  return SVS_OK;
+}
+
 namespace {
 // stage the caller's images (stream 0) in pinned memory and enqueue their upload into the "current" slots on `s`
 int frontend_upload(svs_frontend *fe, int stage, hipStream_t s, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp,
@@ -349,13 +362,19 @@ int frontend_upload(svs_frontend *fe, int stage, hipStream_t s, const uint8_t *h
   SVS_REQUIRE(ctx, fe->prm.use_block_matching ? (h_right && rstride >= w) : (h_disp && dstride >= w));
   uint8_t *in_left = fe->h_in[stage], *in_right = fe->h_in[stage] + (size_t)w * h;
   float *in_disp = reinterpret_cast<float *>(fe->h_in[stage] + 2 * (size_t)w * h);
-  for (int y = 0; y < h; ++y) __builtin_memcpy(in_left + (size_t)y * w, h_left + (size_t)y * lstride, w);
+  // a frame the caller produced IN the staging set (svs_frontend_staging_view) needs no copy; a contiguous image is one memcpy
+  auto stage_rows = [](void *dst, const void *src, size_t row_bytes, size_t sstride_bytes, int rows) {
+    if (dst == src) return;
+    if (sstride_bytes == row_bytes) { __builtin_memcpy(dst, src, row_bytes * (size_t)rows); return; }
+    for (int y = 0; y < rows; ++y) __builtin_memcpy(static_cast<char *>(dst) + (size_t)y * row_bytes, static_cast<const char *>(src) + (size_t)y * sstride_bytes, row_bytes);
+  };
+  stage_rows(in_left, h_left, (size_t)w, (size_t)lstride, h);
   SVS_HIP(ctx, hipMemcpy2DAsync(fe->d_pyr[fe->i_cur][0], fe->stride[0], in_left, w, w, h, hipMemcpyHostToDevice, s));
   if (fe->prm.use_block_matching) {
-    for (int y = 0; y < h; ++y) __builtin_memcpy(in_right + (size_t)y * w, h_right + (size_t)y * rstride, w);
+    stage_rows(in_right, h_right, (size_t)w, (size_t)rstride, h);
     SVS_HIP(ctx, hipMemcpy2DAsync(fe->d_right[fe->i_cur], fe->stride[0], in_right, w, w, h, hipMemcpyHostToDevice, s));
   } else {
-    for (int y = 0; y < h; ++y) __builtin_memcpy(in_disp + (size_t)y * w, h_disp + (size_t)y * dstride, sizeof(float) * w);
+    stage_rows(in_disp, h_disp, sizeof(float) * (size_t)w, sizeof(float) * (size_t)dstride, h);
     SVS_HIP(ctx, hipMemcpy2DAsync(fe->d_disp[fe->i_cur], sizeof(float) * fe->stride[0], in_disp, sizeof(float) * w, sizeof(float) * w, h, hipMemcpyHostToDevice, s));
   }
   return SVS_OK;

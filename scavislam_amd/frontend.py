@@ -612,6 +612,15 @@ class StereoFrontend:
         self.ctx.check(self.ctx.lib.svs_frontend_set_candidates_grouped(self.h, stream, pts.ctypes.data, len(pts), ge.ctypes.data, len(ge)))
         self.n_points[stream] = len(pts)
 
+    def stagingView(self):
+        """numpy views (left u8 [h, w], right u8 [h, w], disp f32 [h, w]) of the pinned buffers the next frame is staged in: a frame written into
+        them and passed on as it is needs no host-side copy"""
+        p = [C.c_void_p() for _ in range(3)]
+        self.ctx.check(self.ctx.lib.svs_frontend_staging_view(self.h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2])))
+        h, w = self.cam["h"], self.cam["w"]
+        mk = lambda ptr, ct, dt: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(h, w)).view(dt)
+        return mk(p[0], C.c_uint8, np.uint8), mk(p[1], C.c_uint8, np.uint8), mk(p[2], C.c_float, np.float32)
+
     def prefetchFrame(self, left, right=None, disp=None):
         left, right, disp = self._img(left, np.uint8), self._img(right, np.uint8), self._img(disp, np.float32)
         w = self.cam["w"]
