@@ -34,7 +34,9 @@ enum {
   SVS_ERR_HIP = 2,          /* HIP runtime error; see svs_last_error */
   SVS_ERR_NO_DEVICE = 3,    /* no gfx950 device / kernels not loadable */
   SVS_ERR_CAPACITY = 4,     /* caller-provided capacity too small */
-  SVS_ERR_UNSUPPORTED = 5
+  SVS_ERR_UNSUPPORTED = 5,
+  SVS_ERR_BUSY = 6          /* the workgroups of a multi-workgroup kernel could not synchronise within its bounded wait (the device is shared with
+                               other work): nothing was applied, the call may be retried */
 };
 
 #define SVS_NUM_PYR_LEVELS 3   /* global.h:107 */
@@ -500,6 +502,9 @@ int svs_ba_window_update(svs_ba *ba, int P, const int32_t *h_pose_ids, const dou
                          const double *h_psi, const int32_t *h_anchor_pose_ids, int n_new, const svs_ba_edge *h_new_obs, int C,
                          const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm);
 int svs_ba_window_reset(svs_ba *ba);
+/* drop the stored observations of keyframes that will never be part of a window again (marginalised / removed from the map): the store is otherwise
+   grow-only, and every svs_ba_window_update filters and sorts all of it.  A failed svs_ba_window_update leaves the store as it found it. */
+int svs_ba_window_forget_keyframes(svs_ba *ba, const int32_t *h_pose_ids, int n);
 /* optimizer.optimize(num_iters) (slam_graph.cpp:346) incl. LM control flow; allreduce may be
    NULL (single GPU) */
 int svs_ba_optimize(svs_ba *ba, svs_allreduce_fn allreduce, void *user, svs_ba_stats *stats);

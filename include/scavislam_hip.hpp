@@ -381,6 +381,24 @@ struct GpuIntrinsics { float focal_length, pp_x, pp_y; void set(double fl, doubl
 struct GpuMatrix34 { float data_colmajor[12]; void set(const double *m_colmajor) { for (int i = 0; i < 12; ++i) data_colmajor[i] = (float)m_colmajor[i]; } };
 struct GpuMatrix4 { float data_colmajor[16]; void set(const double *m_colmajor) { for (int i = 0; i < 16; ++i) data_colmajor[i] = (float)m_colmajor[i]; } };
 struct GpuTrackingData { double hessian[21], jacobian_times_res[6]; };      // packed upper by column, as GpuSymMatrix6 (f64 sums here)
+// The reference's own result layout (gpu/dense_tracking.cuh:40-277): 21 + 6 FLOATS with the copyTo members its caller uses
+// (`tracking_data.hessian.copyTo(H.data())`, dense_tracking.cpp:100-104), for a host that keeps the reference's loop untouched.  The sums are
+// still formed in f64 on the device and narrowed once at the end.
+struct GpuVector6F32 {
+  static const int NUM_ROWS = 6;
+  float data[NUM_ROWS];
+  void copyTo(double *vec) const { for (int i = 0; i < NUM_ROWS; ++i) vec[i] = data[i]; }
+};
+struct GpuSymMatrix6F32 {
+  static const int NUM_ROWS = 6;
+  float data[21];
+  void copyTo(double *mat_colmajor) const {      // gpu/dense_tracking.cuh:118-132
+    int i = 0;
+    for (int c = 0; c < NUM_ROWS; ++c)
+      for (int r = 0; r <= c; ++r) { const float v = data[i]; mat_colmajor[r + NUM_ROWS * c] = v; mat_colmajor[c + NUM_ROWS * r] = v; ++i; }
+  }
+};
+struct GpuTrackingDataF32 { GpuSymMatrix6F32 hessian; GpuVector6F32 jacobian_times_res; };
 inline bool computePointCloud(const Context &c, const GpuMatrix4 &TQ_actkey_from_cur, const float *d_disparities, int width, int height, int stride_in,
                               int stride_out, int factor, float *d_point_cloud4) {
   return c.check(svs_pointcloud_full(c.get(), TQ_actkey_from_cur.data_colmajor, d_disparities, width, height, stride_in, stride_out, factor, d_point_cloud4)) &&
@@ -396,6 +414,15 @@ class GpuTracker {
     if (!pass(d_img_prev, d_point_cloud_prev4, T_cur_from_prev, K, width, height, stride_float_img, stride_float4_img, 1, &s)) return false;
     for (int i = 0; i < 21; ++i) tracking_result->hessian[i] = s.H[i];
     for (int i = 0; i < 6; ++i) tracking_result->jacobian_times_res[i] = s.b[i];
+    return true;
+  }
+  // the same call with the reference's result type (21 + 6 floats)
+  bool jacobianReduction(const float *d_img_prev, const float *d_point_cloud_prev4, const GpuMatrix34 &T_cur_from_prev, const GpuIntrinsics &K, int width, int height,
+                         int stride_float_img, int stride_float4_img, GpuTrackingDataF32 *tracking_result) {
+    GpuTrackingData d;
+    if (!jacobianReduction(d_img_prev, d_point_cloud_prev4, T_cur_from_prev, K, width, height, stride_float_img, stride_float4_img, &d)) return false;
+    for (int i = 0; i < 21; ++i) tracking_result->hessian.data[i] = (float)d.hessian[i];
+    for (int i = 0; i < 6; ++i) tracking_result->jacobian_times_res.data[i] = (float)d.jacobian_times_res[i];
     return true;
   }
   float chi2(const float *d_img_prev, const float *d_point_cloud_prev4, const GpuMatrix34 &T_cur_from_prev, const GpuIntrinsics &K, int width, int height,

@@ -139,6 +139,11 @@ class SlamGraphOptimizer:
     def windowReset(self):
         self.ctx.check(self.ctx.lib.svs_ba_window_reset(self.h))
 
+    def windowForgetKeyframes(self, pose_ids):
+        """drop the stored observations of keyframes that will never be in a window again"""
+        ids = np.ascontiguousarray(pose_ids, np.int32)
+        self.ctx.check(self.ctx.lib.svs_ba_window_forget_keyframes(self.h, ids.ctypes.data, len(ids)))
+
     def reset_state(self, poses, psi):
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
         psi = np.ascontiguousarray(psi, np.float64).reshape(-1, 3)

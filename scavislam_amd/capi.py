@@ -173,6 +173,7 @@ _SIGS = {
     "svs_ba_window_update": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                              C.c_void_p, C.POINTER(Cam), C.POINTER(BaParams)],
     "svs_ba_window_reset": [C.c_void_p],
+    "svs_ba_window_forget_keyframes": [C.c_void_p, C.c_void_p, C.c_int],
     "svs_ba_optimize": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BaStats)],
     "svs_ba_optimize_batch": [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BaStats)],
     "svs_ba_get_state": [C.c_void_p, C.c_void_p, C.c_void_p],

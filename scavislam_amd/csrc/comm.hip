@@ -7,7 +7,15 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
+// The handful of RCCL declarations this file needs, written out (the library is bound at run time with dlopen; building the single-GPU product must
+// not require the rccl development headers).  Values are the stable NCCL 2.x ABI: ncclFloat64 = 8, ncclSum = 0, a 128-byte unique id.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 struct svs_comm {
   svs_ctx *ctx = nullptr;

@@ -1,8 +1,10 @@
 // Drives the C++ adaptor classes (include/scavislam_hip.hpp, the reference-named call surfaces) on the
 // GPU and prints results as text; tests/test_gpu_cpp_adaptor.py compares them with the CPU oracle.
 // Input: a raw u8 image file (w h then pixels) and a BA problem dump written by the test.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "scavislam_hip.hpp"
@@ -62,7 +64,55 @@ int main(int argc, char **argv) {
   svs_cam cam = {camd[0], camd[1], camd[2], camd[3], (int32_t)camd[4], (int32_t)camd[5]};
   SlamGraphBA ba(ctx);
   svs_ba_stats st;
+  const std::vector<double> poses0 = poses, psi0 = psi;
   if (!ba.optimize(OptParams(2, true, 3), cam, &poses, &psi, edges, cons, &st)) return 8;
+  // ---- the same window through the id-based marshalling (SlamGraphBA::optimizeWindow: what a SlamGraph::optimize binding calls) and through the
+  //      sliding-window form: graph ids instead of indices, xyz_anchor instead of psi, (center, level) instead of (obs, info); shuffled observation order,
+  //      two observations from a frame outside the window
+  {
+    const size_t P = poses0.size() / 12, L = psi0.size() / 3;
+    std::vector<int> pose_ids(P), point_ids(L), anchor_ids(L, -1);
+    for (size_t i = 0; i < P; ++i) pose_ids[i] = 100 + 3 * (int)i;
+    for (size_t i = 0; i < L; ++i) point_ids[i] = 7 + 5 * (int)i;
+    std::vector<double> xyz(3 * L);
+    for (size_t i = 0; i < L; ++i) { const double *s = &psi0[3 * i]; xyz[3 * i] = s[0] / s[2]; xyz[3 * i + 1] = s[1] / s[2]; xyz[3 * i + 2] = 1. / s[2]; }
+    std::vector<SlamGraphBA::ObsById> obs(edges.size());
+    for (size_t k = 0; k < edges.size(); ++k) {
+      const size_t src = (k * 7919u) % edges.size();              // a permutation (7919 is prime and does not divide the edge count in the test)
+      const svs_ba_edge &e = edges[src];
+      int level = 0;
+      while (level < 3 && e.info[0] < 1.0 / (double)(1 << (2 * level)) * 0.75) ++level;      // info = 4^-level
+      obs[k].point_id = point_ids[e.point]; obs[k].pose_id = pose_ids[e.pose]; obs[k].level = level;
+      for (int c = 0; c < 3; ++c) obs[k].center[c] = e.obs[c];
+      anchor_ids[e.point] = pose_ids[e.anchor];
+    }
+    for (size_t i = 0; i < L; ++i) if (anchor_ids[i] < 0) anchor_ids[i] = pose_ids[0];
+    SlamGraphBA::ObsById stray = obs[0];
+    stray.pose_id = 9001; obs.push_back(stray); stray.pose_id = 4; obs.push_back(stray);
+    std::vector<SlamGraphBA::ConstraintById> cid(cons.size());
+    for (size_t k = 0; k < cons.size(); ++k) {
+      cid[k].pose_id_1 = pose_ids[cons[k].pose1]; cid[k].pose_id_2 = pose_ids[cons[k].pose2];
+      std::memcpy(cid[k].T_2_from_1, cons[k].T_21, sizeof cons[k].T_21); std::memcpy(cid[k].Lambda_2_from_1, cons[k].info, sizeof cons[k].info);
+    }
+    double worst[2] = {0, 0};
+    for (int variant = 0; variant < 2; ++variant) {
+      std::vector<double> pw = poses0, xw = xyz;
+      svs_ba_stats sw;
+      SlamGraphBA baw(ctx);
+      const bool ok = variant == 0 ? baw.optimizeWindow(OptParams(2, true, 3), cam, pose_ids, &pw, point_ids, anchor_ids, &xw, obs, cid, &sw)
+                                   : baw.optimizeSlidingWindow(OptParams(2, true, 3), cam, pose_ids, &pw, point_ids, anchor_ids, &xw, obs, cid, &sw);
+      if (!ok) return 80 + variant;
+      double dp = 0, dl = 0;
+      for (size_t i = 0; i < pw.size(); ++i) dp = std::fmax(dp, std::fabs(pw[i] - poses[i]));
+      for (size_t i = 0; i < L; ++i) {
+        const double *x = &xw[3 * i];
+        const double ps[3] = {x[0] / x[2], x[1] / x[2], 1. / x[2]};
+        for (int c = 0; c < 3; ++c) dl = std::fmax(dl, std::fabs(ps[c] - psi[3 * i + c]));
+      }
+      std::printf("BAW %d %d %d %d %.17g %.17g\n", variant, sw.iterations, sw.trials, sw.accepted, dp, dl);
+      worst[variant] = dp;
+    }
+  }
   std::printf("BA %d %d %d %.17g %.17g\n", st.iterations, st.trials, st.accepted, st.chi2_init, st.chi2_final);
   for (size_t i = 0; i < poses.size(); ++i) std::printf("P %.17g\n", poses[i]);
   for (size_t i = 0; i < psi.size(); ++i) std::printf("S %.17g\n", psi[i]);

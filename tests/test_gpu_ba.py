@@ -666,3 +666,75 @@ def test_persistent_window_equals_rebuilt_window(gpu_ctx):
         poses[win] = p_inc                                         # the graph takes the result (restoreDataFromG2o) and moves on
         psi[active] = s_inc
     inc.close(); full.close()
+
+
+def test_persistent_window_rollback_and_forget(gpu_ctx):
+    """(1) a svs_ba_window_update that fails after its observations were appended (here: a constraint on a pose that is not in the
+    window) must leave the store as it found it -- the retry with the same observations succeeds and equals the rebuilt window instead of failing
+    on duplicates; (2) svs_ba_window_forget_keyframes drops the observations of keyframes that left the map for good: the store shrinks, later
+    windows are unaffected."""
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BA_CONSTRAINT_DTYPE, BaParams
+    ctx, stream = gpu_ctx
+    Pall, W = 24, 12
+    uni = synth.ba_window(Pall, 1500, seed=17, n_outer=0)
+    cam = _cam(uni["cam"])
+    prm = BaParams.reference_defaults()
+    pose_id = 40 + 2 * np.arange(Pall)
+    point_id = 3 + 5 * np.arange(len(uni["psi"]))
+    edges = uni["edges"]
+    anchor_of = np.full(len(uni["psi"]), -1)
+    anchor_of[edges["point"]] = edges["anchor"]
+    inc, full = SlamGraphOptimizer(ctx, stream), SlamGraphOptimizer(ctx, stream)
+    no_cons = np.zeros(0, BA_CONSTRAINT_DTYPE)
+
+    def window(last):
+        win = np.arange(last - W + 1, last + 1)
+        in_win = np.zeros(Pall, bool); in_win[win] = True
+        e_ok = in_win[edges["pose"]] & in_win[edges["anchor"]]
+        return win, e_ok, np.unique(edges["point"][e_ok])
+
+    def by_id(mask):
+        o = edges[mask].copy()
+        o["point"], o["pose"], o["anchor"] = point_id[edges["point"][mask]], pose_id[edges["pose"][mask]], -1
+        return o
+
+    def rebuilt(win, e_ok, active):
+        rp = np.full(Pall, -1); rp[win] = np.arange(W)
+        rl = np.full(len(uni["psi"]), -1); rl[active] = np.arange(len(active))
+        ef = edges[e_ok].copy()
+        ef["point"], ef["pose"], ef["anchor"] = rl[edges["point"][e_ok]], rp[edges["pose"][e_ok]], rp[edges["anchor"][e_ok]]
+        full.copyDataToG2o(uni["poses"][win], uni["psi"][active], ef, no_cons, cam, prm)
+        st = full.optimize()
+        return st, full.restoreDataFromG2o()
+
+    given = np.zeros(len(edges), bool)
+    win, e_ok, active = window(W - 1)
+    new = e_ok.copy()
+    bad = np.zeros(1, BA_CONSTRAINT_DTYPE)
+    bad[0]["T_21"] = np.eye(3, 4).reshape(12); bad[0]["info"] = np.eye(6).reshape(36)
+    bad[0]["pose1"], bad[0]["pose2"] = pose_id[win[0]], pose_id[Pall - 1]          # the second pose is not in the window
+    with pytest.raises(capi.SvsError):
+        inc.windowUpdate(pose_id[win], uni["poses"][win], point_id[active], uni["psi"][active], pose_id[anchor_of[active]], by_id(new), bad, cam, prm)
+    inc.windowUpdate(pose_id[win], uni["poses"][win], point_id[active], uni["psi"][active], pose_id[anchor_of[active]], by_id(new), no_cons, cam, prm)   # the retry
+    given |= new
+    st = inc.optimize()
+    p_inc, s_inc = inc.restoreDataFromG2o()
+    st_f, (p_f, s_f) = rebuilt(win, e_ok, active)
+    assert (st.trials, st.accepted) == (st_f.trials, st_f.accepted)
+    assert _rel_update_err(p_inc, p_f, uni["poses"][win]) < 1e-8 and _rel_update_err(s_inc, s_f, uni["psi"][active]) < 1e-8
+    # slide by six keyframes, forget the six that left, slide on: every window equals the rebuilt one
+    for last in range(W, Pall):
+        win, e_ok, active = window(last)
+        new = e_ok & ~given
+        given |= new
+        if last == W + 5:
+            inc.windowForgetKeyframes(pose_id[:6])
+        inc.windowUpdate(pose_id[win], uni["poses"][win], point_id[active], uni["psi"][active], pose_id[anchor_of[active]], by_id(new), no_cons, cam, prm)
+        st = inc.optimize()
+        p_inc, s_inc = inc.restoreDataFromG2o()
+        st_f, (p_f, s_f) = rebuilt(win, e_ok, active)
+        assert (st.trials, st.accepted) == (st_f.trials, st_f.accepted), last
+        assert _rel_update_err(p_inc, p_f, uni["poses"][win]) < 1e-8 and _rel_update_err(s_inc, s_f, uni["psi"][active]) < 1e-8, last
+    inc.close(); full.close()

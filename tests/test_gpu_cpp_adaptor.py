@@ -72,13 +72,20 @@ def test_cpp_adaptor_matches_oracle(tmp_path):
     cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
     prm = BaParams.reference_defaults()
     poses_ref, psi_ref, st = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
-    ba = out[3].split()
+    ba = [l for l in out if l.startswith("BA ")][0].split()
     assert ba[0] == "BA" and (int(ba[1]), int(ba[2]), int(ba[3])) == (st.iterations, st.trials, st.accepted)
     np.testing.assert_allclose(float(ba[5]), st.chi2_final, rtol=1e-9)
     P = np.array([float(l.split()[1]) for l in out if l.startswith("P ")]).reshape(-1, 12)
     S = np.array([float(l.split()[1]) for l in out if l.startswith("S ")]).reshape(-1, 3)
     assert np.abs(P - poses_ref).max() < 1e-6 * np.abs(poses_ref - prob["poses"]).max()
     assert np.abs(S - psi_ref).max() < 1e-6 * np.abs(psi_ref - prob["psi"]).max()
+    # SlamGraphBA::optimizeWindow / optimizeSlidingWindow (graph ids, xyz_anchor, (center, level) observations in shuffled order, strays from a frame
+    # outside the window): the same LM record and the same result as the index-based call
+    baw = [l.split() for l in out if l.startswith("BAW ")]
+    assert len(baw) == 2
+    for tok in baw:
+        assert (int(tok[2]), int(tok[3]), int(tok[4])) == (st.iterations, st.trials, st.accepted), tok
+        assert float(tok[5]) < 1e-9 * np.abs(poses_ref - prob["poses"]).max() and float(tok[6]) < 1e-7 * np.abs(psi_ref - prob["psi"]).max(), tok
     # StereoBM
     dl = [l for l in out if l.startswith("DISP ")][0].split()
     dref = O.stereo_bm(img, right)
