@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects everything profiles/r3_* is built from (run on the GPU box from the repo root): bash tools/collect_profiles_r3.sh <tag>
+tag=${1:-r3}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+timeout 400 python bench.py > $out/bench.log 2> $out/bench.err
+echo "bench rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu > $out/trace.log 2>&1
+echo "trace rc=$?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc -- python bench.py --steps 4 --warmup 2 --no-cpu > $out/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $c -d $out/pmcdf_$c -o pmc -- python tools/time_dense_full.py 64 > $out/pmcdf_$c.log 2>&1
+  echo "pmc dense_full $c rc=$?"
+  python tools/pmc_any.py dense_track_full $(find $out/pmcdf_$c -name "*.db") > $out/pmcdf_$c.txt 2>&1
+  rm -rf $out/pmcdf_$c
+done
+python tools/rocpd_summary.py $(find $out/trace -name "*.db") > $out/trace_summary.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do python tools/pmc_any.py "" $(find $out/pmc_$c -name "*.db") > $out/pmc_$c.txt 2>&1; done
+python tools/make_pmc_latest.py $out/pmc_FETCH_SIZE.txt $out/pmc_WRITE_SIZE.txt $out/bench.log $out/pmcdf_FETCH_SIZE.txt $out/pmcdf_WRITE_SIZE.txt $out/pmcdf_FETCH_SIZE.log > $out/pmc_latest.json
+rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+ls -la $out

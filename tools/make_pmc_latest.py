@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def parse(path):
     out = {}
     for line in open(path):
-        m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
+        m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+avg=\s*([0-9.]+)(?:\s+max=\s*([0-9.]+))?", line)
         if m:
-            out[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)) * 1024.0)      # the counters are in KB
+            out[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)) * 1024.0, float(m.group(5) or m.group(4)) * 1024.0)      # the counters are in KB
     return out
 
 
@@ -37,12 +37,24 @@ def main(fetch_txt, write_txt, bench_log, df_fetch_txt=None, df_write_txt=None, 
         return max(ks, key=lambda k: F[k][1]) if ks else None
     k = pick("ba_landmark_kernel<0")
     if k:
-        f, w = F[k][1], W.get(k, (0, 0.0))[1]
+        f, w = F[k][1], W.get(k, (0, 0.0, 0.0))[1]
         res["kernels"]["ba_landmark_kernel<0>"] = {
             "kernel": k, "launches": F[k][0], "fetch_raw": round(f), "write_raw": round(w), "traffic": round(2 * f + w),
             "correction": "edge records, poses and psi arrive as 16 B/lane loads: 2 x FETCH_SIZE + WRITE_SIZE",
             "workload": {"keyframes": bench["schur"]["keyframes"], "landmarks": bench["schur"]["landmarks"], "edges": bench["schur"]["edges"]},
-            "source": "scavislam_amd/csrc/ba.hip", "source_sha16": sha("scavislam_amd/csrc/ba.hip")}
+            "source": "scavislam_amd/csrc/ba_schur.inc", "source_sha16": sha("scavislam_amd/csrc/ba_schur.inc")}
+    # the dominant kernel of every front-end stage at the bench's batch size (the launch with the largest fetch is the batched one): raw counters per launch
+    B = bench["config"]["batch_streams_per_gpu"]
+    for key, sub, src in (("fast_score_kernel", "fast_score_kernel", "fast.hip"), ("match_kernel2", "match_kernel2", "match.hip"),
+                          ("dense_track_cpu_sem_kernel", "dense_track_cpu_sem_kernel", "dense.hip"), ("motion_only_fused_kernel", "motion_only_fused_kernel", "dense.hip"),
+                          ("stereo_bm_kernel", "stereo_bm_kernel", "stereo.hip"), ("stereo_speckle_strip_kernel", "stereo_speckle_strip_kernel", "stereo.hip"),
+                          ("pyr_down_u8_kernel", "pyr_down_u8_kernel", "image.hip")):
+        k = pick(sub)
+        if k:
+            f, w = F[k][2], W.get(k, (0, 0.0, 0.0))[2]
+            res["kernels"][key] = {"kernel": k, "launches_all_batch_sizes": F[k][0], "fetch_raw": round(f), "write_raw": round(w),
+                                   "note": "the LARGEST launch of the run = the launch over all streams of the bench's batch (bench.py also launches smaller batches)",
+                                   "workload": {"batch_streams_per_gpu": B}, "source": "scavislam_amd/csrc/" + src, "source_sha16": sha("scavislam_amd/csrc/" + src)}
     if df_fetch_txt and "dense_full" in bench:
         Fd, Wd = parse(df_fetch_txt), parse(df_write_txt)
         ks = [k for k in Fd if "<false" in k]
@@ -50,7 +62,7 @@ def main(fetch_txt, write_txt, bench_log, df_fetch_txt=None, df_write_txt=None, 
         if ks and line:
             k = ks[0]
             alg = float(re.search(r"alg\s+([0-9.]+) MB", line[-1]).group(1)) * 1e6
-            f, w = Fd[k][1], Wd.get(k, (0, 0.0))[1]
+            f, w = Fd[k][1], Wd.get(k, (0, 0.0, 0.0))[1]
             traffic = f + alg / 4 + w
             res["kernels"]["dense_track_full_kernel"] = {
                 "kernel": k, "launches": Fd[k][0], "fetch_raw": round(f), "write_raw": round(w), "alg_bytes_of_the_profiled_launch": round(alg),
