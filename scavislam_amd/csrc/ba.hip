@@ -121,6 +121,7 @@ class HostPool {
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
   int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
+  int host_marshal = 0;                 // svs_ba_set_problem: 0 = by size (device route from 30k edges), 1 = always on the host (rounds 1-2), 2 = always on the device
 };
 int svs_comm_allreduce_hook(void *d_buf, size_t count, void *user);      // comm.hip
 // waves per workgroup of the Schur kernel: the smallest of 4..8 that gets the grid down to one workgroup per CU (if any does)
@@ -238,9 +239,14 @@ static int stage_upload(svs_ba *ba, void *d_dst, const void *h_src, size_t bytes
     SVS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return SVS_OK;
   }
-  std::memcpy(ba->h_stage + off, h_src, bytes);
   ba->h_stage_used = off + bytes;
-  SVS_HIP(ctx, hipMemcpyAsync(d_dst, ba->h_stage + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // big arrays go in pieces: the DMA of a piece runs while the next one is copied into the pinned area
+  const size_t piece = bytes > (1u << 20) ? (size_t)1 << 19 : bytes;
+  for (size_t o = 0; o < bytes; o += piece) {
+    const size_t nb = std::min(piece, bytes - o);
+    std::memcpy(ba->h_stage + off + o, static_cast<const char *>(h_src) + o, nb);
+    SVS_HIP(ctx, hipMemcpyAsync(static_cast<char *>(d_dst) + o, ba->h_stage + off + o, nb, hipMemcpyHostToDevice, ctx->stream));
+  }
   return SVS_OK;
 }
 
@@ -288,6 +294,9 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   return SVS_OK;
 }
 
+static int window_update_impl(svs_ba *ba, int P, const int32_t *h_pose_ids, const double *h_poses, int L, const int32_t *h_point_ids,
+                              const double *h_psi, const int32_t *h_anchor_pose_ids, int n_new, const svs_ba_edge *h_new_obs, int C,
+                              const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm);
 extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const double *h_psi, int E,
                                   const svs_ba_edge *h_edges, int C, const svs_ba_constraint *h_cons, const svs_cam *cam,
                                   const svs_ba_params *prm, int add_pose_terms) {
@@ -295,6 +304,31 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   SVS_REQUIRE(ctx, ba && h_poses && (L == 0 || h_psi) && (E == 0 || h_edges) && (C == 0 || h_cons) && cam && prm);
   SVS_REQUIRE(ctx, P >= 1 && L >= 0 && E >= 0 && C >= 0);
   SVS_DEVICE(ctx);
+  // Round 3: a complete window handed over by index takes the DEVICE route of the persistent window -- the edges are uploaded as they come and the
+  // sort by (anchor, landmark, observer), the wave chunks, the slot order and the co-visibility pattern are built by kernels (ba_window.inc) -- unless
+  // this rank holds a landmark shard (comm / add_pose_terms == 0), a persistent window is in use on this handle, or a point has no observation.
+  // (Below ~30k edges the ~45 small stream operations of the device route cost more than the host's passes: 15 KF / 3k: 0.45 vs 0.43 ms per call;
+  // 50 KF / 20k: 1.10 vs 1.36 ms.  "host_marshal" = 2 forces the device route for any size: tests.)
+  if (ba->opt.host_marshal != 1 && (E >= 30000 || ba->opt.host_marshal == 2) && !ba->comm && add_pose_terms && ba->w_n == 0 && E > 0 && L > 0 && P <= SOLVE_MAX_P) {
+    ba->problem_valid = false;                   // a call that fails must leave the handle unusable, not half old / half new
+    std::vector<int32_t> pid((size_t)P), lid((size_t)L), aid((size_t)L, -1);
+    for (int i = 0; i < P; ++i) pid[i] = i;
+    for (int i = 0; i < L; ++i) lid[i] = i;
+    bool ok = true;
+    for (int e = 0; e < E && ok; ++e) {
+      const svs_ba_edge &ed = h_edges[e];
+      ok = ed.point >= 0 && ed.point < L && ed.pose >= 0 && ed.pose < P && ed.anchor >= 0 && ed.anchor < P;
+      if (ok) { if (aid[ed.point] < 0) aid[ed.point] = ed.anchor; else ok = aid[ed.point] == ed.anchor; }
+    }
+    SVS_REQUIRE(ctx, ok);                        // an index out of range, or two anchors for one point
+    bool all_seen = true;
+    for (int i = 0; i < L && all_seen; ++i) all_seen = aid[i] >= 0;
+    if (all_seen) {
+      const int rc = window_update_impl(ba, P, pid.data(), h_poses, L, lid.data(), h_psi, aid.data(), E, h_edges, C, h_cons, cam, prm);
+      ba->w_n = 0;                               // the observation store served as scratch: this handle has no persistent window
+      return rc;
+    }
+  }
   // a call that fails half-way must not leave new sizes next to old buffers behind: the handle is unusable until a call completes
   ba->problem_valid = false;
   if (P > SOLVE_MAX_P) { ctx->err = "svs_ba: P > 256 poses not supported by the single-workgroup solve yet"; return SVS_ERR_UNSUPPORTED; }
@@ -1094,6 +1128,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "group") o.group = value == 0 ? 0 : clamp(value, 1, WIN);
   else if (n == "grid_g") o.grid_g = clamp(value, 0, 1024);
   else if (n == "host_threads") o.host_threads = clamp(value, 0, 64);
+  else if (n == "host_marshal") o.host_marshal = clamp(value, 0, 2);
   else SVS_REQUIRE(ctx, !"unknown option");
   ba->profile_ready = false;            // solve-kernel choice depends on the switches
   return SVS_OK;
