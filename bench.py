@@ -335,6 +335,35 @@ def main():
         ocb = OneCall(Bs)
         batch_sweep[str(Bs)] = round(Bs * 10 / timed_steps(ocb, 2, 10), 1)
         ocb.close()
+    # several batched front ends in flight on their own HIP streams: the stage kernels of different groups overlap (every stage is VALU-issue bound at
+    # 40-60 % utilisation with its own latency tails) -- the mode a multi-camera server would run; `value` stays the single batch, whose stage times add up
+    overlapped = None
+    if B >= 512 and world == 1:
+        grp = []
+        for _ in range(3):
+            cg, sg = capi.torch_context(local_rank)
+            grp.append((cg, sg))
+        ctx_main, stream_main = ctx, stream
+        ocs3 = []
+        for cg, sg in grp:
+            ctx, stream = cg, sg                                 # OneCall builds on the enclosing ctx / stream
+            ocs3.append(OneCall(256))
+        ctx, stream = ctx_main, stream_main
+        for _ in range(2):
+            for o in ocs3:
+                o.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            for o in ocs3:
+                o.step()
+        torch.cuda.synchronize()
+        t_ov = (time.perf_counter() - t0) / 10
+        overlapped = {"groups": 3, "streams_per_group": 256, "ms_per_step_of_all_groups": round(t_ov * 1e3, 4), "frames_per_s": round(3 * 256 / t_ov, 1)}
+        for o in ocs3:
+            o.close()
+        for cg, _ in grp:
+            cg.close()
     # the reference's CUDA build of the same path (full-resolution tracker, matcher radius 4) through the same call
     FBc = min(B, 64)
     occ = OneCall(FBc, cuda_build=True)
@@ -749,6 +778,7 @@ def main():
                          "stereo_input_path": dict(stereo_info, ms_per_step=round(t_stereo / max(4, K // 2 * 2) * 1e3, 4), frames_per_s=round(fps_stereo, 1),
                                                    stage_ms_per_batch={k: round(v, 4) for k, v in stage_ms_stereo.items()}),
                          "cuda_build_path": cuda_path,
+                         "overlapped_batches": overlapped,
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},
             "dense_full": dense_full,
             "roofline": roofline,

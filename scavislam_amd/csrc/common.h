@@ -60,6 +60,9 @@ int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
 
 #define SVS_LAUNCH_CHECK(ctx) SVS_HIP(ctx, hipGetLastError())
 
+// internal: svs_pyr_down_u8 that also copies its source image (the front end's copy-in of a caller's device frame rides on the first pyramid step)
+int svs_pyr_down_u8_copy(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride, uint8_t *d_dst, int dstride, size_t d_bstride,
+                         uint8_t *d_copy, int cstride, size_t c_bstride, int batch);
 // internal (not exported through the header): svs_process_matched_points with the record count of the new-feature lists per stream, on the device
 int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n, size_t res_bstride,
                                    size_t pts_bstride, const int32_t *d_n_new_records, const svs_cam *cam, const double *d_T, float max_reproj_error,

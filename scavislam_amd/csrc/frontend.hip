@@ -111,6 +111,7 @@ struct svs_frontend {
   uint8_t *d_right[3] = {};            // right image / disparity of the frame in pyramid slot k
   float *d_disp[3] = {};
   const float *last_disp = nullptr; int last_dstride = 0; size_t last_dbstride = 0;      // disparity the frame processed last was given / produced
+  const uint8_t *ext_left = nullptr; int ext_lstride = 0; size_t ext_lbstride = 0;       // a caller's device frame waiting to be taken in by the first pyramid step
   float *d_cloud[3] = {};               // quarter grid (CPU build) or full resolution (CUDA build), float4 per sample
   size_t cloud_elems[3]{};              // floats per stream and level
   // CUDA build (prm.cuda_build): f32 pyramids of the current / previous frame, derivative images of the current one
@@ -387,11 +388,9 @@ int frontend_take_device_frames(svs_frontend *fe, const svs_frames_dev *in) {
   SVS_REQUIRE(ctx, fe->prm.use_block_matching ? (in->d_right && in->rstride >= w) : (in->d_disp && in->dstride >= w));
   SVS_REQUIRE(ctx, in->lstride % 4 == 0 && (!in->d_right || in->rstride % 4 == 0));
   const dim3 grid(div_up(w / 4, 256), h, fe->B);
-  if (in->d_left != fe->d_pyr[fe->i_cur][0]) {
-    hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, ctx->stream, in->d_left, (size_t)in->lstride, in->l_bstride, fe->d_pyr[fe->i_cur][0], (size_t)fe->stride[0],
-                       fe->lvl_elems[0], w / 4);
-    SVS_LAUNCH_CHECK(ctx);
-  }
+  // the left image is taken into the level-0 buffer by the first pyramid step (frontend_chain): one read of the frame instead of two
+  fe->ext_left = in->d_left != fe->d_pyr[fe->i_cur][0] ? in->d_left : nullptr;
+  fe->ext_lstride = in->lstride; fe->ext_lbstride = in->l_bstride;
   if (fe->prm.use_block_matching && in->d_right != fe->d_right[fe->i_cur]) {
     hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, ctx->stream, in->d_right, (size_t)in->rstride, in->r_bstride, fe->d_right[fe->i_cur], (size_t)fe->stride[0],
                        fe->lvl_elems[0], w / 4);
@@ -407,10 +406,16 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
   svs_ctx *ctx = fe->ctx;
   const int B = fe->B, cur = fe->i_cur, prev = fe->i_prev, n = fe->n_launch;
   int rc;
-  for (int l = 1; l < 3; ++l)                                                                 // "preprocess"
-    if ((rc = svs_pyr_down_u8(ctx, fe->d_pyr[cur][l - 1], fe->w[l - 1], fe->h[l - 1], fe->stride[l - 1], fe->lvl_elems[l - 1], fe->d_pyr[cur][l], fe->stride[l],
-                              fe->lvl_elems[l], B)))
-      return rc;
+  for (int l = 1; l < 3; ++l) {                                                               // "preprocess"
+    if (l == 1 && fe->ext_left)
+      rc = svs_pyr_down_u8_copy(ctx, fe->ext_left, fe->w[0], fe->h[0], fe->ext_lstride, fe->ext_lbstride, fe->d_pyr[cur][1], fe->stride[1], fe->lvl_elems[1],
+                                fe->d_pyr[cur][0], fe->stride[0], fe->lvl_elems[0], B);
+    else
+      rc = svs_pyr_down_u8(ctx, fe->d_pyr[cur][l - 1], fe->w[l - 1], fe->h[l - 1], fe->stride[l - 1], fe->lvl_elems[l - 1], fe->d_pyr[cur][l], fe->stride[l],
+                           fe->lvl_elems[l], B);
+    if (rc) return rc;
+  }
+  fe->ext_left = nullptr;
   const int f32c = fe->i_f32, f32p = 1 - fe->i_f32;
   if (fe->prm.cuda_build) {
     if ((rc = svs_preprocess_gpu_sem(ctx, fe->d_pyr[cur][0], fe->w[0], fe->h[0], fe->stride[0], fe->lvl_elems[0], fe->d_f32[f32c], fe->d_dx, fe->d_dy, fe->stride,

@@ -119,13 +119,18 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // held in registers (three unaligned dword loads per row), horizontal [1 4 6 4 1] per row with V_DOT4_U32_U8, the two
 // vertical combinations on packed u16 pairs; `(s+128)>>8`; one dword store per output row.
 __device__ __forceinline__ uint32_t ld_u32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+// COPY: the lane also stores the 8 x 4 source pixels that only it covers (columns 2 ox .. 2 ox + 7, rows 2 oy .. 2 oy + 3: exactly the byte-aligned dwords
+// d01 / d12 of its four middle rows) into `cpy` -- the front end takes a caller's device frame into its own level-0 buffer while it builds level 1,
+// instead of with a copy kernel of its own (one read of the frame instead of two).
+template <bool COPY>
 __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restrict__ src, int w, int h, int ss,
                                                          size_t sb, uint8_t *__restrict__ dst, int dw, int dh,
-                                                         int ds, size_t db) {
+                                                         int ds, size_t db, uint8_t *__restrict__ cpy, int cs, size_t cb) {
   const int ox = 4 * (blockIdx.x * 64 + threadIdx.x), oy = 2 * (blockIdx.y * 4 + threadIdx.y);      // 4 waves = 4 output row pairs
   if (ox >= dw || oy >= dh) return;
   src += (size_t)blockIdx.z * sb;
   dst += (size_t)blockIdx.z * db;
+  if (COPY) cpy += (size_t)blockIdx.z * cb;
   const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
   // Column borders without divergence: the leftmost lane (sx0 = -2) and the lane whose third dword crosses the right
   // edge load from a clamped in-row address and rebuild their bytes with V_PERM (BORDER_REFLECT_101); rows are reflected
@@ -175,6 +180,19 @@ __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restr
     const uint32_t h3 = __builtin_amdgcn_udot4(d12, W4, (d2 >> 16) & 0xffu, false);     // + byte 10
     hp[r][0].u = h0 | (h1 << 16);
     hp[r][1].u = h2 | (h3 << 16);
+    if (COPY && r >= 2 && r <= 5) {
+      const int cy = 2 * oy + r - 2, cx = 2 * ox;
+      if (cy < h) {
+        uint8_t *q = cpy + (size_t)cy * cs + cx;
+        if (cx + 7 < w && (cs & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)cpy & 3) == 0) {
+          reinterpret_cast<uint32_t *>(q)[0] = d01;
+          reinterpret_cast<uint32_t *>(q)[1] = d12;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (cx + j < w) q[j] = (uint8_t)((j < 4 ? d01 : d12) >> (8 * (j & 3)));
+        }
+      }
+    }
   }
   // vertical pass on packed pairs: (h0 + h4) + 4 (h1 + h3) + 6 h2 <= 16 * 4080 = 65280 fits u16; (s + 128) >> 8
   const us2_t c4 = {4, 4}, c6 = {6, 6}, c128 = {128, 128};
@@ -208,8 +226,20 @@ extern "C" int svs_pyr_down_u8(svs_ctx *ctx, const uint8_t *d_src, int w, int h,
   SVS_DEVICE(ctx);
   int dw = (w + 1) / 2, dh = (h + 1) / 2;
   dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
-  hipLaunchKernelGGL(pyr_down_u8_kernel, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw,
-                     dh, dstride, d_bstride);
+  hipLaunchKernelGGL(pyr_down_u8_kernel<false>, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw,
+                     dh, dstride, d_bstride, (uint8_t *)nullptr, 0, (size_t)0);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+// internal (frontend.hip): one pyrDown step that also copies the source image into d_copy (same size as the source)
+int svs_pyr_down_u8_copy(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride, uint8_t *d_dst, int dstride, size_t d_bstride,
+                         uint8_t *d_copy, int cstride, size_t c_bstride, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_src && d_dst && d_copy && w >= 3 && h >= 3 && batch >= 1);
+  SVS_DEVICE(ctx);
+  int dw = (w + 1) / 2, dh = (h + 1) / 2;
+  dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
+  hipLaunchKernelGGL(pyr_down_u8_kernel<true>, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw, dh, dstride, d_bstride, d_copy,
+                     cstride, c_bstride);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
