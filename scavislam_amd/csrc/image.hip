@@ -69,7 +69,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "trk_regs") c->trk_regs = value > 2 ? 0 : value;
   else if (n == "full_nwg") c->full_nwg = value > 1024 ? 1024 : value;
   else if (n == "mo_legacy") c->mo_legacy = value != 0;
-  else if (n == "match_legacy") c->match_legacy = value != 0;
+  else if (n == "match_legacy") c->match_legacy = (int)value;
   else SVS_REQUIRE(c, !"unknown option");
   return SVS_OK;
 }

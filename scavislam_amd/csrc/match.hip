@@ -85,30 +85,55 @@ __device__ __forceinline__ unsigned quad_key(int px, int py, int W, int H) {
 
 // per-point result of computePrediction + the local affine of warpAffinve (everything that is one scalar evaluation per
 // point): produced one LANE per point by match_predict_kernel, consumed one WAVE per point by match_kernel
-struct PointPred {
-  int32_t status, ui, vi, lvl, kfi, pad_;
+struct alignas(16) PointPred {      // 128 bytes = one cache line, fields grouped into 16-byte loads (match_kernel3 reads it with vector loads)
+  int32_t status, ui, vi, lvl;
   double inv[4];          // inverse of the local affine A (matcher.cpp:415-426)
   double key_uv[2];       // anchor_obs_pyr
-  double xyz_actkey[3];
-  // for match_kernel2: the keyframe's level image (saves the dependent read of the keyframe record) and the search window's cell geometry --
+  // for match_kernel2/3: the keyframe's level image (saves the dependent read of the keyframe record) and the search window's cell geometry --
   // the one column / row boundary it may cross and the four emit thresholds (+1) of the cells it touches
   const uint8_t *kimg;
-  int32_t kstride, xb, yb;
+  int32_t kstride, xb;
+  int32_t yb;
   uint8_t t00m1, t01m1, t10m1, t11m1;      // thresholds - 1 (1..256 does not fit a byte)
+  int32_t kfi, pad_;
+  double xyz_actkey[3];
+  double pad2_;
+};
+static_assert(sizeof(PointPred) == 128, "PointPred layout");
+// what match_kernel3 needs of a pyramid level, as a table in memory: its 16-lane groups work on points of different levels, so the level index is a vector
+// register there and the per-level kernel arguments cannot be picked with scalar indexing (written by match_pose_kernel)
+struct LevelTab {
+  const uint8_t *score, *cimg;
+  size_t score_bstride, cur_bstride;
+  int32_t sstride, cstride, w, h, xhi, yhi, pad_[2];
 };
 struct MatchParams {
   svs_match_args a;
   FastView fv;
   const double *kf_T;     // [n_batch][n_kf][24]: T_cur_from_anchor, T_actkey_from_anchor (match_pose_kernel)
   PointPred *pred;        // [n_batch][n_pts]
+  LevelTab *lt;           // [SVS_NUM_PYR_LEVELS]
 };
 
 // The two relative poses a candidate needs depend only on (camera stream, anchor keyframe), not on
 // the point: T_cur_from_anchor = T_cur_from_w * T_anchor_from_w^-1 (matcher.cpp:113) and
 // (T_anchor_from_w * T_w_from_actkey)^-1 (matcher.cpp:393-394).  One lane per pair, same operation
 // order as the per-point formulation => bit-identical values, ~250 f64 ops less per wavefront.
-__global__ void match_pose_kernel(svs_match_args A, double *__restrict__ out) {
+__global__ void match_pose_kernel(MatchParams M, double *__restrict__ out) {
+  const svs_match_args &A = M.a;
   const int kf = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
+  if (blockIdx.x == 0 && slot == 0) {
+#pragma unroll
+    for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
+      if ((int)threadIdx.x == l && l < M.fv.n_levels) {
+        LevelTab t;
+        t.score = M.fv.score[l]; t.cimg = A.d_cur_pyr[l]; t.score_bstride = M.fv.score_bstride[l]; t.cur_bstride = A.cur_bstride[l];
+        t.sstride = M.fv.score_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
+        t.xhi = min(M.fv.gx[l] * M.fv.cell_w[l], A.cam_vec[l].w - 6); t.yhi = min(M.fv.gy[l] * M.fv.cell_h[l], A.cam_vec[l].h - 6);      // isInFrame(uv, 6) and inside the cell grid
+        t.pad_[0] = t.pad_[1] = 0;
+        M.lt[l] = t;
+      }
+  }
   if (kf >= A.n_kf) return;
   double kfT[12], Tcw[12], Twk[12], t0[12], t1[12];
   for (int i = 0; i < 12; ++i) { kfT[i] = A.d_kfs[(size_t)slot * A.kf_bstride + kf].T_anchor_from_w[i]; Tcw[i] = A.d_T_cur_from_w[(size_t)slot * 12 + i]; Twk[i] = A.d_T_w_from_actkey[(size_t)slot * 12 + i]; }
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   if (ip >= A.n_pts) return;
   const svs_candidate_point ap = A.d_pts[(size_t)slot * A.pts_bstride + ip];
   PointPred pr;
-  pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0;
+  pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0; pr.pad2_ = 0;
   pr.inv[0] = pr.inv[1] = pr.inv[2] = pr.inv[3] = 0; pr.key_uv[0] = ap.anchor_obs_pyr[0]; pr.key_uv[1] = ap.anchor_obs_pyr[1];
   pr.xyz_actkey[0] = pr.xyz_actkey[1] = pr.xyz_actkey[2] = 0;
   pr.kimg = nullptr; pr.kstride = 0; pr.xb = pr.yb = 0x7fffffff; pr.t00m1 = pr.t01m1 = pr.t10m1 = pr.t11m1 = 255;
@@ -566,6 +591,231 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 }
 
+// ---- round 3, second step: FOUR points per wave ------------------------------------------------------------------------------------
+// With one wave per point (both kernels above) ~600 wave instructions go into a point, most of them with a handful of useful lanes: the scoring has
+// one lane per candidate corner (2-10 of 64), the window scan two hits per 64 lanes, the 64-lane sums and the 16 readlanes of the key patch serve one
+// point.  Here a point has a DPP row: 16 lanes = the 8 x 8 key patch as 16 dwords (lane = row, half), which is the layout V_SAD_U8 / V_DOT4_U32_U8
+// want: a candidate costs one dword load and three dot products per lane and a 16-lane butterfly (quad_perm, row_half_mirror, row_mirror: DPP
+// modifiers, no LDS); the key patch never moves; the (2R+1)^2 window is one score-map row per lane (17 rows = 16 lanes + a shared last row), whose
+// non-zero bytes -- the score map is zero except at corners -- are found with byte-mask arithmetic instead of a compare per position.  Four points
+// share every instruction.  Needs 2R+1 <= 17 (the reference's radii: 8 on the CPU build, 4 on the CUDA build); wider windows take match_kernel2.
+constexpr int M3_GROUPS = 16;                      // points per 256-lane block
+constexpr int M3_CAND_CAP = 17 * 17;
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {      // all-reduce over the 16 lanes of a DPP row
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);      // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);      // row_mirror
+  return v;
+}
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ U4 ld_u4u(const uint8_t *p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }      // 16 bytes from any address: one global_load_dwordx4
+__device__ __forceinline__ U2 ld_u2u(const uint8_t *p) { U2 v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t d) { return (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; }      // bit 7 of every non-zero byte
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_kernel3(MatchParams M, svs_match_result *__restrict__ out) {
+  __shared__ uint16_t s_cand[M3_GROUPS][M3_CAND_CAP + 7];      // per point: window positions (wy << 5 | wx) waiting to be scored
+  __shared__ int s_ncand[M3_GROUPS];
+  const svs_match_args &A = M.a;
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int ip = blockIdx.x * M3_GROUPS + grp, slot = blockIdx.y;
+  const bool live = ip < A.n_pts;
+  const PointPred *pp = M.pred + (size_t)slot * A.n_pts + (live ? ip : A.n_pts - 1);
+  int status = pp->status;
+  bool go = live && status == SVS_MATCH_OK;
+  const int R = A.search_radius, side = 2 * R + 1;
+  const int init_dist = A.thr_mean * A.thr_mean * 64;
+  if (sub == 0) s_ncand[grp] = 0;
+  const int lvl = go ? pp->lvl : 0;
+  const LevelTab *Lp = M.lt + lvl;
+  const int x0 = pp->ui - R, y0 = pp->vi - R;
+  const int Lw = Lp->w, Lh = Lp->h;
+  // The kernel is bound by the L1 (it works per instruction and cache line touched) and short of registers at 8 waves per SIMD: wide requests, and
+  // values re-read from the (cached) point record / level table where they are needed rather than carried.
+  // ---- (1) the window's score-map row of this lane: one 16-byte and one 4-byte request
+  uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, ex = 0;
+  const int cy = y0 + sub, cyx = y0 + 16;
+  {
+    const uint8_t *score = Lp->score + (size_t)slot * Lp->score_bstride;
+    const int sstride = Lp->sstride, yhi = Lp->yhi;
+    if (go && sub < side && cy >= 6 && cy < yhi) {
+      const uint8_t *srow = score + (size_t)cy * sstride;
+      if (x0 >= 0 && x0 + 20 <= Lw) {
+        const U4 q = ld_u4u(srow + x0);
+        d0 = q.x; d1 = q.y; d2 = q.z; d3 = q.w;
+        if (side > 16) __builtin_memcpy(&d4, srow + x0 + 16, 4);
+      } else {
+        for (int k = 0; k < side; ++k) {
+          const int cx = x0 + k;
+          const uint32_t b = cx >= 0 && cx < Lw ? (uint32_t)srow[cx] << (8 * (k & 3)) : 0u;
+          d0 |= k < 4 ? b : 0u; d1 |= (k >> 2) == 1 ? b : 0u; d2 |= (k >> 2) == 2 ? b : 0u; d3 |= (k >> 2) == 3 ? b : 0u; d4 |= k >= 16 ? b : 0u;
+        }
+      }
+    }
+    if (go && side > 16 && cyx >= 6 && cyx < yhi) {      // the 17th row: lane = column, the last lane also the 17th column
+      const uint8_t *srow = score + (size_t)cyx * sstride;
+      const int cx = x0 + sub;
+      if (cx >= 0 && cx < Lw) ex = srow[cx];
+      if (sub == 15 && cx + 1 >= 0 && cx + 1 < Lw) ex |= (uint32_t)srow[cx + 1] << 8;
+    }
+  }
+  // ---- (2) warpAffinve, requests: the centre 8x8 of the 10x10 patch (KEY_PATCH, matcher.cpp:376-381), lane = (row, half): four pixels = one packed
+  // dword.  The common case -- a warp close to a translation -- has the lane's four samples on one source row pair within 8 columns: two 8-byte
+  // requests instead of sixteen single bytes; anything else takes the byte path.  px[]: the two 8-byte rows, or per pixel v00 | v10 << 8 | v01 << 16
+  // | v11 << 24; flags: bit j = pixel j inside the image, bit 4 = row-pair case; offs: byte j = column offset of pixel j in the rows.
+  const int prow = sub >> 1, pc0 = 4 * (sub & 1);
+  uint32_t px0 = 0, px1 = 0, px2 = 0, px3 = 0, flags = 0, offs = 0;
+  if (go) {
+    const double i00 = pp->inv[0], i01 = pp->inv[1], i10 = pp->inv[2], i11 = pp->inv[3];
+    const double key_u = pp->key_uv[0], key_v = pp->key_uv[1];
+    const uint8_t *kimg = pp->kimg;
+    const int kstride = pp->kstride;
+    const double dy = prow - 4;                    // iy - 5, iy = row + 1
+    int xis[4], yis[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double dx = pc0 + j - 4;
+      const double r0 = (i00 * dx + i01 * dy) + key_u;
+      const double r1 = (i10 * dx + i11 * dy) + key_v;
+      const double x = floor(r0), y = floor(r1);
+      const bool in = x >= 0 && y >= 0 && !(x + 1 >= Lw) && !(y + 1 >= Lh);
+      flags |= in ? 1u << j : 0u;
+      xis[j] = in ? (int)x : 0; yis[j] = in ? (int)y : 0;
+    }
+    const bool oneRow = flags == 15u && yis[1] == yis[0] && yis[2] == yis[0] && yis[3] == yis[0] && (unsigned)(xis[1] - xis[0]) <= 6u &&
+                        (unsigned)(xis[2] - xis[0]) <= 6u && (unsigned)(xis[3] - xis[0]) <= 6u && xis[0] + 8 <= Lw;
+    if (oneRow) {
+      const uint8_t *q = kimg + (size_t)yis[0] * kstride + xis[0];
+      const U2 ra = ld_u2u(q), rb = ld_u2u(q + kstride);
+      px0 = ra.x; px1 = ra.y; px2 = rb.x; px3 = rb.y;
+      flags |= 16u;
+      offs = (uint32_t)(xis[1] - xis[0]) << 8 | (uint32_t)(xis[2] - xis[0]) << 16 | (uint32_t)(xis[3] - xis[0]) << 24;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (flags >> j & 1u) {
+          const uint8_t *q = kimg + (size_t)yis[j] * kstride + xis[j];
+          const uint32_t t = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[kstride] << 16 | (uint32_t)q[kstride + 1] << 24;
+          if (j == 0) px0 = t; else if (j == 1) px1 = t; else if (j == 2) px2 = t; else px3 = t;
+        }
+    }
+  }
+  // ---- (3) hits of the window: non-zero score bytes that reach the emit threshold of their cell (one cell boundary per axis: match_predict_kernel).
+  // Before the texture gate, whose verdict only decides whether they are scored: the score bytes are not carried through the bilinear arithmetic.
+  {
+    const int xb = pp->xb, yb = pp->yb, xhi = Lp->xhi;
+    const int tU0 = pp->t00m1, tU1 = pp->t01m1, tL0 = pp->t10m1, tL1 = pp->t11m1;      // thresholds - 1: sc >= t  <=>  sc > t - 1
+    uint32_t m = go ? (nonzero_bytes(d0) >> 7) | (nonzero_bytes(d1) >> 6) | (nonzero_bytes(d2) >> 5) | (nonzero_bytes(d3) >> 4) | (nonzero_bytes(d4) >> 3) : 0u;
+    ex = go ? ex : 0u;
+    __builtin_amdgcn_wave_barrier();
+    while (m) {
+      const int pos = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int j = pos & 7, b = pos >> 3, k = 4 * j + b;
+      const uint32_t dj = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : j == 3 ? d3 : d4;
+      const int sc = (int)((dj >> (8 * b)) & 0xffu), cx = x0 + k;
+      const int tm1 = cy >= yb ? (cx >= xb ? tL1 : tL0) : (cx >= xb ? tU1 : tU0);
+      if (k < side && cx >= 6 && cx < xhi && sc > tm1) s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((sub << 5) | k);
+    }
+    while (ex) {
+      const int hi = (ex & 0xffu) ? 0 : 1;
+      const int sc = (int)(hi ? ex >> 8 : ex & 0xffu), k = sub + hi, cx = x0 + k;
+      ex = hi ? 0u : ex & ~0xffu;
+      const int tm1 = cyx >= yb ? (cx >= xb ? tL1 : tL0) : (cx >= xb ? tU1 : tU0);
+      if (cx >= 6 && cx < xhi && sc > tm1) s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((16 << 5) | k);
+    }
+  }
+  // ---- (4) warpAffinve, arithmetic: the sample coordinates again (from the point record: 12 doubles not held across (3)), bilinear weights as the
+  // reference forms them
+  uint32_t keyd = 0;
+  if (go) {
+    const PointPred *pq = pp;
+    asm volatile("" : "+v"(pq));
+    const double i00 = pq->inv[0], i01 = pq->inv[1], i10 = pq->inv[2], i11 = pq->inv[3];
+    const double key_u = pq->key_uv[0], key_v = pq->key_uv[1];
+    const double dy = prow - 4;
+    const bool oneRow = (flags & 16u) != 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double dx = pc0 + j - 4;
+      const double r0 = (i00 * dx + i01 * dy) + key_u;
+      const double r1 = (i10 * dx + i11 * dy) + key_v;
+      const double sx = r0 - floor(r0), sy = r1 - floor(r1);
+      uint32_t t = j == 0 ? px0 : j == 1 ? px1 : j == 2 ? px2 : px3;
+      if (oneRow) {
+        const uint32_t o = (offs >> (8 * j)) & 0xffu, sel = o | ((o + 1u) << 8) | 0x0c0c0000u;      // V_PERM: bytes o, o + 1 of an 8-byte row, zeros above
+        t = __builtin_amdgcn_perm(px1, px0, sel) | __builtin_amdgcn_perm(px3, px2, sel) << 16;
+      }
+      const double v00 = (double)(t & 0xffu), v10 = (double)(t >> 8 & 0xffu), v01 = (double)(t >> 16 & 0xffu), v11 = (double)(t >> 24);
+      const double wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
+      const double sv = (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
+      const uint32_t val = (flags >> j & 1u) ? (uint32_t)(uint8_t)(sv < 255. ? sv : 255.) : 0u;
+      keyd |= val << (8 * j);
+    }
+  }
+  const int sumA = (int)row16_sum(__builtin_amdgcn_sad_u8(keyd, 0u, 0u)), sumAA = (int)row16_sum(__builtin_amdgcn_udot4(keyd, keyd, 0u, false));
+  if (go && sumA * sumA - sumAA < A.thr_std * A.thr_std * 64) { status = SVS_MATCH_TEXTURE; go = false; }
+  const bool textured = go;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  // ---- (5) ZNSSD of every hit, the four points of the wave in step
+  const int n = go ? s_ncand[grp] : 0;
+  const int cstride = Lp->cstride;
+  const uint8_t *pbase = Lp->cimg + (size_t)slot * Lp->cur_bstride + (ptrdiff_t)(y0 - 4 + prow) * cstride + (x0 - 4 + pc0);
+  int best = 0x7fffffff, bu = 0, bv = 0;
+  auto fetch = [&](int i, uint32_t &v, int &wx, int &wy) {
+    v = 0; wx = 0; wy = 0;
+    if (i < n) {
+      const int code = s_cand[grp][i];
+      wx = code & 31; wy = code >> 5;
+      __builtin_memcpy(&v, pbase + (ptrdiff_t)wy * cstride + wx, 4);
+    }
+  };
+  uint32_t v_nx; int wx_nx, wy_nx;
+  fetch(0, v_nx, wx_nx, wy_nx);
+  for (int i = 0; __ballot(i < n) != 0ull; ++i) {
+    const bool act = i < n;
+    const uint32_t v = v_nx;
+    const int wx = wx_nx, wy = wy_nx;
+    fetch(i + 1, v_nx, wx_nx, wy_nx);              // the next hit's pixels travel while this one is summed
+    const int iB = (int)row16_sum(__builtin_amdgcn_sad_u8(v, 0u, 0u));
+    const int sBB = (int)row16_sum(__builtin_amdgcn_udot4(v, v, 0u, false));
+    const int sAB = (int)row16_sum(__builtin_amdgcn_udot4(v, keyd, 0u, false));
+    const int z = sumAA - 2 * sAB - sBB - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
+    // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, quadrant key); z must also beat thr_mean.
+    // The quadrant keys are only needed to break ties, which are rare: behind a wave-uniform branch, so that they are not evaluated (predicated) per hit.
+    const int hx = x0 + wx, hy = y0 + wy;
+    const bool good = act && z < init_dist;
+    if (__ballot(good && z == best) != 0ull) {
+      int hx_ = hx, bu_ = bu;
+      asm volatile("" : "+v"(hx_), "+v"(bu_));      // (keeps the key arithmetic inside the branch: it is cheap enough for the compiler to speculate it)
+      if (good && z == best && quad_key(hx_, hy, Lw, Lh) < quad_key(bu_, bv, Lw, Lh)) { bu = hx; bv = hy; }
+    }
+    if (good && z < best) { best = z; bu = hx; bv = hy; }
+  }
+  double obs0 = 0, obs1 = 0, obs2 = 0;
+  if (go) {
+    if (best == 0x7fffffff) { status = SVS_MATCH_NONE; bu = bv = 0; }
+    else {
+      const double inv_factor = 1.0 / (double)(1 << lvl);
+      const float *disp = A.d_disp + (size_t)slot * A.disp_bstride;
+      const double dd = disp[(size_t)(bv << lvl) * A.disp_stride + (bu << lvl)] * inv_factor;
+      if (dd > 0) {
+        const double sc = (double)(1 << lvl);
+        const float fu_ = (float)bu, fv_ = (float)bv;
+        obs0 = fu_ * sc; obs1 = fv_ * sc; obs2 = (fu_ - dd) * sc;
+      } else status = SVS_MATCH_NO_DISP;
+    }
+  }
+  if (live && sub == 0) {
+    svs_match_result r;
+    r.status = status; r.u = bu; r.v = bv; r.znssd = best == 0x7fffffff ? init_dist : best;
+    r.obs[0] = obs0; r.obs[1] = obs1; r.obs[2] = obs2;
+    r.xyz_actkey[0] = textured ? pp->xyz_actkey[0] : 0.0; r.xyz_actkey[1] = textured ? pp->xyz_actkey[1] : 0.0; r.xyz_actkey[2] = textured ? pp->xyz_actkey[2] : 0.0;
+    out[(size_t)slot * A.out_bstride + ip] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs_match_result *d_out) {
@@ -584,20 +834,26 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   // the per-call tables live in the context (one buffer: relative poses per (stream, keyframe), then the predictions per point)
   const size_t kf_bytes = (((size_t)a->n_batch * a->n_kf * 24 * sizeof(double)) + 255) & ~(size_t)255;
   const size_t pred_bytes = (size_t)a->n_batch * a->n_pts * sizeof(PointPred);
+  const size_t lt_bytes = 256;
+  static_assert(sizeof(LevelTab) * SVS_NUM_PYR_LEVELS <= 256, "level table");
   void *buf = nullptr;
-  { const int rc = svs_ctx_match_scratch(ctx, kf_bytes + pred_bytes, &buf); if (rc) return rc; }
-  double *kf_T = static_cast<double *>(buf);
+  { const int rc = svs_ctx_match_scratch(ctx, lt_bytes + kf_bytes + pred_bytes, &buf); if (rc) return rc; }
+  M.lt = static_cast<LevelTab *>(buf);
+  double *kf_T = reinterpret_cast<double *>(static_cast<char *>(buf) + lt_bytes);
   M.kf_T = kf_T;
-  M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + kf_bytes);
-  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M.a, kf_T);
+  M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + lt_bytes + kf_bytes);
+  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M, kf_T);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
   SVS_LAUNCH_CHECK(ctx);
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
   // the lean scan resolves a window's cells once per point: it needs windows narrower than a cell (always so for the reference's grids and radii)
-  bool lean = !ctx->match_legacy;
+  // (option "match_legacy": 0 = the fastest kernel that applies, 1 = match_kernel, 2 = match_kernel2 where it applies)
+  bool lean = ctx->match_legacy != 1;
   for (int l = 0; l < M.fv.n_levels; ++l) lean = lean && 2 * a->search_radius + 1 <= std::min(M.fv.cell_w[l], M.fv.cell_h[l]);
-  if (lean) hipLaunchKernelGGL(match_kernel2, grid, block, 0, ctx->stream, M, d_out);
+  if (lean && ctx->match_legacy == 0 && 2 * a->search_radius + 1 <= 17)
+    hipLaunchKernelGGL(match_kernel3, dim3(div_up(a->n_pts, M3_GROUPS), a->n_batch), dim3(256), 0, ctx->stream, M, d_out);
+  else if (lean) hipLaunchKernelGGL(match_kernel2, grid, block, 0, ctx->stream, M, d_out);
   else hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;

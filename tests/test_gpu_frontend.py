@@ -135,7 +135,7 @@ def _match_setup(scene_frames, ctx, stream, n_per_level=(300, 150, 60), seed=5):
     return cam, fr, fg, pts, (img_k, disp_k, T_k), (img_c, disp_c, T_c)
 
 
-@pytest.mark.parametrize("legacy", [0, 1])
+@pytest.mark.parametrize("legacy", [0, 1, 2])
 @pytest.mark.parametrize("radius,thr_mean,thr_std", [(8, 22, 10), (4, 22, 10), (5, 12, 0)])
 def test_matcher_bit_exact(gpu_ctx, scene_frames, radius, thr_mean, thr_std, legacy):
     """GuidedMatcher::match: status, best corner, ZNSSD score bit-exact; obs / xyz_actkey to 1e-12.  The three parameter sets the oracle is pinned on against
