@@ -75,6 +75,23 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
   return best;
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t u) { s16x2 r; __builtin_memcpy(&r, &u, 4); return r; }
+__device__ __forceinline__ s16x2 arc9_maxmin_pk(const s16x2 (&d)[16]) {      // arc9_maxmin on two independent 16-bit lanes
+  s16x2 m2[16], m4[16], best = {-1024, -1024};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const s16x2 m8 = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+    const s16x2 m9 = __builtin_elementwise_min(m8, d[(k + 8) & 15]);
+    best = __builtin_elementwise_max(best, m9);
+  }
+  return best;
+}
+
 // K1.  Each lane scores 4 horizontally adjacent pixels: the 7 x 12-byte neighbourhood it needs is read
 // from LDS as 21 dwords (instead of ~20-36 byte reads per pixel) and ring pixels are picked with
 // compile-time byte extracts; the tile itself is staged with (unaligned) dword loads and the four
@@ -179,14 +196,16 @@ __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtr
     const int code = s_surv[i], py = code >> 8, px = code & 0xff;           // tile-local pixel
     const int cb = (py + 3) * (LROW * 4) + px + 4;
     const int v = s_b8[cb];
-    int d[16], e[16];
+    // both polarities at once: v - r in the low and r - v in the high 16-bit half, the min / max ladder on V_PK_MIN_I16 / V_PK_MAX_I16
+    s16x2 d[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int r = s_b8[cb + RDY[q] * (LROW * 4) + RDX[q]];
-      d[q] = v - r;
-      e[q] = r - v;
+      const int x = v - r;
+      d[q] = as_s16x2(((uint32_t)x & 0xffffu) | ((uint32_t)(-x) << 16));
     }
-    const int sc = max(arc9_maxmin(d), arc9_maxmin(e)) - 1;                 // corner at t <=> sc >= t
+    const s16x2 b2 = arc9_maxmin_pk(d);
+    const int sc = max((int)b2.x, (int)b2.y) - 1;                           // corner at t <=> sc >= t
     if (sc >= t) {
       const int s8 = min(sc + 1, 255);
       reinterpret_cast<uint8_t *>(s_sc)[py * 64 + px] = (uint8_t)s8;

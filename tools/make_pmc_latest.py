@@ -45,7 +45,7 @@ def main(fetch_txt, write_txt, bench_log, df_fetch_txt=None, df_write_txt=None, 
             "source": "scavislam_amd/csrc/ba_schur.inc", "source_sha16": sha("scavislam_amd/csrc/ba_schur.inc")}
     # the dominant kernel of every front-end stage at the bench's batch size (the launch with the largest fetch is the batched one): raw counters per launch
     B = bench["config"]["batch_streams_per_gpu"]
-    for key, sub, src in (("fast_score_kernel", "fast_score_kernel", "fast.hip"), ("match_kernel2", "match_kernel2", "match.hip"),
+    for key, sub, src in (("fast_score_kernel", "fast_score_kernel", "fast.hip"), ("match_kernel3", "match_kernel3", "match.hip"),
                           ("dense_track_cpu_sem_kernel", "dense_track_cpu_sem_kernel", "dense.hip"), ("motion_only_fused_kernel", "motion_only_fused_kernel", "dense.hip"),
                           ("stereo_bm_kernel", "stereo_bm_kernel", "stereo.hip"), ("stereo_speckle_strip_kernel", "stereo_speckle_strip_kernel", "stereo.hip"),
                           ("pyr_down_u8_kernel", "pyr_down_u8_kernel", "image.hip")):
