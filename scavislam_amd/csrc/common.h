@@ -27,6 +27,7 @@ struct svs_ctx {
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
+  int fe_overlap = 1;         // "fe_overlap": the one-call front end runs FAST / block matching on a side stream beside the dense tracker (0: one stream)
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow

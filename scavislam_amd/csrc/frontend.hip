@@ -138,6 +138,10 @@ struct svs_frontend {
   uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_upload[2] = {}, ev_done[2] = {};
+  // FAST (and block matching) need the new pyramid only, the dense tracker runs ~18 dependent sweeps per stream with a long tail (streams finish at
+  // different times): the detector stages are enqueued on a second stream and meet the chain again in front of the matcher
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prefetched = false, submitted = false, want_matches = false, want_gated = false;
   int n_submitted = 0;
   // accept / reject record of the dense tracker's LM loop, per stream (svs_frontend_dense_records)
@@ -164,6 +168,7 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   if (!fe) return SVS_OK;
   (void)hipStreamSynchronize(fe->ctx->stream);
   if (fe->copy_stream) (void)hipStreamSynchronize(fe->copy_stream);
+  if (fe->side_stream) (void)hipStreamSynchronize(fe->side_stream);
   if (fe->fast) svs_fast_destroy(fe->fast);
   if (fe->stereo) svs_stereo_destroy(fe->stereo);
   for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) if (fe->d_pyr[k][l]) (void)hipFree(fe->d_pyr[k][l]);
@@ -182,6 +187,9 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   if (fe->d_nrec) (void)hipFree(fe->d_nrec);
   for (hipEvent_t e : fe->ev_stage) if (e) (void)hipEventDestroy(e);
   if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
+  if (fe->side_stream) (void)hipStreamDestroy(fe->side_stream);
+  if (fe->ev_fork) (void)hipEventDestroy(fe->ev_fork);
+  if (fe->ev_join) (void)hipEventDestroy(fe->ev_join);
   delete fe;
   return SVS_OK;
 }
@@ -260,6 +268,13 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
   }
   if (hipHostMalloc((void **)&fe->h_out, fe->h_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(SVS_ERR_HIP);
   if (hipStreamCreateWithFlags(&fe->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(SVS_ERR_HIP);
+  {
+    int least = 0, greatest = 0;      // the chain's own stream keeps the first claim on the CUs
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&fe->side_stream, hipStreamNonBlocking, least) != hipSuccess) return fail(SVS_ERR_HIP);
+    if (hipEventCreateWithFlags(&fe->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_join, hipEventDisableTiming) != hipSuccess)
+      return fail(SVS_ERR_HIP);
+  }
   if (hipMalloc(&fe->d_rec, sizeof(svs_dense_lm_record) * REC_CAP * B) != hipSuccess || hipMalloc(&fe->d_nrec, sizeof(int32_t) * B) != hipSuccess ||
       hipMemsetAsync(fe->d_nrec, 0, sizeof(int32_t) * B, ctx->stream) != hipSuccess)
     return fail(SVS_ERR_HIP);
@@ -424,6 +439,25 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
   }
   double *d_T = fe->d_small, *d_Ta = fe->d_small + 12 * (size_t)B, *d_Tcw = fe->d_small + 24 * (size_t)B, *d_Twa = fe->d_small + 36 * (size_t)B;
   STAGE_MARK(1);
+  // "stereo" + "fast": they read the new pyramid (and the right image) only
+  auto detect = [&]() -> int {
+    int rc2;
+    if (fe->prm.use_block_matching) {                                                         // "stereo"
+      if ((rc2 = svs_stereo_compute(fe->stereo, fe->d_pyr[cur][0], fe->stride[0], fe->lvl_elems[0], fe->d_right[fe->i_cur], fe->stride[0], fe->lvl_elems[0], fe->d_disp[cur],
+                                    fe->stride[0], fe->lvl_elems[0], B)))
+        return rc2;
+      dv = DispView{fe->d_disp[cur], fe->stride[0], fe->lvl_elems[0]};
+    }
+    STAGE_MARK(3);
+    const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
+    const int trials = first ? (fe->prm.fast_trials > 1 ? fe->prm.fast_trials - 1 : 5) : fe->prm.fast_trials;      // stereo_frontend.cpp:118 / :232
+    return svs_fast_detect(fe->fast, imgs, fe->stride, fe->lvl_elems, B, trials);            // "fast"
+  };
+  // With the stage clocks off, the detector stages of a tracked frame go to the side stream, enqueued BEHIND the tracker (which claims the CUs first);
+  // their workgroups fill what the tracker leaves idle -- above all its tail, when most streams have converged.  (With the clocks on, every stage runs
+  // alone on the chain's stream so that the stage times add up to the step.)
+  const bool side = !first && fe->side_stream && ctx->fe_overlap && !fe->timing;
+  if (side) SVS_HIP(ctx, hipEventRecord(fe->ev_fork, ctx->stream));
   if (!first) {                                                                               // "dense tracking"
     if (fe->prm.cuda_build) {
       svs_dense_track_full_args ta{};
@@ -447,16 +481,17 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     }
   }
   STAGE_MARK(2);
-  if (fe->prm.use_block_matching) {                                                           // "stereo"
-    if ((rc = svs_stereo_compute(fe->stereo, fe->d_pyr[cur][0], fe->stride[0], fe->lvl_elems[0], fe->d_right[fe->i_cur], fe->stride[0], fe->lvl_elems[0], fe->d_disp[cur],
-                                 fe->stride[0], fe->lvl_elems[0], B)))
-      return rc;
-    dv = DispView{fe->d_disp[cur], fe->stride[0], fe->lvl_elems[0]};
-  }
-  STAGE_MARK(3);
-  const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
-  const int trials = first ? (fe->prm.fast_trials > 1 ? fe->prm.fast_trials - 1 : 5) : fe->prm.fast_trials;      // stereo_frontend.cpp:118 / :232
-  if ((rc = svs_fast_detect(fe->fast, imgs, fe->stride, fe->lvl_elems, B, trials))) return rc; // "fast"
+  if (side) {
+    hipStream_t chain_stream = ctx->stream;
+    SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_fork, 0));
+    ctx->stream = fe->side_stream;                                                            // (a context is used by one thread at a time)
+    rc = detect();
+    const hipError_t e = rc ? hipSuccess : hipEventRecord(fe->ev_join, fe->side_stream);
+    ctx->stream = chain_stream;
+    if (rc) return rc;
+    SVS_HIP(ctx, e);
+    SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_join, 0));
+  } else if ((rc = detect())) return rc;
   STAGE_MARK(4);
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"

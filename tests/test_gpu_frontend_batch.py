@@ -181,6 +181,27 @@ def test_prefetch_and_split_call_equal_blocking_call(gpu_ctx):
     assert np.abs(results["blocking"][-1][0] - I34).max() > 1e-3
 
 
+@pytest.mark.parametrize("block_matching", [False, True])
+def test_side_stream_schedule_equals_one_stream(gpu_ctx, block_matching):
+    """By default the chain enqueues FAST (and block matching) on a side stream beside the dense tracker (option "fe_overlap"); the schedule must not
+    change a bit of any output, over several frames in a row (the side stream's work of frame N + 1 must wait for frame N's matcher, which reads the
+    same score maps)."""
+    from scavislam_amd import capi
+    ctx, stream = gpu_ctx
+    cam, S = _streams(1, block_matching)
+    prm = capi.FrontendParams.reference(use_block_matching=block_matching)
+    runs = {}
+    for mode in (1, 0):
+        ctx.set_option("fe_overlap", mode)
+        try:
+            runs[mode] = [_single(ctx, cam, S[0], prm), _single(ctx, cam, S[0], prm, prefetch=True)]
+        finally:
+            ctx.set_option("fe_overlap", 1)
+    for a, b in zip(runs[1], runs[0]):
+        _same(a, b, "side stream")
+    assert runs[1][0][0].n_matched > 100
+
+
 def test_two_front_end_levels(gpu_ctx):
     """use_n_levels_in_frontent = 2 (the reference's code default, stereo_frontend.cpp:68): FAST and the matcher run on levels 0 and 1 only.  Corner
     lists of those levels equal the oracle's; candidates of levels 0 / 1 get the results of the three-level run (levels are independent), a level-2
