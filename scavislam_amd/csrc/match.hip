@@ -758,30 +758,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const bool textured = go;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  // ---- (5) ZNSSD of every hit, the four points of the wave in step
+  // ---- (5) ZNSSD of every hit: the four points of the wave in step, TWO hits of a point per step -- the halves of its DPP row take one each, lane = row of the
+  // 8 x 8 patch (one 8-byte request, six dot products, an 8-lane butterfly for iB and sBB + 2 sAB); the key rows move to that layout once per point
   const int n = go ? s_ncand[grp] : 0;
   const int cstride = Lp->cstride;
-  const uint8_t *pbase = Lp->cimg + (size_t)slot * Lp->cur_bstride + (ptrdiff_t)(y0 - 4 + prow) * cstride + (x0 - 4 + pc0);
+  const int r8 = sub & 7, half = sub >> 3;
+  const int lane_k = (int)(threadIdx.x & 48u) + 2 * r8;
+  const uint32_t key_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * lane_k, (int)keyd), key_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * lane_k + 4, (int)keyd);
+  const uint8_t *pbase = Lp->cimg + (size_t)slot * Lp->cur_bstride + (ptrdiff_t)(y0 - 4 + r8) * cstride + (x0 - 4);
   int best = 0x7fffffff, bu = 0, bv = 0;
-  auto fetch = [&](int i, uint32_t &v, int &wx, int &wy) {
-    v = 0; wx = 0; wy = 0;
-    if (i < n) {
-      const int code = s_cand[grp][i];
+  auto fetch = [&](int ci, U2 &v, int &wx, int &wy) {
+    v = U2{0u, 0u}; wx = 0; wy = 0;
+    if (ci < n) {
+      const int code = s_cand[grp][ci];
       wx = code & 31; wy = code >> 5;
-      __builtin_memcpy(&v, pbase + (ptrdiff_t)wy * cstride + wx, 4);
+      v = ld_u2u(pbase + (ptrdiff_t)wy * cstride + wx);
     }
   };
-  uint32_t v_nx; int wx_nx, wy_nx;
-  fetch(0, v_nx, wx_nx, wy_nx);
-  for (int i = 0; __ballot(i < n) != 0ull; ++i) {
-    const bool act = i < n;
-    const uint32_t v = v_nx;
+  U2 v_nx; int wx_nx, wy_nx;
+  fetch(half, v_nx, wx_nx, wy_nx);
+  for (int i = 0; __ballot(2 * i < n) != 0ull; ++i) {
+    const int ci = 2 * i + half;
+    const bool act = ci < n;
+    const U2 v = v_nx;
     const int wx = wx_nx, wy = wy_nx;
-    fetch(i + 1, v_nx, wx_nx, wy_nx);              // the next hit's pixels travel while this one is summed
-    const int iB = (int)row16_sum(__builtin_amdgcn_sad_u8(v, 0u, 0u));
-    const int sBB = (int)row16_sum(__builtin_amdgcn_udot4(v, v, 0u, false));
-    const int sAB = (int)row16_sum(__builtin_amdgcn_udot4(v, keyd, 0u, false));
-    const int z = sumAA - 2 * sAB - sBB - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
+    fetch(ci + 2, v_nx, wx_nx, wy_nx);             // the next pair's pixels travel while this one is summed
+    uint32_t iBl = __builtin_amdgcn_sad_u8(v.y, 0u, __builtin_amdgcn_sad_u8(v.x, 0u, 0u));
+    uint32_t tl = __builtin_amdgcn_udot4(v.y, v.y, __builtin_amdgcn_udot4(v.x, v.x, 0u, false), false) +
+                  2u * __builtin_amdgcn_udot4(v.y, key_hi, __builtin_amdgcn_udot4(v.x, key_lo, 0u, false), false);      // sBB + 2 sAB <= 3 * 64 * 255^2
+    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0xB1, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0xB1, 0xf, 0xf, true);
+    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0x4E, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x4E, 0xf, 0xf, true);
+    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0x141, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x141, 0xf, 0xf, true);
+    const int iB = (int)iBl;
+    const int z = sumAA - (int)tl - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
     // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, quadrant key); z must also beat thr_mean.
     // The quadrant keys are only needed to break ties, which are rare: behind a wave-uniform branch, so that they are not evaluated (predicated) per hit.
     const int hx = x0 + wx, hy = y0 + wy;
@@ -792,6 +801,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (good && z == best && quad_key(hx_, hy, Lw, Lh) < quad_key(bu_, bv, Lw, Lh)) { bu = hx; bv = hy; }
     }
     if (good && z < best) { best = z; bu = hx; bv = hy; }
+  }
+  {   // the two halves of the row meet (row_mirror: lane i <-> 15 - i)
+    const int oz = __builtin_amdgcn_update_dpp(0, best, 0x140, 0xf, 0xf, true), ou = __builtin_amdgcn_update_dpp(0, bu, 0x140, 0xf, 0xf, true),
+              ov = __builtin_amdgcn_update_dpp(0, bv, 0x140, 0xf, 0xf, true);
+    if (__ballot(oz == best && best != 0x7fffffff && (ou != bu || ov != bv)) != 0ull) {
+      int ou_ = ou, bu_ = bu;
+      asm volatile("" : "+v"(ou_), "+v"(bu_));
+      if (oz == best && best != 0x7fffffff && quad_key(ou_, ov, Lw, Lh) < quad_key(bu_, bv, Lw, Lh)) { bu = ou; bv = ov; }
+    }
+    if (oz < best) { best = oz; bu = ou; bv = ov; }
   }
   double obs0 = 0, obs1 = 0, obs2 = 0;
   if (go) {
