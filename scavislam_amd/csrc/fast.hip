@@ -168,22 +168,20 @@ __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtr
     for (int p = 0; p < 2; ++p) {
       const uint32_t vpair = pair_of(win[3], 4 + 2 * p);
       const uint32_t Vd = vpair + Kd, Vb = Kd - vpair;
-      uint32_t dm = 0, bm = 0;      // bit i of a half = compass point i (ring position 4 i)
+      // the verdicts stay where the subtraction leaves them (bit 15 of each half): two consecutive compass points (cyclically) in one polarity is
+      // (X0 & X1) | (X1 & X2) | (X2 & X3) | (X3 & X0) on those bits -- four V_AND_OR per polarity, no mask building
+      uint32_t X[4], Y[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = 4 * i;
         const uint32_t rp = pair_of(win[3 + RDY[q]], 4 + 2 * p + RDX[q]);
-        const uint32_t X = Vd - rp, Y = rp + Vb;
-        dm = ((X >> (15 - i)) & (0x00010001u << i)) | dm;
-        bm = ((Y >> (15 - i)) & (0x00010001u << i)) | bm;
+        X[i] = Vd - rp; Y[i] = rp + Vb;
       }
-      // two consecutive compass points (cyclically) in one polarity: m & rot1(m) on the 4-bit masks of both halves at once
-      const uint32_t dr = ((dm >> 1) | (dm << 3)) & 0x000f000fu, br = ((bm >> 1) | (bm << 3)) & 0x000f000fu;
-      const uint32_t pass = (dm & dr) | (bm & br);
+      const uint32_t pass = ((X[0] & X[1]) | (X[1] & X[2]) | (X[2] & X[3]) | (X[3] & X[0]) | (Y[0] & Y[1]) | (Y[1] & Y[2]) | (Y[2] & Y[3]) | (Y[3] & Y[0])) & 0x80008000u;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 2 * p + h, cx = cx0 + k;
-        const bool surv = row_ok && cx >= 3 && cx < L.cell_w - 3 && ((pass >> (16 * h)) & 0xfu) != 0;
+        const bool surv = row_ok && cx >= 3 && cx < L.cell_w - 3 && ((pass >> (16 * h)) & 0x8000u) != 0;
         if (surv) { const int slot_i = atomicAdd(&s_nsurv, 1); s_surv[slot_i] = (uint16_t)((ty << 8) | (4 * tx + k)); }
       }
     }
