@@ -18,6 +18,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python tools/pmc_any.py dense_track_full $(find $out/pmcdf_$c -name "*.db") > $out/pmcdf_$c.txt 2>&1
   rm -rf $out/pmcdf_$c
 done
+# the multi-process launch line of the contract at world size 1: RCCL bound at run time, the library issues the collectives (count in schur.weak_scaling / config.collective)
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu > $out/torchrun_bench.json 2> $out/torchrun_bench.err
+echo "torchrun rc=$?"
 python tools/rocpd_summary.py $(find $out/trace -name "*.db") > $out/trace_summary.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do python tools/pmc_any.py "" $(find $out/pmc_$c -name "*.db") > $out/pmc_$c.txt 2>&1; done
 python tools/make_pmc_latest.py $out/pmc_FETCH_SIZE.txt $out/pmc_WRITE_SIZE.txt $out/bench.log $out/pmcdf_FETCH_SIZE.txt $out/pmcdf_WRITE_SIZE.txt $out/pmcdf_FETCH_SIZE.log > $out/pmc_latest.json
