@@ -136,11 +136,12 @@ def _match_setup(scene_frames, ctx, stream, n_per_level=(300, 150, 60), seed=5):
 
 
 @pytest.mark.parametrize("legacy", [0, 1, 2])
-@pytest.mark.parametrize("radius,thr_mean,thr_std", [(8, 22, 10), (4, 22, 10), (5, 12, 0)])
+@pytest.mark.parametrize("radius,thr_mean,thr_std", [(8, 22, 10), (4, 22, 10), (5, 12, 0), (10, 22, 10)])
 def test_matcher_bit_exact(gpu_ctx, scene_frames, radius, thr_mean, thr_std, legacy):
     """GuidedMatcher::match: status, best corner, ZNSSD score bit-exact; obs / xyz_actkey to 1e-12.  The three parameter sets the oracle is pinned on against
     the reference-compiled matcher (tests/test_ref_pin_cpu.py): radius 8 = the CPU build, radius 4 = the CUDA build (stereo_frontend.cpp:1043-1047), and
-    (12, 0, 5) = non-default thresholds; each through both kernels (the eight-positions-per-lane scan and the one-point-per-wave one)."""
+    (12, 0, 5) = non-default thresholds, radius 10 = a window wider than 17 (beyond the four-points-per-wave kernel: the library falls back to one wave
+    per point); each with the kernel choice left to the library (0) and forced to the round-1/2 kernel (1) and the lean one-wave-per-point kernel (2)."""
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.frontend import FramePyramid, GuidedMatcher

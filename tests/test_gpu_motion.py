@@ -43,15 +43,23 @@ def _run(gpu_ctx, cam, res_batch, T0, prm=None):
     return d_T.cpu().numpy().reshape(B, 3, 4), [PoseOptStats.from_buffer_copy(raw[i * sz:(i + 1) * sz].tobytes()) for i in range(B)], camc
 
 
-def test_motion_only_matches_oracle(gpu_ctx):
+@pytest.mark.parametrize("shape,n", [("fused", 400), ("fused", 2600), ("legacy", 400)])
+def test_motion_only_matches_oracle(gpu_ctx, shape, n):
+    """the fused kernel with lists short and longer than what its registers hold (4 observations per lane of 512: the rest is re-read through the index
+    list), and the record-walking kernel of rounds 1-2"""
     import oracle as O
     from scavislam_amd import synth
     rng = np.random.default_rng(17)
     cam = synth.CAM_DEFAULT
     T_true = synth.pose(synth.so3_exp(np.array([0.01, -0.02, 0.005])), np.array([0.03, -0.01, 0.08]))
     T0 = synth.pose(np.eye(3), np.zeros(3))
-    batch = np.stack([_synthetic_results(rng, cam, T_true, 400) for _ in range(3)])
-    Tg, stg, camc = _run(gpu_ctx, cam, batch, T0)
+    batch = np.stack([_synthetic_results(rng, cam, T_true, n) for _ in range(3)])
+    ctx = gpu_ctx[0]
+    ctx.set_option("mo_legacy", 1 if shape == "legacy" else 0)
+    try:
+        Tg, stg, camc = _run(gpu_ctx, cam, batch, T0)
+    finally:
+        ctx.set_option("mo_legacy", 0)
     for b in range(3):
         Tr, sr = O.motion_only(batch[b], camc, T0)
         assert stg[b].status == 0 and stg[b].num_obs == sr.num_obs == int((batch[b]["status"] == 0).sum())
