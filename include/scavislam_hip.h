@@ -117,7 +117,11 @@ int svs_ctx_sync(svs_ctx *ctx);
 /* experiment / test switches (0 = automatic choice): "trk_nwg" workgroups per stream of the latency-mode quarter-grid
    tracker, "trk_regs" its register budget (1: one workgroup per CU, 2: two), "full_nwg" workgroups per stream of the
    full-resolution tracker.  The environment (SVS_TRK_NWG, SVS_TRK_ONE_PER_CU / SVS_TRK_TWO_PER_CU, SVS_FULL_NWG) only
-   supplies the initial values, read once by svs_ctx_create. */
+   supplies the initial values, read once by svs_ctx_create.  A/B switches between kernels that return the same results:
+   "match_legacy" (0: four candidate points per wave where the search window allows it, 1: the round-1/2 kernel, 2: one wave per
+   point with the lean scan), "mo_legacy" (1: the record-walking motion-only kernel), "fe_overlap" (default 1: the one-call
+   front end enqueues FAST / block matching on a side stream beside the dense tracker; 0: everything on the context's stream).
+   A context and every handle made from it are used by ONE thread at a time. */
 int svs_ctx_set_option(svs_ctx *ctx, const char *name, int value);
 void *svs_ctx_stream(svs_ctx *ctx);
 const char *svs_last_error(svs_ctx *ctx);
