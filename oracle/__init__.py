@@ -937,7 +937,8 @@ def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, li
         # in scavislam_amd/libscavislam_hip.so on the GPU -- load that library first (through torch's HIP runtime), the branch library binds to it
         from scavislam_amd import capi
         capi.load()
-    L = _ref_lib("libsvs_hipbranch_frame.so" if hip_branch else ("libsvs_ref_frame_cuda.so" if cuda_build else "libsvs_ref_frame.so"))
+    L = _ref_lib(("libsvs_hipbranch_frame_cuda.so" if cuda_build else "libsvs_hipbranch_frame.so") if hip_branch else
+                 ("libsvs_ref_frame_cuda.so" if cuda_build else "libsvs_ref_frame.so"))
     L.svs_refframe_set_fast.argtypes = [C.c_void_p]
     L.svs_refframe_set_fast(C.cast(lib().svs_ref_fast9_16, C.c_void_p))
     n_kf = len(kf_pyrs)
@@ -975,6 +976,86 @@ def ref_process_frame(kf_pyrs, kf_poses, actkey_index, neighbours, cams, pts, li
     for l in range(3):
         out_lines.append(lines[k:k + n_lines[l]].copy()); k += n_lines[l]
     return dict(ok=bool(ok), T=T.reshape(3, 4), clouds=clouds, rimg=rimg, lines=out_lines, av_track_length=av.value, is_frame_dropped=bool(dropped.value))
+
+
+class RefSequence:
+    """BASELINE configs[0]: ONE StereoFrontend of the reference alive across a sequence of frames, driven the way stereo_slam.cpp's main loop drives it
+    (oracle/_ref/libsvs_ref_seq.so = the reference's CPU build; hip_branch=True: libsvs_hipbranch_seq.so = the same translation unit compiled with the
+    SCAVISLAM_HIP_SUPPORT branch in place, its arithmetic on the GPU).  Nothing of the keyframe logic is stubbed: processFirstFrame, processFrame, shallWeSwitchKeyframe,
+    shallWeDropNewKeyframe, addNewKeyframe, addNewPoints / addMorePoints, recomputeFastCorners are the reference's lines (stereo_frontend.cpp:39-528,656-1065)."""
+
+    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011):
+        if hip_branch:
+            from scavislam_amd import capi
+            capi.load()
+        self.L = L = _ref_lib("libsvs_hipbranch_seq.so" if hip_branch else "libsvs_ref_seq.so")
+        L.svs_refseq_create.restype = C.c_void_p
+        L.svs_refseq_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
+        L.svs_refseq_destroy.argtypes = [C.c_void_p]
+        L.svs_refseq_push_frame.argtypes = [C.c_void_p] * 6
+        L.svs_refseq_step.argtypes = [C.c_void_p] * 4
+        L.svs_refseq_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.svs_refseq_fast_thresholds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.svs_refseq_new_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.svs_refseq_recompute_fast_corners.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.svs_refseq_set_var.argtypes = [C.c_char_p, C.c_double]
+        L.svs_refseq_nudge.argtypes = [C.c_void_p, C.c_double]
+        self.cams = cams
+        self.h = L.svs_refseq_create(cams, use_n_levels, C.cast(lib().svs_ref_fast9_16, C.c_void_p), sample_seed)
+
+    def set_var(self, name, value):
+        """a live pangolin::Var of the reference (ui.parallax_thr, ui.num_max_points, ui.max_reproj_error, ui.min_num_points ...)"""
+        self.L.svs_refseq_set_var(name.encode(), float(value))
+
+    def step(self, img_u8, disp):
+        """FrameGrabber::processNextFrame (pyramid + f32 / Sobel images by the oracle's restatement of the OpenCV calls) + processFirstFrame / processFrame.
+        Returns dict(ok, dropped, actkey_id, switched, n_keyframes, id_counter, n_neighbourhood_points, n_new_points, n_vertices, T, av_track_length, lines, fast_thr)."""
+        pyr = build_pyramid(img_u8)
+        fl = [convert_sobel(q) for q in pyr]
+        P3 = C.c_void_p * 3
+        keep = [np.ascontiguousarray(a) for a in pyr] + [np.ascontiguousarray(f[k]) for k in range(3) for f in fl]
+        d = np.ascontiguousarray(disp, np.float32)
+        self.L.svs_refseq_push_frame(self.h, P3(*[a.ctypes.data for a in keep[:3]]), P3(*[a.ctypes.data for a in keep[3:6]]), P3(*[a.ctypes.data for a in keep[6:9]]),
+                                     P3(*[a.ctypes.data for a in keep[9:12]]), _p(d))
+        info = np.zeros(8, np.int32); T = np.zeros(12); av = C.c_double(0)
+        ok = self.L.svs_refseq_step(self.h, _p(info), _p(T), C.byref(av))
+        cap = 8192
+        lines = np.zeros((cap, 5)); n_lines = (C.c_int * 3)()
+        m = self.L.svs_refseq_lines(self.h, _p(lines), cap, n_lines)
+        assert m <= cap
+        out_lines, k = [], 0
+        for l in range(3):
+            out_lines.append(lines[k:k + n_lines[l]].copy()); k += n_lines[l]
+        thr = np.zeros(64, np.int32)
+        nt = self.L.svs_refseq_fast_thresholds(self.h, _p(thr), 64)
+        return dict(ok=bool(ok), dropped=bool(info[0]), actkey_id=int(info[1]), switched=bool(info[2]), n_keyframes=int(info[3]), id_counter=int(info[4]),
+                    n_neighbourhood_points=int(info[5]), n_new_points=int(info[6]), n_vertices=int(info[7]), T=T.reshape(3, 4), av_track_length=av.value,
+                    lines=out_lines, fast_thr=thr[:nt].copy())
+
+    def nudge(self, rel):
+        """scales the translation of T_cur_from_actkey by (1 + rel) between two frames (the yardstick of tests/test_gpu_sequence.py)"""
+        self.L.svs_refseq_nudge(self.h, float(rel))
+
+    def new_points(self, keyframe_id, cap=4096):
+        ids = np.zeros((cap, 2), np.int32); val = np.zeros((cap, 6))
+        n = self.L.svs_refseq_new_points(self.h, int(keyframe_id), _p(ids), _p(val), cap)
+        return ids[:n].copy(), val[:n].copy()
+
+    def recompute_fast_corners(self, keyframe_id, level, cap=8192):
+        xy = np.zeros((cap, 3))
+        n = self.L.svs_refseq_recompute_fast_corners(self.h, int(keyframe_id), int(level), _p(xy), cap)
+        return None if n < 0 else xy[:n].copy()
+
+    def close(self):
+        if self.h:
+            self.L.svs_refseq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _cam6(cams):

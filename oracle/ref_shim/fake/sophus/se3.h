@@ -15,6 +15,7 @@ class SE3 {
   Eigen::Vector3d operator*(const Eigen::Vector3d &p) const { Eigen::Vector3d r; pose_act(T, p.v, r.v); return r; }
   SE3 operator*(const SE3 &o) const { SE3 r; pose_mul(T, o.T, r.T); return r; }
   static SE3 exp(const Eigen::Matrix<double, 6, 1> &x) { SE3 r; se3_exp(x.v, r.T); return r; }
+  Eigen::Vector3d translation() const { return Eigen::Vector3d(T[3], T[7], T[11]); }
   SE3 inverse() const { SE3 r; pose_inv(T, r.T); return r; }
   Eigen::Matrix3d rotation_matrix() const { Eigen::Matrix3d R; pose_R(T, R.v); return R; }
   Eigen::Matrix<double, 6, 6> Adj() const { Eigen::Matrix<double, 6, 6> A; se3_adj(T, A.v); return A; }

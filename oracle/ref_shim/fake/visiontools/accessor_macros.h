@@ -5,6 +5,7 @@
 #pragma once
 #include <cassert>
 #include <tr1/memory>
+#include <utility>
 namespace VisionTools {
 template <class T> const T &svs_elem(const T &v) { return v; }
 template <class T> T *svs_elem(T *const &p) { return p; }
@@ -25,3 +26,14 @@ template <class K, class M> decltype(auto) svs_get_map_elem_ref(const K &k, M *m
 #define GET_MAP_ELEM(key, map) VisionTools::svs_get_map_elem(key, map)
 #define GET_MAP_ELEM_REF(key, map) VisionTools::svs_get_map_elem_ref(key, map)
 #define GET_VEC_VAL_REF(idx, vec) ((vec)->at(idx))
+// IS_IN_SET(key, container): membership by find(); ADD_TO_MAP_ELEM(key, val, pointer to map): map[key] += val, the element made (from val) when absent --
+// as StereoFrontend::addNewKeyframe / shallWeSwitchKeyframe (stereo_frontend.cpp:309-510) use them
+namespace VisionTools {
+template <class K, class M, class V> void svs_add_to_map_elem(const K &k, const V &v, M *m) {
+  typename M::iterator it = m->find(k);
+  if (it == m->end()) m->insert(std::make_pair(k, v));
+  else it->second += v;
+}
+}
+#define IS_IN_SET(key, set) ((set).find(key) != (set).end())
+#define ADD_TO_MAP_ELEM(key, val, map) VisionTools::svs_add_to_map_elem(key, val, map)

@@ -32,6 +32,8 @@ class LinearCamera : public AbstractCamera {
   cv::Size size_;
 };
 inline int zeroFromPyr_i(int pyr, int level) { return pyr << level; }
+inline int pyrFromZero_i(int zero, int level) { return zero >> level; }
+inline Vector2i zeroFromPyr_2i(const Vector2i &pyr, int level) { return Vector2i(zeroFromPyr_i(pyr[0], level), zeroFromPyr_i(pyr[1], level)); }
 inline Vector2d pyrFromZero_2d(const Vector2d &zero, int level) { return Vector2d(pyrFromZero_d(zero[0], level), pyrFromZero_d(zero[1], level)); }
 inline double zeroFromPyr_d(double pyr, int level) { return pyr * (double)(1 << level); }
 inline Vector2d zeroFromPyr_2d(const Vector2d &pyr, int level) { return Vector2d(zeroFromPyr_d(pyr[0], level), zeroFromPyr_d(pyr[1], level)); }

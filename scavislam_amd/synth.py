@@ -394,3 +394,10 @@ def dense_full_case(cam=None, seed=2013, step=0.03, yaw_deg=0.3, holes=True, sce
     if holes:
         disp_p = depth_holes(disp_p, np.random.default_rng(seed + 5))
     return dict(img_prev=img_p, img_cur=img_c, disp_prev=disp_p, T_true=pose_mul(T_c, pose_inv(T_p)), cam=cam)
+
+
+def trajectory_there_and_back(n=200, turn=110, step=0.05, yaw_deg=0.2):
+    """BASELINE configs[0] ("first 200 frames"): forward along `trajectory` for `turn` frames, then back over the same poses -- the way back passes the keyframes the
+    way out dropped, so a front end run over it drops keyframes AND switches back to old ones (stereo_frontend.cpp:445-510)."""
+    fwd = trajectory(max(turn, n - turn) + 1, step, yaw_deg)
+    return [fwd[i if i < turn else 2 * turn - i] for i in range(n)]

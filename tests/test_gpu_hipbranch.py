@@ -85,6 +85,45 @@ def test_reference_process_frame_with_hip_branch_in_place(gpu_ctx, camname):
     print(f"{camname}: HIP branch in place vs the reference's CPU build: pose deviation {dT:.2e}, {n_lines} draw lines identical, residual images agree on {same_rimg}")
 
 
+def test_reference_process_frame_cuda_build_with_hip_branch_in_place(gpu_ctx):
+    """The reference's CUDA build (SCAVISLAM_CUDA_SUPPORT) with the HIP branch in place AT THE CUDA SWITCHES (missing 6): libsvs_hipbranch_frame_cuda.so
+    is the translation unit of libsvs_ref_frame_cuda.so compiled with SCAVISLAM_HIP_SUPPORT as well -- declarations, members and the matcher radius (4) are the CUDA
+    build's, `tracker_.denseTrackingGpu` / the disparity upload / `computeDensePointCloudGpu` (stereo_frontend.cpp:192-196,213-215,298-302) and the CUDA branch of
+    preprocessing run in libscavislam_hip.so.  Against the same unit running the reference's own kernels through the CUDA emulator: draw lists identical, pose within
+    2e-5 (the reference's kernels sum in f32, the HIP tracker in f64), clouds 1e-4."""
+    if not (_have("libsvs_hipbranch_frame_cuda.so") and _have("libsvs_ref_frame_cuda.so")):
+        pytest.skip("oracle/_ref/libsvs_hipbranch_frame_cuda.so / libsvs_ref_frame_cuda.so not present")
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import level_cams
+    from test_gpu_ref_frame import I34, _cuda_case
+    case, pts, list_of, disp_c = _cuda_case()
+    camd = case["cam"]
+    cams = level_cams(camd["f"], camd["cx"], camd["cy"], camd["b"], camd["w"], camd["h"])
+    fp, _, _ = O.preprocess_gpu_sem(case["img_prev"])
+    fc, dx, dy = O.preprocess_gpu_sem(case["img_cur"])
+    cloud_prev = O.ref_pointcloud_gpu(case["disp_prev"], synth.level_cams(camd), I34)
+    pyr_k, pyr_c = O.build_pyramid(case["img_prev"]), O.build_pyramid(case["img_cur"])
+    args = ([pyr_k], [I34.reshape(12)], 0, [], cams, pts, list_of, I34, cloud_prev, fp, pyr_c, fc, dx, dy, disp_c)
+    ref = O.ref_process_frame(*args, cuda_build=True)
+    hip = O.ref_process_frame(*args, cuda_build=True, hip_branch=True)
+    assert ref["ok"] and hip["ok"]
+    n_lines = 0
+    for l in range(3):
+        assert hip["lines"][l].shape == ref["lines"][l].shape, (l, hip["lines"][l].shape, ref["lines"][l].shape)
+        assert np.array_equal(hip["lines"][l], ref["lines"][l]), f"draw lines of level {l}"
+        n_lines += len(ref["lines"][l])
+    assert n_lines > 40
+    dT = np.abs(hip["T"] - ref["T"]).max()
+    assert dT < 2e-5, dT
+    assert abs(hip["av_track_length"] - ref["av_track_length"]) <= 1e-9 * max(1.0, ref["av_track_length"])
+    for l in range(3):
+        a, b = hip["clouds"][l], ref["clouds"][l]
+        assert np.array_equal(a[..., 3], b[..., 3])
+        np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-4)
+    print(f"CUDA build with the HIP branch in place: pose deviation {dT:.2e}, {n_lines} draw lines identical")
+
+
 def _graph_tables(prob, n_outer, rng):
     """a double window in the shape of the reference's tables (ids from one counter, observations of frames outside the window in the vis_sets,
     marginalised pose-pose edges with an OUTER end + co-visibility edges without a constraint), from the flat arrays of synth.ba_window"""

@@ -1,0 +1,55 @@
+"""CPU suite: the sequence fixture tests/golden/ref_seq_*.npz (BASELINE configs[0]) is what the reference's own front-end loop produces -- oracle/_ref/libsvs_ref_seq.so,
+compiled from stereo_frontend.cpp:39-528,656-1065 + matcher + dense tracker + FastGrid where they lie (oracle/Makefile) -- and that loop is reproducible and stable
+enough to be a yardstick: a one-ulp nudge of the pose between two frames leaves every decision and every accepted point of the following frames unchanged."""
+import os
+
+import numpy as np
+import pytest
+
+import seq_common as S
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _seq(camname):
+    import oracle as O
+    from scavislam_amd.ctypes_types import level_cams
+    if not os.path.exists(os.path.join(os.path.dirname(O.__file__), "_ref", "libsvs_ref_seq.so")) and not os.path.isdir("/root/reference/scavislam"):
+        pytest.skip("oracle/_ref/libsvs_ref_seq.so not present (built where /root/reference exists)")
+    cam = S.cam_of(camname)
+    return O.RefSequence(level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"]))
+
+
+def test_sequence_fixture_is_the_reference_loop():
+    fx = dict(np.load(os.path.join(GOLDEN, "ref_seq_newcollege.npz")))
+    assert fx["head"][:, 1].sum() >= 5 and fx["head"][:, 2].sum() >= 3 and len(fx["crc"]) == S.N_FRAMES      # keyframes dropped, switches to old keyframes
+    seq = _seq("newcollege")
+    rec = S.run(seq, "newcollege", 36)      # past the first keyframe drops (frames 16 and 32)
+    if not np.array_equal(np.array([r["crc"] for r in rec], np.uint64), fx["crc"][:36]):
+        pytest.skip("the synthetic renderer produces other bytes on this host than where the fixture was generated")
+    assert S.compare_fixture(rec, fx, pose_tol=0.0, what="reference CPU build vs its fixture") == 0.0
+    kf = int(fx["recompute_kf"][0])
+    for l in range(3):
+        assert np.array_equal(seq.recompute_fast_corners(kf, l).astype(np.int16), fx[f"recompute_0_{l}"])
+    seq.close()
+
+
+def test_reference_loop_is_stable_under_a_one_ulp_nudge():
+    """the yardstick of tests/test_gpu_sequence.py: what a perturbation of the size of a different summation order does to the REFERENCE's own later frames"""
+    seq = _seq("newcollege")
+    ref = S.run(seq, "newcollege", 36)
+    seq.close()
+    seq = _seq("newcollege")
+    rec = []
+    for i, (img, disp) in enumerate(S.frames("newcollege", 36)):
+        r = seq.step(img, disp)
+        r["lines"] = [ln[np.lexsort((ln[:, 4], ln[:, 3], ln[:, 2], ln[:, 1], -ln[:, 0]))] if len(ln) else ln for ln in r["lines"]]
+        if r["dropped"]:
+            r["new_ids"], r["new_val"] = seq.new_points(r["actkey_id"])
+        rec.append(r)
+        if i in (3, 17):
+            seq.nudge(2.2e-16)
+    seq.close()
+    worst, n_lines = S.compare_live(rec, ref, pose_tol=1e-12, what="nudged reference vs reference")
+    assert n_lines > 5000
+    print(f"one-ulp nudges at frames 3 and 17: {n_lines} accepted points identical over 36 frames, max pose deviation {worst:.1e}")
