@@ -28,6 +28,12 @@
 extern "C" {
 #endif
 
+/* ABI version: bumped whenever a struct of this header grows or a signature changes (round 3 grew svs_pose_opt_params / svs_match_args and put a `stream`
+   argument into svs_frontend_device_view without one -- INTEGRATION.md section 6).  A caller checks svs_api_version() == SVS_API_VERSION once, zero-initialises
+   every parameter struct (or takes it from the *_default() initialisers) and sets only the fields it knows. */
+#define SVS_API_VERSION 4
+int svs_api_version(void);             /* the SVS_API_VERSION the loaded library was built with */
+
 enum {
   SVS_OK = 0,
   SVS_ERR_INVALID = 1,      /* bad argument */
@@ -218,6 +224,9 @@ typedef struct {
                               with fewer than min_obs the pose is left untouched and status = 3; 0 = no minimum */
   int32_t pad_;
 } svs_pose_opt_params;
+/* PoseOptimizerParams(robust_kernel = true, kernel_param = 2, num_iter = 15) as the front end passes it (stereo_frontend.cpp:1061); initial_mu = -1, tau = 1e-5
+   (pose_optimizer.h:36-58), min_obs = 0 */
+void svs_pose_opt_params_default(svs_pose_opt_params *p);
 typedef struct {           /* OptimizerStatistics, pose_optimizer.h:59-98 */
   double initial_chi2, chi2, max_err;
   int32_t num_obs;

@@ -998,14 +998,15 @@ class RefSequence:
         L.svs_refseq_fast_thresholds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.svs_refseq_new_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.svs_refseq_recompute_fast_corners.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
-        L.svs_refseq_set_var.argtypes = [C.c_char_p, C.c_double]
+        L.svs_refseq_set_var.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.svs_refseq_nudge.argtypes = [C.c_void_p, C.c_double]
         self.cams = cams
         self.h = L.svs_refseq_create(cams, use_n_levels, C.cast(lib().svs_ref_fast9_16, C.c_void_p), sample_seed)
 
     def set_var(self, name, value):
-        """a live pangolin::Var of the reference (ui.parallax_thr, ui.num_max_points, ui.max_reproj_error, ui.min_num_points ...)"""
-        self.L.svs_refseq_set_var(name.encode(), float(value))
+        """a live pangolin::Var of the reference (ui.parallax_thr, ui.num_max_points, ui.max_reproj_error, ui.min_num_points ...); "svs.<option>": an option of the
+        HIP context behind the branch (svs_ctx_set_option), ignored by the CPU build"""
+        self.L.svs_refseq_set_var(self.h, name.encode(), float(value))
 
     def step(self, img_u8, disp):
         """FrameGrabber::processNextFrame (pyramid + f32 / Sobel images by the oracle's restatement of the OpenCV calls) + processFirstFrame / processFrame.

@@ -191,7 +191,8 @@ _SIGS = {
     "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_int32)],
 }
-EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error", "svs_api_version", "svs_pose_opt_params_default"])
+API_VERSION = 4      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
 
 
 def load():
@@ -213,6 +214,12 @@ def load():
         lib.svs_ctx_stream.restype = C.c_void_p
         lib.svs_last_error.argtypes = [C.c_void_p]
         lib.svs_last_error.restype = C.c_char_p
+        lib.svs_api_version.argtypes = []
+        lib.svs_api_version.restype = C.c_int
+        lib.svs_pose_opt_params_default.argtypes = [C.c_void_p]
+        lib.svs_pose_opt_params_default.restype = None
+        if lib.svs_api_version() != API_VERSION:
+            raise SvsError(f"{LIB_PATH} was built with SVS_API_VERSION {lib.svs_api_version()}, this binding expects {API_VERSION}: rebuild (__graft_entry__.build())")
         _LIB = lib
     return _LIB
 

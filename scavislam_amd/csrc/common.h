@@ -28,6 +28,8 @@ struct svs_ctx {
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
   int fe_overlap = 1;         // "fe_overlap": the one-call front end runs FAST / block matching on a side stream beside the dense tracker (0: one stream)
+  int trk_seq_chi2 = 0;       // "trk_seq_chi2": the quarter-grid tracker decides accept / reject on the reference's own sequential f32 chi2 sums (dense.hip; slow: parity runs)
+  void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // its per-pass term buffer
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow

@@ -101,9 +101,9 @@ __device__ __forceinline__ double div_rn(double a, double b, double r) {
   return __builtin_fma(__builtin_fma(-q, b, a), r, q);
 }
 
-template <bool JAC, bool U8SRC = false>
+template <bool JAC, bool U8SRC = false, bool SEQ = false>
 __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a,
-                                               const float *ip_lut = nullptr) {
+                                               const float *ip_lut = nullptr, float *t_out = nullptr) {
   const float4 c4 = in.c4;
   bool ok = in_range && (c4.w > 0);
   const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
@@ -128,6 +128,7 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   if (res < -0.1) res = -0.1;
   if (!ok) res = 0.f;
   a.v[27] += (double)(res * res);
+  if constexpr (SEQ) { if (t_out) *t_out = res * res; }      // the term of the reference's `float chi2 += res*res` (0 where the reference skips the sample: x + 0 is exact)
   a.n += ok ? 1 : 0;
   if (JAC) {
     const float gx = ok ? (float)(0.5 * (U8SRC ? g8x : interp32f(L.dx, L.fstride, uvx, uvy))) : 0.f;
@@ -374,9 +375,9 @@ struct TrackArgs {
 constexpr int TRK_THREADS = SVS_TRK_THREADS;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
-template <bool JAC, bool U8SRC>
+template <bool JAC, bool U8SRC, bool SEQ = false>
 __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut,
-                                           int first, int nwg) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep
+                                           int first, int nwg, float *t_buf = nullptr) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
@@ -406,9 +407,39 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
       nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
     }
 #pragma unroll
-    for (int q = 0; q < TRK_UNROLL; ++q) sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
+    for (int q = 0; q < TRK_UNROLL; ++q) {
+      if constexpr (SEQ) {
+        const int j = i + q * TRK_THREADS * nwg;
+        sample_cpu_sem<JAC, U8SRC, true>(L, T, cur[q], j < n, a, ip_lut, j < n ? t_buf + j : nullptr);
+      } else {
+        sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
+      }
+    }
   }
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
+}
+
+// "trk_seq_chi2": the reference's `float chi2`, summed the way the reference sums it -- one f32 accumulator, samples in row-major order (dense_tracking.cpp:229-262,
+// 341-367).  Near convergence chi2 - new_chi2 is below the rounding noise of these 19 200-term sums, so the accept test of the last LM steps of a level is decided by
+// the summation order; with this option the loop takes exactly the reference's decisions (the default compares the f64 sums, narrowed).  Wave 0 walks the terms the
+// pass left in t_buf: 64 loads at a time, then 64 dependent adds on values broadcast from the lanes in order.  Slow (~0.1 ms per sum) -- parity runs only.
+__device__ __forceinline__ float seq_sum_f32(const float *t, int n) {
+  float acc = 0.f;
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < n; base += 64) {
+    const float v = base + lane < n ? t[base + lane] : 0.f;      // (written by this workgroup before a barrier: workgroup-scope visibility is enough)
+#pragma unroll
+    for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+  }
+  return acc;
+}
+// every lane of the workgroup gets the sequential sum (wave 0 computes it between two barriers)
+__device__ __forceinline__ float seq_chi2_f32(const float *t, int n) {
+  __shared__ float s_seq;
+  __syncthreads();
+  if (threadIdx.x < 64) { const float v = seq_sum_f32(t, n); if (threadIdx.x == 0) s_seq = v; }
+  __syncthreads();
+  return s_seq;
 }
 
 // MULTI: a few streams only (latency mode) -- gridDim.x workgroups share every sweep of one stream.  Each leaves its 29 partial
@@ -416,11 +447,18 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 // every workgroup add the partials up in the same fixed order, and each then runs the identical LM bookkeeping redundantly,
 // so no pose has to be broadcast.  Partials are double-buffered by pass parity: a workgroup can only overwrite a buffer after
 // everyone has passed the barrier of the pass in between, i.e. after everyone has read it.
+// The cross-workgroup exchange below (partials, arrival counter, hand-over of the coarse level's pose) uses RELAXED agent-scope atomics plus a raw
+// `s_waitcnt vmcnt(0)` instead of release / acquire fences: on gfx950 (and gfx942) vmcnt counts stores as well as loads and sc1 atomics write through /
+// bypass the non-coherent per-XCD L2, so "all my stores have left" + "flag store" is a release in practice.  This is OUTSIDE the HIP memory model and wrong on
+// any target that counts stores separately (vscnt: gfx10 and later) -- hence the hard stop.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "dense.hip: the relaxed-atomic + s_waitcnt vmcnt(0) hand-off is only valid on gfx950 / gfx942"
+#endif
 struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast; };      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
-template <bool U8SRC, bool MULTI, int MINW>
+template <bool U8SRC, bool MULTI, int MINW, bool SEQ = false>      // SEQ: "trk_seq_chi2" (its own instantiation: the hot ones keep their register budget)
 __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
@@ -494,11 +532,13 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, lfirst, lnwg);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    float *const t_buf = SEQ ? reinterpret_cast<float *>(G.part) + (size_t)slot * G.fail_off : nullptr;      // (SEQ is never MULTI: G carries the term buffer and its stream stride)
+    track_pass<true, U8SRC, SEQ>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, t_buf);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     if (!solo) all_workgroups();
     if (MULTI && s_failed) { failed = true; break; }
     ++passes;
-    float chi2 = (float)s_out[27];
+    float chi2;
+    if constexpr (SEQ) chi2 = seq_chi2_f32(t_buf, (L.cam.w / 4) * (L.cam.h / 4)); else chi2 = (float)s_out[27];
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
     if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
     ++n_rec;
@@ -534,11 +574,12 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC>(L, T, s_part, s_out, s_iplut, lfirst, lnwg);      // new_chi2 (:335-367) + H,b for the next iteration
+      track_pass<true, U8SRC, SEQ>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, t_buf);      // new_chi2 (:335-367) + H,b for the next iteration
       if (!solo) all_workgroups();
       if (MULTI && s_failed) { failed = true; break; }
       ++passes;
-      const float new_chi2 = (float)s_out[27];
+      float new_chi2;
+      if constexpr (SEQ) new_chi2 = seq_chi2_f32(t_buf, (L.cam.w / 4) * (L.cam.h / 4)); else new_chi2 = (float)s_out[27];
       const double rho = (double)chi2 - (double)new_chi2;
       if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, rho > 0 ? 1 : 0, chi2, new_chi2};
       ++n_rec;
@@ -730,8 +771,23 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
   // 2 -> 0.211, 4 -> 0.165, 8 -> 0.160, 16 -> 0.184 ms per frame; round 2 (fence per sweep): 4 -> 0.26, 8 -> 0.26, 16 -> 0.28, 1 -> 0.34 ms
   int nwg = batch <= 16 ? 8 : (batch <= 32 ? 4 : 1);
   if (ctx->trk_nwg) nwg = ctx->trk_nwg;
+  float *t_buf = nullptr; size_t t_b = 0;
+  if (ctx->trk_seq_chi2) {      // the reference's sequential f32 chi2 for the accept test: one workgroup per stream, the terms of a pass in a buffer of the context
+    nwg = 1;
+    t_b = (size_t)(a->cam_vec[0].w / 4) * (a->cam_vec[0].h / 4);
+    if (ctx->seq_buf_bytes < (size_t)batch * t_b * sizeof(float)) {
+      if (ctx->seq_buf) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->seq_buf); ctx->seq_buf = nullptr; ctx->seq_buf_bytes = 0; }
+      SVS_HIP(ctx, hipMalloc(&ctx->seq_buf, (size_t)batch * t_b * sizeof(float)));
+      ctx->seq_buf_bytes = (size_t)batch * t_b * sizeof(float);
+    }
+    t_buf = static_cast<float *>(ctx->seq_buf);
+  }
   TrackMulti G{nullptr, nullptr, 0, nullptr};
-  if (nwg >= 2) {
+  if (t_buf) {
+    G.part = reinterpret_cast<double *>(t_buf); G.fail_off = (int)t_b;
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2, true>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 2, true>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  } else if (nwg >= 2) {
     double *scratch = nullptr;
     const size_t n_part = (size_t)batch * 2 * nwg * 32;
     int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch + (size_t)batch * 16);      // + one counter word and one failure flag (4 + 4 bytes) per stream + the hand-over words

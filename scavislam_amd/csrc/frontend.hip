@@ -291,6 +291,7 @@ extern "C" int svs_frontend_create(svs_ctx *ctx, const svs_cam *cam, const svs_f
 extern "C" int svs_frontend_set_candidates_grouped(svs_frontend *fe, int stream, const svs_candidate_point *h_pts, int n, const int32_t *h_group_end, int n_groups) {
   svs_ctx *ctx = fe ? fe->ctx : nullptr;
   SVS_REQUIRE(ctx, fe && stream >= 0 && stream < fe->B && n >= 0 && n <= fe->max_points && (n == 0 || h_pts));
+  SVS_REQUIRE(ctx, !fe->submitted);      // between submit_frame and wait_frame the list of the frame in flight is latched (wait_frame sizes its copies by it)
   SVS_REQUIRE(ctx, h_group_end && n_groups >= 2 && n_groups <= MAX_GROUPS && h_group_end[n_groups - 1] == n);
   for (int g = 0; g < n_groups; ++g) SVS_REQUIRE(ctx, h_group_end[g] >= (g ? h_group_end[g - 1] : 0));
   SVS_DEVICE(ctx);
@@ -322,7 +323,7 @@ extern "C" int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate
 
 extern "C" int svs_frontend_keep_keyframe_of(svs_frontend *fe, int stream, int slot, const double *T_kf_from_w) {
   svs_ctx *ctx = fe ? fe->ctx : nullptr;
-  SVS_REQUIRE(ctx, fe && T_kf_from_w && stream >= 0 && stream < fe->B && slot >= 0 && slot < fe->max_keyframes && fe->have_prev);
+  SVS_REQUIRE(ctx, fe && T_kf_from_w && stream >= 0 && stream < fe->B && slot >= 0 && slot < fe->max_keyframes && fe->have_prev && !fe->submitted);
   SVS_DEVICE(ctx);
   // Frame::clone of the frame processed last (it sits in the "previous" slot after the rotation at the end of process_frame)
   const size_t idx = (size_t)stream * fe->max_keyframes + slot;
@@ -453,8 +454,9 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     const int trials = first ? (fe->prm.fast_trials > 1 ? fe->prm.fast_trials - 1 : 5) : fe->prm.fast_trials;      // stereo_frontend.cpp:118 / :232
     return svs_fast_detect(fe->fast, imgs, fe->stride, fe->lvl_elems, B, trials);            // "fast"
   };
-  // With the stage clocks off, the detector stages of a tracked frame go to the side stream, enqueued BEHIND the tracker (which claims the CUs first);
-  // their workgroups fill what the tracker leaves idle -- above all its tail, when most streams have converged.  (With the clocks on, every stage runs
+  // With the stage clocks off, the detector stages of a tracked frame go to the side stream.  The fork event is recorded in FRONT of the tracker's launch, so
+  // nothing but the streams' priorities (side stream: lowest) orders the two: the detector's workgroups fill what the tracker leaves idle -- above all its
+  // tail, when most streams have converged.  (With the clocks on, every stage runs
   // alone on the chain's stream so that the stage times add up to the step.)
   // (Only while all of the tracker's workgroups -- one per stream, two per CU -- are resident at once: beyond that the tracker has its own queue of
   // workgroups to fill the tail with, and detector workgroups in between only delay it: 7.01 vs 6.78 ms per step at 1024 streams.)
@@ -667,6 +669,9 @@ static void fill_result(const svs_frontend *fe, const uint8_t *small, int stream
   out->n_points = fe->n_points[stream];
   out->n_matched = out->n_points > 0 ? out->pose_stats.num_obs : 0;
   out->tracking_ok = out->n_matched >= fe->prm.min_matches ? 1 : 0;                            // matchAndTrack's minimum (stereo_frontend.cpp:1053-1056)
+  // dense_passes < 0: the multi-workgroup tracker could not get its workgroups resident together (the device is shared with other work) and left the pose
+  // untouched -- the frame was NOT tracked, whatever the matcher made of the motion-model pose (the callers turn this into SVS_ERR_BUSY)
+  if (out->dense_passes < 0) out->tracking_ok = 0;
 }
 
 /* blocking: the results of one stream of the last svs_frontend_process_frames */
@@ -681,6 +686,7 @@ extern "C" int svs_frontend_results(svs_frontend *fe, int stream, svs_frame_resu
   if (n > 0 && h_gated) SVS_HIP(ctx, hipMemcpyAsync(h_gated, fe->d_gated + (size_t)stream * fe->max_points, sizeof(svs_gated_point) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   fill_result(fe, small.data(), stream, out);
+  if (out->dense_passes < 0) { ctx->err = "dense tracker: workgroups of one stream not co-resident (device busy); frame not tracked, call may be repeated"; return SVS_ERR_BUSY; }
   return SVS_OK;
 }
 

@@ -34,6 +34,7 @@ extern "C" int svs_ctx_destroy(svs_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->match_scratch) (void)hipFree(c->match_scratch);
+  if (c->seq_buf) (void)hipFree(c->seq_buf);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SVS_OK;
@@ -71,8 +72,15 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "mo_legacy") c->mo_legacy = value != 0;
   else if (n == "match_legacy") c->match_legacy = (int)value;
   else if (n == "fe_overlap") c->fe_overlap = value != 0;
+  else if (n == "trk_seq_chi2") c->trk_seq_chi2 = value != 0;
   else SVS_REQUIRE(c, !"unknown option");
   return SVS_OK;
+}
+extern "C" int svs_api_version(void) { return SVS_API_VERSION; }
+extern "C" void svs_pose_opt_params_default(svs_pose_opt_params *p) {
+  if (!p) return;
+  __builtin_memset(p, 0, sizeof *p);
+  p->robust_kernel = 1; p->num_iter = 15; p->kernel_param = 2.0; p->initial_mu = -1.0; p->tau = 1e-5; p->min_obs = 0;
 }
 extern "C" int svs_ctx_sync(svs_ctx *c) { SVS_REQUIRE(c, c); SVS_HIP(c, hipStreamSynchronize(c->stream)); return SVS_OK; }
 extern "C" void *svs_ctx_stream(svs_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -33,5 +33,5 @@ for camname in ("default", "newcollege"):
     seq.close()
     path = os.path.join(HERE, f"ref_seq_{camname}.npz")
     np.savez_compressed(path, **d)
-    print(camname, "keyframes dropped:", int(d["head"][:, 1].sum()), "switches:", int(d["head"][:, 2].sum()), "lines/frame:", d["head"][:, 9:].sum(1).mean(),
+    print(camname, "keyframes dropped:", int(d["head"][:, 1].sum()), "switches:", int(d["head"][:, 2].sum()), "accepted points/frame:", len(d["pts"]) / S.N_FRAMES,
           os.path.getsize(path), "bytes")

@@ -376,6 +376,60 @@ def test_dense_tracking_lm_trajectory_many_scenes(gpu_ctx):
     assert n_strict >= 3, f"only {n_strict} of {B} streams without a near-tie"
 
 
+def test_dense_tracking_lm_trajectory_seq_chi2_to_the_end(gpu_ctx):
+    """Option "trk_seq_chi2": the accept test runs on the reference's OWN sums -- `float chi2` accumulated sequentially in f32 over the samples in row-major
+    order (dense_tracking.cpp:229-262,341-383).  Then no near-tie is left to summation order: EVERY stream's accept / reject record equals the oracle's to the
+    end, chi2 of every trial BIT-equal (the per-sample terms are bit-equal, the sum is taken in the same order), final pose 1e-9."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    ctx, stream = gpu_ctx
+    cam = synth.CAM_DEFAULT
+    B = 8
+    sc = synth.Scene(2011)
+    rng = np.random.default_rng(5)
+    base = synth.trajectory(6)
+    T_prev = [base[b % 6] for b in range(B)]
+    T_cur = [synth.pose_mul(synth.pose(synth.so3_exp([rng.normal(0, 5e-4), np.deg2rad(rng.uniform(0.05, 0.5)), rng.normal(0, 5e-4)]),
+                                       [rng.normal(0, 0.003), rng.normal(0, 0.002), -rng.uniform(0.02, 0.08)]), T_prev[b]) for b in range(B)]
+    prev_f = [sc.render(cam, T_prev[b], seed=500 + b) for b in range(B)]
+    cur_f = [sc.render(cam, T_cur[b], seed=600 + b) for b in range(B)]
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    prev.upload(np.stack([f[0] for f in prev_f]), np.stack([f[1] for f in prev_f]))
+    cur.upload(np.stack([f[0] for f in cur_f]), np.stack([f[1] for f in cur_f]))
+    prev.preprocessing(); cur.preprocessing()
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dtp.ref_dense_points
+    ctx.set_option("trk_seq_chi2", 1)
+    try:
+        for from_u8 in (True, False):
+            T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=from_u8)
+            recs = dt.lm_records()
+            for b in range(B):
+                clouds = [O.pointcloud_cpu(prev_f[b][1], prev.cams[l], l, I) for l in range(3)]
+                pyr_p, pyr_c = O.build_pyramid(prev_f[b][0]), O.build_pyramid(cur_f[b][0])
+                fl = [O.convert_sobel(p) for p in pyr_c]
+                T_ref, passes_ref, rec_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cur.cams, I,
+                                                                  want_rec=True)
+                ref = rec_ref.copy()
+                dup = np.zeros(len(ref), bool)
+                for k in range(1, len(ref)):
+                    dup[k] = ref[k, 1] == 0 and ref[k - 1, 1] == 0 and ref[k, 0] == ref[k - 1, 0]      # the reference repeats a rejected trial before it stops
+                ref = ref[~dup]
+                rec = recs[b]
+                assert len(rec) == len(ref) == passes[b], (b, len(rec), len(ref), passes[b])
+                assert np.array_equal(rec["level"], ref[:, 0].astype(np.int32)) and np.array_equal(rec["accepted"], ref[:, 1].astype(np.int32)), f"stream {b}"
+                assert np.array_equal(rec["chi2"].astype(np.float32), ref[:, 2].astype(np.float32)), f"stream {b}: chi2 of the trials"
+                assert np.array_equal(rec["new_chi2"].astype(np.float32), ref[:, 3].astype(np.float32)), f"stream {b}: new_chi2 of the trials"
+                np.testing.assert_allclose(T[b], T_ref, rtol=0, atol=1e-9)
+    finally:
+        ctx.set_option("trk_seq_chi2", 0)
+
+
 def test_dense_full_resolution_variant(gpu_ctx, scene_frames):
     """GpuTracker::jacobianReduction / chi2 and computePointCloud (full-res f32 semantics of
     gpu/dense_tracking.cu): cloud bit-exact, sums within 1e-5 relative (f32 per-pixel math; the
