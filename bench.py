@@ -182,12 +182,12 @@ def main():
             self.T_act = np.stack([T_prev_list[p].reshape(12) for p in pair])
             self.T_pose = [np.tile(I34, (B, 1)), np.stack([T_AB[p].reshape(12) for p in pair])]      # true pose of frame A / B relative to the active keyframe
             self.fe.processFirstFrames(left=self.left[0], right=self.right[0], disp=self.disp[0])     # frame A: the active keyframe, cloud at the identity
+            self.fe.keepKeyframes(0, np.stack([T_prev_list[pair[b]].reshape(12) for b in range(B)]))      # one call for all streams
             for b in range(B):
-                self.fe.keepKeyframe(0, T_prev_list[pair[b]], stream=b)
                 if pair[b] not in pts_of_pair:                  # the keyframe's own FAST corners (this front end's, first frame: 5 trials)
                     pts_of_pair[pair[b]] = candidates_from_corners(pair[b], [self.fe.corners(b, l)[0] for l in range(3)])
-                pp = pts_of_pair[pair[b]]
-                self.fe.setCandidates(pp, len(pp) // 2, stream=b)
+            self.fe.setCandidateListsAll([pts_of_pair[pair[b]] for b in range(B)],
+                                         [[len(pts_of_pair[pair[b]]) // 2, len(pts_of_pair[pair[b]])] for b in range(B)])      # one staged upload
             self.k = 0
 
         def step(self):

@@ -412,6 +412,8 @@ int svs_frontend_first_frame(svs_frontend *fe, const uint8_t *h_left, int lstrid
 /* Frame::clone of the frame processed last into keyframe slot `slot` with its pose (keyframe_map entry + vertex_map pose) */
 int svs_frontend_keep_keyframe(svs_frontend *fe, int slot, const double *T_kf_from_w);
 int svs_frontend_keep_keyframe_of(svs_frontend *fe, int stream, int slot, const double *T_kf_from_w);
+/* ... of ALL streams at once into slot `slot` of each; h_T_kf_from_w [n_streams][12] (one strided copy per level + one table upload) */
+int svs_frontend_keep_keyframes(svs_frontend *fe, int slot, const double *h_T_kf_from_w);
 /* ap_map: h_pts[i].kf_index = keyframe slot of the anchor (a slot svs_frontend_keep_keyframe has filled; < 0 = anchor frame not in keyframe_map,
    matcher.cpp:336-339); records [0, n_new_records) are the "new feature" candidates (:989-1030) */
 int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate_point *h_pts, int n, int n_new_records);
@@ -420,6 +422,9 @@ int svs_frontend_set_candidates(svs_frontend *fe, const svs_candidate_point *h_p
    h_group_end[g] = one past the last record of group g (n_groups >= 2, <= 64; h_group_end[n_groups-1] == n).  The neighbour lists behind the cut
    "2 * obs_list.size() < ui.num_max_points" come back with status SVS_MATCH_SKIPPED and take no part in the refinement or the gate. */
 int svs_frontend_set_candidates_grouped(svs_frontend *fe, int stream, const svs_candidate_point *h_pts, int n, const int32_t *h_group_end, int n_groups);
+/* the lists of ALL streams in one staged upload: h_pts = the streams' records back to back (h_n[b] of stream b), h_group_end [n_streams][n_groups] (the same
+   number of groups for every stream; an absent list is an empty group) */
+int svs_frontend_set_candidates_all(svs_frontend *fe, const svs_candidate_point *h_pts, const int32_t *h_n, const int32_t *h_group_end, int n_groups);
 /* processFrame.  T_cur_from_actkey: the motion-model guess (in); T_actkey_from_w: pose of the active keyframe.  h_matches / h_gated:
    n_points records each (may be NULL).  Blocking, like the reference call. */
 int svs_frontend_process_frame(svs_frontend *fe, const uint8_t *h_left, int lstride, const uint8_t *h_right, int rstride, const float *h_disp,
@@ -465,7 +470,7 @@ int svs_frontend_stage_times(svs_frontend *fe, float *ms);
 /* blocking: the accept / reject record of the dense tracker's LM loop of one stream in the last call (one entry per chi2 evaluation: level, accepted,
    chi2 before / after); *n = records produced, of which the first min(*n, cap, 64) are stored */
 int svs_frontend_dense_records(svs_frontend *fe, int stream, svs_dense_lm_record *h_rec, int cap, int32_t *n);
-/* computeDensePointCloudCpu / Gpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302); n_streams == 1 */
+/* computeDensePointCloudCpu / Gpu again at a pose decided after the frame (keyframe switch, :277-281, :298-302); T_cur_from_actkey [n_streams][12] */
 int svs_frontend_recompute_cloud(svs_frontend *fe, const double *T_cur_from_actkey);
 /* device views of one stream (tests, chaining): level images of the frame processed last, strides, its disparity (the caller's buffer if it passed
    one), reference clouds (quarter grid, or full resolution in the CUDA build), the FastGrid object (shared by all streams: slot = stream) */

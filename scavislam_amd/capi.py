@@ -143,6 +143,8 @@ _SIGS = {
     "svs_frontend_create_batch": [C.c_void_p, C.POINTER(Cam), C.POINTER(FrontendParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "svs_frontend_keep_keyframe_of": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "svs_frontend_set_candidates_grouped": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_frontend_keep_keyframes": [C.c_void_p, C.c_int, C.c_void_p],
+    "svs_frontend_set_candidates_all": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
     "svs_frontend_submit_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "svs_frontend_wait_frame": [C.c_void_p, C.POINTER(FrameResult), C.c_void_p, C.c_void_p],
     "svs_frontend_prefetch_frame": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int],

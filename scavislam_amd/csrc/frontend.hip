@@ -341,6 +341,74 @@ extern "C" int svs_frontend_keep_keyframe_of(svs_frontend *fe, int stream, int s
 }
 extern "C" int svs_frontend_keep_keyframe(svs_frontend *fe, int slot, const double *T_kf_from_w) { return svs_frontend_keep_keyframe_of(fe, 0, slot, T_kf_from_w); }
 
+/* the same for ALL streams in one go: the frame each stream processed last becomes its keyframe `slot`; h_T_kf_from_w [n_streams][12].  One strided copy per pyramid
+   level and one table upload instead of 4 small copies and a synchronisation per stream. */
+extern "C" int svs_frontend_keep_keyframes(svs_frontend *fe, int slot, const double *h_T_kf_from_w) {
+  svs_ctx *ctx = fe ? fe->ctx : nullptr;
+  SVS_REQUIRE(ctx, fe && h_T_kf_from_w && slot >= 0 && slot < fe->max_keyframes && fe->have_prev && !fe->submitted);
+  SVS_DEVICE(ctx);
+  const size_t B = (size_t)fe->B, slot_pitch = fe->kf_bytes * (size_t)fe->max_keyframes;      // distance between the same slot of two consecutive streams
+  for (int l = 0; l < 3; ++l)
+    SVS_HIP(ctx, hipMemcpy2DAsync(fe->d_kf_pyr + fe->kf_bytes * (size_t)slot + fe->kf_level_off[l], slot_pitch, fe->d_pyr[fe->i_prev][l], fe->lvl_elems[l], fe->lvl_elems[l], B,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  for (size_t b = 0; b < B; ++b) {
+    const size_t idx = b * fe->max_keyframes + slot;
+    svs_keyframe &k = fe->h_kfs[idx];
+    uint8_t *base = fe->d_kf_pyr + fe->kf_bytes * idx;
+    for (int l = 0; l < 3; ++l) { k.pyr[l] = base + fe->kf_level_off[l]; k.stride[l] = fe->stride[l]; }
+    for (int i = 0; i < 12; ++i) k.T_anchor_from_w[i] = h_T_kf_from_w[12 * b + i];
+  }
+  SVS_HIP(ctx, hipMemcpyAsync(fe->d_kfs, fe->h_kfs.data(), sizeof(svs_keyframe) * fe->h_kfs.size(), hipMemcpyHostToDevice, ctx->stream));      // (the whole table: h_kfs mirrors it)
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t b = 0; b < B; ++b) fe->kept[b * fe->max_keyframes + slot] = 1;
+  return SVS_OK;
+}
+
+/* svs_frontend_set_candidates_grouped for ALL streams in one go: h_pts = the streams' records back to back (stream b: h_n[b] records), h_group_end
+   [n_streams][n_groups] (every stream with the same number of groups; an absent neighbour list is an empty group).  Staged through one host buffer: three
+   uploads per call instead of four per stream. */
+extern "C" int svs_frontend_set_candidates_all(svs_frontend *fe, const svs_candidate_point *h_pts, const int32_t *h_n, const int32_t *h_group_end, int n_groups) {
+  svs_ctx *ctx = fe ? fe->ctx : nullptr;
+  SVS_REQUIRE(ctx, fe && h_n && h_group_end && n_groups >= 2 && n_groups <= MAX_GROUPS && !fe->submitted);
+  SVS_DEVICE(ctx);
+  const int B = fe->B;
+  size_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    SVS_REQUIRE(ctx, h_n[b] >= 0 && h_n[b] <= fe->max_points && h_group_end[(size_t)b * n_groups + n_groups - 1] == h_n[b]);
+    for (int g = 0; g < n_groups; ++g) SVS_REQUIRE(ctx, h_group_end[(size_t)b * n_groups + g] >= (g ? h_group_end[(size_t)b * n_groups + g - 1] : 0));
+    total += (size_t)h_n[b];
+  }
+  SVS_REQUIRE(ctx, total == 0 || h_pts);
+  {
+    size_t off = 0;
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < h_n[b]; ++i, ++off)
+        SVS_REQUIRE(ctx, h_pts[off].kf_index < 0 || (h_pts[off].kf_index < fe->max_keyframes && fe->kept[(size_t)b * fe->max_keyframes + h_pts[off].kf_index]));
+  }
+  // the device list is [n_streams][max_points]: lay the records out like that on the host (unused tails = 0xff, "no candidate") and send it as one block up to the
+  // longest list's stream-strided extent
+  std::vector<svs_candidate_point> stage((size_t)B * fe->max_points);
+  __builtin_memset(stage.data(), 0xff, stage.size() * sizeof(svs_candidate_point));
+  std::vector<int32_t> ge((size_t)B * MAX_GROUPS, 0), ng((size_t)B, n_groups), nn((size_t)B);
+  size_t off = 0;
+  for (int b = 0; b < B; ++b) {
+    if (h_n[b]) __builtin_memcpy(stage.data() + (size_t)b * fe->max_points, h_pts + off, sizeof(svs_candidate_point) * (size_t)h_n[b]);
+    off += (size_t)h_n[b];
+    for (int g = 0; g < n_groups; ++g) ge[(size_t)b * MAX_GROUPS + g] = h_group_end[(size_t)b * n_groups + g];
+    nn[b] = h_group_end[(size_t)b * n_groups + n_groups - 2];
+  }
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(fe->d_pts, stage.data(), sizeof(svs_candidate_point) * stage.size(), hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(fe->d_group_end, ge.data(), sizeof(int32_t) * ge.size(), hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(fe->d_n_groups, ng.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipMemcpyAsync(fe->d_n_new, nn.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, ctx->stream));
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < B; ++b) { fe->n_points[b] = h_n[b]; fe->n_new_records[b] = nn[b]; }
+  fe->n_launch = *std::max_element(fe->n_points.begin(), fe->n_points.end());
+  fe->max_groups_used = std::max(fe->max_groups_used, n_groups);
+  return SVS_OK;
+}
+
 extern "C" int svs_frontend_input_view(svs_frontend *fe, uint8_t **d_left, int32_t *lstride, size_t *l_bstride, uint8_t **d_right, int32_t *rstride,
                                        size_t *r_bstride, float **d_disp, int32_t *dstride, size_t *d_bstride) {
   if (!fe) return SVS_ERR_INVALID;
@@ -762,18 +830,18 @@ extern "C" int svs_frontend_process_frame(svs_frontend *fe, const uint8_t *h_lef
 /* computeDensePointCloudCpu / Gpu again, at a pose the caller decided on after the frame (keyframe switch, stereo_frontend.cpp:277-281) */
 extern "C" int svs_frontend_recompute_cloud(svs_frontend *fe, const double *T_cur_from_actkey) {
   svs_ctx *ctx = fe ? fe->ctx : nullptr;
-  SVS_REQUIRE(ctx, fe && fe->B == 1 && T_cur_from_actkey && fe->have_prev && !fe->submitted);
+  SVS_REQUIRE(ctx, fe && T_cur_from_actkey && fe->have_prev && !fe->submitted);      // T_cur_from_actkey [n_streams][12]
   SVS_DEVICE(ctx);
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  SVS_HIP(ctx, hipMemcpy(fe->d_small, T_cur_from_actkey, sizeof(double) * 12, hipMemcpyHostToDevice));
+  SVS_HIP(ctx, hipMemcpy(fe->d_small, T_cur_from_actkey, sizeof(double) * 12 * fe->B, hipMemcpyHostToDevice));
   const float *disp = fe->last_disp;      // the disparity the frame processed last was given (the caller's buffer, if it passed one) or produced
   SVS_REQUIRE(ctx, disp);
   for (int l = 0; l < 3; ++l) {
     int rc;
     if (fe->prm.cuda_build)
-      rc = svs_pointcloud_full_pose(ctx, fe->d_small, &fe->cams[l], disp, fe->last_dstride, fe->last_dbstride, fe->w[l], fe->h[l], fe->w[l], fe->cloud_elems[l] / 4, 1 << l, fe->d_cloud[l], 1);
+      rc = svs_pointcloud_full_pose(ctx, fe->d_small, &fe->cams[l], disp, fe->last_dstride, fe->last_dbstride, fe->w[l], fe->h[l], fe->w[l], fe->cloud_elems[l] / 4, 1 << l, fe->d_cloud[l], fe->B);
     else
-      rc = svs_pointcloud_cpu_sem(ctx, disp, fe->last_dstride, fe->last_dbstride, &fe->cams[l], l, fe->d_small, fe->d_cloud[l], fe->cloud_elems[l], 1);
+      rc = svs_pointcloud_cpu_sem(ctx, disp, fe->last_dstride, fe->last_dbstride, &fe->cams[l], l, fe->d_small, fe->d_cloud[l], fe->cloud_elems[l], fe->B);
     if (rc) return rc;
   }
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));

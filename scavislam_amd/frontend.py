@@ -601,6 +601,20 @@ class StereoFrontend:
         T = np.ascontiguousarray(T_kf_from_w, np.float64).reshape(12)
         self.ctx.check(self.ctx.lib.svs_frontend_keep_keyframe_of(self.h, stream, slot, T.ctypes.data))
 
+    def keepKeyframes(self, slot, T_kf_from_w):
+        """all streams at once: the frame each stream processed last -> its keyframe slot `slot`; poses [n_streams][12]"""
+        T = np.ascontiguousarray(T_kf_from_w, np.float64).reshape(self.n_streams, 12)
+        self.ctx.check(self.ctx.lib.svs_frontend_keep_keyframes(self.h, slot, T.ctypes.data))
+
+    def setCandidateListsAll(self, pts_per_stream, group_end_per_stream):
+        """matchAndTrack's lists of ALL streams in one staged upload (every stream with the same number of groups)"""
+        ge = np.ascontiguousarray(group_end_per_stream, np.int32).reshape(self.n_streams, -1)
+        n = np.array([len(p) for p in pts_per_stream], np.int32)
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(p, CANDIDATE_DTYPE) for p in pts_per_stream]), CANDIDATE_DTYPE)
+        self.ctx.check(self.ctx.lib.svs_frontend_set_candidates_all(self.h, pts.ctypes.data, n.ctypes.data, ge.ctypes.data, ge.shape[1]))
+        for b in range(self.n_streams):
+            self.n_points[b] = int(n[b])
+
     def setCandidates(self, pts, n_new_records, stream=0):
         self.setCandidateLists(pts, [int(n_new_records), len(pts)], stream)
 
@@ -718,7 +732,9 @@ class StereoFrontend:
         return rec[:min(n.value, 64)].copy()
 
     def recomputeCloud(self, T_cur_from_actkey):
-        T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(12)
+        """one pose for every stream ([12]) or one per stream ([n_streams][12])"""
+        T = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(-1, 12)
+        T = np.ascontiguousarray(np.broadcast_to(T, (self.n_streams, 12)))
         self.ctx.check(self.ctx.lib.svs_frontend_recompute_cloud(self.h, T.ctypes.data))
 
     def cloud_host(self, level, stream=0):

@@ -131,16 +131,11 @@ def test_process_frame_equals_reference_generated_fixture(gpu_ctx):
     print(f"fixture: pose deviation from the reference {dT:.2e}, {out.point_stats.num_track_points} accepted points, {out.dense_passes} dense sweeps")
 
 
-@pytest.mark.parametrize("camname", ["newcollege", "default"])
-def test_process_frame_equals_reference_compiled_process_frame(gpu_ctx, camname):
-    """Directly against oracle/_ref/libsvs_ref_frame.so on 512 x 384 (New College) and 640 x 480 frames: the case of tests/test_ref_pin_cpu.py
-    (two keyframes, degenerate candidates, holes in the disparity), once with the neighbour's new points behind the cut (ui.num_max_points = 300)."""
-    if not _have_ref("libsvs_ref_frame.so"):
-        pytest.skip("oracle/_ref/libsvs_ref_frame.so not present (built where /root/reference exists); the fixture test covers this path")
+def _ref_case(camname):
+    """the case of tests/test_ref_pin_cpu.py (two keyframes, degenerate candidates, holes in the disparity) through the reference-compiled processFrame"""
     import oracle as O
-    from scavislam_amd import capi, synth
+    from scavislam_amd import synth
     from scavislam_amd.ctypes_types import level_cams
-    ctx, stream = gpu_ctx
     cam = synth.CAM_DEFAULT if camname == "default" else synth.CAM_NEWCOLLEGE
     cams = level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
     sc = synth.Scene(2011)
@@ -167,7 +162,6 @@ def test_process_frame_equals_reference_compiled_process_frame(gpu_ctx, camname)
     n = len(pts)
     list_of = np.where(rngl.random(n) < 0.12, 1, np.where(rngl.random(n) < 0.1, 0, -1)).astype(np.int32)
     list_of[pts["kf_index"] < 0] = -1
-    # ---- the reference
     pyr_k = [O.build_pyramid(img_k0), O.build_pyramid(img_k1)]
     pyr_p, pyr_c = O.build_pyramid(img_p), O.build_pyramid(img_c)
     clouds_prev = [O.pointcloud_cpu(disp_p, cams[l], l, T_prev_from_act) for l in range(3)]
@@ -175,14 +169,79 @@ def test_process_frame_equals_reference_compiled_process_frame(gpu_ctx, camname)
     r = O.ref_process_frame(pyr_k, [traj[k0].reshape(12), traj[k1].reshape(12)], 1, [(0, 37)], cams, pts, list_of, T_prev_from_act, clouds_prev, pyr_p, pyr_c,
                             [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], disp_c)
     assert r["ok"]
-    # ---- the HIP call
-    out, matches, gated, clouds, idx = _run_hip_cpu_build(ctx, cam, [img_k0, img_k1], [traj[k0], traj[k1]], 1, [(0, 37)], pts, list_of, img_p, disp_p,
-                                                          T_prev_from_act, img_c, disp_c, T_act, prev_clouds=clouds_prev)
-    dT = _check_against_reference_outputs(out, matches, gated, clouds, pts[idx], r["T"], r["lines"], r["av_track_length"], r["clouds"], 1e-6, 1e-5)
+    return dict(cam=cam, kf_imgs=[img_k0, img_k1], kf_poses=[traj[k0], traj[k1]], pts=pts, list_of=list_of, img_p=img_p, disp_p=disp_p, T_prev_from_act=T_prev_from_act,
+                img_c=img_c, disp_c=disp_c, T_act=T_act, clouds_prev=clouds_prev, ref=r)
+
+
+@pytest.mark.parametrize("camname", ["newcollege", "default"])
+def test_process_frame_equals_reference_compiled_process_frame(gpu_ctx, camname):
+    """Directly against oracle/_ref/libsvs_ref_frame.so on 512 x 384 (New College) and 640 x 480 frames: the case of tests/test_ref_pin_cpu.py
+    (two keyframes, degenerate candidates, holes in the disparity), once with the neighbour's new points behind the cut (ui.num_max_points = 300)."""
+    if not _have_ref("libsvs_ref_frame.so"):
+        pytest.skip("oracle/_ref/libsvs_ref_frame.so not present (built where /root/reference exists); the fixture test covers this path")
+    ctx, stream = gpu_ctx
+    c = _ref_case(camname)
+    r = c["ref"]
+    out, matches, gated, clouds, idx = _run_hip_cpu_build(ctx, c["cam"], c["kf_imgs"], c["kf_poses"], 1, [(0, 37)], c["pts"], c["list_of"], c["img_p"], c["disp_p"],
+                                                          c["T_prev_from_act"], c["img_c"], c["disp_c"], c["T_act"], prev_clouds=c["clouds_prev"])
+    dT = _check_against_reference_outputs(out, matches, gated, clouds, c["pts"][idx], r["T"], r["lines"], r["av_track_length"], r["clouds"], 1e-6, 1e-5)
     from scavislam_amd.ctypes_types import MATCH_SKIPPED
     n_skipped = int((matches["status"] == MATCH_SKIPPED).sum())
     print(f"{camname}: pose deviation from the reference {dT:.2e}, {out.point_stats.num_track_points} accepted, {n_skipped} records behind the neighbour cut, "
           f"{out.dense_passes} dense sweeps")
+
+
+@pytest.mark.parametrize("seq_chi2", [0, 1])
+def test_streams_of_the_bench_batch_equal_reference_compiled_process_frame(gpu_ctx, seq_chi2):
+    """at the batch size bench.py times (more than two streams per CU: the tracker's four-waves-per-SIMD build, every stage launched once for
+    all streams, the batched setters) streams of the batch are held to the REFERENCE at the reference test's own bar -- identical draw lists, pose 1e-6, clouds --
+    not to each other.  All 520 streams get the 640 x 480 case above; the first, one in the middle and the last are compared with libsvs_ref_frame.so.  Both
+    tracker modes: the default (f64 partial sums) and "trk_seq_chi2" (the reference's sequential f32 chi2 in the accept test)."""
+    if not _have_ref("libsvs_ref_frame.so"):
+        pytest.skip("oracle/_ref/libsvs_ref_frame.so not present (built where /root/reference exists)")
+    import torch
+    from scavislam_amd import capi
+    from scavislam_amd.frontend import StereoFrontend
+    ctx, stream = gpu_ctx
+    c = _ref_case("default")
+    r, cam = c["ref"], c["cam"]
+    B = 2 * 256 + 8
+    dev = torch.device("cuda", 0)
+
+    def dev_frames(img, disp):
+        with torch.cuda.stream(stream):
+            left = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(img, (B,) + img.shape))).to(dev)
+            d = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(disp.astype(np.float32), (B,) + disp.shape))).to(dev)
+        stream.synchronize()
+        return dict(left=left, disp=d)
+
+    ctx.set_option("trk_seq_chi2", seq_chi2)
+    try:
+        fe = StereoFrontend(ctx, cam, max_points=2048, max_keyframes=4, params=capi.FrontendParams.reference(), n_streams=B)
+        zero = np.zeros((cam["h"], cam["w"]), np.float32)
+        for k, img in enumerate(c["kf_imgs"]):
+            fe.processFirstFrames(**dev_frames(img, zero))
+            fe.keepKeyframes(k, np.tile(np.asarray(c["kf_poses"][k]).reshape(1, 12), (B, 1)))
+        prev = dev_frames(c["img_p"], c["disp_p"])
+        fe.processFirstFrames(**prev)
+        fe.recomputeCloud(c["T_prev_from_act"])
+        idx, group_end = _grouped(c["pts"], c["list_of"], 1, [(0, 37)])
+        fe.setCandidateListsAll([c["pts"][idx]] * B, [group_end] * B)
+        f = fe.fast_handle()
+        thr = np.full(64, 25, np.int32)
+        for b in range(B):
+            for l in range(3):
+                fe.ctx.check(fe.ctx.lib.svs_fast_set_thresholds(f, b, l, thr.ctypes.data))
+        fe.processFrames(np.tile(c["T_prev_from_act"].reshape(1, 12), (B, 1)), np.tile(c["T_act"].reshape(1, 12), (B, 1)), **dev_frames(c["img_c"], c["disp_c"]))
+        worst = 0.0
+        for b in (0, 261, B - 1):
+            out, matches, gated = fe.results(b)
+            clouds = [fe.cloud_host(l, stream=b) for l in range(3)]
+            worst = max(worst, _check_against_reference_outputs(out, matches, gated, clouds, c["pts"][idx], r["T"], r["lines"], r["av_track_length"], r["clouds"], 1e-6, 1e-5))
+        fe.close()
+    finally:
+        ctx.set_option("trk_seq_chi2", 0)
+    print(f"trk_seq_chi2 = {seq_chi2}: streams 0 / 261 / {B - 1} of a {B}-stream batch vs the reference-compiled processFrame: draw lists identical, pose deviation {worst:.2e}")
 
 
 def test_neighbour_cut_on_the_device(gpu_ctx):
