@@ -30,8 +30,17 @@ struct svs_ctx {
   int fe_overlap = 1;         // "fe_overlap": the one-call front end runs FAST / block matching on a side stream beside the dense tracker (0: one stream)
   int trk_seq_chi2 = 0;       // "trk_seq_chi2": the quarter-grid tracker decides accept / reject on the reference's own sequential f32 chi2 sums (dense.hip; slow: parity runs)
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // its per-pass term buffer
+  hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
+// Kernels whose workgroups wait for each other INSIDE one launch (the latency-mode trackers, the multi-workgroup Cholesky) size their grids to a device they have
+// to themselves: every workgroup must become resident while its siblings spin.  Next to ordinary kernels of other contexts that always happens -- those finish in
+// bounded time and free their slots -- but two such kernels from two contexts can each hold part of the device and starve the other's missing workgroups until the
+// bounded spins give up (SVS_ERR_BUSY).  The reference runs exactly this concurrency: the front end on the main thread, optimize + re-registration on the backend
+// thread (stereo_slam.cpp:196, backend.cpp:157-224), so the library keeps at most ONE of them on the device at a time: a launch between svs_spin_enter / svs_spin_leave
+// first makes its stream wait for the event the previous device-filling launch of ANOTHER context left behind (stream-side; the host does not block), then leaves its own.
+int svs_spin_enter(svs_ctx *ctx);
+int svs_spin_leave(svs_ctx *ctx);
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
 int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);

@@ -797,8 +797,10 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     G.fail_off = batch;
     G.bcast = scratch + n_part + (size_t)batch;
     SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * ((size_t)batch + (size_t)batch * 16), ctx->stream));
+    if ((rc = svs_spin_enter(ctx))) return rc;      // the workgroups of a stream wait for each other: one such launch on the device at a time (common.h)
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if ((rc = svs_spin_leave(ctx))) return rc;
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

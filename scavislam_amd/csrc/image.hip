@@ -3,9 +3,34 @@
 // the CPU path's convertTo(CV_32F,1/255.) + Sobel(ksize=1).  Integer path is bit-exact to the
 // OpenCV 2.4.2 semantics restated in SURVEY.md A.2; HBM-bound stencils, LDS-tiled.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
+namespace {
+struct SpinGate { std::mutex m; hipEvent_t last = nullptr; svs_ctx *owner = nullptr; };
+SpinGate g_spin_gate[64];      // per device, process-wide
+SpinGate &gate_of(const svs_ctx *c) { return g_spin_gate[(unsigned)c->device % 64u]; }
+}  // namespace
+int svs_spin_enter(svs_ctx *c) {
+  SpinGate &g = gate_of(c);
+  g.m.lock();                    // held until svs_spin_leave: the order of the launches is the order of the chain
+  if (g.last && g.owner != c) {
+    const hipError_t e = hipStreamWaitEvent(c->stream, g.last, 0);
+    if (e != hipSuccess) { g.m.unlock(); c->err = std::string("svs_spin_enter: hipStreamWaitEvent -> ") + hipGetErrorString(e); return SVS_ERR_HIP; }
+  }
+  return SVS_OK;
+}
+int svs_spin_leave(svs_ctx *c) {
+  SpinGate &g = gate_of(c);
+  hipError_t e = hipSuccess;
+  if (!c->spin_ev) e = hipEventCreateWithFlags(&c->spin_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(c->spin_ev, c->stream);
+  if (e == hipSuccess) { g.last = c->spin_ev; g.owner = c; }
+  g.m.unlock();
+  if (e != hipSuccess) { c->err = std::string("svs_spin_leave: ") + hipGetErrorString(e); return SVS_ERR_HIP; }
+  return SVS_OK;
+}
 extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
   if (!out) return SVS_ERR_INVALID;
   int n = 0;
@@ -30,6 +55,12 @@ extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
 extern "C" int svs_ctx_destroy(svs_ctx *c) {
   if (!c) return SVS_OK;
   (void)hipStreamSynchronize(c->stream);
+  {
+    SpinGate &g = gate_of(c);
+    std::lock_guard<std::mutex> lk(g.m);
+    if (g.owner == c) { g.owner = nullptr; g.last = nullptr; }      // (the stream is drained: nobody needs to wait for this context any more)
+  }
+  if (c->spin_ev) (void)hipEventDestroy(c->spin_ev);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->scratch) (void)hipFree(c->scratch);

@@ -1,0 +1,43 @@
+"""Two threads, one GPU -- the reference's actual concurrency (missing 2): stereo_slam runs StereoFrontend::processFrame on the main thread while the
+backend thread runs SlamGraph::optimize and the re-registration matcher (stereo_slam.cpp:196, backend.cpp:157-224,735-779).  tools/two_threads.py drives exactly that
+through the C ABI from two Python threads (ctypes releases the GIL inside a call), each with its own svs_ctx: 1000 latency-mode svs_frontend_process_frame calls on one,
+200 svs_ba_optimize (the 50 keyframe / 20 k landmark inner window and the 230-pose double window with loop closures, which takes the multi-workgroup Cholesky) plus a
+FastGrid::detect + GuidedMatcher::match per round on the other.
+
+The front end's latency-mode tracker (8 workgroups per stream that wait for each other) and the multi-workgroup Cholesky (a grid of workgroups with grid-wide arrivals)
+are sized for a device they have to themselves; the library now keeps at most one such launch on the device at a time (svs_spin_enter / svs_spin_leave,
+scavislam_amd/csrc/common.h: stream-side event chaining between contexts).  Bars: no SVS_ERR_BUSY, no dense_passes = -1, the front end's results under contention are
+the BITS of its serial run, the back end's equal the serial run's to the order of its f64 atomics (1e-9 of the state), same LM statistics."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_frontend_and_backend_threads_share_the_gpu(gpu_ctx):
+    import two_threads as TT
+    sf, sb, cf, cb, errors, wall = TT.run_serial_and_concurrent(n_frames=1000, n_rounds=160)
+    assert not errors, errors
+    # ---- front end: every frame tracked, the same bits as alone
+    assert (cf["passes"] > 0).all() and (sf["passes"] > 0).all(), "dense_passes = -1: the tracker's workgroups were not co-resident"
+    assert np.array_equal(cf["poses"], sf["poses"]), float(np.abs(cf["poses"] - sf["poses"]).max())
+    assert np.array_equal(cf["n_matched"], sf["n_matched"]) and np.array_equal(cf["passes"], sf["passes"])
+    for (m1, g1), (m0, g0) in zip(cf["last"], sf["last"]):
+        assert m1.tobytes() == m0.tobytes() and g1.tobytes() == g0.tobytes()
+    assert (sf["n_matched"] > 300).all()
+    # ---- back end: same LM trajectory, same state to the order of the atomics, same matches
+    assert len(cb["stats"]) == len(sb["stats"]) == 160 + 40
+    for a, b in zip(cb["stats"], sb["stats"]):
+        assert a[:4] == b[:4], (a, b)
+        assert abs(a[4] - b[4]) <= 1e-9 * abs(b[4])
+    for name in ("inner", "double"):
+        for x, y in zip(cb["state"][name], sb["state"][name]):
+            assert np.abs(x - y).max() <= 1e-9 * max(1.0, np.abs(y).max()), name
+    assert cb["match"].tobytes() == sb["match"].tobytes()
+    assert "multi-workgroup" in cb["info"]["double"]["solve_kernel"]
+    s = TT.summarize(sf, sb, cf, cb, wall)
+    print("two threads, one GPU:", s)
