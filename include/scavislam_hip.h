@@ -550,6 +550,11 @@ int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 fu
    register-resident elimination (one front), 3 = the same with two fronts, 4 = multi-workgroup blocked Cholesky; envelope_rows = widest filled block row of the reduced
    system (+1); wave chunks of the Schur kernel; landmarks with more than 64 observations */
 int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide);
+/* the solve's pose order (what LinearSolverCSparse's block ordering is to the reference, slam_graph.cpp:1063-1074): envelope_rows above is that of the order the solve
+   runs in; *envelope_rows_caller_order the one of the caller's pose order; *ordered = 1 when a fill-reducing order (reverse Cuthill-McKee on the pose block graph) is
+   in use -- taken when it narrows the filled envelope by a quarter or more, e.g. a loop closure on a chain of keyframes; h_perm (optional, [P]): solver row k is
+   the caller's pose h_perm[k] (the identity when not ordered).  Option "no_order" (svs_ba_set_option) keeps the caller's order. */
+int svs_ba_order_info(svs_ba *ba, int32_t *ordered, int32_t *envelope_rows_caller_order, int32_t *h_perm);
 /* profiling: bracket the Schur, solve and back-substitution kernels of every LM trial with hipEvents on the ctx stream.
    Off by default: each event record costs ~4 us of stream time (12 per optimize() = 15 % of it at 50 KF / 20k). */
 int svs_ba_set_timing(svs_ba *ba, int on);

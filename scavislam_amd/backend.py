@@ -183,7 +183,16 @@ class SlamGraphOptimizer:
     def info(self):
         k, r, c, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self.ctx.check(self.ctx.lib.svs_ba_info(self.h, C.byref(k), C.byref(r), C.byref(c), C.byref(w)))
-        return dict(solve_kernel=self.SOLVE_KINDS[k.value], envelope_rows=r.value, wave_chunks=c.value, wide_landmarks=w.value)
+        o, rn = C.c_int32(), C.c_int32()
+        self.ctx.check(self.ctx.lib.svs_ba_order_info(self.h, C.byref(o), C.byref(rn), None))
+        return dict(solve_kernel=self.SOLVE_KINDS[k.value], envelope_rows=r.value, pose_order="reverse Cuthill-McKee" if o.value else "caller's",
+                    envelope_rows_callers_order=rn.value, wave_chunks=c.value, wide_landmarks=w.value)
+
+    def pose_order(self):
+        """solver row k is the caller's pose perm[k]"""
+        perm = np.zeros(self.P, np.int32)
+        self.ctx.check(self.ctx.lib.svs_ba_order_info(self.h, None, None, perm.ctypes.data))
+        return perm
 
     def set_timing(self, on):
         """hipEvent brackets around the dominant kernels of every LM trial (profiling; ~4 us per event)."""

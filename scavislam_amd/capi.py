@@ -182,6 +182,7 @@ _SIGS = {
     "svs_ba_reset_state": [C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_reduced_system": [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_ba_info": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "svs_ba_order_info": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p],
     "svs_ba_set_timing": [C.c_void_p, C.c_int],
     "svs_ba_set_option": [C.c_void_p, C.c_char_p, C.c_int],
     "svs_ba_set_comm": [C.c_void_p, C.c_void_p],

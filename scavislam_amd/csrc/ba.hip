@@ -119,6 +119,7 @@ class HostPool {
 };
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
+  int no_order = 0;      // "no_order": keep the caller's pose order in the solve (A/B partner of the fill-reducing order)
   int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
   int host_marshal = 0;                 // svs_ba_set_problem: 0 = by size (device route from 30k edges), 1 = always on the host (rounds 1-2), 2 = always on the device
@@ -159,6 +160,12 @@ struct svs_ba {
   int *d_rowmax = nullptr, *d_colmin = nullptr;
   double *d_upanel = nullptr;           // [P][R][36] panel rows of the LDS-window solve
   int env_R = 0;                        // max envelope row length + 1 (0 = unknown)
+  // fill-reducing order of the pose blocks for the solve (what LinearSolverCSparse's block ordering does for the reference, slam_graph.cpp:1063-1074):
+  // solver row k <-> pose perm[k].  The Schur kernels keep writing the system in the caller's pose order; when the order pays, the solve runs on a permuted
+  // copy (ba_permute_system_kernel) and its x / trial poses are scattered back (ba_unpermute_kernel).  env_R_natural = the envelope without it.
+  bool perm_active = false; int env_R_natural = 0;
+  int *d_perm = nullptr; double *d_perm_sys = nullptr; size_t cap_perm_sys = 0;      // [P]; H' + bp' + bs' + poses' + trial poses' + x'
+  std::vector<int> h_perm;
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
   bool timing = false;                         // hipEvent brackets around the three dominant kernels of every trial (svs_ba_set_timing / svs_ba_kernel_times)
   int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
@@ -276,6 +283,8 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->h_stage) { (void)hipHostFree(ba->h_stage); ba->h_stage = nullptr; ba->h_stage_cap = 0; }
   if (ba->d_ctl) { (void)hipFree(ba->d_ctl); ba->d_ctl = nullptr; }
   if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
+  if (ba->d_perm) (void)hipFree(ba->d_perm);
+  if (ba->d_perm_sys) (void)hipFree(ba->d_perm_sys);
   if (ba->d_xfer) (void)hipFree(ba->d_xfer);
   if (ba->d_flags) (void)hipFree(ba->d_flags);
   if (ba->d_gridbar) (void)hipFree(ba->d_gridbar);
@@ -658,18 +667,91 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
     SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   std::vector<int> rowmax(P), colmin(P);
-  for (int i = 0; i < P; ++i) {
-    rowmax[i] = i;
-    for (int j = P - 1; j > i; --j) if (pat[(size_t)i * P + j] != 0.0) { rowmax[i] = j; break; }
+  auto filled_envelope = [&](const std::vector<double> &pt, std::vector<int> &rm) {      // returns max row length (block rows) and fills rm
+    for (int i = 0; i < P; ++i) {
+      rm[i] = i;
+      for (int j = P - 1; j > i; --j) if (pt[(size_t)i * P + j] != 0.0 || pt[(size_t)j * P + i] != 0.0) { rm[i] = j; break; }
+    }
+    for (int k = 0; k < P; ++k)                       // fill: row k spreads its reach to rows k+1..rowmax[k]
+      for (int i = k + 1; i <= rm[k]; ++i) rm[i] = std::max(rm[i], rm[k]);
+    int Rm = 1;
+    for (int k = 0; k < P; ++k) Rm = std::max(Rm, rm[k] - k + 1);
+    return Rm;
+  };
+  const int R_nat = filled_envelope(pat, rowmax);
+  ba->env_R_natural = R_nat;
+  ba->perm_active = false;
+  // Reverse Cuthill-McKee on the pose block graph (P <= 256 nodes: host, microseconds): a loop closure on a chain of keyframes couples its two ends, which in
+  // the caller's order makes the filled envelope span the whole chain; breadth-first levels from a peripheral node interleave the two arms of the loop and
+  // bring the band back to about twice the co-visibility reach.  Taken only when it pays (a landmark seen from most of the window is a clique no order removes).
+  if (!ba->opt.no_order && P >= 16 && R_nat >= 24) {
+    // the pattern marshalling left (pat) only marks every pose's farthest partners: the full co-visibility pattern comes from the edges on the device
+    {
+      BaDev Bd = make_dev(ba, 0.0);
+      SVS_HIP(ctx, hipMemsetAsync(ba->d_pattern, 0, sizeof(double) * (size_t)P * P, ctx->stream));
+      if (Bd.n_chunks > 0) { hipLaunchKernelGGL(ba_full_pattern_kernel, dim3(Bd.n_chunks), dim3(64), 0, ctx->stream, Bd, ba->d_pattern); SVS_LAUNCH_CHECK(ctx); }
+      if (Bd.n_wide > 0) { hipLaunchKernelGGL(ba_full_pattern_wide_kernel, dim3(Bd.n_wide), dim3(256), 0, ctx->stream, Bd, ba->d_pattern); SVS_LAUNCH_CHECK(ctx); }
+      if (allreduce && allreduce(ba->d_pattern, (size_t)P * P, user)) { ctx->err = "allreduce callback failed"; return SVS_ERR_INVALID; }
+      std::vector<double> full((size_t)P * P);
+      SVS_HIP(ctx, hipMemcpyAsync(full.data(), ba->d_pattern, sizeof(double) * full.size(), hipMemcpyDeviceToHost, ctx->stream));
+      SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (size_t i = 0; i < full.size(); ++i) if (full[i] != 0.0) pat[i] = 1.0;      // + the pose-pose constraints pat already holds
+    }
+    std::vector<std::vector<int>> adj(P);
+    for (int i = 0; i < P; ++i) for (int j = 0; j < P; ++j) if (i != j && (pat[(size_t)i * P + j] != 0.0 || pat[(size_t)j * P + i] != 0.0)) adj[i].push_back(j);
+    auto bfs_levels = [&](int root, std::vector<int> &order, std::vector<char> &seen) {      // appends the component of root in CM order; returns the last node visited
+      size_t head = order.size();
+      order.push_back(root); seen[root] = 1;
+      while (head < order.size()) {
+        const int u = order[head++];
+        std::vector<int> nb;
+        for (int v : adj[u]) if (!seen[v]) { seen[v] = 1; nb.push_back(v); }
+        std::sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; });
+        for (int v : nb) order.push_back(v);
+      }
+      return order.back();
+    };
+    std::vector<int> order;
+    std::vector<char> seen(P, 0);
+    for (int start = 0; start < P; ++start) {
+      if (seen[start]) continue;
+      // pseudo-peripheral root of this component: run the search from the far end of a search from the node of least degree, twice
+      std::vector<char> tmp(seen);
+      std::vector<int> comp;
+      bfs_levels(start, comp, tmp);
+      int root = comp[0];
+      for (int v : comp) if (adj[v].size() < adj[root].size()) root = v;
+      for (int rep = 0; rep < 2; ++rep) { std::vector<char> t2(seen); std::vector<int> o2; root = bfs_levels(root, o2, t2); }
+      bfs_levels(root, order, seen);
+    }
+    std::reverse(order.begin(), order.end());
+    std::vector<double> pp((size_t)P * P, 0.0);
+    for (int i = 0; i < P; ++i) for (int j = 0; j < P; ++j) pp[(size_t)i * P + j] = (pat[(size_t)order[i] * P + order[j]] != 0.0 || pat[(size_t)order[j] * P + order[i]] != 0.0) ? 1.0 : 0.0;
+    std::vector<int> rm_p(P);
+    const int R_perm = filled_envelope(pp, rm_p);
+    if (R_perm * 4 <= R_nat * 3) {      // at least a quarter narrower
+      ba->perm_active = true;
+      ba->h_perm = order;
+      rowmax = rm_p;
+      pat = pp;      // (the two-front profile below reads the pattern of the order the solve runs in)
+      const size_t nblk_p = (size_t)P * (P + 1) / 2, n_sys = nblk_p * 36 + 12 * (size_t)P + 24 * (size_t)P + 6 * (size_t)P;
+      if (!ba->d_perm || ba->cap_perm_sys < sizeof(double) * n_sys) {
+        if (ba->d_perm) (void)hipFree(ba->d_perm);
+        if (ba->d_perm_sys) (void)hipFree(ba->d_perm_sys);
+        ba->d_perm = nullptr; ba->d_perm_sys = nullptr;
+        SVS_HIP(ctx, hipMalloc(&ba->d_perm, sizeof(int) * SOLVE_MAX_P));
+        SVS_HIP(ctx, hipMalloc(&ba->d_perm_sys, sizeof(double) * n_sys));
+        ba->cap_perm_sys = sizeof(double) * n_sys;
+      }
+      { int rc = stage_upload(ba, ba->d_perm, order.data(), sizeof(int) * P); if (rc) return rc; }
+    }
   }
-  for (int k = 0; k < P; ++k)                       // fill: row k spreads its reach to rows k+1..rowmax[k]
-    for (int i = k + 1; i <= rowmax[k]; ++i) rowmax[i] = std::max(rowmax[i], rowmax[k]);
   for (int k = 0; k < P; ++k) { colmin[k] = k; for (int i = 0; i < k; ++i) if (rowmax[i] >= k) { colmin[k] = i; break; } }
   { int rc = stage_upload(ba, ba->d_rowmax, rowmax.data(), sizeof(int) * P); if (rc) return rc; }
   { int rc = stage_upload(ba, ba->d_colmin, colmin.data(), sizeof(int) * P); if (rc) return rc; }
   int R = 1;
   for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
-  ba->env_R = R;
+  ba->env_R = R;                                    // (of the order the solve runs in)
   // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
   const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 128 + (size_t)R * 6) +
                       sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
@@ -860,23 +942,41 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   BaDev B = make_dev(ba, lambda, cur, ctl);
   if (B.n_chunks == 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_scal, 0, sizeof(double) * SC_N, ctx->stream));      // else zeroed by the Schur kernel
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  // the order the solve runs in: a permuted copy of the reduced system where the fill-reducing order pays (ensure_profile)
+  BaDev Bn = B;                         // the system in the caller's pose order (kept for the scatter back)
+  double *x_solve = ba->d_x;
+  if (ba->perm_active) {
+    const size_t nblk = (size_t)ba->P * (ba->P + 1) / 2;
+    double *sys = ba->d_perm_sys;
+    B.H = sys; B.bp = sys + nblk * 36; B.bs = B.bp + 6 * (size_t)ba->P;
+    double *poses_p = B.bs + 6 * (size_t)ba->P, *trial_p = poses_p + 12 * (size_t)ba->P;
+    x_solve = trial_p + 12 * (size_t)ba->P;
+    hipLaunchKernelGGL(ba_permute_system_kernel, dim3((unsigned)std::min<size_t>(nblk, 4096)), dim3(256), 0, ctx->stream, Bn, ba->d_perm, B.H, B.bp, B.bs, poses_p);
+    SVS_LAUNCH_CHECK(ctx);
+    B.poses = poses_p; B.poses_trial = trial_p;
+  }
   if (ba->use_fused_solve)
   {
     FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch};
-    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(ba->fuse_P1 > 0 ? 2 : 1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel,
+    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(ba->fuse_P1 > 0 ? 2 : 1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel,
                        ba->d_rowmax2, ba->env_R, F);
   }
   else if (ba->use_lds_solve)
-    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, ba->d_x, ba->d_upanel, ba->d_rowmax, ba->env_R);
+    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax, ba->env_R);
   else if (ba->grid_G > 0) {
     const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
     SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
     if ((rc = svs_spin_enter(ctx))) return rc;      // grid-wide arrivals: one such launch on the device at a time (common.h)
-    hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
+    hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
     if ((rc = svs_spin_leave(ctx))) return rc;
   }
   else
-    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, ba->d_x, ba->d_linv, ba->d_rowmax, ba->d_colmin);
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_colmin);
+  if (ba->perm_active) {
+    SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(ba_unpermute_kernel, dim3(div_up(ba->P, 64)), dim3(64), 0, ctx->stream, Bn, ba->d_perm, x_solve, B.poses_trial, ba->d_x);
+    B = Bn;                             // everything behind the solve (constraints, back-substitution, trial chi2) works in the caller's pose order
+  }
   SVS_LAUNCH_CHECK(ctx);
   if (ba->timing) SVS_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
   if (B.C > 0 && !B.fuse_cons) { hipLaunchKernelGGL(ba_constraint_kernel<1>, dim3(B.C), dim3(64), 0, ctx->stream, B); SVS_LAUNCH_CHECK(ctx); }
@@ -1119,6 +1219,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   BaOptions &o = ba->opt;
   const std::string n(name);
   if (n == "no_speculation") o.no_speculation = value != 0;
+  else if (n == "no_order") o.no_order = value != 0;
   else if (n == "one_front") o.one_front = value != 0;
   else if (n == "no_fused_solve") o.no_fused_solve = value != 0;
   else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
@@ -1144,6 +1245,16 @@ extern "C" int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_ro
   if (envelope_rows) *envelope_rows = ba->env_R;
   if (n_chunks) *n_chunks = ba->n_chunks;
   if (n_wide) *n_wide = ba->n_wide;
+  return SVS_OK;
+}
+
+extern "C" int svs_ba_order_info(svs_ba *ba, int32_t *ordered, int32_t *envelope_rows_caller_order, int32_t *h_perm) {
+  svs_ctx *ctx = ba ? ba->ctx : nullptr;
+  SVS_REQUIRE(ctx, ba && ba->problem_valid);
+  if (!ba->profile_ready) { const int rc = ensure_profile(ba, ba->comm ? svs_comm_allreduce_hook : nullptr, ba->comm); if (rc) return rc; }
+  if (ordered) *ordered = ba->perm_active ? 1 : 0;
+  if (envelope_rows_caller_order) *envelope_rows_caller_order = ba->env_R_natural;
+  if (h_perm) for (int k = 0; k < ba->P; ++k) h_perm[k] = ba->perm_active ? ba->h_perm[k] : k;
   return SVS_OK;
 }
 
