@@ -94,39 +94,46 @@ def main():
         return float(t.item())
 
     # ------------------------------------------------------------------ synthetic inputs (8d)
-    cam = synth.CAM_DEFAULT
     scene = synth.Scene(2011)
     traj = synth.trajectory(8)
     # NPAIR distinct (previous, current) frame pairs with different inter-frame motions: forward step 2..8 cm, yaw 0.05..0.5 deg,
     # a few mm of lateral drift -- so LM pass counts, FAST thresholds and candidate lists differ between the streams of a batch
     NPAIR = args.pairs
-    kf_id = 0
-    mrng = np.random.default_rng(77)
-    T_prev_list, T_cur_list = [], []
-    for p in range(NPAIR):
-        T_p = traj[4 + p % 4]
-        step, yaw = mrng.uniform(0.02, 0.08), np.deg2rad(mrng.uniform(0.05, 0.5)) * mrng.choice([-1, 1])
-        R_rel = synth.so3_exp(np.array([mrng.normal(0, 0.0005), yaw, mrng.normal(0, 0.0005)]))
-        T_rel_p = synth.pose(R_rel, np.array([mrng.normal(0, 0.003), mrng.normal(0, 0.002), -step]))     # camera moves forward: points come closer
-        T_prev_list.append(T_p)
-        T_cur_list.append(synth.pose_mul(T_rel_p, T_p))
-    rend_prev = [scene.render(cam, T_prev_list[p], seed=100 + p) for p in range(NPAIR)]
-    rend_cur = [scene.render(cam, T_cur_list[p], seed=200 + p) for p in range(NPAIR)]
-    T_right = synth.pose(np.eye(3), np.array([-cam["b"], 0.0, 0.0]))      # right camera of the stereo rig (for the block matcher)
     NRIGHT = min(NPAIR, 4)
-    rend_right = [scene.render(cam, synth.pose_mul(T_right, T_cur_list[p]), seed=1000 + p)[0] for p in range(NRIGHT)]
-    rend_right_prev = [scene.render(cam, synth.pose_mul(T_right, T_prev_list[p]), seed=1100 + p)[0] for p in range(NRIGHT)]
     I34 = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
-    T_AB = [synth.pose_mul(T_cur_list[p], synth.pose_inv(T_prev_list[p])) for p in range(NPAIR)]      # T_B_from_A: the motion between a stream's two frames
-    n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
-    pts_of_pair = {}
 
-    def candidates_from_corners(p, corners):
+    def make_inputs(cam_, npair, with_right=True):
+        mrng = np.random.default_rng(77)
+        T_prev_l, T_cur_l = [], []
+        for p in range(npair):
+            T_p = traj[4 + p % 4]
+            step, yaw = mrng.uniform(0.02, 0.08), np.deg2rad(mrng.uniform(0.05, 0.5)) * mrng.choice([-1, 1])
+            R_rel = synth.so3_exp(np.array([mrng.normal(0, 0.0005), yaw, mrng.normal(0, 0.0005)]))
+            T_rel_p = synth.pose(R_rel, np.array([mrng.normal(0, 0.003), mrng.normal(0, 0.002), -step]))     # camera moves forward: points come closer
+            T_prev_l.append(T_p)
+            T_cur_l.append(synth.pose_mul(T_rel_p, T_p))
+        rp = [scene.render(cam_, T_prev_l[p], seed=100 + p) for p in range(npair)]
+        rc = [scene.render(cam_, T_cur_l[p], seed=200 + p) for p in range(npair)]
+        T_right = synth.pose(np.eye(3), np.array([-cam_["b"], 0.0, 0.0]))      # right camera of the stereo rig (for the block matcher)
+        nr = min(npair, 4) if with_right else 0
+        rr = [scene.render(cam_, synth.pose_mul(T_right, T_cur_l[p]), seed=1000 + p)[0] for p in range(nr)]
+        rrp = [scene.render(cam_, synth.pose_mul(T_right, T_prev_l[p]), seed=1100 + p)[0] for p in range(nr)]
+        return dict(cam=cam_, npair=npair, T_prev_list=T_prev_l, T_cur_list=T_cur_l, rend_prev=rp, rend_cur=rc, rend_right=rr, rend_right_prev=rrp,
+                    T_AB=[synth.pose_mul(T_cur_l[p], synth.pose_inv(T_prev_l[p])) for p in range(npair)],      # T_B_from_A: the motion between a stream's two frames
+                    pts_of_pair={})
+
+    INP = make_inputs(synth.CAM_DEFAULT, NPAIR)
+    cam, T_prev_list, T_cur_list, rend_prev, rend_cur, rend_right, rend_right_prev, T_AB, pts_of_pair = (INP[k] for k in (
+        "cam", "T_prev_list", "T_cur_list", "rend_prev", "rend_cur", "rend_right", "rend_right_prev", "T_AB", "pts_of_pair"))
+    n_per_level = (int(args.points * 0.6), int(args.points * 0.3), args.points - int(args.points * 0.6) - int(args.points * 0.3))
+    def candidates_from_corners(p, corners, inp=None):
         """candidate points of a stream = FAST corners of its active keyframe with their stereo depth (what addNewPoints seeds from the keyframe's
         feature_tree, stereo_frontend.cpp:680-830): up to n_per_level per level, the rest of the quota from level 0 (2000 points)"""
         from scavislam_amd.ctypes_types import CANDIDATE_DTYPE
+        inp = inp or INP
+        cam = inp["cam"]
         rng = np.random.default_rng(2011 + p)
-        disp = rend_prev[p][1]
+        disp = inp["rend_prev"][p][1]
         per_level = []
         for l in range(3):
             xy = corners[l].astype(np.int64)
@@ -162,8 +169,12 @@ def main():
         `points` candidates (half of them "new features"), calcFastMotionOnly, processMatchedPoints' gate, dense cloud.  Guess = the pose of the
         frame before (one inter-frame motion to recover each step, in alternating directions)."""
 
-        def __init__(self, B, block_matching=False, cuda_build=False):
+        def __init__(self, B, block_matching=False, cuda_build=False, inp=None):
             self.B, self.bm = B, block_matching
+            inp = inp or INP
+            cam, NPAIR, pts_of_pair = inp["cam"], inp["npair"], inp["pts_of_pair"]
+            rend_prev, rend_cur, rend_right, rend_right_prev, T_prev_list, T_AB = (inp[k] for k in ("rend_prev", "rend_cur", "rend_right", "rend_right_prev", "T_prev_list", "T_AB"))
+            NRIGHT = len(rend_right)
             prm = capi.FrontendParams.reference(use_block_matching=block_matching, cuda_build=cuda_build)
             self.fe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=1, params=prm, n_streams=B)
             pair = [b % NPAIR for b in range(B)]
@@ -185,7 +196,7 @@ def main():
             self.fe.keepKeyframes(0, np.stack([T_prev_list[pair[b]].reshape(12) for b in range(B)]))      # one call for all streams
             for b in range(B):
                 if pair[b] not in pts_of_pair:                  # the keyframe's own FAST corners (this front end's, first frame: 5 trials)
-                    pts_of_pair[pair[b]] = candidates_from_corners(pair[b], [self.fe.corners(b, l)[0] for l in range(3)])
+                    pts_of_pair[pair[b]] = candidates_from_corners(pair[b], [self.fe.corners(b, l)[0] for l in range(3)], inp)
             self.fe.setCandidateListsAll([pts_of_pair[pair[b]] for b in range(B)],
                                          [[len(pts_of_pair[pair[b]]) // 2, len(pts_of_pair[pair[b]])] for b in range(B)])      # one staged upload
             self.k = 0
@@ -250,7 +261,8 @@ def main():
     sweeps_lvl /= min(B, NPAIR)
     px = sum(lvl_px)
     alg = {
-        "preprocess": 2 * lvl_px[0] + lvl_px[0] + lvl_px[1] + lvl_px[1] + lvl_px[2],      # copy-in (r + w) + two pyrDown steps (r + w)
+        "preprocess": lvl_px[0] + lvl_px[1] + lvl_px[2],      # W H read + W H / 4 + W H / 16 written = 403 200 B per 640 x 480 frame (the caller's frame is read ONCE:
+                                                               # the first pyramid step also stores it into the library's level-0 buffer -- that copy-through, W H more bytes written, is not algorithmic)
         "dense_tracking": int(sum(sweeps_lvl[l] * (lvl_px[l] // 16) * (16 + 1 + 16) for l in range(3))),   # cloud float4 + prev u8 + 4x4 u8 taps per sample and sweep
         "fast": px + 4 * n_corners + 22 * 4,
         "match": n_points * (60 + 121 + 20) + n_points * 10 * 64,
@@ -333,6 +345,40 @@ def main():
                "dense_passes": int(fres.dense_passes), "bytes_in": int(cam["w"] * cam["h"] * 5), "bytes_out": int(len(pts) * (64 + 40) + 600),
                "pose_dev_from_true_motion": host_dev}
     sfe.close()
+    # the reference's other shipped configuration: New College 512 x 384 (data/newcollege.cfg:1-6), the same step at the same batch
+    nc_row = None
+    if world == 1:
+        INP_NC = make_inputs(synth.CAM_NEWCOLLEGE, min(NPAIR, 16), with_right=False)
+        ocn = OneCall(B, inp=INP_NC)
+        t_nc = timed_steps(ocn, 2, K + (K & 1))
+        Tn, okn = ocn.fe.poses()
+        fl = ocn.k & 1
+        nc_err = float(max(np.abs(Tn[b] - np.asarray([I34, INP_NC["T_AB"][b % INP_NC["npair"]].reshape(12)][fl]).reshape(3, 4)).max() for b in range(min(B, INP_NC["npair"]))))
+        ocn.fe.setTiming(True)
+        acc = {}
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                ocn.step()
+                for k_, v_ in ocn.fe.stageTimes().items():
+                    acc.setdefault(k_, []).append(v_)
+        ocn.fe.setTiming(False)
+        nc_row = {"frame": "512x384 (data/newcollege.cfg:1-6: f 389.956, c (254.903, 201.899), b 0.120005)", "batch_streams": B,
+                  "frames_per_s": round(B * (K + (K & 1)) / t_nc, 1), "ms_per_step": round(t_nc / (K + (K & 1)) * 1e3, 4),
+                  "stage_ms_per_batch": {k_: round(float(np.mean(v_)), 4) for k_, v_ in acc.items()}, "tracking_ok_fraction": float(okn.mean()),
+                  "refined_pose_err_vs_true_motion": nc_err}
+        ocn.close()
+        del INP_NC
+    # the reference's concurrency (stereo_slam.cpp:196, backend.cpp:157-224,735-779): processFrame loop on one thread, optimize + re-registration on another,
+    # separate contexts, one GPU (tools/two_threads.py; tests/test_gpu_concurrency.py holds the results equal to the serial runs)
+    two_threads = None
+    if world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import two_threads as TT
+        sf_, sb_, cf_, cb_, errs_, wall_ = TT.run_serial_and_concurrent(n_frames=600, n_rounds=96, device=local_rank)
+        two_threads = dict(TT.summarize(sf_, sb_, cf_, cb_, wall_), errors=errs_,
+                           note="latency-mode svs_frontend_process_frame (host buffers in and out) on thread A; svs_ba_optimize of the 50 KF / 20 k window every round and of "
+                                "the 230-pose double window with loop closures + 180-observation landmarks (multi-workgroup Cholesky) every 4th round, plus FastGrid::detect "
+                                "+ GuidedMatcher::match per round on thread B; 'alone' = each loop run by itself first")
     # batched modes in between (B in {1, 8, 64}): same step, B independent streams per call
     batch_sweep = {"1": round(1e3 / lat_ms, 1), str(B): round(fps / world, 1)}
     for Bs in (8, 64, 256):
@@ -551,13 +597,16 @@ def main():
             schur_rows[name] = row
         other_probs = {"15KF_3k (configs[2])": synth.ba_window(15, 3000, seed=2012),
                        "double_window_30_inner_200_outer": synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(100, 180, 70), n_loops=2),
+                       "double_window_30_inner_200_outer_loop_closures_only": synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(), n_loops=2),
                        "double_window_30_inner_200_outer_no_loop_closure": synth.double_window(n_inner=30, n_outer=200, L=12000, seed=2014, n_long=(), n_loops=0)}
         for name_, pr_ in other_probs.items():
             time_window(name_, pr_)
         # throughput mode: W independent 50 KF / 20k windows in flight (svs_ba_optimize_batch, one context = one stream per window)
         by_w = {"1": round(1e3 / ms_opt, 1)}
         for Wn in (8, 32):
-            ctxs_w = [capi.torch_context(local_rank) for _ in range(Wn)]
+            # library-owned streams (hipStreamCreate): torch hands out its streams from a pool of 32 per device, so a 33rd torch stream IS an earlier one and two
+            # windows would share (and serialise on) it -- that, not the library, was the batch-32 figure of round 3 (5.8 k windows/s)
+            ctxs_w = [(capi.Context(local_rank), None) for _ in range(Wn)]
             opts_w = []
             for cw, sw in ctxs_w:
                 ow = SlamGraphOptimizer(cw, sw)
@@ -742,8 +791,9 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32 (FAST, ZNSSD), f32+f64 (dense tracking), f64 (Schur)",
             "data": "synthetic",
             "value_stereo_input": round(fps_stereo, 2),
-            "config": {"workload": "configs[1]+[3]: StereoFrontend::processFrame as ONE library call for a batch of camera streams on 640x480 stereo frames "
-                                   "resident in HBM -- all eight stages: preprocess (copy-in + pyramid), dense tracking (fused f32 + Sobel taps), stereo "
+            "config": {"workload": "configs[1]+[3]: `value` = frames/s WITH THE DISPARITY IMAGE GIVEN (have_disp_img, RGB-D style input); with stereo input -- cv::StereoBM "
+                                   "block matching inside the step -- it is `value_stereo_input` (about half).  StereoFrontend::processFrame as ONE library call for a "
+                                   "batch of camera streams on 640x480 stereo frames resident in HBM -- all eight stages: preprocess (copy-in + pyramid), dense tracking (fused f32 + Sobel taps), stereo "
                                    "(disparity given for `value`; cv::StereoBM block matching inside the step for `value_stereo_input`), grid FAST, guided "
                                    "ZNSSD match, pose refinement (calcFastMotionOnly), process points (reprojection gate), dense point cloud -- and DWO "
                                    "inner-window Schur solve 50 KF / 20k landmarks",
@@ -786,6 +836,8 @@ def main():
                          "frames_per_s_per_gpu_by_batch": batch_sweep,
                          "stereo_input_path": dict(stereo_info, ms_per_step=round(t_stereo / max(4, K // 2 * 2) * 1e3, 4), frames_per_s=round(fps_stereo, 1),
                                                    stage_ms_per_batch={k: round(v, 4) for k, v in stage_ms_stereo.items()}),
+                         "new_college_512x384": nc_row,
+                         "two_threads_one_gpu": two_threads,
                          "cuda_build_path": cuda_path,
                          "overlapped_batches": overlapped,
                          "speedup_vs_cpu_port": round(fps / cpu["value"], 2) if cpu else None},

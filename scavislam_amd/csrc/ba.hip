@@ -18,7 +18,6 @@
 //    36*P(P+1)/2 + 12P + 1 doubles) and two scalars per LM trial; the 6P x 6P Cholesky is
 //    replicated (deterministic, no broadcast).
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 #include <climits>
 #include <algorithm>
 #include <cmath>
@@ -142,7 +141,8 @@ struct svs_ba {
   svs_ba_edge *w_store = nullptr; size_t w_n = 0, w_cap = 0;           // observation store, ids in .point / .pose, arrival order
   int *w_pose_tab = nullptr, *w_point_tab = nullptr; size_t w_pose_tab_n = 0, w_point_tab_n = 0;      // id -> window index (-1: not in the window)
   void *w_work = nullptr; size_t w_work_bytes = 0;                      // per-call work arrays (grow-only)
-  void *w_sort_tmp = nullptr; size_t w_sort_tmp_bytes = 0;
+  std::vector<svs_ba_constraint> w_cons_idx;
+  void *w_in = nullptr; size_t w_in_bytes = 0;                          // device mirror of the block a window_update call brings (ids, state, new observations, constraints)
   unsigned char *w_hback = nullptr; size_t w_hback_bytes = 0;           // pinned read-back (counters, landmark lengths, pattern)
   int P = 0, L = 0, E = 0, C = 0, n_chunks = 0, n_wide = 0, add_pose_terms = 1;
   std::vector<int> w_chunk_nlm;                       // landmarks per wave chunk (set_problem work vector)
@@ -292,7 +292,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->w_pose_tab) (void)hipFree(ba->w_pose_tab);
   if (ba->w_point_tab) (void)hipFree(ba->w_point_tab);
   if (ba->w_work) (void)hipFree(ba->w_work);
-  if (ba->w_sort_tmp) (void)hipFree(ba->w_sort_tmp);
+  if (ba->w_in) (void)hipFree(ba->w_in);
   if (ba->w_hback) (void)hipHostFree(ba->w_hback);
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
