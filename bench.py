@@ -259,6 +259,11 @@ def main():
         for l in range(3):
             sweeps_lvl[l] += int((rec["level"] == l).sum())
     sweeps_lvl /= min(B, NPAIR)
+    # serial work of each stream's tracker (one workgroup per stream in throughput mode): sweeps x samples per level, in units of one level-0 sweep
+    cost_units = []
+    for b in range(min(B, NPAIR)):
+        rec = oc.fe.denseRecords(b)
+        cost_units.append(round(float(sum(int((rec["level"] == l).sum()) * (lvl_px[l] // 16) for l in range(3))) / (lvl_px[0] // 16), 2))
     px = sum(lvl_px)
     alg = {
         "preprocess": lvl_px[0] + lvl_px[1] + lvl_px[2],      # W H read + W H / 4 + W H / 16 written = 403 200 B per 640 x 480 frame (the caller's frame is read ONCE:
@@ -827,6 +832,8 @@ def main():
                                           "schedule, where FAST (and block matching) run on a side stream beside the dense tracker and fill its tail",
                          "dense_passes_per_frame": round(passes, 2),
                          "dense_sweeps_per_level": [round(float(x), 2) for x in sweeps_lvl],
+                         "dense_serial_work_per_stream_in_level0_sweeps": {"min": min(cost_units), "mean": round(float(np.mean(cost_units)), 2), "max": max(cost_units),
+                                                                           "note": "the tracker launch lasts as long as its longest stream"},
                          "dense_passes_per_frame_spread": {"min": int(passes_all.min()), "max": int(passes_all.max()), "distinct_frame_pairs": NPAIR},
                          "corners_per_frame": n_corners, "matches_per_frame": n_matched, "accepted_points_per_frame": n_accepted,
                          "tracking_ok_fraction": tracking_ok_frac,
