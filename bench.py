@@ -169,7 +169,7 @@ def main():
         `points` candidates (half of them "new features"), calcFastMotionOnly, processMatchedPoints' gate, dense cloud.  Guess = the pose of the
         frame before (one inter-frame motion to recover each step, in alternating directions)."""
 
-        def __init__(self, B, block_matching=False, cuda_build=False, inp=None):
+        def __init__(self, B, block_matching=False, cuda_build=False, inp=None, ctx=ctx, pair_offset=0):
             self.B, self.bm = B, block_matching
             inp = inp or INP
             cam, NPAIR, pts_of_pair = inp["cam"], inp["npair"], inp["pts_of_pair"]
@@ -177,7 +177,7 @@ def main():
             NRIGHT = len(rend_right)
             prm = capi.FrontendParams.reference(use_block_matching=block_matching, cuda_build=cuda_build)
             self.fe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=1, params=prm, n_streams=B)
-            pair = [b % NPAIR for b in range(B)]
+            pair = [(b + pair_offset) % NPAIR for b in range(B)]
             if block_matching:      # only NRIGHT pairs have a rendered right image
                 pair = [p % NRIGHT for p in pair]
             self.pair = pair
