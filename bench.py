@@ -554,6 +554,42 @@ def main():
             kt = opt.kernel_times()
             t_red += kt["reduce_ms"]; t_sol += kt["solve_ms"]; t_bs += kt["backsub_ms"]; n_tr += kt["n_trials"]
         opt.set_timing(False)
+    # the same K optimizes over the second transport of svs_comm: the one-shot P2P exchange (peer-mapped mailboxes, comm.hip) instead of RCCL's ring.
+    # One rank per GPU here, so this row is only comparable with the RCCL row on a multi-GPU node; at one rank both transports are identities.
+    ba_p2p = None
+    if use_dist and comm is not None:
+        comm2, p2p_error = None, None
+        try:
+            with _stdout_to_stderr():
+                g = dist.new_group(backend="gloo") if world > 1 else None      # carries the 64-byte IPC handles (CPU tensors)
+                comm2 = Communicator.p2p(ctx, rank, world, capacity_doubles=1 << 17, group=g)
+        except Exception as e:
+            p2p_error = repr(e)
+        ok = torch.tensor([0 if comm2 is None else 1], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            opt.set_comm(comm2)
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    opt.reset_state(sh["poses"], sh["psi"])
+                    opt.optimize()
+                t_p2p = 0.0
+                for _ in range(K):
+                    opt.reset_state(sh["poses"], sh["psi"])
+                    barrier_sync()
+                    t0 = time.perf_counter()
+                    st2 = opt.optimize()
+                    barrier_sync()
+                    t_p2p += time.perf_counter() - t0
+            ba_p2p = {"ms_per_optimize": round(max_over_ranks(t_p2p) / K * 1e3, 4), "same_lm_trajectory_as_rccl": bool((st2.trials, st2.accepted) == (stats.trials, stats.accepted)),
+                      "chi2_final": st2.chi2_final, **comm2.transport(), **{k: v for k, v in comm2.stats().items() if k in ("n_calls", "n_doubles")}}
+            opt.set_comm(comm)
+        else:
+            ba_p2p = {"error": p2p_error or "unavailable on another rank"}
+        if comm2 is not None:
+            barrier_sync()
+            comm2.close()
     t_ba = max_over_ranks(t_ba)
     ms_opt = t_ba / K * 1e3
     ms_opt_ev = max_over_ranks(t_ba_ev) / K * 1e3
@@ -813,6 +849,7 @@ def main():
                       "ms_per_schur_step": round(ms_opt / max(n_tr / K, 1), 4), "scaling": "strong",
                       "keyframes": P_, "landmarks": L_, "edges": E_total, "edges_this_rank": E_local,
                       "ms_per_optimize_with_event_brackets": round(ms_opt_ev, 4),
+                      "one_shot_p2p_transport": ba_p2p,
                       "kernel_ms": {"landmark_reduce": round(red_ms, 5), "solve_cholesky": round(t_sol / max(n_tr, 1), 5),
                                     "backsub_chi2": round(t_bs / max(n_tr, 1), 5)},
                       "chi2_init": stats.chi2_init, "chi2_final": stats.chi2_final,

@@ -489,6 +489,17 @@ int svs_comm_destroy(svs_comm *c);
 /* sum `count` doubles at d_buf in place across ranks, on the context's stream (asynchronous like every device entry point) */
 int svs_comm_allreduce_f64(svs_comm *c, void *d_buf, size_t count);
 int svs_comm_stats(svs_comm *c, int32_t *rank, int32_t *world, uint64_t *n_calls, uint64_t *n_doubles);
+/* Second transport behind the same svs_comm handle (svs_comm_allreduce_f64 / svs_ba_set_comm work unchanged): a ONE-SHOT exchange over peer-mapped
+   mailboxes (hipIpc + xGMI P2P writes) instead of RCCL's ring -- every rank pushes its vector into every peer's mailbox, waits for the N-1 arrivals and
+   sums in rank order (bit-identical on all ranks).  Meant for the small, latency-bound messages of the sharded back end; world <= 16.
+     1. every rank: svs_comm_create_p2p (mailbox of 2 x world x capacity_doubles; longer messages travel in pieces) -> its svs_ipc_handle
+     2. all-gather the handles out of band (MPI, a TCP store, torch.distributed), then every rank: svs_comm_connect_p2p(c, handles[world])
+   A peer that never arrives makes the result NaN and is counted (svs_comm_transport); destroy collectively (no rank may still be pushing). */
+typedef struct { char bytes[64]; } svs_ipc_handle;      /* = hipIpcMemHandle_t */
+int svs_comm_create_p2p(svs_ctx *ctx, int rank, int world, size_t capacity_doubles, svs_comm **out, svs_ipc_handle *h_mine);
+int svs_comm_connect_p2p(svs_comm *c, const svs_ipc_handle *h_all);
+/* *kind = 0: RCCL, 1: one-shot P2P; *timeouts = reduce launches that gave up waiting for a peer (blocking; either may be NULL) */
+int svs_comm_transport(svs_comm *c, int32_t *kind, uint32_t *timeouts);
 
 /* ---- BA: replaces SlamGraph::optimize (slam_graph.hpp:457-462, slam_graph.cpp:312-355) -------*/
 typedef struct svs_ba svs_ba;

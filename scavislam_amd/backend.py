@@ -69,6 +69,30 @@ class Communicator:
         ctx.check(ctx.lib.svs_comm_create(ctx.h, uid.ctypes.data, rank, world, C.byref(self.h)))
         ctx.children.add(self)
 
+    @classmethod
+    def p2p(cls, ctx, rank, world, capacity_doubles=1 << 16, group=None):
+        """The one-shot transport (svs_comm_create_p2p / svs_comm_connect_p2p): peer-mapped mailboxes instead of RCCL.  The 64-byte IPC handles are
+        all-gathered through torch.distributed (CPU tensors: any backend with CPU support, e.g. gloo; a C++ host would use MPI or a TCP store)."""
+        import torch.distributed as dist
+        self = cls.__new__(cls)
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        mine = np.zeros(64, np.uint8)
+        ctx.check(ctx.lib.svs_comm_create_p2p(ctx.h, rank, world, capacity_doubles, C.byref(self.h), mine.ctypes.data))
+        ctx.children.add(self)
+        if world > 1:
+            out = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(out, torch.as_tensor(mine), group=group)
+            handles = np.ascontiguousarray(np.stack([t.numpy() for t in out]))
+            ctx.check(ctx.lib.svs_comm_connect_p2p(self.h, handles.ctypes.data))
+            dist.barrier(group=group)              # every mailbox is mapped everywhere before the first push
+        return self
+
+    def transport(self):
+        k, t = C.c_int32(), C.c_uint32()
+        self.ctx.check(self.ctx.lib.svs_comm_transport(self.h, C.byref(k), C.byref(t)))
+        return dict(kind="p2p" if k.value else "rccl", timeouts=t.value)
+
     def allreduce(self, d_ptr, count):
         self.ctx.check(self.ctx.lib.svs_comm_allreduce_f64(self.h, d_ptr, count))
 

@@ -191,6 +191,9 @@ _SIGS = {
     "svs_comm_destroy": [C.c_void_p],
     "svs_comm_allreduce_f64": [C.c_void_p, C.c_void_p, C.c_size_t],
     "svs_comm_stats": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "svs_comm_create_p2p": [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p],
+    "svs_comm_connect_p2p": [C.c_void_p, C.c_void_p],
+    "svs_comm_transport": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)],
     "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_int32)],
 }

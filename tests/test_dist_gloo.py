@@ -137,3 +137,89 @@ def test_sharded_optimize_two_processes_hip_shards():
     same_traj, err_p, err_l, n_calls = q.get(timeout=5)
     assert same_traj and err_p < 1e-6 and err_l < 1e-6, (same_traj, err_p, err_l)
     assert n_calls == 1 + 2 * 2          # pattern once, then (system + scalars) per LM trial
+
+
+# ---- the one-shot P2P transport (svs_comm_create_p2p / svs_comm_connect_p2p, comm.hip): `world` PROCESSES share the one GPU of the box, their mailboxes are
+# mapped into each other with hipIpc (the same calls that map a peer GPU's memory over xGMI on a multi-GPU node), the exchange is the library's own push /
+# reduce kernel pair.  (a) raw all-reduces of every message size of the back end, incl. messages longer than a mailbox slot and 40 back-to-back calls (slot
+# parity), bit-equal to the sum in rank order; (b) the sharded optimize with svs_ba_set_comm on that transport vs the oracle.
+def _p2p_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from scavislam_amd import capi, synth
+    from scavislam_amd.backend import Communicator, SlamGraphOptimizer, shard_problem
+    from scavislam_amd.ctypes_types import BaParams, Cam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx, stream = capi.torch_context(0)
+    comm = Communicator.p2p(ctx, rank, world, capacity_doubles=4096)
+    assert comm.transport()["kind"] == "p2p"
+    ok = True
+    worst = 0
+    with torch.cuda.stream(stream):
+        for it, n in enumerate([32, 1, 300, 4096, 4097, 20000] + [777] * 40):
+            vecs = [np.random.default_rng(1000 * it + r).standard_normal(n) * 10.0 ** np.random.default_rng(it).integers(-3, 4) for r in range(world)]
+            t = torch.as_tensor(vecs[rank]).cuda()
+            stream.synchronize()
+            comm.allreduce(t.data_ptr(), n)
+            ctx.sync()
+            want = vecs[0].copy()
+            for r in range(1, world):
+                want = want + vecs[r]                   # rank order, like the reduce kernel
+            got = t.cpu().numpy()
+            ok = ok and np.array_equal(got, want)
+            worst = max(worst, float(np.abs(got - want).max()))
+    tr = comm.transport()
+    # (b) sharded optimize over the same transport
+    prob = synth.ba_window(12, 1500, seed=41)
+    c = prob["cam"]
+    cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"])
+    prm = BaParams.reference_defaults()
+    sh = shard_problem(prob, rank, world)
+    opt = SlamGraphOptimizer(ctx, stream)
+    opt.set_comm(comm)
+    opt.copyDataToG2o(sh["poses"], sh["psi"], sh["edges"], sh["cons"], cam, prm, add_pose_terms=sh["add_pose_terms"])
+    n0 = comm.stats()["n_calls"]
+    st = opt.optimize()
+    poses, psi = opt.restoreDataFromG2o()
+    n_calls = comm.stats()["n_calls"] - n0
+    mine = np.where((sh["owner"] == rank)[:, None], psi, 0.0)
+    t = torch.as_tensor(mine)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    allp = [torch.zeros_like(torch.as_tensor(poses)) for _ in range(world)]
+    dist.all_gather(allp, torch.as_tensor(poses))
+    if rank == 0:
+        import oracle as O
+        poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        upd = np.abs(poses_ref - prob["poses"]).max()
+        err_p = np.abs(poses - poses_ref).max() / upd
+        err_l = np.abs(t.numpy() - psi_ref).max() / np.abs(psi_ref - prob["psi"]).max()
+        replicas_equal = all(torch.equal(allp[0], a) for a in allp)
+        q.put(dict(raw_ok=bool(ok), raw_worst=worst, timeouts=tr["timeouts"], same_traj=bool(st.trials == st_ref.trials and st.accepted == st_ref.accepted),
+                   err_p=float(err_p), err_l=float(err_l), n_calls=int(n_calls), trials=int(st.trials), replicas_equal=bool(replicas_equal)))
+    dist.barrier()                                      # nobody tears its mailbox down while a peer may still push
+    opt.close(); comm.close(); ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_one_shot_transport_processes_on_one_gpu(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90) + world
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    r = q.get(timeout=5)
+    print(f"P2P one-shot transport, {world} processes on one GPU: {r}")
+    assert r["raw_ok"] and r["timeouts"] == 0, r
+    assert r["same_traj"] and r["err_p"] < 1e-6 and r["err_l"] < 1e-6 and r["replicas_equal"], r
+    assert r["n_calls"] == 1 + 2 * r["trials"], r
