@@ -182,6 +182,7 @@ struct svs_ba {
   std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
   std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
   unsigned char *h_stage = nullptr; size_t h_stage_cap = 0, h_stage_used = 0;      // pinned staging of the small per-call uploads
+  std::vector<int32_t> w_ids_p, w_ids_l, w_ids_a;      // svs_ba_set_problem's device route: identity ids, anchors by point
   HostPool *pool = nullptr;                    // marshalling workers: ONE pool per process, shared by all optimizers (created on first use)
   std::vector<double> w_pat_local;
   svs_ba_edge *h_edges = nullptr; size_t h_edges_cap = 0;
@@ -303,9 +304,26 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   return SVS_OK;
 }
 
+// the marshalling workers: ONE pool per process, shared by all optimizers, created on first use
+static HostPool *host_pool(svs_ba *ba) {
+  if (!ba->pool) {
+    static std::mutex pool_mutex;
+    static HostPool *shared_pool = nullptr;
+    std::lock_guard<std::mutex> lk(pool_mutex);
+    if (!shared_pool) {
+      const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+      int nt = (int)std::min(8u, std::max(1u, hc / 2));
+      if (ba->opt.host_threads > 0) nt = std::min(ba->opt.host_threads, (int)hc);      // never more workers than cores
+      shared_pool = new HostPool(nt);                                                  // lives for the process
+    }
+    ba->pool = shared_pool;
+  }
+  return ba->pool;
+}
+
 static int window_update_impl(svs_ba *ba, int P, const int32_t *h_pose_ids, const double *h_poses, int L, const int32_t *h_point_ids,
                               const double *h_psi, const int32_t *h_anchor_pose_ids, int n_new, const svs_ba_edge *h_new_obs, int C,
-                              const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm);
+                              const svs_ba_constraint *h_cons, const svs_cam *cam, const svs_ba_params *prm, bool obs_checked = false);
 extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int L, const double *h_psi, int E,
                                   const svs_ba_edge *h_edges, int C, const svs_ba_constraint *h_cons, const svs_cam *cam,
                                   const svs_ba_params *prm, int add_pose_terms) {
@@ -320,20 +338,38 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   // 50 KF / 20k: 1.10 vs 1.36 ms.  "host_marshal" = 2 forces the device route for any size: tests.)
   if (ba->opt.host_marshal != 1 && (E >= 30000 || ba->opt.host_marshal == 2) && !ba->comm && add_pose_terms && ba->w_n == 0 && E > 0 && L > 0 && P <= SOLVE_MAX_P) {
     ba->problem_valid = false;                   // a call that fails must leave the handle unusable, not half old / half new
-    std::vector<int32_t> pid((size_t)P), lid((size_t)L), aid((size_t)L, -1);
+    std::vector<int32_t> &pid = ba->w_ids_p, &lid = ba->w_ids_l, &aid = ba->w_ids_a;
+    pid.resize((size_t)P); lid.resize((size_t)L); aid.assign((size_t)L, -1);
     for (int i = 0; i < P; ++i) pid[i] = i;
     for (int i = 0; i < L; ++i) lid[i] = i;
-    bool ok = true;
-    for (int e = 0; e < E && ok; ++e) {
-      const svs_ba_edge &ed = h_edges[e];
-      ok = ed.point >= 0 && ed.point < L && ed.pose >= 0 && ed.pose < P && ed.anchor >= 0 && ed.anchor < P;
-      if (ok) { if (aid[ed.point] < 0) aid[ed.point] = ed.anchor; else ok = aid[ed.point] == ed.anchor; }
+    // two passes over the 12 index bytes of every record, on the worker pool: (1) range check, anchor of the point noted (plain racing stores: every
+    // writer of a consistent input stores the same value); (2) every record's anchor equals the noted one -- an inconsistent input fails pass 2 whatever
+    // the interleaving of pass 1 was
+    std::atomic<int> bad{0};
+    {
+      HostPool &pool = *host_pool(ba);
+      std::lock_guard<std::mutex> pool_lock(pool.use_);
+      int32_t *a = aid.data();
+      pool.run([&](int t, int n) {
+        const int e0 = (int)((long long)E * t / n), e1 = (int)((long long)E * (t + 1) / n);
+        for (int e = e0; e < e1; ++e) {
+          const svs_ba_edge &ed = h_edges[e];
+          if (!(ed.point >= 0 && ed.point < L && ed.pose >= 0 && ed.pose < P && ed.anchor >= 0 && ed.anchor < P)) { bad.store(1); return; }
+          __atomic_store_n(a + ed.point, ed.anchor, __ATOMIC_RELAXED);
+        }
+      });
+      if (!bad.load())
+        pool.run([&](int t, int n) {
+          const int e0 = (int)((long long)E * t / n), e1 = (int)((long long)E * (t + 1) / n);
+          for (int e = e0; e < e1; ++e)
+            if (__atomic_load_n(a + h_edges[e].point, __ATOMIC_RELAXED) != h_edges[e].anchor) { bad.store(2); return; }
+        });
     }
-    SVS_REQUIRE(ctx, ok);                        // an index out of range, or two anchors for one point
+    SVS_REQUIRE(ctx, bad.load() == 0);           // an index out of range, or two anchors for one point
     bool all_seen = true;
     for (int i = 0; i < L && all_seen; ++i) all_seen = aid[i] >= 0;
     if (all_seen) {
-      const int rc = window_update_impl(ba, P, pid.data(), h_poses, L, lid.data(), h_psi, aid.data(), E, h_edges, C, h_cons, cam, prm);
+      const int rc = window_update_impl(ba, P, pid.data(), h_poses, L, lid.data(), h_psi, aid.data(), E, h_edges, C, h_cons, cam, prm, true);
       ba->w_n = 0;                               // the observation store served as scratch: this handle has no persistent window
       return rc;
     }
@@ -362,19 +398,7 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   anchor_of.assign(L, -1); n_obs.assign(L, 0);
   int span = 1;
   // worker pool: one pass over the edge records is memory-bound on one core
-  if (!ba->pool) {
-    static std::mutex pool_mutex;
-    static HostPool *shared_pool = nullptr;
-    std::lock_guard<std::mutex> lk(pool_mutex);
-    if (!shared_pool) {
-      const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-      int nt = (int)std::min(8u, std::max(1u, hc / 2));
-      if (ba->opt.host_threads > 0) nt = std::min(ba->opt.host_threads, (int)hc);      // never more workers than cores
-      shared_pool = new HostPool(nt);                                                  // lives for the process
-    }
-    ba->pool = shared_pool;
-  }
-  HostPool &pool = *ba->pool;
+  HostPool &pool = *host_pool(ba);
   std::lock_guard<std::mutex> pool_lock(pool.use_);
   const bool par = pool.size() > 1 && E >= 16384 && (size_t)L * pool.size() <= ((size_t)1 << 24);
   auto for_range = [&](int total, const std::function<void(int, int, int)> &body) {      // body(t, begin, end)

@@ -6,7 +6,9 @@ from scavislam_amd import capi, synth
 from scavislam_amd.backend import SlamGraphOptimizer
 from scavislam_amd.ctypes_types import BaParams, Cam
 ctx, stream = capi.torch_context(0)
-prob = synth.ba_window(50, 20000, seed=2012)
+PP, LL = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (50, 20000)
+prob = synth.ba_window(PP, LL, seed=2012)
+print("window", PP, LL, "edges", len(prob["edges"]))
 c = prob["cam"]; cam = Cam(c["f"], c["cx"], c["cy"], c["b"], c["w"], c["h"]); prm = BaParams.reference_defaults()
 for hm in (2, 1):      # svs_ba_set_option "host_marshal": 2 = marshal on the device, 1 = on the host threads
     opt = SlamGraphOptimizer(ctx, stream)
@@ -21,5 +23,7 @@ for hm in (2, 1):      # svs_ba_set_option "host_marshal": 2 = marshal on the de
         ts["set"] += t1 - t0; ts["opt"] += t2 - t1; ts["get"] += t3 - t2
     print("host_marshal", "device" if hm == 2 else "host", {k: round(v / N * 1e3, 3) for k, v in ts.items()}, "ms")
     opt.set_option("debug", 1)
-    opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    for _ in range(3):
+        opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+        opt.optimize(); opt.restoreDataFromG2o()
     opt.close()
