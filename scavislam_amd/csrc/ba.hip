@@ -334,9 +334,9 @@ extern "C" int svs_ba_set_problem(svs_ba *ba, int P, const double *h_poses, int 
   // Round 3: a complete window handed over by index takes the DEVICE route of the persistent window -- the edges are uploaded as they come and the
   // sort by (anchor, landmark, observer), the wave chunks, the slot order and the co-visibility pattern are built by kernels (ba_window.inc) -- unless
   // this rank holds a landmark shard (comm / add_pose_terms == 0), a persistent window is in use on this handle, or a point has no observation.
-  // (Below ~30k edges the ~45 small stream operations of the device route cost more than the host's passes: 15 KF / 3k: 0.45 vs 0.43 ms per call;
-  // 50 KF / 20k: 1.10 vs 1.36 ms.  "host_marshal" = 2 forces the device route for any size: tests.)
-  if (ba->opt.host_marshal != 1 && (E >= 30000 || ba->opt.host_marshal == 2) && !ba->comm && add_pose_terms && ba->w_n == 0 && E > 0 && L > 0 && P <= SOLVE_MAX_P) {
+  // (Round 4, set + optimize + get per call, device vs host route: 15 KF / 3k (15 k edges) 0.39 vs 0.43 ms; 30 KF / 8k 0.50 vs 0.74; 50 KF / 20k 0.73 vs 1.39.
+  // Below ~8k edges the dozen stream operations of the device route are the larger part.  "host_marshal" = 2 forces the device route for any size: tests.)
+  if (ba->opt.host_marshal != 1 && (E >= 8192 || ba->opt.host_marshal == 2) && !ba->comm && add_pose_terms && ba->w_n == 0 && E > 0 && L > 0 && P <= SOLVE_MAX_P) {
     ba->problem_valid = false;                   // a call that fails must leave the handle unusable, not half old / half new
     std::vector<int32_t> &pid = ba->w_ids_p, &lid = ba->w_ids_l, &aid = ba->w_ids_a;
     pid.resize((size_t)P); lid.resize((size_t)L); aid.assign((size_t)L, -1);
