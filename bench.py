@@ -222,6 +222,12 @@ def main():
 
     oc = OneCall(B)
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
+    # A/B of the tracker's grid order (context option "trk_balance", dense.hip): 0 = workgroups in stream order, 1 (default) = by the LM work of each stream's
+    # last frame, dealt round-robin to the XCDs.  Same K steps; the results of a stream do not depend on the order (one workgroup per stream either way).
+    ctx.set_option("trk_balance", 0)
+    t_front_stream_order = max_over_ranks(timed_steps(oc, 2, K))
+    ctx.set_option("trk_balance", 1)
+    timed_steps(oc, 2, 0)
     fps = world * B * K / t_front
     # what the last step left: poses, matches, dense sweeps (checked against the true motion: the bench is not timing a diverged tracker)
     T_all, ok_all = oc.fe.poses()
@@ -261,9 +267,17 @@ def main():
     sweeps_lvl /= min(B, NPAIR)
     # serial work of each stream's tracker (one workgroup per stream in throughput mode): sweeps x samples per level, in units of one level-0 sweep
     cost_units = []
+    cost_prev = []
     for b in range(min(B, NPAIR)):
         rec = oc.fe.denseRecords(b)
         cost_units.append(round(float(sum(int((rec["level"] == l).sum()) * (lvl_px[l] // 16) for l in range(3))) / (lvl_px[0] // 16), 2))
+    # the same one step further (the other direction of the ping-pong): how well one frame's work predicts the next frame's (the balanced launch relies on it)
+    oc.step(); ctx.sync()
+    for b in range(min(B, NPAIR)):
+        rec = oc.fe.denseRecords(b)
+        cost_prev.append(round(float(sum(int((rec["level"] == l).sum()) * (lvl_px[l] // 16) for l in range(3))) / (lvl_px[0] // 16), 2))
+    oc.step(); ctx.sync()                                # back to the parity the rest of the bench expects
+    work_corr = float(np.corrcoef(cost_units, cost_prev)[0, 1]) if len(cost_units) > 2 else None
     px = sum(lvl_px)
     alg = {
         "preprocess": lvl_px[0] + lvl_px[1] + lvl_px[2],      # W H read + W H / 4 + W H / 16 written = 403 200 B per 640 x 480 frame (the caller's frame is read ONCE:
@@ -869,7 +883,8 @@ def main():
                                           "schedule, where FAST (and block matching) run on a side stream beside the dense tracker and fill its tail",
                          "dense_passes_per_frame": round(passes, 2),
                          "dense_sweeps_per_level": [round(float(x), 2) for x in sweeps_lvl],
-                         "dense_serial_work_per_stream_in_level0_sweeps": {"min": min(cost_units), "mean": round(float(np.mean(cost_units)), 2), "max": max(cost_units),
+                         "ms_per_step_tracker_grid_in_stream_order": round(t_front_stream_order / K * 1e3, 4),
+                         "dense_serial_work_per_stream_in_level0_sweeps": {"min": min(cost_units), "mean": round(float(np.mean(cost_units)), 2), "max": max(cost_units), "correlation_with_the_next_frame": round(work_corr, 3) if work_corr is not None else None, "next_frame": cost_prev, "this_frame": cost_units,
                                                                            "note": "the tracker launch lasts as long as its longest stream"},
                          "dense_passes_per_frame_spread": {"min": int(passes_all.min()), "max": int(passes_all.max()), "distinct_frame_pairs": NPAIR},
                          "corners_per_frame": n_corners, "matches_per_frame": n_matched, "accepted_points_per_frame": n_accepted,

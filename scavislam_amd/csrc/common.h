@@ -24,6 +24,7 @@ struct svs_ctx {
   size_t match_scratch_bytes = 0;
   // switches read ONCE at svs_ctx_create (debug / experiment only; never per call)
   int trk_nwg = 0;            // SVS_TRK_NWG: workgroups per stream of the latency-mode quarter-grid tracker (0 = automatic)
+  int trk_balance = 1;        // big batches (dense.hip, BAL): 1 = grid order by the last frame's LM work, 2 = also 2..4 workgroups for the longest streams (experimental), 0 = stream order
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
@@ -44,6 +45,11 @@ int svs_spin_leave(svs_ctx *ctx);
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
 int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
+// svs_dense_track_cpu_sem with the state of the balanced launch of big batches (dense.hip: per-stream LM work of the last frame -> workgroups per stream);
+// d_bal_state: svs_dense_track_balance_bytes(batch) bytes of device memory, initialised once by svs_dense_track_balance_init; may be NULL
+size_t svs_dense_track_balance_bytes(int batch);
+int svs_dense_track_balance_init(svs_ctx *ctx, void *d_bal_state, int batch);
+int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out, int batch, void *d_bal_state);
 // every entry point that allocates or launches runs on the context's device, whatever the calling thread's current device is
 #define SVS_DEVICE(ctx) SVS_HIP(ctx, hipSetDevice((ctx)->device))
 

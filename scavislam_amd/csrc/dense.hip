@@ -454,25 +454,38 @@ __device__ __forceinline__ float seq_chi2_f32(const float *t, int n) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
 #error "dense.hip: the relaxed-atomic + s_waitcnt vmcnt(0) hand-off is only valid on gfx950 / gfx942"
 #endif
-struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast; };      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
+struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast;
+                    const int *map; const unsigned char *nwg_of; };      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
-template <bool U8SRC, bool MULTI, int MINW, bool SEQ = false>      // SEQ: "trk_seq_chi2" (its own instantiation: the hot ones keep their register budget)
+// BAL ("trk_balance", big batches): MULTI with a per-stream number of workgroups.  All streams of a big batch are resident at once (two workgroups per
+// CU) and the launch lasts as long as the stream with the most LM passes (bench batch: 5.6 .. 17.8 level-0 sweeps per stream, mean 8.8).  The streams that needed
+// the most sweeps in the LAST frame get 2 .. 4 workgroups each (trk_assign_kernel), placed first in the grid so that they are resident together; the
+// single-workgroup streams follow in order of decreasing work, the shortest ones start in the slots the first finishers leave.
+template <bool U8SRC, bool MULTI, int MINW, bool SEQ = false, bool BAL = false>      // SEQ: "trk_seq_chi2" (its own instantiation: the hot ones keep their register budget)
 __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
+  static_assert(!BAL || !SEQ, "BAL: grid order (and, with MULTI, workgroups per stream) from the assignment tables");
+  int bal_entry = 0;
+  if constexpr (BAL) {
+    bal_entry = G.map[blockIdx.x];
+    if (bal_entry < 0 || (!MULTI && (bal_entry & 15) != 0)) return;      // idle workgroup / a sibling of a table made for the split variant: the order-only variant runs part 0 alone
+  }
   __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
   __shared__ double s_out[NSUM + 1];
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
   __shared__ float s_iplut[256];
   __shared__ bool s_failed;
   if (threadIdx.x == 0) s_failed = false;
-  const int slot = MULTI ? blockIdx.y : blockIdx.x, wg = MULTI ? blockIdx.x : 0, nwg = MULTI ? gridDim.x : 1;
+  const int slot = BAL ? (bal_entry >> 4) : (MULTI ? blockIdx.y : blockIdx.x), wg = BAL ? (bal_entry & 15) : (MULTI ? blockIdx.x : 0);
+  const int nwg = !MULTI ? 1 : (BAL ? (int)G.nwg_of[slot] : (int)gridDim.x);
   const int first = wg * TRK_THREADS + threadIdx.x;
   int sweep = 0;
   auto all_workgroups = [&]() {      // s_out[0..NSUM] <- sum over the workgroups of this stream
     if (!MULTI) return;
+    if (BAL && nwg == 1) return;
     // write-through 8-byte words + one arrival counter (relaxed, agent scope): no fence that would write an XCD's whole L2 back
-    double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * nwg * 32;
+    double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * (BAL ? 4 : nwg) * 32;
     if (threadIdx.x <= NSUM) __hip_atomic_store(buf + wg * 32 + threadIdx.x, s_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   for (int level = 2; level >= 0; --level) {
     // MULTI: the coarsest level (1/16 of the samples: less than one per lane and workgroup) is run by workgroup 0 ALONE -- a sweep of it is
     // shorter than the cross-workgroup exchange that sharing it would cost -- and the others pick the pose up when it is done
-    const bool solo = MULTI && level == 2;
+    const bool solo = MULTI && level == 2 && !(BAL && nwg == 1);
     if (solo && wg != 0) {
       if (threadIdx.x == 0) {
         long spin = 0;
@@ -749,8 +762,136 @@ extern "C" int svs_dense_pass_cpu_sem(svs_ctx *ctx, const float *d_cloud, size_t
   return SVS_OK;
 }
 
+namespace {
+// "trk_balance": workgroups per stream from the work of the last frame, and the grid order (one workgroup, B <= 4096 streams).
+//   nwg_b = min(4, ceil(w_b / M)), M = 1.2 x the mean work, raised in steps of 8 % until the extra workgroups fit x_max and the multi-workgroup streams fit
+//   the resident slots (a function of the multiset of works only: streams with equal history get equal treatment, e.g. replicas of one stream);
+//   grid: the multi-workgroup streams in index order, then the others by decreasing work (ties: index), then -1 (idle workgroups).
+constexpr int BAL_MAX_STREAMS = 4096;
+__global__ __launch_bounds__(1024) void trk_assign_kernel(const svs_dense_lm_record *__restrict__ rec, int rec_cap, const int32_t *__restrict__ n_rec, int B, int slots, int x_max, int grid, float ratio, int *__restrict__ map,
+                                                          unsigned char *__restrict__ nwg_of) {
+  __shared__ float s_w[BAL_MAX_STREAMS];
+  __shared__ unsigned char s_n[BAL_MAX_STREAMS];
+  __shared__ float s_red[16];
+  __shared__ int s_cnt[2];
+  const int tid = threadIdx.x;
+  float sum = 0.f;
+  for (int b = tid; b < B; b += 1024) {      // serial work of the stream's last frame in level-0 sweeps: a sweep of level l counts 4^-l (one LM record per sweep)
+    float w = 0.f;
+    const int n = rec ? min(n_rec[b], rec_cap) : 0;
+    for (int i = 0; i < n; ++i) { const int l = rec[(size_t)b * rec_cap + i].level; w += l == 0 ? 1.f : (l == 1 ? 0.25f : 0.0625f); }
+    s_w[b] = w; sum += w;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+  __syncthreads();
+  float mean = 0.f;
+  for (int k = 0; k < 16; ++k) mean += s_red[k];
+  mean /= (float)B;
+  float M = ratio * mean;
+  for (int round = 0; round < 24; ++round) {
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    int extra = 0, multi = 0;
+    for (int b = tid; b < B; b += 1024) {
+      int n = 1;
+      if (mean > 0.f) { n = (int)ceilf(s_w[b] / M); n = n < 1 ? 1 : (n > 4 ? 4 : n); }
+      s_n[b] = (unsigned char)n;
+      extra += n - 1; multi += n > 1 ? n : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { extra += __shfl_xor(extra, o, 64); multi += __shfl_xor(multi, o, 64); }
+    if ((tid & 63) == 0 && extra) { atomicAdd(&s_cnt[0], extra); atomicAdd(&s_cnt[1], multi); }
+    __syncthreads();
+    const bool fits = s_cnt[0] <= x_max && s_cnt[1] <= slots;
+    __syncthreads();
+    if (fits) break;
+    M *= 1.08f;
+    if (round == 23) { for (int b = tid; b < B; b += 1024) s_n[b] = 1; __syncthreads(); if (tid < 2) s_cnt[tid] = 0; __syncthreads(); }
+  }
+  // positions
+  int n_multi_wgs = 0;
+  for (int b = 0; b < B; ++b) n_multi_wgs += s_n[b] > 1 ? s_n[b] : 0;      // (every thread the same few thousand LDS reads)
+  for (int g = tid; g < grid; g += 1024) map[g] = -1;
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int n = s_n[b];
+    const float w = s_w[b];
+    int pos = 0;
+    if (n > 1) { for (int k = 0; k < b; ++k) pos += s_n[k] > 1 ? s_n[k] : 0; }
+    else {
+      pos = n_multi_wgs;
+      for (int k = 0; k < B; ++k) pos += (s_n[k] == 1 && (s_w[k] > w || (s_w[k] == w && k < b))) ? 1 : 0;
+    }
+    for (int k = 0; k < n; ++k) map[pos + k] = (b << 4) | k;
+    nwg_of[b] = (unsigned char)n;
+  }
+}
+
+// the balanced launch of a big batch.  State (owned by the caller, frontend.hip; persistent from frame to frame): grid map [batch + batch/2] i32 | workgroups
+// per stream [batch] u8 | arrival counters, failure flags, hand-over words (zero before every launch).  The assignment for the NEXT frame is made right behind
+// this frame's tracker (from the LM records it leaves), so that nothing small sits between the fork of the side stream and the tracker's launch.
+struct BalState { int *map; unsigned char *nwg_of; double *flags; size_t n_flags; int grid, x_max; };
+BalState bal_state(void *state, int batch) {
+  BalState S;
+  S.x_max = batch / 2; S.grid = batch + S.x_max;
+  char *p = static_cast<char *>(state);
+  auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+  S.map = reinterpret_cast<int *>(take(sizeof(int) * (size_t)S.grid));
+  S.nwg_of = reinterpret_cast<unsigned char *>(take((size_t)batch));
+  S.n_flags = (size_t)batch + (size_t)batch * 16;
+  S.flags = reinterpret_cast<double *>(take(sizeof(double) * S.n_flags));
+  return S;
+}
+int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_record *rec, int rec_cap, const int32_t *n_rec) {
+  const int x_max = ctx->trk_balance == 2 ? S.x_max : 0;
+  const float ratio = 1.2f;
+  SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));
+  hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8src, double *d_T_io, int32_t *d_passes_out, int batch, void *state) {
+  const BalState S = bal_state(state, batch);
+  double *scratch = nullptr;
+  int rc = ensure_scratch(ctx, &scratch, (size_t)batch * 2 * 4 * 32);
+  if (rc) return rc;
+  TrackMulti G{};
+  G.part = scratch;
+  G.bar = reinterpret_cast<unsigned *>(S.flags);
+  G.fail_off = batch;
+  G.bcast = S.flags + (size_t)batch;
+  G.map = S.map; G.nwg_of = S.nwg_of;
+  if (ctx->trk_balance == 2) {      // order + split (experimental): sibling workgroups wait for each other -- one such launch on the device at a time (common.h)
+    if ((rc = svs_spin_enter(ctx))) return rc;
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if ((rc = svs_spin_leave(ctx))) return rc;
+  } else {                          // order only: one workgroup per stream, nothing waits for anything
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  }
+  SVS_LAUNCH_CHECK(ctx);
+  return bal_assign(ctx, S, batch, A.rec, A.rec_cap, A.n_rec);
+}
+}  // namespace
+size_t svs_dense_track_balance_bytes(int batch) {
+  const uintptr_t base = 1 << 16;                                  // (layout arithmetic only: nothing is dereferenced)
+  const BalState S = bal_state(reinterpret_cast<void *>(base), batch);
+  return (size_t)(reinterpret_cast<uintptr_t>(S.flags) - base) + sizeof(double) * S.n_flags + 256;
+}
+// zero history: every stream one workgroup, streams in index order
+int svs_dense_track_balance_init(svs_ctx *ctx, void *state, int batch) {
+  SVS_REQUIRE(ctx, ctx && state && batch >= 1 && batch <= BAL_MAX_STREAMS);
+  SVS_DEVICE(ctx);
+  SVS_HIP(ctx, hipMemsetAsync(state, 0, svs_dense_track_balance_bytes(batch), ctx->stream));
+  return bal_assign(ctx, bal_state(state, batch), batch, nullptr, 0, nullptr);
+}
 extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out,
                                        int batch) {
+  return svs_dense_track_cpu_sem_work(ctx, a, d_T_io, d_passes_out, batch, nullptr);
+}
+// d_bal_state != NULL (frontend.hip; svs_dense_track_balance_bytes / _init): the balanced launch of big batches
+int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out, int batch, void *d_bal_state) {
   SVS_REQUIRE(ctx, ctx && a && d_T_io && batch >= 1);
   SVS_DEVICE(ctx);
   TrackArgs A;
@@ -801,6 +942,8 @@ extern "C" int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args 
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     if ((rc = svs_spin_leave(ctx))) return rc;
+  } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
+    return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

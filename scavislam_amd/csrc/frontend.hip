@@ -146,6 +146,7 @@ struct svs_frontend {
   int n_submitted = 0;
   // accept / reject record of the dense tracker's LM loop, per stream (svs_frontend_dense_records)
   svs_dense_lm_record *d_rec = nullptr; int32_t *d_nrec = nullptr;
+  void *d_trk_work = nullptr;           // state of the tracker's balanced launch (dense.hip: LM work of every stream's last frame -> workgroups per stream); big batches only
   // optional stage timing (svs_frontend_set_timing): events between the stages of the last call
   bool timing = false;
   hipEvent_t ev_stage[SVS_FRONTEND_STAGES + 1] = {};
@@ -185,6 +186,7 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   if (fe->h_out) (void)hipHostFree(fe->h_out);
   if (fe->d_rec) (void)hipFree(fe->d_rec);
   if (fe->d_nrec) (void)hipFree(fe->d_nrec);
+  if (fe->d_trk_work) (void)hipFree(fe->d_trk_work);
   for (hipEvent_t e : fe->ev_stage) if (e) (void)hipEventDestroy(e);
   if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
   if (fe->side_stream) (void)hipStreamDestroy(fe->side_stream);
@@ -278,6 +280,10 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
   if (hipMalloc(&fe->d_rec, sizeof(svs_dense_lm_record) * REC_CAP * B) != hipSuccess || hipMalloc(&fe->d_nrec, sizeof(int32_t) * B) != hipSuccess ||
       hipMemsetAsync(fe->d_nrec, 0, sizeof(int32_t) * B, ctx->stream) != hipSuccess)
     return fail(SVS_ERR_HIP);
+  if (B >= 2 * ctx->n_cu && B <= 4096) {
+    if (hipMalloc(&fe->d_trk_work, svs_dense_track_balance_bytes(B)) != hipSuccess) return fail(SVS_ERR_HIP);
+    if ((rc = svs_dense_track_balance_init(ctx, fe->d_trk_work, B))) return fail(rc);
+  }
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SVS_ERR_HIP);
   *out = fe;
   return SVS_OK;
@@ -549,7 +555,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
         ta.d_cur_u8[l] = fe->d_pyr[cur][l]; ta.c8stride[l] = fe->stride[l]; ta.c8_bstride[l] = fe->lvl_elems[l]; ta.cam_vec[l] = fe->cams[l];
       }
       ta.d_record_out = fe->d_rec; ta.record_cap = REC_CAP; ta.d_n_record_out = fe->d_nrec;
-      if ((rc = svs_dense_track_cpu_sem(ctx, &ta, d_T, fe->d_passes, B))) return rc;
+      if ((rc = svs_dense_track_cpu_sem_work(ctx, &ta, d_T, fe->d_passes, B, fe->d_trk_work))) return rc;
     }
   }
   STAGE_MARK(2);

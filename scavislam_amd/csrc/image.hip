@@ -47,6 +47,7 @@ extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return SVS_ERR_HIP; }
   auto env_int = [](const char *name, int lo, int hi) { const char *e = getenv(name); if (!e) return 0; const int v = atoi(e); return v < lo ? lo : (v > hi ? hi : v); };
   c->trk_nwg = env_int("SVS_TRK_NWG", 1, 64);
+  if (getenv("SVS_TRK_BALANCE")) c->trk_balance = atoi(getenv("SVS_TRK_BALANCE"));
   c->trk_regs = getenv("SVS_TRK_ONE_PER_CU") ? 1 : (getenv("SVS_TRK_TWO_PER_CU") ? 2 : 0);
   c->full_nwg = env_int("SVS_FULL_NWG", 1, 1024);
   *out = c;
@@ -99,6 +100,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   const std::string n(name);
   if (n == "trk_nwg") c->trk_nwg = value > 64 ? 64 : value;
   else if (n == "trk_regs") c->trk_regs = value > 2 ? 0 : value;
+  else if (n == "trk_balance") c->trk_balance = value < 0 || value > 2 ? 1 : value;
   else if (n == "full_nwg") c->full_nwg = value > 1024 ? 1024 : value;
   else if (n == "mo_legacy") c->mo_legacy = value != 0;
   else if (n == "match_legacy") c->match_legacy = (int)value;

@@ -199,6 +199,63 @@ def test_throughput_batch_replicas_agree(gpu_ctx):
         assert (g["accepted"] == gs["accepted"]).mean() > 0.995
 
 
+def test_tracker_grid_order_does_not_change_results(gpu_ctx):
+    """Context option "trk_balance" (dense.hip): in a batch of two or more streams per CU the tracker's workgroups are launched in the order of the LM work
+    their streams needed in the LAST frame (dealt round-robin to the XCDs) instead of stream order; 2 = the experimental variant that also gives the longest
+    streams 2 .. 4 workgroups.  A stream's result must not depend on where its workgroup sits: three tracked frames (the order changes from the second on),
+    0 vs 1 bit-equal in every output, 2 equal up to the summation order of the split streams (pose 1e-9, same LM pass counts, no failed stream)."""
+    import torch
+    from scavislam_amd import capi
+    from scavislam_amd.frontend import StereoFrontend
+    ctx, stream = gpu_ctx
+    cam, S3 = _streams(3)
+    prm = capi.FrontendParams.reference()
+    dev = torch.device("cuda", 0)
+    B = 2 * 256 + 30
+    S = [S3[b % 3] for b in range(B)]
+
+    def frames(name):
+        with torch.cuda.stream(stream):
+            left = torch.as_tensor(np.stack([s["fr"][name][0] for s in S])).to(dev)
+            disp = torch.as_tensor(np.stack([s["fr"][name][2] for s in S]).astype(np.float32)).to(dev)
+        stream.synchronize()
+        return dict(left=left, disp=disp)
+
+    F = {n: frames(n) for n in ("kf", "prev", "cur")}
+    T_guess, T_act = np.stack([s["T_guess"].reshape(12) for s in S]), np.stack([s["T_act"].reshape(12) for s in S])
+
+    def run(mode):
+        ctx.set_option("trk_balance", mode)
+        try:
+            fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=prm, n_streams=B)
+            fe.processFirstFrames(**F["kf"])
+            fe.keepKeyframes(0, np.stack([s["T_kf"].reshape(12) for s in S]))
+            fe.processFirstFrames(**F["prev"])
+            for b, s in enumerate(S):
+                fe.setCandidates(s["pts"], s["n_new"], stream=b)
+            outs = []
+            for name in ("cur", "prev", "cur"):          # prev -> cur, cur -> prev, prev -> cur: three tracked frames with different LM pass counts per stream
+                fe.processFrames(T_guess, T_act, **F[name])
+                outs.append([fe.results(b) for b in (0, 1, 2, 257, B - 2, B - 1)] + [fe.poses()])
+            fe.close()
+            return outs
+        finally:
+            ctx.set_option("trk_balance", 1)
+
+    base, order, split = run(0), run(1), run(2)
+    for k in range(3):
+        for (o0, m0, g0), (o1, m1, g1), (o2, m2, g2) in zip(base[k][:-1], order[k][:-1], split[k][:-1]):
+            assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o1.T_cur_from_actkey)) and o0.dense_passes == o1.dense_passes >= 0, k
+            assert m0.tobytes() == m1.tobytes() and g0.tobytes() == g1.tobytes() and bytes(o0.point_stats) == bytes(o1.point_stats), k
+            assert o2.dense_passes == o0.dense_passes and o2.tracking_ok == o0.tracking_ok, k
+        T0, ok0 = base[k][-1]
+        T1, ok1 = order[k][-1]
+        T2, ok2 = split[k][-1]
+        assert np.array_equal(T0, T1) and np.array_equal(ok0, ok1), k
+        np.testing.assert_allclose(T2, T0, rtol=0, atol=1e-9)
+        assert np.array_equal(ok2, ok0), k
+
+
 def test_prefetch_and_split_call_equal_blocking_call(gpu_ctx):
     """svs_frontend_prefetch_frame (upload on the copy stream) + process_frame(NULL), and submit_frame / wait_frame, return what the blocking call returns;
     a three-frame sequence with the next frame prefetched while the current one is in flight keeps doing so."""
