@@ -28,7 +28,11 @@ def test_sequence_fixture_is_the_reference_loop():
     if not np.array_equal(np.array([r["crc"] for r in rec], np.uint64), fx["crc"][:36]):
         pytest.skip("the synthetic renderer produces other bytes on this host than where the fixture was generated")
     st = S.compare(rec, S.expand(fx)[:36], "reference CPU build vs its fixture", strict=True)
-    assert st["max_dT"] == 0.0 and st["other_points"] == 0
+    # every decision, id, FAST threshold and accepted point identical; the pose to round-off only: the reference iterates tr1::unordered containers keyed by the
+    # ADDRESS of heap objects (global.h:47-54), so the order in which observations enter the pose optimiser's sums follows the allocator's state -- the stand-in
+    # headers pin the Eigen-aligned classes to a fixed arena, the remaining plain `new` objects still move with what the process allocated before (here: a fresh
+    # process running 36 frames vs the generator's process after 200 frames of the other camera): measured 5e-16 from frame 33 on
+    assert st["max_dT"] <= 1e-12 and st["other_points"] == 0
     kf = int(fx["recompute_kf"][0])
     for l in range(3):
         assert np.array_equal(seq.recompute_fast_corners(kf, l).astype(np.int16), fx[f"recompute_0_{l}"])
