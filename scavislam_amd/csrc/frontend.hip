@@ -132,6 +132,12 @@ struct svs_frontend {
   svs_point_stats *d_ptstats = nullptr;
   int32_t *d_passes = nullptr;
   svs_fast *fast = nullptr;
+  // cross-frame pipeline (ctx option "fe_pipeline"): a second detector object for the odd frames (shares the adaptive thresholds with `fast`), so that FAST of
+  // frame N+1 can run while the matcher still reads frame N's corners; fast_cur = the object of the frame processed last (what the views hand out)
+  svs_fast *fast2 = nullptr, *fast_cur = nullptr;
+  hipEvent_t ev_early[2] = {}, ev_late[2] = {};      // by frame parity: pyramid + FAST done (side stream) / everything behind them done (context's stream)
+  hipEvent_t ev_trk[2] = {};                         // ... / the point of the context's stream right in front of the tracker's launch
+  unsigned pipe_run = 0;                             // frames issued through the pipelined path since the last frame that was not
   svs_stereo *stereo = nullptr;
   // pinned host staging: two input sets (images of stream 0, poses of all streams), one output set
   uint8_t *h_in[2] = {}; size_t h_in_bytes = 0; int i_stage = 0;
@@ -170,7 +176,11 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   (void)hipStreamSynchronize(fe->ctx->stream);
   if (fe->copy_stream) (void)hipStreamSynchronize(fe->copy_stream);
   if (fe->side_stream) (void)hipStreamSynchronize(fe->side_stream);
+  if (fe->fast2) svs_fast_destroy(fe->fast2);
   if (fe->fast) svs_fast_destroy(fe->fast);
+  for (hipEvent_t e : fe->ev_early) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : fe->ev_late) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : fe->ev_trk) if (e) (void)hipEventDestroy(e);
   if (fe->stereo) svs_stereo_destroy(fe->stereo);
   for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) if (fe->d_pyr[k][l]) (void)hipFree(fe->d_pyr[k][l]);
   for (int k = 0; k < 2; ++k) for (int l = 0; l < 3; ++l) if (fe->d_f32[k][l]) (void)hipFree(fe->d_f32[k][l]);
@@ -260,6 +270,15 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
   for (int l = 0; l < 3; ++l) fastgrid_for_level(fe->w[l], fe->h[l], l, &grids[l]);
   rc = svs_fast_create(ctx, fe->prm.n_levels, fe->w, fe->h, grids, n_streams, 8192, &fe->fast);
   if (rc) return fail(rc);
+  fe->fast_cur = fe->fast;
+  if (ctx->fe_pipeline && n_streams > 1 && n_streams <= 2 * ctx->n_cu && !prm->use_block_matching && !prm->cuda_build) {
+    if ((rc = svs_fast_create(ctx, fe->prm.n_levels, fe->w, fe->h, grids, n_streams, 8192, &fe->fast2))) return fail(rc);
+    if ((rc = svs_fast_share_thresholds(fe->fast2, fe->fast))) return fail(rc);
+    for (int k = 0; k < 2; ++k)
+      if (hipEventCreateWithFlags(&fe->ev_early[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_late[k], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&fe->ev_trk[k], hipEventDisableTiming) != hipSuccess)
+        return fail(SVS_ERR_HIP);
+  }
   if (prm->use_block_matching) { rc = svs_stereo_create(ctx, fe->w[0], fe->h[0], n_streams, &prm->stereo, &fe->stereo); if (rc) return fail(rc); }
   fe->h_in_bytes = 2 * (size_t)fe->w[0] * fe->h[0] + sizeof(float) * (size_t)fe->w[0] * fe->h[0] + sizeof(double) * 24 * B;
   fe->h_out_bytes = fe->small_bytes + (sizeof(svs_match_result) + sizeof(svs_gated_point)) * (size_t)max_points;
@@ -492,10 +511,34 @@ int frontend_take_device_frames(svs_frontend *fe, const svs_frames_dev *in) {
 struct DispView { const float *p; int stride; size_t bstride; };
 // everything behind the arrival of the images: pyramid, (tracking), stereo, FAST, (match, motion-only, gate), cloud.  first: processFirstFrame
 #define STAGE_MARK(k) do { if (fe->timing) SVS_HIP(ctx, hipEventRecord(fe->ev_stage[k], ctx->stream)); } while (0)
-int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
+int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = false) {
   svs_ctx *ctx = fe->ctx;
   const int B = fe->B, cur = fe->i_cur, prev = fe->i_prev, n = fe->n_launch;
   int rc;
+  // Cross-frame pipeline.  Pyramid + FAST of a frame ("early" part) need nothing of the frames before but free buffers; tracker, matcher, refinement, gate and
+  // cloud ("late" part) need the early part of their own frame and the late part of the frame before.  With the frames in caller-owned device buffers
+  // (complete when the call is made -- the contract of svs_frontend_process_frames) the early part goes to the low-priority side stream and waits only for the
+  // late part of frame N-2 (the last reader of the pyramid slot and of the detector object it writes: three pyramid slots, two detector objects): a caller that
+  // enqueues frame N+1 while frame N is still running gets early(N+1) beside late(N), filling the tails of its tracker and its pose refinement.  Results are
+  // those of the one-stream order (tests/test_gpu_frontend_batch.py).
+  const bool pipe = !first && ext_frames && fe->fast2 && fe->side_stream && ctx->fe_pipeline && ctx->fe_overlap && !fe->timing;
+  svs_fast *const F = pipe && (fe->pipe_run & 1u) ? fe->fast2 : fe->fast;
+  const int par = (int)(fe->pipe_run & 1u);
+  hipStream_t const chain_stream0 = ctx->stream;
+  if (pipe) {
+    if (fe->pipe_run == 0) {                                                                  // first pipelined frame: behind everything enqueued so far
+      SVS_HIP(ctx, hipEventRecord(fe->ev_fork, chain_stream0));
+      SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_fork, 0));
+    } else {
+      if (fe->pipe_run >= 2) SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_late[par], 0));      // late part of frame N-2
+      // ... and not before frame N-1's tracker has been launched: its workgroups (all resident at once, placed by the balanced order) take their slots first,
+      // this frame's early part fills what they leave -- started any earlier it sits in those slots and the tracker's workgroups trickle in behind it
+      SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_trk[1 - par], 0));
+    }
+    ctx->stream = fe->side_stream;                                                            // (a context is used by one thread at a time)
+  } else fe->pipe_run = 0;
+  fe->fast_cur = F;
+  auto back_to_chain = [&](int rc_) { ctx->stream = chain_stream0; return rc_; };
   for (int l = 1; l < 3; ++l) {                                                               // "preprocess"
     if (l == 1 && fe->ext_left)
       rc = svs_pyr_down_u8_copy(ctx, fe->ext_left, fe->w[0], fe->h[0], fe->ext_lstride, fe->ext_lbstride, fe->d_pyr[cur][1], fe->stride[1], fe->lvl_elems[1],
@@ -503,9 +546,18 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     else
       rc = svs_pyr_down_u8(ctx, fe->d_pyr[cur][l - 1], fe->w[l - 1], fe->h[l - 1], fe->stride[l - 1], fe->lvl_elems[l - 1], fe->d_pyr[cur][l], fe->stride[l],
                            fe->lvl_elems[l], B);
-    if (rc) return rc;
+    if (rc) return back_to_chain(rc);
   }
   fe->ext_left = nullptr;
+  if (pipe) {                                                                                 // "fast" of this frame, still on the side stream
+    const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
+    rc = svs_fast_detect(F, imgs, fe->stride, fe->lvl_elems, B, fe->prm.fast_trials);
+    const hipError_t e = rc ? hipSuccess : hipEventRecord(fe->ev_early[par], fe->side_stream);
+    ctx->stream = chain_stream0;
+    if (rc) return rc;
+    SVS_HIP(ctx, e);
+    SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_early[par], 0));
+  }
   const int f32c = fe->i_f32, f32p = 1 - fe->i_f32;
   if (fe->prm.cuda_build) {
     if ((rc = svs_preprocess_gpu_sem(ctx, fe->d_pyr[cur][0], fe->w[0], fe->h[0], fe->stride[0], fe->lvl_elems[0], fe->d_f32[f32c], fe->d_dx, fe->d_dy, fe->stride,
@@ -526,7 +578,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     STAGE_MARK(3);
     const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
     const int trials = first ? (fe->prm.fast_trials > 1 ? fe->prm.fast_trials - 1 : 5) : fe->prm.fast_trials;      // stereo_frontend.cpp:118 / :232
-    return svs_fast_detect(fe->fast, imgs, fe->stride, fe->lvl_elems, B, trials);            // "fast"
+    return svs_fast_detect(F, imgs, fe->stride, fe->lvl_elems, B, trials);            // "fast"
   };
   // With the stage clocks off, the detector stages of a tracked frame go to the side stream.  The fork event is recorded in FRONT of the tracker's launch, so
   // nothing but the streams' priorities (side stream: lowest) orders the two: the detector's workgroups fill what the tracker leaves idle -- above all its
@@ -534,8 +586,9 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
   // alone on the chain's stream so that the stage times add up to the step.)
   // (Only while all of the tracker's workgroups -- one per stream, two per CU -- are resident at once: beyond that the tracker has its own queue of
   // workgroups to fill the tail with, and detector workgroups in between only delay it: 7.01 vs 6.78 ms per step at 1024 streams.)
-  const bool side = !first && fe->side_stream && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
+  const bool side = !pipe && !first && fe->side_stream && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
   if (side) SVS_HIP(ctx, hipEventRecord(fe->ev_fork, ctx->stream));
+  if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));
   if (!first) {                                                                               // "dense tracking"
     if (fe->prm.cuda_build) {
       svs_dense_track_full_args ta{};
@@ -569,7 +622,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     if (rc) return rc;
     SVS_HIP(ctx, e);
     SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_join, 0));
-  } else if ((rc = detect())) return rc;
+  } else if (!pipe && (rc = detect())) return rc;
   STAGE_MARK(4);
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"
@@ -582,7 +635,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
       for (int l = 0; l < 3; ++l) { ma.d_cur_pyr[l] = fe->d_pyr[cur][l]; ma.cur_stride[l] = fe->stride[l]; ma.cur_bstride[l] = fe->lvl_elems[l]; ma.cam_vec[l] = fe->cams[l]; }
       ma.d_disp = dv.p; ma.disp_stride = dv.stride; ma.disp_bstride = dv.bstride;
       ma.search_radius = fe->prm.search_radius; ma.thr_mean = fe->prm.thr_mean; ma.thr_std = fe->prm.thr_std; ma.n_batch = B;
-      if ((rc = svs_match(ctx, &ma, fe->fast, fe->d_res))) return rc;
+      if ((rc = svs_match(ctx, &ma, F, fe->d_res))) return rc;
       if (fe->max_groups_used > 2) {
         hipLaunchKernelGGL(frontend_group_cut_kernel, dim3(B), dim3(256), 0, ctx->stream, fe->d_res, (size_t)fe->max_points, (const int32_t *)fe->d_group_end,
                            (const int32_t *)fe->d_n_groups, fe->prm.num_max_points);
@@ -610,6 +663,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv) {
     if (rc) return rc;
   }
   STAGE_MARK(8);
+  if (pipe) { SVS_HIP(ctx, hipEventRecord(fe->ev_late[par], ctx->stream)); ++fe->pipe_run; }
   fe->last_disp = dv.p; fe->last_dstride = dv.stride; fe->last_dbstride = dv.bstride;
   return SVS_OK;
 }
@@ -726,7 +780,8 @@ extern "C" int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_de
   SVS_HIP(ctx, hipEventRecord(fe->ev_upload[stage], ctx->stream));
   fe->i_stage = 1 - fe->i_stage;
   DispView dv = in && in->d_disp ? DispView{in->d_disp, in->dstride, in->d_bstride} : DispView{fe->d_disp[fe->i_cur], fe->stride[0], fe->lvl_elems[0]};
-  if ((rc = frontend_chain(fe, false, dv))) return rc;
+  const bool ext_frames = in && fe->ext_left && in->d_disp && !fe->prm.use_block_matching;      // caller-owned, complete device frames: the pipelined schedule may run
+  if ((rc = frontend_chain(fe, false, dv, ext_frames))) return rc;
   return frontend_end(fe, 0, false);
 }
 
@@ -864,7 +919,7 @@ extern "C" int svs_frontend_device_view(svs_frontend *fe, int stream, const uint
     if (d_cloud) d_cloud[l] = fe->d_cloud[l] + fe->cloud_elems[l] * stream;
   }
   if (d_disp) *d_disp = fe->last_disp ? fe->last_disp + fe->last_dbstride * stream : nullptr;
-  if (fast) *fast = fe->fast;
+  if (fast) *fast = fe->fast_cur;
   return SVS_OK;
 }
 
