@@ -178,6 +178,8 @@ def main():
             prm = capi.FrontendParams.reference(use_block_matching=block_matching, cuda_build=cuda_build)
             self.fe = StereoFrontend(ctx, cam, max_points=max(args.points, 1), max_keyframes=1, params=prm, n_streams=B)
             pair = [(b + pair_offset) % NPAIR for b in range(B)]
+            if os.environ.get("SVS_BENCH_SHUFFLE"):      # experiment (profiles/r4_notes.md): the same multiset of pairs dealt to the streams in a shuffled order
+                pair = [int(x) for x in np.random.default_rng(5).permutation(pair)]
             if block_matching:      # only NRIGHT pairs have a rendered right image
                 pair = [p % NRIGHT for p in pair]
             self.pair = pair
