@@ -90,7 +90,7 @@ def test_reference_process_frame_cuda_build_with_hip_branch_in_place(gpu_ctx):
     is the translation unit of libsvs_ref_frame_cuda.so compiled with SCAVISLAM_HIP_SUPPORT as well -- declarations, members and the matcher radius (4) are the CUDA
     build's, `tracker_.denseTrackingGpu` / the disparity upload / `computeDensePointCloudGpu` (stereo_frontend.cpp:192-196,213-215,298-302) and the CUDA branch of
     preprocessing run in libscavislam_hip.so.  Against the same unit running the reference's own kernels through the CUDA emulator: draw lists identical, pose within
-    2e-5 (the reference's kernels sum in f32, the HIP tracker in f64), clouds 1e-4."""
+    1e-7 (measured 3.3e-9: the reference's kernels sum in f32, the HIP tracker in f64), clouds 4e-6 absolute (measured: one f32 ulp)."""
     if not (_have("libsvs_hipbranch_frame_cuda.so") and _have("libsvs_ref_frame_cuda.so")):
         pytest.skip("oracle/_ref/libsvs_hipbranch_frame_cuda.so / libsvs_ref_frame_cuda.so not present")
     import oracle as O
@@ -115,12 +115,15 @@ def test_reference_process_frame_cuda_build_with_hip_branch_in_place(gpu_ctx):
         n_lines += len(ref["lines"][l])
     assert n_lines > 40
     dT = np.abs(hip["T"] - ref["T"]).max()
-    assert dT < 2e-5, dT
+    assert dT < 1e-7, dT          # measured 3.3e-9
     assert abs(hip["av_track_length"] - ref["av_track_length"]) <= 1e-9 * max(1.0, ref["av_track_length"])
     for l in range(3):
         a, b = hip["clouds"][l], ref["clouds"][l]
         assert np.array_equal(a[..., 3], b[..., 3])
-        np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-4)
+        valid = a[..., 3] > 0
+        da = np.abs(a[..., :3] - b[..., :3])[valid]
+        print(f"  CUDA build, HIP branch in place, cloud: max abs deviation {da.max():.2e}, max relative {(da / np.maximum(np.abs(b[..., :3][valid]), 1e-3)).max():.2e}")
+        np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=0, atol=4e-6)      # measured 1.9e-6 = one f32 ulp at 16..32 m
     print(f"CUDA build with the HIP branch in place: pose deviation {dT:.2e}, {n_lines} draw lines identical")
 
 

@@ -94,7 +94,12 @@ def _check_against_reference_outputs(out, matches, gated, clouds, pts_grouped, r
     for l in range(3):
         a, b = clouds[l], ref_clouds[l]
         assert np.array_equal(a[..., 3], b[..., 3]), f"cloud validity of level {l}"
-        np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=cloud_rtol, atol=1e-5)
+        valid = a[..., 3] > 0
+        if valid.any() and cloud_rtol > 0:
+            da = np.abs(a[..., :3] - b[..., :3])[valid]
+            print(f"  cloud level {l}: max abs deviation {da.max():.2e}, max relative {(da / np.maximum(np.abs(b[..., :3][valid]), 1e-3)).max():.2e}")
+        # measured (printed above): CUDA build 1.9e-6 = one f32 ulp at 16..32 m (f32 clouds at a pose that differs by ~3e-9); CPU build 0
+        np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=0, atol=4e-6)
     return dT
 
 
@@ -325,7 +330,7 @@ def test_process_frame_cuda_build_equals_reference_compiled_process_frame(gpu_ct
     r = O.ref_process_frame([pyr_k], [I34.reshape(12)], 0, [], cams, pts, list_of, I34, cloud_prev, fp, pyr_c, fc, dx, dy, disp_c, cuda_build=True)
     assert r["ok"]
     out, matches, gated, clouds, idx = _run_hip_cuda_build(ctx, case, pts, list_of, disp_c, prev_clouds=cloud_prev)
-    dT = _check_against_reference_outputs(out, matches, gated, clouds, pts[idx], r["T"], r["lines"], r["av_track_length"], r["clouds"], 2e-5, 1e-4)
+    dT = _check_against_reference_outputs(out, matches, gated, clouds, pts[idx], r["T"], r["lines"], r["av_track_length"], r["clouds"], 1e-7, 1e-4)      # measured: pose 3.3e-9
     print(f"CUDA build: pose deviation from the reference {dT:.2e}, {out.point_stats.num_track_points} accepted, {out.dense_passes} fused sweeps")
 
 
@@ -377,5 +382,5 @@ def test_process_frame_cuda_build_equals_reference_generated_fixture(gpu_ctx):
         if l == 0:                                                         # level 0 is stored every 4th row
             clouds[0] = clouds[0][::4]
     dT = _check_against_reference_outputs(out, matches, gated, clouds, pts[idx], f["T"], [f[f"lines_l{l}"] for l in range(3)], float(f["av_track_length"][0]),
-                                          ref_clouds, 2e-5, 1e-4)
+                                          ref_clouds, 1e-7, 1e-4)
     print(f"CUDA-build fixture: pose deviation from the reference {dT:.2e}")

@@ -11,7 +11,7 @@ def main(src, out, title, notes=None):
     line = [l for l in rd("bench.log").splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     md = [f"# {title}\n",
-          "1 x MI355X `gpurun` box (ROCm 7.2, PyTorch 2.10+rocm7.0).  Produced by `tools/collect_profiles_r2.sh` + `tools/make_r2_summary.py`;\n"
+          "1 x MI355X `gpurun` box (ROCm 7.2, PyTorch 2.10+rocm7.0).  Produced by `tools/collect_profiles_r<N>.sh` + `tools/make_r2_summary.py`;\n"
           "the rocpd databases stay on the box, the tables below are their per-kernel aggregates.\n",
           "## 1. `python bench.py` (N = 1)\n", "```json\n" + line + "\n```\n"]
     rf, sc = d["roofline"], d["schur"]
