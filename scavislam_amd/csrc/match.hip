@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // requests instead of sixteen single bytes; anything else takes the byte path.  px[]: the two 8-byte rows, or per pixel v00 | v10 << 8 | v01 << 16
   // | v11 << 24; flags: bit j = pixel j inside the image, bit 4 = row-pair case; offs: byte j = column offset of pixel j in the rows.
   const int prow = sub >> 1, pc0 = 4 * (sub & 1);
-  uint32_t px0 = 0, px1 = 0, px2 = 0, px3 = 0, flags = 0, offs = 0;
+  uint32_t px0 = 0, px1 = 0, px2 = 0, px3 = 0, px4 = 0, px5 = 0, flags = 0, offs = 0;
   if (go) {
     const double i00 = pp->inv[0], i01 = pp->inv[1], i10 = pp->inv[2], i11 = pp->inv[3];
     const double key_u = pp->key_uv[0], key_v = pp->key_uv[1];
@@ -682,13 +682,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       flags |= in ? 1u << j : 0u;
       xis[j] = in ? (int)x : 0; yis[j] = in ? (int)y : 0;
     }
-    const bool oneRow = flags == 15u && yis[1] == yis[0] && yis[2] == yis[0] && yis[3] == yis[0] && (unsigned)(xis[1] - xis[0]) <= 6u &&
-                        (unsigned)(xis[2] - xis[0]) <= 6u && (unsigned)(xis[3] - xis[0]) <= 6u && xis[0] + 8 <= Lw;
+    // (round 4) the four samples may also straddle TWO source row pairs (a slightly rotated or scaled warp crosses a row boundary inside most waves: with the
+    // row-pair case alone, one lane in 64 on the byte path made the whole wave issue its sixteen byte loads): three 8-byte rows y, y+1, y+2, and a bit per
+    // pixel that says which pair is its own (flags bit 5 + j)
+    const int ymin = min(min(yis[0], yis[1]), min(yis[2], yis[3]));
+    const bool oneRow = flags == 15u && (unsigned)(yis[0] - ymin) <= 1u && (unsigned)(yis[1] - ymin) <= 1u && (unsigned)(yis[2] - ymin) <= 1u &&
+                        (unsigned)(yis[3] - ymin) <= 1u && (unsigned)(xis[1] - xis[0]) <= 6u && (unsigned)(xis[2] - xis[0]) <= 6u &&
+                        (unsigned)(xis[3] - xis[0]) <= 6u && xis[0] + 8 <= Lw;
     if (oneRow) {
-      const uint8_t *q = kimg + (size_t)yis[0] * kstride + xis[0];
-      const U2 ra = ld_u2u(q), rb = ld_u2u(q + kstride);
-      px0 = ra.x; px1 = ra.y; px2 = rb.x; px3 = rb.y;
-      flags |= 16u;
+      const uint8_t *q = kimg + (size_t)ymin * kstride + xis[0];
+      const U2 ra = ld_u2u(q), rb = ld_u2u(q + kstride), rc = ld_u2u(q + (ymin + 2 < Lh ? 2 : 1) * (ptrdiff_t)kstride);      // (row y+2 is only used by pixels on row y+1, whose y+2 is inside)
+      px0 = ra.x; px1 = ra.y; px2 = rb.x; px3 = rb.y; px4 = rc.x; px5 = rc.y;
+      flags |= 16u | (uint32_t)(yis[0] - ymin) << 5 | (uint32_t)(yis[1] - ymin) << 6 | (uint32_t)(yis[2] - ymin) << 7 | (uint32_t)(yis[3] - ymin) << 8;
       offs = (uint32_t)(xis[1] - xis[0]) << 8 | (uint32_t)(xis[2] - xis[0]) << 16 | (uint32_t)(xis[3] - xis[0]) << 24;
     } else {
 #pragma unroll
@@ -744,7 +749,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       uint32_t t = j == 0 ? px0 : j == 1 ? px1 : j == 2 ? px2 : px3;
       if (oneRow) {
         const uint32_t o = (offs >> (8 * j)) & 0xffu, sel = o | ((o + 1u) << 8) | 0x0c0c0000u;      // V_PERM: bytes o, o + 1 of an 8-byte row, zeros above
-        t = __builtin_amdgcn_perm(px1, px0, sel) | __builtin_amdgcn_perm(px3, px2, sel) << 16;
+        const bool lower = (flags >> (5 + j) & 1u) != 0u;
+        t = __builtin_amdgcn_perm(lower ? px3 : px1, lower ? px2 : px0, sel) | __builtin_amdgcn_perm(lower ? px5 : px3, lower ? px4 : px2, sel) << 16;
       }
       const double v00 = (double)(t & 0xffu), v10 = (double)(t >> 8 & 0xffu), v01 = (double)(t >> 16 & 0xffu), v11 = (double)(t >> 24);
       const double wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
