@@ -577,8 +577,8 @@ def main():
         comm2, p2p_error = None, None
         try:
             with _stdout_to_stderr():
-                g = dist.new_group(backend="gloo") if world > 1 else None      # carries the 64-byte IPC handles (CPU tensors)
-                comm2 = Communicator.p2p(ctx, rank, world, capacity_doubles=1 << 17, group=g)
+                comm2 = Communicator.p2p(ctx, rank, world, capacity_doubles=1 << 17, device=dev)      # the 64-byte IPC handles travel over the default (nccl) group
+                                                                                                     # (succeeds or raises on ALL ranks together)
         except Exception as e:
             p2p_error = repr(e)
         ok = torch.tensor([0 if comm2 is None else 1], dtype=torch.int32, device=dev)

@@ -70,22 +70,40 @@ class Communicator:
         ctx.children.add(self)
 
     @classmethod
-    def p2p(cls, ctx, rank, world, capacity_doubles=1 << 16, group=None):
+    def p2p(cls, ctx, rank, world, capacity_doubles=1 << 16, group=None, device=None):
         """The one-shot transport (svs_comm_create_p2p / svs_comm_connect_p2p): peer-mapped mailboxes instead of RCCL.  The 64-byte IPC handles are
-        all-gathered through torch.distributed (CPU tensors: any backend with CPU support, e.g. gloo; a C++ host would use MPI or a TCP store)."""
+        all-gathered through torch.distributed -- CPU tensors (a gloo group) or, with `device`, tensors on that GPU (the nccl backend); a C++ host would use
+        MPI or a TCP store.  Every rank learns whether ALL ranks could map their peers (a MIN all-reduce, so that nobody is left waiting in a barrier for a
+        rank that raised): on failure every rank raises."""
         import torch.distributed as dist
         self = cls.__new__(cls)
         self.ctx, self.rank, self.world = ctx, rank, world
         self.h = C.c_void_p()
         mine = np.zeros(64, np.uint8)
-        ctx.check(ctx.lib.svs_comm_create_p2p(ctx.h, rank, world, capacity_doubles, C.byref(self.h), mine.ctypes.data))
-        ctx.children.add(self)
+        err = None
+        try:
+            ctx.check(ctx.lib.svs_comm_create_p2p(ctx.h, rank, world, capacity_doubles, C.byref(self.h), mine.ctypes.data))
+            ctx.children.add(self)
+        except Exception as e:              # e.g. hipIpcGetMemHandle refused: this rank still takes part in the two collectives below
+            err = e
+            self.h = None
+            if world == 1:
+                raise
         if world > 1:
-            out = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(out, torch.as_tensor(mine), group=group)
-            handles = np.ascontiguousarray(np.stack([t.numpy() for t in out]))
-            ctx.check(ctx.lib.svs_comm_connect_p2p(self.h, handles.ctypes.data))
-            dist.barrier(group=group)              # every mailbox is mapped everywhere before the first push
+            dev = torch.device("cpu") if device is None else device
+            out = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+            dist.all_gather(out, torch.as_tensor(mine).to(dev), group=group)
+            handles = np.ascontiguousarray(np.stack([t.cpu().numpy() for t in out]))
+            if err is None:
+                try:
+                    ctx.check(ctx.lib.svs_comm_connect_p2p(self.h, handles.ctypes.data))
+                except Exception as e:      # e.g. no peer access between two devices
+                    err = e
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # also the barrier: every mailbox is mapped everywhere before the first push
+            if int(ok.item()) == 0:
+                self.close()
+                raise err if err else RuntimeError("one-shot P2P transport: another rank could not map its peers' mailboxes")
         return self
 
     def transport(self):
