@@ -156,6 +156,10 @@ def main():
             rows.append(r)
         pts = np.concatenate(rows)
         pts = pts[rng.permutation(len(pts))]                    # new-feature list and neighbourhood list both hold all levels
+        if os.environ.get("SVS_BENCH_SORT_PTS"):                # experiment: the two lists in image order (level, row, column) instead of hash order
+            h = len(pts) // 2
+            key = lambda q: np.lexsort((q["anchor_obs_pyr"][:, 0], q["anchor_obs_pyr"][:, 1], q["anchor_level"]))
+            pts = np.concatenate([pts[:h][key(pts[:h])], pts[h:][key(pts[h:])]])
         pts["kf_index"] = 0
         pts["point_id"] = np.arange(len(pts))
         return pts

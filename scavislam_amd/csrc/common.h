@@ -28,6 +28,7 @@ struct svs_ctx {
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
+  int match_order = 1;        // "match_order": match_kernel3 takes the points of a stream in image order (counting sort by cell of the predicted position), 0: list order
   int fe_pipeline = 0;        // "fe_pipeline" (set before svs_frontend_create): svs_frontend_process_frames on caller-owned device frames runs pyramid + FAST of frame
                               // N+1 on the side stream while frame N's tracker / matcher / refinement are still running (frontend.hip).  Results identical; OFF by
                               // default: measured 2.856 vs 2.876 ms per 512 frames -- at this batch size the device is busy, the moved work is not free

@@ -112,6 +112,9 @@ struct MatchParams {
   FastView fv;
   const double *kf_T;     // [n_batch][n_kf][24]: T_cur_from_anchor, T_actkey_from_anchor (match_pose_kernel)
   PointPred *pred;        // [n_batch][n_pts]
+  const int32_t *order;   // [n_batch][n_pts] or NULL: the order in which match_kernel3 takes the points of a stream (match_order_kernel)
+  int32_t *keys;          // [n_batch][n_pts] or NULL: the bucket of every point (written by match_predict_kernel, read by match_order_kernel)
+  int32_t ord_sx, ord_sy, ord_nbx, ord_nb;      // its buckets: level * ord_nb + (vi >> ord_sy) * ord_nbx + (ui >> ord_sx); bucket 3 * ord_nb = points that are not searched
   LevelTab *lt;           // [SVS_NUM_PYR_LEVELS]
 };
 
@@ -203,6 +206,14 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
     }
   }
   M.pred[(size_t)slot * A.n_pts + ip] = pr;
+  if (M.keys) {           // bucket of the point for match_order_kernel: (level, cell of the predicted position); the points that are not searched go last
+    int b = 3 * M.ord_nb;
+    if (pr.status == SVS_MATCH_OK) {
+      const int bx = min(max(pr.ui, 0) >> M.ord_sx, M.ord_nbx - 1), by = max(pr.vi, 0) >> M.ord_sy;
+      b = min(pr.lvl * M.ord_nb + by * M.ord_nbx + bx, 3 * M.ord_nb - 1);
+    }
+    M.keys[(size_t)slot * A.n_pts + ip] = b;
+  }
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -599,6 +610,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // modifiers, no LDS); the key patch never moves; the (2R+1)^2 window is one score-map row per lane (17 rows = 16 lanes + a shared last row), whose
 // non-zero bytes -- the score map is zero except at corners -- are found with byte-mask arithmetic instead of a compare per position.  Four points
 // share every instruction.  Needs 2R+1 <= 17 (the reference's radii: 8 on the CPU build, 4 on the CUDA build); wider windows take match_kernel2.
+// The order in which match_kernel3 takes the points of a stream.  The caller's lists come in hash order (the reference iterates tr1::unordered_maps): four
+// points that share a wave then sit anywhere in the image, every wave touches its own score-map, key-patch and image lines, and the kernel runs at the miss
+// rate of the vector L1 / L2.  A counting sort by (level, 32 x 16 pixel cell of the predicted position) makes neighbours in the order neighbours in the image
+// (match 0.83 -> 0.69 ms per 512 x 2000 points) and collects the points that are not searched (behind the camera, outside the frame) in waves of their own.
+// One workgroup per stream; the order inside a cell is whatever the atomics make it -- every point is matched on its own and written to its own record, so
+// the results do not depend on it.
+constexpr int ORD_MAX_BUCKETS = 6144;
+__global__ __launch_bounds__(256) void match_order_kernel(MatchParams M, int32_t *__restrict__ order) {
+  __shared__ int s_cnt[ORD_MAX_BUCKETS + 1];
+  __shared__ int s_part[256];
+  const int slot = blockIdx.x, n = M.a.n_pts, tid = threadIdx.x, nb_tot = 3 * M.ord_nb + 1;
+  const int32_t *keys = M.keys + (size_t)slot * n;
+  for (int b = tid; b < nb_tot; b += 256) s_cnt[b] = 0;
+  __syncthreads();
+  auto bucket = [&](int ip) { return keys[ip]; };
+  for (int ip = tid; ip < n; ip += 256) atomicAdd(&s_cnt[bucket(ip)], 1);
+  __syncthreads();
+  // exclusive scan of the bucket counts: every thread a contiguous run, then the runs' totals
+  const int per = (nb_tot + 255) / 256, b0 = tid * per, b1 = min(nb_tot, b0 + per);
+  int run = 0;
+  for (int b = b0; b < b1; ++b) run += s_cnt[b];
+  s_part[tid] = run;
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int t = 0; t < 256; ++t) { const int c = s_part[t]; s_part[t] = acc; acc += c; } }
+  __syncthreads();
+  int acc = s_part[tid];
+  for (int b = b0; b < b1; ++b) { const int c = s_cnt[b]; s_cnt[b] = acc; acc += c; }
+  __syncthreads();
+  for (int ip = tid; ip < n; ip += 256) order[(size_t)slot * n + atomicAdd(&s_cnt[bucket(ip)], 1)] = ip;
+}
+
 constexpr int M3_GROUPS = 16;                      // points per 256-lane block
 constexpr int M3_CAND_CAP = 17 * 17;
 __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {      // all-reduce over the 16 lanes of a DPP row
@@ -618,8 +660,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ int s_ncand[M3_GROUPS];
   const svs_match_args &A = M.a;
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int ip = blockIdx.x * M3_GROUPS + grp, slot = blockIdx.y;
-  const bool live = ip < A.n_pts;
+  const int ipos = blockIdx.x * M3_GROUPS + grp, slot = blockIdx.y;
+  const bool live = ipos < A.n_pts;
+  const int ip = live && M.order ? M.order[(size_t)slot * A.n_pts + ipos] : ipos;
   const PointPred *pp = M.pred + (size_t)slot * A.n_pts + (live ? ip : A.n_pts - 1);
   int status = pp->status;
   bool go = live && status == SVS_MATCH_OK;
@@ -861,23 +904,41 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   const size_t pred_bytes = (size_t)a->n_batch * a->n_pts * sizeof(PointPred);
   const size_t lt_bytes = 256;
   static_assert(sizeof(LevelTab) * SVS_NUM_PYR_LEVELS <= 256, "level table");
+  const size_t ord_bytes = (((size_t)a->n_batch * a->n_pts * sizeof(int32_t)) + 255) & ~(size_t)255;
   void *buf = nullptr;
-  { const int rc = svs_ctx_match_scratch(ctx, lt_bytes + kf_bytes + pred_bytes, &buf); if (rc) return rc; }
+  { const int rc = svs_ctx_match_scratch(ctx, lt_bytes + kf_bytes + 2 * ord_bytes + pred_bytes, &buf); if (rc) return rc; }
   M.lt = static_cast<LevelTab *>(buf);
   double *kf_T = reinterpret_cast<double *>(static_cast<char *>(buf) + lt_bytes);
   M.kf_T = kf_T;
-  M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + lt_bytes + kf_bytes);
+  int32_t *order = reinterpret_cast<int32_t *>(static_cast<char *>(buf) + lt_bytes + kf_bytes);
+  M.pred = reinterpret_cast<PointPred *>(static_cast<char *>(buf) + lt_bytes + kf_bytes + 2 * ord_bytes);
+  M.order = nullptr; M.keys = nullptr;
+  // (option "match_legacy": 0 = the fastest kernel that applies, 1 = match_kernel, 2 = match_kernel2 where it applies)
+  bool lean = ctx->match_legacy != 1;
+  for (int l = 0; l < M.fv.n_levels; ++l) lean = lean && 2 * a->search_radius + 1 <= std::min(M.fv.cell_w[l], M.fv.cell_h[l]);
+  const bool k3 = lean && ctx->match_legacy == 0 && 2 * a->search_radius + 1 <= 17;
+  const bool ordered = k3 && ctx->match_order && a->n_pts >= 64 && (size_t)a->n_batch * a->n_pts >= 32768;      // a batch: one more launch (~10 us) is not worth it for a stream or two
+  if (ordered) {      // cells of 32 x 16 pixels of level 0 (coarser for frames that would need more than ORD_MAX_BUCKETS buckets)
+    int sx = 5, sy = 4;
+    auto nb = [&]() { return ((M.fv.w[0] + (1 << sx) - 1) >> sx) * ((M.fv.h[0] + (1 << sy) - 1) >> sy); };
+    while (3 * nb() + 1 > ORD_MAX_BUCKETS) { if (sx <= sy + 1) ++sx; else ++sy; }
+    M.ord_sx = sx; M.ord_sy = sy; M.ord_nbx = (M.fv.w[0] + (1 << sx) - 1) >> sx; M.ord_nb = nb();
+    M.keys = order + ord_bytes / sizeof(int32_t);
+  }
   hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M, kf_T);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
   SVS_LAUNCH_CHECK(ctx);
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
   // the lean scan resolves a window's cells once per point: it needs windows narrower than a cell (always so for the reference's grids and radii)
-  // (option "match_legacy": 0 = the fastest kernel that applies, 1 = match_kernel, 2 = match_kernel2 where it applies)
-  bool lean = ctx->match_legacy != 1;
-  for (int l = 0; l < M.fv.n_levels; ++l) lean = lean && 2 * a->search_radius + 1 <= std::min(M.fv.cell_w[l], M.fv.cell_h[l]);
-  if (lean && ctx->match_legacy == 0 && 2 * a->search_radius + 1 <= 17)
+  if (k3) {
+    if (ordered) {
+      hipLaunchKernelGGL(match_order_kernel, dim3(a->n_batch), dim3(256), 0, ctx->stream, M, order);
+      SVS_LAUNCH_CHECK(ctx);
+      M.order = order;
+    }
     hipLaunchKernelGGL(match_kernel3, dim3(div_up(a->n_pts, M3_GROUPS), a->n_batch), dim3(256), 0, ctx->stream, M, d_out);
+  }
   else if (lean) hipLaunchKernelGGL(match_kernel2, grid, block, 0, ctx->stream, M, d_out);
   else hipLaunchKernelGGL(match_kernel, grid, block, 0, ctx->stream, M, d_out);
   SVS_LAUNCH_CHECK(ctx);
