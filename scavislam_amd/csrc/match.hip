@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // share every instruction.  Needs 2R+1 <= 17 (the reference's radii: 8 on the CPU build, 4 on the CUDA build); wider windows take match_kernel2.
 // The order in which match_kernel3 takes the points of a stream.  The caller's lists come in hash order (the reference iterates tr1::unordered_maps): four
 // points that share a wave then sit anywhere in the image, every wave touches its own score-map, key-patch and image lines, and the kernel runs at the miss
-// rate of the vector L1 / L2.  A counting sort by (level, 32 x 16 pixel cell of the predicted position) makes neighbours in the order neighbours in the image
+// rate of the vector L1 / L2.  A counting sort by (level, 16 x 16 pixel cell of the predicted position) makes neighbours in the order neighbours in the image
 // (match 0.83 -> 0.69 ms per 512 x 2000 points) and collects the points that are not searched (behind the camera, outside the frame) in waves of their own.
 // One workgroup per stream; the order inside a cell is whatever the atomics make it -- every point is matched on its own and written to its own record, so
 // the results do not depend on it.
@@ -918,8 +918,8 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
   for (int l = 0; l < M.fv.n_levels; ++l) lean = lean && 2 * a->search_radius + 1 <= std::min(M.fv.cell_w[l], M.fv.cell_h[l]);
   const bool k3 = lean && ctx->match_legacy == 0 && 2 * a->search_radius + 1 <= 17;
   const bool ordered = k3 && ctx->match_order && a->n_pts >= 64 && (size_t)a->n_batch * a->n_pts >= 32768;      // a batch: one more launch (~10 us) is not worth it for a stream or two
-  if (ordered) {      // cells of 32 x 16 pixels of level 0 (coarser for frames that would need more than ORD_MAX_BUCKETS buckets)
-    int sx = 5, sy = 4;
+  if (ordered) {      // cells of 16 x 16 pixels of level 0 (coarser for frames that would need more than ORD_MAX_BUCKETS buckets)
+    int sx = 4, sy = 4;      // (16 x 16 ... 64 x 32 pixel cells measure the same within 2 %: 0.69 - 0.71 ms)
     auto nb = [&]() { return ((M.fv.w[0] + (1 << sx) - 1) >> sx) * ((M.fv.h[0] + (1 << sy) - 1) >> sy); };
     while (3 * nb() + 1 > ORD_MAX_BUCKETS) { if (sx <= sy + 1) ++sx; else ++sy; }
     M.ord_sx = sx; M.ord_sy = sy; M.ord_nbx = (M.fv.w[0] + (1 << sx) - 1) >> sx; M.ord_nb = nb();
