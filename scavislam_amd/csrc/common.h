@@ -29,9 +29,8 @@ struct svs_ctx {
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
   int match_order = 1;        // "match_order": match_kernel3 takes the points of a stream in image order (counting sort by cell of the predicted position), 0: list order
-  int fe_pipeline = 0;        // "fe_pipeline" (set before svs_frontend_create): svs_frontend_process_frames on caller-owned device frames runs pyramid + FAST of frame
-                              // N+1 on the side stream while frame N's tracker / matcher / refinement are still running (frontend.hip).  Results identical; OFF by
-                              // default: measured 2.856 vs 2.876 ms per 512 frames -- at this batch size the device is busy, the moved work is not free
+  int fe_pipeline = 1;        // "fe_pipeline" (read at svs_frontend_create and per call): svs_frontend_process_frames on caller-owned device frames builds the pyramid
+                              // of frame N+1 on the side stream while frame N's pose refinement / gate / cloud run (frontend.hip).  Results identical.
   int fe_overlap = 1;         // "fe_overlap": the one-call front end runs FAST / block matching on a side stream beside the dense tracker (0: one stream)
   int trk_seq_chi2 = 0;       // "trk_seq_chi2": the quarter-grid tracker decides accept / reject on the reference's own sequential f32 chi2 sums (dense.hip; slow: parity runs)
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // its per-pass term buffer
@@ -49,7 +48,6 @@ int svs_spin_leave(svs_ctx *ctx);
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
 int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
-int svs_fast_share_thresholds(svs_fast *f, svs_fast *owner);      // fast.hip
 // svs_dense_track_cpu_sem with the state of the balanced launch of big batches (dense.hip: per-stream LM work of the last frame -> workgroups per stream);
 // d_bal_state: svs_dense_track_balance_bytes(batch) bytes of device memory, initialised once by svs_dense_track_balance_init; may be NULL
 size_t svs_dense_track_balance_bytes(int batch);

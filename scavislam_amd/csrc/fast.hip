@@ -563,7 +563,6 @@ struct svs_fast {
   int *d_ovf = nullptr;       // [batch][ncell_total] cells the list compaction left to the sweep
   bool use_lists = false;
   bool force_cmp16 = false;   // SVS_FAST_NO_LISTS / SVS_FAST_CMP16, read once at svs_fast_create (experiments only)
-  bool owns_thr = true;       // false: P.thr is another object's array (svs_fast_share_thresholds)
 };
 
 extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
@@ -644,24 +643,10 @@ extern "C" int svs_fast_destroy(svs_fast *f) {
   if (!f) return SVS_OK;
   (void)hipStreamSynchronize(f->ctx->stream);
   for (int l = 0; l < f->P.n_levels; ++l) { hipFree(f->P.lv[l].score); hipFree(f->P.lv[l].xy); }
-  hipFree(f->P.hist); if (f->owns_thr) hipFree(f->P.thr); hipFree(f->P.emit); hipFree(f->P.count); hipFree(f->P.offset);
+  hipFree(f->P.hist); hipFree(f->P.thr); hipFree(f->P.emit); hipFree(f->P.count); hipFree(f->P.offset);
   hipFree(f->P.level_total); hipFree(f->d_tiles);
   hipFree(f->P.cand); hipFree(f->P.cand_n); hipFree(f->P.cell_tile0); hipFree(f->P.cell_ntile); hipFree(f->d_ovf);
   delete f;
-  return SVS_OK;
-}
-
-// `f` gives up its own threshold state and from now on reads / updates `owner`'s (same grids, same batch): two objects that take turns on the frames of
-// one sequence (frontend.hip: the detector of frame N+1 runs while the matcher still reads frame N's corners) carry ONE adaptive state between them.
-// `owner` must outlive `f`; the calls on the two objects must be ordered (one stream).
-int svs_fast_share_thresholds(svs_fast *f, svs_fast *owner) {
-  svs_ctx *ctx = f ? f->ctx : nullptr;
-  SVS_REQUIRE(ctx, f && owner && f != owner && f->batch == owner->batch && f->P.ncell_total == owner->P.ncell_total && f->owns_thr);
-  SVS_DEVICE(ctx);
-  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(f->P.thr);
-  f->P.thr = owner->P.thr;
-  f->owns_thr = false;
   return SVS_OK;
 }
 

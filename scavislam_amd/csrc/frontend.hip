@@ -132,11 +132,9 @@ struct svs_frontend {
   svs_point_stats *d_ptstats = nullptr;
   int32_t *d_passes = nullptr;
   svs_fast *fast = nullptr;
-  // cross-frame pipeline (ctx option "fe_pipeline"): a second detector object for the odd frames (shares the adaptive thresholds with `fast`), so that FAST of
-  // frame N+1 can run while the matcher still reads frame N's corners; fast_cur = the object of the frame processed last (what the views hand out)
-  svs_fast *fast2 = nullptr, *fast_cur = nullptr;
-  hipEvent_t ev_early[2] = {}, ev_late[2] = {};      // by frame parity: pyramid + FAST done (side stream) / everything behind them done (context's stream)
-  hipEvent_t ev_trk[2] = {};                         // ... / the point of the context's stream right in front of the tracker's launch
+  // cross-frame pipeline (ctx option "fe_pipeline"): the pyramid of frame N+1 is built on the side stream while frame N's pose refinement / gate / cloud run
+  hipEvent_t ev_early[2] = {}, ev_late[2] = {};      // by frame parity: pyramid done (side stream) / the whole frame done (context's stream)
+  hipEvent_t ev_trk[2] = {};                         // ... / the point of the context's stream right in front of the pose refinement's launch
   unsigned pipe_run = 0;                             // frames issued through the pipelined path since the last frame that was not
   svs_stereo *stereo = nullptr;
   // pinned host staging: two input sets (images of stream 0, poses of all streams), one output set
@@ -176,7 +174,6 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   (void)hipStreamSynchronize(fe->ctx->stream);
   if (fe->copy_stream) (void)hipStreamSynchronize(fe->copy_stream);
   if (fe->side_stream) (void)hipStreamSynchronize(fe->side_stream);
-  if (fe->fast2) svs_fast_destroy(fe->fast2);
   if (fe->fast) svs_fast_destroy(fe->fast);
   for (hipEvent_t e : fe->ev_early) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : fe->ev_late) if (e) (void)hipEventDestroy(e);
@@ -270,10 +267,7 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
   for (int l = 0; l < 3; ++l) fastgrid_for_level(fe->w[l], fe->h[l], l, &grids[l]);
   rc = svs_fast_create(ctx, fe->prm.n_levels, fe->w, fe->h, grids, n_streams, 8192, &fe->fast);
   if (rc) return fail(rc);
-  fe->fast_cur = fe->fast;
   if (ctx->fe_pipeline && n_streams > 1 && n_streams <= 2 * ctx->n_cu && !prm->use_block_matching && !prm->cuda_build) {
-    if ((rc = svs_fast_create(ctx, fe->prm.n_levels, fe->w, fe->h, grids, n_streams, 8192, &fe->fast2))) return fail(rc);
-    if ((rc = svs_fast_share_thresholds(fe->fast2, fe->fast))) return fail(rc);
     for (int k = 0; k < 2; ++k)
       if (hipEventCreateWithFlags(&fe->ev_early[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_late[k], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&fe->ev_trk[k], hipEventDisableTiming) != hipSuccess)
@@ -515,14 +509,13 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
   svs_ctx *ctx = fe->ctx;
   const int B = fe->B, cur = fe->i_cur, prev = fe->i_prev, n = fe->n_launch;
   int rc;
-  // Cross-frame pipeline.  Pyramid + FAST of a frame ("early" part) need nothing of the frames before but free buffers; tracker, matcher, refinement, gate and
-  // cloud ("late" part) need the early part of their own frame and the late part of the frame before.  With the frames in caller-owned device buffers
-  // (complete when the call is made -- the contract of svs_frontend_process_frames) the early part goes to the low-priority side stream and waits only for the
-  // late part of frame N-2 (the last reader of the pyramid slot and of the detector object it writes: three pyramid slots, two detector objects): a caller that
-  // enqueues frame N+1 while frame N is still running gets early(N+1) beside late(N), filling the tails of its tracker and its pose refinement.  Results are
-  // those of the one-stream order (tests/test_gpu_frontend_batch.py).
-  const bool pipe = !first && ext_frames && fe->fast2 && fe->side_stream && ctx->fe_pipeline && ctx->fe_overlap && !fe->timing;
-  svs_fast *const F = pipe && (fe->pipe_run & 1u) ? fe->fast2 : fe->fast;
+  // Cross-frame pipeline.  The pyramid of a frame needs nothing of the frames before but a free slot (three slots: last read by the frame before the previous
+  // one).  With the frames in caller-owned device buffers (complete when the call is made -- the contract of svs_frontend_process_frames) it goes to the
+  // low-priority side stream and is released when the PREVIOUS frame reaches its pose refinement: a caller that enqueues frame N+1 while frame N is still running
+  // gets the 0.2 ms pyramid of N+1 into the tail of N's refinement (one workgroup per stream, <= 15 dependent LM iterations, most streams done early), its gate
+  // and its cloud.  Results are those of the one-stream order (tests/test_gpu_frontend_batch.py).
+  const bool pipe = !first && ext_frames && fe->ev_early[0] && fe->side_stream && ctx->fe_pipeline && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
+  svs_fast *const F = fe->fast;
   const int par = (int)(fe->pipe_run & 1u);
   hipStream_t const chain_stream0 = ctx->stream;
   if (pipe) {
@@ -530,14 +523,11 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
       SVS_HIP(ctx, hipEventRecord(fe->ev_fork, chain_stream0));
       SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_fork, 0));
     } else {
-      if (fe->pipe_run >= 2) SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_late[par], 0));      // late part of frame N-2
-      // ... and not before frame N-1's tracker has been launched: its workgroups (all resident at once, placed by the balanced order) take their slots first,
-      // this frame's early part fills what they leave -- started any earlier it sits in those slots and the tracker's workgroups trickle in behind it
-      SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_trk[1 - par], 0));
+      if (fe->pipe_run >= 2) SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_late[par], 0));      // frame N-2: the last reader of this pyramid slot
+      SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_trk[1 - par], 0));                          // frame N-1 has reached its pose refinement
     }
     ctx->stream = fe->side_stream;                                                            // (a context is used by one thread at a time)
   } else fe->pipe_run = 0;
-  fe->fast_cur = F;
   auto back_to_chain = [&](int rc_) { ctx->stream = chain_stream0; return rc_; };
   for (int l = 1; l < 3; ++l) {                                                               // "preprocess"
     if (l == 1 && fe->ext_left)
@@ -549,12 +539,9 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
     if (rc) return back_to_chain(rc);
   }
   fe->ext_left = nullptr;
-  if (pipe) {                                                                                 // "fast" of this frame, still on the side stream
-    const uint8_t *imgs[3] = {fe->d_pyr[cur][0], fe->d_pyr[cur][1], fe->d_pyr[cur][2]};
-    rc = svs_fast_detect(F, imgs, fe->stride, fe->lvl_elems, B, fe->prm.fast_trials);
-    const hipError_t e = rc ? hipSuccess : hipEventRecord(fe->ev_early[par], fe->side_stream);
+  if (pipe) {
+    const hipError_t e = hipEventRecord(fe->ev_early[par], fe->side_stream);
     ctx->stream = chain_stream0;
-    if (rc) return rc;
     SVS_HIP(ctx, e);
     SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_early[par], 0));
   }
@@ -586,9 +573,8 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
   // alone on the chain's stream so that the stage times add up to the step.)
   // (Only while all of the tracker's workgroups -- one per stream, two per CU -- are resident at once: beyond that the tracker has its own queue of
   // workgroups to fill the tail with, and detector workgroups in between only delay it: 7.01 vs 6.78 ms per step at 1024 streams.)
-  const bool side = !pipe && !first && fe->side_stream && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
+  const bool side = !first && fe->side_stream && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
   if (side) SVS_HIP(ctx, hipEventRecord(fe->ev_fork, ctx->stream));
-  if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));
   if (!first) {                                                                               // "dense tracking"
     if (fe->prm.cuda_build) {
       svs_dense_track_full_args ta{};
@@ -622,7 +608,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
     if (rc) return rc;
     SVS_HIP(ctx, e);
     SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_join, 0));
-  } else if (!pipe && (rc = detect())) return rc;
+  } else if ((rc = detect())) return rc;
   STAGE_MARK(4);
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"
@@ -644,12 +630,14 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
       STAGE_MARK(5);
       svs_pose_opt_params po = fe->prm.pose_opt;
       po.min_obs = fe->prm.min_matches;
+      if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));                     // releases the next frame's pyramid (side stream)
       if ((rc = svs_motion_only(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, B))) return rc;
       STAGE_MARK(6);
       if ((rc = svs_process_matched_points_dev(ctx, fe->d_res, fe->d_pts, n, (size_t)fe->max_points, (size_t)fe->max_points, fe->d_n_new, &fe->cams[0], d_T,
                                                fe->prm.max_reproj_error, fe->d_gated, (size_t)fe->max_points, fe->d_ptstats, B)))
         return rc;
     } else {
+      if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));
       SVS_HIP(ctx, hipMemsetAsync(fe->d_pstats, 0, (sizeof(svs_pose_opt_stats) + sizeof(svs_point_stats)) * (size_t)B, ctx->stream));
       STAGE_MARK(5); STAGE_MARK(6);
     }
@@ -919,7 +907,7 @@ extern "C" int svs_frontend_device_view(svs_frontend *fe, int stream, const uint
     if (d_cloud) d_cloud[l] = fe->d_cloud[l] + fe->cloud_elems[l] * stream;
   }
   if (d_disp) *d_disp = fe->last_disp ? fe->last_disp + fe->last_dbstride * stream : nullptr;
-  if (fast) *fast = fe->fast_cur;
+  if (fast) *fast = fe->fast;
   return SVS_OK;
 }
 

@@ -242,11 +242,11 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
             return outs
         finally:
             ctx.set_option("trk_balance", 1)
-            ctx.set_option("fe_pipeline", 0)
+            ctx.set_option("fe_pipeline", 1)
 
     base, order, split = run(0), run(1, 1), run(2)
-    # the cross-frame pipeline ("fe_pipeline": pyramid + FAST of frame N+1 on the side stream beside the rest of frame N; the three frames above are enqueued
-    # back to back only up to the blocking result reads -- here they are enqueued without a read in between, the bench's pattern)
+    # the cross-frame pipeline ("fe_pipeline": the pyramid of frame N+1 on the side stream beside frame N's pose refinement / gate / cloud; the three frames above
+    # are enqueued back to back only up to the blocking result reads -- here they are enqueued without a read in between, the bench's pattern)
     def run_async(pipeline):
         ctx.set_option("fe_pipeline", pipeline)
         try:
@@ -262,14 +262,14 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
             fe.close()
             return out
         finally:
-            ctx.set_option("fe_pipeline", 0)
+            ctx.set_option("fe_pipeline", 1)
     a0, a1 = run_async(0), run_async(1)
     for (o0, m0, g0), (o1, m1, g1) in zip(a0[:5], a1[:5]):
         assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o1.T_cur_from_actkey)) and o0.dense_passes == o1.dense_passes >= 0
         assert m0.tobytes() == m1.tobytes() and g0.tobytes() == g1.tobytes() and bytes(o0.point_stats) == bytes(o1.point_stats)
     assert np.array_equal(a0[5][0], a1[5][0]) and np.array_equal(a0[5][1], a1[5][1])
     for c0, c1 in zip(a0[6], a1[6]):
-        assert all(np.array_equal(x, y) for x, y in zip(c0, c1))          # corners, cells, thresholds of the last frame: the adaptive state went through both detector objects
+        assert all(np.array_equal(x, y) for x, y in zip(c0, c1))          # corners, cells, thresholds of the last frame
     for k in range(3):
         for (o0, m0, g0), (o1, m1, g1), (o2, m2, g2) in zip(base[k][:-1], order[k][:-1], split[k][:-1]):
             assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o1.T_cur_from_actkey)) and o0.dense_passes == o1.dense_passes >= 0, k
