@@ -768,32 +768,51 @@ namespace {
 //   the resident slots (a function of the multiset of works only: streams with equal history get equal treatment, e.g. replicas of one stream);
 //   grid: the multi-workgroup streams in index order, then the others by decreasing work (ties: index), then -1 (idle workgroups).
 constexpr int BAL_MAX_STREAMS = 4096;
-__global__ __launch_bounds__(1024) void trk_assign_kernel(const svs_dense_lm_record *__restrict__ rec, int rec_cap, const int32_t *__restrict__ n_rec, int B, int slots, int x_max, int grid, float ratio, int *__restrict__ map,
+constexpr int ASSIGN_THREADS = 1024;
+__global__ __launch_bounds__(ASSIGN_THREADS) void trk_assign_kernel(const svs_dense_lm_record *__restrict__ rec, int rec_cap, const int32_t *__restrict__ n_rec, int B, int slots, int x_max, int grid, float ratio, int *__restrict__ map,
                                                           unsigned char *__restrict__ nwg_of) {
-  __shared__ float s_w[BAL_MAX_STREAMS];
+  __shared__ __attribute__((aligned(16))) float s_w[BAL_MAX_STREAMS];
   __shared__ unsigned char s_n[BAL_MAX_STREAMS];
-  __shared__ float s_red[16];
+  __shared__ float s_red[ASSIGN_THREADS / 64];
   __shared__ int s_cnt[2];
   const int tid = threadIdx.x;
-  float sum = 0.f;
-  for (int b = tid; b < B; b += 1024) {      // serial work of the stream's last frame in level-0 sweeps: a sweep of level l counts 4^-l (one LM record per sweep)
-    float w = 0.f;
-    const int n = rec ? min(n_rec[b], rec_cap) : 0;
-    for (int i = 0; i < n; ++i) { const int l = rec[(size_t)b * rec_cap + i].level; w += l == 0 ? 1.f : (l == 1 ? 0.25f : 0.0625f); }
-    s_w[b] = w; sum += w;
+  // serial work of every stream's last frame in level-0 sweeps: a sweep of level l counts 4^-l (one LM record per sweep).  All records of the batch are read
+  // with the whole workgroup, eight 16-byte loads in flight per lane (a lane walking its own stream's 64 records one load at a time took 80 us), and summed
+  // per stream with integer LDS atomics (units of 1/16 sweep: the sum does not depend on the order)
+  int *s_wi = reinterpret_cast<int *>(s_w);
+  for (int b = tid; b < B; b += ASSIGN_THREADS) s_wi[b] = 0;
+  __syncthreads();
+  if (rec) {
+    const int total = B * rec_cap;
+    for (int base = tid; base < total; base += 8 * ASSIGN_THREADS) {
+      int4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = base + u * ASSIGN_THREADS; r[u] = idx < total ? *reinterpret_cast<const int4 *>(rec + idx) : make_int4(3, 0, 0, 0); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * ASSIGN_THREADS;
+        if (idx < total) {
+          const int b = idx / rec_cap, i = idx - b * rec_cap, l = r[u].x;
+          if (i < min(n_rec[b], rec_cap) && l >= 0 && l <= 2) atomicAdd(&s_wi[b], l == 0 ? 16 : (l == 1 ? 4 : 1));
+        }
+      }
+    }
   }
+  __syncthreads();
+  float sum = 0.f;
+  for (int b = tid; b < B; b += ASSIGN_THREADS) { const float w = (float)s_wi[b] * 0.0625f; s_w[b] = w; sum += w; }
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   if ((tid & 63) == 0) s_red[tid >> 6] = sum;
   __syncthreads();
   float mean = 0.f;
-  for (int k = 0; k < 16; ++k) mean += s_red[k];
+  for (int k = 0; k < ASSIGN_THREADS / 64; ++k) mean += s_red[k];
   mean /= (float)B;
   float M = ratio * mean;
   for (int round = 0; round < 24; ++round) {
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
     int extra = 0, multi = 0;
-    for (int b = tid; b < B; b += 1024) {
+    for (int b = tid; b < B; b += ASSIGN_THREADS) {
       int n = 1;
       if (mean > 0.f) { n = (int)ceilf(s_w[b] / M); n = n < 1 ? 1 : (n > 4 ? 4 : n); }
       s_n[b] = (unsigned char)n;
@@ -806,21 +825,31 @@ __global__ __launch_bounds__(1024) void trk_assign_kernel(const svs_dense_lm_rec
     __syncthreads();
     if (fits) break;
     M *= 1.08f;
-    if (round == 23) { for (int b = tid; b < B; b += 1024) s_n[b] = 1; __syncthreads(); if (tid < 2) s_cnt[tid] = 0; __syncthreads(); }
+    if (round == 23) { for (int b = tid; b < B; b += ASSIGN_THREADS) s_n[b] = 1; __syncthreads(); if (tid < 2) s_cnt[tid] = 0; __syncthreads(); }
   }
-  // positions
-  int n_multi_wgs = 0;
-  for (int b = 0; b < B; ++b) n_multi_wgs += s_n[b] > 1 ? s_n[b] : 0;      // (every thread the same few thousand LDS reads)
-  for (int g = tid; g < grid; g += 1024) map[g] = -1;
+  // positions.  Single-workgroup streams: rank by (work descending, index ascending) = the number of keys greater than the own one, keys = work in 1/16 sweeps
+  // << 12 | (4095 - index) packed in LDS and compared four per read (multi-workgroup streams carry key -1: they sit in front of all singles)
+  const int n_multi_wgs = s_cnt[1];
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
+  int *s_key = reinterpret_cast<int *>(s_w);                 // the works are not needed as floats any more
+  const int Bp = (B + 3) & ~3;
+  for (int b = tid; b < Bp; b += ASSIGN_THREADS) {
+    const int key = b < B && s_n[b] == 1 ? ((int)(s_w[b] * 16.f) << 12) | (4095 - b) : -1;      // (read and written by the same lane)
+    s_key[b] = key;
+  }
+  for (int g = tid; g < grid; g += ASSIGN_THREADS) map[g] = -1;
+  __syncthreads();
+  for (int b = tid; b < B; b += ASSIGN_THREADS) {
     const int n = s_n[b];
-    const float w = s_w[b];
     int pos = 0;
     if (n > 1) { for (int k = 0; k < b; ++k) pos += s_n[k] > 1 ? s_n[k] : 0; }
     else {
+      const int mine = s_key[b];
       pos = n_multi_wgs;
-      for (int k = 0; k < B; ++k) pos += (s_n[k] == 1 && (s_w[k] > w || (s_w[k] == w && k < b))) ? 1 : 0;
+      for (int k = 0; k < Bp; k += 4) {
+        const int4 q = *reinterpret_cast<const int4 *>(s_key + k);
+        pos += (q.x > mine) + (q.y > mine) + (q.z > mine) + (q.w > mine);
+      }
     }
     for (int k = 0; k < n; ++k) map[pos + k] = (b << 4) | k;
     nwg_of[b] = (unsigned char)n;
@@ -846,7 +875,7 @@ int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_re
   const int x_max = ctx->trk_balance == 2 ? S.x_max : 0;
   const float ratio = 1.2f;
   SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));
-  hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of);
+  hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(ASSIGN_THREADS), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
