@@ -189,16 +189,24 @@ def test_slamgraph_optimize_hip_branch_and_recorded_graph(gpu_ctx, P, L, n_outer
     trajectory, state update within 1e-6 relative.  (2) SlamGraph::optimize compiled with the SCAVISLAM_HIP_SUPPORT branch in place
     (libsvs_hipbranch_slamgraph.so: tables -> scavislam_hip::SlamGraphBA::optimizeWindow -> GPU -> tables): the poses and points it leaves in the
     reference's tables equal the oracle's result on the recorded graph the same way."""
-    if not (_have("libsvs_hipbranch_slamgraph.so") and _have("libsvs_ref_slamgraph.so")):
-        pytest.skip("oracle/_ref libraries not present (built by oracle/Makefile where /root/reference exists)")
+    have_ref = _have("libsvs_hipbranch_slamgraph.so") and _have("libsvs_ref_slamgraph.so")
+    fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_slamgraph_recorded.npz")
+    if not have_ref and P != 12:
+        pytest.skip("oracle/_ref libraries not present (built by oracle/Makefile where /root/reference exists); the 12-keyframe case runs from tests/golden")
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.backend import SlamGraphOptimizer
     from scavislam_amd.ctypes_types import BaParams, Cam
     ctx, stream = gpu_ctx
     prob = synth.ba_window(P=P, L=L, seed=5, n_outer=n_outer)
-    tables = _graph_tables(prob, n_outer, np.random.default_rng(1))
-    rec = O.ref_slamgraph_optimize(*tables, 2, True, 3.0, 0.0)                    # Backend's own call: OptParams(2, true, 3) (backend.cpp:187)
+    if have_ref:
+        tables = _graph_tables(prob, n_outer, np.random.default_rng(1))
+        rec = O.ref_slamgraph_optimize(*tables, 2, True, 3.0, 0.0)                    # Backend's own call: OptParams(2, true, 3) (backend.cpp:187)
+        if P == 12:                                                                   # the committed fixture IS this recording (tests/golden/make_golden_slamgraph.py)
+            fx = np.load(fixture)
+            assert all(np.array_equal(fx[k], rec[k]) for k in ("vertices", "estimates", "edges", "edge_data"))
+    else:                                                                             # without oracle/_ref: part (1) on the graph the reference recorded when the fixture was made
+        rec = dict(np.load(fixture))
     pose_ids, point_ids, poses0, psi0, edges, cons = _flat_from_recorded_graph(rec)
     assert len(cons) == 2 * len(prob["cons"]) and len(edges) == len(prob["edges"])
     c = prob["cam"]
@@ -225,6 +233,9 @@ def test_slamgraph_optimize_hip_branch_and_recorded_graph(gpu_ctx, P, L, n_outer
         assert (err_l <= 1e-6 * upd_l + 10.0 * a * max(err_pose, 1e-12)).all(), float((err_l - 10.0 * a * err_pose).max() / upd_l)
         assert int((err_l > 1e-6 * upd_l).sum()) <= 8
     landmarks_ok(psi_hip, psi_ref, amp)
+    if not have_ref:
+        print(f"P={P}: recorded graph from the fixture ({len(edges)} observation edges, {len(cons)} pose-pose edges) -> HIP vs oracle: poses {np.abs(poses_hip - poses_ref).max():.1e}")
+        return
     # (2) the reference's optimize() with the HIP branch in place, on the same tables
     hip = O.ref_slamgraph_optimize(*tables, 2, True, 3.0, 0.0, hip_branch=True)
     assert (hip["stats"]["trials"], hip["stats"]["accepted"]) == (st_ref.trials, st_ref.accepted)
