@@ -28,6 +28,7 @@ struct svs_ctx {
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
+  int fe_fuse_tail = 1;       // "fe_fuse_tail": the one-call front end runs the gate and the dense clouds inside the refinement kernel (0: four more launches)
   int match_order = 1;        // "match_order": match_kernel3 takes the points of a stream in image order (counting sort by cell of the predicted position), 0: list order
   int fe_pipeline = 1;        // "fe_pipeline" (read at svs_frontend_create and per call): svs_frontend_process_frames on caller-owned device frames builds the pyramid
                               // of frame N+1 on the side stream while frame N's pose refinement / gate / cloud run (frontend.hip).  Results identical.
@@ -85,6 +86,13 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
 int svs_pyr_down_u8_copy(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int sstride, size_t s_bstride, uint8_t *d_dst, int dstride, size_t d_bstride,
                          uint8_t *d_copy, int cstride, size_t c_bstride, int batch);
 // internal (not exported through the header): svs_process_matched_points with the record count of the new-feature lists per stream, on the device
+// the work a stream's refinement workgroup does after its LM loop when the front end fuses the stages (dense.hip: motion_only_fused_kernel<true>)
+struct svs_mo_tail {
+  const svs_candidate_point *pts; size_t pts_b; const int32_t *n_new; float mre; svs_gated_point *gated; size_t gated_b; svs_point_stats *ptstats;      // processMatchedPoints' gate
+  const float *disp; int ds; size_t disp_b; svs_cam cams[3]; float *cloud[3]; size_t cloud_b[3];                                                     // computeDensePointCloudCpu, 3 levels
+};
+int svs_motion_only_gate_cloud(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam, const svs_pose_opt_params *prm,
+                               double *d_T_io, svs_pose_opt_stats *d_stats, const svs_mo_tail *tail, int batch);
 int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_results, const svs_candidate_point *d_pts, int n, size_t res_bstride,
                                    size_t pts_bstride, const int32_t *d_n_new_records, const svs_cam *cam, const double *d_T, float max_reproj_error,
                                    svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats, int batch);

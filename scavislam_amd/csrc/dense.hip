@@ -672,27 +672,17 @@ __global__ __launch_bounds__(256) void residual_image_cpu_sem_kernel(LevelArgs L
 }
 
 // computeDensePointCloudCpu (dense_tracking.cpp:393-423)
-__global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__restrict__ disp, int ds, size_t disp_b, svs_cam cam,
-                                                                 int level, const double *__restrict__ Tarr,
-                                                                 float *__restrict__ cloud, size_t cloud_b) {
-  const int slot = blockIdx.y;
-  const int cw = cam.w / 4, ch = cam.h / 4;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= cw * ch) return;
-  const int u = i % cw, v = i / cw;
-  double T[12], Ti[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * 12 + k];
+// TQ = [Ti;0 0 0 1] * Q, Ti = inverse of the pose, Q = [1 0 0 -cx; 0 1 0 -cy; 0 0 0 f; 0 0 1/b 0] (stereo_camera.cpp:24-34), evaluated with the same term order
+// as a dense 4x4 product
+__device__ __forceinline__ void cloud_TQ(const double (&T)[12], const svs_cam &cam, double (&TQ)[16]) {
+  double Ti[12];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
 #pragma unroll
   for (int r = 0; r < 3; ++r) Ti[4 * r + 3] = -(Ti[4 * r] * T[3] + Ti[4 * r + 1] * T[7] + Ti[4 * r + 2] * T[11]);
-  // TQ = [Ti;0 0 0 1] * Q, Q = [1 0 0 -cx; 0 1 0 -cy; 0 0 0 f; 0 0 1/b 0] (stereo_camera.cpp:24-34),
-  // evaluated with the same term order as a dense 4x4 product
   const double Q[16] = {1, 0, 0, -cam.cx, 0, 1, 0, -cam.cy, 0, 0, 0, cam.f, 0, 0, 1.0 / cam.b, 0};
-  double TQ[16];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -702,8 +692,12 @@ __global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__
       for (int k = 0; k < 4; ++k) { double tik = r < 3 ? Ti[4 * r + k] : (k == 3 ? 1.0 : 0.0); s += tik * Q[4 * k + c]; }
       TQ[4 * r + c] = s;
     }
+}
+// quarter-grid sample i of one stream's level: disp = the stream's level-0 disparity image, cloud = the stream's cloud of this level
+__device__ __forceinline__ void cloud_sample(const float *__restrict__ disp, int ds, int cw, int level, const double (&TQ)[16], int i, float *__restrict__ cloud) {
+  const int u = i % cw, v = i / cw;
   const double inv_factor = 1.0 / (double)(1 << level);
-  const float d = (float)(disp[slot * disp_b + (size_t)((v * 4) << level) * ds + ((u * 4) << level)] * inv_factor);
+  const float d = (float)(disp[(size_t)((v * 4) << level) * ds + ((u * 4) << level)] * inv_factor);
   float4 o;
   if (d <= 0) o = make_float4(0.f, 0.f, 0.f, -1.f);
   else {
@@ -713,7 +707,20 @@ __global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__
     for (int k = 0; k < 4; ++k) r[k] = TQ[4 * k] * q[0] + TQ[4 * k + 1] * q[1] + TQ[4 * k + 2] * q[2] + TQ[4 * k + 3] * q[3];
     o = make_float4((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]), 1.f);
   }
-  reinterpret_cast<float4 *>(cloud + slot * cloud_b)[i] = o;
+  reinterpret_cast<float4 *>(cloud)[i] = o;
+}
+__global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__restrict__ disp, int ds, size_t disp_b, svs_cam cam,
+                                                                 int level, const double *__restrict__ Tarr,
+                                                                 float *__restrict__ cloud, size_t cloud_b) {
+  const int slot = blockIdx.y;
+  const int cw = cam.w / 4, ch = cam.h / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cw * ch) return;
+  double T[12], TQ[16];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * 12 + k];
+  cloud_TQ(T, cam, TQ);
+  cloud_sample(disp + slot * disp_b, ds, cw, level, TQ, i, cloud + slot * cloud_b);
 }
 
 }  // namespace
@@ -1280,9 +1287,64 @@ __device__ __forceinline__ void mo2_sweep(const double (&T)[12], const MoObs (&o
   if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
 }
 
+// the gate of one stream, run by 256 lanes (tid < 256) of a workgroup: s_cnt [18], s_sum [4] in LDS; the caller has a barrier in front of it
+__device__ __forceinline__ void gate_stream(const svs_match_result *__restrict__ res, const svs_candidate_point *__restrict__ pts, int n, int n_new, const svs_cam &cam,
+                                            const double (&T)[12], float mre, svs_gated_point *__restrict__ out, svs_point_stats *__restrict__ st, int tid, int *s_cnt,
+                                            double *s_sum) {
+  if (tid < 18) s_cnt[tid] = 0;
+  __syncthreads();
+  const int half_w = (int)(cam.w * 0.5), half_h = (int)(cam.h * 0.5);
+  const float third = (float)(1. / 3.);
+  const int third_w = (int)(cam.w * third), third_h = (int)(cam.h * third);
+  const int tt_w = (int)(cam.w * 2 * third), tt_h = (int)(cam.h * 2 * third);
+  double len = 0;
+  for (int i = tid; i < n && tid < 256; i += 256) {
+    svs_gated_point g{};
+    if (res[i].status == 0) {
+      atomicAdd(&s_cnt[17], 1);
+      double d[3];
+      mo_residual<false>(T, res[i], cam, d, nullptr);          // uvu - se3xyz_stereo_.map(T_cur_from_actkey_, point)
+      const int level = pts[i].anchor_level;
+      const int factor = 1 << level;                             // zeroFromPyr_i(1, anchor_level)
+      if (fabs(d[0]) < mre * factor && fabs(d[1]) < mre * factor && fabs(d[2]) < 3. * mre) {
+        const double *uvu = res[i].obs, *q = res[i].xyz_actkey;
+        const int i2 = uvu[0] < half_w ? 0 : 1, j2 = uvu[1] < half_h ? 0 : 1;
+        const int i3 = uvu[0] < third_w ? 0 : (uvu[0] < tt_w ? 1 : 2), j3 = uvu[1] < third_h ? 0 : (uvu[1] < tt_h ? 1 : 2);
+        atomicAdd(&s_cnt[i2 * 2 + j2], 1);
+        atomicAdd(&s_cnt[4 + i3 * 3 + j3], 1);
+        atomicAdd(&s_cnt[13 + level], 1);
+        atomicAdd(&s_cnt[16], 1);
+        const double inv = 1.0 / (double)factor;                 // exact power of two: x * inv == x / factor
+        g.accepted = 1;
+        g.is_new = i < n_new ? 1 : 0;
+        g.uv_pyr[0] = uvu[0] * inv; g.uv_pyr[1] = uvu[1] * inv;
+        g.curkey_uv_pyr[0] = (q[0] / q[2] * cam.f + cam.cx) * inv;
+        g.curkey_uv_pyr[1] = (q[1] / q[2] * cam.f + cam.cy) * inv;
+        const double dx = g.uv_pyr[0] - g.curkey_uv_pyr[0], dy = g.uv_pyr[1] - g.curkey_uv_pyr[1];
+        len += sqrt(dx * dx + dy * dy);
+      }
+    }
+    out[i] = g;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+  if ((tid & 63) == 0 && tid < 256) s_sum[tid >> 6] = len;
+  __syncthreads();
+  if (tid < 4) st->num_points_grid2x2[tid] = s_cnt[tid];
+  else if (tid < 13) st->num_points_grid3x3[tid - 4] = s_cnt[tid];
+  else if (tid < 16) st->num_matched_points[tid - 13] = s_cnt[tid];
+  else if (tid == 16) st->num_track_points = s_cnt[16];
+  else if (tid == 17) st->num_obs = s_cnt[17];
+  else if (tid == 18) { st->pad_[0] = st->pad_[1] = 0; st->sum_track_length = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]); }
+}
+// TAIL: processMatchedPoints' gate and the three dense clouds of a stream run at the end of its refinement workgroup instead of in four launches of their own --
+// the streams that converge early do that work while the slow ones still iterate (the stage lasts as long as its slowest stream: <= 15 dependent iterations),
+// and four launches per frame disappear.  Same device functions as the stand-alone kernels, the gate on the same 256 lanes: identical bits.
+using MoTail = svs_mo_tail;      // common.h
+template <bool TAIL>
 __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
                                                                         svs_pose_opt_params prm, double *__restrict__ T_io,
-                                                                        svs_pose_opt_stats *__restrict__ stats) {
+                                                                        svs_pose_opt_stats *__restrict__ stats, MoTail Q) {
   extern __shared__ int s_idx[];                   // [n]: indices of the status-OK records, in list order
   __shared__ double s_part[MO2_WAVES][32];         // per wave: 28 sums (21 of J^T J, 6 of J^T w f, chi2), max error, max diag
   __shared__ double s_Tn[12], s_Tc[12];        // trial pose / accepted pose (the latter is wave 0's)
@@ -1405,6 +1467,24 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
     st.initial_chi2 = initial_chi2; st.chi2 = chi2; st.max_err = max_err; st.num_obs = num_obs; st.status = status;
     stats[slot] = st;
   }
+  if constexpr (TAIL) {
+    __shared__ int s_gcnt[18];
+    __shared__ double s_gsum[4];
+    __syncthreads();                                 // s_Tc is final
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = s_Tc[i];
+    gate_stream(res, Q.pts + slot * Q.pts_b, n, Q.n_new[slot], cam, T, Q.mre, Q.gated + slot * Q.gated_b, Q.ptstats + slot, tid, s_gcnt, s_gsum);
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+      double TQ[16];
+      cloud_TQ(T, Q.cams[l], TQ);
+      const int cw = Q.cams[l].w / 4, n_px = cw * (Q.cams[l].h / 4);
+      const float *disp = Q.disp + slot * Q.disp_b;
+      float *cloud = Q.cloud[l] + slot * Q.cloud_b[l];
+      for (int i = tid; i < n_px; i += MO2_THREADS) cloud_sample(disp, Q.ds, cw, l, TQ, i, cloud);
+    }
+  }
 }
 
 }  // namespace
@@ -1421,56 +1501,10 @@ __global__ __launch_bounds__(256) void gate_matched_kernel(const svs_match_resul
   __shared__ double s_sum[4];
   const int tid = threadIdx.x, slot = blockIdx.x;
   if (n_new_arr) n_new = n_new_arr[slot];
-  res += slot * res_b; pts += slot * pts_b; out += slot * out_b;
-  if (tid < 18) s_cnt[tid] = 0;
-  __syncthreads();
   double T[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) T[k] = Tarr[12 * slot + k];
-  const int half_w = (int)(cam.w * 0.5), half_h = (int)(cam.h * 0.5);
-  const float third = (float)(1. / 3.);
-  const int third_w = (int)(cam.w * third), third_h = (int)(cam.h * third);
-  const int tt_w = (int)(cam.w * 2 * third), tt_h = (int)(cam.h * 2 * third);
-  double len = 0;
-  for (int i = tid; i < n; i += 256) {
-    svs_gated_point g{};
-    if (res[i].status == 0) {
-      atomicAdd(&s_cnt[17], 1);
-      double d[3];
-      mo_residual<false>(T, res[i], cam, d, nullptr);          // uvu - se3xyz_stereo_.map(T_cur_from_actkey_, point)
-      const int level = pts[i].anchor_level;
-      const int factor = 1 << level;                             // zeroFromPyr_i(1, anchor_level)
-      if (fabs(d[0]) < mre * factor && fabs(d[1]) < mre * factor && fabs(d[2]) < 3. * mre) {
-        const double *uvu = res[i].obs, *q = res[i].xyz_actkey;
-        const int i2 = uvu[0] < half_w ? 0 : 1, j2 = uvu[1] < half_h ? 0 : 1;
-        const int i3 = uvu[0] < third_w ? 0 : (uvu[0] < tt_w ? 1 : 2), j3 = uvu[1] < third_h ? 0 : (uvu[1] < tt_h ? 1 : 2);
-        atomicAdd(&s_cnt[i2 * 2 + j2], 1);
-        atomicAdd(&s_cnt[4 + i3 * 3 + j3], 1);
-        atomicAdd(&s_cnt[13 + level], 1);
-        atomicAdd(&s_cnt[16], 1);
-        const double inv = 1.0 / (double)factor;                 // exact power of two: x * inv == x / factor
-        g.accepted = 1;
-        g.is_new = i < n_new ? 1 : 0;
-        g.uv_pyr[0] = uvu[0] * inv; g.uv_pyr[1] = uvu[1] * inv;
-        g.curkey_uv_pyr[0] = (q[0] / q[2] * cam.f + cam.cx) * inv;
-        g.curkey_uv_pyr[1] = (q[1] / q[2] * cam.f + cam.cy) * inv;
-        const double dx = g.uv_pyr[0] - g.curkey_uv_pyr[0], dy = g.uv_pyr[1] - g.curkey_uv_pyr[1];
-        len += sqrt(dx * dx + dy * dy);
-      }
-    }
-    out[i] = g;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
-  if ((tid & 63) == 0) s_sum[tid >> 6] = len;
-  __syncthreads();
-  svs_point_stats *st = stats + slot;
-  if (tid < 4) st->num_points_grid2x2[tid] = s_cnt[tid];
-  else if (tid < 13) st->num_points_grid3x3[tid - 4] = s_cnt[tid];
-  else if (tid < 16) st->num_matched_points[tid - 13] = s_cnt[tid];
-  else if (tid == 16) st->num_track_points = s_cnt[16];
-  else if (tid == 17) st->num_obs = s_cnt[17];
-  else if (tid == 18) { st->pad_[0] = st->pad_[1] = 0; st->sum_track_length = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]); }
+  gate_stream(res + slot * res_b, pts + slot * pts_b, n, n_new, cam, T, mre, out + slot * out_b, stats + slot, tid, s_cnt, s_sum);
 }
 }  // namespace
 
@@ -1497,14 +1531,28 @@ int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_resul
   return SVS_OK;
 }
 
+// calcFastMotionOnly + processMatchedPoints' gate + the three dense clouds of every stream in ONE launch (frontend.hip; see MoTail).  Returns SVS_ERR_UNSUPPORTED
+// when the fused refinement kernel does not apply (the caller then takes the separate launches).
+int svs_motion_only_gate_cloud(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam, const svs_pose_opt_params *prm,
+                               double *d_T_io, svs_pose_opt_stats *d_stats, const svs_mo_tail *tail, int batch) {
+  SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && tail && batch >= 1 && n >= 1 && d_results);
+  SVS_DEVICE(ctx);
+  if ((size_t)n * sizeof(int) > 48 * 1024 || ctx->mo_legacy) return SVS_ERR_UNSUPPORTED;
+  for (int l = 0; l < 3; ++l) SVS_REQUIRE(ctx, tail->cams[l].w % 4 == 0 && tail->cams[l].h % 4 == 0 && tail->cloud[l]);
+  hipLaunchKernelGGL(motion_only_fused_kernel<true>, dim3(batch), dim3(MO2_THREADS), (size_t)n * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io,
+                     d_stats, *tail);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
 extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam,
                                const svs_pose_opt_params *prm, double *d_T_io, svs_pose_opt_stats *d_stats, int batch) {
   SVS_REQUIRE(ctx, ctx && cam && prm && d_T_io && d_stats && batch >= 1 && n >= 0 && (n == 0 || d_results));
   SVS_DEVICE(ctx);
   // the record-walking kernel stays for candidate lists whose index list does not fit LDS, and as the A/B partner ("mo_legacy")
   if ((size_t)n * sizeof(int) <= 48 * 1024 && !ctx->mo_legacy)
-    hipLaunchKernelGGL(motion_only_fused_kernel, dim3(batch), dim3(MO2_THREADS), (size_t)std::max(n, 1) * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam,
-                       *prm, d_T_io, d_stats);
+    hipLaunchKernelGGL(motion_only_fused_kernel<false>, dim3(batch), dim3(MO2_THREADS), (size_t)std::max(n, 1) * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam,
+                       *prm, d_T_io, d_stats, MoTail{});
   else
     hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
   SVS_LAUNCH_CHECK(ctx);

@@ -610,6 +610,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
     SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_join, 0));
   } else if ((rc = detect())) return rc;
   STAGE_MARK(4);
+  bool fused_tail = false;
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"
       hipLaunchKernelGGL(frontend_pose_kernel, dim3(B), dim3(64), 0, ctx->stream, (const double *)d_T, (const double *)d_Ta, d_Tcw, d_Twa);
@@ -631,11 +632,24 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
       svs_pose_opt_params po = fe->prm.pose_opt;
       po.min_obs = fe->prm.min_matches;
       if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));                     // releases the next frame's pyramid (side stream)
-      if ((rc = svs_motion_only(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, B))) return rc;
-      STAGE_MARK(6);
-      if ((rc = svs_process_matched_points_dev(ctx, fe->d_res, fe->d_pts, n, (size_t)fe->max_points, (size_t)fe->max_points, fe->d_n_new, &fe->cams[0], d_T,
-                                               fe->prm.max_reproj_error, fe->d_gated, (size_t)fe->max_points, fe->d_ptstats, B)))
-        return rc;
+      // refinement, gate and clouds in one launch (not with the stage clocks on: the stages are then launched, and timed, one by one)
+      // (and not for a stream or two: their gate and clouds are faster spread over a hundred workgroups than behind one another in the stream's own)
+      if (!fe->timing && !fe->prm.cuda_build && ctx->fe_fuse_tail && 2 * B >= ctx->n_cu) {
+        svs_mo_tail tl{};
+        tl.pts = fe->d_pts; tl.pts_b = (size_t)fe->max_points; tl.n_new = fe->d_n_new; tl.mre = fe->prm.max_reproj_error; tl.gated = fe->d_gated;
+        tl.gated_b = (size_t)fe->max_points; tl.ptstats = fe->d_ptstats; tl.disp = dv.p; tl.ds = dv.stride; tl.disp_b = dv.bstride;
+        for (int l = 0; l < 3; ++l) { tl.cams[l] = fe->cams[l]; tl.cloud[l] = fe->d_cloud[l]; tl.cloud_b[l] = fe->cloud_elems[l]; }
+        rc = svs_motion_only_gate_cloud(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, &tl, B);
+        if (rc == SVS_OK) fused_tail = true;
+        else if (rc != SVS_ERR_UNSUPPORTED) return rc;
+      }
+      if (!fused_tail) {
+        if ((rc = svs_motion_only(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, B))) return rc;
+        STAGE_MARK(6);
+        if ((rc = svs_process_matched_points_dev(ctx, fe->d_res, fe->d_pts, n, (size_t)fe->max_points, (size_t)fe->max_points, fe->d_n_new, &fe->cams[0], d_T,
+                                                 fe->prm.max_reproj_error, fe->d_gated, (size_t)fe->max_points, fe->d_ptstats, B)))
+          return rc;
+      }
     } else {
       if (pipe) SVS_HIP(ctx, hipEventRecord(fe->ev_trk[par], ctx->stream));
       SVS_HIP(ctx, hipMemsetAsync(fe->d_pstats, 0, (sizeof(svs_pose_opt_stats) + sizeof(svs_point_stats)) * (size_t)B, ctx->stream));
@@ -643,7 +657,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
     }
   } else { STAGE_MARK(5); STAGE_MARK(6); }
   STAGE_MARK(7);
-  for (int l = 0; l < 3; ++l) {                                                               // "dense point cloud" (reference for the next frame)
+  for (int l = 0; l < 3 && !fused_tail; ++l) {                                                // "dense point cloud" (reference for the next frame)
     if (fe->prm.cuda_build)
       rc = svs_pointcloud_full_pose(ctx, d_T, &fe->cams[l], dv.p, dv.stride, dv.bstride, fe->w[l], fe->h[l], fe->w[l], fe->cloud_elems[l] / 4, 1 << l, fe->d_cloud[l], B);
     else
