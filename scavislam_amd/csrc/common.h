@@ -52,6 +52,7 @@ int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);
 // svs_dense_track_cpu_sem with the state of the balanced launch of big batches (dense.hip: per-stream LM work of the last frame -> workgroups per stream);
 // d_bal_state: svs_dense_track_balance_bytes(batch) bytes of device memory, initialised once by svs_dense_track_balance_init; may be NULL
 size_t svs_dense_track_balance_bytes(int batch);
+const int *svs_dense_track_balance_order(svs_ctx *ctx, void *d_bal_state, int batch);
 int svs_dense_track_balance_init(svs_ctx *ctx, void *d_bal_state, int batch);
 int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io, int32_t *d_passes_out, int batch, void *d_bal_state);
 // every entry point that allocates or launches runs on the context's device, whatever the calling thread's current device is
@@ -90,6 +91,7 @@ int svs_pyr_down_u8_copy(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int s
 struct svs_mo_tail {
   const svs_candidate_point *pts; size_t pts_b; const int32_t *n_new; float mre; svs_gated_point *gated; size_t gated_b; svs_point_stats *ptstats;      // processMatchedPoints' gate
   const float *disp; int ds; size_t disp_b; svs_cam cams[3]; float *cloud[3]; size_t cloud_b[3];                                                     // computeDensePointCloudCpu, 3 levels
+  const int *order;                                                                                                                                  // optional: workgroup -> stream << 4 (a permutation)
 };
 int svs_motion_only_gate_cloud(svs_ctx *ctx, const svs_match_result *d_results, int n, size_t res_bstride, const svs_cam *cam, const svs_pose_opt_params *prm,
                                double *d_T_io, svs_pose_opt_stats *d_stats, const svs_mo_tail *tail, int batch);

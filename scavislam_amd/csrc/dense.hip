@@ -910,6 +910,10 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
   return bal_assign(ctx, S, batch, A.rec, A.rec_cap, A.n_rec);
 }
 }  // namespace
+// the grid order the balanced launch will use for the next tracker launch, as (stream << 4) entries -- a permutation of the streams while "trk_balance" is 1
+const int *svs_dense_track_balance_order(svs_ctx *ctx, void *state, int batch) {
+  return state && ctx->trk_balance == 1 ? bal_state(state, batch).map : nullptr;
+}
 size_t svs_dense_track_balance_bytes(int batch) {
   const uintptr_t base = 1 << 16;                                  // (layout arithmetic only: nothing is dereferenced)
   const BalState S = bal_state(reinterpret_cast<void *>(base), batch);
@@ -1350,7 +1354,8 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
   __shared__ double s_Tn[12], s_Tc[12];        // trial pose / accepted pose (the latter is wave 0's)
   __shared__ int s_wcnt[8][MO2_WAVES];
   __shared__ int s_conv;                           // |B|_inf <= 1e-10 at the pose the pending step was taken from
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
+  // TAIL (batches): the streams in the grid order of the tracker (by the last frame's LM work: replicas / neighbours of the caller's order dealt evenly over the XCDs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = TAIL && Q.order ? (Q.order[blockIdx.x] >> 4) : (int)blockIdx.x;
   res += (size_t)slot * res_bstride;
   // ---- compaction of obs_list / point_list (the OK records, in order).  Eight chunks per round: their status words are requested together
   // (one memory round trip instead of eight), one barrier per round

@@ -639,6 +639,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
         tl.pts = fe->d_pts; tl.pts_b = (size_t)fe->max_points; tl.n_new = fe->d_n_new; tl.mre = fe->prm.max_reproj_error; tl.gated = fe->d_gated;
         tl.gated_b = (size_t)fe->max_points; tl.ptstats = fe->d_ptstats; tl.disp = dv.p; tl.ds = dv.stride; tl.disp_b = dv.bstride;
         for (int l = 0; l < 3; ++l) { tl.cams[l] = fe->cams[l]; tl.cloud[l] = fe->d_cloud[l]; tl.cloud_b[l] = fe->cloud_elems[l]; }
+        tl.order = fe->d_trk_work ? svs_dense_track_balance_order(ctx, fe->d_trk_work, B) : nullptr;
         rc = svs_motion_only_gate_cloud(ctx, fe->d_res, n, (size_t)fe->max_points, &fe->cams[0], &po, d_T, fe->d_pstats, &tl, B);
         if (rc == SVS_OK) fused_tail = true;
         else if (rc != SVS_ERR_UNSUPPORTED) return rc;
