@@ -881,7 +881,6 @@ BalState bal_state(void *state, int batch) {
 int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_record *rec, int rec_cap, const int32_t *n_rec) {
   const int x_max = ctx->trk_balance == 2 ? S.x_max : 0;
   const float ratio = 1.2f;
-  SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));
   hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(ASSIGN_THREADS), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
@@ -898,6 +897,7 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
   G.bcast = S.flags + (size_t)batch;
   G.map = S.map; G.nwg_of = S.nwg_of;
   if (ctx->trk_balance == 2) {      // order + split (experimental): sibling workgroups wait for each other -- one such launch on the device at a time (common.h)
+    SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));      // arrival counters, failure flags, hand-over words
     if ((rc = svs_spin_enter(ctx))) return rc;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
