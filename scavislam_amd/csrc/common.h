@@ -28,6 +28,7 @@ struct svs_ctx {
   int trk_regs = 0;           // SVS_TRK_ONE_PER_CU (1) / SVS_TRK_TWO_PER_CU (2): register budget of that tracker (0 = automatic)
   int full_nwg = 0;           // SVS_FULL_NWG: workgroups per stream of the full-resolution tracker (0 = automatic)
   int match_legacy = 0;       // "match_legacy": 0 = four points per wave (match_kernel3), 1 = the round-1/2 kernel (one wave per point, ballots), 2 = one wave per point with the lean scan
+  int mo_spec = 1;            // "mo_spec": calcFastMotionOnly's trials behind a rejection run a chi2-only sweep (the full one follows if the trial is accepted after all); 0: always full
   int fe_fuse_tail = 1;       // "fe_fuse_tail": the one-call front end runs the gate and the dense clouds inside the refinement kernel (0: four more launches)
   int match_order = 1;        // "match_order": match_kernel3 takes the points of a stream in image order (counting sort by cell of the predicted position), 0: list order
   int fe_pipeline = 1;        // "fe_pipeline" (read at svs_frontend_create and per call): svs_frontend_process_frames on caller-owned device frames builds the pyramid

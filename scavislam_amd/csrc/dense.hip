@@ -1193,9 +1193,10 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
 constexpr int MO2_THREADS = 512, MO2_RC = 4, MO2_WAVES = MO2_THREADS / 64;
 struct MoObs { double o[3], q[3]; };
 
-template <bool FIRST>
+template <bool FIRST, bool JAC = true>      // JAC = false: chi2 and max error only (the sweep of a trial that is expected to be rejected)
 __device__ __forceinline__ void mo2_terms(const double (&T)[12], const MoObs &ob, const svs_cam &cam, int robust, double kb, double (&x)[32], double &max_err,
                                           double &max_diag) {
+  static_assert(JAC || !FIRST, "the first sweep needs the Jacobian");
   const double *q = ob.q;
   const double X = T[0] * q[0] + T[1] * q[1] + T[2] * q[2] + T[3];
   const double Y = T[4] * q[0] + T[5] * q[1] + T[6] * q[2] + T[7];
@@ -1229,6 +1230,7 @@ __device__ __forceinline__ void mo2_terms(const double (&T)[12], const MoObs &ob
   }
   x[27] += chi;
   max_err = fmax(max_err, fmax(fabs(f0), fmax(fabs(f1), fabs(f2))));
+  if constexpr (!JAC) return;
   // J^T J, upper triangle row-major (21) -- the structural zeros of frameJac are not multiplied out -- and J^T (w f) (6)
   x[0] += A * A + A * A;          x[1] += 0.0;                     x[2] += A * C + A * E;
   x[3] += A * a3 + A * c3;        x[4] += A * a4 + A * c4;         x[5] += A * a5 + A * a5;
@@ -1291,6 +1293,32 @@ __device__ __forceinline__ void mo2_sweep(const double (&T)[12], const MoObs (&o
   if (lane == 0) { s_part[wave][28] = me; s_part[wave][29] = md; }
 }
 
+// chi2 (and the largest residual) at pose T only -> s_part[wave][27], [28].  Bit-identical to what mo2_sweep leaves there: the same per-lane terms in the same
+// order, and the butterfly below adds them in the association mo2_wave_reduce's halving gives element 27 (own + partner over lane distances 1, 2, 4, 8, 16, 32).
+__device__ __forceinline__ void mo2_sweep_chi2(const double (&T)[12], const MoObs (&ob)[MO2_RC], int n_ok, const int *s_idx, const svs_match_result *__restrict__ res,
+                                               const svs_cam &cam, int robust, double kb, double (*s_part)[32]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double x[32];
+  x[27] = 0.0;
+  double me = 0.0, md = 0.0;
+#pragma unroll
+  for (int k = 0; k < MO2_RC; ++k)
+    if (tid + k * MO2_THREADS < n_ok) mo2_terms<false, false>(T, ob[k], cam, robust, kb, x, me, md);
+  for (int j = tid + MO2_RC * MO2_THREADS; j < n_ok; j += MO2_THREADS) {
+    const svs_match_result &r = res[s_idx[j]];
+    MoObs t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.o[c] = r.obs[c]; t.q[c] = r.xyz_actkey[c]; }
+    mo2_terms<false, false>(T, t, cam, robust, kb, x, me, md);
+  }
+  double v = x[27];
+#pragma unroll
+  for (int o = 1; o <= 32; o <<= 1) v += __shfl_xor(v, o, 64);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) me = fmax(me, __shfl_xor(me, o, 64));
+  if (lane == 0) { s_part[wave][27] = v; s_part[wave][28] = me; }
+}
+
 // the gate of one stream, run by 256 lanes (tid < 256) of a workgroup: s_cnt [18], s_sum [4] in LDS; the caller has a barrier in front of it
 __device__ __forceinline__ void gate_stream(const svs_match_result *__restrict__ res, const svs_candidate_point *__restrict__ pts, int n, int n_new, const svs_cam &cam,
                                             const double (&T)[12], float mre, svs_gated_point *__restrict__ out, svs_point_stats *__restrict__ st, int tid, int *s_cnt,
@@ -1348,7 +1376,7 @@ using MoTail = svs_mo_tail;      // common.h
 template <bool TAIL>
 __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const svs_match_result *__restrict__ res, int n, size_t res_bstride, svs_cam cam,
                                                                         svs_pose_opt_params prm, double *__restrict__ T_io,
-                                                                        svs_pose_opt_stats *__restrict__ stats, MoTail Q) {
+                                                                        svs_pose_opt_stats *__restrict__ stats, MoTail Q, int spec) {
   extern __shared__ int s_idx[];                   // [n]: indices of the status-OK records, in list order
   __shared__ double s_part[MO2_WAVES][32];         // per wave: 28 sums (21 of J^T J, 6 of J^T w f, chi2), max error, max diag
   __shared__ double s_Tn[12], s_Tc[12];        // trial pose / accepted pose (the latter is wave 0's)
@@ -1447,11 +1475,21 @@ __global__ __launch_bounds__(MO2_THREADS) void motion_only_fused_kernel(const sv
       __syncthreads();                               // (B)
       uniform_pose(s_Tn, Tn);
       const int conv = s_conv;
-      mo2_sweep<false>(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
+      // A trial that follows a rejection is almost always rejected too (every refinement ends in five rejections in a row at the noise floor of its chi2: a third
+      // of all sweeps), and a rejected trial's Jacobian sums are never used: such a trial gets a chi2-only sweep ("mo_spec"); should it be accepted after all, the
+      // full sweep at the same pose follows.  Either way the sums the loop goes on with are those of the full sweep: identical bits.
+      const bool lean = spec != 0 && trial >= 1;
+      if (lean) mo2_sweep_chi2(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
+      else mo2_sweep<false>(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
       __syncthreads();                               // (A)
       const double new_chi2 = total(27), new_max = total_max(28);
       if (isnan(new_chi2)) { status = 2; stop = true; break; }      // the reference throws here
       rho = chi2 - new_chi2;
+      if (rho > 0 && lean) {
+        __syncthreads();                             // every lane has read the totals
+        mo2_sweep<false>(Tn, ob, n_ok, s_idx, res, cam, prm.robust_kernel, prm.kernel_param, s_part);
+        __syncthreads();
+      }
       if (rho > 0) {
         if (tid < 12) s_Tc[tid] = s_Tn[tid];         // wave 0 only: it is the one that reads s_Tc (next solve) and rewrites s_Tn (after it)
         chi2 = new_chi2; max_err = new_max;
@@ -1545,7 +1583,7 @@ int svs_motion_only_gate_cloud(svs_ctx *ctx, const svs_match_result *d_results, 
   if ((size_t)n * sizeof(int) > 48 * 1024 || ctx->mo_legacy) return SVS_ERR_UNSUPPORTED;
   for (int l = 0; l < 3; ++l) SVS_REQUIRE(ctx, tail->cams[l].w % 4 == 0 && tail->cams[l].h % 4 == 0 && tail->cloud[l]);
   hipLaunchKernelGGL(motion_only_fused_kernel<true>, dim3(batch), dim3(MO2_THREADS), (size_t)n * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io,
-                     d_stats, *tail);
+                     d_stats, *tail, ctx->mo_spec);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
@@ -1557,7 +1595,7 @@ extern "C" int svs_motion_only(svs_ctx *ctx, const svs_match_result *d_results, 
   // the record-walking kernel stays for candidate lists whose index list does not fit LDS, and as the A/B partner ("mo_legacy")
   if ((size_t)n * sizeof(int) <= 48 * 1024 && !ctx->mo_legacy)
     hipLaunchKernelGGL(motion_only_fused_kernel<false>, dim3(batch), dim3(MO2_THREADS), (size_t)std::max(n, 1) * sizeof(int), ctx->stream, d_results, n, res_bstride, *cam,
-                       *prm, d_T_io, d_stats, MoTail{});
+                       *prm, d_T_io, d_stats, MoTail{}, ctx->mo_spec);
   else
     hipLaunchKernelGGL(motion_only_kernel, dim3(batch), dim3(MO_THREADS), 0, ctx->stream, d_results, n, res_bstride, *cam, *prm, d_T_io, d_stats);
   SVS_LAUNCH_CHECK(ctx);

@@ -108,6 +108,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "fe_pipeline") c->fe_pipeline = value != 0;
   else if (n == "match_order") c->match_order = value != 0;
   else if (n == "fe_fuse_tail") c->fe_fuse_tail = value != 0;
+  else if (n == "mo_spec") c->mo_spec = value != 0;
   else if (n == "trk_seq_chi2") c->trk_seq_chi2 = value != 0;
   else SVS_REQUIRE(c, !"unknown option");
   return SVS_OK;

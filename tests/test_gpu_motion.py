@@ -69,6 +69,36 @@ def test_motion_only_matches_oracle(gpu_ctx, shape, n):
         assert np.abs(Tg[b] - T_true).max() < 5e-3      # robust kernel keeps the 10 % outliers from biasing the pose
 
 
+@pytest.mark.parametrize("n", [400, 1800, 2600])
+def test_motion_only_speculative_trials_leave_the_same_bits(gpu_ctx, n):
+    """Context option "mo_spec": a trial that follows a rejection runs a chi2-only sweep (a third of all sweeps: every refinement ends in five rejections at the
+    noise floor of its chi2); the full sweep follows only if such a trial is accepted after all.  Pose and statistics must be the bits of the always-full loop:
+    24 problems with different motions, starting poses near and far (far starts make mid-run rejections that ARE followed by accepted trials)."""
+    from scavislam_amd import synth
+    rng = np.random.default_rng(23)
+    cam = synth.CAM_DEFAULT
+    ctx = gpu_ctx[0]
+    n_diff_paths = 0
+    for k in range(8):
+        T_true = synth.pose(synth.so3_exp(rng.normal(0, 0.01, 3)), rng.normal(0, 0.04, 3))
+        batch = np.stack([_synthetic_results(rng, cam, T_true, n) for _ in range(3)])
+        far = k % 2 == 1
+        T0 = synth.pose(np.eye(3), np.zeros(3)) if far else synth.pose_mul(synth.pose(synth.so3_exp(rng.normal(0, 0.002, 3)), rng.normal(0, 0.005, 3)), T_true)
+        out = {}
+        for spec in (0, 1):
+            ctx.set_option("mo_spec", spec)
+            try:
+                out[spec] = _run(gpu_ctx, cam, batch, T0)
+            finally:
+                ctx.set_option("mo_spec", 1)
+        T_a, st_a, _ = out[0]
+        T_b, st_b, _ = out[1]
+        assert T_a.tobytes() == T_b.tobytes(), k
+        for a, b in zip(st_a, st_b):
+            assert bytes(a) == bytes(b), k
+            assert a.status == 0 and a.chi2 < a.initial_chi2
+
+
 def test_motion_only_non_robust_and_fixed_mu(gpu_ctx):
     import oracle as O
     from scavislam_amd import synth
