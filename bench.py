@@ -228,6 +228,17 @@ def main():
 
     oc = OneCall(B)
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
+    # the tracker's accept test: by default it takes the reference's decisions -- f64 sums where they can decide `float chi2 - float new_chi2 > 0`,
+    # the reference's sequential float sums (formed bit for bit, in parallel: csrc/seqsum.h) where they cannot.  How many such sums a frame needs, and what the same
+    # steps cost with the f64 sums alone (rounds 1-4: not the reference's decisions near convergence)
+    n_exact0 = ctx.get_stat("trk_exact_sums")
+    timed_steps(oc, 0, 2)
+    exact_sums_per_frame = (ctx.get_stat("trk_exact_sums") - n_exact0) / (2.0 * B)
+    exact_fallbacks = ctx.get_stat("trk_exact_fallbacks")
+    ctx.set_option("trk_lazy_chi2", 0)
+    t_front_f64_accept = max_over_ranks(timed_steps(oc, 2, K))
+    ctx.set_option("trk_lazy_chi2", 1)
+    timed_steps(oc, 2, 0)
     # A/B of the tracker's grid order (context option "trk_balance", dense.hip): 0 = workgroups in stream order, 1 (default) = by the LM work of each stream's
     # last frame, dealt round-robin to the XCDs.  Same K steps; the results of a stream do not depend on the order (one workgroup per stream either way).
     ctx.set_option("trk_balance", 0)
@@ -890,6 +901,10 @@ def main():
                          "dense_passes_per_frame": round(passes, 2),
                          "dense_sweeps_per_level": [round(float(x), 2) for x in sweeps_lvl],
                          "ms_per_step_tracker_grid_in_stream_order": round(t_front_stream_order / K * 1e3, 4),
+                         "accept_test": {"mode": "reference's decisions (f64 sums outside the float sums' rigorous error band, the sequential float sums inside it, formed in parallel bit for bit)",
+                                         "exact_float_sums_per_frame": round(exact_sums_per_frame, 2), "fallbacks_to_the_sequential_chain": exact_fallbacks,
+                                         "ms_per_step_with_f64_sums_alone": round(t_front_f64_accept / K * 1e3, 4),
+                                         "cost_of_parity_frac": round(t_front / t_front_f64_accept - 1.0, 4)},
                          "dense_serial_work_per_stream_in_level0_sweeps": {"min": min(cost_units), "mean": round(float(np.mean(cost_units)), 2), "max": max(cost_units), "correlation_with_the_next_frame": round(work_corr, 3) if work_corr is not None else None, "next_frame": cost_prev, "this_frame": cost_units,
                                                                            "note": "the tracker launch lasts as long as its longest stream"},
                          "dense_passes_per_frame_spread": {"min": int(passes_all.min()), "max": int(passes_all.max()), "distinct_frame_pairs": NPAIR},

@@ -129,6 +129,12 @@ int svs_ctx_sync(svs_ctx *ctx);
    front end enqueues FAST / block matching on a side stream beside the dense tracker; 0: everything on the context's stream).
    A context and every handle made from it are used by ONE thread at a time. */
 int svs_ctx_set_option(svs_ctx *ctx, const char *name, int value);
+/* The accept test of the quarter-grid tracker: DenseTracker::denseTrackingCpu accepts an LM step iff `float chi2 - float new_chi2 > 0` on two sums accumulated
+   sequentially in one float (dense_tracking.cpp:229-262, 341-383).  Default ("trk_lazy_chi2" = 1): the library takes exactly those decisions -- its f64 sums decide
+   wherever their difference is outside the rigorous rounding-error bound of the float sums, and inside the bound the float sums themselves are formed, bit for bit.
+   "trk_seq_chi2" = 1 forms every sum by the literal sequential chain (slow; cross-check), "trk_lazy_chi2" = 0 compares the f64 sums alone (rounds 1-4).
+   Counters (blocking): "trk_exact_sums" float sums formed so far by this context's tracker launches, "trk_exact_fallbacks" how many of them needed the chain. */
+int svs_ctx_get_stat(svs_ctx *ctx, const char *name, long long *out);
 void *svs_ctx_stream(svs_ctx *ctx);
 const char *svs_last_error(svs_ctx *ctx);
 int svs_malloc(svs_ctx *ctx, size_t bytes, void **d_ptr);
@@ -307,6 +313,10 @@ typedef struct {
 } svs_dense_track_args;
 int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double *d_T_io,
                             int32_t *d_passes_out, int batch);
+/* Diagnostic of the accept test above (tests): out[b] = the value of `float chi2 = 0; for (i < n) chi2 += t[b][i];` (dense_tracking.cpp:229-262) for batch rows of
+   non-negative terms.  how = 0: formed as the tracker forms it (parallel, bit-identical by construction: csrc/seqsum.h), 1: the same with the terms read past the caches
+   (latency mode), 2: by the literal sequential chain.  d_fell_back (optional, [batch]): 1 where a self-check of how = 0 / 1 failed and the chain was used. */
+int svs_dense_seq_sum_f32(svs_ctx *ctx, const float *d_terms, int n, size_t bstride, int batch, int how, float *d_out, int32_t *d_fell_back);
 /* DenseTracker::residual_img[level] (dense_tracking.cpp:52-54,279-329): float4 per quarter-grid sample as left by an
    H,b pass at pose d_T[b * T_bstride .. +12): (0,1,0,1) no depth, (1,0,0,1) out of frame, else grey 1 - 50 res^2.
    Either d_cur (f32 level image) or d_cur_u8 (fused source, as in svs_dense_track_args) must be given. */

@@ -89,6 +89,7 @@ _SIGS = {
     "svs_ctx_destroy": [C.c_void_p],
     "svs_ctx_sync": [C.c_void_p],
     "svs_ctx_set_option": [C.c_void_p, C.c_char_p, C.c_int],
+    "svs_ctx_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)],
     "svs_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "svs_free": [C.c_void_p, C.c_void_p],
     "svs_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
@@ -115,6 +116,7 @@ _SIGS = {
     "svs_dense_pass_cpu_sem": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam),
                                C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "svs_dense_seq_sum_f32": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "svs_dense_track_cpu_sem": [C.c_void_p, C.POINTER(DenseTrackArgs), C.c_void_p, C.c_void_p, C.c_int],
     "svs_dense_residual_image_cpu_sem": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
                                          C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
@@ -256,6 +258,12 @@ class Context:
     def set_option(self, name, value):
         """experiment / test switches of the context (see svs_ctx_set_option in the header)"""
         self.call("svs_ctx_set_option", name.encode(), int(value))
+
+    def get_stat(self, name):
+        """counters of the context (svs_ctx_get_stat): "trk_exact_sums", "trk_exact_fallbacks"; blocking"""
+        v = C.c_longlong(0)
+        self.call("svs_ctx_get_stat", name.encode(), C.byref(v))
+        return int(v.value)
 
     def timer_start(self):
         self.check(self.lib.svs_timer_start(self.h))

@@ -35,7 +35,10 @@ struct svs_ctx {
                               // of frame N+1 on the side stream while frame N's pose refinement / gate / cloud run (frontend.hip).  Results identical.
   int fe_overlap = 1;         // "fe_overlap": the one-call front end runs FAST / block matching on a side stream beside the dense tracker (0: one stream)
   int trk_seq_chi2 = 0;       // "trk_seq_chi2": the quarter-grid tracker decides accept / reject on the reference's own sequential f32 chi2 sums (dense.hip; slow: parity runs)
-  void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // its per-pass term buffer
+  int trk_lazy_chi2 = 1;      // "trk_lazy_chi2" (default): the same decisions at full speed -- the f64 sums decide wherever their difference is outside the rigorous error bound of the
+                              // reference's float sums, and inside it the float sums are formed bit for bit without the sequential chain (seqsum.h).  0: f64 sums alone (rounds 1-4)
+  void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
+  void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };

@@ -12,6 +12,7 @@
 //    workgroup per camera stream iterates chi2 / H,b / 6x6 solve / SE3 exp / accept-reject with
 //    LDS broadcasts, so a frame costs one launch instead of ~90 launch+sync+D2H round trips.
 #include "common.h"
+#include "seqsum.h"
 #include <algorithm>
 
 namespace {
@@ -101,7 +102,9 @@ __device__ __forceinline__ double div_rn(double a, double b, double r) {
   return __builtin_fma(__builtin_fma(-q, b, a), r, q);
 }
 
-template <bool JAC, bool U8SRC = false, bool SEQ = false>
+// TM (term mode): what happens to the sample's float term res * res of the reference's `chi2 += res * res` -- 0: nothing; 1: stored at t_out (if not null);
+// 2: stored past the caches (sibling workgroups of the stream will read it: MULTI)
+template <bool JAC, bool U8SRC = false, int TM = 0>
 __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a,
                                                const float *ip_lut = nullptr, float *t_out = nullptr) {
   const float4 c4 = in.c4;
@@ -128,7 +131,9 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   if (res < -0.1) res = -0.1;
   if (!ok) res = 0.f;
   a.v[27] += (double)(res * res);
-  if constexpr (SEQ) { if (t_out) *t_out = res * res; }      // the term of the reference's `float chi2 += res*res` (0 where the reference skips the sample: x + 0 is exact)
+  // the term of the reference's `float chi2 += res*res` (0 where the reference skips the sample: x + 0 is exact)
+  if constexpr (TM == 1) { if (t_out) *t_out = res * res; }
+  if constexpr (TM == 2) { if (t_out) __hip_atomic_store(t_out, res * res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   a.n += ok ? 1 : 0;
   if (JAC) {
     const float gx = ok ? (float)(0.5 * (U8SRC ? g8x : interp32f(L.dx, L.fstride, uvx, uvy))) : 0.f;
@@ -375,9 +380,9 @@ struct TrackArgs {
 constexpr int TRK_THREADS = SVS_TRK_THREADS;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
-template <bool JAC, bool U8SRC, bool SEQ = false>
+template <bool JAC, bool U8SRC, int TM = 0>
 __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut,
-                                           int first, int nwg, float *t_buf = nullptr) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep
+                                           int first, int nwg, float *t_buf = nullptr) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep; t_buf: the pass's terms (TM), or null
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
   Acc a;
   a.zero();
@@ -408,9 +413,9 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
     }
 #pragma unroll
     for (int q = 0; q < TRK_UNROLL; ++q) {
-      if constexpr (SEQ) {
+      if constexpr (TM != 0) {
         const int j = i + q * TRK_THREADS * nwg;
-        sample_cpu_sem<JAC, U8SRC, true>(L, T, cur[q], j < n, a, ip_lut, j < n ? t_buf + j : nullptr);
+        sample_cpu_sem<JAC, U8SRC, TM>(L, T, cur[q], j < n, a, ip_lut, (t_buf && j < n) ? t_buf + j : nullptr);
       } else {
         sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
       }
@@ -423,11 +428,16 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
 // 341-367).  Near convergence chi2 - new_chi2 is below the rounding noise of these 19 200-term sums, so the accept test of the last LM steps of a level is decided by
 // the summation order; with this option the loop takes exactly the reference's decisions (the default compares the f64 sums, narrowed).  Wave 0 walks the terms the
 // pass left in t_buf: 64 loads at a time, then 64 dependent adds on values broadcast from the lanes in order.  Slow (~0.1 ms per sum) -- parity runs only.
+template <bool COH>      // COH: the terms were stored past the caches by sibling workgroups (MULTI) and are read the same way
+__device__ __forceinline__ float seq_term_load(const float *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <bool COH = false>
 __device__ __forceinline__ float seq_sum_f32(const float *t, int n) {
   float acc = 0.f;
   const int lane = threadIdx.x & 63;
   for (int base = 0; base < n; base += 64) {
-    const float v = base + lane < n ? t[base + lane] : 0.f;      // (written by this workgroup before a barrier: workgroup-scope visibility is enough)
+    const float v = base + lane < n ? seq_term_load<COH>(t + base + lane) : 0.f;      // (written by this workgroup before a barrier: workgroup-scope visibility is enough)
 #pragma unroll
     for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
   }
@@ -440,6 +450,120 @@ __device__ __forceinline__ float seq_chi2_f32(const float *t, int n) {
   if (threadIdx.x < 64) { const float v = seq_sum_f32(t, n); if (threadIdx.x == 0) s_seq = v; }
   __syncthreads();
   return s_seq;
+}
+
+// ---- the same bits without the chain (seqsum.h): the default accept test ------------------------------------------------------------------------------
+// The tracker decides on its f64 sums wherever their difference is outside the rigorous error bound of the reference's float sums; inside the bound (most trials of
+// level 0: the bound is 1.1e-3 of chi2 at 19 200 samples, the last LM steps of a level change chi2 by less) it needs the reference's float sums themselves.
+// exact_seq_sum_f32 forms one from the terms a pass left in its buffer, all lanes of the workgroup at work: lane k owns the k-th run of S consecutive terms
+// (f64 sum + count -> workgroup scan -> is my run certainly inside one binade? -> its integer map), a wave-level segmented scan composes the maps of neighbouring
+// safe runs, and wave 0 walks the result: one table look-up per group of safe runs, a readlane chain over the ~10 runs that may straddle a power of two (staged in
+// LDS by their lanes).  ~400 dependent float adds instead of 19 200.  Any failed check -> the plain chain over all terms (never seen; counted by the tests' hook).
+constexpr int SEQ_STAGE_FLOATS = 2048;
+struct SeqShared {
+  SvsSeqMap pref[TRK_THREADS];                       // composition of the safe runs from the start of my group (wave-local) through me
+  unsigned char eb[TRK_THREADS];                     // biased exponent of my run's binade (0: not safe)
+  short slot[TRK_THREADS];                           // my place in `stage` (unsafe runs), -1: none (the walker reads global memory)
+  unsigned long long unsafe[TRK_THREADS / 64];
+  double wave_P[TRK_THREADS / 64];
+  int wave_c[TRK_THREADS / 64], wave_u[TRK_THREADS / 64];
+  float stage[SEQ_STAGE_FLOATS];
+  float result;
+  int fell_back;
+};
+template <bool COH>
+__device__ __noinline__ float exact_seq_sum_f32(const float *t, int n, SeqShared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = max(1, div_up(n, TRK_THREADS));
+  const int j0 = min(n, tid * S), j1 = min(n, j0 + S);
+  const bool empty = j0 >= j1;
+  double ps = 0;
+  int cnt = 0;
+#pragma unroll 4
+  for (int j = j0; j < j1; ++j) { const float v = seq_term_load<COH>(t + j); ps += (double)v; cnt += v != 0.f ? 1 : 0; }
+  double incl = ps;
+  int cincl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(incl, d, 64);
+    const int oc = __shfl_up(cincl, d, 64);
+    if (lane >= d) { incl += o; cincl += oc; }
+  }
+  __syncthreads();                                   // (sh may still be read by the walker of the previous call)
+  if (lane == 63) { sh.wave_P[wave] = incl; sh.wave_c[wave] = cincl; }
+  __syncthreads();
+  double base = 0;
+  int cbase = 0;
+  for (int w = 0; w < wave; ++w) { base += sh.wave_P[w]; cbase += sh.wave_c[w]; }
+  // exclusive prefix as a sum of the earlier runs (never a difference: the bound in svs_seq_safe covers f64 sums of non-negative terms only)
+  const double excl = __shfl_up(incl, 1, 64);
+  const int cexcl = __shfl_up(cincl, 1, 64);
+  const double P_s = base + (lane ? excl : 0.0), P_e = P_s + ps;
+  const int c_s = cbase + (lane ? cexcl : 0), c_e = c_s + cnt;
+  int eb = 0;
+  bool safe = empty || svs_seq_safe(P_s, P_e, c_s, c_e, &eb);
+  sh.eb[tid] = (safe && !empty) ? (unsigned char)eb : (unsigned char)0;
+  __syncthreads();
+  // two neighbouring safe runs share their binade (P_s of one is P_e of the other); nothing below relies on that proof: a change of binade ends the group
+  if (safe && !empty && tid > 0) { const int pe = sh.eb[tid - 1]; if (pe != 0 && pe != eb) safe = false; }
+  const unsigned long long um = __ballot(!safe);
+  if (lane == 0) { sh.unsafe[wave] = um; sh.wave_u[wave] = __popcll(um); }
+  __syncthreads();
+  int ubase = 0;
+  for (int w = 0; w < wave; ++w) ubase += sh.wave_u[w];
+  const int uidx = ubase + __popcll(um & ((1ull << lane) - 1ull));
+  const int slot = (!safe && (uidx + 1) * S <= SEQ_STAGE_FLOATS) ? uidx : -1;
+  sh.slot[tid] = (short)slot;
+  if (!safe) sh.eb[tid] = 0;
+  SvsSeqMap m{0, 0};
+  for (int j = j0; j < j1; ++j) {
+    const float v = seq_term_load<COH>(t + j);
+    if (safe) svs_seq_add_term(m, __builtin_bit_cast(uint32_t, v), eb);
+    else if (slot >= 0) sh.stage[slot * S + (j - j0)] = v;
+  }
+  bool flag = !safe || lane == 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o0 = __shfl_up(m.d0, d, 64), o1 = __shfl_up(m.dd, d, 64), of = __shfl_up((int)flag, d, 64);
+    if (lane >= d && !flag) { m = svs_seq_compose(SvsSeqMap{o0, o1}, m); flag = of != 0; }
+  }
+  sh.pref[tid] = m;
+  __syncthreads();
+  if (wave == 0) {
+    float acc = 0.f;
+    bool ok = true;
+    const int nseg = div_up(n, S);
+    for (int chunk = 0; chunk * 64 < nseg && ok; ++chunk) {
+      const int limit = min(64, nseg - chunk * 64);
+      const unsigned long long mask = sh.unsafe[chunk];
+      int pos = 0;
+      while (pos < limit && ok) {
+        const unsigned long long rest = mask >> pos;
+        const int nxt = rest ? min(limit, pos + (int)__builtin_ctzll(rest)) : limit;
+        if (nxt > pos) {
+          const int last = chunk * 64 + nxt - 1;
+          ok = svs_seq_apply(&acc, sh.pref[last], (int)sh.eb[last]);
+        }
+        if (ok && nxt < limit) {
+          const int seg = chunk * 64 + nxt, sj0 = seg * S, len = min(S, n - sj0), sl = sh.slot[seg];
+          for (int b0 = 0; b0 < len; b0 += 64) {
+            const int k = b0 + lane;
+            // (two loads and a select of VALUES: a select of the two addresses would make a flat pointer out of an LDS and a global one)
+            float v = sh.stage[(sl >= 0 && k < len) ? sl * S + k : 0];
+            if (sl < 0) v = seq_term_load<COH>(t + sj0 + (k < len ? k : 0));
+            if (k >= len) v = 0.f;
+            const int m_ = min(64, len - b0);
+            for (int l = 0; l < m_; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+          }
+        }
+        pos = nxt + 1;
+      }
+    }
+    if (!ok) acc = seq_sum_f32<COH>(t, n);
+    if (lane == 0) { sh.result = acc; if (!ok) sh.fell_back = 1; }
+  }
+  __syncthreads();
+  return sh.result;
 }
 
 // MULTI: a few streams only (latency mode) -- gridDim.x workgroups share every sweep of one stream.  Each leaves its 29 partial
@@ -455,7 +579,8 @@ __device__ __forceinline__ float seq_chi2_f32(const float *t, int n) {
 #error "dense.hip: the relaxed-atomic + s_waitcnt vmcnt(0) hand-off is only valid on gfx950 / gfx942"
 #endif
 struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast;
-                    const int *map; const unsigned char *nwg_of; };      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
+                    const int *map; const unsigned char *nwg_of;
+                    float *terms; size_t terms_b; unsigned *seq_stats; };      // the float terms of the accepted and of the trial pass, [batch][2][terms_b] (null: accept test on the f64 sums alone); [0] exact sums formed, [1] fallbacks to the chain      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
@@ -476,7 +601,10 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
   __shared__ float s_iplut[256];
   __shared__ bool s_failed;
-  if (threadIdx.x == 0) s_failed = false;
+  __shared__ SeqShared s_seq_sh;
+  if (threadIdx.x == 0) { s_failed = false; s_seq_sh.fell_back = 0; }
+  constexpr int TM = MULTI ? 2 : 1;      // the terms of a pass: plain stores, or past the caches when sibling workgroups read them
+  unsigned n_exact = 0;
   const int slot = BAL ? (bal_entry >> 4) : (MULTI ? blockIdx.y : blockIdx.x), wg = BAL ? (bal_entry & 15) : (MULTI ? blockIdx.x : 0);
   const int nwg = !MULTI ? 1 : (BAL ? (int)G.nwg_of[slot] : (int)gridDim.x);
   const int first = wg * TRK_THREADS + threadIdx.x;
@@ -545,13 +673,23 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-    float *const t_buf = SEQ ? reinterpret_cast<float *>(G.part) + (size_t)slot * G.fail_off : nullptr;      // (SEQ is never MULTI: G carries the term buffer and its stream stride)
-    track_pass<true, U8SRC, SEQ>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, t_buf);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    const int n_lvl = (L.cam.w / 4) * (L.cam.h / 4);
+    // SEQ: one term buffer, every sum by the chain ("trk_seq_chi2"; never MULTI: G.part carries the buffer and fail_off its stream stride).
+    // Default: two buffers -- the terms of the accepted pass (tb[cur]) and of the trial -- for the sums the accept test cannot decide in f64 (seqsum.h)
+    float *tb[2];
+    tb[0] = SEQ ? reinterpret_cast<float *>(G.part) + (size_t)slot * G.fail_off : (G.terms ? G.terms + (size_t)slot * 2 * G.terms_b : nullptr);
+    tb[1] = SEQ ? tb[0] : (G.terms ? tb[0] + G.terms_b : nullptr);
+    int cur = 0;
+    track_pass<true, U8SRC, TM>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, tb[cur]);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     if (!solo) all_workgroups();
     if (MULTI && s_failed) { failed = true; break; }
     ++passes;
     float chi2;
-    if constexpr (SEQ) chi2 = seq_chi2_f32(t_buf, (L.cam.w / 4) * (L.cam.h / 4)); else chi2 = (float)s_out[27];
+    double S_old = s_out[27];                  // the f64 sum of the same float terms: exact to 1e-13
+    int nv_old = (int)s_out[NSUM];             // samples that contributed a term (adding the zero of a skipped sample is exact)
+    float seq_old = 0.f;
+    bool seq_old_ok = false;
+    if constexpr (SEQ) chi2 = seq_chi2_f32(tb[0], n_lvl); else chi2 = (float)S_old;
     if (threadIdx.x < 27) s_H[threadIdx.x] = s_out[threadIdx.x];
     if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
     ++n_rec;
@@ -587,16 +725,39 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC, SEQ>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, t_buf);      // new_chi2 (:335-367) + H,b for the next iteration
+      track_pass<true, U8SRC, TM>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, tb[cur ^ 1]);      // new_chi2 (:335-367) + H,b for the next iteration
       if (!solo) all_workgroups();
       if (MULTI && s_failed) { failed = true; break; }
       ++passes;
       float new_chi2;
-      if constexpr (SEQ) new_chi2 = seq_chi2_f32(t_buf, (L.cam.w / 4) * (L.cam.h / 4)); else new_chi2 = (float)s_out[27];
-      const double rho = (double)chi2 - (double)new_chi2;
-      if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, rho > 0 ? 1 : 0, chi2, new_chi2};
+      bool accept;
+      const double S_new = s_out[27];
+      const int nv_new = (int)s_out[NSUM];
+      if constexpr (SEQ) {
+        new_chi2 = seq_chi2_f32(tb[0], n_lvl);
+        accept = (double)chi2 - (double)new_chi2 > 0;
+      } else {
+        // the reference compares two float sums of n terms each: |sum_float - sum_exact| <= ((1 + 2^-24)^(n - 1) - 1) sum_exact.  Outside that band the f64 sums
+        // decide as the float sums would; inside it the float sums are formed, bit for bit (exact_seq_sum_f32)
+        const double gam = 1.0001 * (double)max(nv_old, nv_new) * 5.9604644775390625e-08 + 1e-12;
+        const bool near = tb[0] && !(fabs(S_old - S_new) > gam * (S_old + S_new));
+        if (near) {
+          if (!seq_old_ok) { seq_old = exact_seq_sum_f32<MULTI>(tb[cur], n_lvl, s_seq_sh); seq_old_ok = true; ++n_exact; }
+          const float seq_new = exact_seq_sum_f32<MULTI>(tb[cur ^ 1], n_lvl, s_seq_sh);
+          ++n_exact;
+          chi2 = seq_old; new_chi2 = seq_new;
+          accept = (double)chi2 - (double)new_chi2 > 0;
+          if (accept) seq_old = seq_new;
+        } else {
+          new_chi2 = (float)S_new;
+          accept = S_old > S_new;
+          if (accept) seq_old_ok = false;
+        }
+        if (accept) { S_old = S_new; nv_old = nv_new; cur ^= 1; }
+      }
+      if (A.rec && wg == 0 && threadIdx.x == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, accept ? 1 : 0, chi2, new_chi2};
       ++n_rec;
-      if (rho > 0) {
+      if (accept) {
         chi2 = new_chi2;
         double mx = -1;
         for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(s_x[q]));
@@ -624,6 +785,10 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (threadIdx.x == 0 && passes_out) passes_out[slot] = passes;
   if (threadIdx.x == 0 && A.n_rec) A.n_rec[slot] = n_rec;
   if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
+  if (threadIdx.x == 0 && G.seq_stats && n_exact) {
+    atomicAdd(G.seq_stats, n_exact);
+    if (s_seq_sh.fell_back) atomicAdd(G.seq_stats + 1, 1u);
+  }
 }
 
 // DenseTracker::residual_img[level] (dense_tracking.cpp:279-329): the GUI image an H,b pass at pose T leaves behind.
@@ -885,12 +1050,12 @@ int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_re
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
-int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8src, double *d_T_io, int32_t *d_passes_out, int batch, void *state) {
+int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8src, double *d_T_io, int32_t *d_passes_out, int batch, void *state, const TrackMulti &G0) {
   const BalState S = bal_state(state, batch);
   double *scratch = nullptr;
   int rc = ensure_scratch(ctx, &scratch, (size_t)batch * 2 * 4 * 32);
   if (rc) return rc;
-  TrackMulti G{};
+  TrackMulti G = G0;      // (the term buffers of the accept test)
   G.part = scratch;
   G.bar = reinterpret_cast<unsigned *>(S.flags);
   G.fail_off = batch;
@@ -953,17 +1118,27 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
   int nwg = batch <= 16 ? 8 : (batch <= 32 ? 4 : 1);
   if (ctx->trk_nwg) nwg = ctx->trk_nwg;
   float *t_buf = nullptr; size_t t_b = 0;
-  if (ctx->trk_seq_chi2) {      // the reference's sequential f32 chi2 for the accept test: one workgroup per stream, the terms of a pass in a buffer of the context
-    nwg = 1;
+  // the float terms of the passes (dense_tracking.cpp:229-262: `chi2 += res * res`).  "trk_seq_chi2": one buffer per stream, every sum by the sequential chain, one
+  // workgroup per stream.  Default ("trk_lazy_chi2"): two buffers per stream, read only where the f64 sums cannot decide the accept test (seqsum.h)
+  const bool seq_all = ctx->trk_seq_chi2 != 0, lazy = !seq_all && ctx->trk_lazy_chi2 != 0;
+  float *terms = nullptr;
+  if (seq_all || lazy) {
+    if (seq_all) nwg = 1;
     t_b = (size_t)(a->cam_vec[0].w / 4) * (a->cam_vec[0].h / 4);
-    if (ctx->seq_buf_bytes < (size_t)batch * t_b * sizeof(float)) {
+    const size_t want = (size_t)batch * t_b * sizeof(float) * (lazy ? 2 : 1) + 256;
+    if (ctx->seq_buf_bytes < want) {
       if (ctx->seq_buf) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->seq_buf); ctx->seq_buf = nullptr; ctx->seq_buf_bytes = 0; }
-      SVS_HIP(ctx, hipMalloc(&ctx->seq_buf, (size_t)batch * t_b * sizeof(float)));
-      ctx->seq_buf_bytes = (size_t)batch * t_b * sizeof(float);
+      SVS_HIP(ctx, hipMalloc(&ctx->seq_buf, want));
+      ctx->seq_buf_bytes = want;
     }
-    t_buf = static_cast<float *>(ctx->seq_buf);
+    if (seq_all) t_buf = static_cast<float *>(ctx->seq_buf); else terms = static_cast<float *>(ctx->seq_buf);
+    if (!ctx->seq_stats) {
+      SVS_HIP(ctx, hipMalloc(&ctx->seq_stats, 256));
+      SVS_HIP(ctx, hipMemsetAsync(ctx->seq_stats, 0, 256, ctx->stream));
+    }
   }
-  TrackMulti G{nullptr, nullptr, 0, nullptr};
+  TrackMulti G{};
+  G.terms = terms; G.terms_b = t_b; G.seq_stats = static_cast<unsigned *>(ctx->seq_stats);
   if (t_buf) {
     G.part = reinterpret_cast<double *>(t_buf); G.fail_off = (int)t_b;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2, true>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -983,7 +1158,7 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     if ((rc = svs_spin_leave(ctx))) return rc;
   } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
-    return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state);
+    return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state, G);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -991,6 +1166,30 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   }
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
+
+// diagnostic: the sum of the reference's `float chi2 += t[i]` over batch rows of n terms, formed (how = 0) as the tracker's accept test forms it (exact_seq_sum_f32),
+// (how = 1) the same with the terms read past the caches as the latency-mode tracker reads them, (how = 2) by the literal sequential chain
+namespace {
+template <int HOW>
+__global__ __launch_bounds__(TRK_THREADS) void seq_sum_probe_kernel(const float *__restrict__ t, int n, size_t bstride, float *__restrict__ out, int *__restrict__ fell_back) {
+  __shared__ SeqShared sh;
+  if (threadIdx.x == 0) sh.fell_back = 0;
+  __syncthreads();
+  const float *row = t + (size_t)blockIdx.x * bstride;
+  float v;
+  if constexpr (HOW == 2) v = seq_chi2_f32(row, n); else v = exact_seq_sum_f32<HOW == 1>(row, n, sh);
+  if (threadIdx.x == 0) { out[blockIdx.x] = v; if (fell_back) fell_back[blockIdx.x] = sh.fell_back; }
+}
+}  // namespace
+extern "C" int svs_dense_seq_sum_f32(svs_ctx *ctx, const float *d_terms, int n, size_t bstride, int batch, int how, float *d_out, int32_t *d_fell_back) {
+  SVS_REQUIRE(ctx, ctx && d_terms && d_out && n >= 0 && batch >= 1 && how >= 0 && how <= 2);
+  SVS_DEVICE(ctx);
+  if (how == 0) hipLaunchKernelGGL(seq_sum_probe_kernel<0>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, d_terms, n, bstride, d_out, d_fell_back);
+  else if (how == 1) hipLaunchKernelGGL(seq_sum_probe_kernel<1>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, d_terms, n, bstride, d_out, d_fell_back);
+  else hipLaunchKernelGGL(seq_sum_probe_kernel<2>, dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, d_terms, n, bstride, d_out, d_fell_back);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -67,6 +67,7 @@ extern "C" int svs_ctx_destroy(svs_ctx *c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->match_scratch) (void)hipFree(c->match_scratch);
   if (c->seq_buf) (void)hipFree(c->seq_buf);
+  if (c->seq_stats) (void)hipFree(c->seq_stats);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SVS_OK;
@@ -110,7 +111,21 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "fe_fuse_tail") c->fe_fuse_tail = value != 0;
   else if (n == "mo_spec") c->mo_spec = value != 0;
   else if (n == "trk_seq_chi2") c->trk_seq_chi2 = value != 0;
+  else if (n == "trk_lazy_chi2") c->trk_lazy_chi2 = value != 0;
   else SVS_REQUIRE(c, !"unknown option");
+  return SVS_OK;
+}
+extern "C" int svs_ctx_get_stat(svs_ctx *c, const char *name, long long *out) {
+  SVS_REQUIRE(c, c && name && out);
+  const std::string n(name);
+  SVS_REQUIRE(c, n == "trk_exact_sums" || n == "trk_exact_fallbacks");
+  unsigned v[2] = {0, 0};
+  if (c->seq_stats) {
+    SVS_DEVICE(c);
+    SVS_HIP(c, hipMemcpyAsync(v, c->seq_stats, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    SVS_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  *out = n == "trk_exact_sums" ? v[0] : v[1];
   return SVS_OK;
 }
 extern "C" int svs_api_version(void) { return SVS_API_VERSION; }

@@ -35,23 +35,20 @@ def _cams(camname):
     return level_cams(cam["f"], cam["cx"], cam["cy"], cam["b"], cam["w"], cam["h"])
 
 
-# What the sequence is held to (see seq_common.compare for the hard, per-frame part).  The counted part, measured on MI355X at the time of writing (default / New College
-# camera): 181 / 18x of 200 frames with a pose within 1e-6 ... -- the bars below leave a factor of ~3.
-BARS = dict(frames_with_other_points=30, other_points_frac=2.5e-3, worst_frame_points=16, max_dT=2e-2, median_dT=5e-5)
-
-
-def _check_counted(st, what):
-    assert st["frames_with_other_points"] <= BARS["frames_with_other_points"], (what, st)
-    assert st["other_points"] <= BARS["other_points_frac"] * st["points"], (what, st)
-    assert st["worst_frame_points"] <= BARS["worst_frame_points"], (what, st)
-    assert st["max_dT"] <= BARS["max_dT"] and st["median_dT"] <= BARS["median_dT"], (what, st)
+# What the sequence is held to: seq_common.compare for the hard, per-frame part; _check_strict for the rest -- no accepted point other than the reference's on any frame,
+# pose within 1e-6 on all but four frames (what is left: calcFastMotionOnly's own last steps are decided by the rounding of ITS chi2 sums -- f64, ~1e-14 -- and move
+# the pose by ~1e-8 ... 1e-7; a keyframe dropped at such a frame keeps the offset in its world pose, and every later frame that matches points anchored in other
+# keyframes sees it).  Measured (profiles/r4_gpu_tests.txt, trk_seq_chi2 = 1): 200 / 199 of 200 frames within 1e-6, worst 1.1e-6.
+def _check_strict(st, n_frames, what):
+    assert st["other_points"] == 0 and st["frames_1e6"] >= n_frames - 4 and st["max_dT"] <= 5e-6, (what, st)
 
 
 @pytest.mark.parametrize("camname,seq_chi2", [("default", 1), ("newcollege", 1), ("default", 0), ("newcollege", 0)])
 def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2):
-    """seq_chi2 = 1: the dense tracker's accept test on the reference's own sequential f32 chi2 sums (context option "trk_seq_chi2") -- the LM of every frame ends
-    where the reference's ends: ALL accepted points identical on ALL frames, the poses within 1e-6 (VERDICT round 3's bar; measured: 200 / 199 of 200 frames, worst 1.1e-6).  seq_chi2 = 0: the default (f64 partial
-    sums; what bench.py times): the hard part identical, the rest counted (BARS)."""
+    """seq_chi2 = 0: the DEFAULT accept test of the dense tracker, i.e. the mode bench.py times -- the reference's `float chi2 - float new_chi2 > 0` decided on f64 sums
+    wherever they can decide it and on the reference's own float sums (formed bit for bit, csrc/seqsum.h) wherever they cannot; seq_chi2 = 1: every sum by the literal
+    sequential chain (context option "trk_seq_chi2").  Either way the LM of every frame ends where the reference's ends: ALL accepted points identical on ALL frames, the
+    poses within 1e-6."""
     if not _have("libsvs_hipbranch_seq.so"):
         pytest.skip("oracle/_ref/libsvs_hipbranch_seq.so not present (built by oracle/Makefile where /root/reference exists; travels prebuilt)")
     import oracle as O
@@ -75,12 +72,7 @@ def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2):
         ref_seq.close()
         st = S.compare(hip, ref, "HIP branch in place vs the reference's CPU build")
         how = "reference's CPU build run here"
-    if seq_chi2:
-        # (what is left: calcFastMotionOnly's own last steps are decided by the rounding of ITS chi2 sums -- f64, ~1e-14 -- and move the pose by ~1e-8 ... 1e-7; a
-        # keyframe dropped at such a frame keeps the offset in its world pose, and every later frame that matches points anchored in other keyframes sees it)
-        assert st["other_points"] == 0 and st["frames_1e6"] >= S.N_FRAMES - 4 and st["max_dT"] <= 5e-6, st
-    else:
-        _check_counted(st, camname)
+    _check_strict(st, S.N_FRAMES, (camname, seq_chi2))
     # recomputeFastCorners (stereo_frontend.cpp:91-108) on stored keyframes: FastGrid::detect at the thresholds stored with the frame
     n_rec = 0
     if same_frames:
@@ -117,5 +109,5 @@ def test_sequence_live_full_lists(gpu_ctx):
         assert a is not None and np.array_equal(a, b), (kf, l)
     seq.close()
     st = S.compare(hip, ref, "HIP branch in place vs the reference's CPU build (live)")
-    _check_counted(st, "live")
+    _check_strict(st, n, "live")
     print(f"40 frames live: {st}")
