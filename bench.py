@@ -43,6 +43,41 @@ class _stdout_to_stderr:
         os.close(self.saved)
 
 
+def launch_ranks(args):
+    """one rank per GPU of this node over RCCL: re-exec through torch.distributed.run with the caller's own arguments"""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested, {have} visible on this node")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
+def dry_launch(args, world, rank):
+    """--dry-launch: the ranks of `--gpus N` meet over gloo on the CPU and rank 0 reports them (tests/test_dist_gloo.py keeps the launcher from rotting)"""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "requested": args.gpus, "ranks_seen": sorted(int(t.item()) for t in seen)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +88,14 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="distinct (previous, current) frame pairs with different motions dealt to the streams")
     ap.add_argument("--full-batch", type=int, default=64, help="streams per launch of the full-resolution dense tracker row (BASELINE config 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher check (tests, no GPU): bring up --gpus ranks over gloo, exchange one message, print who answered")
+    ap.add_argument("--quick", action="store_true", help="kernel A/B runs: the front-end headline, its stage times and the accept-test rows only (not the contract's line)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` IS the multi-GPU command: when no launcher has set the rank environment, this process becomes the launcher and starts one rank per
+    # GPU through torch.distributed.run (the driver's explicit `python -m torch.distributed.run ... bench.py --gpus N` finds WORLD_SIZE set and falls through)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -65,7 +107,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:      # never report a 1-GPU line for an N-GPU request
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); use `python bench.py --gpus {args.gpus}` (it launches the ranks itself) "
+                         f"or torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -196,6 +242,9 @@ def main():
                     self.right = [None, None]
                     self.disp = [torch.as_tensor(np.stack([(rend_prev if k == 0 else rend_cur)[p][1] for p in pair]).astype(np.float32)).to(dev) for k in range(2)]
             stream.synchronize()
+            self.ready = torch.cuda.Event()               # svs_frames_dev::ready_event: these frames are complete from here on (they are never rewritten), which is what
+            with torch.cuda.stream(stream):               # lets the library build a frame's pyramid beside the previous frame's pose refinement
+                self.ready.record(stream)
             self.T_act = np.stack([T_prev_list[p].reshape(12) for p in pair])
             self.T_pose = [np.tile(I34, (B, 1)), np.stack([T_AB[p].reshape(12) for p in pair])]      # true pose of frame A / B relative to the active keyframe
             self.fe.processFirstFrames(left=self.left[0], right=self.right[0], disp=self.disp[0])     # frame A: the active keyframe, cloud at the identity
@@ -210,7 +259,7 @@ def main():
         def step(self):
             self.k += 1
             f = self.k & 1                                        # 1: frame B (guess: A's pose), 0: frame A (guess: B's pose)
-            self.fe.processFrames(self.T_pose[1 - f], self.T_act, left=self.left[f], right=self.right[f], disp=self.disp[f])
+            self.fe.processFrames(self.T_pose[1 - f], self.T_act, left=self.left[f], right=self.right[f], disp=self.disp[f], ready_event=self.ready)
 
         def close(self):
             self.fe.close()
@@ -237,6 +286,10 @@ def main():
     exact_fallbacks = ctx.get_stat("trk_exact_fallbacks")
     ctx.set_option("trk_lazy_chi2", 0)
     t_front_f64_accept = max_over_ranks(timed_steps(oc, 2, K))
+    t_front_terms_only = None
+    if args.quick:
+        ctx.set_option("trk_lazy_chi2", 2)
+        t_front_terms_only = max_over_ranks(timed_steps(oc, 2, K))
     ctx.set_option("trk_lazy_chi2", 1)
     timed_steps(oc, 2, 0)
     # A/B of the tracker's grid order (context option "trk_balance", dense.hip): 0 = workgroups in stream order, 1 (default) = by the LM work of each stream's
@@ -274,6 +327,13 @@ def main():
                 stage_acc.setdefault(k_, []).append(v_)
     oc.fe.setTiming(False)
     stage_ms = {k_: float(np.mean(v_)) for k_, v_ in stage_acc.items()}
+    if args.quick:
+        print(json.dumps({"quick": True, "lib": os.path.basename(capi.LIB_PATH), "value": round(fps, 1), "ms_per_step": round(t_front / K * 1e3, 4),
+                          "ms_per_step_f64_accept": round(t_front_f64_accept / K * 1e3, 4), "ms_per_step_terms_stored_f64_accept": round(t_front_terms_only / K * 1e3, 4), "ms_per_step_stream_order": round(t_front_stream_order / K * 1e3, 4),
+                          "ms_one_stream": round(ms_one_stream, 4), "exact_sums_per_frame": round(exact_sums_per_frame, 2), "fallbacks": exact_fallbacks,
+                          "stage_ms": {k_: round(v_, 4) for k_, v_ in stage_ms.items()}, "track_err": track_err, "passes": passes}))
+        oc.close()
+        return
     # dense-tracker bytes from the per-level record of the LM loop (sweeps per level, per stream), SURVEY 8d: 33 B per quarter-grid sample and sweep
     lvl_px = [(cam["w"] >> l) * (cam["h"] >> l) for l in range(3)]
     sweeps_lvl = np.zeros(3)
@@ -748,6 +808,32 @@ def main():
         t_w = max_over_ranks(t_w)
         schur_weak = {"windows_per_s_all_gpus": round(world * K / t_w, 1), "ms_per_optimize_per_gpu": round(t_w / K * 1e3, 4),
                       "scaling": "weak", "note": "one full 50 KF / 20k window per GPU, no collective"}
+    # ... and SURVEY 8e's row proper: ONE window that grows with the node -- 50 keyframes, 20 k landmarks PER GPU, sharded, the reduced system all-reduced by the
+    # library's communicator (RCCL) as in the strong-scaling run above
+    if world > 1 and comm is not None:
+        prob_g = synth.ba_window(P_, L_ * world, seed=2012)
+        sh_g = shard_problem(prob_g, rank, world)
+        optg = SlamGraphOptimizer(ctx, stream)
+        optg.copyDataToG2o(sh_g["poses"], sh_g["psi"], sh_g["edges"], sh_g["cons"], camc, prm, add_pose_terms=sh_g["add_pose_terms"])
+        optg.set_comm(comm)
+        with torch.cuda.stream(stream):
+            for _ in range(W):
+                optg.reset_state(sh_g["poses"], sh_g["psi"])
+                optg.optimize(None)
+            t_g = 0.0
+            for _ in range(K):
+                optg.reset_state(sh_g["poses"], sh_g["psi"])
+                barrier_sync()
+                t0 = time.perf_counter()
+                st_g = optg.optimize(None)
+                barrier_sync()
+                t_g += time.perf_counter() - t0
+        t_g = max_over_ranks(t_g)
+        schur_weak["sharded_window"] = {"keyframes": P_, "landmarks": L_ * world, "landmarks_per_gpu": L_, "edges": len(prob_g["edges"]), "edges_this_rank": len(sh_g["edges"]),
+                                        "ms_per_optimize": round(t_g / K * 1e3, 4), "lm_trials": int(st_g.trials), "chi2_final": st_g.chi2_final,
+                                        "transport": "RCCL ncclAllReduce(ncclDouble) issued by the library"}
+        optg.close()
+        del prob_g, sh_g
     red_ms = t_red / max(n_tr, 1)
     # algorithmic bytes of the Schur (landmark) kernel: edges + psi read once, packed system written once
     nblk = P_ * (P_ + 1) // 2
@@ -872,6 +958,13 @@ def main():
                        "api": "svs_frontend_process_frames (frames by device pointer, poses from the host, results stay on the device)",
                        "stages": list(stage_ms.keys()),
                        "frame": "640x480", "batch_streams_per_gpu": B, "candidate_points": n_points,
+                       # the metric's second half and its comparison, where the driver keeps them (`config` survives its summary; `schur` below is the full record)
+                       "schur_ms_per_optimize": round(ms_opt, 4),
+                       "schur_speedup_vs_cpu_port": round(cpu_schur_ms / ms_opt, 2) if cpu_schur_ms else None,
+                       "schur_ms_per_optimize_one_shot_p2p": (ba_p2p or {}).get("ms_per_optimize"),
+                       "schur_weak_scaling_ms_per_optimize_per_gpu": (schur_weak or {}).get("ms_per_optimize_per_gpu"),
+                       "schur_weak_scaling_sharded_window_ms_per_optimize": ((schur_weak or {}).get("sharded_window") or {}).get("ms_per_optimize"),
+                       "tracker_accept_test": "the reference's decisions (float chi2 sums reproduced where f64 cannot decide); the mode tests/test_gpu_sequence.py holds identical over 200 frames",
                        "parallelism": f"front-end replicas x{world}; Schur landmarks sharded x{world} + all-reduce of reduced system",
                        "collective": (dict(comm.stats(), transport="RCCL ncclAllReduce(ncclDouble) issued by the library on its stream") if comm is not None
                                       else ({"transport": "torch.distributed all_reduce callback (library communicator unavailable)"} if allreduce is not None else None))},

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI version: bumped whenever a struct of this header grows or a signature changes (round 3 grew svs_pose_opt_params / svs_match_args and put a `stream`
    argument into svs_frontend_device_view without one -- INTEGRATION.md section 6).  A caller checks svs_api_version() == SVS_API_VERSION once, zero-initialises
    every parameter struct (or takes it from the *_default() initialisers) and sets only the fields it knows. */
-#define SVS_API_VERSION 4
+#define SVS_API_VERSION 5
 int svs_api_version(void);             /* the SVS_API_VERSION the loaded library was built with */
 
 enum {
@@ -315,7 +315,8 @@ int svs_dense_track_cpu_sem(svs_ctx *ctx, const svs_dense_track_args *a, double 
                             int32_t *d_passes_out, int batch);
 /* Diagnostic of the accept test above (tests): out[b] = the value of `float chi2 = 0; for (i < n) chi2 += t[b][i];` (dense_tracking.cpp:229-262) for batch rows of
    non-negative terms.  how = 0: formed as the tracker forms it (parallel, bit-identical by construction: csrc/seqsum.h), 1: the same with the terms read past the caches
-   (latency mode), 2: by the literal sequential chain.  d_fell_back (optional, [batch]): 1 where a self-check of how = 0 / 1 failed and the chain was used. */
+   (latency mode), 2: by the literal sequential chain.  Rows 16-byte aligned and followed by >= 64 readable floats (bstride >= n + 64, a multiple of 4).
+   d_fell_back (optional, [batch]): 1 where the chain was used after all (n > 20 480, or a failed self-check of how = 0 / 1). */
 int svs_dense_seq_sum_f32(svs_ctx *ctx, const float *d_terms, int n, size_t bstride, int batch, int how, float *d_out, int32_t *d_fell_back);
 /* DenseTracker::residual_img[level] (dense_tracking.cpp:52-54,279-329): float4 per quarter-grid sample as left by an
    H,b pass at pose d_T[b * T_bstride .. +12): (0,1,0,1) no depth, (1,0,0,1) out of frame, else grey 1 - 50 res^2.
@@ -458,6 +459,11 @@ typedef struct {                       /* images of all streams: stream b at + b
   const uint8_t *d_left; int32_t lstride; size_t l_bstride;
   const uint8_t *d_right; int32_t rstride; size_t r_bstride;   /* use_block_matching */
   const float *d_disp; int32_t dstride; size_t d_bstride;      /* otherwise; read in place during the call, not copied */
+  /* WHEN are these frames complete?  NULL: when the work enqueued on the context's stream before this call has run (a kernel or copy of the caller's on that
+     stream may still be writing them at call time: the library reads them behind it, in stream order).  A hipEvent_t: when that event has fired -- the caller
+     recorded it behind whatever produces the frames, on whichever stream.  Only then may the library read the frames on ANOTHER stream than the context's,
+     which is what lets svs_frontend_process_frames build the pyramid of frame N + 1 beside the pose refinement of frame N ("fe_pipeline"). */
+  void *ready_event;
 } svs_frames_dev;
 /* where the NEXT frames may be written in place (then pass in == NULL below): level-0 image, right image (NULL without block matching), disparity.
    Valid until the next first_frames / process_frames call, which moves on to other buffers */
@@ -465,7 +471,9 @@ int svs_frontend_input_view(svs_frontend *fe, uint8_t **d_left, int32_t *lstride
                             float **d_disp, int32_t *dstride, size_t *d_bstride);
 /* processFirstFrame for every stream (blocking) */
 int svs_frontend_first_frames(svs_frontend *fe, const svs_frames_dev *in);
-/* processFrame for every stream: poses [n_streams][12] from the host; ASYNCHRONOUS on the context's stream, results stay on the device */
+/* processFrame for every stream: poses [n_streams][12] from the host; ASYNCHRONOUS on the context's stream, results stay on the device.
+   The frames are read during the call chain, in place: they must stay untouched until the chain has run (svs_ctx_sync, or any blocking call of this front end),
+   and in->ready_event says from when on they are valid (see svs_frames_dev). */
 int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_dev *in, const double *h_T_cur_from_actkey, const double *h_T_actkey_from_w);
 /* blocking downloads after svs_frontend_process_frames: everything of one stream; refined poses [n_streams][12] + tracking flags of all (NULL = not wanted) */
 int svs_frontend_results(svs_frontend *fe, int stream, svs_frame_result *out, svs_match_result *h_matches, svs_gated_point *h_gated);
@@ -504,11 +512,15 @@ int svs_comm_stats(svs_comm *c, int32_t *rank, int32_t *world, uint64_t *n_calls
    sums in rank order (bit-identical on all ranks).  Meant for the small, latency-bound messages of the sharded back end; world <= 16.
      1. every rank: svs_comm_create_p2p (mailbox of 2 x world x capacity_doubles; longer messages travel in pieces) -> its svs_ipc_handle
      2. all-gather the handles out of band (MPI, a TCP store, torch.distributed), then every rank: svs_comm_connect_p2p(c, handles[world])
-   A peer that never arrives makes the result NaN and is counted (svs_comm_transport); destroy collectively (no rank may still be pushing). */
+   A peer that never arrives makes the result NaN and is counted (svs_comm_transport); destroy collectively (no rank may still be pushing).
+   The mailbox is allocated fine-grained (hipExtMallocWithFlags; uncached, then plain memory as fall-backs -- svs_comm_transport says which): peers write it while
+   the owner's kernel polls it.  hipIpcOpenMemHandle cannot open a handle inside the process that exported it: one process driving several GPUs cannot use this
+   transport (one process per GPU, as everywhere in this library). */
 typedef struct { char bytes[64]; } svs_ipc_handle;      /* = hipIpcMemHandle_t */
 int svs_comm_create_p2p(svs_ctx *ctx, int rank, int world, size_t capacity_doubles, svs_comm **out, svs_ipc_handle *h_mine);
 int svs_comm_connect_p2p(svs_comm *c, const svs_ipc_handle *h_all);
-/* *kind = 0: RCCL, 1: one-shot P2P; *timeouts = reduce launches that gave up waiting for a peer (blocking; either may be NULL) */
+/* *kind = 0: RCCL; one-shot P2P with its mailbox in 1: fine-grained, 2: uncached, 3: plain (coarse-grained) device memory; *timeouts = reduce launches that gave
+   up waiting for a peer (blocking; either may be NULL) */
 int svs_comm_transport(svs_comm *c, int32_t *kind, uint32_t *timeouts);
 
 /* ---- BA: replaces SlamGraph::optimize (slam_graph.hpp:457-462, slam_graph.cpp:312-355) -------*/

@@ -109,7 +109,8 @@ class Communicator:
     def transport(self):
         k, t = C.c_int32(), C.c_uint32()
         self.ctx.check(self.ctx.lib.svs_comm_transport(self.h, C.byref(k), C.byref(t)))
-        return dict(kind="p2p" if k.value else "rccl", timeouts=t.value)
+        return dict(kind="p2p" if k.value else "rccl", timeouts=t.value,
+                    mailbox_memory={0: None, 1: "fine-grained", 2: "uncached", 3: "coarse-grained (hipMalloc)"}.get(k.value))
 
     def allreduce(self, d_ptr, count):
         self.ctx.check(self.ctx.lib.svs_comm_allreduce_f64(self.h, d_ptr, count))

@@ -59,7 +59,8 @@ class FramesDev(C.Structure):
     """svs_frames_dev: images of all streams in device memory"""
     _fields_ = [("d_left", C.c_void_p), ("lstride", C.c_int32), ("l_bstride", C.c_size_t),
                 ("d_right", C.c_void_p), ("rstride", C.c_int32), ("r_bstride", C.c_size_t),
-                ("d_disp", C.c_void_p), ("dstride", C.c_int32), ("d_bstride", C.c_size_t)]
+                ("d_disp", C.c_void_p), ("dstride", C.c_int32), ("d_bstride", C.c_size_t),
+                ("ready_event", C.c_void_p)]
 
 
 class PointStatsC(C.Structure):
@@ -200,7 +201,7 @@ _SIGS = {
                             C.POINTER(C.c_int32)],
 }
 EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error", "svs_api_version", "svs_pose_opt_params_default"])
-API_VERSION = 4      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
+API_VERSION = 5      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
 
 
 def load():

@@ -41,6 +41,7 @@ struct P2PState {
   unsigned epoch = 0;
   size_t bytes = 0;
   bool connected = false;
+  int mem_kind = 0;                           // 1: fine-grained device memory, 2: uncached, 3: plain hipMalloc (coarse-grained: last resort)
 };
 
 struct svs_comm {
@@ -212,19 +213,34 @@ extern "C" int svs_comm_create_p2p(svs_ctx *ctx, int rank, int world, size_t cap
   auto fail = [&](int rc) { p2p_free(S); delete c; return rc; };
   S->dev.world = world; S->dev.rank = rank; S->dev.cap = capacity_doubles;
   S->bytes = 2 * (size_t)world * capacity_doubles * sizeof(double) + 2 * (size_t)world * sizeof(unsigned);
-  if (hipMalloc(&S->mine, S->bytes) != hipSuccess || hipMalloc((void **)&S->d_done, 2 * sizeof(unsigned)) != hipSuccess) { ctx->err = "p2p mailbox allocation failed"; return fail(SVS_ERR_HIP); }
+  // The mailbox is written by PEER devices while this device's reduce kernel polls it.  Plain hipMalloc memory is coarse-grained: coherence with other agents is
+  // only guaranteed at kernel boundaries (a per-XCD L2 may keep serving a stale line of a flag or slot).  RCCL allocates its flags fine-grained / uncached for
+  // that reason, and so does this: fine-grained first, uncached second, and plain memory only if neither can be allocated AND exported (reported by
+  // svs_comm_transport, so that a multi-GPU run states what it ran on).  The kernels' sc1 / system-scope accesses stay as they are.
+  __builtin_memset(h_mine, 0, sizeof *h_mine);
+  const unsigned kinds[3] = {hipDeviceMallocFinegrained, hipDeviceMallocUncached, hipDeviceMallocDefault};
+  for (int k = 0; k < 3 && !S->mine; ++k) {
+    void *p = nullptr;
+    if ((k < 2 ? hipExtMallocWithFlags(&p, S->bytes, kinds[k]) : hipMalloc(&p, S->bytes)) != hipSuccess || !p) { (void)hipGetLastError(); continue; }
+    if (world > 1) {
+      hipIpcMemHandle_t h;
+      if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(p);
+        if (k == 2) { ctx->err = "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this driver)"; return fail(SVS_ERR_HIP); }
+        continue;
+      }
+      __builtin_memcpy(h_mine->bytes, &h, sizeof h);
+    }
+    S->mine = p; S->mem_kind = k + 1;
+  }
+  if (!S->mine || hipMalloc((void **)&S->d_done, 2 * sizeof(unsigned)) != hipSuccess) { ctx->err = "p2p mailbox allocation failed"; return fail(SVS_ERR_HIP); }
   S->d_timeouts = S->d_done + 1;
   if (hipMemset(S->mine, 0, S->bytes) != hipSuccess || hipMemset(S->d_done, 0, 2 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     ctx->err = "p2p mailbox initialisation failed"; return fail(SVS_ERR_HIP);
   }
   S->peer[rank] = S->mine;
   S->dev.box[rank] = static_cast<unsigned long long *>(S->mine);
-  __builtin_memset(h_mine, 0, sizeof *h_mine);
-  if (world > 1) {
-    hipIpcMemHandle_t h;
-    if (hipIpcGetMemHandle(&h, S->mine) != hipSuccess) { ctx->err = "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this driver)"; return fail(SVS_ERR_HIP); }
-    __builtin_memcpy(h_mine->bytes, &h, sizeof h);
-  } else S->connected = true;
+  if (world == 1) S->connected = true;
   *out = c;
   return SVS_OK;
 }
@@ -248,10 +264,11 @@ extern "C" int svs_comm_connect_p2p(svs_comm *c, const svs_ipc_handle *h_all) {
   S->connected = true;
   return SVS_OK;
 }
-/* 0: RCCL, 1: one-shot P2P; *timeouts = reduce kernels that gave up waiting for a peer (their output is NaN) -- blocking */
+/* 0: RCCL; one-shot P2P: 1 (mailbox in fine-grained device memory), 2 (uncached), 3 (plain hipMalloc); *timeouts = reduce kernels that gave up waiting for a
+   peer (their output is NaN) -- blocking */
 extern "C" int svs_comm_transport(svs_comm *c, int32_t *kind, uint32_t *timeouts) {
   if (!c) return SVS_ERR_INVALID;
-  if (kind) *kind = c->p2p ? 1 : 0;
+  if (kind) *kind = c->p2p ? c->p2p->mem_kind : 0;
   if (timeouts) {
     *timeouts = 0;
     if (c->p2p) {

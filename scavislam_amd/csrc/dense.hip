@@ -15,6 +15,10 @@
 #include "seqsum.h"
 #include <algorithm>
 
+#ifndef SVS_TRK_LAZY
+#define SVS_TRK_LAZY 1      // (0: build experiments only -- the tracker kernel of rounds 1-4, accept test on the f64 sums alone)
+#endif
+
 namespace {
 
 constexpr int NSUM = 28;   // 21 H + 6 b + chi2 ; n_valid kept separately
@@ -29,12 +33,14 @@ struct Acc {
   }
 };
 
-__device__ __forceinline__ float interp32f(const float *__restrict__ m, int stride, float u, float v) {
+// (P: `const float *`, or the same pointer with its address space spelled out -- see LevelArgsG)
+template <class P>
+__device__ __forceinline__ float interp32f(P m, int stride, float u, float v) {
   float x = floorf(u), y = floorf(v);
   float sx = u - x, sy = v - y;
   float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
   int xi = (int)x, yi = (int)y;
-  const float *p = m + (size_t)yi * stride + xi;
+  const P p = m + (unsigned)(yi * stride + xi);      // (in-frame samples: non-negative, below 2^31)
   float v00 = p[0], v10 = p[1], v01 = p[stride], v11 = p[stride + 1];
   return (wx0 * wy0) * v00 + (wx0 * wy1) * v01 + (wx1 * wy0) * v10 + (wx1 * wy1) * v11;
 }
@@ -47,22 +53,45 @@ struct LevelArgs {
   int c8stride;
 };
 
+// The same with the address space of every pointer spelled out (global memory).  The tracker's sweep is a real call (track_pass_call): its operands come out of
+// LDS, and a pointer that has been through memory is a flat pointer to the compiler -- every access a flat_load that also probes the LDS aperture and counts on
+// both wait counters.
+#define SVS_AS1 __attribute__((address_space(1)))
+typedef float svs_f4 __attribute__((ext_vector_type(4)));
+struct LevelArgsG {
+  const SVS_AS1 float *cloud; const SVS_AS1 uint8_t *prev; const SVS_AS1 float *cur, *dx, *dy;
+  int pstride, fstride;
+  svs_cam cam;
+  const SVS_AS1 uint8_t *cur8;
+  int c8stride;
+};
+__device__ __forceinline__ float4 load_f4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load_f4(const SVS_AS1 float *p) { const svs_f4 v = *(const SVS_AS1 svs_f4 *)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+__device__ __forceinline__ uint32_t load_u32_unaligned(const SVS_AS1 uint8_t *p) {
+  typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+  return *(const SVS_AS1 u32_unaligned *)p;
+}
+
 // Bilinear taps of I, dx, dy straight from the u8 level image.  (float)u8 * float(1/255.) and the
 // centred differences are exactly the values frame_grabber.cpp:315-333 would have materialised, so
 // the results are bit-identical to reading the f32 pyramids -- at 1/8 of the HBM traffic (the f32
 // path touches ~half of three 4 B/px images per pass for a 1/16 sampling grid).  In-frame samples
 // (border 2) never need the REFLECT_101 border rule.
-__device__ __forceinline__ void taps_u8(const uint8_t *__restrict__ img, int stride, float u, float v, float &ic, float &gx, float &gy) {
+template <class P>
+__device__ __forceinline__ void taps_u8(P img, int stride, float u, float v, float &ic, float &gx, float &gy) {
   const float sc = (float)(1. / 255.);
   const float x = floorf(u), y = floorf(v);
   const float sx = u - x, sy = v - y;
   const float wx0 = 1 - sx, wx1 = sx, wy0 = 1 - sy, wy1 = sy;
   const int xi = (int)x, yi = (int)y;
   float f[4][4];
+  // 32-bit offsets from the stream's (scalar) image pointer: the tap loads take the base from scalar registers and the sweep spends no 64-bit multiply-adds
+  // (quarter rate) on addresses.  In-frame samples (border 2) keep yi - 1 >= 1 and xi - 1 >= 1: the offsets are non-negative and far below 2^31
+  const unsigned o0 = (unsigned)((yi - 1) * stride + (xi - 1));
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    uint32_t w4;
-    __builtin_memcpy(&w4, img + (size_t)(yi - 1 + r) * stride + (xi - 1), 4);
+    const uint32_t w4 = load_u32_unaligned(img + (o0 + (unsigned)(r * stride)));
 #pragma unroll
     for (int c = 0; c < 4; ++c) f[r][c] = (float)((w4 >> (8 * c)) & 0xff) * sc;
   }
@@ -78,10 +107,11 @@ __device__ __forceinline__ void taps_u8(const uint8_t *__restrict__ img, int str
 // the pass is bound by gather latency, not by bytes.
 // the two T-independent loads of a sample (stored 3D point, previous-frame intensity): issued one trip ahead by track_pass
 struct SampleIn { float4 c4; uint8_t prev; };
-__device__ __forceinline__ SampleIn sample_load(const LevelArgs &L, int u, int v, int cw, bool in_range) {
+template <class LA>
+__device__ __forceinline__ SampleIn sample_load(const LA &L, int u, int v, int cw, bool in_range) {
   SampleIn s;
-  s.c4 = in_range ? reinterpret_cast<const float4 *>(L.cloud)[(size_t)v * cw + u] : make_float4(0.f, 0.f, 1.f, -1.f);
-  s.prev = L.prev[(size_t)((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4];
+  s.c4 = in_range ? load_f4(L.cloud + 4u * (unsigned)(v * cw + u)) : make_float4(0.f, 0.f, 1.f, -1.f);
+  s.prev = L.prev[(unsigned)(((in_range ? v : 0) * 4) * L.pstride + (in_range ? u : 0) * 4)];
   return s;
 }
 // x / z and y / z share their denominator, and the Jacobian needs 1 / z again: one refined reciprocal serves all three.
@@ -104,9 +134,9 @@ __device__ __forceinline__ double div_rn(double a, double b, double r) {
 
 // TM (term mode): what happens to the sample's float term res * res of the reference's `chi2 += res * res` -- 0: nothing; 1: stored at t_out (if not null);
 // 2: stored past the caches (sibling workgroups of the stream will read it: MULTI)
-template <bool JAC, bool U8SRC = false, int TM = 0>
-__device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double *T, const SampleIn &in, bool in_range, Acc &a,
-                                               const float *ip_lut = nullptr, float *t_out = nullptr) {
+template <bool JAC, bool U8SRC = false, int TM = 0, class LA = LevelArgs>
+__device__ __forceinline__ void sample_cpu_sem(const LA &L, const double *T, const SampleIn &in, bool in_range, Acc &a,
+                                               const float *ip_lut = nullptr, float *term_out = nullptr) {      // term_out (TM != 0): where the caller wants the sample's term
   const float4 c4 = in.c4;
   bool ok = in_range && (c4.w > 0);
   const double xp0 = c4.x, xp1 = c4.y, xp2 = c4.z;
@@ -127,13 +157,14 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
   if (U8SRC) taps_u8(L.cur8, L.c8stride, uvx, uvy, ic, g8x, g8y);
   else ic = interp32f(L.cur, L.fstride, uvx, uvy);
   float res = ip - ic;
-  if (res > 0.1) res = 0.1;
-  if (res < -0.1) res = -0.1;
+  // dense_tracking.cpp:299-300 `if (res > 0.1) res = 0.1; if (res < -0.1) res = -0.1;` on a float res: the comparisons are made in double against the double 0.1,
+  // which lies between 0.1f and the float below it, so `res > 0.1` is `res >= 0.1f` and the assignment stores 0.1f -- min / max with +-0.1f, bit for bit
+  // (res is never NaN: both images are finite), two instructions instead of two conversions and two f64 compares
+  res = fminf(fmaxf(res, -0.1f), 0.1f);
   if (!ok) res = 0.f;
   a.v[27] += (double)(res * res);
   // the term of the reference's `float chi2 += res*res` (0 where the reference skips the sample: x + 0 is exact)
-  if constexpr (TM == 1) { if (t_out) *t_out = res * res; }
-  if constexpr (TM == 2) { if (t_out) __hip_atomic_store(t_out, res * res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if constexpr (TM != 0) *term_out = res * res;
   a.n += ok ? 1 : 0;
   if (JAC) {
     const float gx = ok ? (float)(0.5 * (U8SRC ? g8x : interp32f(L.dx, L.fstride, uvx, uvy))) : 0.f;
@@ -144,13 +175,16 @@ __device__ __forceinline__ void sample_cpu_sem(const LevelArgs &L, const double 
     // need 1e-9 relative agreement with the serial oracle (uv above stays division-exact because the
     // in-frame test and the tap addresses must match bit for bit).
     {
-#pragma clang fp contract(fast)
+      // (every fused multiply-add written out: left to the compiler's contraction the two instantiations of this function -- f32 pyramids / u8 source -- fused
+      // different pairs, and their sums, which the tests hold bit-identical, drifted apart with every unrelated change to the kernel)
       const double f = L.cam.f, iz = ok ? rz : 1.0, iz2 = iz * iz, fx = f * iz, xz = xs * iz2 * f, yz = ys * iz2 * f;
-      const double r0[6] = {-fx, 0, xz, xz * ys, -(f + xz * xs), ys * fx};
-      const double r1[6] = {0, -fx, yz, f + yz * ys, -(yz * xs), -(xs * fx)};
+      const double r0[6] = {-fx, 0, xz, xz * ys, -__builtin_fma(xz, xs, f), ys * fx};
+      const double r1[6] = {0, -fx, yz, __builtin_fma(yz, ys, f), -(yz * xs), -(xs * fx)};
       double J[6];
+      J[0] = gx * r0[0];
+      J[1] = gy * r1[1];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) J[k] = gx * r0[k] + gy * r1[k];
+      for (int k = 2; k < 6; ++k) J[k] = __builtin_fma(gx, r0[k], gy * r1[k]);
       int k = 0;
 #pragma unroll
       for (int c = 0; c < 6; ++c)
@@ -377,13 +411,25 @@ struct TrackArgs {
 #ifndef SVS_TRK_UNROLL
 #define SVS_TRK_UNROLL 1
 #endif
+#ifndef SVS_TRK_MINW_BIG
+#define SVS_TRK_MINW_BIG 4      // waves per SIMD the big-batch instantiations are built for (4: 128 VGPRs, two 512-lane workgroups per CU)
+#endif
+#ifndef SVS_TRK_T_SCALAR
+#define SVS_TRK_T_SCALAR 1
+#endif
 constexpr int TRK_THREADS = SVS_TRK_THREADS;
+constexpr int TRK_MINW_BIG = SVS_TRK_MINW_BIG;
 constexpr int TRK_UNROLL = SVS_TRK_UNROLL;
 
-template <bool JAC, bool U8SRC, int TM = 0>
-__device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut,
+template <bool JAC, bool U8SRC, int TM = 0, class LA = LevelArgs>
+__device__ __forceinline__ void track_pass(const LA &L, const double *T_in, double (*s_part)[NSUM + 1], double *s_out, const float *ip_lut,
                                            int first, int nwg, float *t_buf = nullptr) {      // first = wg * TRK_THREADS + tid; nwg workgroups share the sweep; t_buf: the pass's terms (TM), or null
   const int cw = L.cam.w / 4, ch = L.cam.h / 4, n = cw * ch;
+  // the pose of a sweep is the same in every lane: kept in scalar registers (24 vector registers less over the whole sweep -- the kernel is built for 128)
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+    T[i] = SVS_TRK_T_SCALAR ? __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(T_in[i])), __builtin_amdgcn_readfirstlane(__double2loint(T_in[i]))) : T_in[i];
   Acc a;
   a.zero();
   // TRK_UNROLL samples per lane per trip (independent gather chains in flight); the next trip's stored points and
@@ -401,7 +447,21 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
     const bool in = pv[q] < ch;
     nxt[q] = sample_load(L, in ? pu[q] : 0, in ? pv[q] : 0, cw, in);
   }
+  // TM: the term of a sample is stored one trip LATE, in front of the next trip's loads.  vmcnt counts loads and stores in one queue: a store issued at the end of a
+  // trip would be the youngest entry when the next trip waits for its prefetched operands at the top of the loop -- a full write round trip exposed per trip
+  // (measured: + 18 % on the sweep); issued here it retires under the projection arithmetic and the tap loads that follow.
+  // (the buffer's address space spelled out: the pointer comes out of a two-entry array indexed by the LM loop, and a flat store would tie the loop's LDS waits to memory)
+  typedef __attribute__((address_space(1))) float *gptr_t;
+  static_assert(TM == 0 || TRK_UNROLL == 1, "the deferred term store keeps one term per lane");
+  float pend_t = 0.f;
+  gptr_t pend_p = (gptr_t)t_buf + first - STEP;
+  bool pend = false;
+  auto flush = [&]() {
+    if constexpr (TM == 1) { if (pend) *pend_p = pend_t; }
+    if constexpr (TM == 2) { if (pend) __hip_atomic_store(pend_p, pend_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  };
   for (int i = first; i < n; i += STEP) {
+    if constexpr (TM != 0) { flush(); pend_p += STEP; pend = t_buf != nullptr; }
     SampleIn cur[TRK_UNROLL];
 #pragma unroll
     for (int q = 0; q < TRK_UNROLL; ++q) {
@@ -413,31 +473,64 @@ __device__ __forceinline__ void track_pass(const LevelArgs &L, const double *T, 
     }
 #pragma unroll
     for (int q = 0; q < TRK_UNROLL; ++q) {
-      if constexpr (TM != 0) {
-        const int j = i + q * TRK_THREADS * nwg;
-        sample_cpu_sem<JAC, U8SRC, TM>(L, T, cur[q], j < n, a, ip_lut, (t_buf && j < n) ? t_buf + j : nullptr);
-      } else {
-        sample_cpu_sem<JAC, U8SRC>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
-      }
+      if constexpr (TM != 0) sample_cpu_sem<JAC, U8SRC, TM, LA>(L, T, cur[q], true, a, ip_lut, &pend_t);      // (i < n: in range)
+      else sample_cpu_sem<JAC, U8SRC, 0, LA>(L, T, cur[q], i + q * TRK_THREADS * nwg < n, a, ip_lut);
     }
   }
+  if constexpr (TM != 0) flush();
   block_reduce<TRK_THREADS / 64>(a, s_part, s_out);
+}
+
+// ---- the sweep as a CALL ---------------------------------------------------------------------------------------------------------------------------------
+// The tracker kernel is built for 128 vector registers (two 512-lane workgroups per CU) and the sweep alone fills them: 28 f64 accumulators, the sample in
+// flight, the prefetched next one.  Inlined into the LM loop it shared its register allocation with everything that loop keeps alive -- per-stream pointers, the
+// records, the accept test -- and paid with spills inside the loop over the samples and reloads in every pass.  As a function of its own the sweep gets the whole
+// budget: the caller leaves its operands in LDS (uniform: read back into scalar registers), keeps its own state across the call, and nothing of the LM loop is
+// live inside.  Results in g_s_out as before.
+struct PassArgs { LevelArgs L; double T[12]; float *t_buf; int wg, nwg; };
+__shared__ PassArgs g_pa;
+__shared__ double g_s_part[TRK_THREADS / 64][NSUM + 1];
+__shared__ double g_s_out[NSUM + 1];
+__shared__ float g_iplut[256];
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni_f64(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+template <bool U8SRC, int TM>
+__device__ __noinline__ void track_pass_call() {
+  LevelArgsG L;
+  L.cloud = (const SVS_AS1 float *)uni_ptr(g_pa.L.cloud); L.prev = (const SVS_AS1 uint8_t *)uni_ptr(g_pa.L.prev);
+  L.cur = (const SVS_AS1 float *)uni_ptr(g_pa.L.cur); L.dx = (const SVS_AS1 float *)uni_ptr(g_pa.L.dx); L.dy = (const SVS_AS1 float *)uni_ptr(g_pa.L.dy);
+  L.cur8 = (const SVS_AS1 uint8_t *)uni_ptr(g_pa.L.cur8);
+  L.pstride = uni_i32(g_pa.L.pstride); L.fstride = uni_i32(g_pa.L.fstride); L.c8stride = uni_i32(g_pa.L.c8stride);
+  L.cam.f = uni_f64(g_pa.L.cam.f); L.cam.cx = uni_f64(g_pa.L.cam.cx); L.cam.cy = uni_f64(g_pa.L.cam.cy); L.cam.b = 0;
+  L.cam.w = uni_i32(g_pa.L.cam.w); L.cam.h = uni_i32(g_pa.L.cam.h);
+  const int nwg = uni_i32(g_pa.nwg), first = uni_i32(g_pa.wg) * TRK_THREADS + (int)threadIdx.x;
+  track_pass<true, U8SRC, TM, LevelArgsG>(L, g_pa.T, g_s_part, g_s_out, g_iplut, first, nwg, uni_ptr(g_pa.t_buf));
 }
 
 // "trk_seq_chi2": the reference's `float chi2`, summed the way the reference sums it -- one f32 accumulator, samples in row-major order (dense_tracking.cpp:229-262,
 // 341-367).  Near convergence chi2 - new_chi2 is below the rounding noise of these 19 200-term sums, so the accept test of the last LM steps of a level is decided by
 // the summation order; with this option the loop takes exactly the reference's decisions (the default compares the f64 sums, narrowed).  Wave 0 walks the terms the
 // pass left in t_buf: 64 loads at a time, then 64 dependent adds on values broadcast from the lanes in order.  Slow (~0.1 ms per sum) -- parity runs only.
-template <bool COH>      // COH: the terms were stored past the caches by sibling workgroups (MULTI) and are read the same way
-__device__ __forceinline__ float seq_term_load(const float *p) {
+// a pointer into GLOBAL memory, told to the compiler: exact_seq_sum_f32 is a real call (it must not take part in the register allocation of the tracker's sweeps), and
+// behind a call boundary a plain `const float *` is a flat pointer -- every access a flat_load that also probes the LDS aperture
+typedef const __attribute__((address_space(1))) float *svs_gptr_f32;
+typedef const __attribute__((address_space(1))) svs_f4 *svs_gptr_f4;
+template <bool COH, typename P>      // COH: the terms were stored past the caches by sibling workgroups (MULTI) and are read the same way
+__device__ __forceinline__ float seq_term_load(P p) {
   if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
 }
-template <bool COH = false>
-__device__ __forceinline__ float seq_sum_f32(const float *t, int n) {
+template <bool COH = false, typename P = const float *>
+__device__ __forceinline__ float seq_sum_f32(P t, int n) {
   float acc = 0.f;
   const int lane = threadIdx.x & 63;
   for (int base = 0; base < n; base += 64) {
-    const float v = base + lane < n ? seq_term_load<COH>(t + base + lane) : 0.f;      // (written by this workgroup before a barrier: workgroup-scope visibility is enough)
+    const float v = base + lane < n ? seq_term_load<COH, P>(t + base + lane) : 0.f;      // (written by this workgroup before a barrier: workgroup-scope visibility is enough)
 #pragma unroll
     for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
   }
@@ -459,7 +552,9 @@ __device__ __forceinline__ float seq_chi2_f32(const float *t, int n) {
 // (f64 sum + count -> workgroup scan -> is my run certainly inside one binade? -> its integer map), a wave-level segmented scan composes the maps of neighbouring
 // safe runs, and wave 0 walks the result: one table look-up per group of safe runs, a readlane chain over the ~10 runs that may straddle a power of two (staged in
 // LDS by their lanes).  ~400 dependent float adds instead of 19 200.  Any failed check -> the plain chain over all terms (never seen; counted by the tests' hook).
-constexpr int SEQ_STAGE_FLOATS = 2048;
+constexpr int SEQ_Q = TRK_THREADS >= 512 ? 10 : 13;  // a lane's run of terms lives in SEQ_Q float4 registers: runs of up to 40 terms, i.e. up to 20 480 terms per sum (a 640 x 512 image)
+constexpr int SEQ_RUN_MAX = 4 * SEQ_Q;
+constexpr int SEQ_STAGE_FLOATS = 48 * SEQ_RUN_MAX;   // the runs the walker adds the slow way (typically ~10)
 struct SeqShared {
   SvsSeqMap pref[TRK_THREADS];                       // composition of the safe runs from the start of my group (wave-local) through me
   unsigned char eb[TRK_THREADS];                     // biased exponent of my run's binade (0: not safe)
@@ -471,16 +566,69 @@ struct SeqShared {
   float result;
   int fell_back;
 };
+// the terms [j0, j0 + 4 nq) of a pass as nq float4 (16-byte aligned: the buffers are, and runs are multiples of four terms long); reads up to SEQ_RUN_MAX terms
+// past the last one the caller will use (the buffers are padded by that much)
 template <bool COH>
-__device__ __noinline__ float exact_seq_sum_f32(const float *t, int n, SeqShared &sh) {
+__device__ __forceinline__ void seq_load_run(svs_gptr_f32 p, int nq, svs_f4 (&v)[SEQ_Q]) {
+  if constexpr (COH) {
+    // past the caches, as the sibling workgroups stored them (sc1 = agent scope on gfx950, what an agent-scope atomic load compiles to); all ten requests in
+    // flight before the one wait -- ten atomic dword loads in a row would be forty round trips
+    static_assert(SEQ_Q == 10 || SEQ_Q == 13, "the blocks below issue ten (+ three) loads");
+    asm volatile("global_load_dwordx4 %0, %10, off sc1\n\t"
+                 "global_load_dwordx4 %1, %10, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %10, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %10, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %5, %10, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %10, off offset:96 sc1\n\t"
+                 "global_load_dwordx4 %7, %10, off offset:112 sc1\n\t"
+                 "global_load_dwordx4 %8, %10, off offset:128 sc1\n\t"
+                 "global_load_dwordx4 %9, %10, off offset:144 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9])
+                 : "v"(p)
+                 : "memory");
+    if constexpr (SEQ_Q == 13)
+      asm volatile("global_load_dwordx4 %0, %3, off offset:160 sc1\n\t"
+                   "global_load_dwordx4 %1, %3, off offset:176 sc1\n\t"
+                   "global_load_dwordx4 %2, %3, off offset:192 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(v[SEQ_Q - 3]), "=&v"(v[SEQ_Q - 2]), "=&v"(v[SEQ_Q - 1])
+                   : "v"(p)
+                   : "memory");
+  } else {
+#pragma unroll
+    for (int q = 0; q < SEQ_Q; ++q) v[q] = q < nq ? *reinterpret_cast<svs_gptr_f4>(p + 4 * q) : svs_f4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__shared__ SeqShared g_seq_sh;      // file scope: the routine below is a real call, and a reference handed through a call would be a flat pointer too
+template <bool COH>
+__device__ __noinline__ float exact_seq_sum_f32(const float *t_flat, int n) {
+  SeqShared &sh = g_seq_sh;
+  svs_gptr_f32 t = (svs_gptr_f32)t_flat;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = max(1, div_up(n, TRK_THREADS));
+  const int S = max(4, (div_up(n, TRK_THREADS) + 3) & ~3);      // terms per lane: a multiple of four
+  if (S > SEQ_RUN_MAX) {                                         // images beyond 640 x 512: the chain (never with the reference's cameras)
+    __syncthreads();
+    if (wave == 0) { const float v = seq_sum_f32<COH, svs_gptr_f32>(t, n); if (lane == 0) { sh.result = v; sh.fell_back = 1; } }
+    __syncthreads();
+    return sh.result;
+  }
+  const int nq = S / 4;
   const int j0 = min(n, tid * S), j1 = min(n, j0 + S);
   const bool empty = j0 >= j1;
+  svs_f4 v[SEQ_Q];
+  seq_load_run<COH>(t + (empty ? 0 : j0), nq, v);
   double ps = 0;
   int cnt = 0;
-#pragma unroll 4
-  for (int j = j0; j < j1; ++j) { const float v = seq_term_load<COH>(t + j); ps += (double)v; cnt += v != 0.f ? 1 : 0; }
+#pragma unroll
+  for (int q = 0; q < SEQ_Q; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!(q < nq && j0 + 4 * q + c < j1)) v[q][c] = 0.f;      // past my run / past the last term: zeros add nothing anywhere below
+      ps += (double)v[q][c];
+      cnt += v[q][c] != 0.f ? 1 : 0;
+    }
   double incl = ps;
   int cincl = cnt;
 #pragma unroll
@@ -516,10 +664,15 @@ __device__ __noinline__ float exact_seq_sum_f32(const float *t, int n, SeqShared
   sh.slot[tid] = (short)slot;
   if (!safe) sh.eb[tid] = 0;
   SvsSeqMap m{0, 0};
-  for (int j = j0; j < j1; ++j) {
-    const float v = seq_term_load<COH>(t + j);
-    if (safe) svs_seq_add_term(m, __builtin_bit_cast(uint32_t, v), eb);
-    else if (slot >= 0) sh.stage[slot * S + (j - j0)] = v;
+  if (safe) {
+#pragma unroll
+    for (int q = 0; q < SEQ_Q; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) svs_seq_add_term_fast(m, v[q][c], eb);      // (zeros past the run add nothing)
+  } else if (slot >= 0) {
+#pragma unroll
+    for (int q = 0; q < SEQ_Q; ++q)
+      if (q < nq) *reinterpret_cast<svs_f4 *>(&sh.stage[slot * S + 4 * q]) = v[q];
   }
   bool flag = !safe || lane == 0;
 #pragma unroll
@@ -536,30 +689,30 @@ __device__ __noinline__ float exact_seq_sum_f32(const float *t, int n, SeqShared
     for (int chunk = 0; chunk * 64 < nseg && ok; ++chunk) {
       const int limit = min(64, nseg - chunk * 64);
       const unsigned long long mask = sh.unsafe[chunk];
+      // this chunk's 64 runs, one per lane, in registers: the walk below is a dependent chain, and a readlane is a tenth of an LDS round trip
+      const SvsSeqMap my = sh.pref[chunk * 64 + lane];
+      const int my_eb = sh.eb[chunk * 64 + lane], my_sl = sh.slot[chunk * 64 + lane];
       int pos = 0;
       while (pos < limit && ok) {
         const unsigned long long rest = mask >> pos;
         const int nxt = rest ? min(limit, pos + (int)__builtin_ctzll(rest)) : limit;
         if (nxt > pos) {
-          const int last = chunk * 64 + nxt - 1;
-          ok = svs_seq_apply(&acc, sh.pref[last], (int)sh.eb[last]);
+          const SvsSeqMap g{__builtin_amdgcn_readlane(my.d0, nxt - 1), __builtin_amdgcn_readlane(my.dd, nxt - 1)};
+          ok = svs_seq_apply(&acc, g, __builtin_amdgcn_readlane(my_eb, nxt - 1));
         }
         if (ok && nxt < limit) {
-          const int seg = chunk * 64 + nxt, sj0 = seg * S, len = min(S, n - sj0), sl = sh.slot[seg];
-          for (int b0 = 0; b0 < len; b0 += 64) {
-            const int k = b0 + lane;
-            // (two loads and a select of VALUES: a select of the two addresses would make a flat pointer out of an LDS and a global one)
-            float v = sh.stage[(sl >= 0 && k < len) ? sl * S + k : 0];
-            if (sl < 0) v = seq_term_load<COH>(t + sj0 + (k < len ? k : 0));
-            if (k >= len) v = 0.f;
-            const int m_ = min(64, len - b0);
-            for (int l = 0; l < m_; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-          }
+          const int seg = chunk * 64 + nxt, sj0 = seg * S, len = min(S, n - sj0), sl = __builtin_amdgcn_readlane(my_sl, nxt);      // len <= SEQ_RUN_MAX <= 64: one lane per term
+          // (two loads and a select of VALUES: a select of the two addresses would make a flat pointer out of an LDS and a global one)
+          float x = sh.stage[(sl >= 0 && lane < len) ? sl * S + lane : 0];
+          if (sl < 0) x = seq_term_load<COH, svs_gptr_f32>(t + sj0 + (lane < len ? lane : 0));
+          if (lane >= len) x = 0.f;
+#pragma unroll
+          for (int l = 0; l < SEQ_RUN_MAX; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));      // (+ 0 past the run: exact)
         }
         pos = nxt + 1;
       }
     }
-    if (!ok) acc = seq_sum_f32<COH>(t, n);
+    if (!ok) acc = seq_sum_f32<COH, svs_gptr_f32>(t, n);
     if (lane == 0) { sh.result = acc; if (!ok) sh.fell_back = 1; }
   }
   __syncthreads();
@@ -580,7 +733,7 @@ __device__ __noinline__ float exact_seq_sum_f32(const float *t, int n, SeqShared
 #endif
 struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast;
                     const int *map; const unsigned char *nwg_of;
-                    float *terms; size_t terms_b; unsigned *seq_stats; };      // the float terms of the accepted and of the trial pass, [batch][2][terms_b] (null: accept test on the f64 sums alone); [0] exact sums formed, [1] fallbacks to the chain      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
+                    float *terms; size_t terms_b; unsigned *seq_stats; int terms_only; };      // the float terms of the accepted and of the trial pass, [batch][2][terms_b] (null: accept test on the f64 sums alone); [0] exact sums formed, [1] fallbacks to the chain      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
@@ -596,14 +749,15 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     bal_entry = G.map[blockIdx.x];
     if (bal_entry < 0 || (!MULTI && (bal_entry & 15) != 0)) return;      // idle workgroup / a sibling of a table made for the split variant: the order-only variant runs part 0 alone
   }
-  __shared__ double s_part[TRK_THREADS / 64][NSUM + 1];
-  __shared__ double s_out[NSUM + 1];
+  double (&s_out)[NSUM + 1] = g_s_out;
+  float (&s_iplut)[256] = g_iplut;
   __shared__ double s_T[12], s_Tn[12], s_x[6], s_H[27], s_Tj[3][12];
-  __shared__ float s_iplut[256];
   __shared__ bool s_failed;
-  __shared__ SeqShared s_seq_sh;
-  if (threadIdx.x == 0) { s_failed = false; s_seq_sh.fell_back = 0; }
-  constexpr int TM = MULTI ? 2 : 1;      // the terms of a pass: plain stores, or past the caches when sibling workgroups read them
+  if (threadIdx.x == 0) { s_failed = false; if (!SEQ && SVS_TRK_LAZY) g_seq_sh.fell_back = 0; }
+#ifdef SVS_SCRATCH_PROBE                 // (build experiment: does the SIZE of a kernel's scratch allocation cost anything when nothing touches it?)
+  if (passes_out == reinterpret_cast<int *>(1)) { volatile int big[SVS_SCRATCH_PROBE]; for (int i = 0; i < SVS_SCRATCH_PROBE; ++i) big[i] = i; T_io[0] = big[threadIdx.x % SVS_SCRATCH_PROBE]; }
+#endif
+  constexpr int TM = SEQ ? 1 : (SVS_TRK_LAZY ? (MULTI ? 2 : 1) : 0);      // the terms of a pass: plain stores, or past the caches when sibling workgroups read them
   unsigned n_exact = 0;
   const int slot = BAL ? (bal_entry >> 4) : (MULTI ? blockIdx.y : blockIdx.x), wg = BAL ? (bal_entry & 15) : (MULTI ? blockIdx.x : 0);
   const int nwg = !MULTI ? 1 : (BAL ? (int)G.nwg_of[slot] : (int)gridDim.x);
@@ -665,22 +819,28 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
       __syncthreads();
       continue;
     }
-    const int lfirst = solo ? (int)threadIdx.x : first, lnwg = solo ? 1 : nwg;
+    const int lnwg = solo ? 1 : nwg;
     LevelArgs L = A.lv[level];
     L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
     if (U8SRC) L.cur8 += slot * A.c8_b[level];
     else { L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level]; }
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = s_T[i];
     const int n_lvl = (L.cam.w / 4) * (L.cam.h / 4);
+    // the operands of this level's sweeps (track_pass_call): the level, which workgroups share it; pose and term buffer follow before each sweep
+    __syncthreads();
+    if (threadIdx.x == 0) { g_pa.L = L; g_pa.wg = solo ? 0 : wg; g_pa.nwg = lnwg; }
+    auto sweep_at = [&](const double *s_pose, float *t_buf) {      // s_pose: 12 doubles in LDS
+      if (threadIdx.x < 12) g_pa.T[threadIdx.x] = s_pose[threadIdx.x];
+      if (threadIdx.x == 12) g_pa.t_buf = t_buf;
+      __syncthreads();
+      track_pass_call<U8SRC, TM>();
+    };
     // SEQ: one term buffer, every sum by the chain ("trk_seq_chi2"; never MULTI: G.part carries the buffer and fail_off its stream stride).
     // Default: two buffers -- the terms of the accepted pass (tb[cur]) and of the trial -- for the sums the accept test cannot decide in f64 (seqsum.h)
     float *tb[2];
     tb[0] = SEQ ? reinterpret_cast<float *>(G.part) + (size_t)slot * G.fail_off : (G.terms ? G.terms + (size_t)slot * 2 * G.terms_b : nullptr);
     tb[1] = SEQ ? tb[0] : (G.terms ? tb[0] + G.terms_b : nullptr);
     int cur = 0;
-    track_pass<true, U8SRC, TM>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, tb[cur]);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+    sweep_at(s_T, tb[cur]);        // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
     if (!solo) all_workgroups();
     if (MULTI && s_failed) { failed = true; break; }
     ++passes;
@@ -723,9 +883,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
         }
       }
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 12; ++i) T[i] = s_Tn[i];
-      track_pass<true, U8SRC, TM>(L, T, s_part, s_out, s_iplut, lfirst, lnwg, tb[cur ^ 1]);      // new_chi2 (:335-367) + H,b for the next iteration
+      sweep_at(s_Tn, tb[cur ^ 1]);      // new_chi2 (:335-367) + H,b for the next iteration
       if (!solo) all_workgroups();
       if (MULTI && s_failed) { failed = true; break; }
       ++passes;
@@ -740,11 +898,16 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
         // the reference compares two float sums of n terms each: |sum_float - sum_exact| <= ((1 + 2^-24)^(n - 1) - 1) sum_exact.  Outside that band the f64 sums
         // decide as the float sums would; inside it the float sums are formed, bit for bit (exact_seq_sum_f32)
         const double gam = 1.0001 * (double)max(nv_old, nv_new) * 5.9604644775390625e-08 + 1e-12;
-        const bool near = tb[0] && !(fabs(S_old - S_new) > gam * (S_old + S_new));
+        const bool near = SVS_TRK_LAZY && tb[0] && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));      // (terms_only: kernel A/B -- the stores without the sums)
         if (near) {
-          if (!seq_old_ok) { seq_old = exact_seq_sum_f32<MULTI>(tb[cur], n_lvl, s_seq_sh); seq_old_ok = true; ++n_exact; }
-          const float seq_new = exact_seq_sum_f32<MULTI>(tb[cur ^ 1], n_lvl, s_seq_sh);
-          ++n_exact;
+          float seq_new = 0.f;
+#pragma nounroll
+          for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {      // (one copy of the routine in the kernel: it is long)
+            const float v = exact_seq_sum_f32<MULTI>(tb[k ? cur ^ 1 : cur], n_lvl);
+            if (k) seq_new = v; else seq_old = v;
+            ++n_exact;
+          }
+          seq_old_ok = true;
           chi2 = seq_old; new_chi2 = seq_new;
           accept = (double)chi2 - (double)new_chi2 > 0;
           if (accept) seq_old = seq_new;
@@ -787,7 +950,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
   if (threadIdx.x == 0 && G.seq_stats && n_exact) {
     atomicAdd(G.seq_stats, n_exact);
-    if (s_seq_sh.fell_back) atomicAdd(G.seq_stats + 1, 1u);
+    if (SVS_TRK_LAZY && g_seq_sh.fell_back) atomicAdd(G.seq_stats + 1, 1u);
   }
 }
 
@@ -1064,12 +1227,12 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
   if (ctx->trk_balance == 2) {      // order + split (experimental): sibling workgroups wait for each other -- one such launch on the device at a time (common.h)
     SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));      // arrival counters, failure flags, hand-over words
     if ((rc = svs_spin_enter(ctx))) return rc;
-    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     if ((rc = svs_spin_leave(ctx))) return rc;
   } else {                          // order only: one workgroup per stream, nothing waits for anything
-    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   }
   SVS_LAUNCH_CHECK(ctx);
   return bal_assign(ctx, S, batch, A.rec, A.rec_cap, A.n_rec);
@@ -1125,6 +1288,7 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
   if (seq_all || lazy) {
     if (seq_all) nwg = 1;
     t_b = (size_t)(a->cam_vec[0].w / 4) * (a->cam_vec[0].h / 4);
+    if (lazy) t_b = ((t_b + 3) & ~(size_t)3) + 64;      // 16-byte aligned buffers, padded by more than the longest run a lane reads in one go (SEQ_RUN_MAX)
     const size_t want = (size_t)batch * t_b * sizeof(float) * (lazy ? 2 : 1) + 256;
     if (ctx->seq_buf_bytes < want) {
       if (ctx->seq_buf) { SVS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->seq_buf); ctx->seq_buf = nullptr; ctx->seq_buf_bytes = 0; }
@@ -1138,7 +1302,7 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     }
   }
   TrackMulti G{};
-  G.terms = terms; G.terms_b = t_b; G.seq_stats = static_cast<unsigned *>(ctx->seq_stats);
+  G.terms = terms; G.terms_b = t_b; G.seq_stats = static_cast<unsigned *>(ctx->seq_stats); G.terms_only = ctx->trk_lazy_chi2 == 2;
   if (t_buf) {
     G.part = reinterpret_cast<double *>(t_buf); G.fail_off = (int)t_b;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2, true>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -1160,8 +1324,8 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
   } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
     return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state, G);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
-    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 4>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else {
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 2>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -1175,13 +1339,12 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
 namespace {
 template <int HOW>
 __global__ __launch_bounds__(TRK_THREADS) void seq_sum_probe_kernel(const float *__restrict__ t, int n, size_t bstride, float *__restrict__ out, int *__restrict__ fell_back) {
-  __shared__ SeqShared sh;
-  if (threadIdx.x == 0) sh.fell_back = 0;
+  if (threadIdx.x == 0) g_seq_sh.fell_back = 0;
   __syncthreads();
   const float *row = t + (size_t)blockIdx.x * bstride;
   float v;
-  if constexpr (HOW == 2) v = seq_chi2_f32(row, n); else v = exact_seq_sum_f32<HOW == 1>(row, n, sh);
-  if (threadIdx.x == 0) { out[blockIdx.x] = v; if (fell_back) fell_back[blockIdx.x] = sh.fell_back; }
+  if constexpr (HOW == 2) v = seq_chi2_f32(row, n); else v = exact_seq_sum_f32<HOW == 1>(row, n);
+  if (threadIdx.x == 0) { out[blockIdx.x] = v; if (fell_back) fell_back[blockIdx.x] = HOW == 2 ? 1 : g_seq_sh.fell_back; }
 }
 }  // namespace
 extern "C" int svs_dense_seq_sum_f32(svs_ctx *ctx, const float *d_terms, int n, size_t bstride, int batch, int how, float *d_out, int32_t *d_fell_back) {

@@ -505,16 +505,17 @@ int frontend_take_device_frames(svs_frontend *fe, const svs_frames_dev *in) {
 struct DispView { const float *p; int stride; size_t bstride; };
 // everything behind the arrival of the images: pyramid, (tracking), stereo, FAST, (match, motion-only, gate), cloud.  first: processFirstFrame
 #define STAGE_MARK(k) do { if (fe->timing) SVS_HIP(ctx, hipEventRecord(fe->ev_stage[k], ctx->stream)); } while (0)
-int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = false) {
+int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = false, hipEvent_t frames_ready = nullptr) {
   svs_ctx *ctx = fe->ctx;
   const int B = fe->B, cur = fe->i_cur, prev = fe->i_prev, n = fe->n_launch;
   int rc;
   // Cross-frame pipeline.  The pyramid of a frame needs nothing of the frames before but a free slot (three slots: last read by the frame before the previous
-  // one).  With the frames in caller-owned device buffers (complete when the call is made -- the contract of svs_frontend_process_frames) it goes to the
+  // one).  With the frames in caller-owned device buffers whose completion the caller has tied to an EVENT (svs_frames_dev::ready_event -- without one the frames
+  // may still be in the making on the context's stream, and only that stream's order protects the read) it goes to the
   // low-priority side stream and is released when the PREVIOUS frame reaches its pose refinement: a caller that enqueues frame N+1 while frame N is still running
   // gets the 0.2 ms pyramid of N+1 into the tail of N's refinement (one workgroup per stream, <= 15 dependent LM iterations, most streams done early), its gate
   // and its cloud.  Results are those of the one-stream order (tests/test_gpu_frontend_batch.py).
-  const bool pipe = !first && ext_frames && fe->ev_early[0] && fe->side_stream && ctx->fe_pipeline && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
+  const bool pipe = !first && ext_frames && frames_ready && fe->ev_early[0] && fe->side_stream && ctx->fe_pipeline && ctx->fe_overlap && !fe->timing && B <= 2 * ctx->n_cu;
   svs_fast *const F = fe->fast;
   const int par = (int)(fe->pipe_run & 1u);
   hipStream_t const chain_stream0 = ctx->stream;
@@ -526,6 +527,7 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
       if (fe->pipe_run >= 2) SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_late[par], 0));      // frame N-2: the last reader of this pyramid slot
       SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, fe->ev_trk[1 - par], 0));                          // frame N-1 has reached its pose refinement
     }
+    SVS_HIP(ctx, hipStreamWaitEvent(fe->side_stream, frames_ready, 0));                          // the caller's word that the frames are complete
     ctx->stream = fe->side_stream;                                                            // (a context is used by one thread at a time)
   } else fe->pipe_run = 0;
   auto back_to_chain = [&](int rc_) { ctx->stream = chain_stream0; return rc_; };
@@ -784,7 +786,7 @@ extern "C" int svs_frontend_process_frames(svs_frontend *fe, const svs_frames_de
   fe->i_stage = 1 - fe->i_stage;
   DispView dv = in && in->d_disp ? DispView{in->d_disp, in->dstride, in->d_bstride} : DispView{fe->d_disp[fe->i_cur], fe->stride[0], fe->lvl_elems[0]};
   const bool ext_frames = in && fe->ext_left && in->d_disp && !fe->prm.use_block_matching;      // caller-owned, complete device frames: the pipelined schedule may run
-  if ((rc = frontend_chain(fe, false, dv, ext_frames))) return rc;
+  if ((rc = frontend_chain(fe, false, dv, ext_frames, in ? static_cast<hipEvent_t>(in->ready_event) : nullptr))) return rc;
   return frontend_end(fe, 0, false);
 }
 

@@ -60,6 +60,23 @@ SVS_SEQ_HD bool svs_seq_add_term(SvsSeqMap &m, uint32_t tb, int eb) {
   m.dd += c1 - c0;
   return true;
 }
+// The same update with the float unit doing the rounding: for base = 2^e (mantissa bits zero, even) and 0 <= t < 2^e the sum s = base + t stays in the binade, so
+// bits(s) - bits(base) IS q + c with the tie going to the even neighbour of an EVEN accumulator; d = s - base and r = t - d are exact (Sterbenz; r is a multiple
+// of t's own ulp no larger than t), and |r| = ulp / 2 exactly marks a tie, with the sign of r telling which way the float unit went: r > 0 it rounded down (q even),
+// r < 0 up (q odd).  An accumulator of the other parity goes the other way: + sign(r).  Five vector instructions per term off the tie path.
+// Only valid where svs_seq_add_term's carry case cannot occur (t < 2^e: every term of a safe segment); eb >= 27.
+SVS_SEQ_HD bool svs_seq_add_term_fast(SvsSeqMap &m, float t, int eb) {
+  const float base = svs_seq_float((uint32_t)eb << 23), half_ulp = svs_seq_float((uint32_t)(eb - 24) << 23);
+  const float s_ = base + t, d = s_ - base, r = t - d;
+  const int32_t inc = (int32_t)(svs_seq_bits(s_) - ((uint32_t)eb << 23));
+  const bool tie = (r < 0 ? -r : r) == half_ulp;
+  if (!tie) { m.d0 += inc; return false; }
+  const int32_t sg = r > 0 ? 1 : -1;
+  const int32_t par0 = m.d0 & 1, par1 = (1 + m.d0 + m.dd) & 1;
+  const int32_t n0 = m.d0 + inc + (par0 ? sg : 0), n1 = m.d0 + m.dd + inc + (par1 ? sg : 0);
+  m.d0 = n0; m.dd = n1 - n0;
+  return true;
+}
 // f then g
 SVS_SEQ_HD SvsSeqMap svs_seq_compose(const SvsSeqMap &f, const SvsSeqMap &g) {
   const int32_t f0 = f.d0, f1 = f.d0 + f.dd;

@@ -669,11 +669,14 @@ class StereoFrontend:
         return res, m, g
 
     # ---- all streams, frames in device memory
-    def _frames(self, left, right, disp):
-        """torch tensors [n_streams][h][stride] (u8, u8, f32) -> svs_frames_dev (None = written in place through inputView)"""
+    def _frames(self, left, right, disp, ready_event=None):
+        """torch tensors [n_streams][h][stride] (u8, u8, f32) -> svs_frames_dev (None = written in place through inputView).  ready_event: a torch.cuda.Event recorded
+        behind whatever produced the frames (None: they are produced by work on the context's stream enqueued before the call)"""
         if left is None:
             return None
         fr = capi.FramesDev()
+        if ready_event is not None:
+            fr.ready_event = ready_event.cuda_event
         fr.d_left, fr.lstride, fr.l_bstride = left.data_ptr(), left.stride(1), left.stride(0)
         if right is not None:
             fr.d_right, fr.rstride, fr.r_bstride = right.data_ptr(), right.stride(1), right.stride(0)
@@ -694,9 +697,9 @@ class StereoFrontend:
         fr = self._frames(left, right, disp)
         self.ctx.check(self.ctx.lib.svs_frontend_first_frames(self.h, C.byref(fr) if fr is not None else None))
 
-    def processFrames(self, T_cur_from_actkey, T_actkey_from_w, left=None, right=None, disp=None):
+    def processFrames(self, T_cur_from_actkey, T_actkey_from_w, left=None, right=None, disp=None, ready_event=None):
         """asynchronous; poses [n_streams][12]"""
-        fr = self._frames(left, right, disp)
+        fr = self._frames(left, right, disp, ready_event)
         Tc = np.ascontiguousarray(T_cur_from_actkey, np.float64).reshape(self.n_streams, 12)
         Ta = np.ascontiguousarray(T_actkey_from_w, np.float64).reshape(self.n_streams, 12)
         self.ctx.check(self.ctx.lib.svs_frontend_process_frames(self.h, C.byref(fr) if fr is not None else None, Tc.ctypes.data, Ta.ctypes.data))

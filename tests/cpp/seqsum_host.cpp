@@ -14,14 +14,14 @@ float svs_host_seq_sum_plain(const float *t, int n) {
   return acc;
 }
 // stats[0] = terms added the slow way by the walker, stats[1] = segments that were not safe, stats[2] = 1 if a check failed (result from the plain sum),
-// stats[3] = ties seen
+// stats[3] = ties seen, stats[4] = 1 if svs_seq_add_term_fast disagreed with svs_seq_add_term on a safe segment
 float svs_host_seq_sum_emulated(const float *t, int n, int NT, int *stats) {
   const int S = (n + NT - 1) / NT > 0 ? (n + NT - 1) / NT : 1;
   std::vector<double> psum(NT, 0.0), P_s(NT), P_e(NT);
   std::vector<int> cnt(NT, 0), c_s(NT), c_e(NT), eb(NT, 0);
   std::vector<char> safe(NT, 0);
   std::vector<SvsSeqMap> map(NT), pref(NT);
-  int ties = 0;
+  int ties = 0, mismatch = 0;
   for (int k = 0; k < NT; ++k)
     for (int j = k * S; j < n && j < (k + 1) * S; ++j) { psum[k] += (double)t[j]; cnt[k] += t[j] != 0.f; }
   double P = 0; int c = 0;
@@ -34,8 +34,11 @@ float svs_host_seq_sum_emulated(const float *t, int n, int NT, int *stats) {
     map[k].d0 = 0; map[k].dd = 0;
     // (two neighbouring safe segments share their binade -- P_s[k + 1] = P_e[k] -- but nothing below relies on the proof: a change of binade ends the run)
     if (safe[k] && !empty && k > 0 && safe[k - 1] && eb[k - 1] != e) safe[k] = 0;
-    if (safe[k] && !empty)
-      for (int j = k * S; j < n && j < (k + 1) * S; ++j) ties += svs_seq_add_term(map[k], svs_seq_bits(t[j]), e);
+    if (safe[k] && !empty) {
+      SvsSeqMap fast{0, 0};      // the float-unit form of the same update (what the kernel runs) must give the same map
+      for (int j = k * S; j < n && j < (k + 1) * S; ++j) { ties += svs_seq_add_term(map[k], svs_seq_bits(t[j]), e); svs_seq_add_term_fast(fast, t[j], e); }
+      if (map[k].d0 < SVS_SEQ_CARRY && (fast.d0 != map[k].d0 || fast.dd != map[k].dd)) mismatch = 1;
+    }
   }
   // segmented inclusive scan (reset behind every unsafe segment), Hillis-Steele as the wave does it
   std::vector<char> flag(NT);
@@ -71,7 +74,7 @@ float svs_host_seq_sum_emulated(const float *t, int n, int NT, int *stats) {
       pos = nxt + 1;
     }
   }
-  if (stats) { stats[0] = slow; stats[1] = unsafe; stats[2] = !ok; stats[3] = ties; }
+  if (stats) { stats[0] = slow; stats[1] = unsafe; stats[2] = !ok; stats[3] = ties; stats[4] = mismatch; }
   return ok ? acc : svs_host_seq_sum_plain(t, n);
 }
 }

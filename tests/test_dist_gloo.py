@@ -143,7 +143,7 @@ def test_sharded_optimize_two_processes_hip_shards():
 # mapped into each other with hipIpc (the same calls that map a peer GPU's memory over xGMI on a multi-GPU node), the exchange is the library's own push /
 # reduce kernel pair.  (a) raw all-reduces of every message size of the back end, incl. messages longer than a mailbox slot and 40 back-to-back calls (slot
 # parity), bit-equal to the sum in rank order; (b) the sharded optimize with svs_ba_set_comm on that transport vs the oracle.
-def _p2p_worker(rank, world, port, q):
+def _p2p_worker(rank, world, port, q, one_device=True):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -153,7 +153,9 @@ def _p2p_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctx, stream = capi.torch_context(0)
+    ctx, stream = capi.torch_context(0 if one_device else rank)
+    if not one_device:
+        torch.cuda.set_device(rank)
     comm = Communicator.p2p(ctx, rank, world, capacity_doubles=4096)
     assert comm.transport()["kind"] == "p2p"
     ok = True
@@ -197,7 +199,7 @@ def _p2p_worker(rank, world, port, q):
         err_p = np.abs(poses - poses_ref).max() / upd
         err_l = np.abs(t.numpy() - psi_ref).max() / np.abs(psi_ref - prob["psi"]).max()
         replicas_equal = all(torch.equal(allp[0], a) for a in allp)
-        q.put(dict(raw_ok=bool(ok), raw_worst=worst, timeouts=tr["timeouts"], same_traj=bool(st.trials == st_ref.trials and st.accepted == st_ref.accepted),
+        q.put(dict(raw_ok=bool(ok), raw_worst=worst, timeouts=tr["timeouts"], mailbox_memory=tr["mailbox_memory"], same_traj=bool(st.trials == st_ref.trials and st.accepted == st_ref.accepted),
                    err_p=float(err_p), err_l=float(err_l), n_calls=int(n_calls), trials=int(st.trials), replicas_equal=bool(replicas_equal)))
     dist.barrier()                                      # nobody tears its mailbox down while a peer may still push
     opt.close(); comm.close(); ctx.close()
@@ -223,3 +225,46 @@ def test_p2p_one_shot_transport_processes_on_one_gpu(world):
     assert r["raw_ok"] and r["timeouts"] == 0, r
     assert r["same_traj"] and r["err_p"] < 1e-6 and r["err_l"] < 1e-6 and r["replicas_equal"], r
     assert r["n_calls"] == 1 + 2 * r["trials"], r
+    assert r["mailbox_memory"] in ("fine-grained", "uncached"), r      # peers write the mailbox while its owner polls it: not coarse-grained memory
+
+
+@pytest.mark.gpu
+def test_p2p_one_shot_transport_across_devices():
+    """The same exchange with one process per GPU: the peers' mailboxes are another device's memory (xGMI).  Needs two visible devices (the 1-GPU boxes skip it;
+    on a multi-GPU node this is the validation of the transport across devices)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the cross-device exchange cannot be exercised here")
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, q, False)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    r = q.get(timeout=5)
+    print(f"P2P one-shot transport, 2 processes on 2 GPUs: {r}")
+    assert r["raw_ok"] and r["timeouts"] == 0 and r["same_traj"] and r["err_p"] < 1e-6 and r["err_l"] < 1e-6 and r["replicas_equal"], r
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus N` is the multi-GPU command the driver runs: with no launcher environment it must start N ranks itself (torch.distributed.run, one per
+    GPU), and an N-GPU request must never come back as a one-rank line.  --dry-launch: the ranks meet over gloo on the CPU and rank 0 reports who answered."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"dry_launch": True, "n_gpus": 2, "requested": 2, "ranks_seen": [0, 1]}
+    # a launcher that started the wrong number of ranks: refused with a reason, non-zero
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "--gpus 2" in bad.stderr and not bad.stdout.strip()

@@ -247,7 +247,11 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
     base, order, split = run(0), run(1, 1), run(2)
     # the cross-frame pipeline ("fe_pipeline": the pyramid of frame N+1 on the side stream beside frame N's pose refinement / gate / cloud; the three frames above
     # are enqueued back to back only up to the blocking result reads -- here they are enqueued without a read in between, the bench's pattern)
-    def run_async(pipeline):
+    ready = torch.cuda.Event()
+    with torch.cuda.stream(stream):
+        ready.record(stream)                             # the frames in F are complete (uploaded and synchronised above): the event the pipelined schedule asks for
+
+    def run_async(pipeline, produced_on_the_stream=False):
         ctx.set_option("fe_pipeline", pipeline)
         try:
             fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=prm, n_streams=B)
@@ -256,14 +260,27 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
             fe.processFirstFrames(**F["prev"])
             for b, s in enumerate(S):
                 fe.setCandidates(s["pts"], s["n_new"], stream=b)
+            if produced_on_the_stream:
+                # ONE pair of buffers, rewritten by a copy kernel on the context's stream right in front of every call, no ready event: only the
+                # stream's order says when a frame is complete, so the library must read it in that order (no side-stream pyramid ahead of the copy)
+                with torch.cuda.stream(stream):
+                    buf_l, buf_d = torch.empty_like(F["cur"]["left"]), torch.empty_like(F["cur"]["disp"])
             for name in ("cur", "prev", "cur", "prev", "cur"):
-                fe.processFrames(T_guess, T_act, **F[name])
+                if produced_on_the_stream:
+                    with torch.cuda.stream(stream):
+                        buf_l.copy_(F[name]["left"]); buf_d.copy_(F[name]["disp"])
+                    fe.processFrames(T_guess, T_act, left=buf_l, disp=buf_d)
+                else:
+                    fe.processFrames(T_guess, T_act, ready_event=ready if pipeline else None, **F[name])
             out = [fe.results(b) for b in (0, 1, 2, 257, B - 1)] + [fe.poses(), [fe.corners(b, l) for b in (0, 1, B - 1) for l in range(3)]]
             fe.close()
             return out
         finally:
             ctx.set_option("fe_pipeline", 1)
-    a0, a1 = run_async(0), run_async(1)
+    a0, a1, a2 = run_async(0), run_async(1), run_async(1, produced_on_the_stream=True)
+    for (o0, m0, g0), (o2, m2, g2) in zip(a0[:5], a2[:5]):
+        assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o2.T_cur_from_actkey)) and o0.dense_passes == o2.dense_passes >= 0, "frames produced on the stream"
+        assert m0.tobytes() == m2.tobytes() and g0.tobytes() == g2.tobytes()
     for (o0, m0, g0), (o1, m1, g1) in zip(a0[:5], a1[:5]):
         assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o1.T_cur_from_actkey)) and o0.dense_passes == o1.dense_passes >= 0
         assert m0.tobytes() == m1.tobytes() and g0.tobytes() == g1.tobytes() and bytes(o0.point_stats) == bytes(o1.point_stats)

@@ -42,16 +42,21 @@ def test_seq_sum_bits(gpu_ctx, n):
     kinds = ["tracker"] * 10 + ["ties", "const", "half_ulp", "range", "sparse", "zeros"] * 2
     t = _rows(rng, n, kinds)
     want = np.array([np.cumsum(r, dtype=np.float32)[-1] for r in t], np.float32)
+    stride = (n + 3) // 4 * 4 + 64                 # rows 16-byte aligned and padded like the tracker's term buffers (a lane reads its run as float4)
+    tp = np.zeros((len(t), stride), np.float32)
+    tp[:, :n] = t
+    tp[:, n:] = 1e30                                 # whatever lies behind a row must not matter
     with torch.cuda.stream(stream):
-        d_t = torch.as_tensor(t).cuda()
+        d_t = torch.as_tensor(tp).cuda()
         d_out = torch.zeros((3, len(t)), dtype=torch.float32, device="cuda")
         d_fb = torch.zeros((3, len(t)), dtype=torch.int32, device="cuda")
     for how in range(3):
-        ctx.call("svs_dense_seq_sum_f32", d_t.data_ptr(), n, n, len(t), how, d_out[how].data_ptr(), d_fb[how].data_ptr())
+        ctx.call("svs_dense_seq_sum_f32", d_t.data_ptr(), n, stride, len(t), how, d_out[how].data_ptr(), d_fb[how].data_ptr())
     ctx.sync()
     out, fb = d_out.cpu().numpy(), d_fb.cpu().numpy()
     for how in range(3):
         assert np.array_equal(out[how].view(np.uint32), want.view(np.uint32)), (how, n, np.nonzero(out[how].view(np.uint32) != want.view(np.uint32))[0], out[how], want)
-    # on the tracker's kind of terms no self-check of the parallel form fails (the chain is never needed)
-    assert not fb[:2, :10].any(), fb[:2]
+    # on the tracker's kind of terms no self-check of the parallel form fails (the chain is never needed); sums of more than 20 480 terms (images beyond
+    # 640 x 512) take the chain by design
+    assert fb[:2].all() if n > 20480 else not fb[:2, :10].any(), fb[:2]
     print(f"n = {n}: {len(t)} rows bit-equal to the sequential float sum (parallel form, past-the-caches form, chain); fallbacks on hostile rows: {int(fb[:2, 10:].sum())}")

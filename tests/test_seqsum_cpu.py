@@ -25,9 +25,10 @@ def lib(tmp_path_factory):
 
 def both(L, t, nt=512):
     t = np.ascontiguousarray(t, np.float32)
-    st = np.zeros(4, np.int32)
+    st = np.zeros(5, np.int32)
     a = np.float32(L.svs_host_seq_sum_plain(t.ctypes.data, len(t)))
     b = np.float32(L.svs_host_seq_sum_emulated(t.ctypes.data, len(t), nt, st.ctypes.data))
+    assert st[4] == 0, "the float-unit form of the term update disagrees with the integer form"
     return a, b, st
 
 
