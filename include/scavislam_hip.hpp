@@ -540,6 +540,18 @@ class StereoFrontend {
     return res->tracking_ok != 0;
   }
   bool recomputeDensePointCloud(const double T_cur_from_actkey[12]) { return ctx_.check(svs_frontend_recompute_cloud(fe_, T_cur_from_actkey)); }
+  // computeFastCorners' outputs of the frame processed last (stereo_frontend.cpp:656-679): the corner list of a level in the order FastGrid inserts it into the
+  // quadtree (cells row-major, corners of a cell row-major), corners per cell, and the persistent thresholds as they stand now (the CellGrid2d snapshot a Frame keeps)
+  bool fastCorners(int level, std::vector<Corner> *corners, std::vector<int32_t> *cell_counts, std::vector<int32_t> *thresholds) {
+    svs_fast *f = nullptr;
+    if (!ctx_.check(svs_frontend_device_view(fe_, 0, nullptr, nullptr, nullptr, nullptr, &f)) || !f) return false;
+    corners->resize(16384); cell_counts->assign(SVS_MAX_CELLS, 0); thresholds->assign(SVS_MAX_CELLS, 0);
+    int32_t n = 0;
+    if (!ctx_.check(svs_fast_download(f, 0, level, &(*corners)[0].x, (int)corners->size(), &n, cell_counts->data(), nullptr, thresholds->data()))) return false;
+    corners->resize((size_t)n);
+    return true;
+  }
+  svs_frontend *handle() const { return fe_; }
 
  private:
   const Context &ctx_;

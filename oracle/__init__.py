@@ -984,11 +984,13 @@ class RefSequence:
     SCAVISLAM_HIP_SUPPORT branch in place, its arithmetic on the GPU).  Nothing of the keyframe logic is stubbed: processFirstFrame, processFrame, shallWeSwitchKeyframe,
     shallWeDropNewKeyframe, addNewKeyframe, addNewPoints / addMorePoints, recomputeFastCorners are the reference's lines (stereo_frontend.cpp:39-528,656-1065)."""
 
-    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011):
+    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011, one_call=False):
+        """one_call (with hip_branch): libsvs_hipbranch_seq_onecall.so -- processFrame's body from the dense tracker to the return of matchAndTrack is ONE
+        svs_frontend_process_frame (the binding bench.py times); otherwise one library call per switch point of the reference"""
         if hip_branch:
             from scavislam_amd import capi
             capi.load()
-        self.L = L = _ref_lib("libsvs_hipbranch_seq.so" if hip_branch else "libsvs_ref_seq.so")
+        self.L = L = _ref_lib(("libsvs_hipbranch_seq_onecall.so" if one_call else "libsvs_hipbranch_seq.so") if hip_branch else "libsvs_ref_seq.so")
         L.svs_refseq_create.restype = C.c_void_p
         L.svs_refseq_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
         L.svs_refseq_destroy.argtypes = [C.c_void_p]

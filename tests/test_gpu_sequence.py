@@ -43,18 +43,23 @@ def _check_strict(st, n_frames, what):
     assert st["other_points"] == 0 and st["frames_1e6"] >= n_frames - 4 and st["max_dT"] <= 5e-6, (what, st)
 
 
-@pytest.mark.parametrize("camname,seq_chi2", [("default", 1), ("newcollege", 1), ("default", 0), ("newcollege", 0)])
-def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2):
+@pytest.mark.parametrize("camname,seq_chi2,one_call", [("default", 1, 0), ("newcollege", 1, 0), ("default", 0, 0), ("newcollege", 0, 0), ("default", 0, 1), ("newcollege", 0, 1)])
+def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2, one_call):
     """seq_chi2 = 0: the DEFAULT accept test of the dense tracker, i.e. the mode bench.py times -- the reference's `float chi2 - float new_chi2 > 0` decided on f64 sums
     wherever they can decide it and on the reference's own float sums (formed bit for bit, csrc/seqsum.h) wherever they cannot; seq_chi2 = 1: every sum by the literal
     sequential chain (context option "trk_seq_chi2").  Either way the LM of every frame ends where the reference's ends: ALL accepted points identical on ALL frames, the
-    poses within 1e-6."""
-    if not _have("libsvs_hipbranch_seq.so"):
-        pytest.skip("oracle/_ref/libsvs_hipbranch_seq.so not present (built by oracle/Makefile where /root/reference exists; travels prebuilt)")
+    poses within 1e-6.
+    one_call = 1: the same loop with the OTHER binding (libsvs_hipbranch_seq_onecall.so): processFrame's body from the dense tracker to the return of matchAndTrack
+    (stereo_frontend.cpp:192-237) is ONE svs_frontend_process_frame -- the call bench.py times -- with the previous frame, the keyframes' pyramids, the persistent
+    FAST thresholds and the dense clouds inside the library for all 200 frames; keyframe switching / dropping, addNewPoints and processMatchedPoints stay the
+    reference's.  Same fixture, same bars."""
+    libname = "libsvs_hipbranch_seq_onecall.so" if one_call else "libsvs_hipbranch_seq.so"
+    if not _have(libname):
+        pytest.skip(f"oracle/_ref/{libname} not present (built by oracle/Makefile where /root/reference exists; travels prebuilt)")
     import oracle as O
     fx = dict(np.load(os.path.join(GOLDEN, f"ref_seq_{camname}.npz")))
     t0 = time.time()
-    seq = O.RefSequence(_cams(camname), hip_branch=True)
+    seq = O.RefSequence(_cams(camname), hip_branch=True, one_call=bool(one_call))
     seq.set_var("svs.trk_seq_chi2", seq_chi2)
     hip = S.run(seq, camname)
     t_hip = time.time() - t0
@@ -72,7 +77,7 @@ def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2):
         ref_seq.close()
         st = S.compare(hip, ref, "HIP branch in place vs the reference's CPU build")
         how = "reference's CPU build run here"
-    _check_strict(st, S.N_FRAMES, (camname, seq_chi2))
+    _check_strict(st, S.N_FRAMES, (camname, seq_chi2, one_call))
     # recomputeFastCorners (stereo_frontend.cpp:91-108) on stored keyframes: FastGrid::detect at the thresholds stored with the frame
     n_rec = 0
     if same_frames:
@@ -84,7 +89,7 @@ def test_200_frame_sequence_hip_branch_in_place(gpu_ctx, camname, seq_chi2):
         seq.close()
     drops, switches = sum(r["dropped"] for r in hip), sum(r["switched"] for r in hip)
     assert drops >= 5 and switches >= 3
-    print(f"{camname}, trk_seq_chi2 = {seq_chi2}: 200 frames, HIP branch in place vs {how}: {drops} keyframes dropped, {switches} switches to old keyframes, all decisions / ids / FAST thresholds "
+    print(f"{camname}, trk_seq_chi2 = {seq_chi2}, {'ONE svs_frontend_process_frame per frame' if one_call else 'one call per switch point'}: 200 frames, HIP branch in place vs {how}: {drops} keyframes dropped, {switches} switches to old keyframes, all decisions / ids / FAST thresholds "
           f"identical; {st['points'] - st['other_points']} of {st['points']} accepted points identical ({st['frames_with_other_points']} frames with other points, "
           f"worst {st['worst_frame_points']}); pose within 1e-9 on {st['frames_1e9']}, within 1e-6 on {st['frames_1e6']} frames, median {st['median_dT']:.1e}, "
           f"max {st['max_dT']:.1e}; {n_rec} re-detected corners identical; {t_hip:.1f} s incl. rendering")
