@@ -984,17 +984,27 @@ class RefSequence:
     SCAVISLAM_HIP_SUPPORT branch in place, its arithmetic on the GPU).  Nothing of the keyframe logic is stubbed: processFirstFrame, processFrame, shallWeSwitchKeyframe,
     shallWeDropNewKeyframe, addNewKeyframe, addNewPoints / addMorePoints, recomputeFastCorners are the reference's lines (stereo_frontend.cpp:39-528,656-1065)."""
 
-    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011, one_call=False):
+    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011, one_call=False, stereo_input=False):
         """one_call (with hip_branch): libsvs_hipbranch_seq_onecall.so -- processFrame's body from the dense tracker to the return of matchAndTrack is ONE
         svs_frontend_process_frame (the binding bench.py times); otherwise one library call per switch point of the reference"""
         if hip_branch:
             from scavislam_amd import capi
             capi.load()
-        self.L = L = _ref_lib(("libsvs_hipbranch_seq_onecall.so" if one_call else "libsvs_hipbranch_seq.so") if hip_branch else "libsvs_ref_seq.so")
+        # stereo_input: the New College kind of input -- left + right image, no disparity; the "stereo" stage is the reference's calcDisparityCpu (stereo_frontend.cpp:
+        # 620-653) in both builds: cv::StereoBM -> the oracle's block matcher (CPU build) / the HIP branch at its head (libsvs_hipbranch_seq_bm.so)
+        self.stereo_input = stereo_input
+        if stereo_input:
+            assert not one_call
+            name = "libsvs_hipbranch_seq_bm.so" if hip_branch else "libsvs_ref_seq_bm.so"
+        else:
+            name = ("libsvs_hipbranch_seq_onecall.so" if one_call else "libsvs_hipbranch_seq.so") if hip_branch else "libsvs_ref_seq.so"
+        self.L = L = _ref_lib(name)
         L.svs_refseq_create.restype = C.c_void_p
         L.svs_refseq_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
         L.svs_refseq_destroy.argtypes = [C.c_void_p]
         L.svs_refseq_push_frame.argtypes = [C.c_void_p] * 6
+        if stereo_input:
+            L.svs_refseq_push_right.argtypes = [C.c_void_p] * 3
         L.svs_refseq_step.argtypes = [C.c_void_p] * 4
         L.svs_refseq_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.svs_refseq_fast_thresholds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -1010,7 +1020,7 @@ class RefSequence:
         HIP context behind the branch (svs_ctx_set_option), ignored by the CPU build"""
         self.L.svs_refseq_set_var(self.h, name.encode(), float(value))
 
-    def step(self, img_u8, disp):
+    def step(self, img_u8, disp, right_u8=None):
         """FrameGrabber::processNextFrame (pyramid + f32 / Sobel images by the oracle's restatement of the OpenCV calls) + processFirstFrame / processFrame.
         Returns dict(ok, dropped, actkey_id, switched, n_keyframes, id_counter, n_neighbourhood_points, n_new_points, n_vertices, T, av_track_length, lines, fast_thr)."""
         pyr = build_pyramid(img_u8)
@@ -1020,6 +1030,9 @@ class RefSequence:
         d = np.ascontiguousarray(disp, np.float32)
         self.L.svs_refseq_push_frame(self.h, P3(*[a.ctypes.data for a in keep[:3]]), P3(*[a.ctypes.data for a in keep[3:6]]), P3(*[a.ctypes.data for a in keep[6:9]]),
                                      P3(*[a.ctypes.data for a in keep[9:12]]), _p(d))
+        if self.stereo_input:      # the right image instead of a disparity (disp is ignored: the front end computes its own)
+            r8 = np.ascontiguousarray(right_u8, np.uint8)
+            self.L.svs_refseq_push_right(self.h, _p(r8), C.cast(lib().svs_ref_stereo_bm, C.c_void_p))
         info = np.zeros(8, np.int32); T = np.zeros(12); av = C.c_double(0)
         ok = self.L.svs_refseq_step(self.h, _p(info), _p(T), C.byref(av))
         cap = 8192

@@ -130,4 +130,21 @@ class FastFeatureDetector {
   int thr_;
   bool nonmax_;
 };
+// StereoBM (OpenCV 2.4.2 calib3d: external to the reference): state as calcDisparityCpu sets it (stereo_frontend.cpp:620-641), operator() forwards to a hook.  The
+// sequence pin binds the hook to the oracle's restatement of the block matcher (oracle/stereo.c: svs_ref_stereo_bm), so that what is compiled from the reference is the
+// call site -- which images go in, which parameters, where the disparity lands (CV_32F, pixels) -- and the HIP branch put at its head is compared with exactly that.
+struct svs_shim_stereo_state { int preFilterCap, SADWindowSize, minDisparity, numberOfDisparities, textureThreshold, uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff; };
+typedef void (*svs_shim_stereobm_fn)(const uint8_t *left, const uint8_t *right, int w, int h, int stride, const svs_shim_stereo_state *p, float *disp, int dstride);
+extern svs_shim_stereobm_fn svs_shim_stereobm_hook;
+class StereoBM {
+ public:
+  svs_shim_stereo_state st_, *state;
+  StereoBM() : state(&st_) { std::memset(&st_, 0, sizeof st_); }
+  void operator()(const Mat &left, const Mat &right, Mat &disp, int type) {
+    std::vector<float> buf((size_t)left.rows * left.cols, -1.f);
+    if (svs_shim_stereobm_hook && type == CV_32F && left.step == right.step)
+      svs_shim_stereobm_hook(left.data, right.data, left.cols, left.rows, (int)left.step, state, buf.data(), left.cols);
+    disp = Mat(left.rows, left.cols, CV_32F, buf.data(), (size_t)left.cols * 4).clone();
+  }
+};
 }  // namespace cv

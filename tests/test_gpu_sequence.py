@@ -116,3 +116,33 @@ def test_sequence_live_full_lists(gpu_ctx):
     st = S.compare(hip, ref, "HIP branch in place vs the reference's CPU build (live)")
     _check_strict(st, n, "live")
     print(f"40 frames live: {st}")
+
+
+def test_sequence_on_stereo_input_block_matching_in_place(gpu_ctx):
+    """The shipped New College configuration has NO disparity input: the "stereo" stage of processFrame is calcDisparityCpu -> cv::StereoBM (stereo_frontend.cpp:199-225,
+    620-653).  40 frames at 512 x 384 from rendered LEFT + RIGHT images through the reference's loop with its own calcDisparityCpu in the translation unit: the CPU build
+    (cv::StereoBM = the oracle's restatement of OpenCV 2.4.2's block matcher, bound to the stand-in class) against the HIP build with its branch at the head of
+    calcDisparityCpu (svs_stereo_compute; the disparity stays on the device for the matcher and the clouds and comes back for addNewPoints).  Same bars as the sequences
+    with a given disparity: decisions, ids, FAST thresholds and accepted points identical, poses within 1e-6."""
+    if not (_have("libsvs_hipbranch_seq_bm.so") and _have("libsvs_ref_seq_bm.so")):
+        pytest.skip("oracle/_ref/libsvs_hipbranch_seq_bm.so / libsvs_ref_seq_bm.so not present")
+    import oracle as O
+    n = 40
+    fl = list(S.frames("newcollege", n, with_right=True))
+    t0 = time.time()
+    seq = O.RefSequence(_cams("newcollege"), hip_branch=True, stereo_input=True)
+    hip = S.run(seq, "newcollege", n, stereo_input=True, frame_list=fl)
+    seq.close()
+    t_hip = time.time() - t0
+    t0 = time.time()
+    seq = O.RefSequence(_cams("newcollege"), stereo_input=True)
+    ref = S.run(seq, "newcollege", n, stereo_input=True, frame_list=fl)
+    seq.close()
+    t_ref = time.time() - t0
+    assert len(hip) == len(ref) == n and all(r["ok"] for r in ref) and all(r["ok"] for r in hip)
+    st = S.compare(hip, ref, "stereo input: HIP branch (block matching on the device) vs the reference's CPU build")
+    _check_strict(st, n, "stereo input")
+    drops = sum(r["dropped"] for r in hip)
+    assert drops >= 2 and st["points"] > 5000
+    print(f"stereo input, 40 frames 512 x 384, block matching in place: {drops} keyframes dropped, all decisions / ids / FAST thresholds identical; {st['points']} accepted points "
+          f"identical; pose within 1e-9 on {st['frames_1e9']}, within 1e-6 on {st['frames_1e6']} frames, max {st['max_dT']:.1e}; HIP build {t_hip:.1f} s, CPU build {t_ref:.1f} s")
