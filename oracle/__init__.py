@@ -1048,6 +1048,22 @@ class RefSequence:
                     n_neighbourhood_points=int(info[5]), n_new_points=int(info[6]), n_vertices=int(info[7]), T=T.reshape(3, 4), av_track_length=av.value,
                     lines=out_lines, fast_thr=thr[:nt].copy())
 
+    def onecall_record(self, cap=16384):
+        """(one_call build) what the step just made handed to svs_frontend_process_frame and what came back: dict(kept_slot, kept_pose, T_guess, T_act, pts, group_end,
+        res (FrameResult), matches, recloud / recloud_pose: the cloud was made again behind the call because the keyframe logic changed the pose), or None if the step made no call (the first frame)"""
+        from scavislam_amd import capi
+        from scavislam_amd.ctypes_types import CANDIDATE_DTYPE, MATCH_RESULT_DTYPE
+        self.L.svs_refseq_onecall_record.argtypes = [C.c_void_p] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        meta = np.zeros(5, np.int32); poses = np.zeros(48); pts = np.zeros(cap, CANDIDATE_DTYPE); ge = np.zeros(64, np.int32)
+        res = capi.FrameResult(); m = np.zeros(cap, MATCH_RESULT_DTYPE)
+        rc = self.L.svs_refseq_onecall_record(self.h, _p(meta), _p(poses), _p(pts), cap, _p(ge), C.byref(res), _p(m))
+        assert rc >= 0, "candidate capacity"
+        if rc == 0:
+            return None
+        n, ng = int(meta[1]), int(meta[2])
+        return dict(kept_slot=int(meta[3]), kept_pose=poses[:12].copy(), T_guess=poses[12:24].copy(), T_act=poses[24:36].copy(), pts=pts[:n].copy(), group_end=ge[:ng].copy(),
+                    res=res, matches=m[:n].copy(), recloud=bool(meta[4]), recloud_pose=poses[36:48].copy())
+
     def nudge(self, rel):
         """scales the translation of T_cur_from_actkey by (1 + rel) between two frames (the yardstick of tests/test_gpu_sequence.py)"""
         self.L.svs_refseq_nudge(self.h, float(rel))
