@@ -328,7 +328,23 @@ def main():
     oc.fe.setTiming(False)
     stage_ms = {k_: float(np.mean(v_)) for k_, v_ in stage_acc.items()}
     if args.quick:
-        print(json.dumps({"quick": True, "lib": os.path.basename(capi.LIB_PATH), "value": round(fps, 1), "ms_per_step": round(t_front / K * 1e3, 4),
+        lat_quick = {}
+        oc1 = OneCall(1)
+        oc1.fe.setTiming(True)
+        for mode_, name_ in ((1, "parity"), (2, "terms_stored_f64_accept"), (0, "f64_accept")):
+            ctx.set_option("trk_lazy_chi2", mode_)
+            acc_ = []
+            with torch.cuda.stream(stream):
+                for _ in range(12):
+                    oc1.step()
+                    acc_.append(oc1.fe.stageTimes()["dense_tracking"])
+            lat_quick[name_ + "_tracker_ms"] = round(float(np.mean(acc_[2:])), 4)
+        ctx.set_option("trk_lazy_chi2", 1)
+        with torch.cuda.stream(stream):
+            oc1.step(); oc1.step()
+            lat_quick["stage_ms"] = {k_: round(v_, 4) for k_, v_ in oc1.fe.stageTimes().items()}
+        oc1.close()
+        print(json.dumps({"quick": True, "latency_B1_ms": lat_quick, "lib": os.path.basename(capi.LIB_PATH), "value": round(fps, 1), "ms_per_step": round(t_front / K * 1e3, 4),
                           "ms_per_step_f64_accept": round(t_front_f64_accept / K * 1e3, 4), "ms_per_step_terms_stored_f64_accept": round(t_front_terms_only / K * 1e3, 4), "ms_per_step_stream_order": round(t_front_stream_order / K * 1e3, 4),
                           "ms_one_stream": round(ms_one_stream, 4), "exact_sums_per_frame": round(exact_sums_per_frame, 2), "fallbacks": exact_fallbacks,
                           "stage_ms": {k_: round(v_, 4) for k_, v_ in stage_ms.items()}, "track_err": track_err, "passes": passes}))
@@ -934,7 +950,33 @@ def main():
             O.stereo_bm(rend_cur[nst % NRIGHT][0], rend_right[nst % NRIGHT])
             nst += 1
         cpu_stereo_ms = (time.perf_counter() - t0) / nst * 1e3
-        cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+        # the reference's OWN code timed beside it, as far as this image allows: oracle/_ref/libsvs_ref_seq.so is the reference's front-end loop compiled from
+        # /root/reference (stereo_frontend.cpp:39-528,656-1065 + matcher + dense tracker + FastGrid; built where the reference exists, travels prebuilt) -- processFrame
+        # per frame over the first frames of the BASELINE configs[0] sequence.  Its third-party calls (Eigen, Sophus, OpenCV FAST, VisionTools) are the oracle's
+        # stand-ins, so this is the reference's control flow and data structures on stand-in algebra, not a build against the real libraries (absent).  The back end's
+        # SlamGraph::optimize cannot be timed this way: its solver IS g2o, which is absent (libsvs_ref_slamgraph.so records the graph, it does not solve it).
+        ref_compiled = None
+        try:
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsvs_ref_seq.so")):
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import seq_common as SQ
+                rs = O.RefSequence(cams_c)
+                ts = []
+                t0 = time.perf_counter()
+                for i_, (img_, disp_) in enumerate(SQ.frames("default", 200)):
+                    r_ = rs.step(img_, disp_)
+                    if i_ > 0:
+                        ts.append(rs.last_step_s)
+                    if not r_["ok"] or (time.perf_counter() - t0 > 10.0 and i_ >= 8):
+                        break
+                rs.close()
+                ref_compiled = {"ms_per_processFrame": round(float(np.mean(ts)) * 1e3, 2), "frames": len(ts), "cores": 1,
+                                "what": "StereoFrontend::processFrame of the reference compiled here from its own sources (oracle/_ref/libsvs_ref_seq.so; disparity given; "
+                                        "FrameGrabber::preprocessing not included), third-party algebra = the oracle's stand-ins",
+                                "gpu_frames_per_s_over_this": round(fps * float(np.mean(ts)), 1)}
+        except Exception as e:
+            ref_compiled = {"error": repr(e)}
+        cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": 1, "kind": "port", "reference_compiled": ref_compiled,
                "sample": f"{nfr} frames 640x480 through the CPU oracle (the same eight stages minus block matching, same inputs, disparity given)"
                          f" + {nba} x BA optimize 50KF/20k ({cpu_schur_ms:.1f} ms each); host has {os.cpu_count()} cores, 1 used",
                "schur_ms_per_optimize": round(cpu_schur_ms, 2), "stereo_bm_ms_per_frame": round(cpu_stereo_ms, 1),

@@ -1034,7 +1034,10 @@ class RefSequence:
             r8 = np.ascontiguousarray(right_u8, np.uint8)
             self.L.svs_refseq_push_right(self.h, _p(r8), C.cast(lib().svs_ref_stereo_bm, C.c_void_p))
         info = np.zeros(8, np.int32); T = np.zeros(12); av = C.c_double(0)
+        import time as _time
+        _t0 = _time.perf_counter()
         ok = self.L.svs_refseq_step(self.h, _p(info), _p(T), C.byref(av))
+        self.last_step_s = _time.perf_counter() - _t0      # processFirstFrame / processFrame alone (bench.py: cpu_baseline.reference_compiled)
         cap = 8192
         lines = np.zeros((cap, 5)); n_lines = (C.c_int * 3)()
         m = self.L.svs_refseq_lines(self.h, _p(lines), cap, n_lines)

@@ -692,23 +692,30 @@ __device__ __noinline__ float exact_seq_sum_f32(const float *t_flat, int n) {
       // this chunk's 64 runs, one per lane, in registers: the walk below is a dependent chain, and a readlane is a tenth of an LDS round trip
       const SvsSeqMap my = sh.pref[chunk * 64 + lane];
       const int my_eb = sh.eb[chunk * 64 + lane], my_sl = sh.slot[chunk * 64 + lane];
+      // the terms of an unsafe run, one per lane (staged in LDS by the run's own lane, else from global memory); the NEXT unsafe run's terms are requested
+      // before this one's chain of adds starts, so that only the first LDS round trip of a chunk is exposed
+      auto run_terms = [&](int idx) {
+        const int seg = chunk * 64 + idx, sj0 = seg * S, len = min(S, n - sj0), sl = __builtin_amdgcn_readlane(my_sl, idx);      // len <= SEQ_RUN_MAX <= 64
+        // (two loads and a select of VALUES: a select of the two addresses would make a flat pointer out of an LDS and a global one)
+        float x = sh.stage[(sl >= 0 && lane < len) ? sl * S + lane : 0];
+        if (sl < 0) x = seq_term_load<COH, svs_gptr_f32>(t + sj0 + (lane < len ? lane : 0));
+        return lane < len ? x : 0.f;
+      };
+      unsigned long long m = limit < 64 ? mask & ((1ull << limit) - 1ull) : mask;
+      float x_next = m ? run_terms((int)__builtin_ctzll(m)) : 0.f;
       int pos = 0;
-      while (pos < limit && ok) {
-        const unsigned long long rest = mask >> pos;
-        const int nxt = rest ? min(limit, pos + (int)__builtin_ctzll(rest)) : limit;
+      while (ok) {
+        const int nxt = m ? (int)__builtin_ctzll(m) : limit;
         if (nxt > pos) {
           const SvsSeqMap g{__builtin_amdgcn_readlane(my.d0, nxt - 1), __builtin_amdgcn_readlane(my.dd, nxt - 1)};
           ok = svs_seq_apply(&acc, g, __builtin_amdgcn_readlane(my_eb, nxt - 1));
         }
-        if (ok && nxt < limit) {
-          const int seg = chunk * 64 + nxt, sj0 = seg * S, len = min(S, n - sj0), sl = __builtin_amdgcn_readlane(my_sl, nxt);      // len <= SEQ_RUN_MAX <= 64: one lane per term
-          // (two loads and a select of VALUES: a select of the two addresses would make a flat pointer out of an LDS and a global one)
-          float x = sh.stage[(sl >= 0 && lane < len) ? sl * S + lane : 0];
-          if (sl < 0) x = seq_term_load<COH, svs_gptr_f32>(t + sj0 + (lane < len ? lane : 0));
-          if (lane >= len) x = 0.f;
+        if (nxt >= limit || !ok) break;
+        m &= m - 1ull;
+        const float x = x_next;
+        if (m) x_next = run_terms((int)__builtin_ctzll(m));
 #pragma unroll
-          for (int l = 0; l < SEQ_RUN_MAX; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));      // (+ 0 past the run: exact)
-        }
+        for (int l = 0; l < SEQ_RUN_MAX; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));      // (+ 0 past the run: exact)
         pos = nxt + 1;
       }
     }
@@ -827,12 +834,18 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
     const int n_lvl = (L.cam.w / 4) * (L.cam.h / 4);
     // the operands of this level's sweeps (track_pass_call): the level, which workgroups share it; pose and term buffer follow before each sweep
     __syncthreads();
-    if (threadIdx.x == 0) { g_pa.L = L; g_pa.wg = solo ? 0 : wg; g_pa.nwg = lnwg; }
+    if (MINW != 2 && threadIdx.x == 0) { g_pa.L = L; g_pa.wg = solo ? 0 : wg; g_pa.nwg = lnwg; }
     auto sweep_at = [&](const double *s_pose, float *t_buf) {      // s_pose: 12 doubles in LDS
-      if (threadIdx.x < 12) g_pa.T[threadIdx.x] = s_pose[threadIdx.x];
-      if (threadIdx.x == 12) g_pa.t_buf = t_buf;
-      __syncthreads();
-      track_pass_call<U8SRC, TM>();
+      if constexpr (MINW == 2) {
+        // one workgroup per CU (latency mode, small batches): 256 registers to live in -- the sweep inline, as it always was; its passes are a few
+        // microseconds long and a call (operands through LDS, callee-saved registers to scratch and back) would cost as much again
+        track_pass<true, U8SRC, TM>(L, s_pose, g_s_part, g_s_out, g_iplut, solo ? (int)threadIdx.x : first, lnwg, t_buf);
+      } else {
+        if (threadIdx.x < 12) g_pa.T[threadIdx.x] = s_pose[threadIdx.x];
+        if (threadIdx.x == 12) g_pa.t_buf = t_buf;
+        __syncthreads();
+        track_pass_call<U8SRC, TM>();
+      }
     };
     // SEQ: one term buffer, every sum by the chain ("trk_seq_chi2"; never MULTI: G.part carries the buffer and fail_off its stream stride).
     // Default: two buffers -- the terms of the accepted pass (tb[cur]) and of the trial -- for the sums the accept test cannot decide in f64 (seqsum.h)
@@ -1552,7 +1565,17 @@ __global__ __launch_bounds__(MO_THREADS) void motion_only_kernel(const svs_match
 //    symmetric positive definite, so no pivoting is needed where the reference's ldlt() pivots), exp(delta) * T on the same wave.
 // Same LM schedule and stopping rules as pose_optimizer.h:134-298; sums in a different order and one reciprocal instead of five divisions
 // per residual => the pose agrees with the oracle to ~1e-12 (test bar 1e-9).
-constexpr int MO2_THREADS = 512, MO2_RC = 4, MO2_WAVES = MO2_THREADS / 64;
+// Round 5: 256 lanes and six observations per lane in registers (rounds 3-4: 512 and four).  The kernel needs ~235 vector registers whatever its width, i.e. two
+// waves per SIMD: a 512-lane workgroup had a CU to itself and a batch of 512 streams ran as two rounds of a latency-bound loop (<= 15 dependent LM iterations, two
+// barriers and a 6 x 6 solve on one wave each); two 256-lane workgroups share a CU and the serial parts of one stream hide behind the sweeps of the other:
+// 0.32 -> 0.22 ms per 512 streams.
+#ifndef SVS_MO2_THREADS
+#define SVS_MO2_THREADS 256
+#endif
+#ifndef SVS_MO2_RC
+#define SVS_MO2_RC 6
+#endif
+constexpr int MO2_THREADS = SVS_MO2_THREADS, MO2_RC = SVS_MO2_RC, MO2_WAVES = MO2_THREADS / 64;
 struct MoObs { double o[3], q[3]; };
 
 template <bool FIRST, bool JAC = true>      // JAC = false: chi2 and max error only (the sweep of a trial that is expected to be rejected)
