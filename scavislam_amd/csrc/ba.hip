@@ -990,9 +990,10 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   else if (ba->grid_G > 0) {
     const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
     SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
-    if ((rc = svs_spin_enter(ctx))) return rc;      // grid-wide arrivals: one such launch on the device at a time (common.h)
+    SvsSpinScope gate(ctx, ba->grid_G);      // grid-wide arrivals: one such launch on the device at a time (common.h)
+    if (gate.rc) return gate.rc;
     hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
-    if ((rc = svs_spin_leave(ctx))) return rc;
+    SVS_LAUNCH_CHECK(ctx);
   }
   else
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_colmin);

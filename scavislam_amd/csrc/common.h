@@ -40,6 +40,7 @@ struct svs_ctx {
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
   void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)
+  bool spin_lane = false;            // the launch between the last svs_spin_enter and its svs_spin_leave took the priority lane
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // Kernels whose workgroups wait for each other INSIDE one launch (the latency-mode trackers, the multi-workgroup Cholesky) size their grids to a device they have
@@ -48,8 +49,16 @@ struct svs_ctx {
 // bounded spins give up (SVS_ERR_BUSY).  The reference runs exactly this concurrency: the front end on the main thread, optimize + re-registration on the backend
 // thread (stereo_slam.cpp:196, backend.cpp:157-224), so the library keeps at most ONE of them on the device at a time: a launch between svs_spin_enter / svs_spin_leave
 // first makes its stream wait for the event the previous device-filling launch of ANOTHER context left behind (stream-side; the host does not block), then leaves its own.
-int svs_spin_enter(svs_ctx *ctx);
+int svs_spin_enter(svs_ctx *ctx, int n_workgroups = 0);      // n_workgroups <= 16: the priority lane (image.hip) -- no wait, no gate
 int svs_spin_leave(svs_ctx *ctx);
+// the pair as a scope: the gate is left (mutex released, event recorded behind whatever was launched inside) on EVERY way out of the scope, an early return included
+struct SvsSpinScope {
+  svs_ctx *ctx; int rc;
+  SvsSpinScope(svs_ctx *c, int n_workgroups = 0) : ctx(c), rc(svs_spin_enter(c, n_workgroups)) {}
+  ~SvsSpinScope() { if (!rc) (void)svs_spin_leave(ctx); }
+  SvsSpinScope(const SvsSpinScope &) = delete;
+  SvsSpinScope &operator=(const SvsSpinScope &) = delete;
+};
 // returns ctx-owned device scratch of at least `bytes` (contents undefined); may synchronise the stream when it has to grow
 int svs_ctx_scratch(svs_ctx *ctx, size_t bytes, void **out);
 int svs_ctx_match_scratch(svs_ctx *ctx, size_t bytes, void **out);

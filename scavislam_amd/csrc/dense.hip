@@ -1239,10 +1239,11 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
   G.map = S.map; G.nwg_of = S.nwg_of;
   if (ctx->trk_balance == 2) {      // order + split (experimental): sibling workgroups wait for each other -- one such launch on the device at a time (common.h)
     SVS_HIP(ctx, hipMemsetAsync(S.flags, 0, sizeof(double) * S.n_flags, ctx->stream));      // arrival counters, failure flags, hand-over words
-    if ((rc = svs_spin_enter(ctx))) return rc;
+    SvsSpinScope gate(ctx);
+    if (gate.rc) return gate.rc;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    if ((rc = svs_spin_leave(ctx))) return rc;
+    SVS_LAUNCH_CHECK(ctx);
   } else {                          // order only: one workgroup per stream, nothing waits for anything
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -1330,10 +1331,11 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     G.fail_off = batch;
     G.bcast = scratch + n_part + (size_t)batch;
     SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * ((size_t)batch + (size_t)batch * 16), ctx->stream));
-    if ((rc = svs_spin_enter(ctx))) return rc;      // the workgroups of a stream wait for each other: one such launch on the device at a time (common.h)
+    SvsSpinScope gate(ctx, nwg * batch);      // the workgroups of a stream wait for each other: one such launch on the device at a time (common.h); one stream: priority lane
+    if (gate.rc) return gate.rc;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    if ((rc = svs_spin_leave(ctx))) return rc;
+    SVS_LAUNCH_CHECK(ctx);
   } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
     return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state, G);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create

@@ -834,10 +834,11 @@ extern "C" int svs_dense_track_full(svs_ctx *ctx, const svs_dense_track_full_arg
     A.count = reinterpret_cast<unsigned *>(A.bcast + n_bc);
     A.epoch = A.count + batch;
     SVS_HIP(ctx, hipMemsetAsync(A.count, 0, sizeof(double) * (size_t)batch, ctx->stream));
-    { const int rc2 = svs_spin_enter(ctx); if (rc2) return rc2; }      // workgroups of a stream wait for their leader: one such launch on the device at a time (common.h)
+    SvsSpinScope gate(ctx, nwg * batch);      // workgroups of a stream wait for their leader: one such launch on the device at a time (common.h); small launches: priority lane
+    if (gate.rc) return gate.rc;
     if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
     else hipLaunchKernelGGL((dense_track_full_kernel<false, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
-    { const int rc2 = svs_spin_leave(ctx); if (rc2) return rc2; }
+    SVS_LAUNCH_CHECK(ctx);
   } else {
     if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
     else hipLaunchKernelGGL((dense_track_full_kernel<false, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);

@@ -12,7 +12,14 @@ struct SpinGate { std::mutex m; hipEvent_t last = nullptr; svs_ctx *owner = null
 SpinGate g_spin_gate[64];      // per device, process-wide
 SpinGate &gate_of(const svs_ctx *c) { return g_spin_gate[(unsigned)c->device % 64u]; }
 }  // namespace
-int svs_spin_enter(svs_ctx *c) {
+// n_workgroups: the size of the launch that is about to be made.  A launch of at most SVS_SPIN_SMALL workgroups takes the PRIORITY LANE: it neither waits for the gate
+// nor closes it.  Such a launch (the latency-mode tracker of one camera stream: 8 workgroups) finds room beside whatever fills the device -- every CU keeps wave slots
+// and LDS free next to a workgroup of the multi-workgroup Cholesky -- so it cannot take part in the mutual starvation the gate exists to prevent, and without the lane a
+// real-time frame queued behind a whole 5.8 ms grid solve of the back-end thread (two threads, one GPU: p99 of the frame 6.1 ms).
+constexpr int SVS_SPIN_SMALL = 16;
+int svs_spin_enter(svs_ctx *c, int n_workgroups) {
+  c->spin_lane = n_workgroups > 0 && n_workgroups <= SVS_SPIN_SMALL;
+  if (c->spin_lane) return SVS_OK;
   SpinGate &g = gate_of(c);
   g.m.lock();                    // held until svs_spin_leave: the order of the launches is the order of the chain
   if (g.last && g.owner != c) {
@@ -22,6 +29,7 @@ int svs_spin_enter(svs_ctx *c) {
   return SVS_OK;
 }
 int svs_spin_leave(svs_ctx *c) {
+  if (c->spin_lane) { c->spin_lane = false; return SVS_OK; }
   SpinGate &g = gate_of(c);
   hipError_t e = hipSuccess;
   if (!c->spin_ev) e = hipEventCreateWithFlags(&c->spin_ev, hipEventDisableTiming);
