@@ -275,6 +275,33 @@ def main():
             barrier_sync()
             return time.perf_counter() - t0
 
+    def run_groups(n_groups, streams, reps=10):
+        """n_groups batched front ends of `streams` camera streams each, every group on a context and HIP stream of its own, stepped in turn: a group's matcher,
+        refinement and FAST run in the tail of another group's tracker (one workgroup per stream there: its last workgroups leave most CUs idle)."""
+        nonlocal ctx, stream
+        grp = [capi.torch_context(local_rank) for _ in range(n_groups)]
+        ctx_main, stream_main = ctx, stream
+        ocs = []
+        for cg, sg in grp:
+            ctx, stream = cg, sg                                 # OneCall builds on the enclosing ctx / stream
+            ocs.append(OneCall(streams, ctx=cg))
+        ctx, stream = ctx_main, stream_main
+        for _ in range(2):
+            for o in ocs:
+                o.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for o in ocs:
+                o.step()
+        torch.cuda.synchronize()
+        t_ov = (time.perf_counter() - t0) / reps
+        for o in ocs:
+            o.close()
+        for cg, _ in grp:
+            cg.close()
+        return {"groups": n_groups, "streams_per_group": streams, "ms_per_step_of_all_groups": round(t_ov * 1e3, 4), "frames_per_s": round(n_groups * streams / t_ov, 1)}
+
     oc = OneCall(B)
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
     # the tracker's accept test (DESIGN.md section 4): by default it takes the reference's decisions -- f64 sums where they can decide `float chi2 - float new_chi2 > 0`,
@@ -348,6 +375,10 @@ def main():
                           "ms_per_step_f64_accept": round(t_front_f64_accept / K * 1e3, 4), "ms_per_step_terms_stored_f64_accept": round(t_front_terms_only / K * 1e3, 4), "ms_per_step_stream_order": round(t_front_stream_order / K * 1e3, 4),
                           "ms_one_stream": round(ms_one_stream, 4), "exact_sums_per_frame": round(exact_sums_per_frame, 2), "fallbacks": exact_fallbacks,
                           "stage_ms": {k_: round(v_, 4) for k_, v_ in stage_ms.items()}, "track_err": track_err, "passes": passes}))
+        if os.environ.get("SVS_BENCH_GROUPS"):                  # experiment: "2x512,4x512"
+            for spec in os.environ["SVS_BENCH_GROUPS"].split(","):
+                g_, s_ = (int(v) for v in spec.split("x"))
+                print(json.dumps(run_groups(g_, s_)), flush=True)
         oc.close()
         return
     # dense-tracker bytes from the per-level record of the LM loop (sweeps per level, per stream), SURVEY 8d: 33 B per quarter-grid sample and sweep
@@ -499,35 +530,11 @@ def main():
         ocb = OneCall(Bs)
         batch_sweep[str(Bs)] = round(Bs * 10 / timed_steps(ocb, 2, 10), 1)
         ocb.close()
-    # several batched front ends in flight on their own HIP streams: the stage kernels of different groups overlap (every stage is VALU-issue bound at
-    # 40-60 % utilisation with its own latency tails) -- the mode a multi-camera server would run; `value` stays the single batch, whose stage times add up
+    # several batched front ends in flight on their own HIP streams (run_groups above): the stage kernels of different groups overlap -- the mode a
+    # multi-camera server would run; `value` stays the single batch, whose stage times add up
     overlapped = None
     if B >= 512 and world == 1:
-        grp = []
-        for _ in range(3):
-            cg, sg = capi.torch_context(local_rank)
-            grp.append((cg, sg))
-        ctx_main, stream_main = ctx, stream
-        ocs3 = []
-        for cg, sg in grp:
-            ctx, stream = cg, sg                                 # OneCall builds on the enclosing ctx / stream
-            ocs3.append(OneCall(256))
-        ctx, stream = ctx_main, stream_main
-        for _ in range(2):
-            for o in ocs3:
-                o.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            for o in ocs3:
-                o.step()
-        torch.cuda.synchronize()
-        t_ov = (time.perf_counter() - t0) / 10
-        overlapped = {"groups": 3, "streams_per_group": 256, "ms_per_step_of_all_groups": round(t_ov * 1e3, 4), "frames_per_s": round(3 * 256 / t_ov, 1)}
-        for o in ocs3:
-            o.close()
-        for cg, _ in grp:
-            cg.close()
+        overlapped = run_groups(2, B)
     # the reference's CUDA build of the same path (full-resolution tracker, matcher radius 4) through the same call
     FBc = min(B, 64)
     occ = OneCall(FBc, cuda_build=True)

@@ -107,6 +107,79 @@ __global__ __launch_bounds__(256) void stereo_prefilter_kernel(StereoDev S, cons
 }
 
 
+// The same filter for rows of 16 n pixels on dword-aligned sources (every camera of the reference): 16 padded columns x 4 rows per thread.  The six input rows are
+// read as 24 bytes each (one dwordx4 + the dword on either side), the arithmetic runs on pairs of pixels in packed 16-bit lanes (V_PERM_B32 picks the byte pairs:
+// the pair (b[4m-1], b[4m]) is the minus operand of pixel pair 4m and the plus operand of pair 4m-2, (b[4m+1], b[4m+2]) the plus operand of 4m and the minus operand
+// of 4m+2 -- nine shuffles and eight packed subtractions per input row), and a row of 16 results leaves as one 16-byte store.  Threads are dealt linearly over
+// (row group, column chunk), so no lane idles on the 44 chunks of a 704-byte row.  grid: (ceil(n_chunks * n_rowgroups / 256), 1, 2 * batch), block 256
+typedef short ps2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ps2 as_ps2(uint32_t v) { ps2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(ps2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+__global__ __launch_bounds__(256) void stereo_prefilter16_kernel(StereoDev S, const uint8_t *__restrict__ left, int lstride, size_t l_bstride,
+                                                                 const uint8_t *__restrict__ right, int rstride, size_t r_bstride) {
+  const int w = S.w, h = S.h, cap = S.cap, nct = S.pitch >> 4, nrg = (h + 3) >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z >> 1, side = blockIdx.z & 1;
+  if (t >= nct * nrg) return;
+  const int rg = t / nct, ct = t - rg * nct, y0 = 4 * rg, x0 = 16 * ct - PADL;
+  const uint32_t fill = 0x01010101u * (uint32_t)(cap + 1);      // pads, border columns, odd last row
+  uint8_t *dst = (side ? S.rp : S.lp) + ((size_t)b * h + y0) * S.pitch + 16 * ct;
+  const bool inside = x0 >= 0 && x0 < w;                        // (w is a multiple of 16: a chunk is inside the image or inside a pad)
+  uint4 out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = make_uint4(fill, fill, fill, fill);
+  if (inside) {
+    const uint8_t *src = side ? right + (size_t)b * r_bstride : left + (size_t)b * l_bstride;
+    const int stride = side ? rstride : lstride;
+    const bool has_l = x0 >= 4, has_r = x0 + 20 <= w;
+    ps2 d[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int r = y0 - 1 + i;      // rows outside the image: the row the original's yp / yn pick, i.e. 1 above the top and h-2 below the bottom
+      r = r < 0 ? (h > 1 ? 1 : 0) : (r > h - 1 ? (h > 1 ? h - 2 : 0) : r);
+      r = min(max(r, 0), h - 1);                                // (rows far below the image only feed rows that are not written)
+      const uint8_t *row = src + (size_t)r * stride + x0;
+      const uint4 a = *reinterpret_cast<const uint4 *>(row);
+      uint32_t W[6];
+      W[0] = has_l ? *reinterpret_cast<const uint32_t *>(row - 4) : 0u;      // bytes outside the row only feed border columns, which are overwritten
+      W[1] = a.x; W[2] = a.y; W[3] = a.z; W[4] = a.w;
+      W[5] = has_r ? *reinterpret_cast<const uint32_t *>(row + 16) : 0u;
+      ps2 E[5], O[4];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) E[m] = as_ps2(__builtin_amdgcn_perm(W[m + 1], W[m], 0x0c040c03u));      // (b[4m-1], b[4m])
+#pragma unroll
+      for (int m = 0; m < 4; ++m) O[m] = as_ps2(__builtin_amdgcn_perm(0u, W[m + 1], 0x0c020c01u));         // (b[4m+1], b[4m+2])
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { d[i][2 * m] = O[m] - E[m]; d[i][2 * m + 1] = E[m + 1] - O[m]; }
+    }
+    const ps2 lo = {(short)-cap, (short)-cap}, hi = {(short)cap, (short)cap}, off = {(short)(cap + 1), (short)(cap + 1)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ps2 v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int p = 2 * q + e;
+          const ps2 s3 = d[k][p] + d[k + 1][p] + d[k + 1][p] + d[k + 2][p];
+          v[e] = __builtin_elementwise_min(__builtin_elementwise_max(s3, lo), hi) + off;
+        }
+        o[q] = __builtin_amdgcn_perm(as_u32(v[1]), as_u32(v[0]), 0x06040200u);
+      }
+      if (x0 == 0) o[0] = (o[0] & 0xffffff00u) | (fill & 0x000000ffu);               // column 0
+      if (x0 + 16 == w) o[3] = (o[3] & 0x00ffffffu) | (fill & 0xff000000u);          // column w-1
+      out[k] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = y0 + k;
+    if (y >= h) break;
+    *reinterpret_cast<uint4 *>(dst + (size_t)k * S.pitch) = ((h & 1) && y == h - 1) ? make_uint4(fill, fill, fill, fill) : out[k];
+  }
+}
+
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 union Pk { uint64_t q; us2 h[2]; uint32_t u[2]; };
 
@@ -243,59 +316,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
 
 // columns X < 31 (never searched) and x in [0,3), whose right-image window clamps at column 0 BEFORE the disparity
 // shift (so it is not a contiguous byte window).  Half a wave per pixel: lane = disparity index d.
-// grid: (ceil(3*h/8), batch), block 256 (eight pixels per workgroup: 92 000 two-pixel workgroups per 128 frames cost more in dispatch
-// than in arithmetic)
-constexpr int EDGE_THREADS = 256;
+// grid: (ceil(h/EDGE_ROWS), batch), block 256
+constexpr int EDGE_THREADS = 256, EDGE_ROWS = 64, EDGE_REC = 13;      // rows per workgroup; dwords staged per image row
 __global__ __launch_bounds__(EDGE_THREADS) void stereo_bm_edge_kernel(StereoDev S) {
+  // what the three columns of EDGE_ROWS rows read: right bytes 0..39 and left bytes 28..39 of the rows ybase-3 .. ybase+EDGE_ROWS+2 -- 52 bytes per row, staged once
+  // with aligned dword loads (the per-lane form issued 28 unaligned dword loads per pixel and disparity: 10 M wave-level loads per 512 frames, the whole kernel time)
+  __shared__ uint32_t s_rec[(EDGE_ROWS + 2 * WSZ2) * EDGE_REC];
   const int b = blockIdx.y, w = S.w, h = S.h, tid = threadIdx.x, lane = tid & 63, d = lane & 31;
   const int width1 = w - NDISP + 1, ncol = min(3, width1);
+  const int ybase = blockIdx.x * EDGE_ROWS, nrow = min(EDGE_ROWS, h - ybase);
+  const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL, *rp = S.rp + (size_t)b * h * S.pitch + PADL;      // (PADL and the pitch are multiples of 4)
+  for (int i = tid; i < (nrow + 2 * WSZ2) * EDGE_REC; i += EDGE_THREADS) {
+    const int r = i / EDGE_REC, c = i - r * EDGE_REC, yy = min(max(ybase - WSZ2 + r, 0), h - 1);
+    s_rec[i] = *reinterpret_cast<const uint32_t *>((c < 10 ? rp + 4 * c : lp + 28 + 4 * (c - 10)) + (size_t)yy * S.pitch);
+  }
   {   // the never-searched left border, FILTERED
-    const int n = (NDISP - 1) * h;
-    for (int i = blockIdx.x * EDGE_THREADS + tid; i < n; i += gridDim.x * EDGE_THREADS) {
-      const size_t o = ((size_t)b * h + i / (NDISP - 1)) * w + i % (NDISP - 1);
+    const int n = (NDISP - 1) * nrow;
+    for (int i = tid; i < n; i += EDGE_THREADS) {
+      const size_t o = ((size_t)b * h + ybase + i / (NDISP - 1)) * w + i % (NDISP - 1);
       S.disp16[o] = (int16_t)FILTERED16; S.cost[o] = 0;
     }
   }
-  const int pix = blockIdx.x * (EDGE_THREADS / 32) + (tid >> 5);
-  const bool act = pix < ncol * h;
-  const int y = act ? pix / ncol : 0, x = act ? pix % ncol : 0;
-  const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL, *rp = S.rp + (size_t)b * h * S.pitch + PADL;
-  // A window row: left bytes x+28 .. x+34 (two dwords, 8th byte masked); right bytes max(x + dx, 0) + d for dx = -3..3 -- the clamp repeats
-  // column d, so the seven taps are a byte shuffle (V_PERM) of the two dwords at d .. d+7 (x <= 2, d <= 31: index <= 36 < w, no upper clamp).
-  // 28 dword loads + 14 shuffles + 28 V_SAD_U8 per lane instead of 98 byte loads.
-  const uint32_t selA = x == 0 ? 0x00000000u : x == 1 ? 0x01000000u : 0x02010000u;      // taps dx = -3..0
-  const uint32_t selB = x == 0 ? 0x0c030201u : x == 1 ? 0x0c040302u : 0x0c050403u;      // taps dx = 1..3, then a zero byte
+  __syncthreads();
   const uint32_t ft4 = 0x01010101u * (uint32_t)(S.cap + 1);
-  uint32_t sad_u = 0, tsum_u = 0;
-  for (int dy = -WSZ2; dy <= WSZ2; ++dy) {
-    const int yy = min(max(y + dy, 0), h - 1);
-    const uint8_t *lrow = lp + (size_t)yy * S.pitch + x + NDISP - 1 - WSZ2, *rrow = rp + (size_t)yy * S.pitch + d;
-    const uint32_t l0 = load_u32_unaligned(lrow), l1 = load_u32_unaligned(lrow + 4) & 0x00ffffffu;
-    const uint32_t r0 = load_u32_unaligned(rrow), r1 = load_u32_unaligned(rrow + 4);
-    const uint32_t ra = __builtin_amdgcn_perm(r1, r0, selA), rb = __builtin_amdgcn_perm(r1, r0, selB);
-    sad_u = __builtin_amdgcn_sad_u8(l1, rb, __builtin_amdgcn_sad_u8(l0, ra, sad_u));
-    tsum_u = __builtin_amdgcn_sad_u8(l1 | (ft4 & 0xff000000u), ft4, __builtin_amdgcn_sad_u8(l0, ft4, tsum_u));
-  }
-  const int sad = (int)sad_u, tsum = (int)tsum_u;
-  // selection across the 32 lanes of the pixel (same rules as bm_select)
-  uint32_t key = ((uint32_t)sad << 5) | (uint32_t)d;
+  const int q = d >> 2, sh = d & 3;
+  for (int pix = tid >> 5; pix < ncol * nrow; pix += EDGE_THREADS / 32) {      // half a wave per pixel: lane = disparity index d
+    const int yl = pix / ncol, x = pix - yl * ncol, y = ybase + yl;
+    // A window row: left bytes x+28 .. x+34 (8th byte masked); right bytes max(x + dx, 0) + d for dx = -3..3 -- the clamp repeats column d, so the seven taps are a
+    // byte shuffle (V_PERM) of the bytes d .. d+7 (x <= 2, d <= 31: index <= 36 < w, no upper clamp)
+    const uint32_t selA = x == 0 ? 0x00000000u : x == 1 ? 0x01000000u : 0x02010000u;      // taps dx = -3..0
+    const uint32_t selB = x == 0 ? 0x0c030201u : x == 1 ? 0x0c040302u : 0x0c050403u;      // taps dx = 1..3, then a zero byte
+    uint32_t sad_u = 0, tsum_u = 0;
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 64));
-  const int minsad = (int)(key >> 5), mind = (int)(key & 31), base = lane & 32;
-  const int ip = mind == NDISP - 1 ? NDISP - 2 : mind + 1, in = mind == 0 ? 1 : mind - 1;
-  const int p = __shfl(sad, base + ip, 64), n = __shfl(sad, base + in, 64);
-  const int thresh = minsad + (minsad * S.uniq / 100);
-  const unsigned long long rivals = __ballot(sad <= thresh && (d < mind - 1 || d > mind + 1));
-  const bool rival = ((rivals >> base) & 0xffffffffull) != 0;
-  if (!act || d != 0) return;
-  int16_t d16 = (int16_t)FILTERED16; uint16_t c16 = 0;
-  if (tsum >= S.texthr && !(S.uniq > 0 && rival)) {
-    const int dd = p + n - 2 * minsad + abs(p - n);
-    d16 = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
-    c16 = (uint16_t)minsad;
+    for (int k = 0; k <= 2 * WSZ2; ++k) {
+      const uint32_t *rec = s_rec + (yl + k) * EDGE_REC;
+      const uint32_t w0 = rec[q], w1 = rec[q + 1], w2 = rec[q + 2], a0 = rec[10], a1 = rec[11], a2 = rec[12];
+      const uint32_t r0 = __builtin_amdgcn_alignbyte(w1, w0, sh), r1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+      const uint32_t l0 = __builtin_amdgcn_alignbyte(a1, a0, x), l1 = __builtin_amdgcn_alignbyte(a2, a1, x) & 0x00ffffffu;
+      const uint32_t ra = __builtin_amdgcn_perm(r1, r0, selA), rb = __builtin_amdgcn_perm(r1, r0, selB);
+      sad_u = __builtin_amdgcn_sad_u8(l1, rb, __builtin_amdgcn_sad_u8(l0, ra, sad_u));
+      tsum_u = __builtin_amdgcn_sad_u8(l1 | (ft4 & 0xff000000u), ft4, __builtin_amdgcn_sad_u8(l0, ft4, tsum_u));
+    }
+    const int sad = (int)sad_u, tsum = (int)tsum_u;
+    // selection across the 32 lanes of the pixel (same rules as bm_select)
+    uint32_t key = ((uint32_t)sad << 5) | (uint32_t)d;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 64));
+    const int minsad = (int)(key >> 5), mind = (int)(key & 31), base = lane & 32;
+    const int ip = mind == NDISP - 1 ? NDISP - 2 : mind + 1, in = mind == 0 ? 1 : mind - 1;
+    const int p = __shfl(sad, base + ip, 64), n = __shfl(sad, base + in, 64);
+    const int thresh = minsad + (minsad * S.uniq / 100);
+    const unsigned long long rivals = __ballot(sad <= thresh && (d < mind - 1 || d > mind + 1));
+    const bool rival = ((rivals >> base) & 0xffffffffull) != 0;
+    if (d == 0) {
+      int16_t d16 = (int16_t)FILTERED16; uint16_t c16 = 0;
+      if (tsum >= S.texthr && !(S.uniq > 0 && rival)) {
+        const int dd = p + n - 2 * minsad + abs(p - n);
+        d16 = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+        c16 = (uint16_t)minsad;
+      }
+      const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
+      S.disp16[o] = d16; S.cost[o] = c16;
+    }
   }
-  const size_t o = ((size_t)b * h + y) * w + x + (NDISP - 1);
-  S.disp16[o] = d16; S.cost[o] = c16;
 }
 
 // validateDisparity (with D2): one WAVE per image row, four rows per workgroup (a row is 640 pixels: a 256-lane workgroup per row spent
@@ -927,6 +1010,7 @@ struct svs_stereo {
   int2 *d_pend = nullptr;
   int debug = 0;                                      // SVS_STEREO_DEBUG=1 at create
   int force_frame_ccl = 0;                            // SVS_STEREO_FRAME_CCL=1 at create: the whole-frame union-find path (tests compare the two)
+  int force_prefilter4 = 0;                           // SVS_STEREO_PREFILTER4=1 at create: the generic 4-pixel prefilter kernel on aligned input too (tests compare the two)
 };
 
 extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, const svs_stereo_params *prm, svs_stereo **out) {
@@ -940,6 +1024,7 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
   svs_stereo *s = new svs_stereo();
   s->ctx = ctx; s->w = w; s->h = h; s->max_batch = max_batch; s->pitch = (w + PADL + PADR + 3) & ~3; s->prm = *prm;
   { const char *e = getenv("SVS_STEREO_FRAME_CCL"); s->force_frame_ccl = e && atoi(e) != 0; }
+  { const char *e = getenv("SVS_STEREO_PREFILTER4"); s->force_prefilter4 = e && atoi(e) != 0; }      // A/B: the generic 4-pixel kernel on aligned input too
   { const char *e = getenv("SVS_STEREO_DEBUG"); s->debug = e && atoi(e) != 0; }
   const size_t n = (size_t)w * h * max_batch, np = (size_t)s->pitch * h * max_batch + 64;
   SVS_HIP(ctx, hipMalloc(&s->d_lp, np));
@@ -952,7 +1037,9 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
   // SPK_THREADS concurrent adds stay below the mark bit
   {
     const int wp = (w + 3) & ~3;
-    const int rows = std::min(h, (150 * 1024) / (6 * wp));
+    int strip_kb = 150;
+    { const char *e = getenv("SVS_STEREO_STRIP_KB"); if (e && atoi(e) >= 8 && atoi(e) <= 150) strip_kb = atoi(e); }      // experiment: smaller strips, more workgroups per CU
+    const int rows = std::min(h, (strip_kb * 1024) / (6 * wp));
     if (rows >= 16 && w <= 64 * SPK_MAX_SEG && (size_t)rows * w < (1u << 24) && (long long)(SPK_THREADS + 1) * std::max(prm->speckle_window, w) < SPK_TOUCH) {
       s->strip_rows = rows; s->n_strips = div_up(h, rows);
       SVS_HIP(ctx, hipMalloc(&s->d_brow, sizeof(int32_t) * 2 * (size_t)s->n_strips * w * max_batch));
@@ -988,10 +1075,16 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   S.speckle_window = s->prm.speckle_window; S.speckle_range = s->prm.speckle_range; S.disp12 = s->prm.disp12_max_diff;
   S.lp = s->d_lp; S.rp = s->d_rp; S.disp16 = s->d_disp16; S.cost = s->d_cost; S.label = s->d_label; S.count = s->d_count;
   const int w = s->w, h = s->h, width1 = w - NDISP + 1, n = w * h;
-  hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 16), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
-                     l_bstride, d_right, rstride, r_bstride);
+  const bool aligned16 = w % 16 == 0 && s->pitch % 16 == 0 && lstride % 4 == 0 && rstride % 4 == 0 && l_bstride % 4 == 0 && r_bstride % 4 == 0 &&
+                         ((uintptr_t)d_left | (uintptr_t)d_right) % 4 == 0 && !s->force_prefilter4;
+  if (aligned16)
+    hipLaunchKernelGGL(stereo_prefilter16_kernel, dim3(div_up((s->pitch / 16) * div_up(h, 4), 256), 1, 2 * n_batch), dim3(256), 0, ctx->stream, S, d_left, lstride,
+                       l_bstride, d_right, rstride, r_bstride);
+  else
+    hipLaunchKernelGGL(stereo_prefilter_kernel, dim3(div_up(s->pitch, 256), div_up(h, 16), 2 * n_batch), dim3(64, 4), 0, ctx->stream, S, d_left, lstride,
+                       l_bstride, d_right, rstride, r_bstride);
   SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(3 * h, EDGE_THREADS / 32), n_batch), dim3(EDGE_THREADS), 0, ctx->stream, S);
+  hipLaunchKernelGGL(stereo_bm_edge_kernel, dim3(div_up(h, EDGE_ROWS), n_batch), dim3(EDGE_THREADS), 0, ctx->stream, S);
   SVS_LAUNCH_CHECK(ctx);
   if (width1 > 3) {
     if (S.cap <= 41) hipLaunchKernelGGL(stereo_bm_kernel<true>, dim3(div_up(width1 - 3, 64), div_up(h, BM_STRIP), n_batch), dim3(64), 0, ctx->stream, S);
