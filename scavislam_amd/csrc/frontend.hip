@@ -122,6 +122,7 @@ struct svs_frontend {
   svs_keyframe *d_kfs = nullptr;        // [B][max_keyframes]
   std::vector<svs_keyframe> h_kfs;
   svs_candidate_point *d_pts = nullptr; // [B][max_points]
+  svs_candidate_point *h_cand_stage = nullptr;      // pinned, [B][max_points]: svs_frontend_set_candidates_all's staging block (allocated on first use)
   svs_match_result *d_res = nullptr;
   svs_gated_point *d_gated = nullptr;
   int32_t *d_group_end = nullptr, *d_n_groups = nullptr, *d_n_new = nullptr;      // [B][MAX_GROUPS], [B], [B]: records of the new-feature lists
@@ -191,6 +192,7 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
     if (fe->ev_done[k]) (void)hipEventDestroy(fe->ev_done[k]);
   }
   if (fe->h_out) (void)hipHostFree(fe->h_out);
+  if (fe->h_cand_stage) (void)hipHostFree(fe->h_cand_stage);
   if (fe->d_rec) (void)hipFree(fe->d_rec);
   if (fe->d_nrec) (void)hipFree(fe->d_nrec);
   if (fe->d_trk_work) (void)hipFree(fe->d_trk_work);
@@ -404,20 +406,25 @@ extern "C" int svs_frontend_set_candidates_all(svs_frontend *fe, const svs_candi
       for (int i = 0; i < h_n[b]; ++i, ++off)
         SVS_REQUIRE(ctx, h_pts[off].kf_index < 0 || (h_pts[off].kf_index < fe->max_keyframes && fe->kept[(size_t)b * fe->max_keyframes + h_pts[off].kf_index]));
   }
-  // the device list is [n_streams][max_points]: lay the records out like that on the host (unused tails = 0xff, "no candidate") and send it as one block up to the
-  // longest list's stream-strided extent
-  std::vector<svs_candidate_point> stage((size_t)B * fe->max_points);
-  __builtin_memset(stage.data(), 0xff, stage.size() * sizeof(svs_candidate_point));
+  // the device list is [n_streams][max_points]: lay the records out like that in a pinned block the front end keeps (unused tails = 0xff, "no candidate") and send
+  // the first m records of every stream as one strided copy, m = the longest list now or before (what lies behind a stream's list on the device is 0xff: svs_frontend_create, the per-stream setters)
+  if (!fe->h_cand_stage) SVS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&fe->h_cand_stage), sizeof(svs_candidate_point) * (size_t)fe->B * fe->max_points, hipHostMallocDefault));
+  int m = 0;
+  for (int b = 0; b < B; ++b) m = std::max(m, std::max(h_n[b], fe->n_points[b]));
   std::vector<int32_t> ge((size_t)B * MAX_GROUPS, 0), ng((size_t)B, n_groups), nn((size_t)B);
   size_t off = 0;
+  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (the staging block of the previous call has been read)
   for (int b = 0; b < B; ++b) {
-    if (h_n[b]) __builtin_memcpy(stage.data() + (size_t)b * fe->max_points, h_pts + off, sizeof(svs_candidate_point) * (size_t)h_n[b]);
+    svs_candidate_point *row = fe->h_cand_stage + (size_t)b * fe->max_points;
+    if (h_n[b]) __builtin_memcpy(row, h_pts + off, sizeof(svs_candidate_point) * (size_t)h_n[b]);
+    if (m > h_n[b]) __builtin_memset(row + h_n[b], 0xff, sizeof(svs_candidate_point) * (size_t)(m - h_n[b]));
     off += (size_t)h_n[b];
     for (int g = 0; g < n_groups; ++g) ge[(size_t)b * MAX_GROUPS + g] = h_group_end[(size_t)b * n_groups + g];
     nn[b] = h_group_end[(size_t)b * n_groups + n_groups - 2];
   }
-  SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  SVS_HIP(ctx, hipMemcpyAsync(fe->d_pts, stage.data(), sizeof(svs_candidate_point) * stage.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (m > 0)
+    SVS_HIP(ctx, hipMemcpy2DAsync(fe->d_pts, sizeof(svs_candidate_point) * (size_t)fe->max_points, fe->h_cand_stage, sizeof(svs_candidate_point) * (size_t)fe->max_points,
+                                  sizeof(svs_candidate_point) * (size_t)m, (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemcpyAsync(fe->d_group_end, ge.data(), sizeof(int32_t) * ge.size(), hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemcpyAsync(fe->d_n_groups, ng.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemcpyAsync(fe->d_n_new, nn.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, ctx->stream));
