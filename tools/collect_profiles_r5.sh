@@ -4,8 +4,9 @@ tag=${1:-r5}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+t0=$(date +%s)
 timeout 400 python bench.py > $out/bench.log 2> $out/bench.err
-echo "bench rc=$?"
+echo "bench rc=$? wall $(( $(date +%s) - t0 )) s"
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu > $out/trace.log 2>&1
 echo "trace rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -34,6 +35,10 @@ rm -rf $out/trace_ba
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace_dropin -o trace -- python tools/time_dropin.py > $out/trace_dropin.log 2>&1
 python tools/rocpd_summary.py $(find $out/trace_dropin -name "*.db") > $out/trace_dropin_summary.txt 2>&1
 rm -rf $out/trace_dropin
+# block matching alone, per kernel
+timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace_stereo -o trace -- python tools/time_stereo.py 512 > $out/stereo.log 2>&1
+python tools/rocpd_summary.py $(find $out/trace_stereo -name "*.db") | cut -c1-200 | head -12 > $out/stereo_kernels.txt 2>&1
+rm -rf $out/trace_stereo
 # the accept test of the quarter-grid tracker: what one float sum costs (parallel form / past the caches / sequential chain), and the solve's phase clocks
 python tools/time_seqsum.py > $out/seqsum.log 2>&1
 SVS_BA_DEBUG=1 python tools/time_ba.py 50 20000 2>&1 | grep -i "solve phases" | tail -3 > $out/solve_phases.log
