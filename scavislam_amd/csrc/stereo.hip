@@ -658,6 +658,8 @@ constexpr int SPK_NS = 10;                         // segments of a row handled 
 constexpr int SPK_MAX_SEG = 40;                   // 64-pixel segments per row: w <= 2560
 constexpr int SPK_BIG = (int)0x80000000;           // root value of the BIG set; no real root value is that negative
 constexpr int SPK_TOUCH = 1 << 24;
+// LDS bytes per strip row: label (int) + disparity (int16) per pixel, and for rows of up to SPK_NS segments the four pass masks per segment
+__host__ __device__ constexpr int spk_row_bytes(int w) { return ((w + 3) & ~3) * 6 + ((w + 63) / 64 <= SPK_NS ? 4 * SPK_NS * 8 : 0); }
 // (every loop of the union-find routines is bounded: a parent index is smaller than its child, so a walk takes fewer steps than the strip
 //  has pixels; past that something is broken and the walk gives up -- the library never hangs the GPU -- leaving a mark in *err)
 constexpr int SPK_MAX_STEPS = 1 << 16;
@@ -694,6 +696,24 @@ __device__ __forceinline__ void spk_union(int *lab, int a, int b, int *err) {   
 __device__ __forceinline__ void spk_unpack4(uint2 v, int (&d)[4]) {
   d[0] = (int16_t)(v.x & 0xffff); d[1] = (int16_t)(v.x >> 16); d[2] = (int16_t)(v.y & 0xffff); d[3] = (int16_t)(v.y >> 16);
 }
+// acc with lane `sel` replaced by the wave-uniform `val` (V_WRITELANE_B32; this compiler has no builtin for it).  `sel` is a constant after unrolling at every call
+// site: the switch folds to the one instruction with the lane select as an inline constant.
+__device__ __forceinline__ unsigned spk_writelane(unsigned acc, unsigned val, int sel) {
+#define SPK_WL(n) case n: asm("v_writelane_b32 %0, %1, " #n : "+v"(acc) : "s"(val)); break;
+  switch (sel) {
+    SPK_WL(0) SPK_WL(1) SPK_WL(2) SPK_WL(3) SPK_WL(4) SPK_WL(5) SPK_WL(6) SPK_WL(7) SPK_WL(8) SPK_WL(9)
+    SPK_WL(10) SPK_WL(11) SPK_WL(12) SPK_WL(13) SPK_WL(14) SPK_WL(15) SPK_WL(16) SPK_WL(17) SPK_WL(18) SPK_WL(19)
+    SPK_WL(20) SPK_WL(21) SPK_WL(22) SPK_WL(23) SPK_WL(24) SPK_WL(25) SPK_WL(26) SPK_WL(27) SPK_WL(28) SPK_WL(29)
+    SPK_WL(30) SPK_WL(31) SPK_WL(32) SPK_WL(33) SPK_WL(34) SPK_WL(35) SPK_WL(36) SPK_WL(37) SPK_WL(38) SPK_WL(39)
+    default: break;
+  }
+#undef SPK_WL
+  return acc;
+}
+__device__ __forceinline__ unsigned long long spk_readlane64(unsigned long long v, int l) {      // value of lane l (l wave-uniform)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(StereoDev S, float *__restrict__ out, int dstride, size_t d_bstride) {
   extern __shared__ int s_mem[];
   __shared__ unsigned long long s_bb[SPK_THREADS / 64][SPK_MAX_SEG];
@@ -729,22 +749,43 @@ __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(Stere
   //      Rows of up to SPK_NS segments (640 pixels) are handled in registers: all the row's loads in flight at once, the ballots of its
   //      segments in scalar registers, one label store per pixel -- the stepwise form below paid three LDS round trips per segment.
   const int nseg = (w + 63) >> 6;
+  // Rows of up to SPK_NS segments also leave four bit masks per segment in LDS (`msk`, [row][4][SPK_NS] ballots) that the three later passes scan instead of the
+  // pixels: ST = "unites its run with the one below" (vertically linked and the leftmost linked column of the two runs' overlap), CN = "last pixel of a run that
+  // is not big", CL = "valid pixel of a run that is not big", S = "starts a run".  Their loops then cost two V_READLANE and a scalar branch per 64 pixels
+  // where they read four disparities and evaluated four link tests per pixel (those passes were bound by VALU issue on the strip's one CU).  "Big" is the
+  // state after THIS pass (a single-pixel run that joins BIG while rows are stitched stays listed: its find returns BIG and the entry is dropped).
+  unsigned long long *const msk = reinterpret_cast<unsigned long long *>(dsp + S.strip_rows * wp);
+  constexpr int MSK_ROW = 4 * SPK_NS;
+  const bool use_msk = nseg <= SPK_NS;
   if (nseg <= SPK_NS) {
     for (int row = wave; row < nr; row += SPK_THREADS / 64) {
       const int16_t *d = dsp + row * wp;
       int *l = lab + row * wp;
-      int dv[SPK_NS], dl[SPK_NS];
+      const bool has_b = row + 1 < nr;
+      int dv[SPK_NS], dl[SPK_NS], db[SPK_NS], dbl[SPK_NS];
 #pragma unroll
       for (int sg = 0; sg < SPK_NS; ++sg) {
         const int x = sg * 64 + lane;
         dv[sg] = x < w ? d[x] : FILTERED16;
         dl[sg] = (x < w && x > 0) ? d[x - 1] : FILTERED16;
+        db[sg] = (has_b && x < w) ? d[wp + x] : FILTERED16;
+        dbl[sg] = (has_b && x < w && x > 0) ? d[wp + x - 1] : FILTERED16;
       }
+      // the row's 4 x SPK_NS mask words are assembled in the lanes that will store them (lane = mask * SPK_NS + segment): V_WRITELANE from the scalar ballots
+      unsigned mlo = 0u, mhi = 0u;
+      auto put = [&](int word, unsigned long long v) { mlo = spk_writelane(mlo, (unsigned)v, word); mhi = spk_writelane(mhi, (unsigned)(v >> 32), word); };
       unsigned long long sb[SPK_NS], bb[SPK_NS];
+      unsigned long long vm_prev = 0ull;
 #pragma unroll
       for (int sg = 0; sg < SPK_NS; ++sg) {
         const bool filt = dv[sg] == FILTERED16, start = !filt && !ccl_linked(dv[sg], dl[sg], range);
         sb[sg] = __ballot(start); bb[sg] = __ballot(start || filt);
+        const unsigned long long vm = __ballot(ccl_linked(dv[sg], db[sg], range));        // vertically linked to the pixel below
+        const unsigned long long hb = __ballot(ccl_linked(db[sg], dbl[sg], range));       // the pixel below is linked to its left neighbour
+        const unsigned long long vsh = (vm << 1) | (vm_prev >> 63);                        // the left neighbours are vertically linked
+        put(0 * SPK_NS + sg, vm & ~(vsh & ~bb[sg] & hb));                                  // (~bb: valid and linked to the left neighbour; 0 past the row end)
+        put(3 * SPK_NS + sg, sb[sg]);
+        vm_prev = vm;
       }
       int carry[SPK_NS], nbc[SPK_NS];                         // last run start left of segment sg / first boundary right of it
       { int c = 0; 
@@ -760,9 +801,16 @@ __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(Stere
         const unsigned long long above = lane == 63 ? 0ull : (bb[sg] >> (lane + 1));
         const int st = lower ? sg * 64 + 63 - __clzll((long long)lower) : carry[sg];
         const int nbx = above ? x + __ffsll((long long)above) : nbc[sg];
-        if (x < w) l[x] = dv[sg] == FILTERED16 ? SPK_BIG + 1 : (nbx - st > window) ? SPK_BIG : st == x ? ~0 : row * wp + st;
+        const bool filt = dv[sg] == FILTERED16, isbig = !filt && nbx - st > window;
+        const unsigned long long big = __ballot(isbig && x < w);
+        if (x < w) l[x] = filt ? SPK_BIG + 1 : isbig ? SPK_BIG : st == x ? ~0 : row * wp + st;
+        const unsigned long long cl = (sb[sg] | ~bb[sg]) & ~big;                                                   // valid (starts a run or is linked to the left) and not big
+        const unsigned long long hnext = (~bb[sg] >> 1) | (sg + 1 < SPK_NS ? ~bb[sg + 1 < SPK_NS ? sg + 1 : sg] << 63 : 0ull);      // pixel x + 1 is linked to x
+        put(1 * SPK_NS + sg, cl & ~hnext);
+        put(2 * SPK_NS + sg, cl);
       }
       for (int x = w + lane; x < wp; x += 64) l[x] = SPK_BIG + 1;
+      if (lane < MSK_ROW) msk[(size_t)row * MSK_ROW + lane] = ((unsigned long long)mhi << 32) | mlo;
     }
   } else {
     for (int row = wave; row < nr; row += SPK_THREADS / 64) {
@@ -803,85 +851,83 @@ __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(Stere
   //      off with one entry per lane.
   int *const q = reinterpret_cast<int *>(s_bb[wave]);        // 64 entries (the ballots of the stepwise runs pass are done with)
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // queue entry: column (12 bits) | "starts its run" << 12 | row << 16.  The queue is worked off when it is full and once after the wave's last row: a flush is a
+  // chain of dependent LDS round trips whatever the number of entries, so it is not paid per row.
+  int qn = 0;
+  auto enqueue = [&](unsigned long long m, unsigned long long flag_m, int x0, int row, auto &&flush) {      // the set lanes of m append column x0 + lane
+    if (m == 0) return;
+    const int c = __popcll(m);
+    if (qn + c > 64) { flush(qn); qn = 0; }
+    if ((m >> lane) & 1ull) q[qn + __popcll(m & lt_mask)] = (x0 + lane) | ((int)((flag_m >> lane) & 1ull) << 12) | (row << 16);
+    qn += c;
+  };
+  auto row_masks = [&](int row) { return lane < MSK_ROW ? msk[(size_t)row * MSK_ROW + lane] : 0ull; };      // the row's masks: one LDS read, then lane broadcasts
   // ---- stitch rows.  A pixel unites its run with the one below where it is the LEFTMOST linked column of the two runs' overlap:
   //      vertically linked, and not (left neighbours vertically linked + both horizontal links)
-  for (int row = wave; row < nr - 1; row += SPK_THREADS / 64) {
-    const int16_t *da = dsp + row * wp, *db = da + wp;
-    const int *la = lab + row * wp, *lb = la + wp;
-    auto flush = [&](int qn) {
-      if (lane < qn) {
-        const int x = q[lane];
-        const int a = la[x], c = lb[x];
+  {
+    auto flush = [&](int n_) {
+      if (lane < n_) {
+        const int e = q[lane], x = e & 0xfff, row = e >> 16;
+        const int a = lab[row * wp + x], c = lab[(row + 1) * wp + x];
         // node of a pixel = its run start (the pixel itself where it starts a run or carries SPK_BIG: its word is a root / parent word then)
         if (!(a == SPK_BIG && c == SPK_BIG)) spk_union(lab, a >= 0 ? a : row * wp + x, c >= 0 ? c : (row + 1) * wp + x, S.err);
       }
     };
-    int qn = 0;
-    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
-      int va[SPK_NS], vb[SPK_NS], pa[SPK_NS], pb[SPK_NS];
+    for (int row = wave; row < nr - 1; row += SPK_THREADS / 64) {
+      if (use_msk) {
+        const unsigned long long mv = row_masks(row);
 #pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const int x = (s0 + k) * 64 + lane;
-        const bool in = x < w;
-        va[k] = in ? da[x] : FILTERED16; vb[k] = in ? db[x] : FILTERED16;
-        pa[k] = (in && x > 0) ? da[x - 1] : FILTERED16; pb[k] = (in && x > 0) ? db[x - 1] : FILTERED16;
-      }
-#pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const bool lk = ccl_linked(va[k], vb[k], range);
-        const bool covered = ccl_linked(pa[k], pb[k], range) && ccl_linked(pa[k], va[k], range) && ccl_linked(pb[k], vb[k], range);
-        const bool on = lk && !covered;
-        const unsigned long long m = __ballot(on);
-        if (m == 0) continue;
-        const int c = __popcll(m);
-        if (qn + c > 64) { flush(qn); qn = 0; }
-        if (on) q[qn + __popcll(m & lt_mask)] = (s0 + k) * 64 + lane;
-        qn += c;
+        for (int k = 0; k < SPK_NS; ++k) enqueue(spk_readlane64(mv, 0 * SPK_NS + k), 0ull, k * 64, row, flush);
+      } else {
+        const int16_t *da = dsp + row * wp, *db = da + wp;
+        for (int seg = 0; seg < nseg; ++seg) {
+          const int x = seg * 64 + lane;
+          const bool in = x < w;
+          const int va = in ? da[x] : FILTERED16, vb = in ? db[x] : FILTERED16;
+          const int pa = (in && x > 0) ? da[x - 1] : FILTERED16, pb = (in && x > 0) ? db[x - 1] : FILTERED16;
+          const bool lk = ccl_linked(va, vb, range);
+          const bool covered = ccl_linked(pa, pb, range) && ccl_linked(pa, va, range) && ccl_linked(pb, vb, range);
+          enqueue(__ballot(lk && !covered), 0ull, seg * 64, row, flush);
+        }
       }
     }
-    flush(qn);
+    flush(qn); qn = 0;
   }
   __syncthreads();
   SPK_STAMP(3);
   // ---- count: the last pixel of a run adds the run to its root
   const bool nb_top = y0 > 0, nb_bot = y1 < h;
-  for (int row = wave; row < nr; row += SPK_THREADS / 64) {
-    const int16_t *d = dsp + row * wp;
-    const int *l = lab + row * wp;
-    const bool edge_row = (row == 0 && nb_top) || (row == nr - 1 && nb_bot);
-    auto flush = [&](int qn) {
-      if (lane < qn) {
-        const int e = q[lane], x = e & 0xffff;
-        const int st = (e >> 16) ? row * wp + x : l[x];      // (the word of a start pixel is a root / parent word, not a start index)
+  {
+    auto flush = [&](int n_) {
+      if (lane < n_) {
+        const int e = q[lane], x = e & 0xfff, row = e >> 16;
+        const int st = ((e >> 12) & 1) ? row * wp + x : lab[row * wp + x];      // (the word of a start pixel is a root / parent word, not a start index)
         const int root = spk_find(lab, st, S.err);
         if (root >= 0) {
           if ((~lab[root] & (SPK_TOUCH - 1)) <= window) atomicSub(&lab[root], row * wp + x - st + 1);      // ~(V + len) = ~V - len
-          if (edge_row) atomicAnd(&lab[root], ~SPK_TOUCH);                                                    // sets the mark in V
+          if ((row == 0 && nb_top) || (row == nr - 1 && nb_bot)) atomicAnd(&lab[root], ~SPK_TOUCH);            // sets the mark in V
         }
       }
     };
-    int qn = 0;
-    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
-      int dv[SPK_NS], dl[SPK_NS], dr[SPK_NS], lv[SPK_NS];
+    for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+      if (use_msk) {
+        const unsigned long long mv = row_masks(row);
 #pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const int x = (s0 + k) * 64 + lane;
-        const bool in = x < w;
-        dv[k] = in ? d[x] : FILTERED16; lv[k] = in ? l[x] : SPK_BIG + 1;
-        dl[k] = (in && x > 0) ? d[x - 1] : FILTERED16; dr[k] = (in && x + 1 < w) ? d[x + 1] : FILTERED16;
-      }
-#pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const bool on = dv[k] != FILTERED16 && lv[k] != SPK_BIG && !ccl_linked(dv[k], dr[k], range);      // last pixel of a run that is not big
-        const unsigned long long m = __ballot(on);
-        if (m == 0) continue;
-        const int c = __popcll(m);
-        if (qn + c > 64) { flush(qn); qn = 0; }
-        if (on) q[qn + __popcll(m & lt_mask)] = ((s0 + k) * 64 + lane) | ((ccl_linked(dv[k], dl[k], range) ? 0 : 1) << 16);
-        qn += c;
+        for (int k = 0; k < SPK_NS; ++k) enqueue(spk_readlane64(mv, 1 * SPK_NS + k), spk_readlane64(mv, 3 * SPK_NS + k), k * 64, row, flush);
+      } else {
+        const int16_t *d = dsp + row * wp;
+        const int *l = lab + row * wp;
+        for (int seg = 0; seg < nseg; ++seg) {
+          const int x = seg * 64 + lane;
+          const bool in = x < w;
+          const int dv = in ? d[x] : FILTERED16, lv = in ? l[x] : SPK_BIG + 1;
+          const int dl = (in && x > 0) ? d[x - 1] : FILTERED16, dr = (in && x + 1 < w) ? d[x + 1] : FILTERED16;
+          const bool on = dv != FILTERED16 && lv != SPK_BIG && !ccl_linked(dv, dr, range);      // last pixel of a run that is not big
+          enqueue(__ballot(on), __ballot(!ccl_linked(dv, dl, range)), seg * 64, row, flush);
+        }
       }
     }
-    flush(qn);
+    flush(qn); qn = 0;
   }
   __syncthreads();
   SPK_STAMP(4);
@@ -890,17 +936,15 @@ __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(Stere
   __shared__ unsigned s_pmask[2][SPK_MAX_SEG * 2];            // undecided pixels of the first / last row
   for (int i = tid; i < 2 * SPK_MAX_SEG * 2; i += SPK_THREADS) (&s_pmask[0][0])[i] = 0u;
   __syncthreads();
-  for (int row = wave; row < nr; row += SPK_THREADS / 64) {
-    int16_t *d = dsp + row * wp;
-    const int *l = lab + row * wp;
-    auto flush = [&](int qn) {
-      if (lane < qn) {
-        const int e = q[lane], x = e & 0xffff, idx = row * wp + x;
-        const int root = spk_find(lab, (e >> 16) ? idx : l[x], S.err);
+  {
+    auto flush = [&](int n_) {
+      if (lane < n_) {
+        const int e = q[lane], x = e & 0xfff, row = e >> 16, idx = row * wp + x;
+        const int root = spk_find(lab, ((e >> 12) & 1) ? idx : lab[idx], S.err);
         if (root >= 0) {                                      // else: joined BIG
           const int V = ~lab[root];
           if ((V & (SPK_TOUCH - 1)) <= window) {
-            if (!(V & SPK_TOUCH)) d[x] = (int16_t)FILTERED16;
+            if (!(V & SPK_TOUCH)) dsp[idx] = (int16_t)FILTERED16;
             else {                                            // undecided: decided after the strips have been united
               const int rrow = root / wp, node = (y0 + rrow) * w + (root - rrow * wp);      // frame index of the root pixel
               if (root == idx) { S.label[fbase + node] = node; S.count[fbase + node] = 0; }
@@ -916,28 +960,23 @@ __global__ __launch_bounds__(SPK_THREADS) void stereo_speckle_strip_kernel(Stere
         }
       }
     };
-    int qn = 0;
-    for (int s0 = 0; s0 < nseg; s0 += SPK_NS) {
-      int dv[SPK_NS], dl[SPK_NS], lv[SPK_NS];
+    for (int row = wave; row < nr; row += SPK_THREADS / 64) {
+      if (use_msk) {
+        const unsigned long long mv = row_masks(row);
 #pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const int x = (s0 + k) * 64 + lane;
-        const bool in = x < w;
-        dv[k] = in ? d[x] : FILTERED16; lv[k] = in ? l[x] : SPK_BIG + 1;
-        dl[k] = (in && x > 0) ? d[x - 1] : FILTERED16;
-      }
-#pragma unroll
-      for (int k = 0; k < SPK_NS; ++k) {
-        const bool on = dv[k] != FILTERED16 && lv[k] != SPK_BIG;
-        const unsigned long long m = __ballot(on);
-        if (m == 0) continue;
-        const int c = __popcll(m);
-        if (qn + c > 64) { flush(qn); qn = 0; }
-        if (on) q[qn + __popcll(m & lt_mask)] = ((s0 + k) * 64 + lane) | ((ccl_linked(dv[k], dl[k], range) ? 0 : 1) << 16);
-        qn += c;
+        for (int k = 0; k < SPK_NS; ++k) enqueue(spk_readlane64(mv, 2 * SPK_NS + k), spk_readlane64(mv, 3 * SPK_NS + k), k * 64, row, flush);
+      } else {
+        const int16_t *d = dsp + row * wp;
+        const int *l = lab + row * wp;
+        for (int seg = 0; seg < nseg; ++seg) {
+          const int x = seg * 64 + lane;
+          const bool in = x < w;
+          const int dv = in ? d[x] : FILTERED16, lv = in ? l[x] : SPK_BIG + 1, dl = (in && x > 0) ? d[x - 1] : FILTERED16;
+          enqueue(__ballot(dv != FILTERED16 && lv != SPK_BIG), __ballot(!ccl_linked(dv, dl, range)), seg * 64, row, flush);
+        }
       }
     }
-    flush(qn);
+    flush(qn); qn = 0;
   }
   __syncthreads();
   SPK_STAMP(5);
@@ -1037,16 +1076,16 @@ extern "C" int svs_stereo_create(svs_ctx *ctx, int w, int h, int max_batch, cons
   // SPK_THREADS concurrent adds stay below the mark bit
   {
     const int wp = (w + 3) & ~3;
-    int strip_kb = 150;
-    { const char *e = getenv("SVS_STEREO_STRIP_KB"); if (e && atoi(e) >= 8 && atoi(e) <= 150) strip_kb = atoi(e); }      // experiment: smaller strips, more workgroups per CU
-    const int rows = std::min(h, (strip_kb * 1024) / (6 * wp));
+    int strip_kb = 151;                                  // dynamic LDS of a strip; the kernel's static arrays take 6 KB of the CU's 160 KB
+    { const char *e = getenv("SVS_STEREO_STRIP_KB"); if (e && atoi(e) >= 8 && atoi(e) <= 151) strip_kb = atoi(e); }      // experiment: smaller strips, more workgroups per CU
+    const int rows = std::min(h, (strip_kb * 1024) / spk_row_bytes(w));
     if (rows >= 16 && w <= 64 * SPK_MAX_SEG && (size_t)rows * w < (1u << 24) && (long long)(SPK_THREADS + 1) * std::max(prm->speckle_window, w) < SPK_TOUCH) {
       s->strip_rows = rows; s->n_strips = div_up(h, rows);
       SVS_HIP(ctx, hipMalloc(&s->d_brow, sizeof(int32_t) * 2 * (size_t)s->n_strips * w * max_batch));
       SVS_HIP(ctx, hipMalloc(&s->d_pend, sizeof(int2) * n));
       SVS_HIP(ctx, hipMalloc(&s->d_npend, sizeof(int32_t) * ((size_t)max_batch * s->n_strips + 32)));
       SVS_HIP(ctx, hipMemset(s->d_npend, 0, sizeof(int32_t) * ((size_t)max_batch * s->n_strips + 32)));
-      SVS_HIP(ctx, hipFuncSetAttribute((const void *)stereo_speckle_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rows * wp * 6));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)stereo_speckle_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rows * spk_row_bytes(w)));
     }
   }
   *out = s;
@@ -1099,7 +1138,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   const dim3 gp(div_up(n, 256), n_batch);
   if (ccl && s->strip_rows > 0 && !s->force_frame_ccl) {
     S.strip_rows = s->strip_rows; S.n_strips = s->n_strips; S.brow = s->d_brow; S.pend = s->d_pend; S.npend = s->d_npend; S.err = s->d_npend + (((size_t)s->max_batch * s->n_strips + 1) & ~(size_t)1); S.timing = s->debug;
-    hipLaunchKernelGGL(stereo_speckle_strip_kernel, dim3(s->n_strips, n_batch), dim3(SPK_THREADS), (size_t)s->strip_rows * ((w + 3) & ~3) * 6, ctx->stream, S, d_disp, dstride, d_bstride);
+    hipLaunchKernelGGL(stereo_speckle_strip_kernel, dim3(s->n_strips, n_batch), dim3(SPK_THREADS), (size_t)s->strip_rows * spk_row_bytes(w), ctx->stream, S, d_disp, dstride, d_bstride);
     SVS_LAUNCH_CHECK(ctx);
     if (s->n_strips > 1) {
       hipLaunchKernelGGL(stereo_speckle_merge_kernel, dim3(s->n_strips - 1, n_batch), dim3(256), 0, ctx->stream, S);
