@@ -580,7 +580,8 @@ int svs_ba_reset_state(svs_ba *ba, const double *h_poses, const double *h_psi);
 int svs_ba_reduced_system(svs_ba *ba, double lambda, double *h_Hred /* (6P)^2 full sym */,
                           double *h_bred /* 6P */, double *h_chi2);
 /* what the last svs_ba_set_problem led to: solve_kind 0 = global-memory blocked Cholesky, 1 = LDS-window pipeline, 2 = fused
-   register-resident elimination (one front), 3 = the same with two fronts, 4 = multi-workgroup blocked Cholesky; envelope_rows = widest filled block row of the reduced
+   register-resident elimination (one front), 3 = the same with two fronts, 4 = multi-workgroup blocked Cholesky (one block row per step, trailing matrix in global memory; option "no_tile_solve"), 5 = multi-workgroup
+   tile-resident blocked Cholesky (24 x 24 tiles owned by workgroups in LDS: the default for wide envelopes); envelope_rows = widest filled block row of the reduced
    system (+1); wave chunks of the Schur kernel; landmarks with more than 64 observations */
 int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide);
 /* the solve's pose order (what LinearSolverCSparse's block ordering is to the reference, slam_graph.cpp:1063-1074): envelope_rows above is that of the order the solve

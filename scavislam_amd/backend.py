@@ -221,7 +221,8 @@ class SlamGraphOptimizer:
         self.ctx.check(self.ctx.lib.svs_ba_set_comm(self.h, comm.h if comm is not None else None))
 
     SOLVE_KINDS = ("global-memory blocked Cholesky", "LDS-window pipeline", "fused register-resident elimination, one front",
-                   "fused register-resident elimination, two fronts", "multi-workgroup blocked Cholesky (wide envelope)")
+                   "fused register-resident elimination, two fronts", "multi-workgroup blocked Cholesky (wide envelope)",
+                   "multi-workgroup tile-resident blocked Cholesky (wide envelope)")
 
     def info(self):
         k, r, c, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

@@ -35,6 +35,7 @@ namespace {
 
 #include "ba_schur.inc"
 #include "ba_solve.inc"
+#include "ba_solve_tiles.inc"
 // expands the packed upper blocks to a full symmetric matrix + bred (parity tests)
 __global__ void ba_expand_kernel(BaDev B, double *__restrict__ Hfull, double *__restrict__ bred) {
   const int P = B.P, n = 6 * P;
@@ -119,7 +120,7 @@ class HostPool {
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
   int no_order = 0;      // "no_order": keep the caller's pose order in the solve (A/B partner of the fill-reducing order)
-  int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, debug = 0;
+  int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, no_tile_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
   int host_marshal = 0;                 // svs_ba_set_problem: 0 = by size (device route from 30k edges), 1 = always on the host (rounds 1-2), 2 = always on the device
 };
@@ -171,6 +172,7 @@ struct svs_ba {
   int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   unsigned *d_gridbar = nullptr; int grid_G = 0;      // multi-workgroup solve: arrival counter + failure flag, number of workgroups (0 = not used)
+  double *d_tilews = nullptr; size_t cap_tilews = 0; int tiles_G = 0, tiles_S = 0, tiles_tpw = 0, tiles_gq = 0, tiles_ncm = 0;      // tile-resident variant of it (ba_solve_tiles.inc): workspace, grid, tile rows, own tiles per workgroup (tiles_G = 0: not used)
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
   int ctl_iters = 0;
   std::vector<hipEvent_t> spec_ev;      // 6 events per speculative trial
@@ -289,6 +291,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->d_xfer) (void)hipFree(ba->d_xfer);
   if (ba->d_flags) (void)hipFree(ba->d_flags);
   if (ba->d_gridbar) (void)hipFree(ba->d_gridbar);
+  if (ba->d_tilews) (void)hipFree(ba->d_tilews);
   if (ba->w_store) (void)hipFree(ba->w_store);
   if (ba->w_pose_tab) (void)hipFree(ba->w_pose_tab);
   if (ba->w_point_tab) (void)hipFree(ba->w_point_tab);
@@ -850,6 +853,31 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
     }
     const size_t smem_g = sizeof(double) * ((size_t)P * 36 + 36 + 6 * (size_t)P);
     if (smem_g > 64 * 1024) SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
+    // the tile-resident blocked Cholesky where its tiles fit the workgroups' LDS (ba_solve_tiles.inc); the kernel above otherwise (and as the A/B switch "no_tile_solve")
+    ba->tiles_G = 0;
+    if (!ba->opt.no_tile_solve) {
+      const int S = div_up(P, TS_M);
+      int gq = 1;
+      while ((gq + 1) * (gq + 1) <= ctx->n_cu - 48) ++gq;      // square workgroup grid: tile (I, J) belongs to workgroup (I mod gq, J mod gq).  One workgroup per CU, and a
+                                                               // fifth of the CUs stays free: the latency-mode tracker of the front end (eight 512-lane workgroups at 180 registers:
+                                                               // nothing fits beside them) goes through the spin gate's priority lane and must find room at once -- measured with
+                                                               // two threads on one GPU: p99 of a frame 0.67 ms with 196 of 256 CUs taken, 1.2-1.5 ms with 225
+      if (ba->opt.grid_g > 0) { gq = 1; while ((gq + 1) * (gq + 1) <= std::min(ba->opt.grid_g, ctx->n_cu)) ++gq; }      // experiments only      // square workgroup grid: tile (I, J) belongs to workgroup (I mod gq, J mod gq).  One workgroup per CU, and 16+
+                                                               // CUs stay free: a latency-mode frame of the front end (<= 16 workgroups, the spin gate's priority lane) must find room at once
+      const int G = gq * gq, per = div_up(S, gq), tpw = per * (per + 1) / 2;      // own tiles at most: the upper triangle of a per x per block
+      const int ncm = 2 * per;                            // the rows and the columns of a per x per block of tiles
+      if (tpw <= TS_MAXT && ncm <= 2 * TS_MAXT && ts_lds_bytes(tpw, ncm) <= 158 * 1024) {
+        const size_t want = sizeof(double) * ts_ws_doubles(S);
+        if (!ba->d_tilews || ba->cap_tilews < want) {
+          if (ba->d_tilews) (void)hipFree(ba->d_tilews);
+          ba->d_tilews = nullptr; ba->cap_tilews = 0;
+          SVS_HIP(ctx, hipMalloc(&ba->d_tilews, want + want / 4));
+          ba->cap_tilews = want + want / 4;
+        }
+        SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ts_lds_bytes(tpw, ncm)));
+        ba->tiles_G = G; ba->tiles_S = S; ba->tiles_tpw = tpw; ba->tiles_gq = gq; ba->tiles_ncm = ncm;
+      }
+    }
   }
   ba->profile_ready = true;
   return SVS_OK;
@@ -992,6 +1020,14 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
     SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
     SvsSpinScope gate(ctx, ba->grid_G);      // grid-wide arrivals: one such launch on the device at a time (common.h)
     if (gate.rc) return gate.rc;
+    if (ba->tiles_G > 0) {
+      TilesArgs TA{};
+      const int S = ba->tiles_S;
+      TA.S = S; TA.tpw = ba->tiles_tpw; TA.gq = ba->tiles_gq; TA.ncm = ba->tiles_ncm;
+      TA.rowbuf = ba->d_tilews; TA.bbuf = TA.rowbuf + 2 * (size_t)S * TS_T; TA.ufac = TA.bbuf + 2 * TS_N; TA.ybuf = TA.ufac + (size_t)S * (S + 1) / 2 * TS_T;
+      TA.bar = ba->d_gridbar;
+      hipLaunchKernelGGL(ba_solve_tiles_kernel, dim3(ba->tiles_G), dim3(TS_THREADS), ts_lds_bytes(ba->tiles_tpw, ba->tiles_ncm), ctx->stream, B, x_solve, TA);
+    } else
     hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
     SVS_LAUNCH_CHECK(ctx);
   }
@@ -1250,6 +1286,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
   else if (n == "no_fused_cons") o.no_fused_cons = value != 0;
   else if (n == "no_grid_solve") o.no_grid_solve = value != 0;
+  else if (n == "no_tile_solve") o.no_tile_solve = value != 0;
   else if (n == "debug") o.debug = clamp(value, 0, 2);
   else if (n == "nw") o.nw = value == 0 ? 0 : clamp(value, 4, 8);
   else if (n == "p1") o.p1 = value < 0 ? -1 : clamp(value, 0, SOLVE_MAX_P);
@@ -1266,7 +1303,7 @@ extern "C" int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_ro
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->problem_valid);
   if (!ba->profile_ready) { const int rc = ensure_profile(ba, ba->comm ? svs_comm_allreduce_hook : nullptr, ba->comm); if (rc) return rc; }
-  if (solve_kind) *solve_kind = ba->use_fused_solve ? (ba->fuse_P1 > 0 ? 3 : 2) : (ba->use_lds_solve ? 1 : (ba->grid_G > 0 ? 4 : 0));
+  if (solve_kind) *solve_kind = ba->use_fused_solve ? (ba->fuse_P1 > 0 ? 3 : 2) : (ba->use_lds_solve ? 1 : (ba->grid_G > 0 ? (ba->tiles_G > 0 ? 5 : 4) : 0));
   if (envelope_rows) *envelope_rows = ba->env_R;
   if (n_chunks) *n_chunks = ba->n_chunks;
   if (n_wide) *n_wide = ba->n_wide;

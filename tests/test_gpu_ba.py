@@ -263,12 +263,13 @@ def _with_loop_closure(prob, i, j, rng):
 
 
 @pytest.mark.parametrize("case", ["fused_two_fronts", "fused_one_front", "lds_forced", "global_forced", "lds_wide_envelope",
-                                  "global_wide_envelope", "grid_wide_envelope", "ordered_loop_closure"])
+                                  "global_wide_envelope", "grid_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"])
 def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
-    """The reduced camera system is solved by one of four kernels depending on the width of its block envelope: the fused
+    """The reduced camera system is solved by one of five kernels depending on the width of its block envelope: the fused
     register-resident elimination (<= 10 block rows; two fronts when the window is long enough), the LDS-window pipeline
-    (<= 28 and it fits LDS), the multi-workgroup blocked Cholesky (wide envelopes), the one-workgroup global-memory blocked
-    Cholesky (narrow envelopes with the LDS variants switched off, or on request).  Each must give the oracle's update to 1e-6."""
+    (<= 28 and it fits LDS), the multi-workgroup tile-resident blocked Cholesky (wide envelopes; round 5) and the multi-workgroup
+    Cholesky by block rows it replaced (option "no_tile_solve"), the one-workgroup global-memory blocked Cholesky (narrow envelopes
+    with the LDS variants switched off, or on request).  Each must give the oracle's update to 1e-6."""
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.backend import SlamGraphOptimizer
@@ -277,10 +278,11 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     rng = np.random.default_rng(3)
     P = 40
     prob = synth.ba_window(P, 4000, seed=11, n_outer=2)
-    options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve", "global_wide_envelope": "no_grid_solve"}
+    options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve", "global_wide_envelope": "no_grid_solve",
+               "grid_rows_wide_envelope": "no_tile_solve"}
     if case == "lds_wide_envelope":
         prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows: too wide for the LDS window at P = 40 (194 KB), one workgroup
-    elif case in ("global_wide_envelope", "grid_wide_envelope", "ordered_loop_closure"):
+    elif case in ("global_wide_envelope", "grid_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"):
         prob = _with_loop_closure(prob, 0, P - 1, rng)       # full envelope: 40 block rows (one workgroup / spread over several)
     cam = _cam(prob["cam"])
     prm = BaParams.reference_defaults()
@@ -291,7 +293,8 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
         opt.set_option("no_order", 1)                        # these cases are about the kernels for wide envelopes: keep the caller's pose order
     opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
     expect = {"fused_two_fronts": "two fronts", "fused_one_front": "one front", "lds_forced": "LDS-window", "global_forced": "global-memory",
-              "lds_wide_envelope": "global-memory", "global_wide_envelope": "global-memory", "grid_wide_envelope": "multi-workgroup",
+              "lds_wide_envelope": "global-memory", "global_wide_envelope": "global-memory", "grid_wide_envelope": "multi-workgroup tile-resident",
+              "grid_rows_wide_envelope": "multi-workgroup blocked",
               "ordered_loop_closure": "LDS-window"}[case]      # (the same loop closure in the fill-reducing order: 40 -> 15 block rows, back in LDS)
     assert expect in opt.info()["solve_kernel"], opt.info()
     if case == "ordered_loop_closure":
@@ -384,11 +387,12 @@ def test_landmarks_with_64_observations(gpu_ctx):
     opt.close()
 
 
-def test_double_window_230_poses_wide_landmarks(gpu_ctx):
+@pytest.mark.parametrize("tiles", [True, False])
+def test_double_window_230_poses_wide_landmarks(gpu_ctx, tiles):
     """The reference's real window shape (data/newcollege.cfg:21-22, backend.cpp:141-144): 30 inner + 200 outer poses, all free
     (slam_graph.cpp:932), ~400 pose-pose constraints incl. two loop closures (slam_graph.cpp:937-981), active points observed from
     every window pose that sees them -- among them landmarks with 100 and 180 observations (no cap in slam_graph.cpp:1001-1027).
-    Reduced system <= 1e-10 and optimize <= 1e-6 vs the oracle; the wide envelope lands on the global-memory solve."""
+    Reduced system <= 1e-10 and optimize <= 1e-6 vs the oracle; the wide envelope (224 block rows) lands on the multi-workgroup solves: the tile-resident blocked Cholesky and, on request, the one by block rows."""
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.backend import SlamGraphOptimizer
@@ -401,7 +405,10 @@ def test_double_window_230_poses_wide_landmarks(gpu_ctx):
     cam = _cam(prob["cam"])
     prm = BaParams.reference_defaults()
     opt = SlamGraphOptimizer(ctx, stream)
+    if not tiles:
+        opt.set_option("no_tile_solve", 1)                   # the multi-workgroup Cholesky by block rows (rounds 3-4) instead of the tile-resident one
     opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+    assert ("tile-resident" in opt.info()["solve_kernel"]) == tiles, opt.info()
     H, b, chi2 = opt.reduced_system(50.0)
     H_ref, b_ref = O.ba_reduced_system(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm, 50.0)
     np.testing.assert_allclose(H, H_ref, rtol=0, atol=1e-10 * np.abs(H_ref).max())

@@ -4,6 +4,7 @@ window (50 keyframes / 20 k landmarks) and on the 30 + 200 double window with lo
 GuidedMatcher::match, backend.cpp:735-779).  Each thread has its OWN svs_ctx (its own HIP stream and scratch), as include/scavislam_hip.h asks.
 
 Used by tests/test_gpu_concurrency.py (results under contention == results of the serial runs, no SVS_ERR_BUSY) and by bench.py (both latencies under contention)."""
+import os
 import threading
 import time
 
@@ -106,6 +107,9 @@ class BackendLoop:
         for name in ("inner", "double"):
             p = wl[name]
             o = SlamGraphOptimizer(self.ctx, self.stream)
+            for kv in os.environ.get("SVS_TT_BA_OPTIONS", "").split(","):      # experiments: "grid_g=144,no_tile_solve=1"
+                if "=" in kv:
+                    o.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             o.copyDataToG2o(p["poses"], p["psi"], p["edges"], p["cons"], p["cam"])
             self.opts[name] = o
         # re-registration (backend.cpp:735-779): the root keyframe's corners at ITS stored thresholds, candidates matched into it
