@@ -570,7 +570,7 @@ int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi);
    (test hook). */
 int svs_ba_set_comm(svs_ba *ba, svs_comm *comm);
 /* experiment / test switches of one optimizer (0 = default behaviour): "no_speculation", "one_front", "no_fused_solve",
-   "no_lds_solve", "no_grid_solve", "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
+   "no_lds_solve", "no_grid_solve", "no_tile_solve" (wide envelopes: the multi-workgroup Cholesky by block rows instead of the tile-resident one), "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
    "p1" (rows of the reversed front), "group" (anchors dealt round-robin), "host_threads", "host_marshal" (svs_ba_set_problem: 0 = device marshalling from
    8k edges, 1 = always host, 2 = always device).  The environment (SVS_BA_*,
    SVS_HOST_THREADS) only supplies the initial values, read once by svs_ba_create; values are clamped to their valid ranges. */
