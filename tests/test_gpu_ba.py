@@ -263,7 +263,7 @@ def _with_loop_closure(prob, i, j, rng):
 
 
 @pytest.mark.parametrize("case", ["fused_two_fronts", "fused_one_front", "lds_forced", "global_forced", "lds_wide_envelope",
-                                  "global_wide_envelope", "grid_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"])
+                                  "global_wide_envelope", "grid_wide_envelope", "grid_p45_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"])
 def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     """The reduced camera system is solved by one of five kernels depending on the width of its block envelope: the fused
     register-resident elimination (<= 10 block rows; two fronts when the window is long enough), the LDS-window pipeline
@@ -276,13 +276,13 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     from scavislam_amd.ctypes_types import BaParams
     ctx, stream = gpu_ctx
     rng = np.random.default_rng(3)
-    P = 40
+    P = 45 if case == "grid_p45_wide_envelope" else 40      # (45 poses: the last 24 x 24 tile row of the tile-resident solve is padded by three identity blocks)
     prob = synth.ba_window(P, 4000, seed=11, n_outer=2)
     options = {"fused_one_front": "one_front", "lds_forced": "no_fused_solve", "global_forced": "no_lds_solve", "global_wide_envelope": "no_grid_solve",
                "grid_rows_wide_envelope": "no_tile_solve"}
     if case == "lds_wide_envelope":
         prob = _with_loop_closure(prob, 5, 27, rng)          # envelope of 23 block rows: too wide for the LDS window at P = 40 (194 KB), one workgroup
-    elif case in ("global_wide_envelope", "grid_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"):
+    elif case in ("global_wide_envelope", "grid_wide_envelope", "grid_p45_wide_envelope", "grid_rows_wide_envelope", "ordered_loop_closure"):
         prob = _with_loop_closure(prob, 0, P - 1, rng)       # full envelope: 40 block rows (one workgroup / spread over several)
     cam = _cam(prob["cam"])
     prm = BaParams.reference_defaults()
@@ -294,7 +294,7 @@ def test_every_solve_variant_matches_oracle(gpu_ctx, monkeypatch, case):
     opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
     expect = {"fused_two_fronts": "two fronts", "fused_one_front": "one front", "lds_forced": "LDS-window", "global_forced": "global-memory",
               "lds_wide_envelope": "global-memory", "global_wide_envelope": "global-memory", "grid_wide_envelope": "multi-workgroup tile-resident",
-              "grid_rows_wide_envelope": "multi-workgroup blocked",
+              "grid_p45_wide_envelope": "multi-workgroup tile-resident", "grid_rows_wide_envelope": "multi-workgroup blocked",
               "ordered_loop_closure": "LDS-window"}[case]      # (the same loop closure in the fill-reducing order: 40 -> 15 block rows, back in LDS)
     assert expect in opt.info()["solve_kernel"], opt.info()
     if case == "ordered_loop_closure":
