@@ -780,11 +780,14 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
   for (int k = 0; k < P; ++k) R = std::max(R, rowmax[k] - k + 1);
   ba->env_R = R;                                    // (of the order the solve runs in)
   // LDS budget of the window solve: rhs + R*R window + 2 x (Z, Y) panels + U_kk + 1/diag + z + scratch + envelope + block LUT
-  const size_t need = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + (size_t)P * 42 + 16 + 128 + (size_t)R * 6) +
-                      sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
-  ba->use_lds_solve = need <= 150 * 1024 && R * 36 <= 64 * PIPE_LD && !ba->opt.no_lds_solve;
+  // (the fused kernel keeps U_kk of all rows in LDS: P * 42 doubles; the window kernel only the current row's, the rest in global memory)
+  const size_t need_common = sizeof(double) * ((size_t)6 * P + (size_t)R * R * 36 + 4 * (size_t)R * 36 + 16 + 128 + (size_t)R * 6) +
+                             sizeof(int) * (size_t)P + (size_t)R * (R - 1) + 16;
+  const size_t need_lds = need_common + sizeof(double) * 48, need_fused = need_common + sizeof(double) * (size_t)P * 42;
+  ba->use_lds_solve = need_lds <= 150 * 1024 && R * 36 <= 64 * PIPE_LD && !ba->opt.no_lds_solve;
+  ba->use_fused_solve = ba->use_lds_solve && need_fused <= 150 * 1024 && R <= FUSE_SLOTS && !ba->opt.no_fused_solve;
+  const size_t need = ba->use_fused_solve ? need_fused : need_lds;
   ba->lds_solve_smem = need;
-  ba->use_fused_solve = ba->use_lds_solve && R <= FUSE_SLOTS && !ba->opt.no_fused_solve;
   // two-front elimination (fused kernel only): front 1 takes the last P1 block rows in reversed order.  Balance: front 0
   // needs front 1's deltas when it reaches row P_top-(R-1), i.e. after P - P1 - (R-1) stages; front 1 needs P1 stages + the hand-over.
   ba->fuse_P1 = 0;
@@ -1014,7 +1017,8 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
                        ba->d_rowmax2, ba->env_R, F);
   }
   else if (ba->use_lds_solve)
-    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax, ba->env_R);
+    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax, ba->env_R,
+                       ba->d_upanel + (36 * (size_t)ba->P * std::max(ba->env_R, FUSE_SLOTS) + 128));      // U_kk of all rows: the second front's half of the panel buffer (unused by this kernel)
   else if (ba->grid_G > 0) {
     const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
     SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
