@@ -535,9 +535,10 @@ def dense_pixel_terms_full(cloud, prev, cur, dx, dy, f, cx, cy, T34_colmajor):
     return out
 
 
-def dense_tracking_gpu(cloud, prev, cur, dx, dy, f, cx, cy, T, sum_mode=SUM_F64):
+def dense_tracking_gpu(cloud, prev, cur, dx, dy, f, cx, cy, T, sum_mode=SUM_F64, force=None):
     """DenseTracker::denseTrackingGpu restated (dense_tracking.cpp:60-193).  cloud/prev/cur/dx/dy: lists of 3 level
-    arrays; f, cx, cy: per-level intrinsics.  Returns (T 3x4, passes, records [n][4], T_jac [3][3][4])."""
+    arrays; f, cx, cy: per-level intrinsics.  Returns (T 3x4, passes, records [n][4], T_jac [3][3][4]).
+    force: optional {record index: 0 / 1} -- take that accept decision at that record instead of the loop's own (near-ties, tests only)."""
     cloud = [np.ascontiguousarray(a, np.float32) for a in cloud]
     prev, cur, dx, dy = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (prev, cur, dx, dy)]
     w = (C.c_int * 3)(*[c.shape[1] for c in cloud])
@@ -549,13 +550,16 @@ def dense_tracking_gpu(cloud, prev, cur, dx, dy, f, cx, cy, T, sum_mode=SUM_F64)
     nrec = C.c_int(0)
     Tj = np.zeros((3, 12))
     L = lib()
-    L.svs_ref_dense_tracking_gpu.restype = C.c_int
-    L.svs_ref_dense_tracking_gpu.argtypes = None
-    passes = L.svs_ref_dense_tracking_gpu(
+    L.svs_ref_dense_tracking_gpu_forced.restype = C.c_int
+    L.svs_ref_dense_tracking_gpu_forced.argtypes = None
+    fo = np.full(256, -1, np.int32)
+    for k, v in (force or {}).items():
+        fo[int(k)] = int(v)
+    passes = L.svs_ref_dense_tracking_gpu_forced(
         P3(*[a.ctypes.data for a in cloud]), w, P3(*[a.ctypes.data for a in prev]), P3(*[a.ctypes.data for a in cur]),
         P3(*[a.ctypes.data for a in dx]), P3(*[a.ctypes.data for a in dy]), w, w, h,
         D3(*[float(v) for v in f]), D3(*[float(v) for v in cx]), D3(*[float(v) for v in cy]), _p(T), C.c_int(int(sum_mode)),
-        _p(rec), C.c_int(256), C.byref(nrec), _p(Tj))
+        _p(rec), C.c_int(256), C.byref(nrec), _p(Tj), _p(fo), C.c_int(256))
     return T.reshape(3, 4), passes, rec[:nrec.value].copy(), Tj.reshape(3, 3, 4)
 
 
@@ -984,7 +988,7 @@ class RefSequence:
     SCAVISLAM_HIP_SUPPORT branch in place, its arithmetic on the GPU).  Nothing of the keyframe logic is stubbed: processFirstFrame, processFrame, shallWeSwitchKeyframe,
     shallWeDropNewKeyframe, addNewKeyframe, addNewPoints / addMorePoints, recomputeFastCorners are the reference's lines (stereo_frontend.cpp:39-528,656-1065)."""
 
-    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011, one_call=False, stereo_input=False):
+    def __init__(self, cams, hip_branch=False, use_n_levels=3, sample_seed=2011, one_call=False, stereo_input=False, heap_jitter_seed=0):
         """one_call (with hip_branch): libsvs_hipbranch_seq_onecall.so -- processFrame's body from the dense tracker to the return of matchAndTrack is ONE
         svs_frontend_process_frame (the binding bench.py times); otherwise one library call per switch point of the reference"""
         if hip_branch:
@@ -1013,6 +1017,8 @@ class RefSequence:
         L.svs_refseq_set_var.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.svs_refseq_nudge.argtypes = [C.c_void_p, C.c_double]
         self.cams = cams
+        L.svs_refseq_heap_jitter.argtypes = [C.c_uint]
+        L.svs_refseq_heap_jitter(int(heap_jitter_seed))      # 0 (default): the arena's fixed addresses; else: another run's heap (yardstick, see heap_jitter)
         self.h = L.svs_refseq_create(cams, use_n_levels, C.cast(lib().svs_ref_fast9_16, C.c_void_p), sample_seed)
 
     def set_var(self, name, value):
@@ -1066,6 +1072,10 @@ class RefSequence:
         n, ng = int(meta[1]), int(meta[2])
         return dict(kept_slot=int(meta[3]), kept_pose=poses[:12].copy(), T_guess=poses[12:24].copy(), T_act=poses[24:36].copy(), pts=pts[:n].copy(), group_end=ge[:ng].copy(),
                     res=res, matches=m[:n].copy(), recloud=bool(meta[4]), recloud_pose=poses[36:48].copy())
+
+    def heap_jitter(self, seed):
+        """(CPU build) from now on the objects the reference orders by heap address land at pseudo-randomly padded addresses: another run of the same binary (yardstick)"""
+        self.L.svs_refseq_heap_jitter(int(seed))
 
     def nudge(self, rel):
         """scales the translation of T_cur_from_actkey by (1 + rel) between two frames (the yardstick of tests/test_gpu_sequence.py)"""

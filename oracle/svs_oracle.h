@@ -254,6 +254,11 @@ int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3]
                                const int fstride[3], const int w[3], const int h[3], const double f[3],
                                const double cx[3], const double cy[3], double T[12], int sum_mode, double *rec, int rec_cap,
                                int *n_rec, double *T_jac);
+int svs_ref_dense_tracking_gpu_forced(const float *const cloud[3], const int stride4[3], const float *const prev[3],
+                               const float *const cur[3], const float *const dx[3], const float *const dy[3],
+                               const int fstride[3], const int w[3], const int h[3], const double f[3],
+                               const double cx[3], const double cy[3], double T[12], int sum_mode, double *rec, int rec_cap,
+                               int *n_rec, double *T_jac, const int *force, int n_force);
 /* FrameGrabber::preprocessing, CUDA build (frame_grabber.cpp:291-313,102-115); OpenCV gpu semantics ASSUMED, see vision.c */
 void svs_ref_pyr_down_f32(const float *src, int w, int h, int sstride, float *dst, int dstride);
 void svs_ref_deriv_replicate(const float *img, int w, int h, int stride, float *dx, float *dy, int dstride);

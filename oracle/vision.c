@@ -733,11 +733,13 @@ void svs_ref_residual_image_full(const float *cloud, int w, int h, int s4, const
    the trial}; T_jac (optional [3][12]): the pose of the last jacobianReduction of each level, which is the pose the
    reference renders residualImage with (:177-186 pass gpuT_cur_from_prev, not the final pose).  Returns the number of
    kernel passes the reference would have launched. */
-int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3], const float *const prev[3],
+/* force (optional, n_force entries indexed like rec): -1 = the loop's own decision, 0 / 1 = take this decision at that record instead (tests: a near-tie of
+   `chi2 - new_chi2` may legitimately fall the other way in another summation order -- the test then follows that branch through the SAME loop) */
+int svs_ref_dense_tracking_gpu_forced(const float *const cloud[3], const int stride4[3], const float *const prev[3],
                                const float *const cur[3], const float *const dx[3], const float *const dy[3],
                                const int fstride[3], const int w[3], const int h[3], const double f[3],
                                const double cx[3], const double cy[3], double *T, int sum_mode, double *rec, int rec_cap,
-                               int *n_rec, double *T_jac) {
+                               int *n_rec, double *T_jac, const int *force, int n_force) {
   int passes = 0, nr = 0;
 #define SVS_REC(l, a, c0, c1) do { if (rec && nr < rec_cap) { rec[4 * nr] = (l); rec[4 * nr + 1] = (a); rec[4 * nr + 2] = (c0); rec[4 * nr + 3] = (c1); } ++nr; } while (0)
   for (int l = 2; l >= 0; --l) {
@@ -773,6 +775,7 @@ int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3]
         ++passes;
         const float new_chi2 = (float)s2.chi2;
         rho = chi2 - new_chi2;                      /* float - float, then widened (:142) */
+        if (force && nr < n_force && force[nr] >= 0) rho = force[nr] ? fabs(rho) + 1e-30 : -fabs(rho);      /* (tests only) */
         SVS_REC(l, rho > 0 ? 1 : 0, chi2, new_chi2);
         if (rho > 0) {
           memcpy(T, Tn, sizeof(double) * 12);
@@ -798,6 +801,13 @@ int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3]
 #undef SVS_REC
   if (n_rec) *n_rec = nr;
   return passes;
+}
+int svs_ref_dense_tracking_gpu(const float *const cloud[3], const int stride4[3], const float *const prev[3],
+                               const float *const cur[3], const float *const dx[3], const float *const dy[3],
+                               const int fstride[3], const int w[3], const int h[3], const double f[3],
+                               const double cx[3], const double cy[3], double *T, int sum_mode, double *rec, int rec_cap,
+                               int *n_rec, double *T_jac) {
+  return svs_ref_dense_tracking_gpu_forced(cloud, stride4, prev, cur, dx, dy, fstride, w, h, f, cx, cy, T, sum_mode, rec, rec_cap, n_rec, T_jac, 0, 0);
 }
 
 /* FrameGrabber::preprocessing, CUDA build (frame_grabber.cpp:291-313): level 0 = gpu convertTo(CV_32F, 1/255.),

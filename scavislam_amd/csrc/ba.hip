@@ -860,16 +860,18 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
     ba->tiles_G = 0;
     if (!ba->opt.no_tile_solve) {
       const int S = div_up(P, TS_M);
+      // square workgroup grid: tile (I, J) belongs to workgroup (I mod gq, J mod gq), one workgroup per CU.  A fifth of the CUs stays free for the front end's
+      // latency-mode frame (eight 512-lane workgroups at 180 registers: nothing fits beside them on a CU), which takes the spin gate's priority lane while its
+      // workgroups + these fit the device together (image.hip) -- two threads on one GPU: p99 of a frame 0.67 ms with 196 of 256 CUs taken, 1.2-1.5 ms with 225
       int gq = 1;
-      while ((gq + 1) * (gq + 1) <= ctx->n_cu - 48) ++gq;      // square workgroup grid: tile (I, J) belongs to workgroup (I mod gq, J mod gq).  One workgroup per CU, and a
-                                                               // fifth of the CUs stays free: the latency-mode tracker of the front end (eight 512-lane workgroups at 180 registers:
-                                                               // nothing fits beside them) goes through the spin gate's priority lane and must find room at once -- measured with
-                                                               // two threads on one GPU: p99 of a frame 0.67 ms with 196 of 256 CUs taken, 1.2-1.5 ms with 225
-      if (ba->opt.grid_g > 0) { gq = 1; while ((gq + 1) * (gq + 1) <= std::min(ba->opt.grid_g, ctx->n_cu)) ++gq; }      // experiments only      // square workgroup grid: tile (I, J) belongs to workgroup (I mod gq, J mod gq).  One workgroup per CU, and 16+
-                                                               // CUs stay free: a latency-mode frame of the front end (<= 16 workgroups, the spin gate's priority lane) must find room at once
+      while ((gq + 1) * (gq + 1) <= ctx->n_cu - 48) ++gq;
+      if (ba->opt.grid_g > 0) { gq = 1; while ((gq + 1) * (gq + 1) <= std::min(ba->opt.grid_g, ctx->n_cu)) ++gq; }      // experiments only
       const int G = gq * gq, per = div_up(S, gq), tpw = per * (per + 1) / 2;      // own tiles at most: the upper triangle of a per x per block
       const int ncm = 2 * per;                            // the rows and the columns of a per x per block of tiles
-      if (tpw <= TS_MAXT && ncm <= 2 * TS_MAXT && ts_lds_bytes(tpw, ncm) <= 158 * 1024) {
+      // the tiles must fit the LDS a workgroup of THIS device can have (gfx950: 160 KB): the runtime is asked, and a part that refuses (64 KB of LDS) keeps the grid
+      // kernel above instead of failing the whole call
+      if (tpw <= TS_MAXT && ncm <= 2 * TS_MAXT && ts_lds_bytes(tpw, ncm) <= 158 * 1024 &&
+          hipFuncSetAttribute((const void *)ba_solve_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ts_lds_bytes(tpw, ncm)) == hipSuccess) {
         const size_t want = sizeof(double) * ts_ws_doubles(S);
         if (!ba->d_tilews || ba->cap_tilews < want) {
           if (ba->d_tilews) (void)hipFree(ba->d_tilews);
@@ -877,7 +879,6 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
           SVS_HIP(ctx, hipMalloc(&ba->d_tilews, want + want / 4));
           ba->cap_tilews = want + want / 4;
         }
-        SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ts_lds_bytes(tpw, ncm)));
         ba->tiles_G = G; ba->tiles_S = S; ba->tiles_tpw = tpw; ba->tiles_gq = gq; ba->tiles_ncm = ncm;
       }
     }
@@ -1022,7 +1023,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   else if (ba->grid_G > 0) {
     const size_t smem_g = sizeof(double) * ((size_t)ba->P * 36 + 36 + 6 * (size_t)ba->P);
     SVS_HIP(ctx, hipMemsetAsync(ba->d_gridbar, 0, sizeof(unsigned) * (32 * GRID_NBAR + 4), ctx->stream));      // arrival counter + failure flag of this launch (a speculative
-    SvsSpinScope gate(ctx, ba->grid_G);      // grid-wide arrivals: one such launch on the device at a time (common.h)
+    SvsSpinScope gate(ctx, ba->tiles_G > 0 ? ba->tiles_G : ba->grid_G);      // grid-wide arrivals; the size of the launch that is really made (grid_G is 8..16 where tiles_G is 196)
     if (gate.rc) return gate.rc;
     if (ba->tiles_G > 0) {
       TilesArgs TA{};
@@ -1034,6 +1035,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
     } else
     hipLaunchKernelGGL(ba_solve_grid_kernel, dim3(ba->grid_G), dim3(SOLVE_THREADS), smem_g, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_gridbar, 0u);      // launch may be skipped, so the counter starts at 0 every time)
     SVS_LAUNCH_CHECK(ctx);
+    if (int grc = gate.leave()) return grc;
   }
   else
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(SOLVE_THREADS), smem_fallback, ctx->stream, B, x_solve, ba->d_linv, ba->d_rowmax, ba->d_colmin);

@@ -37,10 +37,14 @@ struct svs_ctx {
   int trk_seq_chi2 = 0;       // "trk_seq_chi2": the quarter-grid tracker decides accept / reject on the reference's own sequential f32 chi2 sums (dense.hip; slow: parity runs)
   int trk_lazy_chi2 = 1;      // "trk_lazy_chi2" (default): the same decisions at full speed -- the f64 sums decide wherever their difference is outside the rigorous error bound of the
                               // reference's float sums, and inside it the float sums are formed bit for bit without the sequential chain (seqsum.h).  0: f64 sums alone (rounds 1-4)
+  int trk_flat = 1;           // "trk_flat": big batches run the flat state-machine tracker kernel (dense.hip, round 6: the sweep inlined, LM state in LDS); 0: the round-5 kernel (sweep as a call) -- same bits
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
   void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)
+  hipEvent_t lane_ev = nullptr;      // the same behind my latest priority-lane launch
   bool spin_lane = false;            // the launch between the last svs_spin_enter and its svs_spin_leave took the priority lane
+  int spin_demand = 0;               // compute units that launch may hold (one per workgroup)
+  long long spin_n_lane = 0, spin_n_gated = 0;      // svs_ctx_get_stat "spin_lane_launches" / "spin_gated_launches"
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // Kernels whose workgroups wait for each other INSIDE one launch (the latency-mode trackers, the multi-workgroup Cholesky) size their grids to a device they have
@@ -49,13 +53,17 @@ struct svs_ctx {
 // bounded spins give up (SVS_ERR_BUSY).  The reference runs exactly this concurrency: the front end on the main thread, optimize + re-registration on the backend
 // thread (stereo_slam.cpp:196, backend.cpp:157-224), so the library keeps at most ONE of them on the device at a time: a launch between svs_spin_enter / svs_spin_leave
 // first makes its stream wait for the event the previous device-filling launch of ANOTHER context left behind (stream-side; the host does not block), then leaves its own.
-int svs_spin_enter(svs_ctx *ctx, int n_workgroups = 0);      // n_workgroups <= 16: the priority lane (image.hip) -- no wait, no gate
+// n_workgroups: the REAL size of the launch (0: the whole device).  Small launches (<= 16 workgroups) skip the gate while they provably fit beside everything of this
+// kind that is in flight (image.hip: the invariant and its book-keeping).
+int svs_spin_enter(svs_ctx *ctx, int n_workgroups = 0);
 int svs_spin_leave(svs_ctx *ctx);
-// the pair as a scope: the gate is left (mutex released, event recorded behind whatever was launched inside) on EVERY way out of the scope, an early return included
+// the pair as a scope.  Normal path: `if (int rc = gate.leave()) return rc;` right behind the launch (the event record can fail, and then the NEXT context's launch would
+// run ungated without anybody knowing); the destructor is the safety net of the early returns only.
 struct SvsSpinScope {
-  svs_ctx *ctx; int rc;
-  SvsSpinScope(svs_ctx *c, int n_workgroups = 0) : ctx(c), rc(svs_spin_enter(c, n_workgroups)) {}
-  ~SvsSpinScope() { if (!rc) (void)svs_spin_leave(ctx); }
+  svs_ctx *ctx; int rc; bool open;
+  SvsSpinScope(svs_ctx *c, int n_workgroups = 0) : ctx(c), rc(svs_spin_enter(c, n_workgroups)), open(rc == 0) {}
+  int leave() { if (!open) return SVS_OK; open = false; return svs_spin_leave(ctx); }
+  ~SvsSpinScope() { if (open) (void)svs_spin_leave(ctx); }
   SvsSpinScope(const SvsSpinScope &) = delete;
   SvsSpinScope &operator=(const SvsSpinScope &) = delete;
 };

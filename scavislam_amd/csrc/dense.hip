@@ -765,7 +765,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (passes_out == reinterpret_cast<int *>(1)) { volatile int big[SVS_SCRATCH_PROBE]; for (int i = 0; i < SVS_SCRATCH_PROBE; ++i) big[i] = i; T_io[0] = big[threadIdx.x % SVS_SCRATCH_PROBE]; }
 #endif
   constexpr int TM = SEQ ? 1 : (SVS_TRK_LAZY ? (MULTI ? 2 : 1) : 0);      // the terms of a pass: plain stores, or past the caches when sibling workgroups read them
-  unsigned n_exact = 0;
+  unsigned n_exact = 0, n_decisions = 0;      // exact float sums formed by this workgroup; (MULTI) accept decisions the leader has published so far
   const int slot = BAL ? (bal_entry >> 4) : (MULTI ? blockIdx.y : blockIdx.x), wg = BAL ? (bal_entry & 15) : (MULTI ? blockIdx.x : 0);
   const int nwg = !MULTI ? 1 : (BAL ? (int)G.nwg_of[slot] : (int)gridDim.x);
   const int first = wg * TRK_THREADS + threadIdx.x;
@@ -914,11 +914,47 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
         const bool near = SVS_TRK_LAZY && tb[0] && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));      // (terms_only: kernel A/B -- the stores without the sums)
         if (near) {
           float seq_new = 0.f;
+          // MULTI: the stream's LEADER workgroup forms the sums and its siblings take its word (G.bcast [13]: both sums, [14]: how many such decisions have been
+          // published).  (a) the sums were formed eight times over from terms read past the caches (round 5: 0.075 ms of a latency-mode frame); (b) ADVICE round 5: the
+          // term buffers are not double-buffered against the NEXT sweep -- a sibling that went on while a slower one was still reading would overwrite what that one
+          // reads.  Now nobody starts the next sweep before the only reader is done.
+          const bool shared_decision = MULTI && !solo && nwg > 1;
+          if (!shared_decision || wg == 0) {
 #pragma nounroll
-          for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {      // (one copy of the routine in the kernel: it is long)
-            const float v = exact_seq_sum_f32<MULTI>(tb[k ? cur ^ 1 : cur], n_lvl);
-            if (k) seq_new = v; else seq_old = v;
-            ++n_exact;
+            for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {      // (one copy of the routine in the kernel: it is long)
+              const float v = exact_seq_sum_f32<MULTI>(tb[k ? cur ^ 1 : cur], n_lvl);
+              if (k) seq_new = v; else seq_old = v;
+              ++n_exact;
+            }
+          }
+          if constexpr (MULTI) {
+            if (shared_decision) {
+              ++n_decisions;
+              unsigned long long *word = reinterpret_cast<unsigned long long *>(G.bcast + (size_t)slot * 16 + 13);
+              unsigned *epoch = reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 14);
+              if (wg == 0) {
+                if (threadIdx.x == 0) {
+                  const unsigned long long w = ((unsigned long long)__float_as_uint(seq_old) << 32) | (unsigned long long)__float_as_uint(seq_new);
+                  __hip_atomic_store(word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  __hip_atomic_store(epoch, n_decisions, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              } else {
+                __shared__ unsigned long long s_word;
+                if (threadIdx.x == 0) {
+                  long spin = 0;
+                  for (; spin < (1l << 24) && __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_decisions; ++spin) __builtin_amdgcn_s_sleep(1);
+                  if (spin >= (1l << 24)) { __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = true; }
+                  s_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (s_failed) { failed = true; break; }
+                const unsigned long long w = s_word;
+                if (!seq_old_ok) seq_old = __uint_as_float((unsigned)(w >> 32));
+                seq_new = __uint_as_float((unsigned)w);
+                __syncthreads();                       // (s_word is rewritten at the next decision)
+              }
+            }
           }
           seq_old_ok = true;
           chi2 = seq_old; new_chi2 = seq_new;
@@ -963,6 +999,172 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (A.T_jac && threadIdx.x < 36) A.T_jac[(size_t)slot * 36 + threadIdx.x] = s_Tj[threadIdx.x / 12][threadIdx.x % 12];
   if (threadIdx.x == 0 && G.seq_stats && n_exact) {
     atomicAdd(G.seq_stats, n_exact);
+    if (SVS_TRK_LAZY && g_seq_sh.fell_back) atomicAdd(G.seq_stats + 1, 1u);
+  }
+}
+
+// ---- big batches, round 6: the LM loop as a flat state machine around ONE inlined sweep ------------------------------------------------------------------------
+// dense_track_cpu_sem_kernel<., false, 4> calls its sweep (track_pass_call): the sweep fills the 128-register budget by itself, so as a callee it saves and restores every
+// callee-saved register it touches -- 29 dwords per lane and call, 59 KB per workgroup each way, 18 calls per frame: 0.55 GB written (and read back) per 512-stream batch for
+// nothing (round 5's rocprof: WRITE_SIZE 996 MB against 0.34 GB of terms).  Inlining it into the level / iteration loops was worse: everything those loops keep alive (sums,
+// flags, buffers: uniform values the compiler cannot prove uniform) shared the sweep's allocation and spilled inside the loop over the samples.
+// Here the LM state of the stream lives in LDS (TrkState: one lane writes it, everybody reads what it needs), the kernel is ONE loop { sweep; step }, and nothing of the step
+// is alive while the sweep runs: no call on the hot path, no callee-saved traffic, no spills in the sweep.  Same sweep, same sums, same solve, same decisions as the kernel
+// above: bit-identical results (tests/test_gpu_frontend.py::test_flat_tracker_kernel_is_bit_identical).
+struct TrkState {
+  double S_old; float chi2, seq_old;
+  int level, it, cur, passes, n_rec, nv_old, seq_old_ok, phase;      // phase 0: the sweep just run was the level's first (chi2 + H,b at the accepted pose); 1: a trial
+  unsigned n_exact;
+};
+__shared__ TrkState g_ts;
+template <bool U8SRC>
+__device__ __forceinline__ void track_pass_from_lds() {      // the body of track_pass_call, inlined: operands out of g_pa into scalar registers
+  LevelArgsG L;
+  L.cloud = (const SVS_AS1 float *)uni_ptr(g_pa.L.cloud); L.prev = (const SVS_AS1 uint8_t *)uni_ptr(g_pa.L.prev);
+  L.cur = (const SVS_AS1 float *)uni_ptr(g_pa.L.cur); L.dx = (const SVS_AS1 float *)uni_ptr(g_pa.L.dx); L.dy = (const SVS_AS1 float *)uni_ptr(g_pa.L.dy);
+  L.cur8 = (const SVS_AS1 uint8_t *)uni_ptr(g_pa.L.cur8);
+  L.pstride = uni_i32(g_pa.L.pstride); L.fstride = uni_i32(g_pa.L.fstride); L.c8stride = uni_i32(g_pa.L.c8stride);
+  L.cam.f = uni_f64(g_pa.L.cam.f); L.cam.cx = uni_f64(g_pa.L.cam.cx); L.cam.cy = uni_f64(g_pa.L.cam.cy); L.cam.b = 0;
+  L.cam.w = uni_i32(g_pa.L.cam.w); L.cam.h = uni_i32(g_pa.L.cam.h);
+  track_pass<true, U8SRC, SVS_TRK_LAZY ? 1 : 0, LevelArgsG>(L, g_pa.T, g_s_part, g_s_out, g_iplut, (int)threadIdx.x, 1, uni_ptr(g_pa.t_buf));
+}
+// the solve of an iteration, on wave 0 (seven lanes): H.ldlt().solve(-Jres), undamped (dense_tracking.cpp:332) + exp(x) * T.  A function of its own, called by ONE
+// wave: its 70-odd live doubles are not part of the kernel's allocation, and whatever it saves on entry it saves for 64 lanes, not 512.
+__shared__ double g_sT[12], g_sTn[12], g_sx[6], g_sH[27], g_sTj[3][12];
+__device__ __noinline__ void track_solve_call() {
+  const int lane = threadIdx.x;
+  double col[6], x[6], Tc[12], Tn[12];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int lo = r < lane ? r : lane, hi = r < lane ? lane : r;      // packed upper by column: (lo, hi) at hi (hi + 1) / 2 + lo
+    col[r] = lane < 6 ? g_sH[hi * (hi + 1) / 2 + lo] : (lane == 6 ? -g_sH[21 + r] : (r == 0 ? 1.0 : 0.0));
+  }
+  wave_solve6(col, x);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Tc[i] = g_sT[i];
+  mo2_exp_mul(x, Tc, Tn);
+  if (lane < 12) {
+    double v = Tn[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) v = lane == i ? Tn[i] : v;
+    g_sTn[lane] = v;
+  }
+  if (lane < 6) {
+    double v = x[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) v = lane == i ? x[i] : v;
+    g_sx[lane] = v;
+  }
+}
+template <bool U8SRC, bool BAL>
+__global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
+  int slot = blockIdx.x;
+  if constexpr (BAL) {
+    const int e = G.map[blockIdx.x];
+    if (e < 0 || (e & 15) != 0) return;      // idle workgroup / a sibling entry of a table made for the split variant
+    slot = e >> 4;
+  }
+  const int tid = threadIdx.x;
+  float *const tb0 = G.terms ? G.terms + (size_t)slot * 2 * G.terms_b : nullptr;
+  // level set-up (one lane): the operands of the level's sweeps, the first one at the accepted pose into term buffer 0
+  auto enter_level = [&](int level) {
+    LevelArgs L = A.lv[level];
+    L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
+    if (U8SRC) L.cur8 += slot * A.c8_b[level];
+    else { L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level]; }
+    g_pa.L = L; g_pa.wg = 0; g_pa.nwg = 1; g_pa.t_buf = tb0;
+    g_ts.level = level; g_ts.phase = 0; g_ts.cur = 0; g_ts.it = 0;
+  };
+  if (tid < 12) { const double v = T_io[(size_t)slot * 12 + tid]; g_sT[tid] = v; g_pa.T[tid] = v; }
+  for (int i = tid; i < 256; i += TRK_THREADS) g_iplut[i] = (float)((1. / 255.) * i);
+  if (tid == 0) {
+    g_seq_sh.fell_back = 0;
+    g_ts.passes = 0; g_ts.n_rec = 0; g_ts.n_exact = 0;
+    enter_level(2);
+  }
+  __syncthreads();
+#pragma nounroll
+  for (;;) {
+    track_pass_from_lds<U8SRC>();                  // (ends in a barrier: g_s_out is complete)
+    // ---- the LM step: every lane reads the state, one lane writes it back
+    const int level = g_ts.level, phase = g_ts.phase, cur = g_ts.cur, n_rec = g_ts.n_rec;
+    const int n_lvl = (A.lv[level].cam.w / 4) * (A.lv[level].cam.h / 4);
+    bool level_done;
+    if (phase == 0) {                              // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+      const double S = g_s_out[27];
+      const float chi2 = (float)S;
+      __syncthreads();                             // (everybody has read g_s_out / the state)
+      if (tid < 27) g_sH[tid] = g_s_out[tid];
+      if (tid == 0) {
+        g_ts.S_old = S; g_ts.nv_old = (int)g_s_out[NSUM]; g_ts.chi2 = chi2; g_ts.seq_old_ok = 0; g_ts.seq_old = 0.f;
+        ++g_ts.passes; ++g_ts.n_rec;
+        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
+      }
+      level_done = false;
+    } else {                                       // new_chi2 (:335-367) + H,b for the next iteration
+      const double S_old = g_ts.S_old, S_new = g_s_out[27];
+      const int nv_old = g_ts.nv_old, nv_new = (int)g_s_out[NSUM];
+      float chi2 = g_ts.chi2, new_chi2, seq_old = g_ts.seq_old;
+      int seq_old_ok = g_ts.seq_old_ok;
+      unsigned n_exact = 0;
+      bool accept;
+      // the reference compares two float sums of n terms each: |sum_float - sum_exact| <= ((1 + 2^-24)^(n - 1) - 1) sum_exact.  Outside that band the f64 sums decide as
+      // the float sums would; inside it the float sums are formed, bit for bit (exact_seq_sum_f32)
+      const double gam = 1.0001 * (double)max(nv_old, nv_new) * 5.9604644775390625e-08 + 1e-12;
+      const bool near = SVS_TRK_LAZY && tb0 && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));
+      if (near) {
+        float seq_new = 0.f;
+#pragma nounroll
+        for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {
+          const float v = exact_seq_sum_f32<false>(tb0 + (size_t)((k ? cur ^ 1 : cur)) * G.terms_b, n_lvl);
+          if (k) seq_new = v; else seq_old = v;
+          ++n_exact;
+        }
+        seq_old_ok = 1;
+        chi2 = seq_old; new_chi2 = seq_new;
+        accept = (double)chi2 - (double)new_chi2 > 0;
+        if (accept) seq_old = seq_new;
+      } else {
+        new_chi2 = (float)S_new;
+        accept = S_old > S_new;
+        if (accept) seq_old_ok = 0;
+      }
+      double mx = -1;
+      for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(g_sx[q]));
+      const int it = g_ts.it + 1;
+      level_done = !accept || mx <= 1e-10 || it >= 15;
+      __syncthreads();                             // (everybody has read g_s_out / the state / g_sx)
+      if (accept) {
+        if (tid < 12) g_sT[tid] = g_sTn[tid];
+        if (tid < 27) g_sH[tid] = g_s_out[tid];
+      }
+      if (tid == 0) {
+        if (accept) { g_ts.S_old = S_new; g_ts.nv_old = nv_new; g_ts.cur = cur ^ 1; g_ts.chi2 = new_chi2; }
+        g_ts.seq_old = seq_old; g_ts.seq_old_ok = seq_old_ok; g_ts.it = it; g_ts.n_exact += n_exact;
+        ++g_ts.passes; ++g_ts.n_rec;
+        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, accept ? 1 : 0, chi2, new_chi2};
+      }
+    }
+    __syncthreads();                               // the state, g_sT and g_sH are those of the accepted pass
+    if (level_done) {
+      if (level == 0) break;
+      if (tid == 0) enter_level(level - 1);
+      if (tid >= 64 && tid < 76) g_pa.T[tid - 64] = g_sT[tid - 64];
+    } else {                                       // the next trial: solve at the accepted pose, sweep at the trial pose into the other term buffer
+      if (tid >= 64 && tid < 76) g_sTj[level][tid - 64] = g_sT[tid - 64];      // the reference's H,b pass of this iteration ran at the accepted pose
+      if (tid < 64) track_solve_call();
+      __syncthreads();
+      if (tid < 12) g_pa.T[tid] = g_sTn[tid];
+      if (tid == 12) { g_pa.t_buf = tb0 ? tb0 + (size_t)(g_ts.cur ^ 1) * G.terms_b : nullptr; g_ts.phase = 1; }
+    }
+    __syncthreads();
+  }
+  if (tid < 12) T_io[(size_t)slot * 12 + tid] = g_sT[tid];
+  if (tid == 0 && passes_out) passes_out[slot] = g_ts.passes;
+  if (tid == 0 && A.n_rec) A.n_rec[slot] = g_ts.n_rec;
+  if (A.T_jac && tid < 36) A.T_jac[(size_t)slot * 36 + tid] = g_sTj[tid / 12][tid % 12];
+  if (tid == 0 && G.seq_stats && g_ts.n_exact) {
+    atomicAdd(G.seq_stats, g_ts.n_exact);
     if (SVS_TRK_LAZY && g_seq_sh.fell_back) atomicAdd(G.seq_stats + 1, 1u);
   }
 }
@@ -1244,7 +1446,11 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     SVS_LAUNCH_CHECK(ctx);
-  } else {                          // order only: one workgroup per stream, nothing waits for anything
+    if (int grc = gate.leave()) return grc;
+  } else if (ctx->trk_flat) {       // order only: one workgroup per stream, nothing waits for anything -- the flat kernel (round 6), bit-identical to the one below
+    if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_batch_kernel<false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+  } else {
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   }
@@ -1336,8 +1542,12 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     SVS_LAUNCH_CHECK(ctx);
+    if (int grc = gate.leave()) return grc;
   } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
     return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state, G);
+  } else if (((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) && ctx->trk_flat) {
+    if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    else hipLaunchKernelGGL((dense_track_batch_kernel<false, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

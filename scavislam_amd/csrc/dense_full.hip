@@ -839,6 +839,7 @@ extern "C" int svs_dense_track_full(svs_ctx *ctx, const svs_dense_track_full_arg
     if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
     else hipLaunchKernelGGL((dense_track_full_kernel<false, true>), dim3(nwg * batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
     SVS_LAUNCH_CHECK(ctx);
+    if (int grc = gate.leave()) return grc;
   } else {
     if (fuse) hipLaunchKernelGGL((dense_track_full_kernel<true, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);
     else hipLaunchKernelGGL((dense_track_full_kernel<false, false>), dim3(batch), dim3(FULL_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out);

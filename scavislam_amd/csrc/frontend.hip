@@ -497,6 +497,9 @@ int frontend_take_device_frames(svs_frontend *fe, const svs_frames_dev *in) {
   SVS_REQUIRE(ctx, in->d_left && in->lstride >= w && (fe->B == 1 || in->l_bstride >= (size_t)h * in->lstride));
   SVS_REQUIRE(ctx, fe->prm.use_block_matching ? (in->d_right && in->rstride >= w) : (in->d_disp && in->dstride >= w));
   SVS_REQUIRE(ctx, in->lstride % 4 == 0 && (!in->d_right || in->rstride % 4 == 0));
+  // "frames are complete when this event has fired, recorded on whichever stream": every read of the caller's buffers on the context's stream comes behind it -- the
+  // right-image copy below, the first pyramid step of the unpipelined chain and of svs_frontend_first_frames (the pipelined chain waits on its side stream as well)
+  if (in->ready_event) SVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, static_cast<hipEvent_t>(in->ready_event), 0));
   const dim3 grid(div_up(w / 4, 256), h, fe->B);
   // the left image is taken into the level-0 buffer by the first pyramid step (frontend_chain): one read of the frame instead of two
   fe->ext_left = in->d_left != fe->d_pyr[fe->i_cur][0] ? in->d_left : nullptr;

@@ -3,41 +3,81 @@
 // the CPU path's convertTo(CV_32F,1/255.) + Sobel(ksize=1).  Integer path is bit-exact to the
 // OpenCV 2.4.2 semantics restated in SURVEY.md A.2; HBM-bound stencils, LDS-tiled.
 #include "common.h"
+#include <algorithm>
 #include <mutex>
+#include <vector>
 #include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct SpinGate { std::mutex m; hipEvent_t last = nullptr; svs_ctx *owner = nullptr; };
-SpinGate g_spin_gate[64];      // per device, process-wide
+// Per device, process-wide.  `last` = the event behind the latest launch that went THROUGH the gate, `last_cus` the compute units that launch may hold; `lanes` = the latest
+// priority-lane launch of every other context (its event + its compute units).  All of it is touched under `m`, which a context holds from svs_spin_enter to
+// svs_spin_leave (host side of one launch: microseconds -- nobody ever blocks on device work while holding it).
+struct SpinLane { svs_ctx *c; hipEvent_t ev; int cus; };
+struct SpinGate { std::mutex m; hipEvent_t last = nullptr; svs_ctx *owner = nullptr; int last_cus = 0; std::vector<SpinLane> lanes; };
+SpinGate g_spin_gate[64];
 SpinGate &gate_of(const svs_ctx *c) { return g_spin_gate[(unsigned)c->device % 64u]; }
 }  // namespace
-// n_workgroups: the size of the launch that is about to be made.  A launch of at most SVS_SPIN_SMALL workgroups takes the PRIORITY LANE: it neither waits for the gate
-// nor closes it.  Such a launch (the latency-mode tracker of one camera stream: 8 workgroups) finds room beside whatever fills the device -- every CU keeps wave slots
-// and LDS free next to a workgroup of the multi-workgroup Cholesky -- so it cannot take part in the mutual starvation the gate exists to prevent, and without the lane a
-// real-time frame queued behind a whole 5.8 ms grid solve of the back-end thread (two threads, one GPU: p99 of the frame 6.1 ms).
+// The invariant the gate keeps: the workgroups of all kernels in flight whose workgroups wait for each other INSIDE the launch fit the device TOGETHER, counted at one
+// whole compute unit per workgroup (the latency-mode trackers: 512 lanes at 180+ registers, nothing fits beside one on a CU; the tile-resident Cholesky: > 80 KB of LDS
+// each).  Then every one of them becomes resident whatever the dispatcher does, and none can starve another.
+//  * n_workgroups: the size of the launch that is about to be made (0: unknown -- the whole device).
+//  * A launch of at most SVS_SPIN_SMALL workgroups may take the PRIORITY LANE: it neither waits for the gate nor closes it -- but only while the invariant holds WITH it:
+//    its workgroups + those of the gated launch still in flight (event not yet fired) + those of the other contexts' lane launches still in flight <= #CUs.  (Rounds 4-5
+//    assumed that; a 16-workgroup grid solve beside a full-device tracker did not fit the assumption.)  Otherwise it goes through the gate like everything else.
+//  * A gated launch waits (stream-side) for the previous gated launch of another context, and for the other contexts' lane launches if it does not fit beside them.
+// Why the lane exists: a real-time frame of the front end (one camera stream: 8 workgroups) queued behind a whole 5.8 ms grid solve of the back-end thread -- two
+// threads, one GPU: p99 of the frame 6.1 ms; with the lane 0.66 ms (the tile solve leaves 60 of 256 CUs free for exactly this).
 constexpr int SVS_SPIN_SMALL = 16;
 int svs_spin_enter(svs_ctx *c, int n_workgroups) {
-  c->spin_lane = n_workgroups > 0 && n_workgroups <= SVS_SPIN_SMALL;
-  if (c->spin_lane) return SVS_OK;
   SpinGate &g = gate_of(c);
+  const int demand = n_workgroups > 0 ? std::min(n_workgroups, c->n_cu) : c->n_cu;
   g.m.lock();                    // held until svs_spin_leave: the order of the launches is the order of the chain
-  if (g.last && g.owner != c) {
-    const hipError_t e = hipStreamWaitEvent(c->stream, g.last, 0);
-    if (e != hipSuccess) { g.m.unlock(); c->err = std::string("svs_spin_enter: hipStreamWaitEvent -> ") + hipGetErrorString(e); return SVS_ERR_HIP; }
+  // lane launches that have finished no longer count
+  for (size_t i = 0; i < g.lanes.size();) {
+    if (g.lanes[i].c != c && hipEventQuery(g.lanes[i].ev) == hipErrorNotReady) ++i;
+    else if (g.lanes[i].c == c) ++i;                                   // my own: ordered behind by my stream (kept for the others to see; replaced at leave)
+    else { g.lanes[i] = g.lanes.back(); g.lanes.pop_back(); }
   }
+  int lanes_busy = 0;
+  for (const SpinLane &l : g.lanes) if (l.c != c) lanes_busy += l.cus;
+  const bool gated_busy = g.last && g.owner != c && hipEventQuery(g.last) == hipErrorNotReady;
+  (void)hipGetLastError();       // (hipErrorNotReady is an answer, not an error to be found by the next SVS_LAUNCH_CHECK)
+  c->spin_demand = demand;
+  c->spin_lane = n_workgroups > 0 && n_workgroups <= SVS_SPIN_SMALL && demand + lanes_busy + (gated_busy ? g.last_cus : 0) <= c->n_cu;
+  if (c->spin_lane) { ++c->spin_n_lane; return SVS_OK; }
+  ++c->spin_n_gated;
+  hipError_t e = hipSuccess;
+  if (g.last && g.owner != c) e = hipStreamWaitEvent(c->stream, g.last, 0);
+  if (demand + lanes_busy > c->n_cu)
+    for (const SpinLane &l : g.lanes) if (l.c != c && e == hipSuccess) e = hipStreamWaitEvent(c->stream, l.ev, 0);
+  if (e != hipSuccess) { g.m.unlock(); c->err = std::string("svs_spin_enter: hipStreamWaitEvent -> ") + hipGetErrorString(e); return SVS_ERR_HIP; }
   return SVS_OK;
 }
 int svs_spin_leave(svs_ctx *c) {
-  if (c->spin_lane) { c->spin_lane = false; return SVS_OK; }
   SpinGate &g = gate_of(c);
   hipError_t e = hipSuccess;
-  if (!c->spin_ev) e = hipEventCreateWithFlags(&c->spin_ev, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(c->spin_ev, c->stream);
-  if (e == hipSuccess) { g.last = c->spin_ev; g.owner = c; }
+  hipEvent_t &ev = c->spin_lane ? c->lane_ev : c->spin_ev;
+  if (!ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
+  if (e == hipSuccess) {
+    if (c->spin_lane) {
+      bool found = false;
+      for (SpinLane &l : g.lanes) if (l.c == c) { l.ev = ev; l.cus = c->spin_demand; found = true; }
+      if (!found) g.lanes.push_back(SpinLane{c, ev, c->spin_demand});
+    } else { g.last = ev; g.owner = c; g.last_cus = c->spin_demand; }
+  }
+  c->spin_lane = false;
   g.m.unlock();
   if (e != hipSuccess) { c->err = std::string("svs_spin_leave: ") + hipGetErrorString(e); return SVS_ERR_HIP; }
   return SVS_OK;
+}
+// a context that goes away takes its entries with it (its events are destroyed with it)
+static void spin_forget(svs_ctx *c) {
+  SpinGate &g = gate_of(c);
+  std::lock_guard<std::mutex> lk(g.m);
+  for (size_t i = 0; i < g.lanes.size();) { if (g.lanes[i].c == c) { g.lanes[i] = g.lanes.back(); g.lanes.pop_back(); } else ++i; }
+  if (g.owner == c) { g.last = nullptr; g.owner = nullptr; g.last_cus = 0; }
 }
 extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
   if (!out) return SVS_ERR_INVALID;
@@ -64,12 +104,9 @@ extern "C" int svs_ctx_create(int device, void *hip_stream, svs_ctx **out) {
 extern "C" int svs_ctx_destroy(svs_ctx *c) {
   if (!c) return SVS_OK;
   (void)hipStreamSynchronize(c->stream);
-  {
-    SpinGate &g = gate_of(c);
-    std::lock_guard<std::mutex> lk(g.m);
-    if (g.owner == c) { g.owner = nullptr; g.last = nullptr; }      // (the stream is drained: nobody needs to wait for this context any more)
-  }
+  spin_forget(c);                                                   // (the stream is drained: nobody needs to wait for this context any more)
   if (c->spin_ev) (void)hipEventDestroy(c->spin_ev);
+  if (c->lane_ev) (void)hipEventDestroy(c->lane_ev);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -118,6 +155,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "match_order") c->match_order = value != 0;
   else if (n == "fe_fuse_tail") c->fe_fuse_tail = value != 0;
   else if (n == "mo_spec") c->mo_spec = value != 0;
+  else if (n == "trk_flat") c->trk_flat = value != 0;
   else if (n == "trk_seq_chi2") c->trk_seq_chi2 = value != 0;
   else if (n == "trk_lazy_chi2") c->trk_lazy_chi2 = value > 2 ? 1 : value;      // (2: kernel A/B only -- the passes store their terms, the accept test stays on the f64 sums)
   else SVS_REQUIRE(c, !"unknown option");
@@ -126,6 +164,9 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
 extern "C" int svs_ctx_get_stat(svs_ctx *c, const char *name, long long *out) {
   SVS_REQUIRE(c, c && name && out);
   const std::string n(name);
+  // the spin gate's book-keeping of this context (host-side counters): launches that took the priority lane / that went through the gate
+  if (n == "spin_lane_launches") { *out = c->spin_n_lane; return SVS_OK; }
+  if (n == "spin_gated_launches") { *out = c->spin_n_gated; return SVS_OK; }
   SVS_REQUIRE(c, n == "trk_exact_sums" || n == "trk_exact_fallbacks");
   unsigned v[2] = {0, 0};
   if (c->seq_stats) {

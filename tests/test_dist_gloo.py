@@ -1,4 +1,4 @@
-"""world_size-2 (and 4) gloo test of the landmark-sharded BA path on CPU.
+"""world_size-2 (and 4, and 8 = BASELINE configs[3]'s shard count) gloo test of the landmark-sharded BA path on CPU.
 
 The HIP kernels cannot run here, so each rank builds its shard's partial reduced camera system with
 the CPU oracle (the checker) and the test exercises what is specific to N>1: the product's
@@ -56,7 +56,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_reduced_system_allreduce_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -207,7 +207,7 @@ def _p2p_worker(rank, world, port, q, one_device=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])      # 8: eight mailboxes per rank, multi-piece messages (4097 / 20000 doubles against 4096-double slots)
 def test_p2p_one_shot_transport_processes_on_one_gpu(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

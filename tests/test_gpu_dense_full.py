@@ -177,24 +177,37 @@ def test_single_pass_sums(gpu_ctx, case640, level):
     np.testing.assert_allclose(chi2, ref["chi2"], rtol=1e-9)
 
 
-def _oracle_track(case, T0):
+def _oracle_track(case, T0, force=None):
     import oracle as O
     cams = case["cams"]
     return O.dense_tracking_gpu(case["cloud"], case["fp"], case["fc"], case["dx"], case["dy"], [c["f"] for c in cams],
-                                [c["cx"] for c in cams], [c["cy"] for c in cams], T0, O.SUM_F64)
+                                [c["cx"] for c in cams], [c["cy"] for c in cams], T0, O.SUM_F64, force=force)
 
 
 def _check_track(case, T, passes, rec, Tj, label):
-    """device-resident LM of one stream vs the restated denseTrackingGpu loop"""
-    T_o, passes_o, rec_o, Tj_o = _oracle_track(case, I34)
-    trials = rec_o[rec_o[:, 1] < 2]
-    near_tie = np.abs(trials[:, 2] - trials[:, 3]) <= 2e-6 * np.abs(trials[:, 2])
+    """device-resident LM of one stream vs the restated denseTrackingGpu loop.
+
+    The CUDA build decides `float chi2 - float new_chi2 > 0` on block-tree sums (gpu/dense_tracking.cu:376-491); a trial whose two chi2 agree to 2e-6 may fall either
+    way in another summation order (SURVEY B-9).  Such a trial no longer ends the comparison: wherever the device took the OTHER decision than the oracle, that record must
+    be a near-tie IN THE ORACLE'S OWN RECORD, the oracle is re-run with that one decision forced, and the comparison goes on along that branch -- so every record, every
+    chi2 and the final pose are held to the oracle's loop on the branch the device really took (at most four forced near-ties)."""
     n_rec = len(rec)
     assert passes == n_rec, label                                    # one fused sweep per chi2 evaluation
-    if near_tie.any():                                               # accept / reject may legitimately flip (SURVEY B-9): report, compare loosely
-        print(f"{label}: {int(near_tie.sum())} near-tie trial(s) of {len(trials)}; trajectory not asserted")
-        assert np.abs(T - case["T_true"]).max() < 0.5 * np.abs(I34 - case["T_true"]).max()
-        return
+    force = {}
+    for attempt in range(5):
+        T_o, passes_o, rec_o, Tj_o = _oracle_track(case, I34, force)
+        m = min(n_rec, len(rec_o))
+        diff = np.nonzero(rec["accepted"][:m] != rec_o[:m, 1].astype(np.int32))[0]
+        if len(diff) == 0:
+            break
+        k = int(diff[0])
+        assert rec_o[k, 1] < 2 and abs(rec_o[k, 2] - rec_o[k, 3]) <= 2e-6 * abs(rec_o[k, 2]), \
+            f"{label}: record {k}: the device decided {int(rec['accepted'][k])}, the oracle {int(rec_o[k, 1])} on chi2 {rec_o[k, 2]!r} -> {rec_o[k, 3]!r}: not a near-tie"
+        assert attempt < 4, f"{label}: more than four near-ties decided the other way"
+        force[k] = int(rec["accepted"][k])
+    if force:
+        print(f"{label}: near-tie(s) at record(s) {sorted(force)} fell the other way on the device; compared along that branch of the oracle's loop")
+    trials = rec_o[rec_o[:, 1] < 2]
     assert n_rec == len(rec_o), f"{label}: {n_rec} chi2 evaluations vs {len(rec_o)}"
     assert np.array_equal(rec["level"], rec_o[:, 0].astype(np.int32)) and np.array_equal(rec["accepted"], rec_o[:, 1].astype(np.int32)), label
     # every sweep runs at the pose ROUNDED TO F32 (GpuMatrix34): a 1e-16 difference in the f64 pose (summation order) that

@@ -224,9 +224,10 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
     F = {n: frames(n) for n in ("kf", "prev", "cur")}
     T_guess, T_act = np.stack([s["T_guess"].reshape(12) for s in S]), np.stack([s["T_act"].reshape(12) for s in S])
 
-    def run(mode, pipeline=0):
+    def run(mode, pipeline=0, flat=1):
         ctx.set_option("trk_balance", mode)
         ctx.set_option("fe_pipeline", pipeline)
+        ctx.set_option("trk_flat", flat)
         try:
             fe = StereoFrontend(ctx, cam, max_points=1024, max_keyframes=3, params=prm, n_streams=B)
             fe.processFirstFrames(**F["kf"])
@@ -243,8 +244,19 @@ def test_tracker_grid_order_does_not_change_results(gpu_ctx):
         finally:
             ctx.set_option("trk_balance", 1)
             ctx.set_option("fe_pipeline", 1)
+            ctx.set_option("trk_flat", 1)
 
     base, order, split = run(0), run(1, 1), run(2)
+    # "trk_flat" (round 6): big batches run the flat state-machine kernel (the sweep inlined, the LM state in LDS: no callee-saved traffic around 18 calls per frame);
+    # 0 = the round-5 kernel (the sweep as a call).  Same sweep, sums, solve and decisions: every output bit-equal, in stream order and in the balanced order
+    for mode in (0, 1):
+        old = run(mode, 0, flat=0)
+        new = base if mode == 0 else order
+        for k in range(3):
+            for (o0, m0, g0), (o1, m1, g1) in zip(old[k][:-1], new[k][:-1]):
+                assert np.array_equal(np.array(o0.T_cur_from_actkey), np.array(o1.T_cur_from_actkey)) and o0.dense_passes == o1.dense_passes >= 0, ("trk_flat", mode, k)
+                assert m0.tobytes() == m1.tobytes() and g0.tobytes() == g1.tobytes() and bytes(o0.point_stats) == bytes(o1.point_stats), ("trk_flat", mode, k)
+            assert np.array_equal(old[k][-1][0], new[k][-1][0]) and np.array_equal(old[k][-1][1], new[k][-1][1]), ("trk_flat", mode, k)
     # the cross-frame pipeline ("fe_pipeline": the pyramid of frame N+1 on the side stream beside frame N's pose refinement / gate / cloud; the three frames above
     # are enqueued back to back only up to the blocking result reads -- here they are enqueued without a read in between, the bench's pattern)
     ready = torch.cuda.Event()

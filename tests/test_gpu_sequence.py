@@ -36,11 +36,11 @@ def _cams(camname):
 
 
 # What the sequence is held to: seq_common.compare for the hard, per-frame part; _check_strict for the rest -- no accepted point other than the reference's on any frame,
-# pose within 1e-6 on all but four frames (what is left: calcFastMotionOnly's own last steps are decided by the rounding of ITS chi2 sums -- f64, ~1e-14 -- and move
+# pose within 1e-6 on all but ONE frame and within 2e-6 on that one (what is left: calcFastMotionOnly's own last steps are decided by the rounding of ITS chi2 sums -- f64, ~1e-14 -- and move
 # the pose by ~1e-8 ... 1e-7; a keyframe dropped at such a frame keeps the offset in its world pose, and every later frame that matches points anchored in other
 # keyframes sees it).  Measured (profiles/r4_gpu_tests.txt, trk_seq_chi2 = 1): 200 / 199 of 200 frames within 1e-6, worst 1.1e-6.
 def _check_strict(st, n_frames, what):
-    assert st["other_points"] == 0 and st["frames_1e6"] >= n_frames - 4 and st["max_dT"] <= 5e-6, (what, st)
+    assert st["other_points"] == 0 and st["frames_1e6"] >= n_frames - 1 and st["max_dT"] <= 2e-6, (what, st)
 
 
 @pytest.mark.parametrize("camname,seq_chi2,one_call", [("default", 1, 0), ("newcollege", 1, 0), ("default", 0, 0), ("newcollege", 0, 0), ("default", 0, 1), ("newcollege", 0, 1)])

@@ -94,7 +94,7 @@ class FrontendLoop:
 
 
 class BackendLoop:
-    def __init__(self, wl, device=0):
+    def __init__(self, wl, device=0, ba_options=None):
         import torch
         from scavislam_amd import capi
         from scavislam_amd.backend import SlamGraphOptimizer
@@ -110,6 +110,8 @@ class BackendLoop:
             for kv in os.environ.get("SVS_TT_BA_OPTIONS", "").split(","):      # experiments: "grid_g=144,no_tile_solve=1"
                 if "=" in kv:
                     o.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+            for k, v in (ba_options or {}).items():
+                o.set_option(k, int(v))
             o.copyDataToG2o(p["poses"], p["psi"], p["edges"], p["cons"], p["cam"])
             self.opts[name] = o
         # re-registration (backend.cpp:735-779): the root keyframe's corners at ITS stored thresholds, candidates matched into it
@@ -159,17 +161,24 @@ class BackendLoop:
         self.ctx.close()
 
 
-def run_serial_and_concurrent(n_frames=1000, n_rounds=160, small=False, device=0, cam=None):
-    """returns (serial_front, serial_back, conc_front, conc_back, errors): each loop once alone, then both at the same time from two threads"""
+def run_serial_and_concurrent(n_frames=1000, n_rounds=160, small=False, device=0, cam=None, third=None):
+    """returns (serial_front, serial_back, conc_front, conc_back, errors): each loop once alone, then both at the same time from two threads.
+    third: BA options of a SECOND back-end thread (e.g. dict(grid_g=16, no_tile_solve=1): its double window takes the 16-workgroup grid solve, i.e. the spin gate's
+    priority lane); its serial / contended records are returned as sb["third"] / cb["third"], the contexts' gate counters as cb["gate"]"""
     from scavislam_amd import synth
     fwl = frontend_workload(cam or synth.CAM_DEFAULT)
     bwl = backend_workload(small)
     A, Bk = FrontendLoop(fwl, device), BackendLoop(bwl, device)
+    C3 = BackendLoop(bwl, device, ba_options=third) if third else None
     sf, sb, cf, cb = {}, {}, {}, {}
+    s3, c3 = {}, {}
     A.run(min(n_frames, 64), {})                       # warm-up (first launches, pinned staging)
     Bk.run(2, {})
     A.run(n_frames, sf)
     Bk.run(n_rounds, sb)
+    if C3:
+        C3.run(2, {})
+        C3.run(n_rounds, s3)
     errors = []
 
     def guarded(fn, *a):
@@ -178,11 +187,24 @@ def run_serial_and_concurrent(n_frames=1000, n_rounds=160, small=False, device=0
         except Exception as e:      # SvsError (e.g. SVS_ERR_BUSY) in a thread must reach the caller
             errors.append(repr(e))
 
+    gate0 = [(c.ctx.get_stat("spin_lane_launches"), c.ctx.get_stat("spin_gated_launches")) for c in (A, Bk) + ((C3,) if C3 else ())]
     ta = threading.Thread(target=guarded, args=(A.run, n_frames, cf))
     tb = threading.Thread(target=guarded, args=(Bk.run, n_rounds, cb))
+    tc = threading.Thread(target=guarded, args=(C3.run, n_rounds, c3)) if C3 else None
     t0 = time.perf_counter()
-    ta.start(); tb.start(); ta.join(); tb.join()
+    ta.start(); tb.start()
+    if tc:
+        tc.start()
+    ta.join(); tb.join()
+    if tc:
+        tc.join()
     wall = time.perf_counter() - t0
+    # launches of the contended phase that took the spin gate's priority lane / went through the gate, per thread
+    gate1 = [(c.ctx.get_stat("spin_lane_launches"), c.ctx.get_stat("spin_gated_launches")) for c in (A, Bk) + ((C3,) if C3 else ())]
+    cb["gate"] = {name: dict(lane=int(g1[0] - g0[0]), gated=int(g1[1] - g0[1])) for name, g0, g1 in zip(("frontend", "backend", "third"), gate0, gate1)}
+    if C3:
+        sb["third"], cb["third"] = s3, c3
+        C3.close()
     A.close(); Bk.close()
     return sf, sb, cf, cb, errors, wall
 
