@@ -120,6 +120,7 @@ class HostPool {
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
   int no_order = 0;      // "no_order": keep the caller's pose order in the solve (A/B partner of the fill-reducing order)
+  int no_lds_panel = 0;      // "no_lds_panel": the fused solve's back-substitution panel through global memory (rounds 3-5), A/B only
   int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, no_tile_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
   int host_marshal = 0;                 // svs_ba_set_problem: 0 = by size (device route from 30k edges), 1 = always on the host (rounds 1-2), 2 = always on the device
@@ -169,6 +170,7 @@ struct svs_ba {
   std::vector<int> h_perm;
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
   bool timing = false;                         // hipEvent brackets around the three dominant kernels of every trial (svs_ba_set_timing / svs_ba_kernel_times)
+  int fuse_lds_panel = 0;                      // the fused solve keeps its back-substitution panel in LDS (ensure_profile)
   int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   unsigned *d_gridbar = nullptr; int grid_G = 0;      // multi-workgroup solve: arrival counter + failure flag, number of workgroups (0 = not used)
@@ -815,6 +817,13 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
     if (!ok) ba->fuse_P1 = 0;
   }
   if (ba->fuse_P1 == 0) for (int k = 0; k < P; ++k) rm2[k] = rowmax[k];
+  // the fused kernel's back-substitution panel in LDS where the rows of the larger front fit beside the rest (gfx950: 160 KB per workgroup)
+  ba->fuse_lds_panel = 0;
+  if (ba->use_fused_solve && !ba->opt.no_lds_panel) {
+    const int rows = ba->fuse_P1 > 0 ? std::max(P - ba->fuse_P1, ba->fuse_P1 + R - 1) : P;
+    const size_t extra = sizeof(double) * ((size_t)rows * FUSE_SLOTS * 36 + 400) + 32;      // + the zero region behind the rows + alignment
+    if (ba->lds_solve_smem + extra <= 158 * 1024) { ba->fuse_lds_panel = 1; ba->lds_solve_smem += extra; }
+  }
   if (ba->use_fused_solve) {
     if (!ba->d_rowmax2 || ba->cap_rowmax2 < sizeof(int) * rm2.size()) {
       if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
@@ -839,9 +848,12 @@ static int ensure_profile(svs_ba *ba, svs_allreduce_fn allreduce, void *user) {
     // the fused kernel's zero block sits right behind the P x 10 panel rows of each front (position depends on P): clear sink + zero block
     SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel + (up_count / 2 - 128), 0, sizeof(double) * 128, ctx->stream));
     SVS_HIP(ctx, hipMemsetAsync(ba->d_upanel + (up_count - 128), 0, sizeof(double) * 128, ctx->stream));
-    if (need > 64 * 1024) {
-      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    if (ba->lds_solve_smem > 64 * 1024) {
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->lds_solve_smem));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->lds_solve_smem));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->lds_solve_smem));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->lds_solve_smem));
+      SVS_HIP(ctx, hipFuncSetAttribute((const void *)ba_solve_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->lds_solve_smem));
     }
   }
   // wide envelopes (neither LDS variant fits): the trailing updates are spread over several workgroups once they are worth it
@@ -1013,9 +1025,16 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   }
   if (ba->use_fused_solve)
   {
-    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch};
-    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(ba->fuse_P1 > 0 ? 2 : 1), dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel,
-                       ba->d_rowmax2, ba->env_R, F);
+    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch, ba->fuse_lds_panel};
+    const dim3 fgrid(ba->fuse_P1 > 0 ? 2 : 1);
+    const bool dbg_clocks = ba->opt.debug != 0;      // the per-stage clocks of SVS_BA_DEBUG: their own instantiations (they sit on the pivot wave's critical path)
+    if (ba->fuse_lds_panel) {
+      if (dbg_clocks) hipLaunchKernelGGL((ba_solve_fused_kernel<true, true>), fgrid, dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax2, ba->env_R, F);
+      else hipLaunchKernelGGL((ba_solve_fused_kernel<true, false>), fgrid, dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax2, ba->env_R, F);
+    } else {
+      if (dbg_clocks) hipLaunchKernelGGL((ba_solve_fused_kernel<false, true>), fgrid, dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax2, ba->env_R, F);
+      else hipLaunchKernelGGL((ba_solve_fused_kernel<false, false>), fgrid, dim3(FUSE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax2, ba->env_R, F);
+    }
   }
   else if (ba->use_lds_solve)
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(PIPE_THREADS), ba->lds_solve_smem, ctx->stream, B, x_solve, ba->d_upanel, ba->d_rowmax, ba->env_R,
@@ -1289,6 +1308,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "no_order") o.no_order = value != 0;
   else if (n == "one_front") o.one_front = value != 0;
   else if (n == "no_fused_solve") o.no_fused_solve = value != 0;
+  else if (n == "no_lds_panel") o.no_lds_panel = value != 0;
   else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
   else if (n == "no_fused_cons") o.no_fused_cons = value != 0;
   else if (n == "no_grid_solve") o.no_grid_solve = value != 0;

@@ -38,6 +38,10 @@ struct svs_ctx {
   int trk_lazy_chi2 = 1;      // "trk_lazy_chi2" (default): the same decisions at full speed -- the f64 sums decide wherever their difference is outside the rigorous error bound of the
                               // reference's float sums, and inside it the float sums are formed bit for bit without the sequential chain (seqsum.h).  0: f64 sums alone (rounds 1-4)
   int trk_flat = 1;           // "trk_flat": big batches run the flat state-machine tracker kernel (dense.hip, round 6: the sweep inlined, LM state in LDS); 0: the round-5 kernel (sweep as a call) -- same bits
+  int trk_split = 10;         // "trk_split" (with trk_flat): K -- a stream of a big batch that is still iterating after K trials on the finest level parks and is finished by a
+                              // second launch with several workgroups per stream (dense.hip: the continuation launch); 0: off.  Measured on the bench batch (512
+                              // streams): tracker stage 1.40 ms unsplit, 1.30 at K = 8..9, 1.33 at K = 10; the whole step 2.66-2.69 unsplit, 2.75 at K = 8 (the side
+                              // stream's FAST no longer finds the tail to run in), 2.63 at K = 10
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
   void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)

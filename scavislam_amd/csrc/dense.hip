@@ -1017,7 +1017,7 @@ struct TrkState {
   unsigned n_exact;
 };
 __shared__ TrkState g_ts;
-template <bool U8SRC>
+template <bool U8SRC, int TM>
 __device__ __forceinline__ void track_pass_from_lds() {      // the body of track_pass_call, inlined: operands out of g_pa into scalar registers
   LevelArgsG L;
   L.cloud = (const SVS_AS1 float *)uni_ptr(g_pa.L.cloud); L.prev = (const SVS_AS1 uint8_t *)uni_ptr(g_pa.L.prev);
@@ -1026,7 +1026,8 @@ __device__ __forceinline__ void track_pass_from_lds() {      // the body of trac
   L.pstride = uni_i32(g_pa.L.pstride); L.fstride = uni_i32(g_pa.L.fstride); L.c8stride = uni_i32(g_pa.L.c8stride);
   L.cam.f = uni_f64(g_pa.L.cam.f); L.cam.cx = uni_f64(g_pa.L.cam.cx); L.cam.cy = uni_f64(g_pa.L.cam.cy); L.cam.b = 0;
   L.cam.w = uni_i32(g_pa.L.cam.w); L.cam.h = uni_i32(g_pa.L.cam.h);
-  track_pass<true, U8SRC, SVS_TRK_LAZY ? 1 : 0, LevelArgsG>(L, g_pa.T, g_s_part, g_s_out, g_iplut, (int)threadIdx.x, 1, uni_ptr(g_pa.t_buf));
+  const int nwg = uni_i32(g_pa.nwg), first = uni_i32(g_pa.wg) * TRK_THREADS + (int)threadIdx.x;
+  track_pass<true, U8SRC, TM, LevelArgsG>(L, g_pa.T, g_s_part, g_s_out, g_iplut, first, nwg, uni_ptr(g_pa.t_buf));
 }
 // the solve of an iteration, on wave 0 (seven lanes): H.ldlt().solve(-Jres), undamped (dense_tracking.cpp:332) + exp(x) * T.  A function of its own, called by ONE
 // wave: its 70-odd live doubles are not part of the kernel's allocation, and whatever it saves on entry it saves for 64 lanes, not 512.
@@ -1056,96 +1057,211 @@ __device__ __noinline__ void track_solve_call() {
     g_sx[lane] = v;
   }
 }
-template <bool U8SRC, bool BAL>
-__global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G) {
-  int slot = blockIdx.x;
-  if constexpr (BAL) {
+// ---- the tail of a big batch: the CONTINUATION launch ("trk_split", VERDICT round 5 item 2 iii) ------------------------------------------------------------------
+// All streams of a big batch are resident at once (two workgroups per CU) and the launch lasts as long as its longest stream: 16.75 level-0 sweeps in the bench's batch
+// against a mean of 8.7 -- and the last sweeps of a stream are the ones whose accept test needs the exact float sums, one after the other on the critical path.  Predicting
+// the long streams from the last frame does not work (correlation -0.18 in the bench).  So the first launch (CONT = 0) runs every stream with one workgroup as before, but a
+// stream that has taken K trials on level 0 and is still not done PARKS: its LM state -- the accepted pose, H,b of the accepted pass, the sums the accept test carries,
+// the term buffers (they are in global memory already) -- goes to global memory, its index to a list, and the workgroup exits.  The second launch (CONT = 1) takes the list:
+// every parked stream is resumed by NW workgroups (NW = what fits the device for the number of parked streams, decided on the device) that share each sweep exactly like
+// the latency mode does (partial sums through write-through words + one arrival counter, the leader forms the exact float sums and publishes the decision).  A trial of a
+// parked stream then takes ~30 us instead of ~170.  K is a constant, so which sweeps run in which form is a function of the data alone: deterministic results; the
+// partial sums of a shared sweep are added in another order than the one-workgroup sweep's, so H,b differ from the unsplit run in their last bits (pose 1e-12), while the
+// accept decisions are the reference's either way (exact float sums of the terms).
+struct TrkPark { TrkState ts; double T[12], H[27], Tj[36]; };
+struct TrackCont { TrkPark *park; int *list; unsigned *count; int K; int slots; };      // K < 0: no parking; slots: resident workgroup slots of the device for the second launch
+constexpr int CONT_MAX_NWG = 8;
+template <bool U8SRC, bool BAL, int CONT>      // CONT 0: first launch (BAL: grid order from the table); 1: the continuation (grid = CONT_MAX_NWG x batch, blockIdx.y = index into the list)
+__global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_kernel(TrackArgs A, double *__restrict__ T_io, int *__restrict__ passes_out, TrackMulti G, TrackCont C) {
+  constexpr bool MULTI = CONT == 1;
+  constexpr int TM = SVS_TRK_LAZY ? (MULTI ? 2 : 1) : 0;
+  int slot = blockIdx.x, wg = 0, nwg = 1;
+  if constexpr (BAL && !MULTI) {
     const int e = G.map[blockIdx.x];
     if (e < 0 || (e & 15) != 0) return;      // idle workgroup / a sibling entry of a table made for the split variant
     slot = e >> 4;
   }
+  if constexpr (MULTI) {
+    const int n_parked = (int)*C.count;
+    if ((int)blockIdx.y >= n_parked) return;
+    // workgroups per parked stream: as many as are resident together (all of a stream's workgroups wait for each other; siblings are neighbours in the grid)
+    nwg = C.slots / n_parked;
+    nwg = nwg >= 8 ? 8 : (nwg >= 4 ? 4 : (nwg >= 2 ? 2 : 1));
+    wg = blockIdx.x;
+    if (wg >= nwg) return;
+    slot = C.list[blockIdx.y];
+  }
   const int tid = threadIdx.x;
+  __shared__ bool s_failed;
   float *const tb0 = G.terms ? G.terms + (size_t)slot * 2 * G.terms_b : nullptr;
-  // level set-up (one lane): the operands of the level's sweeps, the first one at the accepted pose into term buffer 0
-  auto enter_level = [&](int level) {
+  // level set-up (one lane): the operands of the level's sweeps
+  auto set_level = [&](int level) {
     LevelArgs L = A.lv[level];
     L.cloud += slot * A.cloud_b[level]; L.prev += slot * A.prev_b[level];
     if (U8SRC) L.cur8 += slot * A.c8_b[level];
     else { L.cur += slot * A.f_b[level]; L.dx += slot * A.f_b[level]; L.dy += slot * A.f_b[level]; }
-    g_pa.L = L; g_pa.wg = 0; g_pa.nwg = 1; g_pa.t_buf = tb0;
+    g_pa.L = L; g_pa.wg = wg; g_pa.nwg = nwg;
+  };
+  auto enter_level = [&](int level) {          // ... the first sweep of the level at the accepted pose into term buffer 0
+    set_level(level);
+    g_pa.t_buf = tb0;
     g_ts.level = level; g_ts.phase = 0; g_ts.cur = 0; g_ts.it = 0;
   };
-  if (tid < 12) { const double v = T_io[(size_t)slot * 12 + tid]; g_sT[tid] = v; g_pa.T[tid] = v; }
   for (int i = tid; i < 256; i += TRK_THREADS) g_iplut[i] = (float)((1. / 255.) * i);
-  if (tid == 0) {
-    g_seq_sh.fell_back = 0;
-    g_ts.passes = 0; g_ts.n_rec = 0; g_ts.n_exact = 0;
-    enter_level(2);
+  if (tid == 0) { g_seq_sh.fell_back = 0; s_failed = false; }
+  int sweep = 0;                                   // MULTI: sweeps shared so far (parity of the partials' buffer, target of the arrival counter)
+  unsigned n_decisions = 0;
+  if constexpr (!MULTI) {
+    if (tid < 12) { const double v = T_io[(size_t)slot * 12 + tid]; g_sT[tid] = v; g_pa.T[tid] = v; }
+    if (tid == 0) {
+      g_ts.passes = 0; g_ts.n_rec = 0; g_ts.n_exact = 0;
+      enter_level(2);
+    }
+    __syncthreads();
+  } else {
+    // resume: the state as the first launch left it (behind a trial step that did not end the level); every workgroup of the stream loads it and goes on with the solve
+    const TrkPark &P = C.park[slot];
+    if (tid == 0) { g_ts = P.ts; if (wg != 0) g_ts.n_exact = 0; }
+    if (tid < 12) g_sT[tid] = P.T[tid];
+    if (tid >= 64 && tid < 64 + 27) g_sH[tid - 64] = P.H[tid - 64];
+    if (tid >= 128 && tid < 128 + 36) g_sTj[(tid - 128) / 12][(tid - 128) % 12] = P.Tj[tid - 128];
+    __syncthreads();
+    if (tid == 0) set_level(g_ts.level);
+    __syncthreads();
   }
-  __syncthreads();
+  // MULTI: g_s_out <- the sums of all workgroups of the stream, added in workgroup order (dense_track_cpu_sem_kernel::all_workgroups: relaxed agent-scope words + vmcnt(0)
+  // + one arrival counter, valid on gfx950 / gfx942 only -- see the #error above)
+  auto all_workgroups = [&]() {
+    if (nwg == 1) return;
+    double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * CONT_MAX_NWG * 32;
+    if (tid <= NSUM) __hip_atomic_store(buf + wg * 32 + tid, g_s_out[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++sweep;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(G.bar + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)sweep * (unsigned)nwg;
+      long spin = 0;
+      for (; spin < (1l << 24) && __hip_atomic_load(G.bar + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(1);
+      if (spin >= (1l << 24)) __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_failed = __hip_atomic_load(G.bar + G.fail_off + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
+    __syncthreads();
+    if (tid <= NSUM) {
+      double acc = 0;
+      for (int w = 0; w < nwg; ++w) acc += __hip_atomic_load(buf + w * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g_s_out[tid] = acc;
+    }
+    __syncthreads();
+  };
+  bool failed = false, parked = false;
+  bool resume = MULTI;                             // the continuation enters the loop behind a step: solve first
 #pragma nounroll
   for (;;) {
-    track_pass_from_lds<U8SRC>();                  // (ends in a barrier: g_s_out is complete)
-    // ---- the LM step: every lane reads the state, one lane writes it back
-    const int level = g_ts.level, phase = g_ts.phase, cur = g_ts.cur, n_rec = g_ts.n_rec;
-    const int n_lvl = (A.lv[level].cam.w / 4) * (A.lv[level].cam.h / 4);
-    bool level_done;
-    if (phase == 0) {                              // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
-      const double S = g_s_out[27];
-      const float chi2 = (float)S;
-      __syncthreads();                             // (everybody has read g_s_out / the state)
-      if (tid < 27) g_sH[tid] = g_s_out[tid];
-      if (tid == 0) {
-        g_ts.S_old = S; g_ts.nv_old = (int)g_s_out[NSUM]; g_ts.chi2 = chi2; g_ts.seq_old_ok = 0; g_ts.seq_old = 0.f;
-        ++g_ts.passes; ++g_ts.n_rec;
-        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
-      }
-      level_done = false;
-    } else {                                       // new_chi2 (:335-367) + H,b for the next iteration
-      const double S_old = g_ts.S_old, S_new = g_s_out[27];
-      const int nv_old = g_ts.nv_old, nv_new = (int)g_s_out[NSUM];
-      float chi2 = g_ts.chi2, new_chi2, seq_old = g_ts.seq_old;
-      int seq_old_ok = g_ts.seq_old_ok;
-      unsigned n_exact = 0;
-      bool accept;
-      // the reference compares two float sums of n terms each: |sum_float - sum_exact| <= ((1 + 2^-24)^(n - 1) - 1) sum_exact.  Outside that band the f64 sums decide as
-      // the float sums would; inside it the float sums are formed, bit for bit (exact_seq_sum_f32)
-      const double gam = 1.0001 * (double)max(nv_old, nv_new) * 5.9604644775390625e-08 + 1e-12;
-      const bool near = SVS_TRK_LAZY && tb0 && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));
-      if (near) {
-        float seq_new = 0.f;
-#pragma nounroll
-        for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {
-          const float v = exact_seq_sum_f32<false>(tb0 + (size_t)((k ? cur ^ 1 : cur)) * G.terms_b, n_lvl);
-          if (k) seq_new = v; else seq_old = v;
-          ++n_exact;
-        }
-        seq_old_ok = 1;
-        chi2 = seq_old; new_chi2 = seq_new;
-        accept = (double)chi2 - (double)new_chi2 > 0;
-        if (accept) seq_old = seq_new;
-      } else {
-        new_chi2 = (float)S_new;
-        accept = S_old > S_new;
-        if (accept) seq_old_ok = 0;
-      }
-      double mx = -1;
-      for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(g_sx[q]));
-      const int it = g_ts.it + 1;
-      level_done = !accept || mx <= 1e-10 || it >= 15;
-      __syncthreads();                             // (everybody has read g_s_out / the state / g_sx)
-      if (accept) {
-        if (tid < 12) g_sT[tid] = g_sTn[tid];
+    bool level_done = false;
+    int level;
+    if (!resume) {
+      track_pass_from_lds<U8SRC, TM>();            // (ends in a barrier: g_s_out is complete)
+      if constexpr (MULTI) { all_workgroups(); if (s_failed) { failed = true; break; } }
+      // ---- the LM step: every lane reads the state, one lane writes it back
+      level = g_ts.level;
+      const int phase = g_ts.phase, cur = g_ts.cur, n_rec = g_ts.n_rec;
+      const int n_lvl = (A.lv[level].cam.w / 4) * (A.lv[level].cam.h / 4);
+      if (phase == 0) {                              // chi2 (dense_tracking.cpp:229-261) + H,b of iteration 0
+        const double S = g_s_out[27];
+        const float chi2 = (float)S;
+        __syncthreads();                             // (everybody has read g_s_out / the state)
         if (tid < 27) g_sH[tid] = g_s_out[tid];
+        if (tid == 0) {
+          g_ts.S_old = S; g_ts.nv_old = (int)g_s_out[NSUM]; g_ts.chi2 = chi2; g_ts.seq_old_ok = 0; g_ts.seq_old = 0.f;
+          ++g_ts.passes; ++g_ts.n_rec;
+          if (A.rec && wg == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
+        }
+      } else {                                       // new_chi2 (:335-367) + H,b for the next iteration
+        const double S_old = g_ts.S_old, S_new = g_s_out[27];
+        const int nv_old = g_ts.nv_old, nv_new = (int)g_s_out[NSUM];
+        float chi2 = g_ts.chi2, new_chi2, seq_old = g_ts.seq_old;
+        int seq_old_ok = g_ts.seq_old_ok;
+        unsigned n_exact = 0;
+        bool accept;
+        // the reference compares two float sums of n terms each: |sum_float - sum_exact| <= ((1 + 2^-24)^(n - 1) - 1) sum_exact.  Outside that band the f64 sums decide as
+        // the float sums would; inside it the float sums are formed, bit for bit (exact_seq_sum_f32)
+        const double gam = 1.0001 * (double)max(nv_old, nv_new) * 5.9604644775390625e-08 + 1e-12;
+        const bool near = SVS_TRK_LAZY && tb0 && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));
+        if (near) {
+          float seq_new = 0.f;
+          const bool shared_decision = MULTI && nwg > 1;      // the leader forms the sums, its siblings take its word (dense_track_cpu_sem_kernel)
+          if (!shared_decision || wg == 0) {
+#pragma nounroll
+            for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {
+              const float v = exact_seq_sum_f32<MULTI>(tb0 + (size_t)((k ? cur ^ 1 : cur)) * G.terms_b, n_lvl);
+              if (k) seq_new = v; else seq_old = v;
+              ++n_exact;
+            }
+          }
+          if constexpr (MULTI) {
+            if (shared_decision) {
+              ++n_decisions;
+              unsigned long long *word = reinterpret_cast<unsigned long long *>(G.bcast + (size_t)slot * 16 + 13);
+              unsigned *epoch = reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 14);
+              if (wg == 0) {
+                if (tid == 0) {
+                  const unsigned long long w = ((unsigned long long)__float_as_uint(seq_old) << 32) | (unsigned long long)__float_as_uint(seq_new);
+                  __hip_atomic_store(word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  __hip_atomic_store(epoch, n_decisions, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              } else {
+                __shared__ unsigned long long s_word;
+                if (tid == 0) {
+                  long spin = 0;
+                  for (; spin < (1l << 24) && __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_decisions; ++spin) __builtin_amdgcn_s_sleep(1);
+                  if (spin >= (1l << 24)) { __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = true; }
+                  s_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (s_failed) { failed = true; break; }
+                const unsigned long long w = s_word;
+                if (!seq_old_ok) seq_old = __uint_as_float((unsigned)(w >> 32));
+                seq_new = __uint_as_float((unsigned)w);
+              }
+            }
+          }
+          seq_old_ok = 1;
+          chi2 = seq_old; new_chi2 = seq_new;
+          accept = (double)chi2 - (double)new_chi2 > 0;
+          if (accept) seq_old = seq_new;
+        } else {
+          new_chi2 = (float)S_new;
+          accept = S_old > S_new;
+          if (accept) seq_old_ok = 0;
+        }
+        double mx = -1;
+        for (int q = 0; q < 6; ++q) mx = fmax(mx, fabs(g_sx[q]));
+        const int it = g_ts.it + 1;
+        level_done = !accept || mx <= 1e-10 || it >= 15;
+        __syncthreads();                             // (everybody has read g_s_out / the state / g_sx / s_word)
+        if (accept) {
+          if (tid < 12) g_sT[tid] = g_sTn[tid];
+          if (tid < 27) g_sH[tid] = g_s_out[tid];
+        }
+        if (tid == 0) {
+          if (accept) { g_ts.S_old = S_new; g_ts.nv_old = nv_new; g_ts.cur = cur ^ 1; g_ts.chi2 = new_chi2; }
+          g_ts.seq_old = seq_old; g_ts.seq_old_ok = seq_old_ok; g_ts.it = it; g_ts.n_exact += n_exact;
+          ++g_ts.passes; ++g_ts.n_rec;
+          if (A.rec && wg == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, accept ? 1 : 0, chi2, new_chi2};
+        }
+        // first launch: a stream that is still going after K trials on the finest level parks here (state of the accepted pass, before the solve)
+        if constexpr (!MULTI) {
+          if (!level_done && level == 0 && C.K >= 0 && it >= C.K) parked = true;
+        }
       }
-      if (tid == 0) {
-        if (accept) { g_ts.S_old = S_new; g_ts.nv_old = nv_new; g_ts.cur = cur ^ 1; g_ts.chi2 = new_chi2; }
-        g_ts.seq_old = seq_old; g_ts.seq_old_ok = seq_old_ok; g_ts.it = it; g_ts.n_exact += n_exact;
-        ++g_ts.passes; ++g_ts.n_rec;
-        if (A.rec && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, accept ? 1 : 0, chi2, new_chi2};
-      }
+      __syncthreads();                               // the state, g_sT and g_sH are those of the accepted pass
+      if (parked) break;
+    } else {
+      resume = false;
+      level = g_ts.level;
     }
-    __syncthreads();                               // the state, g_sT and g_sH are those of the accepted pass
     if (level_done) {
       if (level == 0) break;
       if (tid == 0) enter_level(level - 1);
@@ -1159,6 +1275,18 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
     }
     __syncthreads();
   }
+  if constexpr (!MULTI) {
+    if (parked) {
+      TrkPark &P = C.park[slot];
+      if (tid == 0) { P.ts = g_ts; C.list[atomicAdd(C.count, 1u)] = slot; }
+      if (tid < 12) P.T[tid] = g_sT[tid];
+      if (tid >= 64 && tid < 64 + 27) P.H[tid - 64] = g_sH[tid - 64];
+      if (tid >= 128 && tid < 128 + 36) P.Tj[tid - 128] = g_sTj[(tid - 128) / 12][(tid - 128) % 12];
+      return;
+    }
+  }
+  if (wg != 0) return;
+  if (failed) { if (tid == 0 && passes_out) passes_out[slot] = -1; return; }      // (MULTI: a sibling never arrived) pose left as it came in
   if (tid < 12) T_io[(size_t)slot * 12 + tid] = g_sT[tid];
   if (tid == 0 && passes_out) passes_out[slot] = g_ts.passes;
   if (tid == 0 && A.n_rec) A.n_rec[slot] = g_ts.n_rec;
@@ -1409,6 +1537,42 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void trk_assign_kernel(const svs_de
 // the balanced launch of a big batch.  State (owned by the caller, frontend.hip; persistent from frame to frame): grid map [batch + batch/2] i32 | workgroups
 // per stream [batch] u8 | arrival counters, failure flags, hand-over words (zero before every launch).  The assignment for the NEXT frame is made right behind
 // this frame's tracker (from the LM records it leaves), so that nothing small sits between the fork of the side stream and the tracker's launch.
+// scratch of the continuation launch (dense_track_batch_kernel<., ., 1>): partial sums of the shared sweeps, arrival counters + failure flags, decision words, the
+// parked states and their list.  Returns G / C filled in; enqueues the memset of the words that must start at zero.
+static int cont_setup(svs_ctx *ctx, int batch, TrackMulti &G, TrackCont &C) {
+  const size_t n_part = (size_t)batch * 2 * CONT_MAX_NWG * 32, n_bar = (size_t)batch, n_bc = (size_t)batch * 16, n_cnt = 2, n_list = (size_t)batch / 2 + 1;
+  const size_t n_park = ((size_t)batch * sizeof(TrkPark) + 7) / 8;
+  double *scr = nullptr;
+  const int rc = ensure_scratch(ctx, &scr, n_part + n_bar + n_bc + n_cnt + n_list + n_park);
+  if (rc) return rc;
+  G.part = scr;
+  G.bar = reinterpret_cast<unsigned *>(scr + n_part);
+  G.fail_off = batch;
+  G.bcast = scr + n_part + n_bar;
+  C.count = reinterpret_cast<unsigned *>(scr + n_part + n_bar + n_bc);
+  C.list = reinterpret_cast<int *>(scr + n_part + n_bar + n_bc + n_cnt);
+  C.park = reinterpret_cast<TrkPark *>(scr + n_part + n_bar + n_bc + n_cnt + n_list);
+  C.K = ctx->trk_split; C.slots = 2 * ctx->n_cu;
+  SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (n_bar + n_bc + n_cnt), ctx->stream));
+  return SVS_OK;
+}
+// the first launch of a big batch (grid: one workgroup per stream / the balanced table) and, with "trk_split", its continuation
+template <bool BAL>
+static int launch_batch_tracker(svs_ctx *ctx, const TrackArgs &A, bool u8src, double *d_T_io, int32_t *d_passes_out, int batch, int grid, TrackMulti G) {
+  TrackCont C{nullptr, nullptr, nullptr, -1, 0};
+  if (ctx->trk_split > 0) { const int rc = cont_setup(ctx, batch, G, C); if (rc) return rc; }
+  if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, BAL, 0>), dim3(grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G, C);
+  else hipLaunchKernelGGL((dense_track_batch_kernel<false, BAL, 0>), dim3(grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G, C);
+  SVS_LAUNCH_CHECK(ctx);
+  if (C.K < 0) return SVS_OK;
+  // the parked streams, several workgroups each: they wait for each other inside the launch -- through the spin gate like every launch of that kind (common.h)
+  SvsSpinScope gate(ctx);
+  if (gate.rc) return gate.rc;
+  if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, false, 1>), dim3(CONT_MAX_NWG, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G, C);
+  else hipLaunchKernelGGL((dense_track_batch_kernel<false, false, 1>), dim3(CONT_MAX_NWG, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G, C);
+  SVS_LAUNCH_CHECK(ctx);
+  return gate.leave();
+}
 struct BalState { int *map; unsigned char *nwg_of; double *flags; size_t n_flags; int grid, x_max; };
 BalState bal_state(void *state, int batch) {
   BalState S;
@@ -1448,8 +1612,7 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
     SVS_LAUNCH_CHECK(ctx);
     if (int grc = gate.leave()) return grc;
   } else if (ctx->trk_flat) {       // order only: one workgroup per stream, nothing waits for anything -- the flat kernel (round 6), bit-identical to the one below
-    if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_batch_kernel<false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (int lrc = launch_batch_tracker<true>(ctx, A, u8src, d_T_io, d_passes_out, batch, S.grid, G)) return lrc;
   } else {
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -1546,8 +1709,7 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
   } else if (d_bal_state && ctx->trk_balance && batch >= 2 * ctx->n_cu && batch <= BAL_MAX_STREAMS && A.rec && A.n_rec) {
     return svs_dense_track_cpu_sem_balanced(ctx, A, u8src, d_T_io, d_passes_out, batch, d_bal_state, G);
   } else if (((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) && ctx->trk_flat) {
-    if (u8src) hipLaunchKernelGGL((dense_track_batch_kernel<true, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
-    else hipLaunchKernelGGL((dense_track_batch_kernel<false, false>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
+    if (int lrc = launch_batch_tracker<false>(ctx, A, u8src, d_T_io, d_passes_out, batch, batch, G)) return lrc;
   } else if ((batch > ctx->n_cu && ctx->trk_regs != 1) || ctx->trk_regs == 2) {      // trk_regs: tests / experiments, latched at svs_ctx_create
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

@@ -389,6 +389,66 @@ def test_dense_tracking_lm_trajectory_many_scenes(gpu_ctx, B):
         np.testing.assert_allclose(T_c, T, rtol=0, atol=1e-12)
 
 
+def test_dense_tracking_big_batch_continuation_launch(gpu_ctx):
+    """A batch of more than one stream per CU runs the flat tracker kernel, and with "trk_split" = K its streams that are still iterating after K trials on the finest
+    level PARK and are finished by a second launch with 1 / 2 / 4 / 8 workgroups per stream (dense.hip: the continuation launch).  300 streams over 8 scenes, K = 0 (off),
+    1, 3, 5, 8: however many streams park and however many workgroups resume them, EVERY stream's accept / reject record equals the oracle's to the end, the poses agree with
+    the oracle to 1e-9 and with the unsplit run to 1e-12, no stream reports a failed hand-over, and the replicas of a scene inside one batch are bit-equal."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    ctx, stream = gpu_ctx
+    cam = synth.CAM_DEFAULT
+    NS, B = 8, 300
+    sc = synth.Scene(2011)
+    rng = np.random.default_rng(5)
+    base = synth.trajectory(6)
+    T_prev = [base[b % 6] for b in range(NS)]
+    T_cur = [synth.pose_mul(synth.pose(synth.so3_exp([rng.normal(0, 5e-4), np.deg2rad(rng.uniform(0.05, 0.5)), rng.normal(0, 5e-4)]),
+                                       [rng.normal(0, 0.003), rng.normal(0, 0.002), -rng.uniform(0.02, 0.08)]), T_prev[b]) for b in range(NS)]
+    prev_f = [sc.render(cam, T_prev[b], seed=500 + b) for b in range(NS)]
+    cur_f = [sc.render(cam, T_cur[b], seed=600 + b) for b in range(NS)]
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    prev.upload(np.stack([prev_f[b % NS][0] for b in range(B)]), np.stack([prev_f[b % NS][1] for b in range(B)]))
+    cur.upload(np.stack([cur_f[b % NS][0] for b in range(B)]), np.stack([cur_f[b % NS][1] for b in range(B)]))
+    prev.preprocessing(); cur.preprocessing()
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dtp.ref_dense_points
+    refs = {}
+    for s_ in range(NS):
+        clouds = [O.pointcloud_cpu(prev_f[s_][1], prev.cams[l], l, I) for l in range(3)]
+        pyr_p, pyr_c = O.build_pyramid(prev_f[s_][0]), O.build_pyramid(cur_f[s_][0])
+        fl = [O.convert_sobel(p) for p in pyr_c]
+        refs[s_] = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cur.cams, I, want_rec=True)
+    lvl0_trials = [int(((r[2][:, 0] == 0) & (r[2][:, 1] < 2)).sum()) for r in refs.values()]
+    out = {}
+    try:
+        for K in (0, 1, 3, 5, 8):
+            ctx.set_option("trk_split", K)
+            T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+            recs = dt.lm_records()
+            assert (passes > 0).all(), f"K = {K}: dense_passes = -1 (a sibling workgroup of a parked stream never arrived)"
+            assert ctx.get_stat("trk_exact_fallbacks") == 0
+            for b in range(B):
+                T_ref, passes_ref, rec_ref = refs[b % NS]
+                if b < 2 * NS or b >= B - NS:
+                    _check_cpu_sem_trajectory(recs[b], passes[b], rec_ref, passes_ref, f"K = {K}, stream {b}")
+                np.testing.assert_allclose(T[b], T_ref, rtol=0, atol=1e-9)
+                assert np.array_equal(T[b], T[b % NS]) and passes[b] == passes[b % NS] and recs[b].tobytes() == recs[b % NS].tobytes(), (K, b)      # replicas: the same bits
+            out[K] = (T.copy(), passes.copy())
+    finally:
+        ctx.set_option("trk_split", 10)
+    for K in (1, 3, 5, 8):
+        assert np.array_equal(out[K][1], out[0][1])
+        np.testing.assert_allclose(out[K][0], out[0][0], rtol=0, atol=1e-12)
+    print(f"continuation launch: level-0 trials per scene {lvl0_trials}; K = 0 / 1 / 3 / 5 / 8: all records = the oracle's, poses of the split runs within "
+          f"{max(float(np.abs(out[K][0] - out[0][0]).max()) for K in (1, 3, 5, 8)):.1e} of the unsplit run")
+
+
 def test_dense_tracking_lm_trajectory_seq_chi2_to_the_end(gpu_ctx):
     """Option "trk_seq_chi2": the accept test runs on the reference's OWN sums -- `float chi2` accumulated sequentially in f32 over the samples in row-major
     order (dense_tracking.cpp:229-262,341-383).  Then no near-tie is left to summation order: EVERY stream's accept / reject record equals the oracle's to the

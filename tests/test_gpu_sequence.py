@@ -12,6 +12,7 @@ It is compared with the SAME translation unit compiled without the define (libsv
 the fixture tests/golden/ref_seq_*.npz (generated from it by tests/golden/make_golden_seq.py) otherwise.  Bars, per frame: identical keyframe-switch / drop decisions,
 identical ids of keyframes and seeded points, identical accepted points (kind, level, pixel position: the draw lists), equal persistent FAST thresholds, pose within
 1e-6; the double-valued line ends and seeded coordinates within 1e-6 (they inherit the keyframe poses, which differ in their last bits between the builds)."""
+import json
 import os
 import time
 
@@ -187,10 +188,17 @@ def test_batched_call_runs_eight_sequences_of_the_reference_loop(gpu_ctx):
         ref = S.run(ref_seq, "default", M, frame_list=sub)
         ref_seq.close()
         st = S.compare(hip, ref, f"stream {b} (frames {b * STEP}..{b * STEP + M - 1}): one-call binding in the reference's loop vs the reference's CPU build")
-        # pose within 1e-6 on EVERY frame; accepted points: identical but for the handful that sit on the reprojection gate when calcFastMotionOnly ends one step apart
-        # (its last step is decided by the rounding of its own f64 chi2 sums, ~1e-14, and is 1e-8 ... 1e-7 long: measured 2.4e-8 and 4 points of ~12 000 on one of
-        # the eight sub-sequences, none on the others and none on the two 200-frame fixtures)
-        assert st["frames_1e6"] == M and st["max_dT"] <= 1e-6 and st["other_points"] <= 6 and st["frames_with_other_points"] <= 3, (b, st)
+        # pose within 1e-6 on EVERY frame; accepted points: identical but for the handful that sit on the reprojection gate when calcFastMotionOnly ends one step apart.
+        # Its accept test is `chi2 - new_chi2 > 0` on two sums accumulated sequentially in one double IN LIST ORDER (pose_optimizer.h:236-269), and the list order follows
+        # the heap (global.h:47-54 hashes shared pointers by address; stereo_frontend.cpp:337-342 walks an unordered_set of them): the reference's own CPU build, run on
+        # these same eight sub-sequences with nothing changed but the addresses its objects land at, differs from itself by up to YARD points in a stream
+        # (tests/golden/yardstick_heap_order.json, made by tools/yardstick_heap_order.py: 10 of 128 runs with other points, 2 runs failing even compare()'s hard part).
+        # The HIP branch is held to that spread, not to more: at most the reference's own (measured here: 2 on one stream, 0 on the others).
+        yard = json.load(open(os.path.join(GOLDEN, "yardstick_heap_order.json")))
+        YARD = int(yard["max_other_points"])
+        assert YARD >= 1 and yard["runs_with_other_points"] >= 1
+        assert st["frames_1e6"] == M and st["max_dT"] <= 1e-6 and st["other_points"] <= YARD and st["frames_with_other_points"] <= 1, \
+            (f"stream {b}: more accepted points differ from the reference's CPU build than the reference differs from ITSELF on another heap layout ({YARD})", st)
         worst_other = max(worst_other, st["other_points"])
         assert rec[0] is None and all(x is not None for x in rec[1:])
         recs.append(rec); outs.append(hip)
