@@ -31,7 +31,7 @@ extern "C" {
 /* ABI version: bumped whenever a struct of this header grows or a signature changes (round 3 grew svs_pose_opt_params / svs_match_args and put a `stream`
    argument into svs_frontend_device_view without one -- INTEGRATION.md section 6).  A caller checks svs_api_version() == SVS_API_VERSION once, zero-initialises
    every parameter struct (or takes it from the *_default() initialisers) and sets only the fields it knows. */
-#define SVS_API_VERSION 5
+#define SVS_API_VERSION 6
 int svs_api_version(void);             /* the SVS_API_VERSION the loaded library was built with */
 
 enum {
@@ -595,6 +595,12 @@ int svs_ba_set_timing(svs_ba *ba, int on);
 /* last-call timing of the dominant kernels, ms (zeros unless svs_ba_set_timing(ba, 1)) */
 int svs_ba_kernel_times(svs_ba *ba, float *reduce_ms, float *solve_ms, float *backsub_ms,
                         int32_t *n_reduce_launches);
+/* How svs_ba_optimize enqueues its work.  The all-accepted optimize of a resident window (SlamGraph::optimize, slam_graph.cpp:312-355: num_iters x { build, solve,
+   update, compare }) has a fixed launch topology; the library records it ONCE per problem layout as a HIP graph and replays it with one launch per call (the first rejected
+   trial falls back to the host-driven loop, as before).  *launches: optimizes replayed from a graph so far; *captures: recordings made (a new one whenever the layout,
+   the buffers or the parameters change).  Option "no_graph" (svs_ba_set_option) keeps the kernel-by-kernel path.  Not used with an all-reduce callback / communicator,
+   with svs_ba_set_timing, or with the multi-workgroup solves of wide envelopes. */
+int svs_ba_graph_stats(svs_ba *ba, int64_t *launches, int64_t *captures);
 
 #ifdef __cplusplus
 }

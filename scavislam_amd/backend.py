@@ -247,6 +247,12 @@ class SlamGraphOptimizer:
         self.ctx.lib.svs_ba_kernel_times(self.h, C.byref(r), C.byref(s), C.byref(b), C.byref(n))
         return dict(reduce_ms=r.value, solve_ms=s.value, backsub_ms=b.value, n_trials=n.value)
 
+    def graph_stats(self):
+        """(optimizes replayed from a recorded HIP graph, recordings made) -- svs_ba_graph_stats"""
+        a, b = C.c_int64(), C.c_int64()
+        self.ctx.check(self.ctx.lib.svs_ba_graph_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def close(self):
         if self.h and self.ctx.h:
             self.ctx.lib.svs_ba_destroy(self.h)

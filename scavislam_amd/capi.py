@@ -199,9 +199,10 @@ _SIGS = {
     "svs_comm_transport": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)],
     "svs_ba_kernel_times": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_int32)],
+    "svs_ba_graph_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
 }
 EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error", "svs_api_version", "svs_pose_opt_params_default"])
-API_VERSION = 5      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
+API_VERSION = 6      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
 
 
 def load():

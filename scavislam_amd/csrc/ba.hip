@@ -120,6 +120,7 @@ class HostPool {
 
 struct BaOptions {                      // experiment / test switches, latched at svs_ba_create (never read from the environment per call)
   int no_order = 0;      // "no_order": keep the caller's pose order in the solve (A/B partner of the fill-reducing order)
+  int no_graph = 0;          // "no_graph": the speculative trials of an optimize are enqueued kernel by kernel (rounds 1-5) instead of replayed from a HIP graph
   int no_lds_panel = 0;      // "no_lds_panel": the fused solve's back-substitution panel through global memory (rounds 3-5), A/B only
   int no_speculation = 0, one_front = 0, no_fused_solve = 0, no_lds_solve = 0, no_fused_cons = 0, no_grid_solve = 0, no_tile_solve = 0, debug = 0;
   int nw = 0, nw4 = 0, p1 = -1, group = 0, host_threads = 0, grid_g = 0;
@@ -175,6 +176,13 @@ struct svs_ba {
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   unsigned *d_gridbar = nullptr; int grid_G = 0;      // multi-workgroup solve: arrival counter + failure flag, number of workgroups (0 = not used)
   double *d_tilews = nullptr; size_t cap_tilews = 0; int tiles_G = 0, tiles_S = 0, tiles_tpw = 0, tiles_gq = 0, tiles_ncm = 0;      // tile-resident variant of it (ba_solve_tiles.inc): workspace, grid, tile rows, own tiles per workgroup (tiles_G = 0: not used)
+  // The all-accepted optimize of a resident window has a FIXED launch topology -- control upload, num_iters x (clear, Schur, [permute,] solve, [unpermute,] back-substitute,
+  // decide), control read-back: ~25 stream operations, ~5 us of host time each, i.e. the ceiling of windows in flight (6 k windows / s in bench.py where the kernels
+  // would allow 10 k).  It is captured ONCE per (problem layout, current state buffer) and replayed with one hipGraphLaunch (slam_graph.cpp:312-355 = one call).
+  struct Graph { hipGraphExec_t exec = nullptr; uint64_t sig = 0; };
+  Graph graph[2];                              // by ba->cur at the start of the call
+  bool capturing = false;                      // enqueue_trial is being recorded: constant flag epoch + flag reset instead of the launch counter
+  long long n_graph_launches = 0, n_graph_captures = 0;
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
   int ctl_iters = 0;
   std::vector<hipEvent_t> spec_ev;      // 6 events per speculative trial
@@ -302,6 +310,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->w_hback) (void)hipHostFree(ba->w_hback);
   for (auto &e : ba->spec_ev) if (e) (void)hipEventDestroy(e);
   ba->spec_ev.clear();
+  for (auto &g : ba->graph) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   ba->free_all();
   ba->pool = nullptr;                   // shared, not owned
   for (auto &e : ba->ev) if (e) (void)hipEventDestroy(e);
@@ -1025,7 +1034,12 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   }
   if (ba->use_fused_solve)
   {
-    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ++ba->fuse_epoch, ba->fuse_lds_panel};
+    // the hand-over flags of the two fronts hold the launch epoch; a recorded launch is replayed with the SAME arguments, so it uses a constant epoch (no launch counter
+    // ever reaches it) and clears the flags in front of itself
+    constexpr unsigned GRAPH_EPOCH = 0x40000000u;
+    if (ba->capturing && ba->fuse_P1 > 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_flags, 0, sizeof(unsigned) * 4, ctx->stream));
+    if (!ba->capturing && ++ba->fuse_epoch >= GRAPH_EPOCH) ba->fuse_epoch = 1;
+    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ba->capturing ? GRAPH_EPOCH : ba->fuse_epoch, ba->fuse_lds_panel};
     const dim3 fgrid(ba->fuse_P1 > 0 ? 2 : 1);
     const bool dbg_clocks = ba->opt.debug != 0;      // the per-stage clocks of SVS_BA_DEBUG: their own instantiations (they sit on the pivot wave's critical path)
     if (ba->fuse_lds_panel) {
@@ -1141,17 +1155,58 @@ static int optimize_begin(svs_ba *ba, svs_allreduce_fn allreduce, void *user, Op
     while (ba->spec_ev.size() < 6 * (size_t)n_it) { hipEvent_t e; SVS_HIP(ctx, hipEventCreate(&e)); ba->spec_ev.push_back(e); }
     for (size_t i = 0; i < n_ctl; ++i) ba->h_ctl[i] = 0.0;
     ba->h_ctl[0] = lambda;
-    SVS_HIP(ctx, hipMemcpyAsync(ba->d_ctl, ba->h_ctl, sizeof(double) * n_ctl, hipMemcpyHostToDevice, ctx->stream));
-    int cur = ba->cur;
-    for (int j = 0; j < n_it; ++j) {
-      int rc = enqueue_trial(ba, lambda, cur, ba->d_ctl, &ba->spec_ev[6 * j], smem, allreduce, user);
-      if (rc) return rc;
-      BaDev B = make_dev(ba, lambda, cur, ba->d_ctl);
-      hipLaunchKernelGGL(ba_lm_kernel, dim3(1), dim3(64), 0, ctx->stream, B, j);      // (taking this decision in the last workgroup of the
-      SVS_LAUNCH_CHECK(ctx);                                                           //  previous kernel costs more than the launch: 400 same-address tickets)
-      cur = 1 - cur;                   // as if accepted
+    auto enqueue_all = [&]() -> int {
+      SVS_HIP(ctx, hipMemcpyAsync(ba->d_ctl, ba->h_ctl, sizeof(double) * n_ctl, hipMemcpyHostToDevice, ctx->stream));
+      int cur = ba->cur;
+      for (int j = 0; j < n_it; ++j) {
+        int rc = enqueue_trial(ba, lambda, cur, ba->d_ctl, &ba->spec_ev[6 * j], smem, allreduce, user);
+        if (rc) return rc;
+        BaDev B = make_dev(ba, lambda, cur, ba->d_ctl);
+        hipLaunchKernelGGL(ba_lm_kernel, dim3(1), dim3(64), 0, ctx->stream, B, j);      // (taking this decision in the last workgroup of the
+        SVS_LAUNCH_CHECK(ctx);                                                           //  previous kernel costs more than the launch: 400 same-address tickets)
+        cur = 1 - cur;                   // as if accepted
+      }
+      SVS_HIP(ctx, hipMemcpyAsync(ba->h_ctl, ba->d_ctl, sizeof(double) * n_ctl, hipMemcpyDeviceToHost, ctx->stream));
+      return SVS_OK;
+    };
+    // Replay from a graph where the launch sequence is a function of the resident problem alone: no collective callback between the kernels, no event brackets, and
+    // not the multi-workgroup solves (they go through the process-wide spin gate: a mutex and events of other contexts, nothing a recording can hold).
+    const bool graphable = !allreduce && !ba->timing && !ba->opt.no_graph && !(ba->grid_G > 0 && !ba->use_lds_solve);
+    if (!graphable) return enqueue_all();
+    // everything a recorded launch bakes in: the device view of the problem (pointers, counts, lambda) + the solver's configuration + the control blocks
+    uint64_t sig = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = static_cast<const unsigned char *>(p); for (size_t i = 0; i < nbytes; ++i) { sig ^= b[i]; sig *= 1099511628211ull; } };
+    { BaDev B0 = make_dev(ba, lambda, ba->cur, ba->d_ctl); mix(&B0, sizeof B0); }
+    const uint64_t cfg[] = {(uint64_t)ba->P, (uint64_t)ba->nw_sched, (uint64_t)ba->opt.nw, (uint64_t)ba->opt.nw4, (uint64_t)ba->use_fused_solve, (uint64_t)ba->use_lds_solve,
+                            (uint64_t)ba->fuse_P1, (uint64_t)ba->fuse_lds_panel, (uint64_t)ba->lds_solve_smem, (uint64_t)ba->env_R, (uint64_t)ba->perm_active, (uint64_t)n_it,
+                            (uint64_t)smem, (uint64_t)ba->red_count, (uint64_t)(uintptr_t)ba->d_x, (uint64_t)(uintptr_t)ba->d_upanel, (uint64_t)(uintptr_t)ba->d_rowmax2,
+                            (uint64_t)(uintptr_t)ba->d_rowmax, (uint64_t)(uintptr_t)ba->d_linv, (uint64_t)(uintptr_t)ba->d_colmin, (uint64_t)(uintptr_t)ba->d_perm,
+                            (uint64_t)(uintptr_t)ba->d_perm_sys, (uint64_t)(uintptr_t)ba->d_xfer, (uint64_t)(uintptr_t)ba->d_flags, (uint64_t)(uintptr_t)ba->d_ctl,
+                            (uint64_t)(uintptr_t)ba->h_ctl, (uint64_t)(uintptr_t)ba->d_red, (uint64_t)(uintptr_t)ba->d_scal, (uint64_t)(uintptr_t)ctx->stream};
+    mix(cfg, sizeof cfg);
+    svs_ba::Graph &G = ba->graph[ba->cur & 1];
+    if (!G.exec || G.sig != sig) {
+      if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      SVS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+      ba->capturing = true;
+      const int rc = enqueue_all();
+      ba->capturing = false;
+      const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc || e_end != hipSuccess || !graph) {      // a recording that failed leaves nothing behind: this call (and the next) takes the kernel-by-kernel path
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        ba->opt.no_graph = 1;
+        return rc ? rc : enqueue_all();
+      }
+      const hipError_t e_inst = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e_inst != hipSuccess) { G.exec = nullptr; (void)hipGetLastError(); ba->opt.no_graph = 1; return enqueue_all(); }
+      G.sig = sig;
+      ++ba->n_graph_captures;
     }
-    SVS_HIP(ctx, hipMemcpyAsync(ba->h_ctl, ba->d_ctl, sizeof(double) * n_ctl, hipMemcpyDeviceToHost, ctx->stream));
+    SVS_HIP(ctx, hipGraphLaunch(G.exec, ctx->stream));
+    ++ba->n_graph_launches;
   }
   return SVS_OK;
 }
@@ -1309,6 +1364,7 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   else if (n == "one_front") o.one_front = value != 0;
   else if (n == "no_fused_solve") o.no_fused_solve = value != 0;
   else if (n == "no_lds_panel") o.no_lds_panel = value != 0;
+  else if (n == "no_graph") o.no_graph = value != 0;
   else if (n == "no_lds_solve") o.no_lds_solve = value != 0;
   else if (n == "no_fused_cons") o.no_fused_cons = value != 0;
   else if (n == "no_grid_solve") o.no_grid_solve = value != 0;
@@ -1325,6 +1381,12 @@ extern "C" int svs_ba_set_option(svs_ba *ba, const char *name, int value) {
   return SVS_OK;
 }
 
+extern "C" int svs_ba_graph_stats(svs_ba *ba, int64_t *launches, int64_t *captures) {
+  if (!ba) return SVS_ERR_INVALID;
+  if (launches) *launches = ba->n_graph_launches;
+  if (captures) *captures = ba->n_graph_captures;
+  return SVS_OK;
+}
 extern "C" int svs_ba_info(svs_ba *ba, int32_t *solve_kind, int32_t *envelope_rows, int32_t *n_chunks, int32_t *n_wide) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->problem_valid);

@@ -42,6 +42,7 @@ struct svs_ctx {
                               // second launch with several workgroups per stream (dense.hip: the continuation launch); 0: off.  Measured on the bench batch (512
                               // streams): tracker stage 1.40 ms unsplit, 1.30 at K = 8..9, 1.33 at K = 10; the whole step 2.66-2.69 unsplit, 2.75 at K = 8 (the side
                               // stream's FAST no longer finds the tail to run in), 2.63 at K = 10
+  int trk_cont_slots = 0;     // "trk_cont_slots": workgroup slots the continuation launch sizes itself for (0: two per CU)
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
   void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)

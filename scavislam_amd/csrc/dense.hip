@@ -1552,7 +1552,7 @@ static int cont_setup(svs_ctx *ctx, int batch, TrackMulti &G, TrackCont &C) {
   C.count = reinterpret_cast<unsigned *>(scr + n_part + n_bar + n_bc);
   C.list = reinterpret_cast<int *>(scr + n_part + n_bar + n_bc + n_cnt);
   C.park = reinterpret_cast<TrkPark *>(scr + n_part + n_bar + n_bc + n_cnt + n_list);
-  C.K = ctx->trk_split; C.slots = 2 * ctx->n_cu;
+  C.K = ctx->trk_split; C.slots = ctx->trk_cont_slots > 0 ? ctx->trk_cont_slots : 2 * ctx->n_cu;
   SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * (n_bar + n_bc + n_cnt), ctx->stream));
   return SVS_OK;
 }

@@ -157,6 +157,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "mo_spec") c->mo_spec = value != 0;
   else if (n == "trk_flat") c->trk_flat = value != 0;
   else if (n == "trk_split") c->trk_split = value > 15 ? 15 : value;
+  else if (n == "trk_cont_slots") c->trk_cont_slots = value > 4096 ? 4096 : value;
   else if (n == "trk_seq_chi2") c->trk_seq_chi2 = value != 0;
   else if (n == "trk_lazy_chi2") c->trk_lazy_chi2 = value > 2 ? 1 : value;      // (2: kernel A/B only -- the passes store their terms, the accept test stays on the f64 sums)
   else SVS_REQUIRE(c, !"unknown option");

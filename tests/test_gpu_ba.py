@@ -827,3 +827,43 @@ def test_set_problem_device_route_equals_host_route(gpu_ctx, P, L):
     if P <= 15:
         poses_ref, psi_ref, st_ref = O.ba_optimize(prob["poses"], prob["psi"], edges, prob["cons"], cam, prm)
         assert _rel_update_err(pd, poses_ref, prob["poses"]) < 1e-6 and _rel_update_err(ld, psi_ref, prob["psi"]) < 1e-6
+
+
+def test_optimize_replays_a_recorded_graph(gpu_ctx):
+    """the all-accepted optimize of a resident window is recorded once as a HIP graph and replayed (svs_ba_graph_stats); same LM trajectory
+    and the same state (to the order of the f64 atomics) as the kernel-by-kernel path ("no_graph"), over repeated calls, after a reset of the state, after a rejected trial
+    (the host-driven remainder takes over behind the replay) and after the problem is replaced by one of another layout (new recording)."""
+    from scavislam_amd import synth
+    from scavislam_amd.backend import SlamGraphOptimizer
+    from scavislam_amd.ctypes_types import BaParams
+    ctx, stream = gpu_ctx
+    prm = BaParams.reference_defaults()
+    outs = {}
+    for mode in ("graph", "no_graph"):
+        opt = SlamGraphOptimizer(ctx, stream)
+        if mode == "no_graph":
+            opt.set_option("no_graph", 1)
+        rows = []
+        for (P, L, seed) in ((50, 20000, 2012), (50, 20000, 2012), (15, 3000, 7), (15, 3000, 7)):
+            prob = synth.ba_window(P, L, seed=seed)
+            cam = _cam(prob["cam"])
+            if not rows or rows[-1][0] != (P, L, seed):
+                opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
+            else:
+                opt.reset_state(prob["poses"], prob["psi"])
+            st = opt.optimize()
+            st2 = opt.optimize()                     # a second optimize from the state the first one left (the other state buffer is current if one trial was accepted)
+            poses, psi = opt.restoreDataFromG2o()
+            rows.append(((P, L, seed), (st.trials, st.accepted, st.iterations, st.terminated, st2.trials, st2.accepted), st.chi2_final, st2.chi2_final, poses, psi))
+        outs[mode] = (rows, opt.graph_stats())
+        opt.close()
+    (rg, (launches, captures)), (rn, (l0, c0)) = outs["graph"], outs["no_graph"]
+    assert (l0, c0) == (0, 0)
+    assert launches == 8 and 2 <= captures <= 6, (launches, captures)      # one recording per (layout, current state buffer), not one per call
+    for a, b in zip(rg, rn):
+        assert a[1] == b[1], (a[0], a[1], b[1])
+        np.testing.assert_allclose([a[2], a[3]], [b[2], b[3]], rtol=1e-9)
+        # poses to the order of the f64 atomics; landmarks: that pose noise times the back-substitution's amplification for weak-parallax points (several hundred, see
+        # test_every_solve_variant_matches_oracle) over two optimizes -- measured 1e-7 of psi ~ 1
+        assert np.abs(a[4] - b[4]).max() <= 1e-9 * max(1.0, np.abs(b[4]).max()) and np.abs(a[5] - b[5]).max() <= 1e-6 * max(1.0, np.abs(b[5]).max())
+    print(f"graph replay: {launches} optimizes from {captures} recordings; LM trajectories and states equal to the kernel-by-kernel path")
