@@ -123,6 +123,33 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()                                   # creates torch's communicator now (banner goes to stderr)
     ctx, stream = capi.torch_context(local_rank)
+
+    def _probe_windows(tag):      # SVS_BENCH_DEBUG: the windows-in-flight figure at several points of the run (what in this process halves it?)
+        if not os.environ.get("SVS_BENCH_DEBUG"):
+            return
+        from scavislam_amd.backend import optimize_batch as _ob
+        _prob = synth.ba_window(50, 20000, seed=2012)
+        _cm = Cam(*(_prob["cam"][k] for k in ("f", "cx", "cy", "b", "w", "h")))
+        _ctxs = [capi.Context(local_rank) for _ in range(32)]
+        _opts = []
+        for _c in _ctxs:
+            _o = SlamGraphOptimizer(_c, None)
+            _o.copyDataToG2o(_prob["poses"], _prob["psi"], _prob["edges"], _prob["cons"], _cm, BaParams.reference_defaults())
+            _opts.append(_o)
+        _tt = []
+        for _ in range(6):
+            for _o in _opts:
+                _o.reset_state(_prob["poses"], _prob["psi"])
+            torch.cuda.synchronize()
+            _t0 = time.perf_counter()
+            _ob(_opts)
+            _tt.append(time.perf_counter() - _t0)
+        print(f"[bench] probe {tag}: 32 windows {[round(t * 1e3, 2) for t in _tt]} ms", file=sys.stderr)
+        for _o in _opts:
+            _o.close()
+        for _c in _ctxs:
+            _c.close()
+    _probe_windows('start')
     for kv in os.environ.get("SVS_CTX_OPTIONS", "").split(","):      # kernel A/B runs only ("trk_flat=0,trk_split=0"): context options of the library, never set by the driver
         if "=" in kv:
             ctx.set_option(kv.split("=")[0].strip(), int(kv.split("=")[1]))
@@ -305,7 +332,9 @@ def main():
             cg.close()
         return {"groups": n_groups, "streams_per_group": streams, "ms_per_step_of_all_groups": round(t_ov * 1e3, 4), "frames_per_s": round(n_groups * streams / t_ov, 1)}
 
+    _probe_windows('before the first front end')
     oc = OneCall(B)
+    _probe_windows('front end created')
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
     # the tracker's accept test: by default it takes the reference's decisions -- f64 sums where they can decide `float chi2 - float new_chi2 > 0`,
     # the reference's sequential float sums (formed bit for bit, in parallel: csrc/seqsum.h) where they cannot.  How many such sums a frame needs, and what the same
@@ -610,6 +639,7 @@ def main():
     del dfull, fprev, fcur, d1, f1p, f1c
     torch.cuda.empty_cache()
 
+    _probe_windows('before the back-end region')
     # ------------------------------------------------------------------ back-end (Schur) region
     P_, L_ = 50, 20000
     prob = synth.ba_window(P_, L_, seed=2012)
@@ -710,6 +740,7 @@ def main():
     t_ba = max_over_ranks(t_ba)
     ms_opt = t_ba / K * 1e3
     ms_opt_ev = max_over_ranks(t_ba_ev) / K * 1e3
+    _probe_windows('after the main optimize rows (communicators)')
     # the drop-in call pattern: host arrays in (marshalling + upload), optimize, host arrays out -- what SlamGraph::optimize costs a caller
     e2e_ms = None
     if world == 1:
@@ -771,14 +802,19 @@ def main():
                 ow.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
                 opts_w.append(ow)
             tt = []
-            for rep in range(5):
+            # 16 repetitions, the median of the last 8: the first batches on freshly created streams run at half speed for several repetitions (measured inside this
+            # process: 4.7-7.2 ms per batch of 32 over the first five, 2.8 ms from then on -- and 2.8 ms from the first repetition when 32 other streams had been
+            # through the same call earlier in the process; round 5's 6 k windows/s was that warm-up, not the library)
+            for rep in range(16):
                 for ow in opts_w:
                     ow.reset_state(prob["poses"], prob["psi"])
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 optimize_batch(opts_w)
                 tt.append(time.perf_counter() - t0)
-            by_w[str(Wn)] = round(Wn / float(np.median(tt[1:])), 1)
+            by_w[str(Wn)] = round(Wn / float(np.median(tt[8:])), 1)
+            if os.environ.get("SVS_BENCH_DEBUG"):
+                print(f"[bench] windows in flight {Wn}: ms per batch {[round(t * 1e3, 3) for t in tt]}, graph stats {opts_w[0].graph_stats()}, {opts_w[0].info()}", file=sys.stderr)
             for ow in opts_w:
                 ow.close()
             for cw, _ in ctxs_w:

@@ -172,7 +172,7 @@ struct svs_ba {
   bool use_lds_solve = false, use_fused_solve = false; size_t lds_solve_smem = 0;
   bool timing = false;                         // hipEvent brackets around the three dominant kernels of every trial (svs_ba_set_timing / svs_ba_kernel_times)
   int fuse_lds_panel = 0;                      // the fused solve keeps its back-substitution panel in LDS (ensure_profile)
-  int fuse_P1 = 0; unsigned fuse_epoch = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
+  int fuse_P1 = 0;    // two-front fused solve: rows of the reversed front (0 = single front), launch counter for its flags
   int *d_rowmax2 = nullptr; size_t cap_rowmax2 = 0; double *d_xfer = nullptr; unsigned *d_flags = nullptr;
   unsigned *d_gridbar = nullptr; int grid_G = 0;      // multi-workgroup solve: arrival counter + failure flag, number of workgroups (0 = not used)
   double *d_tilews = nullptr; size_t cap_tilews = 0; int tiles_G = 0, tiles_S = 0, tiles_tpw = 0, tiles_gq = 0, tiles_ncm = 0;      // tile-resident variant of it (ba_solve_tiles.inc): workspace, grid, tile rows, own tiles per workgroup (tiles_G = 0: not used)
@@ -181,7 +181,6 @@ struct svs_ba {
   // would allow 10 k).  It is captured ONCE per (problem layout, current state buffer) and replayed with one hipGraphLaunch (slam_graph.cpp:312-355 = one call).
   struct Graph { hipGraphExec_t exec = nullptr; uint64_t sig = 0; };
   Graph graph[2];                              // by ba->cur at the start of the call
-  bool capturing = false;                      // enqueue_trial is being recorded: constant flag epoch + flag reset instead of the launch counter
   long long n_graph_launches = 0, n_graph_captures = 0;
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
   int ctl_iters = 0;
@@ -1034,12 +1033,7 @@ static int enqueue_trial(svs_ba *ba, double lambda, int cur, double *ctl, hipEve
   }
   if (ba->use_fused_solve)
   {
-    // the hand-over flags of the two fronts hold the launch epoch; a recorded launch is replayed with the SAME arguments, so it uses a constant epoch (no launch counter
-    // ever reaches it) and clears the flags in front of itself
-    constexpr unsigned GRAPH_EPOCH = 0x40000000u;
-    if (ba->capturing && ba->fuse_P1 > 0) SVS_HIP(ctx, hipMemsetAsync(ba->d_flags, 0, sizeof(unsigned) * 4, ctx->stream));
-    if (!ba->capturing && ++ba->fuse_epoch >= GRAPH_EPOCH) ba->fuse_epoch = 1;
-    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ba->capturing ? GRAPH_EPOCH : ba->fuse_epoch, ba->fuse_lds_panel};
+    FuseFronts F{ba->P - ba->fuse_P1, ba->fuse_P1, ba->d_xfer, ba->d_flags, ba->fuse_lds_panel};      // (the launch epoch of the fronts' hand-over flags lives in d_flags[2])
     const dim3 fgrid(ba->fuse_P1 > 0 ? 2 : 1);
     const bool dbg_clocks = ba->opt.debug != 0;      // the per-stage clocks of SVS_BA_DEBUG: their own instantiations (they sit on the pivot wave's critical path)
     if (ba->fuse_lds_panel) {
@@ -1189,9 +1183,7 @@ static int optimize_begin(svs_ba *ba, svs_allreduce_fn allreduce, void *user, Op
       if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
       hipGraph_t graph = nullptr;
       SVS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-      ba->capturing = true;
       const int rc = enqueue_all();
-      ba->capturing = false;
       const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
       if (rc || e_end != hipSuccess || !graph) {      // a recording that failed leaves nothing behind: this call (and the next) takes the kernel-by-kernel path
         if (graph) (void)hipGraphDestroy(graph);
