@@ -126,14 +126,21 @@ int svs_ctx_sync(svs_ctx *ctx);
    supplies the initial values, read once by svs_ctx_create.  A/B switches between kernels that return the same results:
    "match_legacy" (0: four candidate points per wave where the search window allows it, 1: the round-1/2 kernel, 2: one wave per
    point with the lean scan), "mo_legacy" (1: the record-walking motion-only kernel), "fe_overlap" (default 1: the one-call
-   front end enqueues FAST / block matching on a side stream beside the dense tracker; 0: everything on the context's stream).
+   front end enqueues FAST / block matching on a side stream beside the dense tracker; 0: everything on the context's stream),
+   "trk_flat" (default 1: batches of more than one stream per CU run the flat tracker kernel -- the sweep inlined, the LM state in LDS; 0: the
+   round-5 kernel, same bits), "trk_split" (default 10: in such batches a stream still iterating after that many trials on the finest level is
+   finished by a second launch with up to eight workgroups per stream -- same accept decisions, poses equal to 1e-12; 0: one launch).
    A context and every handle made from it are used by ONE thread at a time. */
 int svs_ctx_set_option(svs_ctx *ctx, const char *name, int value);
 /* The accept test of the quarter-grid tracker: DenseTracker::denseTrackingCpu accepts an LM step iff `float chi2 - float new_chi2 > 0` on two sums accumulated
    sequentially in one float (dense_tracking.cpp:229-262, 341-383).  Default ("trk_lazy_chi2" = 1): the library takes exactly those decisions -- its f64 sums decide
    wherever their difference is outside the rigorous rounding-error bound of the float sums, and inside the bound the float sums themselves are formed, bit for bit.
    "trk_seq_chi2" = 1 forms every sum by the literal sequential chain (slow; cross-check), "trk_lazy_chi2" = 0 compares the f64 sums alone (rounds 1-4).
-   Counters (blocking): "trk_exact_sums" float sums formed so far by this context's tracker launches, "trk_exact_fallbacks" how many of them needed the chain. */
+   Counters (blocking): "trk_exact_sums" float sums formed so far by this context's tracker launches, "trk_exact_fallbacks" how many of them needed the chain.
+   Host-side counters of the spin gate (kernels whose workgroups wait for each other inside one launch -- latency-mode trackers, multi-workgroup solves -- are kept from
+   starving each other across the contexts of a process; DenseTracker / SlamGraph::optimize on two threads, stereo_slam.cpp:196, backend.cpp:157-224):
+   "spin_lane_launches" launches of this context that skipped the gate (<= 16 workgroups AND provably fitting beside everything of that kind in flight),
+   "spin_gated_launches" launches that went through it. */
 int svs_ctx_get_stat(svs_ctx *ctx, const char *name, long long *out);
 void *svs_ctx_stream(svs_ctx *ctx);
 const char *svs_last_error(svs_ctx *ctx);
@@ -572,7 +579,8 @@ int svs_ba_set_comm(svs_ba *ba, svs_comm *comm);
 /* experiment / test switches of one optimizer (0 = default behaviour): "no_speculation", "one_front", "no_fused_solve",
    "no_lds_solve", "no_grid_solve", "no_tile_solve" (wide envelopes: the multi-workgroup Cholesky by block rows instead of the tile-resident one), "no_fused_cons", "debug" (1: phase timers, 2: Schur kernel timeline), "nw" (waves per Schur workgroup, 4..8),
    "p1" (rows of the reversed front), "group" (anchors dealt round-robin), "host_threads", "host_marshal" (svs_ba_set_problem: 0 = device marshalling from
-   8k edges, 1 = always host, 2 = always device).  The environment (SVS_BA_*,
+   8k edges, 1 = always host, 2 = always device), "no_graph" (1: svs_ba_optimize enqueues kernel by kernel instead of replaying its recorded graph,
+   see svs_ba_graph_stats), "no_lds_panel" (1: the fused solve's back-substitution panel through global memory, rounds 3-5).  The environment (SVS_BA_*,
    SVS_HOST_THREADS) only supplies the initial values, read once by svs_ba_create; values are clamped to their valid ranges. */
 int svs_ba_set_option(svs_ba *ba, const char *name, int value);
 /* building blocks exposed for parity tests and profiling */
@@ -596,7 +604,7 @@ int svs_ba_set_timing(svs_ba *ba, int on);
 int svs_ba_kernel_times(svs_ba *ba, float *reduce_ms, float *solve_ms, float *backsub_ms,
                         int32_t *n_reduce_launches);
 /* How svs_ba_optimize enqueues its work.  The all-accepted optimize of a resident window (SlamGraph::optimize, slam_graph.cpp:312-355: num_iters x { build, solve,
-   update, compare }) has a fixed launch topology; the library records it ONCE per problem layout as a HIP graph and replays it with one launch per call (the first rejected
+   update, compare }) has a fixed launch topology; the library records it once per problem layout (when a layout is seen for the second time) as a HIP graph and replays it with one launch per call (the first rejected
    trial falls back to the host-driven loop, as before).  *launches: optimizes replayed from a graph so far; *captures: recordings made (a new one whenever the layout,
    the buffers or the parameters change).  Option "no_graph" (svs_ba_set_option) keeps the kernel-by-kernel path.  Not used with an all-reduce callback / communicator,
    with svs_ba_set_timing, or with the multi-workgroup solves of wide envelopes. */

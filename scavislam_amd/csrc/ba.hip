@@ -179,7 +179,7 @@ struct svs_ba {
   // The all-accepted optimize of a resident window has a FIXED launch topology -- control upload, num_iters x (clear, Schur, [permute,] solve, [unpermute,] back-substitute,
   // decide), control read-back: ~25 stream operations, ~5 us of host time each, i.e. the ceiling of windows in flight (6 k windows / s in bench.py where the kernels
   // would allow 10 k).  It is captured ONCE per (problem layout, current state buffer) and replayed with one hipGraphLaunch (slam_graph.cpp:312-355 = one call).
-  struct Graph { hipGraphExec_t exec = nullptr; uint64_t sig = 0; };
+  struct Graph { hipGraphExec_t exec = nullptr; uint64_t sig = 0, seen = 0; };      // seen: the signature of the last call that ran kernel by kernel
   Graph graph[2];                              // by ba->cur at the start of the call
   long long n_graph_launches = 0, n_graph_captures = 0;
   double *d_ctl = nullptr, *h_ctl = nullptr;   // LM control block of the speculative path (device + pinned host mirror)
@@ -1179,6 +1179,9 @@ static int optimize_begin(svs_ba *ba, svs_allreduce_fn allreduce, void *user, Op
                             (uint64_t)(uintptr_t)ba->h_ctl, (uint64_t)(uintptr_t)ba->d_red, (uint64_t)(uintptr_t)ba->d_scal, (uint64_t)(uintptr_t)ctx->stream};
     mix(cfg, sizeof cfg);
     svs_ba::Graph &G = ba->graph[ba->cur & 1];
+    // a layout is recorded when it comes back: a sliding window whose observation count changes with every call (svs_ba_window_update) would otherwise pay a recording
+    // (capture + instantiation, ~0.2 ms) per call and never replay it
+    if ((!G.exec || G.sig != sig) && G.seen != sig) { G.seen = sig; return enqueue_all(); }
     if (!G.exec || G.sig != sig) {
       if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
       hipGraph_t graph = nullptr;

@@ -726,6 +726,54 @@ __device__ __noinline__ float exact_seq_sum_f32(const float *t_flat, int n) {
   return sh.result;
 }
 
+// The exact float sums of a near-tie when several workgroups share a stream (latency mode, continuation launch).  Every workgroup must take the same decision, the
+// sums must be formed ONCE (round 5 formed them in all eight workgroups), and nobody may start the next sweep -- which overwrites one of the two term buffers -- before
+// the readers are done.  Workgroup 0 forms the trial pass's sum; when the accepted pass's sum is not known either (the level's first near-tie, or the
+// first after an accepted step that needed no sums) workgroup 1 forms it AT THE SAME TIME on its own CU.  Each publishes ONE 8-byte word (count of such events << 32 | the
+// float's bits: value and flag in one atomic store, no fence, no second store) in the stream's hand-over block (bc[13]: trial sum, bc[15]: accepted sum), and every
+// workgroup waits for the word(s) it did not form itself.  n_dec / n_old: how many trial / accepted sums this stream has needed so far, this one included (all workgroups count alike).
+struct NearSums { float seq_old, seq_new; bool failed; };
+template <bool COH>
+__device__ __forceinline__ NearSums shared_near_sums(const float *t_old, const float *t_new, int n, int wg, int nwg, bool need_old, float seq_old_in, unsigned n_dec, unsigned n_old,
+                                                     double *bc, unsigned *fail_word, unsigned &n_exact) {
+  __shared__ unsigned long long s_words[2];
+  __shared__ int s_nf;
+  NearSums R{seq_old_in, 0.f, false};
+  if (nwg <= 1) {                                    // one workgroup: both sums here, nothing to hand over
+    if (need_old) { R.seq_old = exact_seq_sum_f32<COH>(t_old, n); ++n_exact; }
+    R.seq_new = exact_seq_sum_f32<COH>(t_new, n); ++n_exact;
+    return R;
+  }
+  unsigned long long *w_new = reinterpret_cast<unsigned long long *>(bc + 13), *w_old = reinterpret_cast<unsigned long long *>(bc + 15);
+  if (wg == 0) {
+    R.seq_new = exact_seq_sum_f32<COH>(t_new, n); ++n_exact;
+    if (threadIdx.x == 0) __hip_atomic_store(w_new, ((unsigned long long)n_dec << 32) | (unsigned long long)__float_as_uint(R.seq_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (wg == 1 && need_old) {
+    R.seq_old = exact_seq_sum_f32<COH>(t_old, n); ++n_exact;
+    if (threadIdx.x == 0) __hip_atomic_store(w_old, ((unsigned long long)n_old << 32) | (unsigned long long)__float_as_uint(R.seq_old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    int nf = 0;
+    auto wait_word = [&](const unsigned long long *w, unsigned want) {
+      unsigned long long v = 0;
+      long spin = 0;
+      for (; spin < (1l << 24); ++spin) { v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((unsigned)(v >> 32) >= want) break; __builtin_amdgcn_s_sleep(1); }
+      if (spin >= (1l << 24)) nf = 1;
+      return v;
+    };
+    s_words[0] = wg == 0 ? 0ull : wait_word(w_new, n_dec);
+    s_words[1] = (need_old && wg != 1) ? wait_word(w_old, n_old) : 0ull;
+    if (nf) __hip_atomic_store(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_nf = nf;
+  }
+  __syncthreads();
+  if (wg != 0) R.seq_new = __uint_as_float((unsigned)s_words[0]);
+  if (need_old && wg != 1) R.seq_old = __uint_as_float((unsigned)s_words[1]);
+  R.failed = s_nf != 0;
+  __syncthreads();                                   // (s_words is rewritten at the next near-tie)
+  return R;
+}
+
 // MULTI: a few streams only (latency mode) -- gridDim.x workgroups share every sweep of one stream.  Each leaves its 29 partial
 // sums in global memory, a device-scope counter barrier (all workgroups of the launch are resident: NW * batch <= #CUs) lets
 // every workgroup add the partials up in the same fixed order, and each then runs the identical LM bookkeeping redundantly,
@@ -765,7 +813,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   if (passes_out == reinterpret_cast<int *>(1)) { volatile int big[SVS_SCRATCH_PROBE]; for (int i = 0; i < SVS_SCRATCH_PROBE; ++i) big[i] = i; T_io[0] = big[threadIdx.x % SVS_SCRATCH_PROBE]; }
 #endif
   constexpr int TM = SEQ ? 1 : (SVS_TRK_LAZY ? (MULTI ? 2 : 1) : 0);      // the terms of a pass: plain stores, or past the caches when sibling workgroups read them
-  unsigned n_exact = 0, n_decisions = 0;      // exact float sums formed by this workgroup; (MULTI) accept decisions the leader has published so far
+  unsigned n_exact = 0, n_decisions = 0, n_old_sums = 0;      // exact float sums formed by this workgroup; near-ties of this stream so far / those of them that needed the accepted pass's sum as well (shared_near_sums)
   const int slot = BAL ? (bal_entry >> 4) : (MULTI ? blockIdx.y : blockIdx.x), wg = BAL ? (bal_entry & 15) : (MULTI ? blockIdx.x : 0);
   const int nwg = !MULTI ? 1 : (BAL ? (int)G.nwg_of[slot] : (int)gridDim.x);
   const int first = wg * TRK_THREADS + threadIdx.x;
@@ -914,47 +962,13 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
         const bool near = SVS_TRK_LAZY && tb[0] && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));      // (terms_only: kernel A/B -- the stores without the sums)
         if (near) {
           float seq_new = 0.f;
-          // MULTI: the stream's LEADER workgroup forms the sums and its siblings take its word (G.bcast [13]: both sums, [14]: how many such decisions have been
-          // published).  (a) the sums were formed eight times over from terms read past the caches (round 5: 0.075 ms of a latency-mode frame); (b) ADVICE round 5: the
-          // term buffers are not double-buffered against the NEXT sweep -- a sibling that went on while a slower one was still reading would overwrite what that one
-          // reads.  Now nobody starts the next sweep before the only reader is done.
-          const bool shared_decision = MULTI && !solo && nwg > 1;
-          if (!shared_decision || wg == 0) {
-#pragma nounroll
-            for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {      // (one copy of the routine in the kernel: it is long)
-              const float v = exact_seq_sum_f32<MULTI>(tb[k ? cur ^ 1 : cur], n_lvl);
-              if (k) seq_new = v; else seq_old = v;
-              ++n_exact;
-            }
-          }
-          if constexpr (MULTI) {
-            if (shared_decision) {
-              ++n_decisions;
-              unsigned long long *word = reinterpret_cast<unsigned long long *>(G.bcast + (size_t)slot * 16 + 13);
-              unsigned *epoch = reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 14);
-              if (wg == 0) {
-                if (threadIdx.x == 0) {
-                  const unsigned long long w = ((unsigned long long)__float_as_uint(seq_old) << 32) | (unsigned long long)__float_as_uint(seq_new);
-                  __hip_atomic_store(word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                  __hip_atomic_store(epoch, n_decisions, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              } else {
-                __shared__ unsigned long long s_word;
-                if (threadIdx.x == 0) {
-                  long spin = 0;
-                  for (; spin < (1l << 24) && __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_decisions; ++spin) __builtin_amdgcn_s_sleep(1);
-                  if (spin >= (1l << 24)) { __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = true; }
-                  s_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (s_failed) { failed = true; break; }
-                const unsigned long long w = s_word;
-                if (!seq_old_ok) seq_old = __uint_as_float((unsigned)(w >> 32));
-                seq_new = __uint_as_float((unsigned)w);
-                __syncthreads();                       // (s_word is rewritten at the next decision)
-              }
-            }
+          {
+            const bool shared = MULTI && !solo;      // (the coarsest level of a shared stream is run by its leader alone: its near-ties are not counted, the siblings never see them)
+            if (shared) { ++n_decisions; if (!seq_old_ok) ++n_old_sums; }
+            const NearSums ns = shared_near_sums<MULTI>(tb[cur], tb[cur ^ 1], n_lvl, shared ? wg : 0, shared ? nwg : 1, !seq_old_ok, seq_old, n_decisions, n_old_sums,
+                                                        MULTI ? G.bcast + (size_t)slot * 16 : nullptr, MULTI ? G.bar + G.fail_off + slot : nullptr, n_exact);
+            if (ns.failed) { s_failed = true; failed = true; break; }
+            seq_old = ns.seq_old; seq_new = ns.seq_new;
           }
           seq_old_ok = true;
           chi2 = seq_old; new_chi2 = seq_new;
@@ -1110,7 +1124,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
   for (int i = tid; i < 256; i += TRK_THREADS) g_iplut[i] = (float)((1. / 255.) * i);
   if (tid == 0) { g_seq_sh.fell_back = 0; s_failed = false; }
   int sweep = 0;                                   // MULTI: sweeps shared so far (parity of the partials' buffer, target of the arrival counter)
-  unsigned n_decisions = 0;
+  unsigned n_decisions = 0, n_old_sums = 0;          // near-ties of this stream so far / those that needed the accepted pass's sum too (shared_near_sums)
   if constexpr (!MULTI) {
     if (tid < 12) { const double v = T_io[(size_t)slot * 12 + tid]; g_sT[tid] = v; g_pa.T[tid] = v; }
     if (tid == 0) {
@@ -1190,42 +1204,13 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
         const bool near = SVS_TRK_LAZY && tb0 && !G.terms_only && !(fabs(S_old - S_new) > gam * (S_old + S_new));
         if (near) {
           float seq_new = 0.f;
-          const bool shared_decision = MULTI && nwg > 1;      // the leader forms the sums, its siblings take its word (dense_track_cpu_sem_kernel)
-          if (!shared_decision || wg == 0) {
-#pragma nounroll
-            for (int k = seq_old_ok ? 1 : 0; k < 2; ++k) {
-              const float v = exact_seq_sum_f32<MULTI>(tb0 + (size_t)((k ? cur ^ 1 : cur)) * G.terms_b, n_lvl);
-              if (k) seq_new = v; else seq_old = v;
-              ++n_exact;
-            }
-          }
-          if constexpr (MULTI) {
-            if (shared_decision) {
-              ++n_decisions;
-              unsigned long long *word = reinterpret_cast<unsigned long long *>(G.bcast + (size_t)slot * 16 + 13);
-              unsigned *epoch = reinterpret_cast<unsigned *>(G.bcast + (size_t)slot * 16 + 14);
-              if (wg == 0) {
-                if (tid == 0) {
-                  const unsigned long long w = ((unsigned long long)__float_as_uint(seq_old) << 32) | (unsigned long long)__float_as_uint(seq_new);
-                  __hip_atomic_store(word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                  __hip_atomic_store(epoch, n_decisions, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              } else {
-                __shared__ unsigned long long s_word;
-                if (tid == 0) {
-                  long spin = 0;
-                  for (; spin < (1l << 24) && __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_decisions; ++spin) __builtin_amdgcn_s_sleep(1);
-                  if (spin >= (1l << 24)) { __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = true; }
-                  s_word = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (s_failed) { failed = true; break; }
-                const unsigned long long w = s_word;
-                if (!seq_old_ok) seq_old = __uint_as_float((unsigned)(w >> 32));
-                seq_new = __uint_as_float((unsigned)w);
-              }
-            }
+          {
+            ++n_decisions;
+            if (!seq_old_ok) ++n_old_sums;
+            const NearSums ns = shared_near_sums<MULTI>(tb0 + (size_t)cur * G.terms_b, tb0 + (size_t)(cur ^ 1) * G.terms_b, n_lvl, wg, nwg, !seq_old_ok, seq_old, n_decisions, n_old_sums,
+                                                        MULTI ? G.bcast + (size_t)slot * 16 : nullptr, MULTI ? G.bar + G.fail_off + slot : nullptr, n_exact);
+            if (ns.failed) { if (tid == 0) s_failed = true; failed = true; break; }
+            seq_old = ns.seq_old; seq_new = ns.seq_new;
           }
           seq_old_ok = 1;
           chi2 = seq_old; new_chi2 = seq_new;

@@ -859,11 +859,13 @@ def test_optimize_replays_a_recorded_graph(gpu_ctx):
         opt.close()
     (rg, (launches, captures)), (rn, (l0, c0)) = outs["graph"], outs["no_graph"]
     assert (l0, c0) == (0, 0)
-    assert launches == 8 and 2 <= captures <= 6, (launches, captures)      # one recording per (layout, current state buffer), not one per call
+    # a layout is recorded when it is seen the second time (a window whose layout changes with every call never pays a recording): of the 8 optimizes the first of each
+    # (layout, current state buffer) runs kernel by kernel
+    assert 2 <= launches <= 6 and 2 <= captures <= 4 and captures <= launches, (launches, captures)
     for a, b in zip(rg, rn):
         assert a[1] == b[1], (a[0], a[1], b[1])
         np.testing.assert_allclose([a[2], a[3]], [b[2], b[3]], rtol=1e-9)
         # poses to the order of the f64 atomics; landmarks: that pose noise times the back-substitution's amplification for weak-parallax points (several hundred, see
         # test_every_solve_variant_matches_oracle) over two optimizes -- measured 1e-7 of psi ~ 1
         assert np.abs(a[4] - b[4]).max() <= 1e-9 * max(1.0, np.abs(b[4]).max()) and np.abs(a[5] - b[5]).max() <= 1e-6 * max(1.0, np.abs(b[5]).max())
-    print(f"graph replay: {launches} optimizes from {captures} recordings; LM trajectories and states equal to the kernel-by-kernel path")
+    print(f"graph replay: {launches} of 8 optimizes replayed from {captures} recordings; LM trajectories and states equal to the kernel-by-kernel path")
