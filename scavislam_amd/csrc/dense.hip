@@ -821,6 +821,42 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
   auto all_workgroups = [&]() {      // s_out[0..NSUM] <- sum over the workgroups of this stream
     if (!MULTI) return;
     if (BAL && nwg == 1) return;
+    if constexpr (!BAL) {
+      // Round 6: every 8-byte word carries its own flag (4 bytes of data + the sweep number: what NCCL calls the LL protocol).  A workgroup publishes its 29 sums as 58
+      // such words and reads the others' the moment they carry this sweep's number: ONE store-to-load hop between workgroups -- no drain of the store queue, no arrival
+      // counter (a device-scope read-modify-write), no second wait.  Rounds 2-5: stores, s_waitcnt vmcnt(0), barrier, counter += 1, poll the counter, barrier, loads --
+      // 4-5 us of a 10 us pass in latency mode.  Two parities of buffers: a word is overwritten two sweeps later, which its writer can only reach after every sibling has
+      // consumed this sweep (it needs their next sweep's words to get there).  The buffers are zeroed before the launch (sweep numbers start at 1).
+      const unsigned ep = (unsigned)(++sweep);
+      unsigned long long *buf = reinterpret_cast<unsigned long long *>(G.part) + ((size_t)slot * 2 + (ep & 1u)) * (size_t)nwg * 64;
+      bool timed_out = false;
+      if (threadIdx.x < 2 * (NSUM + 1)) {
+        const int k = threadIdx.x;
+        const double mine = s_out[k >> 1];
+        const unsigned my_half = (k & 1) ? (unsigned)__double2hiint(mine) : (unsigned)__double2loint(mine);
+        __hip_atomic_store(buf + (size_t)wg * 64 + k, ((unsigned long long)ep << 32) | my_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double acc = 0;
+        long budget = 1l << 24;
+        for (int w = 0; w < nwg; ++w) {                      // workgroup order: the same sum in every workgroup
+          unsigned h = my_half;
+          if (w != wg) {
+            unsigned long long v = __hip_atomic_load(buf + (size_t)w * 64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((unsigned)(v >> 32) != ep && budget > 0) { __builtin_amdgcn_s_sleep(1); --budget; v = __hip_atomic_load(buf + (size_t)w * 64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if ((unsigned)(v >> 32) != ep) timed_out = true;
+            h = (unsigned)v;
+          }
+          const unsigned other = (unsigned)__shfl_xor((int)h, 1, 64);      // even lane: the low half is mine, the high half my neighbour's
+          acc += __hiloint2double((int)((k & 1) ? h : other), (int)((k & 1) ? other : h));
+        }
+        if (!(k & 1)) s_out[k >> 1] = acc;                     // (this wave published from s_out before any lane of it writes here)
+      }
+      // a sibling never published (not resident: the device is shared with other work): raise the stream's failure flag -- the pose is left as it came in, passes_out reports -1
+      if (__syncthreads_or(timed_out ? 1 : 0)) {
+        if (threadIdx.x == 0) { __hip_atomic_store(G.bar + G.fail_off + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = true; }
+        __syncthreads();
+      }
+      return;
+    }
     // write-through 8-byte words + one arrival counter (relaxed, agent scope): no fence that would write an XCD's whole L2 back
     double *buf = G.part + ((size_t)slot * 2 + (sweep & 1)) * (BAL ? 4 : nwg) * 32;
     if (threadIdx.x <= NSUM) __hip_atomic_store(buf + wg * 32 + threadIdx.x, s_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1677,14 +1713,14 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, 2, true>), dim3(batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
   } else if (nwg >= 2) {
     double *scratch = nullptr;
-    const size_t n_part = (size_t)batch * 2 * nwg * 32;
+    const size_t n_part = (size_t)batch * 2 * nwg * 64;      // per stream, parity and workgroup: 58 (+ 6) flagged 8-byte words (all_workgroups)
     int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch + (size_t)batch * 16);      // + one counter word and one failure flag (4 + 4 bytes) per stream + the hand-over words
     if (rc) return rc;
     G.part = scratch;
     G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
     G.fail_off = batch;
     G.bcast = scratch + n_part + (size_t)batch;
-    SVS_HIP(ctx, hipMemsetAsync(G.bar, 0, sizeof(double) * ((size_t)batch + (size_t)batch * 16), ctx->stream));
+    SVS_HIP(ctx, hipMemsetAsync(scratch, 0, sizeof(double) * (n_part + (size_t)batch + (size_t)batch * 16), ctx->stream));      // flagged words, failure flags, hand-over words: one clear
     SvsSpinScope gate(ctx, nwg * batch);      // the workgroups of a stream wait for each other: one such launch on the device at a time (common.h); one stream: priority lane
     if (gate.rc) return gate.rc;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
