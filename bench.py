@@ -802,9 +802,9 @@ def main():
                 ow.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], camc, prm)
                 opts_w.append(ow)
             tt = []
-            # 16 repetitions, the median of the last 8: the first batches on freshly created streams run at half speed for several repetitions (measured inside this
-            # process: 4.7-7.2 ms per batch of 32 over the first five, 2.8 ms from then on -- and 2.8 ms from the first repetition when 32 other streams had been
-            # through the same call earlier in the process; round 5's 6 k windows/s was that warm-up, not the library)
+            # 16 repetitions, the median of the last 8.  The figure depends on how the runtime maps these 32 streams onto its hardware queues (4 per process by
+            # default): 10.4-11.5 k windows/s in a fresh process or when the streams are created before the front end's (which then loses a fifth of ITS throughput), 6-8 k
+            # created here, 8.7 k with GPU_MAX_HW_QUEUES=16 -- same library, same kernels (profiles/r6_notes.md section 5)
             for rep in range(16):
                 for ow in opts_w:
                     ow.reset_state(prob["poses"], prob["psi"])
