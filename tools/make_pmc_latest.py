@@ -53,6 +53,15 @@ def main(fetch_txt, write_txt, bench_log, df_fetch_txt=None, df_write_txt=None, 
         if sub == "dense_track_cpu_sem_kernel":      # the instantiation the bench batch runs by default: grid order by last frame's work (5th argument true), one workgroup per stream
             bal = [kk for kk in F if sub in kk and kk.rstrip().endswith("false, true>")]
             k = max(bal, key=lambda kk: F[kk][2]) if bal else k
+            # round 6: the bench batch runs the flat kernel (first launch: <U8SRC, BAL, 0>; the continuation <., ., 1> is reported beside it)
+            flat = [kk for kk in F if "dense_track_batch_kernel" in kk and ", 0>" in kk]
+            if flat:
+                k = max(flat, key=lambda kk: F[kk][2])
+                cont = [kk for kk in F if "dense_track_batch_kernel" in kk and ", 1>" in kk]
+                if cont:
+                    kc = max(cont, key=lambda kk: F[kk][2])
+                    res["kernels"]["dense_track_batch_kernel_continuation"] = {"kernel": kc, "launches_all_batch_sizes": F[kc][0], "fetch_raw": round(F[kc][2]), "write_raw": round(W.get(kc, (0, 0.0, 0.0))[2]),
+                                                                               "workload": {"batch_streams_per_gpu": B}, "source": "scavislam_amd/csrc/dense.hip", "source_sha16": sha("scavislam_amd/csrc/dense.hip")}
         if k:
             f, w = F[k][2], W.get(k, (0, 0.0, 0.0))[2]
             res["kernels"][key] = {"kernel": k, "launches_all_batch_sizes": F[k][0], "fetch_raw": round(f), "write_raw": round(w),
