@@ -125,6 +125,10 @@ int svs_process_matched_points_dev(svs_ctx *ctx, const svs_match_result *d_resul
                                    size_t pts_bstride, const int32_t *d_n_new_records, const svs_cam *cam, const double *d_T, float max_reproj_error,
                                    svs_gated_point *d_gated, size_t gated_bstride, svs_point_stats *d_stats, int batch);
 
+// internal: the dense clouds of the three levels in one launch (dense.hip)
+int svs_pointcloud_cpu_sem_levels(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride, const svs_cam *cams, const double *d_T, float *const *d_cloud,
+                                  const size_t *cloud_bstride, int batch);
+
 __host__ __device__ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 // ---- wave64 reductions (DPP/bpermute via __shfl; no LDS, no volatile warp idioms) -----------

@@ -1415,7 +1415,44 @@ __global__ __launch_bounds__(256) void pointcloud_cpu_sem_kernel(const float *__
   cloud_sample(disp + slot * disp_b, ds, cw, level, TQ, i, cloud + slot * cloud_b);
 }
 
+// the three levels' clouds of a frame in ONE launch (latency mode: three launches of 75 / 19 / 5 blocks each paid a launch gap); the same per-sample function: identical bits
+struct CloudLevels { svs_cam cam[3]; float *cloud[3]; size_t cloud_b[3]; int blocks[3]; };
+__global__ __launch_bounds__(256) void pointcloud_cpu_sem_levels_kernel(const float *__restrict__ disp, int ds, size_t disp_b, CloudLevels Q, const double *__restrict__ Tarr) {
+  const int slot = blockIdx.y;
+  int bx = blockIdx.x, level = 0;
+  if (bx >= Q.blocks[0]) { bx -= Q.blocks[0]; level = 1; if (bx >= Q.blocks[1]) { bx -= Q.blocks[1]; level = 2; } }
+  const svs_cam cam = level == 0 ? Q.cam[0] : (level == 1 ? Q.cam[1] : Q.cam[2]);
+  float *cloud = level == 0 ? Q.cloud[0] : (level == 1 ? Q.cloud[1] : Q.cloud[2]);
+  const size_t cloud_b = level == 0 ? Q.cloud_b[0] : (level == 1 ? Q.cloud_b[1] : Q.cloud_b[2]);
+  const int cw = cam.w / 4, ch = cam.h / 4;
+  const int i = bx * 256 + threadIdx.x;
+  if (i >= cw * ch) return;
+  double T[12], TQ[16];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = Tarr[(size_t)slot * 12 + k];
+  cloud_TQ(T, cam, TQ);
+  cloud_sample(disp + slot * disp_b, ds, cw, level, TQ, i, cloud + slot * cloud_b);
+}
+
 }  // namespace
+
+// internal (frontend.hip): computeDensePointCloudCpu of all three levels, one launch
+int svs_pointcloud_cpu_sem_levels(svs_ctx *ctx, const float *d_disp, int disp_stride, size_t disp_bstride, const svs_cam *cams, const double *d_T, float *const *d_cloud,
+                                  const size_t *cloud_bstride, int batch) {
+  SVS_REQUIRE(ctx, ctx && d_disp && cams && d_T && d_cloud && cloud_bstride && batch >= 1);
+  SVS_DEVICE(ctx);
+  CloudLevels Q;
+  int total = 0;
+  for (int l = 0; l < 3; ++l) {
+    SVS_REQUIRE(ctx, cams[l].w % 4 == 0 && cams[l].h % 4 == 0 && d_cloud[l]);
+    Q.cam[l] = cams[l]; Q.cloud[l] = d_cloud[l]; Q.cloud_b[l] = cloud_bstride[l];
+    Q.blocks[l] = div_up((cams[l].w / 4) * (cams[l].h / 4), 256);
+    total += Q.blocks[l];
+  }
+  hipLaunchKernelGGL(pointcloud_cpu_sem_levels_kernel, dim3(total, batch), dim3(256), 0, ctx->stream, d_disp, disp_stride, disp_bstride, Q, d_T);
+  SVS_LAUNCH_CHECK(ctx);
+  return SVS_OK;
+}
 
 static int ensure_scratch(svs_ctx *ctx, double **p, size_t count) {      // ctx-owned (common.h)
   void *v = nullptr;

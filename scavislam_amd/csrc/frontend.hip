@@ -670,7 +670,11 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
     }
   } else { STAGE_MARK(5); STAGE_MARK(6); }
   STAGE_MARK(7);
-  for (int l = 0; l < 3 && !fused_tail; ++l) {                                                // "dense point cloud" (reference for the next frame)
+  if (!fused_tail && !fe->prm.cuda_build) {                                                   // "dense point cloud" (reference for the next frame): three levels, one launch
+    size_t cb[3] = {fe->cloud_elems[0], fe->cloud_elems[1], fe->cloud_elems[2]};
+    if ((rc = svs_pointcloud_cpu_sem_levels(ctx, dv.p, dv.stride, dv.bstride, fe->cams, d_T, fe->d_cloud, cb, B))) return rc;
+  }
+  for (int l = 0; l < 3 && !fused_tail && fe->prm.cuda_build; ++l) {
     if (fe->prm.cuda_build)
       rc = svs_pointcloud_full_pose(ctx, d_T, &fe->cams[l], dv.p, dv.stride, dv.bstride, fe->w[l], fe->h[l], fe->w[l], fe->cloud_elems[l] / 4, 1 << l, fe->d_cloud[l], B);
     else
