@@ -389,6 +389,50 @@ def test_dense_tracking_lm_trajectory_many_scenes(gpu_ctx, B):
         np.testing.assert_allclose(T_c, T, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("nwg", [2, 16])
+def test_dense_tracking_latency_mode_other_workgroup_counts(gpu_ctx, nwg):
+    """Latency mode with 2 and 16 workgroups per stream (context option "trk_nwg"; the default of a one-stream call is 8): the per-sweep exchange as flagged 8-byte words
+    and the two-workgroup hand-over of a near-tie's float sums (round 6) do not depend on the count -- every LM record of four streams equals the oracle's, pose within 1e-9."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.frontend import DenseTracker, FramePyramid
+    ctx, stream = gpu_ctx
+    cam = synth.CAM_DEFAULT
+    B = 4
+    sc = synth.Scene(2011)
+    rng = np.random.default_rng(11)
+    base = synth.trajectory(6)
+    T_prev = [base[b % 6] for b in range(B)]
+    T_cur = [synth.pose_mul(synth.pose(synth.so3_exp([rng.normal(0, 5e-4), np.deg2rad(rng.uniform(0.05, 0.5)), rng.normal(0, 5e-4)]),
+                                       [rng.normal(0, 0.003), rng.normal(0, 0.002), -rng.uniform(0.02, 0.08)]), T_prev[b]) for b in range(B)]
+    prev_f = [sc.render(cam, T_prev[b], seed=700 + b) for b in range(B)]
+    cur_f = [sc.render(cam, T_cur[b], seed=800 + b) for b in range(B)]
+    prev = FramePyramid(ctx, stream, cam, batch=B)
+    cur = FramePyramid(ctx, stream, cam, batch=B)
+    prev.upload(np.stack([f[0] for f in prev_f]), np.stack([f[1] for f in prev_f]))
+    cur.upload(np.stack([f[0] for f in cur_f]), np.stack([f[1] for f in cur_f]))
+    prev.preprocessing(); cur.preprocessing()
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    dtp = DenseTracker(ctx, prev)
+    dtp.computeDensePointCloudCpu(I.reshape(12))
+    dt = DenseTracker(ctx, cur)
+    dt.ref_dense_points = dtp.ref_dense_points
+    ctx.set_option("trk_nwg", nwg)
+    try:
+        T, passes = dt.denseTrackingCpu(prev.pyr, I.reshape(12), from_u8=True)
+        recs = dt.lm_records()
+    finally:
+        ctx.set_option("trk_nwg", 0)
+    assert (passes > 0).all()
+    for b in range(B):
+        clouds = [O.pointcloud_cpu(prev_f[b][1], prev.cams[l], l, I) for l in range(3)]
+        pyr_p, pyr_c = O.build_pyramid(prev_f[b][0]), O.build_pyramid(cur_f[b][0])
+        fl = [O.convert_sobel(p) for p in pyr_c]
+        T_ref, passes_ref, rec_ref = O.dense_tracking_cpu(clouds, pyr_p, [f[0] for f in fl], [f[1] for f in fl], [f[2] for f in fl], cur.cams, I, want_rec=True)
+        _check_cpu_sem_trajectory(recs[b], passes[b], rec_ref, passes_ref, f"{nwg} workgroups per stream, stream {b}")
+        np.testing.assert_allclose(T[b], T_ref, rtol=0, atol=1e-9)
+
+
 def test_dense_tracking_big_batch_continuation_launch(gpu_ctx):
     """A batch of more than one stream per CU runs the flat tracker kernel, and with "trk_split" = K its streams that are still iterating after K trials on the finest
     level PARK and are finished by a second launch with 1 / 2 / 4 / 8 workgroups per stream (dense.hip: the continuation launch).  300 streams over 8 scenes, K = 0 (off),
