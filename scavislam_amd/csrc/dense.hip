@@ -788,7 +788,7 @@ __device__ __forceinline__ NearSums shared_near_sums(const float *t_old, const f
 #endif
 struct TrackMulti { double *part; unsigned *bar; int fail_off; double *bcast;
                     const int *map; const unsigned char *nwg_of;
-                    float *terms; size_t terms_b; unsigned *seq_stats; int terms_only; };      // the float terms of the accepted and of the trial pass, [batch][2][terms_b] (null: accept test on the f64 sums alone); [0] exact sums formed, [1] fallbacks to the chain      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
+                    float *terms; size_t terms_b; unsigned *seq_stats; int terms_only; int *work16; };      // work16 (optional, flat kernel): [batch] the stream's passes counted as 16 / 4 / 1 per sweep of level 0 / 1 / 2      // the float terms of the accepted and of the trial pass, [batch][2][terms_b] (null: accept test on the f64 sums alone); [0] exact sums formed, [1] fallbacks to the chain      // BAL only: workgroup -> (stream << 4 | part), workgroups per stream      // bcast [batch][16]: the pose after the coarsest level + a ready word (zeroed before the launch)      // [batch][2][nwg][32]; [batch] arrival counters + [batch] failure flags at bar + fail_off (zeroed before the launch)
 // MINW = minimum waves per SIMD the register allocation must allow: 2 (<= 256 VGPRs; the kernel takes 147: one 8-wave
 // workgroup per CU) when there is at most one stream per CU, 4 (<= 128 VGPRs, a few spills, two workgroups per CU) for
 // bigger batches, where the second resident workgroup hides the first one's dependent chains: 0.55 -> 0.45 ms per 256 streams.
@@ -1063,6 +1063,7 @@ __global__ __launch_bounds__(TRK_THREADS, MINW) void dense_track_cpu_sem_kernel(
 // above: bit-identical results (tests/test_gpu_frontend.py::test_flat_tracker_kernel_is_bit_identical).
 struct TrkState {
   double S_old; float chi2, seq_old;
+  int work16;                                                        // passes so far, weighted 16 / 4 / 1 by level (what trk_assign_kernel orders the next frame's grid by)
   int level, it, cur, passes, n_rec, nv_old, seq_old_ok, phase;      // phase 0: the sweep just run was the level's first (chi2 + H,b at the accepted pose); 1: a trial
   unsigned n_exact;
 };
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
   if constexpr (!MULTI) {
     if (tid < 12) { const double v = T_io[(size_t)slot * 12 + tid]; g_sT[tid] = v; g_pa.T[tid] = v; }
     if (tid == 0) {
-      g_ts.passes = 0; g_ts.n_rec = 0; g_ts.n_exact = 0;
+      g_ts.passes = 0; g_ts.n_rec = 0; g_ts.n_exact = 0; g_ts.work16 = 0;
       enter_level(2);
     }
     __syncthreads();
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
         if (tid < 27) g_sH[tid] = g_s_out[tid];
         if (tid == 0) {
           g_ts.S_old = S; g_ts.nv_old = (int)g_s_out[NSUM]; g_ts.chi2 = chi2; g_ts.seq_old_ok = 0; g_ts.seq_old = 0.f;
-          ++g_ts.passes; ++g_ts.n_rec;
+          ++g_ts.passes; ++g_ts.n_rec; g_ts.work16 += 16 >> (2 * level);
           if (A.rec && wg == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, 2, chi2, chi2};
         }
       } else {                                       // new_chi2 (:335-367) + H,b for the next iteration
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
         if (tid == 0) {
           if (accept) { g_ts.S_old = S_new; g_ts.nv_old = nv_new; g_ts.cur = cur ^ 1; g_ts.chi2 = new_chi2; }
           g_ts.seq_old = seq_old; g_ts.seq_old_ok = seq_old_ok; g_ts.it = it; g_ts.n_exact += n_exact;
-          ++g_ts.passes; ++g_ts.n_rec;
+          ++g_ts.passes; ++g_ts.n_rec; g_ts.work16 += 16 >> (2 * level);
           if (A.rec && wg == 0 && n_rec < A.rec_cap) A.rec[(size_t)slot * A.rec_cap + n_rec] = svs_dense_lm_record{level, accept ? 1 : 0, chi2, new_chi2};
         }
         // first launch: a stream that is still going after K trials on the finest level parks here (state of the accepted pass, before the solve)
@@ -1311,6 +1312,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_MINW_BIG) void dense_track_batch_k
   if (tid < 12) T_io[(size_t)slot * 12 + tid] = g_sT[tid];
   if (tid == 0 && passes_out) passes_out[slot] = g_ts.passes;
   if (tid == 0 && A.n_rec) A.n_rec[slot] = g_ts.n_rec;
+  if (tid == 0 && G.work16) G.work16[slot] = g_ts.work16;
   if (A.T_jac && tid < 36) A.T_jac[(size_t)slot * 36 + tid] = g_sTj[tid / 12][tid % 12];
   if (tid == 0 && G.seq_stats && g_ts.n_exact) {
     atomicAdd(G.seq_stats, g_ts.n_exact);
@@ -1506,7 +1508,7 @@ namespace {
 constexpr int BAL_MAX_STREAMS = 4096;
 constexpr int ASSIGN_THREADS = 1024;
 __global__ __launch_bounds__(ASSIGN_THREADS) void trk_assign_kernel(const svs_dense_lm_record *__restrict__ rec, int rec_cap, const int32_t *__restrict__ n_rec, int B, int slots, int x_max, int grid, float ratio, int *__restrict__ map,
-                                                          unsigned char *__restrict__ nwg_of) {
+                                                          unsigned char *__restrict__ nwg_of, const int *__restrict__ work16) {      // work16 (optional): the streams' work in 1/16 sweeps, left by the flat tracker kernel
   __shared__ __attribute__((aligned(16))) float s_w[BAL_MAX_STREAMS];
   __shared__ unsigned char s_n[BAL_MAX_STREAMS];
   __shared__ float s_red[ASSIGN_THREADS / 64];
@@ -1518,7 +1520,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void trk_assign_kernel(const svs_de
   int *s_wi = reinterpret_cast<int *>(s_w);
   for (int b = tid; b < B; b += ASSIGN_THREADS) s_wi[b] = 0;
   __syncthreads();
-  if (rec) {
+  if (work16) {      // round 6: the tracker counted while it ran (one word per stream instead of 64 records per stream: 524 KB through one workgroup was half of this kernel)
+    for (int b = tid; b < B; b += ASSIGN_THREADS) s_wi[b] = work16[b];
+  } else if (rec) {
     const int total = B * rec_cap;
     for (int base = tid; base < total; base += 8 * ASSIGN_THREADS) {
       int4 r[8];
@@ -1544,6 +1548,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void trk_assign_kernel(const svs_de
   for (int k = 0; k < ASSIGN_THREADS / 64; ++k) mean += s_red[k];
   mean /= (float)B;
   float M = ratio * mean;
+  if (x_max == 0) {      // order only ("trk_balance" = 1): every stream one workgroup -- nothing to fit (the loop below needed ~7 rounds of two barriers to find that out)
+    for (int b = tid; b < B; b += ASSIGN_THREADS) s_n[b] = 1;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+  } else
   for (int round = 0; round < 24; ++round) {
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
@@ -1631,7 +1640,7 @@ static int launch_batch_tracker(svs_ctx *ctx, const TrackArgs &A, bool u8src, do
   SVS_LAUNCH_CHECK(ctx);
   return gate.leave();
 }
-struct BalState { int *map; unsigned char *nwg_of; double *flags; size_t n_flags; int grid, x_max; };
+struct BalState { int *map; unsigned char *nwg_of; double *flags; size_t n_flags; int grid, x_max; int *work16; };      // work16 [batch]: each stream's LM work of the last frame in 1/16 level-0 sweeps (written by the flat tracker kernel)
 BalState bal_state(void *state, int batch) {
   BalState S;
   S.x_max = batch / 2; S.grid = batch + S.x_max;
@@ -1641,12 +1650,14 @@ BalState bal_state(void *state, int batch) {
   S.nwg_of = reinterpret_cast<unsigned char *>(take((size_t)batch));
   S.n_flags = (size_t)batch + (size_t)batch * 16;
   S.flags = reinterpret_cast<double *>(take(sizeof(double) * S.n_flags));
+  S.work16 = reinterpret_cast<int *>(take(sizeof(int) * (size_t)batch));
   return S;
 }
-int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_record *rec, int rec_cap, const int32_t *n_rec) {
+int bal_assign(svs_ctx *ctx, const BalState &S, int batch, const svs_dense_lm_record *rec, int rec_cap, const int32_t *n_rec, bool have_work = false) {
   const int x_max = ctx->trk_balance == 2 ? S.x_max : 0;
   const float ratio = 1.2f;
-  hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(ASSIGN_THREADS), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of);
+  hipLaunchKernelGGL(trk_assign_kernel, dim3(1), dim3(ASSIGN_THREADS), 0, ctx->stream, rec, rec_cap, n_rec, batch, 2 * ctx->n_cu, x_max, S.grid, ratio, S.map, S.nwg_of,
+                     have_work ? S.work16 : nullptr);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
@@ -1670,7 +1681,9 @@ int svs_dense_track_cpu_sem_balanced(svs_ctx *ctx, const TrackArgs &A, bool u8sr
     SVS_LAUNCH_CHECK(ctx);
     if (int grc = gate.leave()) return grc;
   } else if (ctx->trk_flat) {       // order only: one workgroup per stream, nothing waits for anything -- the flat kernel (round 6), bit-identical to the one below
+    G.work16 = S.work16;
     if (int lrc = launch_batch_tracker<true>(ctx, A, u8src, d_T_io, d_passes_out, batch, S.grid, G)) return lrc;
+    return bal_assign(ctx, S, batch, A.rec, A.rec_cap, A.n_rec, true);
   } else {
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
     else hipLaunchKernelGGL((dense_track_cpu_sem_kernel<false, false, TRK_MINW_BIG, false, true>), dim3(S.grid), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);
@@ -1686,7 +1699,7 @@ const int *svs_dense_track_balance_order(svs_ctx *ctx, void *state, int batch) {
 size_t svs_dense_track_balance_bytes(int batch) {
   const uintptr_t base = 1 << 16;                                  // (layout arithmetic only: nothing is dereferenced)
   const BalState S = bal_state(reinterpret_cast<void *>(base), batch);
-  return (size_t)(reinterpret_cast<uintptr_t>(S.flags) - base) + sizeof(double) * S.n_flags + 256;
+  return (size_t)(reinterpret_cast<uintptr_t>(S.work16) - base) + sizeof(int) * (size_t)batch + 256;
 }
 // zero history: every stream one workgroup, streams in index order
 int svs_dense_track_balance_init(svs_ctx *ctx, void *state, int batch) {
