@@ -43,6 +43,9 @@ struct svs_ctx {
                               // streams): tracker stage 1.40 ms unsplit, 1.30 at K = 8..9, 1.33 at K = 10; the whole step 2.66-2.69 unsplit, 2.75 at K = 8 (the side
                               // stream's FAST no longer finds the tail to run in), 2.63 at K = 10
   int trk_cont_slots = 0;     // "trk_cont_slots": workgroup slots the continuation launch sizes itself for (0: two per CU)
+  // set by the one-call front end around svs_match (few keyframes): the tracked pose / the active keyframe's pose per stream, from which the matcher's prediction kernel forms
+  // T_cur_from_w / T_w_from_actkey and the per-keyframe relative poses itself (match.hip) -- two small launches less between tracker and matcher
+  const double *match_src_T = nullptr, *match_src_Ta = nullptr;
   void *seq_buf = nullptr; size_t seq_buf_bytes = 0;      // the per-pass term buffers of both modes
   void *seq_stats = nullptr;                              // device: [0] exact float sums formed, [1] of those by the fallback chain (svs_ctx_get_stat)
   hipEvent_t spin_ev = nullptr;      // "a device-filling kernel of mine has finished" (svs_spin_enter / svs_spin_leave)

@@ -625,8 +625,13 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
   bool fused_tail = false;
   if (!first) {
     if (n > 0) {                                                                              // "match" + calcFastMotionOnly + "process points"
-      hipLaunchKernelGGL(frontend_pose_kernel, dim3(B), dim3(64), 0, ctx->stream, (const double *)d_T, (const double *)d_Ta, d_Tcw, d_Twa);
-      SVS_LAUNCH_CHECK(ctx);
+      // T_cur_from_w / T_w_from_actkey (matcher.cpp:326-330): with a handful of keyframes per stream the matcher's prediction kernel forms them itself (match.hip:
+      // match_predict_kernel<true>, same expressions, same bits) -- between the tracker and the matcher every launch is on the step's critical path
+      const bool pose_in_matcher = fe->max_keyframes <= 8;
+      if (!pose_in_matcher) {
+        hipLaunchKernelGGL(frontend_pose_kernel, dim3(B), dim3(64), 0, ctx->stream, (const double *)d_T, (const double *)d_Ta, d_Tcw, d_Twa);
+        SVS_LAUNCH_CHECK(ctx);
+      }
       svs_match_args ma{};
       ma.d_kfs = fe->d_kfs; ma.n_kf = fe->max_keyframes; ma.kf_bstride = (size_t)fe->max_keyframes; ma.d_pts = fe->d_pts; ma.n_pts = n;
       ma.pts_bstride = (size_t)fe->max_points; ma.out_bstride = (size_t)fe->max_points;
@@ -634,7 +639,10 @@ int frontend_chain(svs_frontend *fe, bool first, DispView dv, bool ext_frames = 
       for (int l = 0; l < 3; ++l) { ma.d_cur_pyr[l] = fe->d_pyr[cur][l]; ma.cur_stride[l] = fe->stride[l]; ma.cur_bstride[l] = fe->lvl_elems[l]; ma.cam_vec[l] = fe->cams[l]; }
       ma.d_disp = dv.p; ma.disp_stride = dv.stride; ma.disp_bstride = dv.bstride;
       ma.search_radius = fe->prm.search_radius; ma.thr_mean = fe->prm.thr_mean; ma.thr_std = fe->prm.thr_std; ma.n_batch = B;
-      if ((rc = svs_match(ctx, &ma, F, fe->d_res))) return rc;
+      ctx->match_src_T = pose_in_matcher ? d_T : nullptr; ctx->match_src_Ta = pose_in_matcher ? d_Ta : nullptr;
+      rc = svs_match(ctx, &ma, F, fe->d_res);
+      ctx->match_src_T = ctx->match_src_Ta = nullptr;
+      if (rc) return rc;
       if (fe->max_groups_used > 2) {
         hipLaunchKernelGGL(frontend_group_cut_kernel, dim3(B), dim3(256), 0, ctx->stream, fe->d_res, (size_t)fe->max_points, (const int32_t *)fe->d_group_end,
                            (const int32_t *)fe->d_n_groups, fe->prm.num_max_points);

@@ -116,6 +116,9 @@ struct MatchParams {
   int32_t *keys;          // [n_batch][n_pts] or NULL: the bucket of every point (written by match_predict_kernel, read by match_order_kernel)
   int32_t ord_sx, ord_sy, ord_nbx, ord_nb;      // its buckets: level * ord_nb + (vi >> ord_sy) * ord_nbx + (ui >> ord_sx); bucket 3 * ord_nb = points that are not searched
   LevelTab *lt;           // [SVS_NUM_PYR_LEVELS]
+  // optional (the one-call front end, few keyframes): the tracked pose and the active keyframe's pose per stream -- match_predict_kernel<true> then forms the two poses of
+  // matcher.cpp:326-330 and the per-keyframe relative poses itself (what frontend_pose_kernel + match_pose_kernel did in two launches of their own between tracker and matcher)
+  const double *src_T, *src_Ta;
 };
 
 // The two relative poses a candidate needs depend only on (camera stream, anchor keyframe), not on
@@ -151,9 +154,45 @@ __global__ void match_pose_kernel(MatchParams M, double *__restrict__ out) {
 
 // computePrediction (matcher.cpp:98-142) and the affine set-up of warpAffinve (:403-426), one lane per candidate point.
 // The same f64 expressions as before, evaluated once per point instead of redundantly by the 64 lanes of its wave.
+constexpr int PRED_FUSE_MAX_KF = 8;
+template <bool FUSE>
 __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   const svs_match_args &A = M.a;
   const int ip = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
+  __shared__ double s_kfT[FUSE ? PRED_FUSE_MAX_KF : 1][24];
+  if constexpr (FUSE) {
+    if (blockIdx.x == 0 && slot == 0) {                  // the level table match_kernel3 reads (match_pose_kernel's other job)
+#pragma unroll
+      for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
+        if ((int)threadIdx.x == l && l < M.fv.n_levels) {
+          LevelTab t;
+          t.score = M.fv.score[l]; t.cimg = A.d_cur_pyr[l]; t.score_bstride = M.fv.score_bstride[l]; t.cur_bstride = A.cur_bstride[l];
+          t.sstride = M.fv.score_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
+          t.xhi = min(M.fv.gx[l] * M.fv.cell_w[l], A.cam_vec[l].w - 6); t.yhi = min(M.fv.gy[l] * M.fv.cell_h[l], A.cam_vec[l].h - 6);
+          t.pad_[0] = t.pad_[1] = 0;
+          M.lt[l] = t;
+        }
+    }
+    const int kf = threadIdx.x;
+    if (kf < A.n_kf) {
+      // T_cur_from_w = T_cur_from_actkey * T_actkey_from_w, T_w_from_actkey = T_actkey_from_w^-1 (matcher.cpp:326-330; frontend_pose_kernel's operation order), then the
+      // two relative poses of keyframe kf (match_pose_kernel's): the same expressions in the same order, i.e. the same bits, computed per block instead of fetched
+      double Tc[12], Ta[12], Tcw[12], Twk[12], kfT[12], t0[12], t1[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { Tc[i] = M.src_T[(size_t)slot * 12 + i]; Ta[i] = M.src_Ta[(size_t)slot * 12 + i]; kfT[i] = A.d_kfs[(size_t)slot * A.kf_bstride + kf].T_anchor_from_w[i]; }
+      d_pose_mul(Tc, Ta, Tcw);
+      d_pose_inv(Ta, Twk);
+      d_pose_inv(kfT, t0);
+      d_pose_mul(Tcw, t0, t1);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s_kfT[kf][i] = t1[i];
+      d_pose_mul(kfT, Twk, t0);
+      d_pose_inv(t0, t1);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s_kfT[kf][12 + i] = t1[i];
+    }
+    __syncthreads();
+  }
   if (ip >= A.n_pts) return;
   const svs_candidate_point ap = A.d_pts[(size_t)slot * A.pts_bstride + ip];
   PointPred pr;
@@ -165,7 +204,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) pr.status = SVS_MATCH_NONE;  // no feature_tree for that level
   if (pr.status == SVS_MATCH_OK) {
     const svs_cam cam = A.cam_vec[ap.anchor_level];
-    const double *kfT = M.kf_T + ((size_t)slot * A.n_kf + ap.kf_index) * 24;
+    const double *kfT = FUSE ? s_kfT[ap.kf_index] : M.kf_T + ((size_t)slot * A.n_kf + ap.kf_index) * 24;
     double T_cur_from_anchor[12], xyz_cur[3];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T_cur_from_anchor[i] = kfT[i];
@@ -925,10 +964,17 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
     M.ord_sx = sx; M.ord_sy = sy; M.ord_nbx = (M.fv.w[0] + (1 << sx) - 1) >> sx; M.ord_nb = nb();
     M.keys = order + ord_bytes / sizeof(int32_t);
   }
-  hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M, kf_T);
-  SVS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(match_predict_kernel, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
-  SVS_LAUNCH_CHECK(ctx);
+  M.src_T = ctx->match_src_T; M.src_Ta = ctx->match_src_Ta;
+  if (M.src_T && M.src_Ta && a->n_kf <= PRED_FUSE_MAX_KF) {      // one launch instead of three (frontend_pose_kernel, match_pose_kernel, match_predict_kernel): the one-call front end
+    hipLaunchKernelGGL(match_predict_kernel<true>, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
+    SVS_LAUNCH_CHECK(ctx);
+  } else {
+    SVS_REQUIRE(ctx, a->d_T_cur_from_w && a->d_T_w_from_actkey);
+    hipLaunchKernelGGL(match_pose_kernel, dim3(div_up(a->n_kf, 64), a->n_batch), dim3(64), 0, ctx->stream, M, kf_T);
+    SVS_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(match_predict_kernel<false>, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
+    SVS_LAUNCH_CHECK(ctx);
+  }
   dim3 grid(div_up(a->n_pts, WAVES_PER_BLOCK), a->n_batch), block(64 * WAVES_PER_BLOCK);
   // the lean scan resolves a window's cells once per point: it needs windows narrower than a cell (always so for the reference's grids and radii)
   if (k3) {
