@@ -31,7 +31,7 @@ extern "C" {
 /* ABI version: bumped whenever a struct of this header grows or a signature changes (round 3 grew svs_pose_opt_params / svs_match_args and put a `stream`
    argument into svs_frontend_device_view without one -- INTEGRATION.md section 6).  A caller checks svs_api_version() == SVS_API_VERSION once, zero-initialises
    every parameter struct (or takes it from the *_default() initialisers) and sets only the fields it knows. */
-#define SVS_API_VERSION 6
+#define SVS_API_VERSION 7
 int svs_api_version(void);             /* the SVS_API_VERSION the loaded library was built with */
 
 enum {
@@ -202,9 +202,11 @@ int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const int32_t *str
 int svs_fast_download(svs_fast *f, int slot, int level, int16_t *h_xy, int cap, int32_t *h_n,
                       int32_t *h_cell_count, int32_t *h_emit_thr, int32_t *h_thr_state);
 int svs_fast_set_thresholds(svs_fast *f, int slot, int level, const int32_t *h_thr);
-/* device views for chaining into svs_match (score map: 0 = no corner, else score+1) */
-int svs_fast_device_view(svs_fast *f, int level, const uint8_t **d_score, int32_t *score_stride,
-                         size_t *score_bstride, const int32_t **d_emit_thr, size_t *emit_bstride);
+/* device view of a level's result for callers that chain their own kernels: the corner bitmap the matcher reads (1 bit per pixel, set = a corner of the last
+   detection; pixel (x, y) of cell column ci = x / cell_w is bit x + (cell_column_bits - cell_w) * ci of the row at byte y * row_stride_bytes -- cell columns start
+   on dword boundaries, rows end in >= 8 zero bytes) and the per-cell thresholds of that detection.  (API 7: replaces the dense score map of API <= 6.) */
+int svs_fast_device_view(svs_fast *f, int level, const uint32_t **d_corner_bits, int32_t *row_stride_bytes, size_t *batch_stride_bytes,
+                         int32_t *cell_column_bits, const int32_t **d_emit_thr, size_t *emit_bstride);
 
 /* ---- guided matcher: replaces GuidedMatcher<StereoCamera>::match (matcher.hpp:67-83) --------*/
 typedef struct {

@@ -109,8 +109,8 @@ _SIGS = {
     "svs_fast_download": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
                           C.c_void_p, C.c_void_p, C.c_void_p],
     "svs_fast_set_thresholds": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
-    "svs_fast_device_view": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
-                             C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "svs_fast_device_view": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_int32),
+                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "svs_match": [C.c_void_p, C.POINTER(MatchArgs), C.c_void_p, C.c_void_p],
     "svs_pointcloud_cpu_sem": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(Cam), C.c_int,
                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_int],
@@ -202,7 +202,7 @@ _SIGS = {
     "svs_ba_graph_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
 }
 EXPORTS = sorted(list(_SIGS) + ["svs_ctx_stream", "svs_last_error", "svs_api_version", "svs_pose_opt_params_default"])
-API_VERSION = 6      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
+API_VERSION = 7      # SVS_API_VERSION of include/scavislam_hip.h this binding was written against
 
 
 def load():

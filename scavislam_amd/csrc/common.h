@@ -53,6 +53,8 @@ struct svs_ctx {
   bool spin_lane = false;            // the launch between the last svs_spin_enter and its svs_spin_leave took the priority lane
   int spin_demand = 0;               // compute units that launch may hold (one per workgroup)
   long long spin_n_lane = 0, spin_n_gated = 0;      // svs_ctx_get_stat "spin_lane_launches" / "spin_gated_launches"
+  int xcd_swizzle = 1;        // "xcd_swizzle": tile kernels whose neighbouring tiles share image lines (FAST score, block matching, ...) hand every XCD a CONTIGUOUS range of
+                              // the linear workgroup index (xcd_contiguous below) so the shared lines are fetched into one L2, not into 2-3; 0: the dispatcher's round robin (A/B)
   int mo_legacy = 0;          // "mo_legacy": the record-walking motion-only kernel of rounds 1-2 instead of the fused one (A/B experiments)
 };
 // Kernels whose workgroups wait for each other INSIDE one launch (the latency-mode trackers, the multi-workgroup Cholesky) size their grids to a device they have
@@ -133,6 +135,14 @@ int svs_pointcloud_cpu_sem_levels(svs_ctx *ctx, const float *d_disp, int disp_st
                                   const size_t *cloud_bstride, int batch);
 
 __host__ __device__ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroup b of a launch is observed on XCD b % 8 (nothing promises it: speed only, never correctness).  Kernels whose neighbouring tiles share cache lines take their tile from
+// this bijective remap of the linear workgroup index instead: XCD x works through the contiguous range [x * n / 8, (x + 1) * n / 8) in dispatch order, so the lines two neighbours
+// share arrive in ONE L2 (any n, also n % 8 != 0).
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = id & 7u, k = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
 
 // ---- wave64 reductions (DPP/bpermute via __shfl; no LDS, no volatile warp idioms) -----------
 __device__ __forceinline__ int wave_sum_i32(int v) {

@@ -12,7 +12,14 @@
 //               clamps) on the suffix-summed histograms and produces the emit threshold, the
 //               persistent threshold and the output offset of every cell.
 //   K3 compact: one workgroup per cell emits the corners of the LAST executed detection in the
-//               reference's order (cells row-major, row-major inside the cell ROI).
+//               reference's order (cells row-major, row-major inside the cell ROI) and leaves them as
+//               a 1-bit-per-pixel CORNER BITMAP for the matcher.
+// There is no dense score image (rounds 1-5 wrote one byte per pixel and the compaction and the matcher read it back):
+// the score kernel leaves, per 64 x 32 tile, the sparse list of pixels whose score reaches t_lo (the lowest threshold
+// any cell can take) and the per-cell histograms; the compaction sets the listed pixels that reach the cell's emit
+// threshold in an LDS bitmap of the cell, counts / scans / emits from the bitmap (row-major = the reference's
+// order, any number of corners) and stores the bitmap; match.hip tests window positions against it (the reference's
+// matcher asks a quadtree of the emitted corners, matcher.cpp:351-357 -- not a score image).
 // Integer arithmetic throughout => corner lists are bit-exact to the oracle.
 #include "common.h"
 #include "fast_view.h"
@@ -27,9 +34,11 @@ struct LevelDev {
   int gx, gy, cell_w, cell_h;
   int min_inner, min_outer, max_inner, max_outer, fast_min, fast_max;
   int cell_base;          // index of this level's first cell in the per-slot cell arrays
-  uint8_t *score;         // [batch][h][score_stride]
-  int score_stride;
-  size_t score_bstride;
+  // corner bitmap [batch][h][bm_stride bytes]: pixel (x, y) of cell column ci is bit ci * 32 * bm_wpr + (x - ci * cell_w) of row y -- every cell column starts on a
+  // dword, so a cell's workgroup owns its dwords (plain stores of the whole cell every frame: no atomics, nothing to clear) and the pad bits between columns stay 0
+  uint32_t *bm;
+  int bm_wpr, bm_stride;  // dwords per cell row; bytes per image row (>= 8 bytes of zero padding behind the last bit a window can ask for)
+  size_t bm_bstride;      // bytes per slot
   int16_t *xy;            // [batch][cap][2]
 };
 struct FastParams {
@@ -38,14 +47,15 @@ struct FastParams {
   unsigned *hist;         // [batch][ncell_total][256]
   int *thr, *emit, *count, *offset;   // [batch][ncell_total]
   int *level_total;       // [batch][n_levels]
-  // corner candidates (score >= t_lo) of every tile, written by the score kernel: the compaction sorts these few records
-  // instead of sweeping the score map again.  cand [batch][n_tiles][CAND_CAP] = score8 << 24 | cell-local y << 12 | x
-  uint32_t *cand; int *cand_n;      // cand_n [batch][n_tiles] (may exceed CAND_CAP: then the cell falls back to the sweep)
+  // corner candidates (score >= t_lo) of every tile, written by the score kernel.  cand [batch][n_tiles][CAND_CAP] = score8 << 24 | cell-local y << 12 | x;
+  // CAND_CAP = the pixels of a tile, so a list cannot overflow (2 MB of address space per 640 x 480 frame slot, of which a textured frame touches ~25 KB)
+  uint32_t *cand; int *cand_n;      // cand_n [batch][n_tiles]
   int *cell_tile0, *cell_ntile;     // [ncell_total]: tiles of a cell are contiguous in the tile list
   int n_tiles;
+  int swz;                          // tiles in XCD-contiguous order (common.h: xcd_contiguous)
 };
-constexpr int CAND_CAP = 512;       // per 64x32 tile (2048 pixels)
-constexpr int CAND_CELL_CAP = 4096; // sorted in LDS per cell
+constexpr int CAND_CAP = 2048;      // per 64x32 tile = its pixels
+constexpr int BM_LDS_MAX = 144 * 1024;      // LDS bytes of the largest cell's bitmap + row offsets the compaction may use (checked at svs_fast_create)
 struct ImgPtrs {
   const uint8_t *img[SVS_NUM_PYR_LEVELS];
   int stride[SVS_NUM_PYR_LEVELS];
@@ -109,12 +119,14 @@ __device__ __forceinline__ uint32_t pair_of(const uint32_t (&w)[3], int b) {
 __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtrs I, const TileDesc *__restrict__ tiles) {
   __shared__ uint32_t s_img[(TH + 2 * HALO) * LROW];
   __shared__ unsigned s_hist[256];
-  __shared__ uint32_t s_sc[TH * 16];      // scores of the tile, one dword per 4 pixels
-  __shared__ uint16_t s_list[TW * TH];    // corners at t_lo (tile-local y<<8 | x)
   __shared__ uint16_t s_surv[TW * TH];    // pixels that pass the compass pre-test
   __shared__ int s_ncorn, s_nsurv;
-  const TileDesc td = tiles[blockIdx.x];
-  const int slot = blockIdx.y;
+  // neighbouring tiles share their halo rows (a 72-byte row of a tile lies in the 128-byte lines of two tiles): with the dispatcher's round robin the eight XCDs work on the
+  // same frame and every line is fetched into 2-3 L2s; in XCD-contiguous order an XCD works through whole frames
+  unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (P.swz) wg = xcd_contiguous(wg, gridDim.x * gridDim.y);
+  const int tile_i = wg % gridDim.x, slot = wg / gridDim.x;
+  const TileDesc td = tiles[tile_i];
   const LevelDev &L = P.lv[td.level];
   const int tid = threadIdx.x;
   const int ci = td.cell % L.gx, cj = td.cell / L.gx;
@@ -145,7 +157,6 @@ __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtr
   //      (ring positions 0, 4, 8, 12), so a corner at t needs two consecutive compass pixels that are both brighter than v + t or both darker than
   //      v - t.  Four ring positions instead of sixteen, three LDS rows instead of seven; ~20 % of the pixels of a textured frame survive at
   //      t_lo = 10 and are queued (the full 16-position boolean test cost 4x as much on every pixel).
-  for (int i = tid; i < TH * 16; i += 256) s_sc[i] = 0;
   if (tid == 0) { s_ncorn = 0; s_nsurv = 0; }
   __syncthreads();
   const int t = P.t_lo;
@@ -187,9 +198,10 @@ __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtr
     }
   }
   __syncthreads();
-  // ---- phase B: FAST score (max t) of the survivors; those that are corners at t_lo (score >= t_lo) are recorded
+  // ---- phase B: FAST score (max t) of the survivors; those that are corners at t_lo (score >= t_lo) go to the tile's candidate list and the cell's histogram
   const int nsurv = s_nsurv;
   const uint8_t *s_b8 = reinterpret_cast<const uint8_t *>(s_img);
+  uint32_t *cand = P.cand + ((size_t)slot * P.n_tiles + tile_i) * CAND_CAP;
   for (int i = tid; i < nsurv; i += 256) {
     const int code = s_surv[i], py = code >> 8, px = code & 0xff;           // tile-local pixel
     const int cb = (py + 3) * (LROW * 4) + px + 4;
@@ -206,32 +218,12 @@ __global__ __launch_bounds__(256, 8) void fast_score_kernel(FastParams P, ImgPtr
     const int sc = max((int)b2.x, (int)b2.y) - 1;                           // corner at t <=> sc >= t
     if (sc >= t) {
       const int s8 = min(sc + 1, 255);
-      reinterpret_cast<uint8_t *>(s_sc)[py * 64 + px] = (uint8_t)s8;
       atomicAdd(&s_hist[s8], 1u);
-      const int slot_i = atomicAdd(&s_ncorn, 1);
-      s_list[slot_i] = (uint16_t)code;
+      cand[atomicAdd(&s_ncorn, 1)] = ((uint32_t)s8 << 24) | ((uint32_t)(td.y0 + py) << 12) | (uint32_t)(td.x0 + px);      // (at most the tile's pixels = CAND_CAP)
     }
   }
   __syncthreads();
-  const int ncorn = s_ncorn;
-  {
-    uint32_t *cand = P.cand + ((size_t)slot * P.n_tiles + blockIdx.x) * CAND_CAP;
-    for (int i = tid; i < min(ncorn, CAND_CAP); i += 256) {
-      const int code = s_list[i], py = code >> 8, px = code & 0xff;
-      cand[i] = ((uint32_t)reinterpret_cast<const uint8_t *>(s_sc)[py * 64 + px] << 24) | ((uint32_t)(td.y0 + py) << 12) | (uint32_t)(td.x0 + px);
-    }
-    if (tid == 0) P.cand_n[(size_t)slot * P.n_tiles + blockIdx.x] = ncorn;
-  }
-  for (int ty = tid >> 4; ty < TH; ty += 16) {
-    const int cy = td.y0 + ty;
-    if (cy < L.cell_h && cx0 < L.cell_w) {
-      const uint32_t packed = s_sc[ty * 16 + tx];          // dword of this lane's 4 pixels
-      uint8_t *dst = L.score + (size_t)slot * L.score_bstride + (size_t)(v0 + cy) * L.score_stride + (u0 + cx0);
-      if (cx0 + 3 < L.cell_w) __builtin_memcpy(dst, &packed, 4);
-      else
-        for (int k = 0; k < 4 && cx0 + k < L.cell_w; ++k) dst[k] = (uint8_t)(packed >> (8 * k));
-    }
-  }
+  if (tid == 0) P.cand_n[(size_t)slot * P.n_tiles + tile_i] = s_ncorn;
   const unsigned c = s_hist[tid];
   if (c) atomicAdd(&P.hist[((size_t)slot * P.ncell_total + L.cell_base + td.cell) * 256 + tid], c);
 }
@@ -304,252 +296,79 @@ __global__ __launch_bounds__(256) void fast_adapt_kernel(FastParams P, int trial
   }
 }
 
-// K3: ordered compaction of one cell.  Sweep 1 counts per ROI row (one wave per row), an LDS scan
-// turns counts into offsets, sweep 2 writes (x,y) with a ballot prefix.
-__global__ __launch_bounds__(256) void fast_compact_2sweep_kernel(FastParams P, const int *__restrict__ ovf) {
-  if (ovf && !ovf[(size_t)blockIdx.y * P.ncell_total + blockIdx.x]) return;      // done by fast_compact_list_kernel
-  __shared__ int s_row[1024];
-  const int slot = blockIdx.y;
-  int c = blockIdx.x, lvl = 0;
-  while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
-  const LevelDev &L = P.lv[lvl];
-  const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
-  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
-  const int base = P.offset[(size_t)slot * P.ncell_total + c];
-  const uint8_t *score = L.score + (size_t)slot * L.score_bstride;
-  const int rows = L.cell_h - 6, cols = L.cell_w - 6;    // ROI interior
-  if (rows <= 0 || cols <= 0 || thr1 > 255) return;
-  {
-    const int nr = rows;                                   // <= 1024, checked at create
-    for (int r = wave; r < nr; r += 4) {
-      const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
-      int n = 0;
-      for (int xb = 0; xb < cols; xb += 64) {
-        int x = xb + lane;
-        bool hit = x < cols && p[x] >= thr1;
-        n += __popcll(__ballot(hit));
-      }
-      if (lane == 0) s_row[r] = n;
-    }
-    __syncthreads();
-    // exclusive scan of s_row[0..nr) by wave 0 (16 values per lane)
-    if (wave == 0) {
-      int v[16], tot = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; v[k] = idx < nr ? s_row[idx] : 0; tot += v[k]; }
-      int run = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { int dn = __shfl_up(run, o, 64); if (lane >= o) run += dn; }
-      int excl = run - tot;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; if (idx < nr) s_row[idx] = excl; excl += v[k]; }
-    }
-    __syncthreads();
-    int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
-    for (int r = wave; r < nr; r += 4) {
-      const int y = v0 + 3 + r;
-      const uint8_t *p = score + (size_t)y * L.score_stride + u0 + 3;
-      int o = base + s_row[r];
-      for (int xb = 0; xb < cols; xb += 64) {
-        int x = xb + lane;
-        bool hit = x < cols && p[x] >= thr1;
-        unsigned long long m = __ballot(hit);
-        if (hit) {
-          int pos = o + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < P.cap) { xy[2 * pos] = (int16_t)(u0 + 3 + x); xy[2 * pos + 1] = (int16_t)y; }
-        }
-        o += __popcll(m);
-      }
-    }
-  }
-}
-
-// K3 (default).  One global sweep: a wave reads one ROI row per load (4 score bytes per lane, unaligned
-// dword), turns it into four 64-bit ballots (bit = lane, one ballot per byte position) kept in LDS
-// with the row count; after the row scan the corners are emitted from the LDS masks alone.
-// Order inside a row: x = 4*lane + j  =>  rank = sum_j popc(ballot_j & lanes_below) + popc(own bits < j).
-constexpr int CMP_MAXROWS = 1024;
-// CMP_WAVES waves per cell: the sweep is a chain of global round trips per wave, so 16 waves (fewer trips each) win when
-// few cells are in flight (latency mode), 4 waves when the batch fills the device anyway.
-template <int CMP_WAVES>
-__global__ __launch_bounds__(CMP_WAVES * 64) void fast_compact_kernel(FastParams P, const int *__restrict__ ovf) {
-  if (ovf && !ovf[(size_t)blockIdx.y * P.ncell_total + blockIdx.x]) return;      // done by fast_compact_list_kernel
-  extern __shared__ unsigned long long s_mask[];      // [rows][chunks][4]
-  __shared__ int s_row[CMP_MAXROWS];
-  const int slot = blockIdx.y;
-  int c = blockIdx.x, lvl = 0;
-  while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
-  const LevelDev &L = P.lv[lvl];
-  const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
-  const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
-  const int base = P.offset[(size_t)slot * P.ncell_total + c];
-  const uint8_t *score = L.score + (size_t)slot * L.score_bstride;
-  const int rows = L.cell_h - 6, cols = L.cell_w - 6;    // ROI interior
-  if (rows <= 0 || cols <= 0 || thr1 > 255) return;
-  const int chunks = (cols + 255) / 256;
-  // 8 rows in flight per wave: the loads of a batch are issued back to back, so the sweep pays one
-  // global round trip per 8 rows instead of one per row
-  constexpr int RB = 8;
-  for (int r0 = wave * RB; r0 < rows; r0 += CMP_WAVES * RB) {
-    for (int ch = 0; ch < chunks; ++ch) {
-      const int x = ch * 256 + 4 * lane;
-      uint32_t v[RB];
-      if (cols >= 4) {
-        // branch-free: every lane loads a dword from a clamped position (the lane straddling the ROI edge shifts the
-        // out-of-ROI bytes away).  With a per-byte tail path the compiler put a full wait behind every row's load and
-        // the 8 loads of a batch were 16 serial round trips.
-        const int xs = min(x, cols - 4), sh = 8 * (x - xs);
-        const bool lane_in = x < cols;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-          const int r = min(r0 + i, rows - 1);
-          uint32_t raw;
-          __builtin_memcpy(&raw, score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3 + xs, 4);
-          v[i] = (lane_in && r0 + i < rows) ? (raw >> (sh & 31)) : 0u;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-          const int r = r0 + i;
-          v[i] = 0;
-          if (r < rows) {
-            const uint8_t *p = score + (size_t)(v0 + 3 + r) * L.score_stride + u0 + 3;
-            for (int j = 0; j < 4; ++j) if (x + j < cols) v[i] |= (uint32_t)p[x + j] << (8 * j);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int r = r0 + i;
-        if (r >= rows) break;                              // wave-uniform
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned long long bb = __ballot((int)((v[i] >> (8 * j)) & 0xff) >= thr1);
-          n += __popcll(bb);
-          if (lane == 0) s_mask[((size_t)r * chunks + ch) * 4 + j] = bb;
-        }
-        if (lane == 0) s_row[r] = (ch == 0 ? 0 : s_row[r]) + n;
-      }
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {                                       // exclusive scan of the row counts
-    int v[16], tot = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; v[k] = idx < rows ? s_row[idx] : 0; tot += v[k]; }
-    int run = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int dn = __shfl_up(run, o, 64); if (lane >= o) run += dn; }
-    int excl = run - tot;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { int idx = lane * 16 + k; if (idx < rows) s_row[idx] = excl; excl += v[k]; }
-  }
-  __syncthreads();
-  int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (int r = wave; r < rows; r += CMP_WAVES) {
-    int o = base + s_row[r];
-    const int y = v0 + 3 + r;
-    for (int ch = 0; ch < chunks; ++ch) {
-      unsigned long long b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = s_mask[((size_t)r * chunks + ch) * 4 + j];
-      int pos = o + __popcll(b[0] & below) + __popcll(b[1] & below) + __popcll(b[2] & below) + __popcll(b[3] & below);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if ((b[j] >> lane) & 1ull) {
-          if (pos < P.cap) {      // (x, y) as one dword store
-            const uint32_t pk = (uint32_t)(uint16_t)(u0 + 3 + ch * 256 + 4 * lane + j) | ((uint32_t)(uint16_t)y << 16);
-            __builtin_memcpy(xy + 2 * pos, &pk, 4);
-          }
-          ++pos;
-        }
-      }
-      o += __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
-    }
-  }
-}
-
-// K3 from the candidate lists: the cell's candidates at or above its emit threshold are collected in LDS (one wave per
-// tile list, 16 waves), ordered by (y, x) -- the row-major order of the reference -- and written out.  Up to 1024 corners
-// are ordered by counting ("my rank = number of smaller keys": n broadcast LDS reads per lane, no barrier), more by a
-// bitonic network.  A cell whose tiles or whose own list overflowed is left to the sweep kernels (ovf[cell] = 1).
-// grid: (ncell_total, batch), block 256 or 1024.
-constexpr int LST_MAXTILES = 1024;
-template <int LST_THREADS>      // 1024 when few cells are in flight (latency mode), 256 when the batch fills the device
-__global__ __launch_bounds__(LST_THREADS) void fast_compact_list_kernel(FastParams P, int *__restrict__ ovf) {
-  __shared__ uint32_t s_key[CAND_CELL_CAP];
-  __shared__ int s_tn[LST_MAXTILES];
-  __shared__ int s_n, s_ovf;
+// K3: ordered compaction of one cell from the candidate lists.  The listed pixels that reach the cell's emit threshold are set in an LDS bitmap of the
+// cell (one wave per tile list; LDS atomic OR, any order), a thread per row counts its bits, one wave scans the row counts, a thread per bitmap
+// dword emits its corners -- row-major = the reference's order (fast_grid.cpp:60-83: the cell's keypoints in cv::FAST's scan order) -- and the
+// bitmap leaves as the cell's part of the level's corner bitmap (match.hip).  No cap on the corners of a cell, nothing sorted, one launch.
+// grid: (ncell_total, batch); dynamic LDS: (rows * wpr + rows) * 4 bytes of the largest cell.
+template <int NT>      // 1024 when few cells are in flight (latency mode), 256 when the batch fills the device
+__global__ __launch_bounds__(NT) void fast_compact_bitmap_kernel(FastParams P) {
+  extern __shared__ uint32_t s_bm[];      // [rows][wpr] bitmap, then [rows] row offsets
   const int slot = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int lvl = 0;
   while (lvl + 1 < P.n_levels && c >= P.lv[lvl + 1].cell_base) ++lvl;
   const LevelDev &L = P.lv[lvl];
   const int cl = c - L.cell_base, ci = cl % L.gx, cj = cl / L.gx;
   const int u0 = ci * L.cell_w, v0 = cj * L.cell_h;
+  const int rows = L.cell_h, wpr = L.bm_wpr;
+  int *s_row = reinterpret_cast<int *>(s_bm + rows * wpr);
   const int thr1 = min(max(P.emit[(size_t)slot * P.ncell_total + c], 0), 255) + 1;
   const int base = P.offset[(size_t)slot * P.ncell_total + c];
-  const int t0 = P.cell_tile0[c], nt = P.cell_ntile[c];
-  if (tid == 0) { s_n = 0; s_ovf = nt > LST_MAXTILES ? 1 : 0; }
-  for (int t = tid; t < min(nt, LST_MAXTILES); t += LST_THREADS) s_tn[t] = P.cand_n[(size_t)slot * P.n_tiles + t0 + t];
+  for (int i = tid; i < rows * wpr; i += NT) s_bm[i] = 0u;
   __syncthreads();
-  if (thr1 <= 255 && !s_ovf)
-    for (int t = wave; t < nt; t += LST_THREADS / 64) {
-      const int n = s_tn[t];
-      if (n > CAND_CAP) { if (lane == 0) s_ovf = 1; continue; }
+  if (thr1 <= 255) {
+    const int t0 = P.cell_tile0[c], nt = P.cell_ntile[c];
+    for (int t = wave; t < nt; t += NT / 64) {
+      const int n = min(P.cand_n[(size_t)slot * P.n_tiles + t0 + t], CAND_CAP);
       const uint32_t *cand = P.cand + ((size_t)slot * P.n_tiles + t0 + t) * CAND_CAP;
       for (int i = lane; i < n; i += 64) {
         const uint32_t r = cand[i];
         if ((int)(r >> 24) >= thr1) {
-          const int k = atomicAdd(&s_n, 1);
-          if (k < CAND_CELL_CAP) s_key[k] = ((r >> 12) & 0xfffu) << 16 | (r & 0xfffu);
+          const int x = r & 0xfffu, y = (r >> 12) & 0xfffu;      // cell-local
+          atomicOr(&s_bm[y * wpr + (x >> 5)], 1u << (x & 31));
         }
       }
     }
-  __syncthreads();
-  const int n = s_n;
-  const bool over = s_ovf != 0 || n > CAND_CELL_CAP;
-  if (tid == 0) ovf[(size_t)slot * P.ncell_total + c] = over ? 1 : 0;
-  if (over || n == 0) return;
-  int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
-  auto emit = [&](int rank, uint32_t key) {
-    const int pos = base + rank;
-    if (pos < P.cap) {
-      const uint32_t pk = (uint32_t)(uint16_t)(u0 + (int)(key & 0xffffu)) | ((uint32_t)(uint16_t)(v0 + (int)(key >> 16)) << 16);
-      __builtin_memcpy(xy + 2 * pos, &pk, 4);
-    }
-  };
-  if (n <= 1024) {
-    for (int i = tid; i < n; i += LST_THREADS) {
-      const uint32_t key = s_key[i];
-      int rank = 0;
-      for (int j = 0; j < n; ++j) rank += s_key[j] < key;      // keys are distinct pixel positions
-      emit(rank, key);
-    }
-    return;
   }
-  int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = n + tid; i < m; i += LST_THREADS) s_key[i] = 0xffffffffu;
   __syncthreads();
-  for (int k = 2; k <= m; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < m; i += LST_THREADS) {
-        const int l = i ^ j;
-        if (l > i) {
-          const uint32_t a = s_key[i], b = s_key[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) { s_key[i] = b; s_key[l] = a; }
-        }
-      }
-      __syncthreads();
+  for (int r = tid; r < rows; r += NT) {
+    int n = 0;
+    for (int j = 0; j < wpr; ++j) n += __popc(s_bm[r * wpr + j]);
+    s_row[r] = n;
+  }
+  __syncthreads();
+  if (wave == 0) {                                       // exclusive scan of the row counts, 64 rows per step
+    int carry = 0;
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+      const int v = r0 + lane < rows ? s_row[r0 + lane] : 0;
+      int run = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int dn = __shfl_up(run, o, 64); if (lane >= o) run += dn; }
+      if (r0 + lane < rows) s_row[r0 + lane] = carry + run - v;
+      carry += __shfl(run, 63, 64);
     }
-  for (int i = tid; i < n; i += LST_THREADS) emit(i, s_key[i]);
+  }
+  __syncthreads();
+  int16_t *xy = L.xy + (size_t)slot * P.cap * 2;
+  uint32_t *gbm = L.bm + (size_t)slot * (L.bm_bstride / 4) + (size_t)v0 * (L.bm_stride / 4) + ci * wpr;
+  for (int i = tid; i < rows * wpr; i += NT) {
+    const int r = i / wpr, j = i - r * wpr;
+    uint32_t w = s_bm[i];
+    gbm[(size_t)r * (L.bm_stride / 4) + j] = w;
+    if (w) {
+      int pos = base + s_row[r];
+      for (int k = 0; k < j; ++k) pos += __popc(s_bm[r * wpr + k]);
+      while (w) {
+        const int b = __ffs((int)w) - 1;
+        w &= w - 1;
+        if (pos < P.cap) {      // (x, y) as one dword store
+          const uint32_t pk = (uint32_t)(uint16_t)(u0 + 32 * j + b) | ((uint32_t)(uint16_t)(v0 + r) << 16);
+          __builtin_memcpy(xy + 2 * pos, &pk, 4);
+        }
+        ++pos;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -559,10 +378,7 @@ struct svs_fast {
   FastParams P;
   int batch;
   TileDesc *d_tiles; int n_tiles;
-  std::vector<int> t_lo_src;
-  int *d_ovf = nullptr;       // [batch][ncell_total] cells the list compaction left to the sweep
-  bool use_lists = false;
-  bool force_cmp16 = false;   // SVS_FAST_NO_LISTS / SVS_FAST_CMP16, read once at svs_fast_create (experiments only)
+  size_t cmp_lds = 0;         // dynamic LDS of the compaction: bitmap + row offsets of the largest cell
 };
 
 extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, const int32_t *h,
@@ -576,20 +392,25 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
   P.n_levels = n_levels; P.cap = cap;
   std::vector<TileDesc> tiles;
   std::vector<int> cell_tile0, cell_ntile;
-  bool lists_ok = true;
   int cell_base = 0, t_lo = 255;
   for (int l = 0; l < n_levels; ++l) {
     const svs_fastgrid &g = grids[l];
     SVS_REQUIRE(ctx, g.gx >= 1 && g.gy >= 1 && g.gx * g.gy <= SVS_MAX_CELLS && g.cell_w * g.gx <= w[l] && g.cell_h * g.gy <= h[l]);
-    SVS_REQUIRE(ctx, g.cell_h - 6 <= 1024);
+    SVS_REQUIRE(ctx, g.cell_w <= 4096 && g.cell_h <= 4096);      // 12-bit cell-local coordinates in the candidate records
     LevelDev &L = P.lv[l];
     L.w = w[l]; L.h = h[l]; L.gx = g.gx; L.gy = g.gy; L.cell_w = g.cell_w; L.cell_h = g.cell_h;
     L.min_inner = g.min_inner; L.min_outer = g.min_outer; L.max_inner = g.max_inner; L.max_outer = g.max_outer;
     L.fast_min = g.fast_min; L.fast_max = g.fast_max; L.cell_base = cell_base;
-    L.score_stride = (w[l] + 63) / 64 * 64;
-    L.score_bstride = (size_t)L.score_stride * h[l];
-    SVS_HIP(ctx, hipMalloc(&L.score, L.score_bstride * batch));
-    SVS_HIP(ctx, hipMemsetAsync(L.score, 0, L.score_bstride * batch, ctx->stream));
+    // corner bitmap: cell columns on dword boundaries; a row ends with >= 8 zero bytes behind the last bit a window can ask for (match.hip reads 8 bytes from the
+    // byte of any in-image pixel), rows below the cell grid and the pad bits are zeroed here and never written
+    L.bm_wpr = (g.cell_w + 31) / 32;
+    const int gap = 32 * L.bm_wpr - g.cell_w;
+    L.bm_stride = ((std::max(w[l], g.gx * g.cell_w) + gap * (g.gx - 1) + 7) / 8 + 8 + 15) / 16 * 16;
+    SVS_REQUIRE(ctx, L.bm_stride >= 4 * L.bm_wpr * g.gx);
+    L.bm_bstride = (size_t)L.bm_stride * h[l] + 16;
+    SVS_HIP(ctx, hipMalloc(&L.bm, L.bm_bstride * batch));
+    SVS_HIP(ctx, hipMemsetAsync(L.bm, 0, L.bm_bstride * batch, ctx->stream));
+    f->cmp_lds = std::max(f->cmp_lds, ((size_t)g.cell_h * L.bm_wpr + g.cell_h) * 4);
     SVS_HIP(ctx, hipMalloc(&L.xy, sizeof(int16_t) * 2 * (size_t)cap * batch));
     for (int c = 0; c < g.gx * g.gy; ++c) {
       t_lo = std::min(t_lo, std::min(g.fast_min, g.thr[c]));
@@ -598,12 +419,16 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
         for (int x0 = 0; x0 < g.cell_w; x0 += TW) tiles.push_back(TileDesc{(int16_t)l, (int16_t)c, (int16_t)x0, (int16_t)y0});
       cell_ntile.push_back((int)tiles.size() - cell_tile0.back());
     }
-    lists_ok = lists_ok && g.cell_w <= 4096 && g.cell_h <= 4096;
     cell_base += g.gx * g.gy;
   }
   P.ncell_total = cell_base;
   P.t_lo = std::max(t_lo, 0);
   SVS_REQUIRE(ctx, (size_t)P.ncell_total * 256 * 4 <= 64 * 1024);
+  SVS_REQUIRE(ctx, f->cmp_lds <= (size_t)BM_LDS_MAX);      // a cell's bitmap lives in LDS during the compaction: cells up to ~1.1 M pixels (e.g. 1184 x 1024)
+  if (f->cmp_lds > 64 * 1024) {
+    SVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fast_compact_bitmap_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->cmp_lds));
+    SVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fast_compact_bitmap_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->cmp_lds));
+  }
   size_t nc = (size_t)P.ncell_total * batch;
   SVS_HIP(ctx, hipMalloc(&P.hist, nc * 256 * sizeof(unsigned)));
   SVS_HIP(ctx, hipMemsetAsync(P.hist, 0, nc * 256 * sizeof(unsigned), ctx->stream));
@@ -623,13 +448,10 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
   SVS_HIP(ctx, hipMemcpyAsync(P.thr, thr0.data(), nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   f->n_tiles = (int)tiles.size();
   P.n_tiles = f->n_tiles;
-  f->use_lists = lists_ok && !getenv("SVS_FAST_NO_LISTS");
-  f->force_cmp16 = getenv("SVS_FAST_CMP16") != nullptr;
   SVS_HIP(ctx, hipMalloc(&P.cand, sizeof(uint32_t) * (size_t)batch * tiles.size() * CAND_CAP));
   SVS_HIP(ctx, hipMalloc(&P.cand_n, sizeof(int) * (size_t)batch * tiles.size()));
   SVS_HIP(ctx, hipMalloc(&P.cell_tile0, sizeof(int) * cell_tile0.size()));
   SVS_HIP(ctx, hipMalloc(&P.cell_ntile, sizeof(int) * cell_ntile.size()));
-  SVS_HIP(ctx, hipMalloc(&f->d_ovf, sizeof(int) * nc));
   SVS_HIP(ctx, hipMemcpyAsync(P.cell_tile0, cell_tile0.data(), sizeof(int) * cell_tile0.size(), hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMemcpyAsync(P.cell_ntile, cell_ntile.data(), sizeof(int) * cell_ntile.size(), hipMemcpyHostToDevice, ctx->stream));
   SVS_HIP(ctx, hipMalloc(&f->d_tiles, sizeof(TileDesc) * tiles.size()));
@@ -642,10 +464,10 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
 extern "C" int svs_fast_destroy(svs_fast *f) {
   if (!f) return SVS_OK;
   (void)hipStreamSynchronize(f->ctx->stream);
-  for (int l = 0; l < f->P.n_levels; ++l) { hipFree(f->P.lv[l].score); hipFree(f->P.lv[l].xy); }
+  for (int l = 0; l < f->P.n_levels; ++l) { hipFree(f->P.lv[l].bm); hipFree(f->P.lv[l].xy); }
   hipFree(f->P.hist); hipFree(f->P.thr); hipFree(f->P.emit); hipFree(f->P.count); hipFree(f->P.offset);
   hipFree(f->P.level_total); hipFree(f->d_tiles);
-  hipFree(f->P.cand); hipFree(f->P.cand_n); hipFree(f->P.cell_tile0); hipFree(f->P.cell_ntile); hipFree(f->d_ovf);
+  hipFree(f->P.cand); hipFree(f->P.cand_n); hipFree(f->P.cell_tile0); hipFree(f->P.cell_ntile);
   delete f;
   return SVS_OK;
 }
@@ -657,34 +479,13 @@ extern "C" int svs_fast_detect(svs_fast *f, const uint8_t *const *d_img, const i
   svs_ctx *ctx = f->ctx;
   ImgPtrs I{};
   for (int l = 0; l < f->P.n_levels; ++l) { I.img[l] = d_img[l]; I.stride[l] = stride[l]; I.bstride[l] = bstride[l]; }
+  f->P.swz = ctx->xcd_swizzle;
   hipLaunchKernelGGL(fast_score_kernel, dim3(f->n_tiles, n_batch), dim3(256), 0, ctx->stream, f->P, I, f->d_tiles);
   SVS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(fast_adapt_kernel, dim3(n_batch), dim3(256), (size_t)f->P.ncell_total * 256 * sizeof(int), ctx->stream, f->P, trials);
   SVS_LAUNCH_CHECK(ctx);
-  // LDS need of the mask version: rows x chunks x 4 ballots of the largest cell
-  size_t mask_bytes = 0;
-  for (int l = 0; l < f->P.n_levels; ++l) {
-    const LevelDev &L = f->P.lv[l];
-    mask_bytes = std::max(mask_bytes, (size_t)std::max(L.cell_h - 6, 0) * (size_t)((std::max(L.cell_w - 6, 1) + 255) / 256) * 32);
-  }
-  // compaction from the score kernel's candidate lists; cells whose lists overflowed (and everything, if the lists are
-  // switched off) go through the score-map sweep
-  const int *ovf = nullptr;
-  if (f->use_lists) {
-    if ((long)f->P.ncell_total * n_batch <= 1024) hipLaunchKernelGGL(fast_compact_list_kernel<1024>, dim3(f->P.ncell_total, n_batch), dim3(1024), 0, ctx->stream, f->P, f->d_ovf);
-    else hipLaunchKernelGGL(fast_compact_list_kernel<256>, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P, f->d_ovf);
-    SVS_LAUNCH_CHECK(ctx);
-    ovf = f->d_ovf;
-  }
-  if (mask_bytes <= 56 * 1024)
-  {
-    if ((long)f->P.ncell_total * n_batch <= 1024 || f->force_cmp16)
-      hipLaunchKernelGGL(fast_compact_kernel<16>, dim3(f->P.ncell_total, n_batch), dim3(1024), mask_bytes, ctx->stream, f->P, ovf);
-    else
-      hipLaunchKernelGGL(fast_compact_kernel<4>, dim3(f->P.ncell_total, n_batch), dim3(256), mask_bytes, ctx->stream, f->P, ovf);
-  }
-  else
-    hipLaunchKernelGGL(fast_compact_2sweep_kernel, dim3(f->P.ncell_total, n_batch), dim3(256), 0, ctx->stream, f->P, ovf);
+  if ((long)f->P.ncell_total * n_batch <= 1024) hipLaunchKernelGGL(fast_compact_bitmap_kernel<1024>, dim3(f->P.ncell_total, n_batch), dim3(1024), f->cmp_lds, ctx->stream, f->P);
+  else hipLaunchKernelGGL(fast_compact_bitmap_kernel<256>, dim3(f->P.ncell_total, n_batch), dim3(256), f->cmp_lds, ctx->stream, f->P);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
@@ -725,13 +526,14 @@ extern "C" int svs_fast_set_thresholds(svs_fast *f, int slot, int level, const i
   return SVS_OK;
 }
 
-extern "C" int svs_fast_device_view(svs_fast *f, int level, const uint8_t **d_score, int32_t *score_stride,
-                                    size_t *score_bstride, const int32_t **d_emit_thr, size_t *emit_bstride) {
+extern "C" int svs_fast_device_view(svs_fast *f, int level, const uint32_t **d_corner_bits, int32_t *row_stride_bytes, size_t *batch_stride_bytes,
+                                    int32_t *cell_column_bits, const int32_t **d_emit_thr, size_t *emit_bstride) {
   SVS_REQUIRE(f ? f->ctx : nullptr, f && level >= 0 && level < f->P.n_levels);
   const LevelDev &L = f->P.lv[level];
-  if (d_score) *d_score = L.score;
-  if (score_stride) *score_stride = L.score_stride;
-  if (score_bstride) *score_bstride = L.score_bstride;
+  if (d_corner_bits) *d_corner_bits = L.bm;
+  if (row_stride_bytes) *row_stride_bytes = L.bm_stride;
+  if (batch_stride_bytes) *batch_stride_bytes = L.bm_bstride;
+  if (cell_column_bits) *cell_column_bits = 32 * L.bm_wpr;
   if (d_emit_thr) *d_emit_thr = f->P.emit + L.cell_base;
   if (emit_bstride) *emit_bstride = (size_t)f->P.ncell_total;
   return SVS_OK;
@@ -743,7 +545,7 @@ FastView svs_fast_view_internal(const svs_fast *f) {
   v.n_levels = f->P.n_levels; v.emit = f->P.emit; v.ncell_total = f->P.ncell_total;
   for (int l = 0; l < f->P.n_levels; ++l) {
     const LevelDev &L = f->P.lv[l];
-    v.score[l] = L.score; v.score_stride[l] = L.score_stride; v.score_bstride[l] = L.score_bstride;
+    v.bm[l] = reinterpret_cast<const uint8_t *>(L.bm); v.bm_stride[l] = L.bm_stride; v.bm_bstride[l] = L.bm_bstride; v.bm_gap[l] = 32 * L.bm_wpr - L.cell_w;
     v.cell_base[l] = L.cell_base; v.gx[l] = L.gx; v.gy[l] = L.gy; v.cell_w[l] = L.cell_w; v.cell_h[l] = L.cell_h;
     v.w[l] = L.w; v.h[l] = L.h;
   }

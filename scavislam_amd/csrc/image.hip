@@ -155,6 +155,7 @@ extern "C" int svs_ctx_set_option(svs_ctx *c, const char *name, int value) {
   else if (n == "match_order") c->match_order = value != 0;
   else if (n == "fe_fuse_tail") c->fe_fuse_tail = value != 0;
   else if (n == "mo_spec") c->mo_spec = value != 0;
+  else if (n == "xcd_swizzle") c->xcd_swizzle = value != 0;
   else if (n == "trk_flat") c->trk_flat = value != 0;
   else if (n == "trk_split") c->trk_split = value > 15 ? 15 : value;
   else if (n == "trk_cont_slots") c->trk_cont_slots = value > 4096 ? 4096 : value;

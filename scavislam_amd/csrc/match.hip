@@ -11,7 +11,7 @@
 //   match_kernel          ONE WAVEFRONT per candidate point: lane = pixel of the 8x8 key patch (only the used centre of the
 //                         reference's 10x10 warp is formed; the patch never leaves registers), texture sums by wave
 //                         reduction; the quadtree of the reference is replaced by a scan of the (2R+1)^2 search window in
-//                         the FAST score map of fast.hip (four positions per lane from one dword; a pixel is a candidate iff
+//                         the corner bitmap of fast.hip (a pixel is a candidate iff
 //                         its score clears the emit threshold of its cell); hits are compacted in LDS and scored one lane
 //                         per candidate with V_SAD_U8 / V_DOT4_U32_U8; the winner is the minimum ZNSSD, and the reference's
 //                         tie-break (first hit in QuadTree::query DFS order, strict '<') is reproduced with a quadrant key
@@ -89,12 +89,12 @@ struct alignas(16) PointPred {      // 128 bytes = one cache line, fields groupe
   int32_t status, ui, vi, lvl;
   double inv[4];          // inverse of the local affine A (matcher.cpp:415-426)
   double key_uv[2];       // anchor_obs_pyr
-  // for match_kernel2/3: the keyframe's level image (saves the dependent read of the keyframe record) and the search window's cell geometry --
-  // the one column / row boundary it may cross and the four emit thresholds (+1) of the cells it touches
+  // for match_kernel2/3: the keyframe's level image (saves the dependent read of the keyframe record) and where the search window's rows start in the corner
+  // bitmap of fast.hip: the padded bit position of the window's first in-image column and the one cell-column boundary the window may cross
   const uint8_t *kimg;
   int32_t kstride, xb;
   int32_t yb;
-  uint8_t t00m1, t01m1, t10m1, t11m1;      // thresholds - 1 (1..256 does not fit a byte)
+  int32_t pb_lo;          // max(ui - R, 0) + gap * (cell column of it)
   int32_t kfi, pad_;
   double xyz_actkey[3];
   double pad2_;
@@ -103,9 +103,9 @@ static_assert(sizeof(PointPred) == 128, "PointPred layout");
 // what match_kernel3 needs of a pyramid level, as a table in memory: its 16-lane groups work on points of different levels, so the level index is a vector
 // register there and the per-level kernel arguments cannot be picked with scalar indexing (written by match_pose_kernel)
 struct LevelTab {
-  const uint8_t *score, *cimg;
-  size_t score_bstride, cur_bstride;
-  int32_t sstride, cstride, w, h, xhi, yhi, pad_[2];
+  const uint8_t *bm, *cimg;
+  size_t bm_bstride, cur_bstride;
+  int32_t bm_stride, cstride, w, h, xhi, yhi, gap, pad_;
 };
 struct MatchParams {
   svs_match_args a;
@@ -133,10 +133,10 @@ __global__ void match_pose_kernel(MatchParams M, double *__restrict__ out) {
     for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
       if ((int)threadIdx.x == l && l < M.fv.n_levels) {
         LevelTab t;
-        t.score = M.fv.score[l]; t.cimg = A.d_cur_pyr[l]; t.score_bstride = M.fv.score_bstride[l]; t.cur_bstride = A.cur_bstride[l];
-        t.sstride = M.fv.score_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
+        t.bm = M.fv.bm[l]; t.cimg = A.d_cur_pyr[l]; t.bm_bstride = M.fv.bm_bstride[l]; t.cur_bstride = A.cur_bstride[l];
+        t.bm_stride = M.fv.bm_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
         t.xhi = min(M.fv.gx[l] * M.fv.cell_w[l], A.cam_vec[l].w - 6); t.yhi = min(M.fv.gy[l] * M.fv.cell_h[l], A.cam_vec[l].h - 6);      // isInFrame(uv, 6) and inside the cell grid
-        t.pad_[0] = t.pad_[1] = 0;
+        t.gap = M.fv.bm_gap[l]; t.pad_ = 0;
         M.lt[l] = t;
       }
   }
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
       for (int l = 0; l < SVS_NUM_PYR_LEVELS; ++l)
         if ((int)threadIdx.x == l && l < M.fv.n_levels) {
           LevelTab t;
-          t.score = M.fv.score[l]; t.cimg = A.d_cur_pyr[l]; t.score_bstride = M.fv.score_bstride[l]; t.cur_bstride = A.cur_bstride[l];
-          t.sstride = M.fv.score_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
+          t.bm = M.fv.bm[l]; t.cimg = A.d_cur_pyr[l]; t.bm_bstride = M.fv.bm_bstride[l]; t.cur_bstride = A.cur_bstride[l];
+          t.bm_stride = M.fv.bm_stride[l]; t.cstride = A.cur_stride[l]; t.w = A.cam_vec[l].w; t.h = A.cam_vec[l].h;
           t.xhi = min(M.fv.gx[l] * M.fv.cell_w[l], A.cam_vec[l].w - 6); t.yhi = min(M.fv.gy[l] * M.fv.cell_h[l], A.cam_vec[l].h - 6);
-          t.pad_[0] = t.pad_[1] = 0;
+          t.gap = M.fv.bm_gap[l]; t.pad_ = 0;
           M.lt[l] = t;
         }
     }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
   pr.status = SVS_MATCH_OK; pr.ui = pr.vi = 0; pr.lvl = ap.anchor_level; pr.kfi = ap.kf_index; pr.pad_ = 0; pr.pad2_ = 0;
   pr.inv[0] = pr.inv[1] = pr.inv[2] = pr.inv[3] = 0; pr.key_uv[0] = ap.anchor_obs_pyr[0]; pr.key_uv[1] = ap.anchor_obs_pyr[1];
   pr.xyz_actkey[0] = pr.xyz_actkey[1] = pr.xyz_actkey[2] = 0;
-  pr.kimg = nullptr; pr.kstride = 0; pr.xb = pr.yb = 0x7fffffff; pr.t00m1 = pr.t01m1 = pr.t10m1 = pr.t11m1 = 255;
+  pr.kimg = nullptr; pr.kstride = 0; pr.xb = pr.yb = 0x7fffffff; pr.pb_lo = 0;
   if (ap.kf_index < 0 || ap.kf_index >= A.n_kf) pr.status = SVS_MATCH_NO_ANCHOR;
   else if (ap.anchor_level < 0 || ap.anchor_level >= M.fv.n_levels) pr.status = SVS_MATCH_NONE;  // no feature_tree for that level
   if (pr.status == SVS_MATCH_OK) {
@@ -232,16 +232,13 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
       const int lvl = ap.anchor_level, R = A.search_radius;
       const svs_keyframe &kf = A.d_kfs[(size_t)slot * A.kf_bstride + ap.kf_index];
       pr.kimg = kf.pyr[lvl]; pr.kstride = kf.stride[lvl];
-      const int *emit = M.fv.emit + (size_t)slot * M.fv.ncell_total + M.fv.cell_base[lvl];
       const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
       const int x0 = pr.ui - R, y0 = pr.vi - R;
       int cxa = 0, cya = 0;
       for (int q = 1; q < gx; ++q) cxa += max(x0, 0) >= q * cw;
       for (int q = 1; q < gy; ++q) cya += max(y0, 0) >= q * chh;
       pr.xb = cxa + 1 < gx ? (cxa + 1) * cw : 0x7fffffff; pr.yb = cya + 1 < gy ? (cya + 1) * chh : 0x7fffffff;
-      const int cxb = min(cxa + 1, gx - 1), cyb = min(cya + 1, gy - 1);
-      pr.t00m1 = (uint8_t)min(max(emit[cya * gx + cxa], 0), 255); pr.t01m1 = (uint8_t)min(max(emit[cya * gx + cxb], 0), 255);
-      pr.t10m1 = (uint8_t)min(max(emit[cyb * gx + cxa], 0), 255); pr.t11m1 = (uint8_t)min(max(emit[cyb * gx + cxb], 0), 255);
+      pr.pb_lo = max(x0, 0) + M.fv.bm_gap[lvl] * cxa;
     }
   }
   M.pred[(size_t)slot * A.n_pts + ip] = pr;
@@ -253,6 +250,36 @@ __global__ __launch_bounds__(64) void match_predict_kernel(MatchParams M) {
     }
     M.keys[(size_t)slot * A.n_pts + ip] = b;
   }
+}
+
+// ---- the corner bitmap of fast.hip (fast.hip, LevelDev): pixel (x, y) of cell column ci is bit x + gap * ci of row y; rows end in >= 8 zero bytes ----
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ U4 ld_u4u(const uint8_t *p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }      // 16 bytes from any address: one global_load_dwordx4
+__device__ __forceinline__ U2 ld_u2u(const uint8_t *p) { U2 v; __builtin_memcpy(&v, p, 8); return v; }
+// one pixel (any x inside the image), the cell column found by compares: the general matcher, whose windows may be wider than a cell
+__device__ __forceinline__ bool corner_bit(const uint8_t *row, int x, int cw, int gx, int gap) {
+  int ci = 0;
+  for (int q = 1; q < gx; ++q) ci += x >= q * cw;
+  const int pb = x + gap * ci;
+  return ((row[pb >> 3] >> (pb & 7)) & 1u) != 0u;
+}
+// up to 25 window positions x0 .. of one row, bit k = position x0 + k, from the 8 bytes `q` at byte pb_lo >> 3 of the row: pb_lo = the padded position of max(x0, 0),
+// xb = the one cell-column boundary the positions may cross (windows narrower than a cell).  Positions left of the image read 0; the bits behind the window are the
+// caller's to mask.
+__device__ __forceinline__ uint32_t window_bits(U2 q, int pb_lo, int x0, int xb, int gap) {
+  const unsigned long long raw = (((unsigned long long)q.y << 32) | q.x) >> (pb_lo & 7);
+  const unsigned long long t = raw << max(-x0, 0);
+  const int nb = min(max(xb - x0, 0), 32);
+  const uint32_t lowmask = nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
+  return ((uint32_t)t & lowmask) | ((uint32_t)(t >> gap) & ~lowmask);
+}
+// bits of the positions x0 + k inside [xlo, xhi), k < n
+__device__ __forceinline__ uint32_t span_mask(int x0, int n, int xlo, int xhi) {
+  const int a = max(xlo - x0, 0), b = min(min(xhi - x0, n), 32);
+  if (b <= a) return 0u;
+  const uint32_t hi = b >= 32 ? 0xffffffffu : (1u << b) - 1u;
+  return hi & ~((1u << a) - 1u);
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -312,9 +339,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
       if (sumA * sumA - sumAA < A.thr_std * A.thr_std * 64) status = SVS_MATCH_TEXTURE;
       else {
         // ---- window scan + ZNSSD of every candidate corner ----------------------------------
-        const uint8_t *score = M.fv.score[lvl] + (size_t)slot * M.fv.score_bstride[lvl];
-        const int sstride = M.fv.score_stride[lvl];
-        const int *emit = M.fv.emit + (size_t)slot * M.fv.ncell_total + M.fv.cell_base[lvl];
+        const uint8_t *bm = M.fv.bm[lvl] + (size_t)slot * M.fv.bm_bstride[lvl];
+        const int bm_stride = M.fv.bm_stride[lvl], gap = M.fv.bm_gap[lvl];
         const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
         const uint8_t *cimg = A.d_cur_pyr[lvl] + (size_t)slot * A.cur_bstride[lvl];
         const int cstride = A.cur_stride[lvl];
@@ -332,7 +358,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
         int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-lane running best
         unsigned gkey = 0xffffffffu;
         int ncand = 0;                                 // wave-uniform fill of s_cand
-        // a lane tests four horizontally adjacent window positions from one (unaligned) dword of the score map
+        // a lane tests four horizontally adjacent window positions against the corner bitmap
         const int ngrp = (side + 3) >> 2, ntask = side * ngrp;
         const float inv_ngrp = 1.0f / (float)ngrp;
         const int xlo = 6, xhi = min(gx * cw, cam.w - 6), ylo = 6, yhi = min(gy * chh, cam.h - 6);      // isInFrame(uv, 6) and inside the cell grid
@@ -342,30 +368,14 @@ __global__ __launch_bounds__(256) void match_kernel(MatchParams M, svs_match_res
           const int wy = (int)(((float)task + 0.5f) * inv_ngrp), g4 = 4 * (task - wy * ngrp);      // exact for task < 2^12
           const int cy = vi - R + wy, cx0 = ui - R + g4;
           const bool row_ok = valid && cy >= ylo && cy < yhi;
-          uint32_t sc4 = 0;
-          int thrA = 256, thrB = 256, xb = 0x7fffffff;
-          if (row_ok) {
-            const uint8_t *srow = score + (size_t)cy * sstride;
-            if (cx0 >= 0 && cx0 + 3 < cam.w) __builtin_memcpy(&sc4, srow + cx0, 4);
-            else {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) if (cx0 + k >= 0 && cx0 + k < cam.w) sc4 |= (uint32_t)srow[cx0 + k] << (8 * k);
-            }
-            int cellx = 0, celly = 0;                   // grids are at most a few cells wide: compares beat divides
-            const int cxc = max(cx0, 0);
-            for (int q = 1; q < gx; ++q) cellx += cxc >= q * cw;
-            for (int q = 1; q < gy; ++q) celly += cy >= q * chh;
-            thrA = min(max(emit[celly * gx + cellx], 0), 255) + 1;
-            thrB = min(max(emit[celly * gx + min(cellx + 1, gx - 1)], 0), 255) + 1;
-            xb = (cellx + 1) * cw;                      // a 4-pixel group straddles at most one cell boundary (cells are >= 4 wide)
-          }
+          const uint8_t *brow = bm + (size_t)(row_ok ? cy : 0) * bm_stride;
           int nh = 0;
           unsigned long long mk[4];
           bool hk[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int cx = cx0 + k, sc = (int)((sc4 >> (8 * k)) & 0xffu);
-            hk[k] = row_ok && g4 + k < side && cx >= xlo && cx < xhi && sc >= (cx >= xb ? thrB : thrA);
+            const int cx = cx0 + k;
+            hk[k] = row_ok && g4 + k < side && cx >= xlo && cx < xhi && corner_bit(brow, cx, cw, gx, gap);
             mk[k] = __ballot(hk[k]);
           }
           const unsigned long long lt = (1ull << lane) - 1ull;
@@ -481,31 +491,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int lvl = __builtin_amdgcn_readfirstlane(pp.lvl);
     const svs_cam cam = A.cam_vec[lvl];
     const int ui = __builtin_amdgcn_readfirstlane(pp.ui), vi = __builtin_amdgcn_readfirstlane(pp.vi);
-    // ---- the first (at R <= 10: the only) trip of the window scan is requested NOW: its addresses depend on the prediction alone, so the score-map
+    // ---- the first (at R <= 10: the only) trip of the window scan is requested NOW: its addresses depend on the prediction alone, so the bitmap
     // read travels together with the keyframe pixels of the warp below instead of behind the texture gate
-    const uint8_t *score = M.fv.score[lvl] + (size_t)slot * M.fv.score_bstride[lvl];
-    const int sstride = M.fv.score_stride[lvl];
+    const uint8_t *bm = M.fv.bm[lvl] + (size_t)slot * M.fv.bm_bstride[lvl];
+    const int bm_stride = M.fv.bm_stride[lvl], gap = M.fv.bm_gap[lvl];
     const int gx = M.fv.gx[lvl], gy = M.fv.gy[lvl], cw = M.fv.cell_w[lvl], chh = M.fv.cell_h[lvl];
     const int side = 2 * R + 1, x0 = ui - R, y0 = vi - R;
     const int xlo = 6, xhi = min(gx * cw, cam.w - 6), ylo = 6, yhi = min(gy * chh, cam.h - 6);      // isInFrame(uv, 6) and inside the cell grid
     const int nseg = (side + 7) >> 3, ntask = side * nseg;
     const float inv_nseg = 1.0f / (float)nseg;
+    // a task = eight adjacent positions of a window row: the 8 bytes of the row's bitmap at the segment's first in-image column (`lo`: the bits, `hi`: the padded bit
+    // position of that column; the segment crosses at most one cell-column boundary)
     auto read8 = [&](int task, int &cy, int &cx0, int &g8, bool &row_ok, uint32_t &lo, uint32_t &hi) {
       const int wy = (int)(((float)task + 0.5f) * inv_nseg);      // exact for task < 2^12
       g8 = 8 * (task - wy * nseg);
       cy = y0 + wy; cx0 = x0 + g8;
-      row_ok = task < ntask && cy >= ylo && cy < yhi;
+      row_ok = task < ntask && cy >= ylo && cy < yhi && cx0 < cam.w && cx0 + 8 > 0;
       lo = 0; hi = 0;
       if (row_ok) {
-        const uint8_t *srow = score + (size_t)cy * sstride;
-        if (cx0 >= 0 && cx0 + 7 < cam.w) { __builtin_memcpy(&lo, srow + cx0, 4); __builtin_memcpy(&hi, srow + cx0 + 4, 4); }
-        else {
-          for (int k = 0; k < 8; ++k) {
-            const int cx = cx0 + k;
-            const uint32_t b = cx >= 0 && cx < cam.w ? (uint32_t)srow[cx] : 0u;
-            if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
-          }
-        }
+        const int xl = max(cx0, 0);
+        int ci = 0;
+        for (int q = 1; q < gx; ++q) ci += xl >= q * cw;
+        const int pb = xl + gap * ci;
+        const U2 w = ld_u2u(bm + (size_t)cy * bm_stride + (pb >> 3));
+        lo = window_bits(w, pb, cx0, ci + 1 < gx ? (ci + 1) * cw : 0x7fffffff, gap) & span_mask(cx0, min(8, side - g8), xlo, xhi);
       }
     };
     int cy_f, cx0_f, g8_f; bool row_ok_f; uint32_t lo_f, hi_f;
@@ -545,23 +554,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       uint32_t key4[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) key4[i] = (uint32_t)__builtin_amdgcn_readlane((int)kd, 4 * i);
-      // the window's cell geometry comes with the prediction (match_predict_kernel): one boundary per axis, four thresholds
-      const int xb = pp.xb, yb = pp.yb;
-      const int t00 = pp.t00m1 + 1, t01 = pp.t01m1 + 1, t10 = pp.t10m1 + 1, t11 = pp.t11m1 + 1;
       int gbest = 0x7fffffff, gx_ = 0, gy_ = 0;      // per-lane running best
       unsigned gkey = 0xffffffffu;
       for (int p0 = 0; p0 < ntask; p0 += 64) {
         if (lane == 0) s_ncand[wave] = 0;
         int cy = cy_f, cx0 = cx0_f, g8 = g8_f; bool row_ok = row_ok_f; uint32_t lo = lo_f, hi = hi_f;
         if (p0) read8(p0 + lane, cy, cx0, g8, row_ok, lo, hi);
-        const int tA = cy >= yb ? t10 : t00, tB = cy >= yb ? t11 : t01;
-        unsigned hits = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int cx = cx0 + k, sc = (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xffu);
-          const bool h = g8 + k < side && cx >= xlo && cx < xhi && sc >= (cx >= xb ? tB : tA);
-          hits |= (unsigned)h << k;
-        }
+        unsigned hits = lo;
+        (void)hi; (void)g8;
         hits = row_ok ? hits : 0u;
         __builtin_amdgcn_wave_barrier();
         while (hits) {                                 // sparse: ~10 hits per window
@@ -646,11 +646,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // one lane per candidate corner (2-10 of 64), the window scan two hits per 64 lanes, the 64-lane sums and the 16 readlanes of the key patch serve one
 // point.  Here a point has a DPP row: 16 lanes = the 8 x 8 key patch as 16 dwords (lane = row, half), which is the layout V_SAD_U8 / V_DOT4_U32_U8
 // want: a candidate costs one dword load and three dot products per lane and a 16-lane butterfly (quad_perm, row_half_mirror, row_mirror: DPP
-// modifiers, no LDS); the key patch never moves; the (2R+1)^2 window is one score-map row per lane (17 rows = 16 lanes + a shared last row), whose
-// non-zero bytes -- the score map is zero except at corners -- are found with byte-mask arithmetic instead of a compare per position.  Four points
+// modifiers, no LDS); the key patch never moves; the (2R+1)^2 window is one row of the corner bitmap per lane (17 rows = 16 lanes + a shared last row: 17 bits of an
+// 8-byte read).  Four points
 // share every instruction.  Needs 2R+1 <= 17 (the reference's radii: 8 on the CPU build, 4 on the CUDA build); wider windows take match_kernel2.
 // The order in which match_kernel3 takes the points of a stream.  The caller's lists come in hash order (the reference iterates tr1::unordered_maps): four
-// points that share a wave then sit anywhere in the image, every wave touches its own score-map, key-patch and image lines, and the kernel runs at the miss
+// points that share a wave then sit anywhere in the image, every wave touches its own bitmap, key-patch and image lines, and the kernel runs at the miss
 // rate of the vector L1 / L2.  A counting sort by (level, 16 x 16 pixel cell of the predicted position) makes neighbours in the order neighbours in the image
 // (match 0.83 -> 0.69 ms per 512 x 2000 points) and collects the points that are not searched (behind the camera, outside the frame) in waves of their own.
 // One workgroup per stream; the order inside a cell is whatever the atomics make it -- every point is matched on its own and written to its own record, so
@@ -689,11 +689,6 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {      // all-reduce o
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);      // row_mirror
   return v;
 }
-typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-typedef uint32_t U2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ U4 ld_u4u(const uint8_t *p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }      // 16 bytes from any address: one global_load_dwordx4
-__device__ __forceinline__ U2 ld_u2u(const uint8_t *p) { U2 v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t d) { return (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; }      // bit 7 of every non-zero byte
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_kernel3(MatchParams M, svs_match_result *__restrict__ out) {
   __shared__ uint16_t s_cand[M3_GROUPS][M3_CAND_CAP + 7];      // per point: window positions (wy << 5 | wx) waiting to be scored
   __shared__ int s_ncand[M3_GROUPS];
@@ -714,32 +709,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int Lw = Lp->w, Lh = Lp->h;
   // The kernel is bound by the L1 (it works per instruction and cache line touched) and short of registers at 8 waves per SIMD: wide requests, and
   // values re-read from the (cached) point record / level table where they are needed rather than carried.
-  // ---- (1) the window's score-map row of this lane: one 16-byte and one 4-byte request
-  uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, ex = 0;
+  // ---- (1) the window's corner-bitmap row of this lane and the 17th row (the same 8 bytes for the 16 lanes of the point: one request): 8-byte requests from the byte of the
+  // window's first in-image column (fast.hip: a bit per pixel, cell columns on dword boundaries, rows padded with zeros)
+  U2 w0 = {0u, 0u}, w1 = {0u, 0u};
   const int cy = y0 + sub, cyx = y0 + 16;
   {
-    const uint8_t *score = Lp->score + (size_t)slot * Lp->score_bstride;
-    const int sstride = Lp->sstride, yhi = Lp->yhi;
-    if (go && sub < side && cy >= 6 && cy < yhi) {
-      const uint8_t *srow = score + (size_t)cy * sstride;
-      if (x0 >= 0 && x0 + 20 <= Lw) {
-        const U4 q = ld_u4u(srow + x0);
-        d0 = q.x; d1 = q.y; d2 = q.z; d3 = q.w;
-        if (side > 16) __builtin_memcpy(&d4, srow + x0 + 16, 4);
-      } else {
-        for (int k = 0; k < side; ++k) {
-          const int cx = x0 + k;
-          const uint32_t b = cx >= 0 && cx < Lw ? (uint32_t)srow[cx] << (8 * (k & 3)) : 0u;
-          d0 |= k < 4 ? b : 0u; d1 |= (k >> 2) == 1 ? b : 0u; d2 |= (k >> 2) == 2 ? b : 0u; d3 |= (k >> 2) == 3 ? b : 0u; d4 |= k >= 16 ? b : 0u;
-        }
-      }
-    }
-    if (go && side > 16 && cyx >= 6 && cyx < yhi) {      // the 17th row: lane = column, the last lane also the 17th column
-      const uint8_t *srow = score + (size_t)cyx * sstride;
-      const int cx = x0 + sub;
-      if (cx >= 0 && cx < Lw) ex = srow[cx];
-      if (sub == 15 && cx + 1 >= 0 && cx + 1 < Lw) ex |= (uint32_t)srow[cx + 1] << 8;
-    }
+    const uint8_t *bm = Lp->bm + (size_t)slot * Lp->bm_bstride + (pp->pb_lo >> 3);
+    const int bm_stride = Lp->bm_stride, yhi = Lp->yhi;
+    const bool col_ok = go && x0 < Lw;
+    if (col_ok && sub < side && cy >= 6 && cy < yhi) w0 = ld_u2u(bm + (size_t)cy * bm_stride);
+    if (col_ok && side > 16 && cyx >= 6 && cyx < yhi) w1 = ld_u2u(bm + (size_t)cyx * bm_stride);
   }
   // ---- (2) warpAffinve, requests: the centre 8x8 of the 10x10 patch (KEY_PATCH, matcher.cpp:376-381), lane = (row, half): four pixels = one packed
   // dword.  The common case -- a warp close to a translation -- has the lane's four samples on one source row pair within 8 columns: two 8-byte
@@ -787,29 +766,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
   }
-  // ---- (3) hits of the window: non-zero score bytes that reach the emit threshold of their cell (one cell boundary per axis: match_predict_kernel).
-  // Before the texture gate, whose verdict only decides whether they are scored: the score bytes are not carried through the bilinear arithmetic.
+  // ---- (3) hits of the window: the set bits of the lane's row inside [6, xhi) (isInFrame(uv, 6) and inside the cell grid).  Before the texture gate, whose verdict
+  // only decides whether they are scored.
   {
-    const int xb = pp->xb, yb = pp->yb, xhi = Lp->xhi;
-    const int tU0 = pp->t00m1, tU1 = pp->t01m1, tL0 = pp->t10m1, tL1 = pp->t11m1;      // thresholds - 1: sc >= t  <=>  sc > t - 1
-    uint32_t m = go ? (nonzero_bytes(d0) >> 7) | (nonzero_bytes(d1) >> 6) | (nonzero_bytes(d2) >> 5) | (nonzero_bytes(d3) >> 4) | (nonzero_bytes(d4) >> 3) : 0u;
-    ex = go ? ex : 0u;
+    const int xb = pp->xb, pb_lo = pp->pb_lo, gap = Lp->gap;
+    const uint32_t span = span_mask(x0, side, 6, Lp->xhi);
+    uint32_t m = window_bits(w0, pb_lo, x0, xb, gap) & span;
+    const uint32_t m17 = window_bits(w1, pb_lo, x0, xb, gap) & span;
+    uint32_t ex = (m17 >> sub) & (sub == 15 ? 3u : 1u);      // the 17th row: lane = column, the last lane also the 17th column
     __builtin_amdgcn_wave_barrier();
     while (m) {
-      const int pos = __ffs((int)m) - 1;
+      const int k = __ffs((int)m) - 1;
       m &= m - 1;
-      const int j = pos & 7, b = pos >> 3, k = 4 * j + b;
-      const uint32_t dj = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : j == 3 ? d3 : d4;
-      const int sc = (int)((dj >> (8 * b)) & 0xffu), cx = x0 + k;
-      const int tm1 = cy >= yb ? (cx >= xb ? tL1 : tL0) : (cx >= xb ? tU1 : tU0);
-      if (k < side && cx >= 6 && cx < xhi && sc > tm1) s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((sub << 5) | k);
+      s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((sub << 5) | k);
     }
     while (ex) {
-      const int hi = (ex & 0xffu) ? 0 : 1;
-      const int sc = (int)(hi ? ex >> 8 : ex & 0xffu), k = sub + hi, cx = x0 + k;
-      ex = hi ? 0u : ex & ~0xffu;
-      const int tm1 = cyx >= yb ? (cx >= xb ? tL1 : tL0) : (cx >= xb ? tU1 : tU0);
-      if (cx >= 6 && cx < xhi && sc > tm1) s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((16 << 5) | k);
+      const int k = sub + ((ex & 1u) ? 0 : 1);
+      ex &= ex - 1;
+      s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((16 << 5) | k);
     }
   }
   // ---- (4) warpAffinve, arithmetic: the sample coordinates again (from the point record: 12 doubles not held across (3)), bilinear weights as the

@@ -42,6 +42,7 @@ struct StereoDev {
   int32_t *npend;        // [batch][n_strips]
   int timing;            // SVS_STEREO_DEBUG: phase stamps of one workgroup behind the error word
   int *err;              // [1] set when a bounded walk of the strip path gave up (never expected)
+  int swz;               // workgroups in XCD-contiguous order (common.h: xcd_contiguous)
 };
 
 __device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
@@ -265,11 +266,16 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
 template <bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void stereo_bm_kernel(StereoDev S) {
   __shared__ SelScr s_scr[64];
-  const int lane = threadIdx.x, b = blockIdx.z;
+  // column neighbours share 44 of their right-image bytes per row, strip neighbours six rows: an XCD works through whole frames (xcd_contiguous), so those lines
+  // are fetched into one L2
+  unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (S.swz) wg = xcd_contiguous(wg, gridDim.x * gridDim.y * gridDim.z);
+  const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y;
+  const int lane = threadIdx.x, b = wg / (gridDim.x * gridDim.y);
   const int w = S.w, h = S.h, width1 = w - NDISP + 1;
-  const int x = min(3 + blockIdx.x * 64 + lane, width1 - 1);      // lanes past the end redo the last column (no store)
-  const bool store = 3 + blockIdx.x * 64 + lane < width1;
-  const int y0 = blockIdx.y * BM_STRIP, y1 = min(y0 + BM_STRIP, h);
+  const int x = min(3 + bx * 64 + lane, width1 - 1);      // lanes past the end redo the last column (no store)
+  const bool store = 3 + bx * 64 + lane < width1;
+  const int y0 = by * BM_STRIP, y1 = min(y0 + BM_STRIP, h);
   const uint8_t *lp = S.lp + (size_t)b * h * S.pitch + PADL + (NDISP - 1) - WSZ2;      // uniform bases + one 32-bit lane offset for both images
   const uint8_t *rp = S.rp + (size_t)b * h * S.pitch + PADL - WSZ2;
   const uint32_t ft4 = 0x01010101u * (uint32_t)(S.cap + 1);
@@ -1113,6 +1119,7 @@ extern "C" int svs_stereo_compute(svs_stereo *s, const uint8_t *d_left, int lstr
   S.cap = s->prm.prefilter_cap; S.texthr = s->prm.texture_threshold; S.uniq = s->prm.uniqueness_ratio;
   S.speckle_window = s->prm.speckle_window; S.speckle_range = s->prm.speckle_range; S.disp12 = s->prm.disp12_max_diff;
   S.lp = s->d_lp; S.rp = s->d_rp; S.disp16 = s->d_disp16; S.cost = s->d_cost; S.label = s->d_label; S.count = s->d_count;
+  S.swz = ctx->xcd_swizzle;
   const int w = s->w, h = s->h, width1 = w - NDISP + 1, n = w * h;
   const bool aligned16 = w % 16 == 0 && s->pitch % 16 == 0 && lstride % 4 == 0 && rstride % 4 == 0 && l_bstride % 4 == 0 && r_bstride % 4 == 0 &&
                          ((uintptr_t)d_left | (uintptr_t)d_right) % 4 == 0 && !s->force_prefilter4;

@@ -1,14 +1,18 @@
 """block-matching stage on B stereo pairs (640x480): ms per batch; with rocprofv3 --kernel-trace --stats around it the per-kernel split.
-usage: python tools/time_stereo.py [B]"""
+usage: python tools/time_stereo.py [B] [first pair] [name=value ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from scavislam_amd import capi, synth
 from scavislam_amd.frontend import FramePyramid, StereoMatcher
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-OFF = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # first frame pair
+opts = [a for a in sys.argv[1:] if "=" in a]      # context options, e.g. xcd_swizzle=0
+args = [a for a in sys.argv[1:] if "=" not in a]
+B = int(args[0]) if len(args) > 0 else 512
+OFF = int(args[1]) if len(args) > 1 else 0      # first frame pair
 ctx, stream = capi.torch_context(0)
+for a in opts:
+    ctx.set_option(a.split("=")[0], int(a.split("=")[1]))
 sc = synth.Scene(2011)
 traj = synth.trajectory(5)
 pairs = [synth.render_stereo(sc, synth.CAM_DEFAULT, traj[i], seed=10 + i) for i in range(4)]
