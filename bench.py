@@ -336,6 +336,10 @@ def main():
     oc = OneCall(B)
     _probe_windows('front end created')
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
+    if os.environ.get("SVS_BENCH_TRACE_STOP"):      # kernel timelines (tools/timeline.py over a rocprofv3 trace): the trace ends with the headline's own steps
+        print(json.dumps({"trace_stop": True, "ms_per_step": round(t_front / K * 1e3, 4)}))
+        oc.close()
+        return
     # the tracker's accept test: by default it takes the reference's decisions -- f64 sums where they can decide `float chi2 - float new_chi2 > 0`,
     # the reference's sequential float sums (formed bit for bit, in parallel: csrc/seqsum.h) where they cannot.  How many such sums a frame needs, and what the same
     # steps cost with the f64 sums alone (rounds 1-4: not the reference's decisions near convergence)

@@ -238,12 +238,20 @@ __device__ __forceinline__ uint32_t ld_u32u(const uint8_t *p) { uint32_t v; __bu
 template <bool COPY>
 __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restrict__ src, int w, int h, int ss,
                                                          size_t sb, uint8_t *__restrict__ dst, int dw, int dh,
-                                                         int ds, size_t db, uint8_t *__restrict__ cpy, int cs, size_t cb) {
-  const int ox = 4 * (blockIdx.x * 64 + threadIdx.x), oy = 2 * (blockIdx.y * 4 + threadIdx.y);      // 4 waves = 4 output row pairs
-  if (ox >= dw || oy >= dh) return;
-  src += (size_t)blockIdx.z * sb;
-  dst += (size_t)blockIdx.z * db;
-  if (COPY) cpy += (size_t)blockIdx.z * cb;
+                                                         int ds, size_t db, uint8_t *__restrict__ cpy, int cs, size_t cb, int swz) {
+  // work items (4 x 2 output patches) are dealt to the lanes in row-major order over the whole image: every lane of every wave but the last has a patch (a 64 x 4 block of
+  // lanes per 256 x 8 outputs left 3 of 8 lanes idle on a 320-column level).  Vertical neighbours share three of their source rows: blocks in XCD-contiguous order (an
+  // XCD works through whole images), so those rows are fetched into one L2
+  unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (swz) wg = xcd_contiguous(wg, gridDim.x * gridDim.y);
+  const int ncol = (dw + 3) >> 2, nrow = (dh + 1) >> 1;
+  const int bz = wg / gridDim.x, item = (int)(wg % gridDim.x) * 256 + (int)threadIdx.x;
+  if (item >= ncol * nrow) return;
+  const int oyh = item / ncol;
+  const int ox = 4 * (item - oyh * ncol), oy = 2 * oyh;
+  src += (size_t)bz * sb;
+  dst += (size_t)bz * db;
+  if (COPY) cpy += (size_t)bz * cb;
   const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
   // Column borders without divergence: the leftmost lane (sx0 = -2) and the lane whose third dword crosses the right
   // edge load from a clamped in-row address and rebuild their bytes with V_PERM (BORDER_REFLECT_101); rows are reflected
@@ -267,23 +275,46 @@ __global__ __launch_bounds__(256) void pyr_down_u8_kernel(const uint8_t *__restr
   union Pk2 { uint32_t u; us2_t h; };
   Pk2 hp[7][2];      // hsum[r][0..1], hsum[r][2..3] as packed u16 (max 16 * 255 = 4080)
   const uint32_t W4 = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+  // the 21 dwords of the footprint are requested up front where the whole wave is on the dword path (every interior wave): one round trip per wave, not one per row
+  // -- with the row loads inside the per-row `if (fast)` the compiler waited for each row before it asked for the next, and the kernel ran at a third of the copy rate
+  uint32_t D0[7], D1[7], D2[7];
+  if (h >= 8 && __all(fast)) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      int y = sy0 + r;                                          // in [-2, h + 3]: one reflection is enough
+      y = y < 0 ? -y : y;
+      y = y >= h ? 2 * h - 2 - y : y;
+      const uint8_t *p = src + (size_t)y * ss;
+      D0[r] = ld_u32u(p + (left ? 0 : sx0)); D1[r] = ld_u32u(p + sx0 + 4); D2[r] = ld_u32u(p + off2);
+    }
+  } else {
+#pragma unroll 1
+    for (int r = 0; r < 7; ++r) {
+      const uint8_t *p = src + (size_t)reflect101(sy0 + r, h) * ss;
+      uint32_t d0, d1, d2;
+      if (fast) {
+        d0 = __builtin_amdgcn_perm(0u, ld_u32u(p + (left ? 0 : sx0)), sel0);
+        d1 = ld_u32u(p + sx0 + 4);
+        d2 = __builtin_amdgcn_perm(0u, ld_u32u(p + off2), sel2);
+      } else {
+        uint32_t bt[12];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) bt[k] = p[reflect101(sx0 + k, w)];
+        bt[11] = 0;
+        d0 = bt[0] | (bt[1] << 8) | (bt[2] << 16) | (bt[3] << 24);
+        d1 = bt[4] | (bt[5] << 8) | (bt[6] << 16) | (bt[7] << 24);
+        d2 = bt[8] | (bt[9] << 8) | (bt[10] << 16);
+      }
+      // (dynamic index: this path is the image border's and tiny images')
+      if (r == 0) { D0[0] = d0; D1[0] = d1; D2[0] = d2; } else if (r == 1) { D0[1] = d0; D1[1] = d1; D2[1] = d2; } else if (r == 2) { D0[2] = d0; D1[2] = d1; D2[2] = d2; }
+      else if (r == 3) { D0[3] = d0; D1[3] = d1; D2[3] = d2; } else if (r == 4) { D0[4] = d0; D1[4] = d1; D2[4] = d2; } else if (r == 5) { D0[5] = d0; D1[5] = d1; D2[5] = d2; }
+      else { D0[6] = d0; D1[6] = d1; D2[6] = d2; }
+    }
+    sel0 = 0x03020100u; sel2 = 0x03020100u;                     // already in place
+  }
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    const uint8_t *p = src + (size_t)reflect101(sy0 + r, h) * ss;
-    uint32_t d0, d1, d2;
-    if (fast) {
-      d0 = __builtin_amdgcn_perm(0u, ld_u32u(p + (left ? 0 : sx0)), sel0);
-      d1 = ld_u32u(p + sx0 + 4);
-      d2 = __builtin_amdgcn_perm(0u, ld_u32u(p + off2), sel2);
-    } else {
-      uint32_t bt[12];
-#pragma unroll
-      for (int k = 0; k < 11; ++k) bt[k] = p[reflect101(sx0 + k, w)];
-      bt[11] = 0;
-      d0 = bt[0] | (bt[1] << 8) | (bt[2] << 16) | (bt[3] << 24);
-      d1 = bt[4] | (bt[5] << 8) | (bt[6] << 16) | (bt[7] << 24);
-      d2 = bt[8] | (bt[9] << 8) | (bt[10] << 16);
-    }
+    const uint32_t d0 = __builtin_amdgcn_perm(0u, D0[r], sel0), d1 = D1[r], d2 = __builtin_amdgcn_perm(0u, D2[r], sel2);
     // horizontal pass: out_j = [1 4 6 4] . bytes[2j..2j+3] + bytes[2j+4]  -> V_DOT4_U32_U8 on byte-aligned dwords
     const uint32_t d01 = __builtin_amdgcn_alignbyte(d1, d0, 2);      // bytes 2..5
     const uint32_t d12 = __builtin_amdgcn_alignbyte(d2, d1, 2);      // bytes 6..9
@@ -338,9 +369,9 @@ extern "C" int svs_pyr_down_u8(svs_ctx *ctx, const uint8_t *d_src, int w, int h,
   SVS_REQUIRE(ctx, ctx && d_src && d_dst && w >= 3 && h >= 3 && batch >= 1);
   SVS_DEVICE(ctx);
   int dw = (w + 1) / 2, dh = (h + 1) / 2;
-  dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
+  dim3 grid(div_up(div_up(dw, 4) * div_up(dh, 2), 256), batch), block(256);
   hipLaunchKernelGGL(pyr_down_u8_kernel<false>, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw,
-                     dh, dstride, d_bstride, (uint8_t *)nullptr, 0, (size_t)0);
+                     dh, dstride, d_bstride, (uint8_t *)nullptr, 0, (size_t)0, ctx->xcd_swizzle);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }
@@ -350,9 +381,9 @@ int svs_pyr_down_u8_copy(svs_ctx *ctx, const uint8_t *d_src, int w, int h, int s
   SVS_REQUIRE(ctx, ctx && d_src && d_dst && d_copy && w >= 3 && h >= 3 && batch >= 1);
   SVS_DEVICE(ctx);
   int dw = (w + 1) / 2, dh = (h + 1) / 2;
-  dim3 grid(div_up(div_up(dw, 4), 64), div_up(div_up(dh, 2), 4), batch), block(64, 4);
+  dim3 grid(div_up(div_up(dw, 4) * div_up(dh, 2), 256), batch), block(256);
   hipLaunchKernelGGL(pyr_down_u8_kernel<true>, grid, block, 0, ctx->stream, d_src, w, h, sstride, s_bstride, d_dst, dw, dh, dstride, d_bstride, d_copy,
-                     cstride, c_bstride);
+                     cstride, c_bstride, ctx->xcd_swizzle);
   SVS_LAUNCH_CHECK(ctx);
   return SVS_OK;
 }

@@ -119,6 +119,7 @@ struct MatchParams {
   // optional (the one-call front end, few keyframes): the tracked pose and the active keyframe's pose per stream -- match_predict_kernel<true> then forms the two poses of
   // matcher.cpp:326-330 and the per-keyframe relative poses itself (what frontend_pose_kernel + match_pose_kernel did in two launches of their own between tracker and matcher)
   const double *src_T, *src_Ta;
+  int swz;                // match_kernel3 takes its blocks in XCD-contiguous order (common.h: xcd_contiguous)
 };
 
 // The two relative poses a candidate needs depend only on (camera stream, anchor keyframe), not on
@@ -694,7 +695,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ int s_ncand[M3_GROUPS];
   const svs_match_args &A = M.a;
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int ipos = blockIdx.x * M3_GROUPS + grp, slot = blockIdx.y;
+  // the points of a stream come in image order (match_order_kernel): neighbouring blocks read neighbouring bitmap rows, key patches and image lines.  In XCD-contiguous
+  // order an XCD works through whole streams and those lines meet in ONE L2
+  unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (M.swz) wg = xcd_contiguous(wg, gridDim.x * gridDim.y);
+  const int ipos = (int)(wg % gridDim.x) * M3_GROUPS + grp, slot = wg / gridDim.x;
   const bool live = ipos < A.n_pts;
   const int ip = live && M.order ? M.order[(size_t)slot * A.n_pts + ipos] : ipos;
   const PointPred *pp = M.pred + (size_t)slot * A.n_pts + (live ? ip : A.n_pts - 1);
@@ -708,7 +713,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int x0 = pp->ui - R, y0 = pp->vi - R;
   const int Lw = Lp->w, Lh = Lp->h;
   // The kernel is bound by the L1 (it works per instruction and cache line touched) and short of registers at 8 waves per SIMD: wide requests, and
-  // values re-read from the (cached) point record / level table where they are needed rather than carried.
+  // values re-read from the (cached) point record / level table where they are needed rather than carried.  (Round 6, measured: carrying the bilinear
+  // fractions from (2) to (4) instead of recomputing them -- 60 f64 instructions less, 80 VGPRs, 6 waves -- costs 0.05 ms per 512 x 2000 points: occupancy, not VALU.)
   // ---- (1) the window's corner-bitmap row of this lane and the 17th row (the same 8 bytes for the 16 lanes of the point: one request): 8-byte requests from the byte of the
   // window's first in-image column (fast.hip: a bit per pixel, cell columns on dword boundaries, rows padded with zeros)
   U2 w0 = {0u, 0u}, w1 = {0u, 0u};
@@ -939,6 +945,7 @@ extern "C" int svs_match(svs_ctx *ctx, const svs_match_args *a, svs_fast *f, svs
     M.keys = order + ord_bytes / sizeof(int32_t);
   }
   M.src_T = ctx->match_src_T; M.src_Ta = ctx->match_src_Ta;
+  M.swz = ctx->xcd_swizzle;
   if (M.src_T && M.src_Ta && a->n_kf <= PRED_FUSE_MAX_KF) {      // one launch instead of three (frontend_pose_kernel, match_pose_kernel, match_predict_kernel): the one-call front end
     hipLaunchKernelGGL(match_predict_kernel<true>, dim3(div_up(a->n_pts, 64), a->n_batch), dim3(64), 0, ctx->stream, M);
     SVS_LAUNCH_CHECK(ctx);
