@@ -127,6 +127,8 @@ int svs_ctx_sync(svs_ctx *ctx);
    "match_legacy" (0: four candidate points per wave where the search window allows it, 1: the round-1/2 kernel, 2: one wave per
    point with the lean scan), "mo_legacy" (1: the record-walking motion-only kernel), "fe_overlap" (default 1: the one-call
    front end enqueues FAST / block matching on a side stream beside the dense tracker; 0: everything on the context's stream),
+   "xcd_swizzle" (default 1: tile kernels whose neighbours share image lines -- FAST score, pyramid, block matching, the four-points-per-wave matcher -- take their
+   blocks in XCD-contiguous order; 0: the dispatcher's round robin),
    "trk_flat" (default 1: batches of more than one stream per CU run the flat tracker kernel -- the sweep inlined, the LM state in LDS; 0: the
    round-5 kernel, same bits), "trk_split" (default 10: in such batches a stream still iterating after that many trials on the finest level is
    finished by a second launch with up to eight workgroups per stream -- same accept decisions, poses equal to 1e-12; 0: one launch).

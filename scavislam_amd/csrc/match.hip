@@ -83,6 +83,24 @@ __device__ __forceinline__ unsigned quad_key(int px, int py, int W, int H) {
   return key;
 }
 
+// quad_key(ax, ay) < quad_key(bx, by) without forming the keys: the two points share their box as long as their digits agree, so ONE box is halved until the
+// digits differ (a rolled loop, a dozen registers: match_kernel3 calls it behind wave-uniform branches -- ties of the ZNSSD are rare -- and has no registers
+// to spare for two unrolled key computations there)
+__device__ __forceinline__ bool quad_less(int ax, int ay, int bx, int by, int W, int H) {
+  int x0 = 0, y0 = 0, bw = W << 12, bh = H << 12;
+  const int AX = ax << 12, AY = ay << 12, BX = bx << 12, BY = by << 12;
+  bool less = false;
+#pragma unroll 1
+  for (int d = 0; d < 12; ++d) {
+    bw >>= 1; bh >>= 1;
+    const unsigned ahx = AX >= x0 + bw, ahy = AY >= y0 + bh, bhx = BX >= x0 + bw, bhy = BY >= y0 + bh;
+    const unsigned da = (ahx << 1) | ahy, db = (bhx << 1) | bhy;
+    if (da != db) { less = da < db; break; }
+    x0 += ahx ? bw : 0;
+    y0 += ahy ? bh : 0;
+  }
+  return less;
+}
 // per-point result of computePrediction + the local affine of warpAffinve (everything that is one scalar evaluation per
 // point): produced one LANE per point by match_predict_kernel, consumed one WAVE per point by match_kernel
 struct alignas(16) PointPred {      // 128 bytes = one cache line, fields grouped into 16-byte loads (match_kernel3 reads it with vector loads)
@@ -693,6 +711,7 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {      // all-reduce o
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_kernel3(MatchParams M, svs_match_result *__restrict__ out) {
   __shared__ uint16_t s_cand[M3_GROUPS][M3_CAND_CAP + 7];      // per point: window positions (wy << 5 | wx) waiting to be scored
   __shared__ int s_ncand[M3_GROUPS];
+  __shared__ uint32_t s_key[M3_GROUPS][16];                   // per point: the warped 8 x 8 key patch, 16 packed dwords
   const svs_match_args &A = M.a;
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
   // the points of a stream come in image order (match_order_kernel): neighbouring blocks read neighbouring bitmap rows, key patches and image lines.  In XCD-contiguous
@@ -792,6 +811,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       s_cand[grp][atomicAdd(&s_ncand[grp], 1)] = (uint16_t)((16 << 5) | k);
     }
   }
+  // ---- (3b) the pixels of the point's first 16 hits are requested NOW: their round trip runs under the bilinear arithmetic of (4) (a lane = a hit, eight 8-byte rows from
+  // ONE running address -- the barrier keeps the compiler from forming eight addresses first: sixteen registers the kernel does not have at 8 waves per SIMD)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const int cstride = Lp->cstride;
+  const uint8_t *pbase = Lp->cimg + (size_t)slot * Lp->cur_bstride + (ptrdiff_t)(y0 - 4) * cstride + (x0 - 4);
+  // (FIRST rows only: all eight would cost sixteen registers across (4) that the kernel does not have)
+  auto fetch16 = [&](int c0, int n_, int r_lo, int r_hi, U2 (&v)[8], int &wx, int &wy) __attribute__((always_inline)) {
+    const bool act = c0 + sub < n_;
+    const int code = act ? s_cand[grp][c0 + sub] : 0;
+    wx = code & 31; wy = code >> 5;
+    const uint8_t *q = pbase + (ptrdiff_t)(wy + r_lo) * cstride + wx;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r >= r_lo && r < r_hi) {
+        v[r] = act ? ld_u2u(q) : U2{0u, 0u};
+        q += cstride;
+        asm volatile("" : "+v"(q));
+      }
+  };
+  constexpr int M3_PRE = 4;
+  U2 v[8];
+  int wx, wy;
+  fetch16(0, go ? s_ncand[grp] : 0, 0, M3_PRE, v, wx, wy);
   // ---- (4) warpAffinve, arithmetic: the sample coordinates again (from the point record: 12 doubles not held across (3)), bilinear weights as the
   // reference forms them
   uint32_t keyd = 0;
@@ -826,39 +869,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const bool textured = go;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  // ---- (5) ZNSSD of every hit: the four points of the wave in step, TWO hits of a point per step -- the halves of its DPP row take one each, lane = row of the
-  // 8 x 8 patch (one 8-byte request, six dot products, an 8-lane butterfly for iB and sBB + 2 sAB); the key rows move to that layout once per point
+  // ---- (5) ZNSSD of every hit, ONE LANE PER HIT (round 6): the 16 lanes of a point take 16 of its hits at a time, a lane sums its hit's whole 8 x 8 patch -- eight 8-byte
+  // rows against the key rows, which all lanes of the point read from LDS (a broadcast) -- with six V_SAD_U8 / V_DOT4_U32_U8 per row and NO cross-lane step per hit; the
+  // point's best is one 16-lane butterfly at the end.  (Rounds 3-5: two hits per step, lane = patch row, an 8-lane butterfly per pair of hits: ~55 wave instructions per
+  // pair and as many steps as the busiest of the wave's four points has pairs -- 0.18 of the kernel's 0.49 ms at 512 x 2000 points.)  The first 16 hits' pixels were
+  // requested in (3b).
   const int n = go ? s_ncand[grp] : 0;
-  const int cstride = Lp->cstride;
-  const int r8 = sub & 7, half = sub >> 3;
-  const int lane_k = (int)(threadIdx.x & 48u) + 2 * r8;
-  const uint32_t key_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * lane_k, (int)keyd), key_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * lane_k + 4, (int)keyd);
-  const uint8_t *pbase = Lp->cimg + (size_t)slot * Lp->cur_bstride + (ptrdiff_t)(y0 - 4 + r8) * cstride + (x0 - 4);
+  s_key[grp][sub] = keyd;                          // key rows: dwords 2 r, 2 r + 1 = row r
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   int best = 0x7fffffff, bu = 0, bv = 0;
-  auto fetch = [&](int ci, U2 &v, int &wx, int &wy) {
-    v = U2{0u, 0u}; wx = 0; wy = 0;
-    if (ci < n) {
-      const int code = s_cand[grp][ci];
-      wx = code & 31; wy = code >> 5;
-      v = ld_u2u(pbase + (ptrdiff_t)wy * cstride + wx);
+  for (int c0 = 0; __ballot(c0 < n) != 0ull; c0 += 16) {
+    fetch16(c0, n, c0 ? 0 : M3_PRE, 8, v, wx, wy);      // the rest of the rows (all of them behind the first 16 hits: rare)
+    const bool act = c0 + sub < n;
+    uint32_t iBl = 0, sBB = 0, sAB = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t k0 = s_key[grp][2 * r], k1 = s_key[grp][2 * r + 1];
+      iBl = __builtin_amdgcn_sad_u8(v[r].y, 0u, __builtin_amdgcn_sad_u8(v[r].x, 0u, iBl));
+      sBB = __builtin_amdgcn_udot4(v[r].y, v[r].y, __builtin_amdgcn_udot4(v[r].x, v[r].x, sBB, false), false);
+      sAB = __builtin_amdgcn_udot4(v[r].y, k1, __builtin_amdgcn_udot4(v[r].x, k0, sAB, false), false);
     }
-  };
-  U2 v_nx; int wx_nx, wy_nx;
-  fetch(half, v_nx, wx_nx, wy_nx);
-  for (int i = 0; __ballot(2 * i < n) != 0ull; ++i) {
-    const int ci = 2 * i + half;
-    const bool act = ci < n;
-    const U2 v = v_nx;
-    const int wx = wx_nx, wy = wy_nx;
-    fetch(ci + 2, v_nx, wx_nx, wy_nx);             // the next pair's pixels travel while this one is summed
-    uint32_t iBl = __builtin_amdgcn_sad_u8(v.y, 0u, __builtin_amdgcn_sad_u8(v.x, 0u, 0u));
-    uint32_t tl = __builtin_amdgcn_udot4(v.y, v.y, __builtin_amdgcn_udot4(v.x, v.x, 0u, false), false) +
-                  2u * __builtin_amdgcn_udot4(v.y, key_hi, __builtin_amdgcn_udot4(v.x, key_lo, 0u, false), false);      // sBB + 2 sAB <= 3 * 64 * 255^2
-    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0xB1, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0xB1, 0xf, 0xf, true);
-    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0x4E, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x4E, 0xf, 0xf, true);
-    iBl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iBl, 0x141, 0xf, 0xf, true); tl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x141, 0xf, 0xf, true);
     const int iB = (int)iBl;
-    const int z = sumAA - (int)tl - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;
+    const int z = sumAA - (int)(sBB + 2u * sAB) - (sumA * sumA - 2 * sumA * iB - iB * iB) / 64;      // sBB + 2 sAB <= 3 * 64 * 255^2
     // strict '<' in DFS order (matcher.cpp:173)  <=>  lexicographic min of (z, quadrant key); z must also beat thr_mean.
     // The quadrant keys are only needed to break ties, which are rare: behind a wave-uniform branch, so that they are not evaluated (predicated) per hit.
     const int hx = x0 + wx, hy = y0 + wy;
@@ -866,20 +899,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (__ballot(good && z == best) != 0ull) {
       int hx_ = hx, bu_ = bu;
       asm volatile("" : "+v"(hx_), "+v"(bu_));      // (keeps the key arithmetic inside the branch: it is cheap enough for the compiler to speculate it)
-      if (good && z == best && quad_key(hx_, hy, Lw, Lh) < quad_key(bu_, bv, Lw, Lh)) { bu = hx; bv = hy; }
+      if (good && z == best && quad_less(hx_, hy, bu_, bv, Lw, Lh)) { bu = hx; bv = hy; }
     }
     if (good && z < best) { best = z; bu = hx; bv = hy; }
   }
-  {   // the two halves of the row meet (row_mirror: lane i <-> 15 - i)
-    const int oz = __builtin_amdgcn_update_dpp(0, best, 0x140, 0xf, 0xf, true), ou = __builtin_amdgcn_update_dpp(0, bu, 0x140, 0xf, 0xf, true),
-              ov = __builtin_amdgcn_update_dpp(0, bv, 0x140, 0xf, 0xf, true);
-    if (__ballot(oz == best && best != 0x7fffffff && (ou != bu || ov != bv)) != 0ull) {
-      int ou_ = ou, bu_ = bu;
-      asm volatile("" : "+v"(ou_), "+v"(bu_));
-      if (oz == best && best != 0x7fffffff && quad_key(ou_, ov, Lw, Lh) < quad_key(bu_, bv, Lw, Lh)) { bu = ou; bv = ov; }
-    }
-    if (oz < best) { best = oz; bu = ou; bv = ov; }
+  // the 16 lanes of the point meet: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after every step both partners hold the same winner
+#define M3_MEET(CTRL)                                                                                                                                        \
+  {                                                                                                                                                          \
+    const int oz = __builtin_amdgcn_update_dpp(0, best, CTRL, 0xf, 0xf, true), ou = __builtin_amdgcn_update_dpp(0, bu, CTRL, 0xf, 0xf, true),                \
+              ov = __builtin_amdgcn_update_dpp(0, bv, CTRL, 0xf, 0xf, true);                                                                                 \
+    if (__ballot(oz == best && best != 0x7fffffff && (ou != bu || ov != bv)) != 0ull) {                                                                      \
+      int ou_ = ou, bu_ = bu;                                                                                                                                \
+      asm volatile("" : "+v"(ou_), "+v"(bu_));                                                                                                               \
+      if (oz == best && best != 0x7fffffff && quad_less(ou_, ov, bu_, bv, Lw, Lh)) { bu = ou; bv = ov; }                                                     \
+    }                                                                                                                                                        \
+    if (oz < best) { best = oz; bu = ou; bv = ov; }                                                                                                          \
   }
+  M3_MEET(0xB1) M3_MEET(0x4E) M3_MEET(0x141) M3_MEET(0x140)
+#undef M3_MEET
   double obs0 = 0, obs1 = 0, obs2 = 0;
   if (go) {
     if (best == 0x7fffffff) { status = SVS_MATCH_NONE; bu = bv = 0; }
@@ -898,7 +935,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     svs_match_result r;
     r.status = status; r.u = bu; r.v = bv; r.znssd = best == 0x7fffffff ? init_dist : best;
     r.obs[0] = obs0; r.obs[1] = obs1; r.obs[2] = obs2;
-    r.xyz_actkey[0] = textured ? pp->xyz_actkey[0] : 0.0; r.xyz_actkey[1] = textured ? pp->xyz_actkey[1] : 0.0; r.xyz_actkey[2] = textured ? pp->xyz_actkey[2] : 0.0;
+    const PointPred *pe = pp;
+    asm volatile("" : "+v"(pe));      // (read here, not carried from the top of the kernel in registers the loop above needs)
+    r.xyz_actkey[0] = textured ? pe->xyz_actkey[0] : 0.0; r.xyz_actkey[1] = textured ? pe->xyz_actkey[1] : 0.0; r.xyz_actkey[2] = textured ? pe->xyz_actkey[2] : 0.0;
     out[(size_t)slot * A.out_bstride + ip] = r;
   }
 }
