@@ -179,6 +179,24 @@ class FastGrid:
         thr = np.ascontiguousarray(thr, np.int32)
         self.ctx.check(self.ctx.lib.svs_fast_set_thresholds(self.h, slot, level, thr.ctypes.data))
 
+    def corner_bits(self, slot=0, level=0):
+        """The level's corner bitmap as a bool image [h][w] (svs_fast_device_view, API 7): True = a corner of the last detection -- what
+        GuidedMatcher::match tests its window positions against (the reference asks a quadtree of these corners, matcher.cpp:351-357)."""
+        import torch
+        d_bits, stride, bstride, colbits = C.c_void_p(), C.c_int32(), C.c_size_t(), C.c_int32()
+        self.ctx.check(self.ctx.lib.svs_fast_device_view(self.h, level, C.byref(d_bits), C.byref(stride), C.byref(bstride), C.byref(colbits), None, None))
+        self.ctx.sync()
+        g, w, h = self.grids[level], self.frame.w[level], self.frame.h[level]
+        raw = np.zeros((h, stride.value), np.uint8)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(raw.ctypes.data, d_bits.value + slot * bstride.value, raw.nbytes, 2)      # hipMemcpyDeviceToHost
+        assert rc == 0, rc
+        bits = np.unpackbits(raw, axis=1, bitorder="little")
+        x = np.arange(w)
+        ci = np.minimum(x // g.cell_w, g.gx - 1)
+        return bits[:, x + (colbits.value - g.cell_w) * ci].astype(bool)
+
     def close(self):
         if self.h and self.ctx.h:
             self.ctx.lib.svs_fast_destroy(self.h)

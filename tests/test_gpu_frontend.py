@@ -86,6 +86,11 @@ def test_fastgrid_adaptive_sequence_bit_exact(gpu_ctx, w, h):
             xy_ref, cc_ref = O.fastgrid_detect(grids[s][l], pyr[l])
             xy, cc, et, ts = fg.corners(s, l)
             assert np.array_equal(xy, xy_ref) and np.array_equal(cc, cc_ref)
+            # the corner bitmap the matcher reads (svs_fast_device_view: 1 bit per pixel, cell columns on dword boundaries) holds exactly these corners
+            bits = fg.corner_bits(s, l)
+            ref_bits = np.zeros_like(bits)
+            ref_bits[xy_ref[:, 1], xy_ref[:, 0]] = True
+            assert np.array_equal(bits, ref_bits), (s, l, int(bits.sum()), len(xy_ref))
 
 
 def test_fast_empty_and_saturated_images(gpu_ctx):
@@ -734,8 +739,8 @@ def test_dense_tracking_multi_workgroup_variant(gpu_ctx, scene_frames, monkeypat
 
 
 def test_fastgrid_large_frame_two_sweep_compaction(gpu_ctx):
-    """A 2560x1440 frame: level-0 cells are 853x480 pixels, so the per-cell corner masks no longer fit the one-sweep
-    compaction's LDS budget and the two-sweep kernel emits the corners; lists stay bit-exact (order included)."""
+    """A 2560x1440 frame: level-0 cells are 853x480 pixels and hold ~20 000 candidates each (rounds 1-5: beyond the list sort's cap and the one-sweep
+    compaction's LDS budget -- the two-sweep fallback; round 6: the cell's bitmap, 54 KB of LDS, has no cap); lists stay bit-exact (order included)."""
     import oracle as O
     from scavislam_amd import synth
     from scavislam_amd.frontend import FastGrid

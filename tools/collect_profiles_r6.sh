@@ -39,6 +39,15 @@ rm -rf $out/trace_dropin
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace_stereo -o trace -- python tools/time_stereo.py 512 > $out/stereo.log 2>&1
 python tools/rocpd_summary.py $(find $out/trace_stereo -name "*.db") | cut -c1-200 | head -12 > $out/stereo_kernels.txt 2>&1
 rm -rf $out/trace_stereo
+# grid FAST alone (in the bench step it runs beside the dense tracker), per kernel + its HBM counters
+timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace_fast -o trace -- python tools/time_fast.py 512 > $out/fast.log 2>&1
+python tools/rocpd_summary.py $(find $out/trace_fast -name "*.db") | cut -c1-200 | grep -E "^\| kernel|^\|---|fast_" > $out/fast_kernels.txt 2>&1
+rm -rf $out/trace_fast
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $c -d $out/pmcfast -o pmc -- python tools/time_fast.py 512 > /dev/null 2>&1
+  python tools/pmc_any.py fast_ $(find $out/pmcfast -name "*.db") >> $out/fast_pmc.txt 2>&1
+  rm -rf $out/pmcfast
+done
 # the accept test of the quarter-grid tracker: what one float sum costs (parallel form / past the caches / sequential chain), and the solve's phase clocks
 python tools/time_seqsum.py > $out/seqsum.log 2>&1
 SVS_BA_DEBUG=1 python tools/time_ba.py 50 20000 2>&1 | grep -i "solve phases" | tail -3 > $out/solve_phases.log

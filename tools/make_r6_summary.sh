@@ -20,6 +20,8 @@ md += "* RCCL: `" + json.dumps(t['config']['collective']) + "`\n* one-shot P2P t
 md += "\n## 8. `__amd_rocclr_copyBuffer` launches in the traced run (section 2)\n\nThe traced command now contains rows that are host-IO by definition and did not exist in round 3's trace: the two-threads row (600 + 64 latency-mode frames with host images in and records out: 6 copies per frame, about 4 000; 120 + optimizes with state restore, about 700), the latency rows (about 110 host-IO frames, about 700) and the drop-in BA rows (6 - 8 staged pieces per call).  The per-stream setup copies of a 512-stream batch that round 3's verdict counted (about 2 000 per batch object) are gone: `svs_frontend_keep_keyframes` / `svs_frontend_set_candidates_all` are one staged upload per call (2 + 4 copies per batch object).\n"
 md += "\n## 9. Block matching alone, per kernel: `rocprofv3 --kernel-trace --stats -- python tools/time_stereo.py 512` (512 pairs of 640 x 480)\n\n" + open(src + 'stereo_kernels.txt').read()
 md += "\n```\n" + "\n".join(l for l in open(src + 'stereo.log').read().splitlines() if 'ms per' in l or 'differs' in l) + "\n```\n"
+md += "\n## 9b. Grid FAST alone (round 6: no score image -- candidate lists + LDS bitmap compaction): `rocprofv3 --kernel-trace --stats -- python tools/time_fast.py 512`, then one `--pmc` pass each for FETCH_SIZE / WRITE_SIZE (KB per launch of 512 frames)\n\n" + open(src + 'fast_kernels.txt').read()
+md += "\n```\n" + "\n".join(l for l in open(src + 'fast.log').read().splitlines() if 'ms per' in l or 'corners' in l) + "\n" + open(src + 'fast_pmc.txt').read() + "```\n"
 md += "\n## 10. The tracker's float sums (`tools/time_seqsum.py`) and the solve's phase clocks (`SVS_BA_DEBUG=1 python tools/time_ba.py 50 20000`)\n\n```\n" + open(src + 'seqsum.log').read() + open(src + 'solve_phases.log').read() + "```\n"
 md += "\n## 11. Two threads, one GPU (`tools/time_two_threads_row.py`)\n\n```\n" + open(src + 'two_threads.json').read() + "```\n"
 open('profiles/r6_summary.md', 'w').write(md)
