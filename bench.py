@@ -336,6 +336,8 @@ def main():
     oc = OneCall(B)
     _probe_windows('front end created')
     t_front = max_over_ranks(timed_steps(oc, W + (W & 1), K))          # even warm-up: the timed region starts with a frame-B step
+    if os.environ.get("SVS_BENCH_REPEAT"):          # run-to-run spread of the headline inside ONE process: the same K steps again, N times
+        print(json.dumps({"repeat_ms_per_step": [round(t_front / K * 1e3, 4)] + [round(timed_steps(oc, 0, K) / K * 1e3, 4) for _ in range(int(os.environ["SVS_BENCH_REPEAT"]))]}), flush=True)
     if os.environ.get("SVS_BENCH_TRACE_STOP"):      # kernel timelines (tools/timeline.py over a rocprofv3 trace): the trace ends with the headline's own steps
         print(json.dumps({"trace_stop": True, "ms_per_step": round(t_front / K * 1e3, 4)}))
         oc.close()
