@@ -102,10 +102,10 @@ __device__ __forceinline__ s16x2 arc9_maxmin_pk(const s16x2 (&d)[16]) {      // 
   return best;
 }
 
-// K1.  Each lane scores 4 horizontally adjacent pixels: the 7 x 12-byte neighbourhood it needs is read
-// from LDS as 21 dwords (instead of ~20-36 byte reads per pixel) and ring pixels are picked with
-// compile-time byte extracts; the tile itself is staged with (unaligned) dword loads and the four
-// scores leave as one dword store.  LDS row = 72 bytes: [4 left halo | 64 tile | 4 right halo].
+// K1.  Each lane pre-tests 4 horizontally adjacent pixels per step from three LDS rows (phase A), the survivors are scored one
+// per lane (phase B); the tile itself is staged with (unaligned) dword loads.  Nothing per pixel leaves the kernel: the pixels
+// whose score reaches t_lo go to the tile's candidate list and the cell's histogram.
+// LDS row = 72 bytes: [4 left halo | 64 tile | 4 right halo].
 constexpr int LROW = 19;   // dwords per LDS row (18 used + 1 pad)
 __device__ __forceinline__ int byte_of(const uint32_t (&w)[3], int b) { return (w[b >> 2] >> (8 * (b & 3))) & 0xff; }
 // bytes b and b+1 of the 12-byte row window, zero-extended into the two 16-bit halves (one v_perm_b32)

@@ -359,7 +359,7 @@ def test_prefetch_and_split_call_equal_blocking_call(gpu_ctx):
 def test_side_stream_schedule_equals_one_stream(gpu_ctx, block_matching):
     """By default the chain enqueues FAST (and block matching) on a side stream beside the dense tracker (option "fe_overlap"); the schedule must not
     change a bit of any output, over several frames in a row (the side stream's work of frame N + 1 must wait for frame N's matcher, which reads the
-    same score maps)."""
+    same corner bitmaps)."""
     from scavislam_amd import capi
     ctx, stream = gpu_ctx
     cam, S = _streams(1, block_matching)
