@@ -288,8 +288,9 @@ __device__ __forceinline__ bool corner_bit(const uint8_t *row, int x, int cw, in
 // caller's to mask.
 __device__ __forceinline__ uint32_t window_bits(U2 q, int pb_lo, int x0, int xb, int gap) {
   const unsigned long long raw = (((unsigned long long)q.y << 32) | q.x) >> (pb_lo & 7);
-  const unsigned long long t = raw << max(-x0, 0);
-  const int nb = min(max(xb - x0, 0), 32);
+  const unsigned long long t = raw << min(max(-x0, 0), 63);      // (a window far left of the image: everything shifted out)
+  // positions in front of the boundary; no boundary (xb = INT_MAX, last cell column) or one behind the window: all 32.  (Compared before subtracting: xb - x0 must not wrap.)
+  const int nb = xb >= x0 + 32 ? 32 : max(xb - x0, 0);
   const uint32_t lowmask = nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
   return ((uint32_t)t & lowmask) | ((uint32_t)(t >> gap) & ~lowmask);
 }

@@ -222,6 +222,75 @@ def test_matcher_tie_break_follows_quadtree_order(gpu_ctx):
     assert np.array_equal(res["znssd"], ref["znssd"])
 
 
+@pytest.mark.parametrize("legacy", [0, 1, 2])
+def test_matcher_one_cell_column_and_windows_over_the_left_border(gpu_ctx, legacy):
+    """The matcher reads FAST's corner bitmap, whose cell columns start on dword boundaries (pad bits between them).  Two corners of that layout: a grid with ONE cell
+    column whose width is no multiple of 32 (pad bits but no column boundary to cross), and search windows that hang over the image's left / right border (bits left of
+    column 0 read as 0, the window's first in-image column is column 0).  All three kernels against the oracle on the same corners."""
+    import oracle as O
+    from scavislam_amd import synth
+    from scavislam_amd.ctypes_types import CANDIDATE_DTYPE
+    from scavislam_amd.frontend import FastGrid, GuidedMatcher, fastgrid_for_level
+    ctx, stream = gpu_ctx
+    cam = dict(synth.CAM_DEFAULT)
+    h, w = cam["h"], cam["w"]
+    img = np.random.default_rng(41).integers(0, 256, (h, w)).astype(np.uint8)      # white noise: corners everywhere, up to the first and last column a cell can have
+    disp = np.full((h, w), 6.0, np.float32)
+    fr = _frame(ctx, stream, cam, [img], [disp])
+    grids = []
+    for l in range(3):
+        g = fastgrid_for_level(fr.w[l], fr.h[l], l)
+        g.gx, g.gy = 1, 2
+        g.cell_w, g.cell_h = fr.w[l] - 10, fr.h[l] // 2          # 630 / 310 / 150 columns: 10 / 10 / 10 pad bits behind the only cell column
+        grids.append(g)
+    fg = FastGrid(ctx, fr, corner_cap=320 * 1024, grids=grids)
+    for l in range(3):
+        fg.set_thresholds(0, l, [24, 24])                       # FastGrid::detect at a low static threshold: a dense corner set (windows with dozens of hits: more than the
+    fg.detect()                                                 # 16 a point's lanes take at a time), corners in the first and last columns a cell can have
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    z = cam["f"] * cam["b"] / 6.0
+    rng = np.random.default_rng(19)
+    rows, n_left, n_right = [], 0, 0
+    for lvl in range(3):
+        xy = fg.corners(0, lvl)[0].astype(np.int64)
+        s = 1 << lvl
+        inner = xy[(xy[:, 1] >= 12) & (xy[:, 1] < (h >> lvl) - 12)]
+        # anchors ON corners (identity motion: the corner itself is the perfect match): the ones within 8 pixels of the left border (their window starts left of the
+        # image), the ones at the right end of the cell column, and a sample of the rest
+        left, right = inner[inner[:, 0] < 8], inner[inner[:, 0] >= grids[lvl].cell_w - 12]
+        rest = inner[rng.permutation(len(inner))[:60]]
+        n_left += len(left[:40]); n_right += len(right[:40])
+        for ul, vl in np.concatenate([left[:40], right[:40], rest]):
+            r = np.zeros(1, CANDIDATE_DTYPE)
+            u0, v0 = ul * s, vl * s
+            r["xyz_anchor"] = ((u0 - cam["cx"]) / cam["f"] * z, (v0 - cam["cy"]) / cam["f"] * z, z)
+            r["anchor_obs_pyr"] = (ul, vl, (u0 - 6.0) / s)
+            r["anchor_level"] = lvl
+            rows.append(r)
+    pts = np.concatenate(rows)
+    assert n_left >= 10 and n_right >= 10, (n_left, n_right)      # (the pyramid smooths the noise: most of them on level 0)
+    gm = GuidedMatcher(ctx, fr, fg)
+    ctx.set_option("match_legacy", legacy)
+    try:
+        res = gm.match([(fr.pyr, 0, I.reshape(12))], I.reshape(12), I.reshape(12), pts, thr_std=0)[0]
+    finally:
+        ctx.set_option("match_legacy", 0)
+    pyr = O.build_pyramid(img)
+    trees = []
+    for l in range(3):
+        xy, cc, et, ts = fg.corners(0, l)
+        trees.append(O.quadtree_from_corners(xy, cc, pyr[l].shape[1], pyr[l].shape[0]))
+        bits = fg.corner_bits(0, l)
+        ref_bits = np.zeros_like(bits)
+        ref_bits[xy[:, 1], xy[:, 0]] = True
+        assert np.array_equal(bits, ref_bits), l
+    ref = O.match([pyr], [I.reshape(12)], I, I, pyr, disp, trees, fr.cams, pts, thr_std=0)
+    assert np.array_equal(res["status"], ref["status"])
+    assert (ref["status"] == 0).sum() > 100, np.bincount(ref["status"])
+    assert np.array_equal(res["u"], ref["u"]) and np.array_equal(res["v"], ref["v"])
+    assert np.array_equal(res["znssd"], ref["znssd"])
+
+
 def _dense_setup(scene_frames, ctx, stream):
     import oracle as O
     from scavislam_amd import synth
