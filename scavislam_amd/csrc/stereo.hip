@@ -209,19 +209,25 @@ __device__ __forceinline__ void row_sads(const RowWin &wv, uint32_t ft4, Pk (&hh
 union SelScr { uint32_t u[17]; unsigned short s[34]; };
 // winner selection of one pixel from its 32 window SADs (findStereoCorrespondenceBM inner loop).  Dynamic indexing
 // (sad[mind +- 1], masking the winner's neighbourhood) goes through the per-lane LDS scratch.
+// (p - n) * 256 / dd of the sub-pixel step (C division: towards zero) without the 30-instruction integer division: |p - n| * 256 < 2^24 and dd < 2^15 are exact
+// floats, the product with the reciprocal is within 0.4 of the quotient, one step up or down on the integer remainder makes it exact
+__device__ __forceinline__ int div_trunc_small(int num, int den) {      // |num| < 2^24, 0 < den < 2^15
+  const int a = abs(num);
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)den));
+  const int rem = a - q * den;
+  q += rem >= den ? 1 : (rem < 0 ? -1 : 0);
+  return num < 0 ? -q : q;
+}
 template <bool SMALL>      // SMALL: every SAD < 4096 (prefilter cap <= 41)
 __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const StereoDev &S, SelScr &scr, int16_t &disp, uint16_t &cost) {
   disp = (int16_t)FILTERED16; cost = 0;
   int minsad, mind;
-  if (SMALL) {      // 49 taps x |difference| <= 2 cap: every SAD < 4096, so a 16-bit key holds sad << 4 | dword index and both
-    us2 m = {0xffff, 0xffff};      // halves of the 16 dwords are searched at once; first minimum wins within a half, d = 2 * index + half
-#pragma unroll
+  if (SMALL) {      // 49 taps x |difference| <= 2 cap: every SAD < 4096, so a 16-bit KEY holds sad << 4 | dword index and both halves of the 16 dwords are searched
+    us2 m = {0xffff, 0xffff};      // at once; first minimum wins within a half, d = 2 * index + half.  The kernel keeps its running sums AS keys (the index rides in the four
+#pragma unroll                   // low bits, which the shifted row SADs never touch): the search is sixteen packed minima
     for (int g = 0; g < 8; ++g)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const us2 idx = {(unsigned short)(2 * g + j), (unsigned short)(2 * g + j)};
-        m = __builtin_elementwise_min(m, (us2)((sad[g].h[j] << 4) | idx));
-      }
+      for (int j = 0; j < 2; ++j) m = __builtin_elementwise_min(m, sad[g].h[j]);
     const int s0 = m.x >> 4, d0 = 2 * (m.x & 15), s1 = m.y >> 4, d1 = 2 * (m.y & 15) + 1;
     const bool first = s0 < s1 || (s0 == s1 && d0 < d1);
     minsad = first ? s0 : s1; mind = first ? d0 : d1;
@@ -240,8 +246,9 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
 #pragma unroll
   for (int g = 0; g < 8; ++g) { scr.u[2 * g] = sad[g].u[0]; scr.u[2 * g + 1] = sad[g].u[1]; }
   unsigned short *s16 = scr.s;
+  constexpr int KS = SMALL ? 4 : 0;      // the scratch holds keys (SMALL) or plain sums
   // sad[mind + 1], sad[mind - 1] with the mirrored ends sad[-1] = sad[1], sad[32] = sad[30]
-  const int p = s16[mind == NDISP - 1 ? NDISP - 2 : mind + 1], n = s16[mind == 0 ? 1 : mind - 1];
+  const int p = s16[mind == NDISP - 1 ? NDISP - 2 : mind + 1] >> KS, n = s16[mind == 0 ? 1 : mind - 1] >> KS;
   if (S.uniq > 0) {
     // the scan of the original stops at a d outside [mind-1, mind+1] with sad[d] <= thresh: mask those three, take the min
     const int thresh = minsad + (minsad * S.uniq / 100);
@@ -251,10 +258,10 @@ __device__ __forceinline__ void bm_select(const Pk (&sad)[8], int tsum, const St
     us2 m = {0xffff, 0xffff};
 #pragma unroll
     for (int k = 0; k < 16; ++k) { Pk t; t.u[0] = scr.u[k]; m = __builtin_elementwise_min(m, t.h[0]); }
-    if ((int)min(m.x, m.y) <= thresh) return;
+    if ((int)(min(m.x, m.y) >> KS) <= thresh) return;      // (keys: a masked slot reads 4095 >= every real sum, and 29 real sums are always in the minimum)
   }
   const int dd = p + n - 2 * minsad + abs(p - n);
-  disp = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+  disp = (int16_t)(((NDISP - mind - 1) * 256 + (dd != 0 ? (SMALL ? div_trunc_small((p - n) * 256, dd) : (p - n) * 256 / dd) : 0) + 15) >> 4);
   cost = (uint16_t)minsad;
 }
 
@@ -283,13 +290,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
   constexpr int NR = 2 * WSZ2 + 1;      // ring slots = window rows
   Pk sad[8], ring[NR][8];
   int tring[NR];
+  // SMALL: the running sums are kept as the selection's KEYS, sum << 4 | dword index (bm_select): the index is put in once, the row SADs enter and leave shifted
+  // (one packed shift per dword of the entering row instead of a shift and an OR per dword of every selection)
 #pragma unroll
-  for (int g = 0; g < 8; ++g) sad[g].q = 0;
+  for (int g = 0; g < 8; ++g) { sad[g].u[0] = SMALL ? 0x00010001u * (uint32_t)(2 * g) : 0u; sad[g].u[1] = SMALL ? 0x00010001u * (uint32_t)(2 * g + 1) : 0u; }
+  auto as_keys = [](Pk (&r)[8]) __attribute__((always_inline)) {
+    if (SMALL) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { r[g].h[0] <<= 4; r[g].h[1] <<= 4; }
+    }
+  };
   int tsum = 0;
 #pragma unroll
   for (int j = 0; j < NR - 1; ++j) {      // rows y0-3 .. y0+2 of the first window
     const RowWin wv = win(y0 - WSZ2 + j);
     row_sads(wv, ft4, ring[j], tring[j]);
+    as_keys(ring[j]);
 #pragma unroll
     for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[j][g].h[0]; sad[g].h[1] += ring[j][g].h[1]; }
     tsum += tring[j];
@@ -302,6 +318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void st
       if (y < y1) {      // (uniform)
         const int in = (k + NR - 1) % NR;
         row_sads(wa, ft4, ring[in], tring[in]);
+        as_keys(ring[in]);
         wa = win(y + WSZ2 + 1);      // next step's row: issued as soon as this step's is consumed, in flight during the selection
 #pragma unroll
         for (int g = 0; g < 8; ++g) { sad[g].h[0] += ring[in][g].h[0]; sad[g].h[1] += ring[in][g].h[1]; }
