@@ -934,6 +934,29 @@ def main():
         ratio = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["dense_track_full_kernel"].get("traffic_over_algorithmic")
         df_traffic = int(ratio * dense_full["roofline"]["alg_bytes_per_launch"]) if ratio else None
     dense_full["roofline"]["traffic"], dense_full["roofline"]["traffic_source"] = df_traffic, df_src
+    # the front-end stages: raw FETCH_SIZE + WRITE_SIZE of each stage's dominant kernel in the launch over the whole batch (same file, same rule: only while the
+    # kernel's source is unchanged and the batch is the profiled one).  Raw counters -- 16 B/lane loads count half there (MI355X_MICROARCH.md), so this is a lower
+    # bound of the bytes moved; `traffic_over_alg` = that / the stage's algorithmic bytes.
+    try:
+        import hashlib
+        pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+        for stage_, key_ in (("preprocess", "pyr_down_u8_kernel"), ("dense_tracking", "dense_track_cpu_sem_kernel"), ("fast", "fast_score_kernel"), ("match", "match_kernel3"),
+                             ("pose_refinement", "motion_only_fused_kernel"), ("stereo", "stereo_bm_kernel")):
+            pj = pk.get(key_)
+            if not pj or pj["workload"].get("batch_streams_per_gpu") != B:
+                continue
+            if hashlib.sha256(open(os.path.join(ROOT, pj["source"]), "rb").read()).hexdigest()[:16] != pj["source_sha16"]:
+                continue
+            raw = int(pj["fetch_raw"] + pj["write_raw"])
+            roofline_frontend[stage_]["dominant_kernel"] = pj["kernel"]
+            roofline_frontend[stage_]["dominant_kernel_fetch_plus_write_raw_bytes_per_batch"] = raw
+            alg_ = roofline_frontend[stage_]["alg_bytes_per_frame"]
+            if stage_ == "pose_refinement":      # in the default schedule this kernel also runs the gate and writes the three dense clouds (fe_fuse_tail): their bytes belong to it
+                alg_ += roofline_frontend["process_points"]["alg_bytes_per_frame"] + roofline_frontend["pointcloud"]["alg_bytes_per_frame"]
+                roofline_frontend[stage_]["dominant_kernel_note"] = "the fused kernel = refinement + gate + clouds: ratio against the three stages' algorithmic bytes"
+            roofline_frontend[stage_]["dominant_kernel_raw_traffic_over_stage_alg"] = round(raw / (alg_ * B), 3)
+    except Exception:
+        pass
 
     # ------------------------------------------------------------------ CPU baseline (oracle, rank 0, N=1)
     cpu = None
