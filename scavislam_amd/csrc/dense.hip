@@ -1764,13 +1764,16 @@ int svs_dense_track_cpu_sem_work(svs_ctx *ctx, const svs_dense_track_args *a, do
   } else if (nwg >= 2) {
     double *scratch = nullptr;
     const size_t n_part = (size_t)batch * 2 * nwg * 64;      // per stream, parity and workgroup: 58 (+ 6) flagged 8-byte words (all_workgroups)
-    int rc = ensure_scratch(ctx, &scratch, n_part + (size_t)batch + (size_t)batch * 16);      // + one counter word and one failure flag (4 + 4 bytes) per stream + the hand-over words
+    // (the cleared size rounded up to 64 bytes: a clear whose size is no multiple of 16 bytes is TWO fill kernels in the runtime -- an aligned bulk and a tail --
+    //  and in latency mode every launch in front of the tracker is on the frame's critical path)
+    const size_t n_clear = (n_part + (size_t)batch + (size_t)batch * 16 + 7) & ~(size_t)7;
+    int rc = ensure_scratch(ctx, &scratch, n_clear);      // + one counter word and one failure flag (4 + 4 bytes) per stream + the hand-over words
     if (rc) return rc;
     G.part = scratch;
     G.bar = reinterpret_cast<unsigned *>(scratch + n_part);
     G.fail_off = batch;
     G.bcast = scratch + n_part + (size_t)batch;
-    SVS_HIP(ctx, hipMemsetAsync(scratch, 0, sizeof(double) * (n_part + (size_t)batch + (size_t)batch * 16), ctx->stream));      // flagged words, failure flags, hand-over words: one clear
+    SVS_HIP(ctx, hipMemsetAsync(scratch, 0, sizeof(double) * n_clear, ctx->stream));      // flagged words, failure flags, hand-over words: one clear
     SvsSpinScope gate(ctx, nwg * batch);      // the workgroups of a stream wait for each other: one such launch on the device at a time (common.h); one stream: priority lane
     if (gate.rc) return gate.rc;
     if (u8src) hipLaunchKernelGGL((dense_track_cpu_sem_kernel<true, true, 2>), dim3(nwg, batch), dim3(TRK_THREADS), 0, ctx->stream, A, d_T_io, d_passes_out, G);

@@ -141,6 +141,7 @@ struct svs_frontend {
   // pinned host staging: two input sets (images of stream 0, poses of all streams), one output set
   uint8_t *h_in[2] = {}; size_t h_in_bytes = 0; int i_stage = 0;
   uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
+  uint8_t *d_out_block = nullptr;      // one stream: d_small | d_res | d_gated carved from ONE allocation in h_out's layout -- the frame's results go home in one copy
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_upload[2] = {}, ev_done[2] = {};
   // FAST (and block matching) need the new pyramid only, the dense tracker runs ~18 dependent sweeps per stream with a long tail (streams finish at
@@ -183,6 +184,7 @@ extern "C" int svs_frontend_destroy(svs_frontend *fe) {
   for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) if (fe->d_pyr[k][l]) (void)hipFree(fe->d_pyr[k][l]);
   for (int k = 0; k < 2; ++k) for (int l = 0; l < 3; ++l) if (fe->d_f32[k][l]) (void)hipFree(fe->d_f32[k][l]);
   for (int l = 0; l < 3; ++l) { if (fe->d_cloud[l]) (void)hipFree(fe->d_cloud[l]); if (fe->d_dx[l]) (void)hipFree(fe->d_dx[l]); if (fe->d_dy[l]) (void)hipFree(fe->d_dy[l]); }
+  if (fe->d_out_block) { (void)hipFree(fe->d_out_block); fe->d_res = nullptr; fe->d_gated = nullptr; fe->d_small = nullptr; }
   void *ptrs[] = {fe->d_right[0], fe->d_right[1], fe->d_right[2], fe->d_disp[0], fe->d_disp[1], fe->d_disp[2], fe->d_n_new, fe->d_kf_pyr, fe->d_kfs, fe->d_pts, fe->d_res, fe->d_gated, fe->d_small,
                   fe->d_group_end, fe->d_n_groups};
   for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -248,9 +250,19 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
         return fail(SVS_ERR_HIP);
     }
   }
+  // per-stream scalars (poses in and out, statistics): a multiple of 256 bytes, so that the record arrays may follow it in one allocation
+  fe->small_bytes = ((sizeof(double) * 48 + sizeof(svs_pose_opt_stats) + sizeof(svs_point_stats) + 8) * B + 255) & ~(size_t)255;
+  if (B == 1) {      // latency mode: d_small | d_res | d_gated in the layout of the pinned result buffer -- ONE device-to-host copy per frame instead of three (12 us apart each)
+    const size_t bytes = fe->small_bytes + (sizeof(svs_match_result) + sizeof(svs_gated_point)) * (size_t)max_points;
+    if (hipMalloc(&fe->d_out_block, bytes) != hipSuccess) return fail(SVS_ERR_HIP);
+    fe->d_small = reinterpret_cast<double *>(fe->d_out_block);
+    fe->d_res = reinterpret_cast<svs_match_result *>(fe->d_out_block + fe->small_bytes);
+    fe->d_gated = reinterpret_cast<svs_gated_point *>(fe->d_out_block + fe->small_bytes + sizeof(svs_match_result) * (size_t)max_points);
+  } else if (hipMalloc(&fe->d_res, sizeof(svs_match_result) * max_points * B) != hipSuccess || hipMalloc(&fe->d_gated, sizeof(svs_gated_point) * max_points * B) != hipSuccess ||
+             hipMalloc(&fe->d_small, fe->small_bytes) != hipSuccess)
+    return fail(SVS_ERR_HIP);
   if (hipMalloc(&fe->d_kf_pyr, fe->kf_bytes * max_keyframes * B) != hipSuccess || hipMalloc(&fe->d_kfs, sizeof(svs_keyframe) * max_keyframes * B) != hipSuccess ||
-      hipMalloc(&fe->d_pts, sizeof(svs_candidate_point) * max_points * B) != hipSuccess || hipMalloc(&fe->d_res, sizeof(svs_match_result) * max_points * B) != hipSuccess ||
-      hipMalloc(&fe->d_gated, sizeof(svs_gated_point) * max_points * B) != hipSuccess || hipMalloc(&fe->d_group_end, sizeof(int32_t) * MAX_GROUPS * B) != hipSuccess ||
+      hipMalloc(&fe->d_pts, sizeof(svs_candidate_point) * max_points * B) != hipSuccess || hipMalloc(&fe->d_group_end, sizeof(int32_t) * MAX_GROUPS * B) != hipSuccess ||
       hipMalloc(&fe->d_n_groups, sizeof(int32_t) * B) != hipSuccess || hipMalloc(&fe->d_n_new, sizeof(int32_t) * B) != hipSuccess)
     return fail(SVS_ERR_HIP);
   // unused keyframe slots hold null pyramids, unused candidate records kf_index = -1 (-> SVS_MATCH_NO_ANCHOR): nothing a kernel could follow
@@ -258,8 +270,6 @@ extern "C" int svs_frontend_create_batch(svs_ctx *ctx, const svs_cam *cam, const
       hipMemsetAsync(fe->d_pts, 0xff, sizeof(svs_candidate_point) * max_points * B, ctx->stream) != hipSuccess ||
       hipMemsetAsync(fe->d_n_groups, 0, sizeof(int32_t) * B, ctx->stream) != hipSuccess || hipMemsetAsync(fe->d_n_new, 0, sizeof(int32_t) * B, ctx->stream) != hipSuccess)
     return fail(SVS_ERR_HIP);
-  fe->small_bytes = (sizeof(double) * 48 + sizeof(svs_pose_opt_stats) + sizeof(svs_point_stats) + 8) * B;
-  if (hipMalloc(&fe->d_small, fe->small_bytes) != hipSuccess) return fail(SVS_ERR_HIP);
   if (hipMemsetAsync(fe->d_small, 0, fe->small_bytes, ctx->stream) != hipSuccess) return fail(SVS_ERR_HIP);
   fe->d_pstats = reinterpret_cast<svs_pose_opt_stats *>(fe->d_small + 48 * B);
   fe->d_ptstats = reinterpret_cast<svs_point_stats *>(fe->d_pstats + B);
@@ -879,11 +889,16 @@ extern "C" int svs_frontend_submit_frame(svs_frontend *fe, const uint8_t *h_left
   if ((rc = frontend_chain(fe, false, DispView{fe->d_disp[fe->i_cur], fe->stride[0], fe->lvl_elems[0]}))) return rc;
   // one download: small block, then the records
   const int n = fe->n_points[0];
-  SVS_HIP(ctx, hipMemcpyAsync(fe->h_out, fe->d_small, fe->small_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  svs_match_result *o_res = reinterpret_cast<svs_match_result *>(fe->h_out + fe->small_bytes);
-  svs_gated_point *o_gated = reinterpret_cast<svs_gated_point *>(fe->h_out + fe->small_bytes + sizeof(svs_match_result) * (size_t)fe->max_points);
-  if (n > 0 && want_matches) SVS_HIP(ctx, hipMemcpyAsync(o_res, fe->d_res, sizeof(svs_match_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (n > 0 && want_gated) SVS_HIP(ctx, hipMemcpyAsync(o_gated, fe->d_gated, sizeof(svs_gated_point) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (fe->d_out_block && n > 0 && want_matches && want_gated) {      // the device block has the pinned buffer's layout: everything up to the last gated record in ONE copy
+    SVS_HIP(ctx, hipMemcpyAsync(fe->h_out, fe->d_out_block, fe->small_bytes + sizeof(svs_match_result) * (size_t)fe->max_points + sizeof(svs_gated_point) * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    SVS_HIP(ctx, hipMemcpyAsync(fe->h_out, fe->d_small, fe->small_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    svs_match_result *o_res = reinterpret_cast<svs_match_result *>(fe->h_out + fe->small_bytes);
+    svs_gated_point *o_gated = reinterpret_cast<svs_gated_point *>(fe->h_out + fe->small_bytes + sizeof(svs_match_result) * (size_t)fe->max_points);
+    if (n > 0 && want_matches) SVS_HIP(ctx, hipMemcpyAsync(o_res, fe->d_res, sizeof(svs_match_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 0 && want_gated) SVS_HIP(ctx, hipMemcpyAsync(o_gated, fe->d_gated, sizeof(svs_gated_point) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if ((rc = frontend_end(fe, stage, true))) return rc;
   fe->submitted = true; fe->want_matches = want_matches != 0; fe->want_gated = want_gated != 0;
   return SVS_OK;
