@@ -193,6 +193,7 @@ struct svs_ba {
   std::vector<int> w_cnt;                      // [workers][L] per-worker landmark counts -> start offsets
   std::vector<uint64_t> w_keys, w_ent;         // per edge: (point, pose) / per slot: (pose, source index)
   unsigned char *h_stage = nullptr; size_t h_stage_cap = 0, h_stage_used = 0;      // pinned staging of the small per-call uploads
+  unsigned char *h_state = nullptr; size_t h_state_cap = 0;                         // pinned landing area of svs_ba_get_state
   std::vector<int32_t> w_ids_p, w_ids_l, w_ids_a;      // svs_ba_set_problem's device route: identity ids, anchors by point
   HostPool *pool = nullptr;                    // marshalling workers: ONE pool per process, shared by all optimizers (created on first use)
   std::vector<double> w_pat_local;
@@ -293,6 +294,7 @@ extern "C" int svs_ba_destroy(svs_ba *ba) {
   if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
   if (ba->h_ctl) { (void)hipHostFree(ba->h_ctl); ba->h_ctl = nullptr; }
   if (ba->h_stage) { (void)hipHostFree(ba->h_stage); ba->h_stage = nullptr; ba->h_stage_cap = 0; }
+  if (ba->h_state) { (void)hipHostFree(ba->h_state); ba->h_state = nullptr; ba->h_state_cap = 0; }
   if (ba->d_ctl) { (void)hipFree(ba->d_ctl); ba->d_ctl = nullptr; }
   if (ba->d_rowmax2) (void)hipFree(ba->d_rowmax2);
   if (ba->d_perm) (void)hipFree(ba->d_perm);
@@ -1335,9 +1337,21 @@ extern "C" int svs_ba_get_state(svs_ba *ba, double *h_poses, double *h_psi) {
   svs_ctx *ctx = ba ? ba->ctx : nullptr;
   SVS_REQUIRE(ctx, ba && ba->d_poses[0] && ba->problem_valid);
   SVS_DEVICE(ctx);
-  if (h_poses) SVS_HIP(ctx, hipMemcpyAsync(h_poses, ba->d_poses[ba->cur], sizeof(double) * 12 * (size_t)ba->P, hipMemcpyDeviceToHost, ctx->stream));
-  if (h_psi && ba->L) SVS_HIP(ctx, hipMemcpyAsync(h_psi, ba->d_psi[ba->cur], sizeof(double) * 3 * (size_t)ba->L, hipMemcpyDeviceToHost, ctx->stream));
+  // both arrays land in a pinned area of the library's own, the two copies back to back, ONE wait; then a host copy into the caller's (pageable) arrays.  Straight
+  // into pageable memory every copy is a synchronous, staged transfer of its own: 40 us of host turn-around between them in the drop-in call's timeline
+  const size_t nb_poses = h_poses ? sizeof(double) * 12 * (size_t)ba->P : 0, nb_psi = (h_psi && ba->L) ? sizeof(double) * 3 * (size_t)ba->L : 0;
+  if (nb_poses + nb_psi > ba->h_state_cap) {
+    if (ba->h_state) (void)hipHostFree(ba->h_state);
+    ba->h_state = nullptr; ba->h_state_cap = 0;
+    const size_t want = (nb_poses + nb_psi) + (nb_poses + nb_psi) / 4 + 4096;
+    SVS_HIP(ctx, hipHostMalloc((void **)&ba->h_state, want, hipHostMallocDefault));
+    ba->h_state_cap = want;
+  }
+  if (nb_poses) SVS_HIP(ctx, hipMemcpyAsync(ba->h_state, ba->d_poses[ba->cur], nb_poses, hipMemcpyDeviceToHost, ctx->stream));
+  if (nb_psi) SVS_HIP(ctx, hipMemcpyAsync(ba->h_state + nb_poses, ba->d_psi[ba->cur], nb_psi, hipMemcpyDeviceToHost, ctx->stream));
   SVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (nb_poses) std::memcpy(h_poses, ba->h_state, nb_poses);
+  if (nb_psi) std::memcpy(h_psi, ba->h_state + nb_poses, nb_psi);
   return SVS_OK;
 }
 

@@ -22,6 +22,9 @@ for hm in (2, 1):      # svs_ba_set_option "host_marshal": 2 = marshal on the de
         opt.optimize(); t2 = time.perf_counter(); opt.restoreDataFromG2o(); t3 = time.perf_counter()
         ts["set"] += t1 - t0; ts["opt"] += t2 - t1; ts["get"] += t3 - t2
     print("host_marshal", "device" if hm == 2 else "host", {k: round(v / N * 1e3, 3) for k, v in ts.items()}, "ms")
+    if os.environ.get("SVS_DROPIN_TRACE"):      # kernel timelines (tools/timeline.py): the trace ends with plain device-route calls
+        opt.close()
+        break
     opt.set_option("debug", 1)
     for _ in range(3):
         opt.copyDataToG2o(prob["poses"], prob["psi"], prob["edges"], prob["cons"], cam, prm)
