@@ -385,6 +385,18 @@ extern "C" int svs_fast_create(svs_ctx *ctx, int n_levels, const int32_t *w, con
                                const svs_fastgrid *grids, int batch, int cap, svs_fast **out) {
   SVS_REQUIRE(ctx, ctx && out && w && h && grids && n_levels >= 1 && n_levels <= SVS_NUM_PYR_LEVELS && batch >= 1 && cap >= 1);
   SVS_DEVICE(ctx);
+  {      // everything that can be refused is refused before the first allocation
+    int nc = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      const svs_fastgrid &g = grids[l];
+      SVS_REQUIRE(ctx, g.gx >= 1 && g.gy >= 1 && g.gx * g.gy <= SVS_MAX_CELLS && g.cell_w >= 1 && g.cell_h >= 1 && g.cell_w * g.gx <= w[l] && g.cell_h * g.gy <= h[l]);
+      SVS_REQUIRE(ctx, g.cell_w <= 4096 && g.cell_h <= 4096);      // 12-bit cell-local coordinates in the candidate records
+      // a cell's bitmap lives in LDS during the compaction: cells up to ~1.1 M pixels (e.g. 1184 x 1024)
+      SVS_REQUIRE(ctx, ((size_t)g.cell_h * ((g.cell_w + 31) / 32) + g.cell_h) * 4 <= (size_t)BM_LDS_MAX);
+      nc += g.gx * g.gy;
+    }
+    SVS_REQUIRE(ctx, (size_t)nc * 256 * 4 <= 64 * 1024);          // the adaptation kernel's suffix-summed histograms of one stream in LDS
+  }
   svs_fast *f = new svs_fast();
   f->ctx = ctx; f->batch = batch;
   FastParams &P = f->P;

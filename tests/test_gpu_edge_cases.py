@@ -158,3 +158,16 @@ def test_fast_small_image_and_capacity(gpu_ctx):
     fg2.detectAdaptively(trials=6)
     with pytest.raises(capi.SvsError, match="status 4"):
         fg2.corners(0, 0)
+    # a cell whose corner bitmap does not fit the compaction's LDS (2560 x 1440 pixels as ONE cell: 461 KB of bits) is refused at create, before anything is
+    # allocated -- SVS_ERR_INVALID (status 1), not a launch failure later
+    from scavislam_amd.frontend import fastgrid_for_level
+    camb = dict(synth.CAM_DEFAULT, w=2560, h=1440, cx=1280.0, cy=720.0)
+    frb = FramePyramid(ctx, stream, camb, batch=1, with_float=False)
+    gb = []
+    for l in range(3):
+        g = fastgrid_for_level(frb.w[l], frb.h[l], l)
+        g.gx = g.gy = 1
+        g.cell_w, g.cell_h = frb.w[l], frb.h[l]
+        gb.append(g)
+    with pytest.raises(capi.SvsError, match="status 1"):
+        FastGrid(ctx, frb, grids=gb)
